@@ -1,0 +1,728 @@
+/*
+ * sfgwas_oracle.c — CPU restatement of the SF-GWAS local hot path.  TEST INFRASTRUCTURE ONLY
+ * (see sfgwas_oracle.h for the usage rule and the "parity unpinned" statement).
+ *
+ * Every function cites the reference file:line (under /root/reference) whose behaviour it
+ * follows, or — for arithmetic that lives in the absent third-party modules — the upstream
+ * package/function whose published algorithm is restated.
+ */
+#define _GNU_SOURCE
+#include "sfgwas_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <quadmath.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+/* ------------------------------------------------------------------ PRNG */
+u64 orc_splitmix64(u64 *state) {
+    u64 z = (*state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline u64 uniform_mod(u64 *st, u64 q) { return (u64)(((u128)orc_splitmix64(st) * q) >> 64); }
+
+/* ------------------------------------------------------------------ modular arithmetic */
+u64 orc_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+u64 orc_powmod(u64 a, u64 e, u64 q) {
+    u64 r = 1 % q; a %= q;
+    while (e) { if (e & 1) r = orc_mulmod(r, a, q); a = orc_mulmod(a, a, q); e >>= 1; }
+    return r;
+}
+u64 orc_invmod(u64 a, u64 q) { return orc_powmod(a, q - 2, q); } /* q prime */
+
+/* lattigo ring.MRedParams: q^-1 mod 2^64 (positive inverse), used at matmult.go:333,352 */
+u64 orc_mred_params(u64 q) {
+    u64 qinv = 1, x = q;
+    for (int i = 0; i < 63; i++) { qinv *= x; x *= x; }
+    return qinv;
+}
+/* lattigo ring.BRedParams: floor(2^128 / q) as {hi, lo}; consumed by MForm (matmult.go:433-440) */
+void orc_bred_params(u64 q, u64 u[2]) {
+    /* 2^128 / q by long division on (2^128 - 1)/q, corrected (q is odd so 2^128 is never divisible) */
+    u128 all1 = ~(u128)0;
+    u128 quo = all1 / q; /* floor((2^128-1)/q) == floor(2^128/q) because q does not divide 2^128 */
+    u[0] = (u64)(quo >> 64); u[1] = (u64)quo;
+}
+/* matmult.go:433-440 MForm: a * 2^64 mod q via Barrett constants */
+u64 orc_mform(u64 a, u64 q, const u64 u[2]) {
+    u64 mhi = (u64)(((u128)a * u[1]) >> 64);
+    u64 r = (u64)(-(a * u[0] + mhi)) * q;
+    if (r >= q) r -= q;
+    return r;
+}
+/* lattigo ring.MRed: x*y*2^-64 mod q */
+u64 orc_mred(u64 x, u64 y, u64 q, u64 qinv) {
+    u128 m = (u128)x * y;
+    u64 mhi = (u64)(m >> 64), mlo = (u64)m;
+    u64 hhi = (u64)(((u128)(mlo * qinv) * q) >> 64);
+    u64 r = mhi - hhi + q;
+    if (r >= q) r -= q;
+    return r;
+}
+
+/* ------------------------------------------------------------------ ring */
+struct orc_ring {
+    int logN, N, nq, np;
+    u64 q[ORC_MAXMOD], psi[ORC_MAXMOD], ninv[ORC_MAXMOD];
+    u64 *psi_rev[ORC_MAXMOD], *psi_inv_rev[ORC_MAXMOD];
+};
+static inline uint32_t brev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+/* smallest primitive root of prime q (lattigo ring.primitiveRoot), then psi = g^((q-1)/2N) */
+static u64 derive_psi(u64 q, int logN) {
+    u64 phi = q - 1, n = phi; u64 fac[64]; int nf = 0;
+    for (u64 p = 2; p * p <= n; p += (p == 2 ? 1 : 2)) {
+        if (n % p == 0) { fac[nf++] = p; while (n % p == 0) n /= p; }
+    }
+    if (n > 1) fac[nf++] = n;
+    for (u64 g = 2;; g++) {
+        int ok = 1;
+        for (int i = 0; i < nf && ok; i++) if (orc_powmod(g, phi / fac[i], q) == 1) ok = 0;
+        if (ok) return orc_powmod(g, phi >> (logN + 1), q);
+    }
+}
+orc_ring *orc_ring_new(int logN, int nq, int np, const u64 *moduli, const u64 *psi) {
+    if (nq + np > ORC_MAXMOD) return NULL;
+    orc_ring *r = calloc(1, sizeof *r);
+    r->logN = logN; r->N = 1 << logN; r->nq = nq; r->np = np;
+    int N = r->N;
+    for (int m = 0; m < nq + np; m++) {
+        u64 q = moduli[m];
+        if ((q - 1) % (2ULL * N)) { orc_ring_free(r); return NULL; }
+        r->q[m] = q;
+        r->psi[m] = psi ? psi[m] : derive_psi(q, logN);
+        if (orc_powmod(r->psi[m], N, q) != q - 1) { orc_ring_free(r); return NULL; } /* psi^N = -1 */
+        u64 psi_inv = orc_invmod(r->psi[m], q);
+        r->ninv[m] = orc_invmod((u64)N, q);
+        r->psi_rev[m] = malloc(sizeof(u64) * N); r->psi_inv_rev[m] = malloc(sizeof(u64) * N);
+        u64 p = 1, pi = 1;
+        for (int k = 0; k < N; k++) {
+            uint32_t b = brev((uint32_t)k, logN);
+            r->psi_rev[m][b] = p; r->psi_inv_rev[m][b] = pi;
+            p = orc_mulmod(p, r->psi[m], q); pi = orc_mulmod(pi, psi_inv, q);
+        }
+    }
+    return r;
+}
+void orc_ring_free(orc_ring *r) {
+    if (!r) return;
+    for (int m = 0; m < ORC_MAXMOD; m++) { free(r->psi_rev[m]); free(r->psi_inv_rev[m]); }
+    free(r);
+}
+int orc_ring_N(const orc_ring *r) { return r->N; }
+u64 orc_ring_psi(const orc_ring *r, int mod) { return r->psi[mod]; }
+u64 orc_ring_modulus(const orc_ring *r, int mod) { return r->q[mod]; }
+
+/* lattigo ring.NTT restated: Cooley-Tukey, twiddles psi^brev(m+i), natural in -> bit-reversed out,
+ * exact final reduction.  out[i] = p(psi^(2*brev(i)+1)).  Called behind encoder.EncodeNTT
+ * (matmult.go:723) and inside every key switch. */
+void orc_ntt(const orc_ring *r, int mod, u64 *a) {
+    int N = r->N; u64 q = r->q[mod]; const u64 *w = r->psi_rev[mod];
+    int t = N;
+    for (int m = 1; m < N; m <<= 1) {
+        t >>= 1;
+        for (int i = 0; i < m; i++) {
+            int j1 = 2 * i * t; u64 W = w[m + i];
+            for (int j = j1; j < j1 + t; j++) {
+                u64 U = a[j], V = orc_mulmod(a[j + t], W, q);
+                u64 s = U + V; if (s >= q) s -= q;
+                u64 d = U >= V ? U - V : U + q - V;
+                a[j] = s; a[j + t] = d;
+            }
+        }
+    }
+}
+/* lattigo ring.InvNTT restated: Gentleman-Sande with psi^-brev, then * N^-1 */
+void orc_intt(const orc_ring *r, int mod, u64 *a) {
+    int N = r->N; u64 q = r->q[mod]; const u64 *w = r->psi_inv_rev[mod];
+    int t = 1;
+    for (int m = N; m > 1; m >>= 1) {
+        int j1 = 0, h = m >> 1;
+        for (int i = 0; i < h; i++) {
+            u64 W = w[h + i];
+            for (int j = j1; j < j1 + t; j++) {
+                u64 U = a[j], V = a[j + t];
+                u64 s = U + V; if (s >= q) s -= q;
+                u64 d = U >= V ? U - V : U + q - V;
+                a[j] = s; a[j + t] = orc_mulmod(d, W, q);
+            }
+            j1 += 2 * t;
+        }
+        t <<= 1;
+    }
+    for (int j = 0; j < N; j++) a[j] = orc_mulmod(a[j], r->ninv[mod], q);
+}
+
+/* ------------------------------------------------------------------ matmult.go integer kernels */
+/* matmult.go:247-289 MulCoeffsAndAdd128: c[j] += a[j]*b[j] exactly in 128 bits, no reduction */
+void orc_mul_coeffs_and_add128(const u64 *a, const u64 *b, u64 *c, int n) {
+    for (int j = 0; j < n; j++) {
+        u128 p = (u128)a[j] * b[j];
+        u64 hi = (u64)(p >> 64), lo = (u64)p;
+        u64 nlo = c[2 * j + 1] + lo;
+        u64 carry = nlo < lo;
+        c[2 * j + 1] = nlo;
+        c[2 * j] += hi + carry;
+    }
+}
+/* matmult.go:291-324 ReduceAndAddUint128: out[j] += in.hi - hi64((in.lo*qInv)*q) + q  (lazy REDC) */
+void orc_reduce_and_add_uint128(const u64 *in, u64 *out, u64 qinv, u64 q, int n) {
+    for (int j = 0; j < n; j++) {
+        u64 hhi = (u64)(((u128)(in[2 * j + 1] * qinv) * q) >> 64);
+        out[j] += in[2 * j] - hhi + q;
+    }
+}
+/* matmult.go:411-431 MFormLvl over one modulus row */
+void orc_mform_vec(u64 *a, int n, u64 q) {
+    u64 u[2]; orc_bred_params(q, u);
+    for (int j = 0; j < n; j++) a[j] = orc_mform(a[j], q, u);
+}
+/* eval.Reduce(ct, ct) at matmult.go:358 — canonical representative in [0, q) */
+void orc_canonical_reduce(u64 *a, int n, u64 q) { for (int j = 0; j < n; j++) a[j] %= q; }
+
+/* matmult.go:380-399 CPMultAccWithoutMRedV2 over s broadcast rows of one rotated-ciphertext set */
+void orc_cpmult_acc_v2(const u64 *rot, const u64 *pt, u64 *acc, int s, int L, int N) {
+    for (int i = 0; i < s; i++)
+        for (int l = 0; l < L; l++)
+            for (int p = 0; p < 2; p++)
+                orc_mul_coeffs_and_add128(rot + (((size_t)i * 2 + p) * L + l) * N, pt + (size_t)l * N,
+                                          acc + ((((size_t)i * 2 + p) * L + l) * N) * 2, N);
+}
+
+/* ------------------------------------------------------------------ diagonals */
+static inline int mod_i(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+/* matmult.go:627-631 */
+int orc_get_diag_bool(int r, int c, int dim, int index) {
+    index = mod_i(index, dim);
+    return (dim + 1 - r) <= index || index <= c - 1;
+}
+/* matmult.go:636-664 */
+int orc_get_diag(double *dst, const int8_t *X, size_t ld, int r, int c, int dim, int index) {
+    index = mod_i(index, dim);
+    if (!((dim + 1 - r) <= index || index <= c - 1)) return 0;
+    int i = mod_i(-index, dim);
+    for (int j = 0; j < dim; j++) {
+        dst[j] = (i < r && j < c) ? (double)X[(size_t)i * ld + j] : 0.0;
+        i = mod_i(i + 1, dim);
+    }
+    return 1;
+}
+/* matmult.go:666-672 convertToComplex128WithRot (real parts) */
+void orc_rot_right(const double *v, double *out, int n, int nrot) {
+    for (int i = 0; i < n; i++) out[mod_i(i + nrot, n)] = v[i];
+}
+
+/* ------------------------------------------------------------------ CKKS encode
+ * lattigo ckks.EncoderBig (EncodeNTT at matmult.go:699,723) computes, with `prec`-bit big floats,
+ *   w = invSpecialFFT(values);  coeff[c] = round(scale*Re w_c), coeff[c+n] = round(scale*Im w_c)
+ * where decode is v_t = sum_c w_c zeta^(5^t c), zeta = exp(2 pi i / 2N), n = N/2 slots.  Inverting:
+ *   w_c = (1/n) sum_t v_t zeta^(-5^t c) = zeta^(-c)/n * DFT_n(u)_c ,  u[(5^t-1)/4 mod n] = v_t.
+ * With 128/256-bit big floats the reference result is the exactly rounded value; this restatement
+ * computes the same real number with 113-bit (__float128) or double-double arithmetic and rounds
+ * half away from zero (lattigo scaleUpVecExactBigFloat adds +-0.5 and truncates). */
+typedef struct { double hi, lo; } dd;
+static inline dd dd_from(double a) { dd r = {a, 0.0}; return r; }
+static inline dd dd_two_sum(double a, double b) { double s = a + b, bb = s - a; dd r = {s, (a - (s - bb)) + (b - bb)}; return r; }
+static inline dd dd_quick(double a, double b) { double s = a + b; dd r = {s, b - (s - a)}; return r; }
+static inline dd dd_add(dd a, dd b) {
+    dd s = dd_two_sum(a.hi, b.hi), t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi; s = dd_quick(s.hi, s.lo); s.lo += t.lo; return dd_quick(s.hi, s.lo);
+}
+static inline dd dd_neg(dd a) { dd r = {-a.hi, -a.lo}; return r; }
+static inline dd dd_sub(dd a, dd b) { return dd_add(a, dd_neg(b)); }
+static inline dd dd_mul(dd a, dd b) {
+    double p = a.hi * b.hi, e = fma(a.hi, b.hi, -p);
+    e += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick(p, e);
+}
+static inline dd dd_from_q(__float128 x) { double h = (double)x; dd r = {h, (double)(x - (__float128)h)}; return r; }
+static int64_t dd_round(dd x) { /* half away from zero */
+    double n = nearbyint(x.hi);
+    double diff = (x.hi - n) + x.lo;
+    if (diff > 0.5 || (diff == 0.5 && n >= 0)) n += 1.0;
+    else if (diff < -0.5 || (diff == -0.5 && n <= 0)) n -= 1.0;
+    return (int64_t)n;
+}
+static int64_t q_round(__float128 x) { return x >= 0 ? (int64_t)floorq(x + 0.5Q) : -(int64_t)floorq(-x + 0.5Q); }
+
+#define FFT_TMPL(NAME, R, ADD, SUB, MUL, FROMQ)                                              \
+    /* in-place forward DFT (sign -) of size n (power of two) over (re,im) arrays */        \
+    static void NAME(R *re, R *im, int n) {                                                  \
+        int lg = 0; while ((1 << lg) < n) lg++;                                              \
+        for (int i = 0; i < n; i++) { int j = (int)brev((uint32_t)i, lg);                    \
+            if (j > i) { R t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; } } \
+        for (int len = 2; len <= n; len <<= 1) {                                             \
+            int h = len >> 1;                                                                \
+            for (int k = 0; k < h; k++) {                                                    \
+                __float128 ang = -2.0Q * M_PIq * (__float128)k / (__float128)len;            \
+                R wr = FROMQ(cosq(ang)), wi = FROMQ(sinq(ang));                              \
+                for (int i = k; i < n; i += len) {                                           \
+                    int j = i + h;                                                           \
+                    R tr = SUB(MUL(re[j], wr), MUL(im[j], wi));                              \
+                    R ti = ADD(MUL(re[j], wi), MUL(im[j], wr));                              \
+                    re[j] = SUB(re[i], tr); im[j] = SUB(im[i], ti);                          \
+                    re[i] = ADD(re[i], tr); im[i] = ADD(im[i], ti);                          \
+                }                                                                            \
+            }                                                                                \
+        }                                                                                    \
+    }
+#define Q_ADD(a, b) ((a) + (b))
+#define Q_SUB(a, b) ((a) - (b))
+#define Q_MUL(a, b) ((a) * (b))
+#define Q_ID(a) (a)
+FFT_TMPL(fft_q, __float128, Q_ADD, Q_SUB, Q_MUL, Q_ID)
+FFT_TMPL(fft_dd, dd, dd_add, dd_sub, dd_mul, dd_from_q)
+
+void orc_encode_coeffs(const orc_ring *r, const double *v, double scale, int64_t *coeffs, int prec) {
+    int N = r->N, n = N / 2; u64 M = 2ULL * N;
+    int *perm = malloc(sizeof(int) * n);
+    u64 g = 1;
+    for (int t = 0; t < n; t++) { perm[t] = (int)(((g - 1) / 4) % n); g = (g * 5) % M; }
+    if (prec == 0) {
+        __float128 *re = calloc(n, sizeof *re), *im = calloc(n, sizeof *im);
+        for (int t = 0; t < n; t++) re[perm[t]] = (__float128)v[t];
+        fft_q(re, im, n);
+        for (int c = 0; c < n; c++) {
+            __float128 ang = -2.0Q * M_PIq * (__float128)c / (__float128)M;
+            __float128 zr = cosq(ang), zi = sinq(ang);
+            __float128 wr = (re[c] * zr - im[c] * zi) / (__float128)n, wi = (re[c] * zi + im[c] * zr) / (__float128)n;
+            coeffs[c] = q_round(wr * (__float128)scale);
+            coeffs[c + n] = q_round(wi * (__float128)scale);
+        }
+        free(re); free(im);
+    } else {
+        dd *re = calloc(n, sizeof *re), *im = calloc(n, sizeof *im);
+        for (int t = 0; t < n; t++) re[perm[t]] = dd_from(v[t]);
+        fft_dd(re, im, n);
+        dd sc = dd_from(scale / (double)n); /* n and (in practice) scale are powers of two: exact */
+        for (int c = 0; c < n; c++) {
+            __float128 ang = -2.0Q * M_PIq * (__float128)c / (__float128)M;
+            dd zr = dd_from_q(cosq(ang)), zi = dd_from_q(sinq(ang));
+            dd wr = dd_mul(dd_sub(dd_mul(re[c], zr), dd_mul(im[c], zi)), sc);
+            dd wi = dd_mul(dd_add(dd_mul(re[c], zi), dd_mul(im[c], zr)), sc);
+            coeffs[c] = dd_round(wr);
+            coeffs[c + n] = dd_round(wi);
+        }
+        free(re); free(im);
+    }
+    free(perm);
+}
+void orc_encode_ntt(const orc_ring *r, const double *v, double scale, int nlev, u64 *out, int prec) {
+    int N = r->N;
+    int64_t *c = malloc(sizeof(int64_t) * N);
+    orc_encode_coeffs(r, v, scale, c, prec);
+    for (int l = 0; l < nlev; l++) {
+        u64 q = r->q[l]; u64 *o = out + (size_t)l * N;
+        for (int j = 0; j < N; j++) { int64_t x = c[j] % (int64_t)q; o[j] = x < 0 ? (u64)(x + (int64_t)q) : (u64)x; } /* big.Int.Mod: non-negative */
+        orc_ntt(r, l, o);
+    }
+    free(c);
+}
+
+/* ------------------------------------------------------------------ rotations
+ * crypto/basics.go:201-224: RotateRight(ct, nrot) = eval.RotateNew(ct, slots - nrot).
+ * lattigo ckks evaluator.permuteNTT restated: key-switch c1 with the key of galEl = 5^k mod 2N,
+ * add to c0, then apply the NTT-domain automorphism index map to both polynomials. */
+struct orc_rotkeys { const orc_ring *r; int n, cap; u64 *gal; u64 **key; size_t key_words; };
+int orc_rotkeys_beta(const orc_ring *r) { return (r->nq + r->np - 1) / r->np; }
+orc_rotkeys *orc_rotkeys_new(const orc_ring *r) {
+    orc_rotkeys *k = calloc(1, sizeof *k); k->r = r;
+    k->key_words = (size_t)orc_rotkeys_beta(r) * 2 * (r->nq + r->np) * r->N;
+    return k;
+}
+void orc_rotkeys_free(orc_rotkeys *k) { if (!k) return; for (int i = 0; i < k->n; i++) free(k->key[i]); free(k->key); free(k->gal); free(k); }
+void orc_rotkeys_set(orc_rotkeys *k, u64 g, const u64 *key) {
+    for (int i = 0; i < k->n; i++) if (k->gal[i] == g) { memcpy(k->key[i], key, k->key_words * 8); return; }
+    if (k->n == k->cap) { k->cap = k->cap ? 2 * k->cap : 16; k->gal = realloc(k->gal, 8 * k->cap); k->key = realloc(k->key, sizeof(u64 *) * k->cap); }
+    k->gal[k->n] = g; k->key[k->n] = malloc(k->key_words * 8); memcpy(k->key[k->n], key, k->key_words * 8); k->n++;
+}
+const u64 *orc_rotkeys_get(const orc_rotkeys *k, u64 g) { for (int i = 0; i < k->n; i++) if (k->gal[i] == g) return k->key[i]; return NULL; }
+u64 orc_galois_for_rotation(const orc_ring *r, int k) {
+    u64 M = 2ULL * r->N; int n = r->N / 2; k = mod_i(k, n);
+    u64 g = 1; for (int i = 0; i < k; i++) g = (g * 5) % M; return g;
+}
+/* lattigo ring.PermuteNTTIndex: out[i] = in[index[i]] realises p(X) -> p(X^galEl) in the NTT domain */
+void orc_automorphism_index(const orc_ring *r, u64 g, uint32_t *index) {
+    int N = r->N, lg = r->logN; u64 mask = 2ULL * N - 1;
+    for (int i = 0; i < N; i++) {
+        u64 t1 = 2ULL * brev((uint32_t)i, lg) + 1;
+        u64 t2 = ((g * t1 & mask) - 1) >> 1;
+        index[i] = brev((uint32_t)t2, lg);
+    }
+}
+/* exact (float-corrected) RNS basis extension of the digit held in coefficient-domain rows src[0..a)
+ * (moduli qs[0..a)) to target modulus qt — lattigo ring.Decomposer.DecomposeAndSplit /
+ * FastBasisExtender.modUpExact restated: y_m = x_m*(D/q_m)^-1 mod q_m, v = uint64(sum float64(y_m)/float64(q_m)),
+ * out = sum y_m*(D/q_m) - v*D  (mod qt).  a == 1 is a raw copy (value kept as an integer < q_src). */
+static void basis_extend(int N, int a, const u64 *const *src, const u64 *qs, u64 qt, u64 *out) {
+    if (a == 1) { for (int x = 0; x < N; x++) out[x] = src[0][x] % qt; return; }
+    u64 qhat_inv[ORC_MAXMOD], qhat_t[ORC_MAXMOD], D_t = 1 % qt;
+    for (int m = 0; m < a; m++) {
+        u64 h = 1, ht = 1 % qt;
+        for (int k = 0; k < a; k++) if (k != m) { h = orc_mulmod(h, qs[k] % qs[m], qs[m]); ht = orc_mulmod(ht, qs[k] % qt, qt); }
+        qhat_inv[m] = orc_invmod(h, qs[m]); qhat_t[m] = ht;
+        D_t = orc_mulmod(D_t, qs[m] % qt, qt);
+    }
+    for (int x = 0; x < N; x++) {
+        double vf = 0.0; u64 acc = 0;
+        for (int m = 0; m < a; m++) {
+            u64 y = orc_mulmod(src[m][x], qhat_inv[m], qs[m]);
+            vf += (double)y / (double)qs[m];
+            acc = (acc + orc_mulmod(y % qt, qhat_t[m], qt)) % qt;
+        }
+        u64 v = (u64)vf;
+        u64 sub = orc_mulmod(v % qt, D_t, qt);
+        out[x] = acc >= sub ? acc - sub : acc + qt - sub;
+    }
+}
+/* lattigo evaluator.switchKeysInPlace restated (hybrid key switching, alpha = #P primes per digit,
+ * beta = ceil((level+1)/alpha) digits; ModDown by P with floor-type exact basis extension) */
+void orc_keyswitch(const orc_ring *r, int level, const u64 *cx, const u64 *key, u64 *d0, u64 *d1) {
+    int N = r->N, nq = r->nq, np = r->np, nl = level + 1, alpha = np, nmod = nq + np;
+    int beta = (nl + alpha - 1) / alpha;
+    u64 *c2 = malloc(sizeof(u64) * nl * N);
+    memcpy(c2, cx, sizeof(u64) * nl * N);
+    for (int m = 0; m < nl; m++) orc_intt(r, m, c2 + (size_t)m * N);
+    /* accumulators over targets: first nl are Q moduli 0..level, then np P moduli */
+    int nt = nl + np;
+    u64 *acc0 = calloc((size_t)nt * N, 8), *acc1 = calloc((size_t)nt * N, 8), *ext = malloc(sizeof(u64) * N);
+    for (int i = 0; i < beta; i++) {
+        int st = i * alpha, ed = st + alpha; if (ed > nl) ed = nl; int a = ed - st;
+        const u64 *src[ORC_MAXMOD]; u64 qs[ORC_MAXMOD];
+        for (int m = 0; m < a; m++) { src[m] = c2 + (size_t)(st + m) * N; qs[m] = r->q[st + m]; }
+        const u64 *kb = key + ((size_t)i * 2 + 0) * nmod * N, *ka = key + ((size_t)i * 2 + 1) * nmod * N;
+        for (int t = 0; t < nt; t++) {
+            int mod = t < nl ? t : nq + (t - nl);
+            u64 qt = r->q[mod]; const u64 *e;
+            if (t >= st && t < ed) e = cx + (size_t)t * N; /* in-digit modulus: the original NTT row */
+            else { basis_extend(N, a, src, qs, qt, ext); orc_ntt(r, mod, ext); e = ext; }
+            const u64 *kb_t = kb + (size_t)mod * N, *ka_t = ka + (size_t)mod * N;
+            u64 *a0 = acc0 + (size_t)t * N, *a1 = acc1 + (size_t)t * N;
+            for (int x = 0; x < N; x++) {
+                a0[x] = (a0[x] + orc_mulmod(e[x], kb_t[x], qt)) % qt;
+                a1[x] = (a1[x] + orc_mulmod(e[x], ka_t[x], qt)) % qt;
+            }
+        }
+    }
+    /* ModDownSplitNTTPQ: out = (accQ - NTT(ext_{P->Q}(INTT(accP)))) * P^-1 */
+    for (int pass = 0; pass < 2; pass++) {
+        u64 *acc = pass ? acc1 : acc0, *dst = pass ? d1 : d0;
+        const u64 *src[ORC_MAXMOD]; u64 qs[ORC_MAXMOD];
+        for (int p = 0; p < np; p++) { orc_intt(r, nq + p, acc + (size_t)(nl + p) * N); src[p] = acc + (size_t)(nl + p) * N; qs[p] = r->q[nq + p]; }
+        for (int t = 0; t < nl; t++) {
+            u64 qt = r->q[t], Pinv = 1;
+            for (int p = 0; p < np; p++) Pinv = orc_mulmod(Pinv, r->q[nq + p] % qt, qt);
+            Pinv = orc_invmod(Pinv, qt);
+            basis_extend(N, np, src, qs, qt, ext); orc_ntt(r, t, ext);
+            const u64 *aq = acc + (size_t)t * N; u64 *o = dst + (size_t)t * N;
+            for (int x = 0; x < N; x++) { u64 df = aq[x] >= ext[x] ? aq[x] - ext[x] : aq[x] + qt - ext[x]; o[x] = orc_mulmod(df, Pinv, qt); }
+        }
+    }
+    free(c2); free(acc0); free(acc1); free(ext);
+}
+int orc_rotate_left(const orc_ring *r, const orc_rotkeys *keys, int level, const u64 *ct, int k, u64 *out) {
+    int N = r->N, nl = level + 1, n = N / 2; k = mod_i(k, n);
+    if (k == 0) { memcpy(out, ct, sizeof(u64) * 2 * nl * N); return 0; }
+    u64 g = orc_galois_for_rotation(r, k);
+    const u64 *key = orc_rotkeys_get(keys, g); if (!key) return -1;
+    u64 *d0 = malloc(sizeof(u64) * nl * N), *d1 = malloc(sizeof(u64) * nl * N);
+    uint32_t *idx = malloc(sizeof(uint32_t) * N);
+    orc_keyswitch(r, level, ct + (size_t)nl * N, key, d0, d1);
+    orc_automorphism_index(r, g, idx);
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m]; const u64 *c0 = ct + (size_t)m * N; u64 *t0 = d0 + (size_t)m * N, *t1 = d1 + (size_t)m * N;
+        u64 *o0 = out + (size_t)m * N, *o1 = out + (size_t)(nl + m) * N;
+        for (int x = 0; x < N; x++) { u64 s = t0[x] + c0[x]; if (s >= q) s -= q; t0[x] = s; }
+        for (int x = 0; x < N; x++) { o0[x] = t0[idx[x]]; o1[x] = t1[idx[x]]; }
+    }
+    free(d0); free(d1); free(idx); return 0;
+}
+int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, const u64 *ct, int nrot, u64 *out) {
+    int n = r->N / 2; nrot = mod_i(nrot, n);
+    return orc_rotate_left(r, keys, level, ct, nrot ? n - nrot : 0, out);
+}
+
+/* ------------------------------------------------------------------ test-side CKKS helpers */
+void orc_gen_secret(const orc_ring *r, u64 seed, int8_t *s) {
+    u64 st = seed; for (int i = 0; i < r->N; i++) s[i] = (int8_t)((int)uniform_mod(&st, 3) - 1);
+}
+static void small_to_ntt(const orc_ring *r, int mod, const int8_t *s, u64 *out) {
+    u64 q = r->q[mod]; for (int i = 0; i < r->N; i++) out[i] = s[i] < 0 ? q - (u64)(-s[i]) : (u64)s[i];
+    orc_ntt(r, mod, out);
+}
+/* key digit i = (b_i, a_i): b_i = -a_i*phi_{g^-1}(s) + e_i + P*g_i*s, NTT domain, all nq+np moduli */
+void orc_gen_rotkey(const orc_ring *r, const int8_t *s, u64 g, u64 seed, u64 *key) {
+    int N = r->N, nq = r->nq, np = r->np, nmod = nq + np, beta = orc_rotkeys_beta(r); u64 M = 2ULL * N;
+    /* g^-1 mod 2N */
+    u64 ginv = 1; for (u64 t = 1; t < M; t += 2) if ((t * g) % M == 1) { ginv = t; break; }
+    int8_t *sg = calloc(N, 1); /* phi_{ginv}(s): X^i -> X^(i*ginv mod 2N) with sign */
+    for (int i = 0; i < N; i++) { u64 e = ((u64)i * ginv) % M; if (e < (u64)N) sg[e] += s[i]; else sg[e - N] -= s[i]; }
+    u64 *s_ntt = malloc(8 * N), *sg_ntt = malloc(8 * N), *e_ntt = malloc(8 * N); int8_t *e = malloc(N);
+    u64 st = seed;
+    for (int i = 0; i < beta; i++) {
+        for (int x = 0; x < N; x++) e[x] = (int8_t)((int)uniform_mod(&st, 7) - 3);
+        for (int m = 0; m < nmod; m++) {
+            u64 q = r->q[m]; u64 *b = key + (((size_t)i * 2 + 0) * nmod + m) * N, *a = key + (((size_t)i * 2 + 1) * nmod + m) * N;
+            small_to_ntt(r, m, s, s_ntt); small_to_ntt(r, m, sg, sg_ntt); small_to_ntt(r, m, e, e_ntt);
+            u64 st_a = seed ^ (0xA5A5ULL + 977ULL * (u64)(i * nmod + m));
+            u64 Pg = 0;
+            if (m < nq && m / np == i) { Pg = 1; for (int p = 0; p < np; p++) Pg = orc_mulmod(Pg, r->q[nq + p] % q, q); }
+            for (int x = 0; x < N; x++) {
+                a[x] = uniform_mod(&st_a, q);
+                u64 v = (q - orc_mulmod(a[x], sg_ntt[x], q)) % q;
+                v = (v + e_ntt[x]) % q;
+                v = (v + orc_mulmod(Pg, s_ntt[x], q)) % q;
+                b[x] = v;
+            }
+        }
+    }
+    free(sg); free(s_ntt); free(sg_ntt); free(e_ntt); free(e);
+}
+void orc_encrypt_coeffs(const orc_ring *r, const int8_t *s, int level, const int64_t *mc, u64 seed, u64 *ct) {
+    int N = r->N, nl = level + 1; u64 *s_ntt = malloc(8 * N), *m_ntt = malloc(8 * N); int8_t *e = malloc(N);
+    u64 st = seed ^ 0xE77ULL; for (int x = 0; x < N; x++) e[x] = (int8_t)((int)uniform_mod(&st, 7) - 3);
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m]; u64 *c0 = ct + (size_t)m * N, *c1 = ct + (size_t)(nl + m) * N;
+        small_to_ntt(r, m, s, s_ntt);
+        for (int x = 0; x < N; x++) { int64_t v = (mc[x] + e[x]) % (int64_t)q; m_ntt[x] = v < 0 ? (u64)(v + (int64_t)q) : (u64)v; }
+        orc_ntt(r, m, m_ntt);
+        u64 st_a = seed + 0x1000ULL * (u64)(m + 1);
+        for (int x = 0; x < N; x++) { c1[x] = uniform_mod(&st_a, q); c0[x] = (m_ntt[x] + q - orc_mulmod(c1[x], s_ntt[x], q)) % q; }
+    }
+    free(s_ntt); free(m_ntt); free(e);
+}
+void orc_decrypt_residues(const orc_ring *r, const int8_t *s, int level, const u64 *ct, u64 *out) {
+    int N = r->N, nl = level + 1; u64 *s_ntt = malloc(8 * N);
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m]; const u64 *c0 = ct + (size_t)m * N, *c1 = ct + (size_t)(nl + m) * N; u64 *o = out + (size_t)m * N;
+        small_to_ntt(r, m, s, s_ntt);
+        for (int x = 0; x < N; x++) o[x] = (c0[x] + orc_mulmod(c1[x], s_ntt[x], q)) % q;
+        orc_intt(r, m, o);
+    }
+    free(s_ntt);
+}
+/* synthetic "computationally uniform" ciphertext: element (poly p, modulus m, coeff x) is
+ * splitmix64 counter-mode on seed + ((p*nlev + m)*N + x), mapped to [0,q) by mulhi */
+void orc_fill_uniform(const orc_ring *r, int level, u64 seed, u64 *ct) {
+    int N = r->N, nl = level + 1;
+    for (int p = 0; p < 2; p++) for (int m = 0; m < nl; m++) {
+        u64 *o = ct + ((size_t)p * nl + m) * N; u64 q = r->q[m];
+        for (int x = 0; x < N; x++) { u64 st = seed + 0x9E3779B97F4A7C15ULL * (u64)(((size_t)p * nl + m) * N + x); o[x] = uniform_mod(&st, q); }
+    }
+}
+
+/* ------------------------------------------------------------------ MatMult4Stream (matmult.go:1238-1505) */
+int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
+                       const u64 *A, int s, int in_level, int max_level,
+                       const int8_t *geno_in, size_t nrow, size_t ncol,
+                       int compute_sqsum, int square, int enc_prec,
+                       u64 *out, double *sum, double *sqsum) {
+    int N = r->N, slots = N / 2;
+    int d = (int)ceil(sqrt((double)slots));                                   /* :1249 */
+    int m_ct = (int)((ncol - 1) / slots) + 1, nbr = (int)((nrow - 1) / slots) + 1; /* :1253-1254 */
+    int L = max_level;                       /* accumulate over the first maxLevel moduli (:1386, :231-241) */
+    int lev = in_level > max_level ? max_level : in_level; /* DropLevel (:1256-1259) */
+    int nl_in = in_level + 1, nl = lev + 1;
+    size_t ctw_in = (size_t)2 * nl_in * N, ctw = (size_t)2 * nl * N, outw = (size_t)2 * L * N;
+    int rc = 0;
+
+    /* working copy of genotypes: missing -> 0, sums, optional squaring (:1291-1304) */
+    int8_t *geno = malloc(nrow * ncol);
+    memcpy(geno, geno_in, nrow * ncol);
+    if (compute_sqsum) { memset(sum, 0, 8 * ncol); memset(sqsum, 0, 8 * ncol); }
+    for (size_t i = 0; i < nrow; i++) for (size_t j = 0; j < ncol; j++) {
+        int8_t *x = &geno[i * ncol + j];
+        if (*x < 0) *x = 0;
+        if (compute_sqsum) { sqsum[j] += (double)(int8_t)(*x * *x); sum[j] += (double)*x; }
+        if (square) *x = (int8_t)(*x * *x);
+    }
+
+    u64 ***acc = calloc(s, sizeof *acc);              /* accCache[i][giant] -> m_ct*2*L*N {hi,lo} */
+    for (int i = 0; i < s; i++) acc[i] = calloc(d, sizeof **acc);
+    u64 **rot = calloc((size_t)s * d, sizeof *rot);   /* rotCache[i][baby] */
+    double *diag = malloc(8 * slots), *diagr = malloc(8 * slots);
+    u64 *pt = malloc(8 * (size_t)L * N), *ct_lvl = malloc(8 * ctw);
+    uint8_t *baby_t = malloc(d), *giant_t = malloc(d), *shift_t = malloc(slots);
+    u64 qinv[ORC_MAXMOD]; for (int l = 0; l < L; l++) qinv[l] = orc_mred_params(r->q[l]);
+
+    for (int bi = 0; bi < nbr && !rc; bi++) {
+        int nr = (int)(((size_t)(bi + 1) * slots < nrow ? (size_t)(bi + 1) * slots : nrow) - (size_t)bi * slots);
+        memset(baby_t, 0, d); memset(giant_t, 0, d); memset(shift_t, 0, slots);
+        for (int shift = 0; shift < slots; shift++) {           /* :1329-1336 */
+            int any = 0;
+            for (int bj = 0; bj < m_ct && !any; bj++) {
+                int nc = (int)(((size_t)(bj + 1) * slots < ncol ? (size_t)(bj + 1) * slots : ncol) - (size_t)bj * slots);
+                any = orc_get_diag_bool(nr, nc, slots, -shift);
+            }
+            if (any) { baby_t[shift % d] = 1; giant_t[shift / d] = 1; shift_t[shift] = 1; }
+        }
+        /* rotation cache (:1373-1377): rotCache[i][baby] = RotateRight(A[i][bi], -baby) at the dropped level */
+        for (int baby = 0; baby < d && !rc; baby++) if (baby_t[baby]) for (int i = 0; i < s; i++) {
+            const u64 *a_in = A + ((size_t)i * nbr + bi) * ctw_in;
+            for (int p = 0; p < 2; p++) memcpy(ct_lvl + (size_t)p * nl * N, a_in + (size_t)p * nl_in * N, 8 * (size_t)nl * N);
+            u64 **slot = &rot[(size_t)i * d + baby];
+            if (!*slot) *slot = malloc(8 * ctw);
+            if (orc_rotate_right(r, keys, lev, ct_lvl, -baby, *slot)) { rc = -1; break; }
+        }
+        if (rc) break;
+        for (int g = 0; g < d; g++) if (giant_t[g]) for (int i = 0; i < s; i++)
+            if (!acc[i][g]) acc[i][g] = calloc((size_t)m_ct * outw * 2, 8);             /* :1382-1390 */
+        for (int shift = 0; shift < slots; shift++) if (shift_t[shift]) {               /* :1423-1435 */
+            int baby = shift % d, giant = shift / d;
+            for (int bj = 0; bj < m_ct; bj++) {
+                int nc = (int)(((size_t)(bj + 1) * slots < ncol ? (size_t)(bj + 1) * slots : ncol) - (size_t)bj * slots);
+                const int8_t *X = geno + (size_t)bi * slots * ncol + (size_t)bj * slots;
+                if (!orc_get_diag(diag, X, ncol, nr, nc, slots, -shift)) continue;     /* nil plaintext, skipped at :392 */
+                orc_rot_right(diag, diagr, slots, d * giant);                           /* :723 nrot = d*giant */
+                orc_encode_ntt(r, diagr, scale, L, pt, enc_prec);                       /* level maxLevel has L+1 moduli; only L are used */
+                for (int l = 0; l < L; l++) orc_mform_vec(pt + (size_t)l * N, N, r->q[l]); /* :1428 ToMontgomeryForm */
+                for (int i = 0; i < s; i++) {                                           /* :1430-1434 */
+                    const u64 *rc_ct = rot[(size_t)i * d + baby];
+                    u64 *a = acc[i][giant] + (size_t)bj * outw * 2;
+                    for (int l = 0; l < L; l++) {
+                        orc_mul_coeffs_and_add128(rc_ct + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
+                        orc_mul_coeffs_and_add128(rc_ct + (size_t)(nl + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
+                    }
+                }
+            }
+        }
+    }
+    /* post-processing (:1443-1502): ModularReduceV2, giant alignment, aggregation */
+    if (!rc) {
+        memset(out, 0, 8 * (size_t)s * m_ct * outw);
+        u64 *cv = malloc(8 * outw), *cvr = malloc(8 * outw);
+        for (int i = 0; i < s && !rc; i++) for (int g = 0; g < d && !rc; g++) if (acc[i][g]) {
+            for (int bj = 0; bj < m_ct; bj++) {
+                memset(cv, 0, 8 * outw);
+                const u64 *a = acc[i][g] + (size_t)bj * outw * 2;
+                for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* matmult.go:351-359 */
+                    u64 *o = cv + ((size_t)p * L + l) * N;
+                    orc_reduce_and_add_uint128(a + (((size_t)p * L + l) * N) * 2, o, qinv[l], r->q[l], N);
+                    orc_canonical_reduce(o, N, r->q[l]);
+                }
+                const u64 *src = cv;
+                if (g > 0) { if (orc_rotate_right(r, keys, L - 1, cv, -g * d, cvr)) { rc = -1; break; } src = cvr; } /* :1474-1478 */
+                u64 *o = out + ((size_t)i * m_ct + bj) * outw;
+                for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* eva.Add :1494 */
+                    u64 q = r->q[l]; size_t off = ((size_t)p * L + l) * N;
+                    for (int x = 0; x < N; x++) { u64 v = o[off + x] + src[off + x]; if (v >= q) v -= q; o[off + x] = v; }
+                }
+            }
+        }
+        free(cv); free(cvr);
+    }
+    for (int i = 0; i < s; i++) { for (int g = 0; g < d; g++) free(acc[i][g]); free(acc[i]); }
+    for (size_t k = 0; k < (size_t)s * d; k++) free(rot[k]);
+    free(acc); free(rot); free(diag); free(diagr); free(pt); free(ct_lvl); free(baby_t); free(giant_t); free(shift_t); free(geno);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ DiagCache (filestream.go:19-282) */
+struct orc_diagcache { FILE *f; int d, writing, at_head; u64 hdr[6]; uint8_t *baby, *giant; uint8_t *buf; };
+orc_diagcache *orc_diagcache_create(const char *path, int d) {
+    FILE *f = fopen(path, "wb"); if (!f) return NULL;
+    orc_diagcache *dc = calloc(1, sizeof *dc); dc->f = f; dc->d = d; dc->writing = 1; dc->at_head = 1;
+    dc->baby = calloc(d, 1); dc->giant = calloc(d, 1); return dc;
+}
+void orc_diagcache_set_tables(orc_diagcache *dc, const uint8_t *b, const uint8_t *g) { memcpy(dc->baby, b, dc->d); memcpy(dc->giant, g, dc->d); }
+static void put_le64(uint8_t *p, u64 v) { for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i)); }
+static u64 get_le64(const uint8_t *p) { u64 v = 0; for (int i = 0; i < 8; i++) v |= (u64)p[i] << (8 * i); return v; }
+static void put_be64(uint8_t *p, u64 v) { for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (56 - 8 * i)); }
+static u64 get_be64(const uint8_t *p) { u64 v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
+int orc_diagcache_write(orc_diagcache *dc, const u64 *const *pv, int vlen, int level, double scale, int n, int nmod, uint32_t shift) {
+    if (dc->at_head) {                                                         /* filestream.go:146-200 */
+        u64 sb; memcpy(&sb, &scale, 8);
+        u64 datalen = (u64)n * nmod * 8;                                       /* Poly.GetDataLen(false) */
+        dc->hdr[0] = vlen; dc->hdr[1] = level; dc->hdr[2] = sb; dc->hdr[3] = n; dc->hdr[4] = nmod; dc->hdr[5] = 4 + (1 + datalen) * vlen;
+        uint8_t h[48]; for (int i = 0; i < 6; i++) put_le64(h + 8 * i, dc->hdr[i]);
+        fwrite(h, 1, 48, dc->f); fwrite(dc->baby, 1, dc->d, dc->f); fwrite(dc->giant, 1, dc->d, dc->f);
+        dc->buf = malloc(dc->hdr[5]); dc->at_head = 0;
+    }
+    uint8_t *b = dc->buf; b[0] = shift & 255; b[1] = (shift >> 8) & 255; b[2] = (shift >> 16) & 255; b[3] = shift >> 24;
+    size_t ptr = 4;
+    for (int i = 0; i < vlen; i++) {                                           /* :204-222 */
+        b[ptr++] = pv[i] ? 0 : 1;
+        if (pv[i]) for (int m = 0; m < nmod; m++) for (int x = 0; x < n; x++) { put_be64(b + ptr, pv[i][(size_t)m * n + x]); ptr += 8; }
+    }
+    uint8_t l8[8]; put_le64(l8, ptr); fwrite(l8, 1, 8, dc->f); fwrite(b, 1, ptr, dc->f);   /* :224-227 */
+    return 0;
+}
+orc_diagcache *orc_diagcache_open(const char *path, int d) {
+    FILE *f = fopen(path, "rb"); if (!f) return NULL;
+    orc_diagcache *dc = calloc(1, sizeof *dc); dc->f = f; dc->d = d; dc->baby = calloc(d, 1); dc->giant = calloc(d, 1);
+    uint8_t h[48];
+    if (fread(h, 1, 48, f) != 48 || fread(dc->baby, 1, d, f) != (size_t)d || fread(dc->giant, 1, d, f) != (size_t)d) { orc_diagcache_close(dc); return NULL; }
+    for (int i = 0; i < 6; i++) dc->hdr[i] = get_le64(h + 8 * i);
+    dc->buf = malloc(dc->hdr[5]); return dc;
+}
+int orc_diagcache_header(const orc_diagcache *dc, u64 hdr[6], uint8_t *baby, uint8_t *giant) {
+    memcpy(hdr, dc->hdr, 48); if (baby) memcpy(baby, dc->baby, dc->d); if (giant) memcpy(giant, dc->giant, dc->d); return 0;
+}
+int orc_diagcache_read(orc_diagcache *dc, u64 *const *bufs, uint8_t *empty, uint32_t *shift) {
+    uint8_t l8[8]; if (fread(l8, 1, 8, dc->f) != 8) return 0;                 /* :249-260 */
+    u64 len = get_le64(l8); if (len > dc->hdr[5] || fread(dc->buf, 1, len, dc->f) != len) return 0;
+    const uint8_t *b = dc->buf; *shift = (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24;
+    size_t ptr = 4; int n = (int)dc->hdr[3], nmod = (int)dc->hdr[4];
+    for (int i = 0; i < (int)dc->hdr[0]; i++) {
+        empty[i] = b[ptr++] == 1;
+        if (!empty[i]) for (int m = 0; m < nmod; m++) for (int x = 0; x < n; x++) { bufs[i][(size_t)m * n + x] = get_be64(b + ptr); ptr += 8; }
+    }
+    return 1;
+}
+void orc_diagcache_close(orc_diagcache *dc) { if (!dc) return; if (dc->f) fclose(dc->f); free(dc->baby); free(dc->giant); free(dc->buf); free(dc); }
+
+/* ------------------------------------------------------------------ Beaver local products (beavermult.go:94-147)
+ * mpc-core RElem arithmetic restated as plain prime-field arithmetic on `limbs` little-endian 64-bit limbs */
+#define BL 4
+static int big_cmp(const u64 *a, const u64 *b, int n) { for (int i = n - 1; i >= 0; i--) { if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1; } return 0; }
+static u64 big_add(u64 *r, const u64 *a, const u64 *b, int n) { u64 c = 0; for (int i = 0; i < n; i++) { u128 s = (u128)a[i] + b[i] + c; r[i] = (u64)s; c = (u64)(s >> 64); } return c; }
+static void big_sub(u64 *r, const u64 *a, const u64 *b, int n) { u64 br = 0; for (int i = 0; i < n; i++) { u128 d = (u128)a[i] - b[i] - br; r[i] = (u64)d; br = (u64)(d >> 64) & 1; } }
+static void f_add(u64 *r, const u64 *a, const u64 *b, const u64 *p, int n) { u64 c = big_add(r, a, b, n); if (c || big_cmp(r, p, n) >= 0) big_sub(r, r, p, n); }
+static void f_mul(u64 *r, const u64 *a, const u64 *b, const u64 *p, int n) { /* MSB-first double-and-add */
+    u64 acc[BL] = {0}, t[BL];
+    for (int bit = 64 * n - 1; bit >= 0; bit--) {
+        f_add(t, acc, acc, p, n); memcpy(acc, t, 8 * n);
+        if ((b[bit >> 6] >> (bit & 63)) & 1) { f_add(t, acc, a, p, n); memcpy(acc, t, 8 * n); }
+    }
+    memcpy(r, acc, 8 * n);
+}
+void orc_beaver_elem(int pid, int n, const u64 *p, const u64 *ar, const u64 *am, const u64 *br, const u64 *bm, u64 *out, size_t cnt) {
+    for (size_t e = 0; e < cnt; e++) {
+        const u64 *xar = ar + e * n, *xam = am + e * n, *xbr = br + e * n, *xbm = bm + e * n; u64 *o = out + e * n, t[BL], u[BL];
+        if (pid == 0) { f_mul(o, xam, xbm, p, n); continue; }                  /* :116-120 */
+        f_mul(t, xar, xbm, p, n); f_mul(u, xbr, xam, p, n); f_add(o, t, u, p, n); /* :125-126 */
+        if (pid == 1) { f_mul(t, xar, xbr, p, n); f_add(u, o, t, p, n); memcpy(o, u, 8 * n); } /* :127-129 */
+    }
+}
+static void f_matmul_acc(u64 *out, const u64 *A, const u64 *B, const u64 *p, int n, int m, int k, int nn) {
+    u64 t[BL], u[BL];
+    for (int i = 0; i < m; i++) for (int j = 0; j < nn; j++) for (int x = 0; x < k; x++) {
+        f_mul(t, A + ((size_t)i * k + x) * n, B + ((size_t)x * nn + j) * n, p, n);
+        f_add(u, out + ((size_t)i * nn + j) * n, t, p, n); memcpy(out + ((size_t)i * nn + j) * n, u, 8 * n);
+    }
+}
+void orc_beaver_matmul(int pid, int n, const u64 *p, const u64 *ar, const u64 *am, const u64 *br, const u64 *bm, u64 *out, int m, int k, int nn) {
+    memset(out, 0, 8 * (size_t)n * m * nn);
+    if (pid == 0) { f_matmul_acc(out, am, bm, p, n, m, k, nn); return; }       /* :137-139 */
+    f_matmul_acc(out, ar, bm, p, n, m, k, nn); f_matmul_acc(out, am, br, p, n, m, k, nn); /* :141-142 */
+    if (pid == 1) f_matmul_acc(out, ar, br, p, n, m, k, nn);                   /* :143-145 */
+}
+
+/* ------------------------------------------------------------------ sketch (pca.go:152-162) */
+void orc_sketch(const int8_t *X, size_t nrow, size_t ncol, const int32_t *bucket, const int8_t *sgn, int kp, double *sk, u64 *xsum, u64 *x2sum) {
+    memset(sk, 0, 8 * (size_t)kp * ncol); memset(xsum, 0, 8 * ncol); memset(x2sum, 0, 8 * ncol);
+    for (size_t i = 0; i < nrow; i++) for (size_t j = 0; j < ncol; j++) {
+        int8_t x = X[i * ncol + j];
+        sk[(size_t)bucket[i] * ncol + j] += (double)sgn[i] * (double)x;
+        xsum[j] += (u64)(int64_t)x;                     /* Go uint64(int8) sign-extends: -1 -> 2^64-1 (wraps) */
+        x2sum[j] += (u64)(int64_t)(int8_t)(x * x);
+    }
+}
