@@ -1,0 +1,151 @@
+/*
+ * sfgwas_hip.h — C-ABI of libsfgwas_hip.so: the MI355X (gfx950) implementation of SF-GWAS's
+ * per-party local linear-algebra hot path.
+ *
+ * The reference (hhcho/sfgwas, 100 % Go) has no FFI/plugin seam; the seam is cut at Go function level
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces (file:line under
+ * the reference tree); INTEGRATION.md shows the cgo stub a maintainer would add on the Go side.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns 0 on success, non-zero on error, and
+ *    sfg_last_error(ctx) describes the failure (the reference panics on this path — matmult.go:361,
+ *    filestream.go:60 — so the Go shim turns non-zero into panic()).
+ *  - Ring: N = 2^logN (logN = 14 for the PN14QP438 preset used by the reference, gwas.go:169),
+ *    nq ciphertext primes q_0..q_{nq-1} followed by np special primes; all < 2^50 and == 1 mod 2N.
+ *  - Polynomial rows are N uint64 canonical residues in lattigo's NTT order
+ *    (row[i] = p(psi^(2*bitrev(i)+1))); a ciphertext at level l is [2][l+1][N]
+ *    (= ct.Value()[k].Coeffs[m][:] flattened, crypto.go:32-60).
+ *  - "_dev" pointers are device (HBM) addresses on the context's GPU; "_host" are host pointers.
+ *  - A context is re-entrant across threads only through separate contexts or external locking
+ *    (the Go evaluator pool has the same exclusivity rule, crypto.go:311-316).
+ */
+#ifndef SFGWAS_HIP_H
+#define SFGWAS_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfg_ctx sfg_ctx;
+typedef struct sfg_geno sfg_geno;
+
+/* ---- context: created after CollectiveInit (gwas.go:212), from cryptoParams.Params + ring tables ----
+ * replaces: ring.NewRing(N, Qi) at matmult.go:328,345,403 and the evaluator/encoder pools (crypto.go:89-135).
+ * psi[m]: the primitive 2N-th root lattigo uses for modulus m (ring.Ring.PsiMont un-Montgomery'd); NULL =>
+ * derived from the smallest primitive root exactly as lattigo derives it. */
+int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int np,
+                   const uint64_t *moduli, const uint64_t *psi, double scale);
+void sfg_ctx_destroy(sfg_ctx *ctx);
+const char *sfg_last_error(const sfg_ctx *ctx);     /* ctx may be NULL: error of a failed sfg_ctx_create */
+int sfg_ctx_synchronize(sfg_ctx *ctx);
+/* run all subsequent work of this context on the given hipStream_t (NULL = the context's own stream) */
+int sfg_ctx_set_stream(sfg_ctx *ctx, void *hip_stream);
+
+/* rotation key of one Galois element (cryptoParams.RotKs, crypto.go:50; generated at mhe.go:73, crypto.go:232-275).
+ * key_host: [beta][2][nq+np][N], beta = ceil(nq/np), NTT domain; montgomery_form != 0 if the words are in
+ * lattigo's Montgomery representation (they are in lattigo's SwitchingKey) */
+int sfg_ctx_load_rotkey(sfg_ctx *ctx, uint64_t galois_el, const uint64_t *key_host, int montgomery_form);
+int sfg_ctx_has_rotkey(const sfg_ctx *ctx, uint64_t galois_el);
+uint64_t sfg_galois_for_rotation(const sfg_ctx *ctx, int k_left);
+
+/* ---- device memory (so ciphertexts / genotypes stay resident across calls) ---- */
+int sfg_malloc(sfg_ctx *ctx, void **dev_ptr, size_t bytes);
+int sfg_free(sfg_ctx *ctx, void *dev_ptr);
+int sfg_memcpy_h2d(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int sfg_memcpy_d2h(sfg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- ring substrate (lattigo ring.NTT / ring.InvNTT behind crypto/basics.go) ----
+ * rows: nrows device rows of N words; mod_idx[r] selects the modulus (0..nq+np-1) of row r (host array) */
+int sfg_ntt_rows(sfg_ctx *ctx, uint64_t *rows_dev, int nrows, const int *mod_idx_host);
+int sfg_intt_rows(sfg_ctx *ctx, uint64_t *rows_dev, int nrows, const int *mod_idx_host);
+
+/* ---- A1/A2/A4: the lazy MAC (matmult.go:247-399) as a batched modular GEMM ----
+ * For every coefficient c < N and modulus l < L:
+ *    out[n][r][l][c] (+)= sum_{k<K} rot[k][r][l][c] * pt[k][n][l][c]   mod q_l
+ * rot: [K][R][L][N] rotated-ciphertext rows (R = 2*s: (i, poly)), pt: [K][Ncols][L][N] NTT-domain plaintexts
+ * (canonical, NOT Montgomery form), out: [Ncols][R][L][N].  accumulate != 0 adds onto out.
+ * Net effect of MulCoeffsAndAdd128 + ReduceAndAddUint128 + MForm + eval.Reduce: the canonical sum. */
+int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot_dev, const uint64_t *pt_dev, uint64_t *out_dev,
+                int K, int R, int Ncols, int L, int accumulate);
+
+/* ---- A6/A7: diagonal extraction + CKKS encode (matmult.go:636-731, EncodeNTT) ----
+ * Encodes the generalized diagonals `shift` in [shift0, shift0+nshift) of one <= slots x slots int8 block
+ * (block rows r, cols c, row stride ld; transposed != 0 reads the block transposed), each right-rotated by
+ * d*(shift/d), into NTT-domain plaintexts for moduli 0..L-1: pt_dev[nshift][L][N] canonical residues.
+ * Genotype values must already be cleaned (missing -> 0; squared if requested). */
+int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block_dev, size_t ld, int r, int c, int transposed,
+                         int shift0, int nshift, int L, uint64_t *pt_dev);
+/* coefficient-domain result of the encoder for arbitrary real slot vectors (host convenience used by
+ * Mask/MaskTrunc-style callers, basics.go:110-172): values_host[nvec][slots] -> coeffs_host[nvec][N] int64 */
+int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, int64_t *coeffs_host);
+
+/* ---- C1/A8: rotations (crypto/basics.go:201-224 -> ckks.Evaluator.RotateNew) ----
+ * batch of nct ciphertexts at `level`, each [2][level+1][N]; ct j is rotated RIGHT by nrot_host[j]
+ * (RotateRightWithEvaluator semantics: nrot mod slots, 0 = copy). in/out may not alias. */
+int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *ct_in_dev, uint64_t *ct_out_dev, int nct, int level,
+                         const int *nrot_host);
+/* C4: element-wise ciphertext add (eval.Add, basics.go:174, matmult.go:1225,1494): out = a + b */
+int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
+
+/* ---- F1 + A11: genotype matrix residency (replaces GenoFileStream reads + the DiagCache of
+ * MatMult4StreamPreprocess, matmult.go:914-1041; filestream.go:284-494).
+ * geno: nrow x ncol int8 row-major (row stride ld), -1 = missing.  The handle keeps ONE int8 copy in HBM
+ * that serves both X (transpose = 0) and X^T (transpose = 1) products. */
+int sfg_geno_upload(sfg_ctx *ctx, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
+int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *geno_dev, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
+void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g);
+/* P2: per-column sum / sum of squares after missing->0 (matmult.go:1292-1300); either may be NULL */
+int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *sqsum_host);
+
+/* ---- A9/A10: the full product (MatMult4Stream matmult.go:1238-1505, MatMult4StreamCompute :1043-1236) ----
+ * A: s x nbr ciphertexts [s][nbr][2][in_level+1][N] (nbr = ceil(rows/slots) of the operand orientation);
+ * out: s x m_ct ciphertexts [s][m_ct][2][max_level][N] at level max_level-1, scale = A.scale * Params.Scale().
+ * The result is the deterministic sum over giant steps; the reference adds it onto a fresh encryption of zero
+ * (CZeroMat, matmult.go:1174,1443) which the Go shim keeps doing.
+ * flags: SFG_SQUARE squares genotypes after missing->0 (matmult.go:1301-1303); SFG_TRANSPOSE multiplies by X^T. */
+#define SFG_SQUARE 1u
+#define SFG_TRANSPOSE 2u
+int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,
+                            const sfg_geno *g, unsigned flags, uint64_t *out_dev);
+/* host-pointer form, one call = MatMult4Stream(cps, A, gfs, maxLevel, computeSquaredSum, square, nproc) */
+int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level, int max_level,
+                      const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, unsigned flags,
+                      uint64_t *out_host, double *sum_host, double *sqsum_host);
+/* sharding hooks for one-process-per-GPU runs: restrict a resident product to block columns
+ * [j0, j1) of the output (X: SNP-column blocks) or block rows [b0, b1) of the contraction (X^T) */
+int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,
+                                  const sfg_geno *g, unsigned flags, int blk0, int blk1, uint64_t *out_dev);
+/* after an integer all-reduce(sum) of partial outputs across ranks: canonical reduction mod q_l of [rows][L][N] */
+int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows_dev, size_t nrows_of_L, int L);
+
+/* ---- B1-B3: Beaver local products (mpc/beavermult.go:94-147) over a prime field of `limbs` 64-bit LE limbs ---- */
+int sfg_beaver_elem_dev(sfg_ctx *ctx, int pid, int limbs, const uint64_t *modulus_host,
+                        const uint64_t *ar_dev, const uint64_t *am_dev, const uint64_t *br_dev, const uint64_t *bm_dev,
+                        uint64_t *out_dev, size_t n);
+int sfg_beaver_elem(sfg_ctx *ctx, int pid, int limbs, const uint64_t *modulus_host,
+                    const uint64_t *ar_host, const uint64_t *am_host, const uint64_t *br_host, const uint64_t *bm_host,
+                    uint64_t *out_host, size_t n);
+int sfg_beaver_matmul(sfg_ctx *ctx, int pid, int limbs, const uint64_t *modulus_host,
+                      const uint64_t *ar_host, const uint64_t *am_host, const uint64_t *br_host, const uint64_t *bm_host,
+                      uint64_t *out_host, int m, int k, int n);
+
+/* ---- P1: count-sketch + moments (gwas/pca.go:152-162) ----
+ * sketch[kp][ncol] fp64 (exact integers), xsum/x2sum[ncol] uint64 */
+int sfg_sketch(sfg_ctx *ctx, const sfg_geno *g, const int32_t *bucket_host, const int8_t *sgn_host, int kp,
+               double *sketch_host, uint64_t *xsum_host, uint64_t *x2sum_host);
+
+/* ---- synthetic data generators used by bench.py / tests (counter-mode splitmix64) ---- */
+int sfg_fill_uniform_ct_dev(sfg_ctx *ctx, uint64_t *ct_dev, int nct, int level, uint64_t seed);
+int sfg_fill_geno_dev(sfg_ctx *ctx, int8_t *geno_dev, size_t nrow, size_t ncol, uint64_t seed);
+int sfg_fill_rotkeys_synthetic(sfg_ctx *ctx, const int *rot_left, int nrot, uint64_t seed);
+
+/* last kernel timing hooks for bench.py: milliseconds spent (HIP events on the ctx stream) in the named phase
+ * of the most recent matmul call: "encode", "ntt", "mac", "rotate", "skew" ; returns <0 if unknown */
+double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase);
+int sfg_last_phase_launches(const sfg_ctx *ctx, const char *phase);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

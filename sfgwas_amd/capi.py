@@ -1,0 +1,187 @@
+"""ctypes binding of libsfgwas_hip.so (the C-ABI declared in include/sfgwas_hip.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is no CPU
+fallback: if the library is missing or no GPU is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfgwas_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+_lib = None
+
+SFG_SQUARE = 1
+SFG_TRANSPOSE = 2
+
+
+class SfgError(RuntimeError):
+    pass
+
+
+def _sig(L):
+    vp, i, u64, d, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_size_t
+    S = {
+        "sfg_ctx_create": (i, [C.POINTER(vp), i, i, i, i, u64p, u64p, d]),
+        "sfg_ctx_destroy": (None, [vp]),
+        "sfg_last_error": (C.c_char_p, [vp]),
+        "sfg_ctx_synchronize": (i, [vp]),
+        "sfg_ctx_set_stream": (i, [vp, vp]),
+        "sfg_ctx_load_rotkey": (i, [vp, u64, u64p, i]),
+        "sfg_ctx_has_rotkey": (i, [vp, u64]),
+        "sfg_galois_for_rotation": (u64, [vp, i]),
+        "sfg_malloc": (i, [vp, C.POINTER(vp), sz]),
+        "sfg_free": (i, [vp, vp]),
+        "sfg_memcpy_h2d": (i, [vp, vp, vp, sz]),
+        "sfg_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "sfg_ntt_rows": (i, [vp, vp, i, C.POINTER(i)]),
+        "sfg_intt_rows": (i, [vp, vp, i, C.POINTER(i)]),
+        "sfg_mac_dev": (i, [vp, vp, vp, vp, i, i, i, i, i]),
+        "sfg_encode_diags_dev": (i, [vp, vp, sz, i, i, i, i, i, i, vp]),
+        "sfg_encode_coeffs_host": (i, [vp, C.POINTER(d), i, C.POINTER(C.c_int64)]),
+        "sfg_rotate_right_dev": (i, [vp, vp, vp, i, i, C.POINTER(i)]),
+        "sfg_ct_add_dev": (i, [vp, vp, vp, vp, i, i]),
+        "sfg_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
+        "sfg_geno_from_device": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
+        "sfg_geno_free": (None, [vp, vp]),
+        "sfg_geno_colsums": (i, [vp, vp, C.POINTER(d), C.POINTER(d)]),
+        "sfg_matmul_resident_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, vp]),
+        "sfg_matmul_stream": (i, [vp, u64p, i, i, i, vp, sz, sz, sz, C.c_uint, u64p, C.POINTER(d), C.POINTER(d)]),
+        "sfg_matmul_resident_range_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, vp]),
+        "sfg_reduce_rows_dev": (i, [vp, vp, sz, i]),
+        "sfg_beaver_elem_dev": (i, [vp, i, i, u64p, vp, vp, vp, vp, vp, sz]),
+        "sfg_beaver_elem": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, sz]),
+        "sfg_beaver_matmul": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, i, i, i]),
+        "sfg_sketch": (i, [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int8), i, C.POINTER(d), u64p, u64p]),
+        "sfg_fill_uniform_ct_dev": (i, [vp, vp, i, i, u64]),
+        "sfg_fill_geno_dev": (i, [vp, vp, sz, sz, u64]),
+        "sfg_fill_rotkeys_synthetic": (i, [vp, C.POINTER(i), i, u64]),
+        "sfg_last_phase_ms": (d, [vp, C.c_char_p]),
+        "sfg_last_phase_launches": (i, [vp, C.c_char_p]),
+    }
+    for name, (res, args) in S.items():
+        fn = getattr(L, name)         # AttributeError here = the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return list(S.keys())
+
+
+EXPORTS = []
+
+
+def lib():
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfgError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+        _lib = C.CDLL(LIB_PATH)
+        EXPORTS = _sig(_lib)
+    return _lib
+
+
+def p64(a):
+    assert a.dtype == np.uint64 and a.flags.c_contiguous
+    return a.ctypes.data_as(u64p)
+
+
+class Context:
+    """sfg_ctx wrapper. moduli = q list + p list; psi=None derives lattigo's root."""
+
+    def __init__(self, q, p, scale=2.0 ** 34, logN=14, device=0, psi=None):
+        L = lib()
+        self.q, self.p = list(q), list(p)
+        self.nq, self.np_ = len(q), len(p)
+        self.N, self.slots = 1 << logN, (1 << logN) // 2
+        mods = np.array(self.q + self.p, dtype=np.uint64)
+        h = C.c_void_p()
+        ps = None if psi is None else p64(np.array(psi, dtype=np.uint64))
+        rc = L.sfg_ctx_create(C.byref(h), device, logN, self.nq, self.np_, p64(mods), ps, float(scale))
+        if rc:
+            raise SfgError("sfg_ctx_create: " + L.sfg_last_error(None).decode())
+        self.h = h
+        self.beta = (self.nq + self.np_ - 1) // self.np_
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sfg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what):
+        if rc:
+            raise SfgError(f"{what}: {lib().sfg_last_error(self.h).decode()}")
+
+    # ---- memory
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(lib().sfg_malloc(self.h, C.byref(p), nbytes), "sfg_malloc")
+        return p
+
+    def free(self, p):
+        self.check(lib().sfg_free(self.h, p), "sfg_free")
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        self.check(lib().sfg_memcpy_h2d(self.h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+        return p
+
+    def to_host(self, p, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self.check(lib().sfg_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), p, out.nbytes), "d2h")
+        return out
+
+    def sync(self):
+        self.check(lib().sfg_ctx_synchronize(self.h), "sync")
+
+    # ---- ring substrate
+    def ntt_rows(self, rows, mod_idx, inverse=False):
+        """rows: [nrows][N] uint64 host array; returns transformed copy (round-trips through HBM)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        n = rows.shape[0]
+        mi = (C.c_int * n)(*[int(x) for x in mod_idx])
+        d = self.to_device(rows)
+        fn = lib().sfg_intt_rows if inverse else lib().sfg_ntt_rows
+        self.check(fn(self.h, d, n, mi), "ntt_rows")
+        out = self.to_host(d, rows.shape, np.uint64)
+        self.free(d)
+        return out
+
+    def load_rotkey(self, galois, key, montgomery=False):
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        self.check(lib().sfg_ctx_load_rotkey(self.h, int(galois), p64(key), int(montgomery)), "load_rotkey")
+
+    def galois(self, k):
+        return lib().sfg_galois_for_rotation(self.h, k)
+
+    def phase_ms(self, name):
+        return lib().sfg_last_phase_ms(self.h, name.encode())
+
+
+def _ctx_mac(self, rot, pt, L, out_init=None):
+    """rot: [K][R][L][N], pt: [K][Ncols][L][N] -> out [Ncols][R][L][N] (host arrays, staged through HBM)."""
+    rot = np.ascontiguousarray(rot, dtype=np.uint64)
+    pt = np.ascontiguousarray(pt, dtype=np.uint64)
+    K, R = rot.shape[0], rot.shape[1]
+    Ncols = pt.shape[1]
+    assert rot.shape[2] == L and pt.shape[2] == L and pt.shape[0] == K
+    d_rot, d_pt = self.to_device(rot), self.to_device(pt)
+    if out_init is not None:
+        d_out = self.to_device(np.ascontiguousarray(out_init, dtype=np.uint64))
+    else:
+        d_out = self.malloc(Ncols * R * L * self.N * 8)
+    self.check(lib().sfg_mac_dev(self.h, d_rot, d_pt, d_out, K, R, Ncols, L, int(out_init is not None)), "sfg_mac_dev")
+    out = self.to_host(d_out, (Ncols, R, L, self.N), np.uint64)
+    for p in (d_rot, d_pt, d_out):
+        self.free(p)
+    return out
+
+
+Context.mac = _ctx_mac

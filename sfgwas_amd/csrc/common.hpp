@@ -1,0 +1,140 @@
+// common.hpp — shared host/device definitions of libsfgwas_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/sfgwas_hip.h"
+
+typedef unsigned long long u64;
+typedef unsigned __int128 u128;
+
+constexpr int SFG_LOGN = 14;
+constexpr int SFG_N = 1 << SFG_LOGN;      // ring degree (PN14QP438, gwas.go:169)
+constexpr int SFG_SLOTS = SFG_N / 2;
+constexpr int SFG_D = 91;                 // ceil(sqrt(8192)), matmult.go:1047
+constexpr int SFG_MAXMOD = 16;
+
+// per-modulus constants, device copy
+struct ModConst {
+    double q, qinv;        // q and 1/q as doubles
+    double ninv, ninv_q;   // N^-1 mod q and (N^-1 mod q)/q  (INTT scaling)
+    u64 qi;                // q as integer
+};
+
+struct RotKey {
+    u64 *key_dev = nullptr;        // [beta][2][nmod][N] normal form
+    uint16_t *index_dev = nullptr; // automorphism index map (N entries)
+};
+
+struct PhaseStat { double ms = 0; int launches = 0; };
+
+struct sfg_geno {
+    const int8_t *dev = nullptr;
+    size_t nrow = 0, ncol = 0, ld = 0;
+    bool owned = false;
+};
+
+struct sfg_ctx {
+    int device = 0;
+    int logN = SFG_LOGN, N = SFG_N, nq = 0, np = 0, nmod = 0, beta = 0;
+    double scale = 0;
+    u64 q[SFG_MAXMOD] = {0}, psi[SFG_MAXMOD] = {0};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // device tables
+    double2 *tw_fwd = nullptr;   // [nmod][N] {w, w/q}, index m+i as in the CT loop (psi^bitrev)
+    double2 *tw_inv = nullptr;   // [nmod][N] {w, w/q} for psi^-bitrev
+    ModConst *modc = nullptr;    // [nmod]
+    ModConst modc_host[SFG_MAXMOD];
+    // encoder tables (double-double twiddles), see encode.hip
+    void *enc_tables = nullptr;
+    // rotation keys
+    std::map<u64, RotKey> rotkeys;
+    // scratch
+    void *ws = nullptr; size_t ws_bytes = 0;
+    std::string err;
+    std::map<std::string, PhaseStat> phases;
+};
+
+extern thread_local std::string g_create_error;
+
+#define SFG_FAIL(ctx, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); (ctx)->err = _b; return 1; } while (0)
+#define SFG_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[512]; \
+    snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); (ctx)->err = _b; return 1; } } while (0)
+#define SFG_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// workspace (grow-only scratch owned by the context)
+int sfg_ws_reserve(sfg_ctx *ctx, size_t bytes);
+
+// host modular helpers
+static inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+static inline u64 h_powmod(u64 a, u64 e, u64 q) { u64 r = 1 % q; a %= q; while (e) { if (e & 1) r = h_mulmod(r, a, q); a = h_mulmod(a, a, q); e >>= 1; } return r; }
+static inline u64 h_invmod(u64 a, u64 q) { return h_powmod(a, q - 2, q); }
+static inline uint32_t h_brev(uint32_t x, int bits) { uint32_t r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+// phase timing helper: records HIP events around a region on the ctx stream
+struct PhaseTimer {
+    sfg_ctx *ctx; const char *name; hipEvent_t e0, e1; bool on;
+    PhaseTimer(sfg_ctx *c, const char *n, bool enable = true) : ctx(c), name(n), on(enable) {
+        if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, ctx->stream); }
+    }
+    void stop(int launches = 1) {
+        if (!on) return;
+        (void)hipEventRecord(e1, ctx->stream); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        auto &p = ctx->phases[name]; p.ms += ms; p.launches += launches;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); on = false;
+    }
+    ~PhaseTimer() { stop(0); }
+};
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device arithmetic
+// All ring arithmetic on the device is done on exact integers held in fp64 registers (|x| < 2^53):
+// measured on gfx950 v_fma_f64 and v_mad_u64_u32 issue at the same rate (profiles/r01_ubench_*.txt),
+// and the fp64 form needs no carry chains.
+
+// x*w mod q, result in (-q, q) (not canonical). Requires |x|*w < 2^105, |x| < 2^51, wq = w/q (rounded).
+__device__ __forceinline__ double mulmod_lazy(double x, double w, double wq, double q) {
+    double qh = __builtin_rint(x * wq);
+    double h = x * w;
+    double l = __builtin_fma(x, w, -h);
+    double r = __builtin_fma(-qh, q, h);
+    return r + l;
+}
+// canonical representative in [0, q) of an integer-valued double |x| < 2^52
+__device__ __forceinline__ double canon(double x, double q, double qinv) {
+    double qh = __builtin_floor(x * qinv);
+    double r = __builtin_fma(-qh, q, x);
+    r = r < 0.0 ? r + q : r;
+    r = r >= q ? r - q : r;
+    return r;
+}
+// partial reduction to (-q, q): cheap, for lazy sums that would otherwise grow
+__device__ __forceinline__ double pred(double x, double q, double qinv) {
+    double qh = __builtin_rint(x * qinv);
+    return __builtin_fma(-qh, q, x);
+}
+__device__ __forceinline__ double u64_to_f64(u64 x) {            // exact for x < 2^52
+    return __longlong_as_double((long long)(x | 0x4330000000000000ULL)) - 4503599627370496.0;
+}
+__device__ __forceinline__ u64 f64_to_u64(double x) {            // exact for integer 0 <= x < 2^52
+    return (u64)__double_as_longlong(x + 4503599627370496.0) & 0x000FFFFFFFFFFFFFULL;
+}
+__device__ __forceinline__ u64 d_mulmod_u64(u64 a, u64 b, u64 q) { // generic (slow) path for setup kernels
+    u64 hi = __umul64hi(a, b), lo = a * b;
+    // 128-by-64 division by shift-subtract (setup only)
+    u64 r = hi % q;
+    for (int i = 63; i >= 0; i--) { u64 top = r >> 63; r = (r << 1) | ((lo >> i) & 1); if (top || r >= q) r -= q; }
+    return r;
+}
+__device__ __forceinline__ u64 splitmix_at(u64 seed, u64 idx) {   // counter-mode splitmix64 (element idx, 0-based)
+    u64 z = seed + 0x9E3779B97F4A7C15ULL * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+#endif

@@ -1,0 +1,155 @@
+// ctx.hip — context, tables, memory and key management of libsfgwas_hip.
+#include "common.hpp"
+
+thread_local std::string g_create_error;
+
+// smallest primitive root g of prime q, psi = g^((q-1)/2N): how lattigo's ring.NewRing derives its
+// 2N-th root (used when the caller does not hand over ring.PsiMont)
+static u64 derive_psi(u64 q, int logN) {
+    u64 phi = q - 1, n = phi; std::vector<u64> fac;
+    for (u64 p = 2; p * p <= n; p += (p == 2 ? 1 : 2)) if (n % p == 0) { fac.push_back(p); while (n % p == 0) n /= p; }
+    if (n > 1) fac.push_back(n);
+    for (u64 g = 2;; g++) {
+        bool ok = true;
+        for (u64 f : fac) if (h_powmod(g, phi / f, q) == 1) { ok = false; break; }
+        if (ok) return h_powmod(g, phi >> (logN + 1), q);
+    }
+}
+
+int sfg_encoder_init(sfg_ctx *ctx);      // encode.hip
+void sfg_encoder_destroy(sfg_ctx *ctx);
+
+extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int np,
+                              const uint64_t *moduli, const uint64_t *psi, double scale) {
+    *out = nullptr;
+    if (logN != SFG_LOGN) { g_create_error = "only logN = 14 (PN14QP438) is built into this library"; return 1; }
+    if (nq < 1 || np < 1 || nq + np > SFG_MAXMOD) { g_create_error = "bad modulus counts"; return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device: libsfgwas_hip has no CPU fallback"; return 1; }
+    if (device < 0 || device >= ndev) { g_create_error = "bad device index"; return 1; }
+    sfg_ctx *ctx = new sfg_ctx();
+    ctx->device = device; ctx->nq = nq; ctx->np = np; ctx->nmod = nq + np; ctx->beta = (nq + np - 1) / np; ctx->scale = scale;
+    auto fail = [&](const char *m) { g_create_error = m; sfg_ctx_destroy(ctx); return 1; };
+    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    ctx->stream = ctx->own_stream;
+    const int N = SFG_N;
+    std::vector<double2> twf((size_t)ctx->nmod * N), twi((size_t)ctx->nmod * N);
+    for (int m = 0; m < ctx->nmod; m++) {
+        u64 q = moduli[m];
+        if (q >= (1ULL << 50) || (q - 1) % (2ULL * N)) return fail("modulus must be < 2^50 and == 1 mod 2N");
+        ctx->q[m] = q;
+        ctx->psi[m] = psi ? psi[m] : derive_psi(q, logN);
+        if (h_powmod(ctx->psi[m], N, q) != q - 1) return fail("psi is not a primitive 2N-th root of unity");
+        u64 psi_inv = h_invmod(ctx->psi[m], q), p = 1, pi = 1;
+        for (int k = 0; k < N; k++) {
+            uint32_t b = h_brev((uint32_t)k, logN);
+            twf[(size_t)m * N + b] = make_double2((double)p, (double)p / (double)q);
+            twi[(size_t)m * N + b] = make_double2((double)pi, (double)pi / (double)q);
+            p = h_mulmod(p, ctx->psi[m], q); pi = h_mulmod(pi, psi_inv, q);
+        }
+        ModConst &mc = ctx->modc_host[m];
+        mc.q = (double)q; mc.qinv = 1.0 / (double)q; mc.qi = q;
+        u64 ninv = h_invmod((u64)N, q);
+        mc.ninv = (double)ninv; mc.ninv_q = (double)ninv / (double)q;
+    }
+    if (hipMalloc(&ctx->tw_fwd, twf.size() * sizeof(double2)) != hipSuccess || hipMalloc(&ctx->tw_inv, twi.size() * sizeof(double2)) != hipSuccess ||
+        hipMalloc(&ctx->modc, sizeof(ModConst) * SFG_MAXMOD) != hipSuccess) return fail("hipMalloc of tables failed");
+    if (hipMemcpy(ctx->tw_fwd, twf.data(), twf.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->tw_inv, twi.data(), twi.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->modc, ctx->modc_host, sizeof(ModConst) * SFG_MAXMOD, hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
+    if (sfg_encoder_init(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (auto &kv : ctx->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
+    sfg_encoder_destroy(ctx);
+    (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char *sfg_last_error(const sfg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int sfg_ctx_synchronize(sfg_ctx *ctx) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) { ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return 0; }
+
+int sfg_ws_reserve(sfg_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return 0;
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) SFG_HIP(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr; ctx->ws_bytes = 0;
+    SFG_HIP(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return 0;
+}
+
+extern "C" int sfg_malloc(sfg_ctx *ctx, void **p, size_t bytes) { SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMalloc(p, bytes)); return 0; }
+extern "C" int sfg_free(sfg_ctx *ctx, void *p) { SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); SFG_HIP(ctx, hipFree(p)); return 0; }
+extern "C" int sfg_memcpy_h2d(sfg_ctx *ctx, void *d, const void *s, size_t n) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+}
+extern "C" int sfg_memcpy_d2h(sfg_ctx *ctx, void *d, const void *s, size_t n) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+}
+
+extern "C" double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase) {
+    auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1.0 : it->second.ms;
+}
+extern "C" int sfg_last_phase_launches(const sfg_ctx *ctx, const char *phase) {
+    auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1 : it->second.launches;
+}
+
+// ---------------------------------------------------------------- rotation keys
+extern "C" uint64_t sfg_galois_for_rotation(const sfg_ctx *ctx, int k) {
+    const u64 M = 2ULL * SFG_N; int n = SFG_SLOTS; k %= n; if (k < 0) k += n;
+    u64 g = 1; for (int i = 0; i < k; i++) g = (g * 5) % M; return g;
+}
+extern "C" int sfg_ctx_has_rotkey(const sfg_ctx *ctx, uint64_t g) { return ctx->rotkeys.count(g) ? 1 : 0; }
+
+// lattigo ring.InvMForm: x * 2^-64 mod q, applied when the caller hands keys in Montgomery form
+__global__ void k_from_montgomery(u64 *rows, int nmod, const ModConst *modc, size_t total_rows) {
+    size_t row = blockIdx.y; int m = (int)(row % nmod); u64 q = modc[m].qi;
+    // 2^-64 mod q computed per block (setup path, not hot)
+    __shared__ u64 r64inv;
+    if (threadIdx.x == 0) {
+        u64 r = ((~0ULL) % q + 1) % q;          // 2^64 mod q
+        // modular inverse by Fermat
+        u64 e = q - 2, base = r, acc = 1;
+        while (e) { if (e & 1) acc = d_mulmod_u64(acc, base, q); base = d_mulmod_u64(base, base, q); e >>= 1; }
+        r64inv = acc;
+    }
+    __syncthreads();
+    u64 *p = rows + row * SFG_N;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < SFG_N; x += gridDim.x * blockDim.x) p[x] = d_mulmod_u64(p[x], r64inv, q);
+}
+
+extern "C" int sfg_ctx_load_rotkey(sfg_ctx *ctx, uint64_t g, const uint64_t *key_host, int mont) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const int N = SFG_N; size_t words = (size_t)ctx->beta * 2 * ctx->nmod * N;
+    RotKey rk;
+    auto it = ctx->rotkeys.find(g);
+    if (it != ctx->rotkeys.end()) rk = it->second;
+    else { SFG_HIP(ctx, hipMalloc(&rk.key_dev, words * 8)); SFG_HIP(ctx, hipMalloc(&rk.index_dev, N * sizeof(uint16_t))); }
+    SFG_HIP(ctx, hipMemcpyAsync(rk.key_dev, key_host, words * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (mont) {
+        dim3 grid(8, (unsigned)((size_t)ctx->beta * 2 * ctx->nmod));
+        hipLaunchKernelGGL(k_from_montgomery, grid, dim3(256), 0, ctx->stream, rk.key_dev, ctx->nmod, ctx->modc, (size_t)grid.y);
+    }
+    // lattigo ring.PermuteNTTIndex: out[i] = in[index[i]]
+    std::vector<uint16_t> idx(N); u64 mask = 2ULL * N - 1;
+    for (int i = 0; i < N; i++) { u64 t1 = 2ULL * h_brev((uint32_t)i, SFG_LOGN) + 1; u64 t2 = ((g * t1 & mask) - 1) >> 1; idx[i] = (uint16_t)h_brev((uint32_t)t2, SFG_LOGN); }
+    SFG_HIP(ctx, hipMemcpyAsync(rk.index_dev, idx.data(), N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rotkeys[g] = rk;
+    return 0;
+}

@@ -1,0 +1,199 @@
+// mac.hip — the hot loop of the hot path: lazy multiply-accumulate of rotated ciphertext rows with encoded
+// diagonals (MulCoeffsAndAdd128 / CPMultAccWithoutMRedV2 / ReduceAndAddUint128, gwas/matmult.go:247-399).
+//
+// The reference walks diagonals outermost and keeps s*d*m_ct u128 accumulator polynomials in RAM (440 GB at
+// 100k x 1M).  Here the same sums are organised as a batched modular GEMM: for every coefficient c and modulus l
+//       out[n][r][l][c] (+)= sum_{k<K} rot[k][r][l][c] * pt[k][n][l][c]   (mod q_l)
+// k = (block row, baby step), n = (giant step, block column), r = (ciphertext row i, poly).  Coefficients are
+// independent, so nothing is shared across lanes except the `rot` operand, which every column of a workgroup
+// re-uses: it is staged once per workgroup in LDS (as fp64), each `pt` word is read exactly once from HBM
+// straight into registers, and the R accumulators of a column never leave VGPRs until the K loop ends.
+//
+// Arithmetic (measured: v_fma_f64 and v_mad_u64_u32 issue at the same rate on gfx950, fp64 needs no carry
+// chain): exact integer dot products in fp64 limbs —
+//   q < 2^36 ("small"): pt = p0 + p1*2^12 + p2*2^24 (12-bit limbs), acc_j += rot * p_j      3 FMA / MAC
+//   q < 2^47 ("big")  : rot = r0 + r1*2^23, pt = p0 + p1*2^23,  acc00,acc01,acc11            4 FMA / MAC
+// every product is < 2^48 so >= 24 terms add exactly below 2^53; accumulators are folded to (-q,q) every
+// `flush` terms, recombined and canonically reduced once at the end.  The canonical sum is what
+// MForm + u128 MAC + REDC + eval.Reduce produce in the reference, so outputs are bit-identical.
+#include "common.hpp"
+#include "kernels.hpp"
+
+constexpr int MAC_CL = 16;        // coefficients per workgroup (lanes 0..15 of each 16-lane group)
+constexpr int MAC_CG = 4;         // column groups per wave
+constexpr int MAC_WAVES = 8;
+constexpr int MAC_COLS = MAC_CG * MAC_WAVES;   // 32 output columns per workgroup
+constexpr int MAC_KC = 8;         // k-steps staged per LDS chunk
+constexpr int MAC_RMAX = 30;      // rows per pass (2 * kp, kp = 15: pca.go:87)
+
+struct MacArgs {
+    const u64 *rot; const u64 *pt; u64 *out;
+    int K, R, Ncols, L, accumulate;
+    int r0;            // first row of this pass
+    int l0, nl;        // moduli handled by this launch [l0, l0+nl)
+    int flush;         // fold accumulators every `flush` k-steps (multiple of MAC_KC)
+    int ntile;
+};
+
+template <bool BIG, int RT>
+__global__ void __launch_bounds__(512, 2) k_mac(MacArgs a, const ModConst *modc) {
+    constexpr int RW = BIG ? 2 : 1;                    // doubles per staged rot word
+    __shared__ double lds[2][MAC_KC][RT][MAC_CL * RW];
+    const int N = SFG_N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cc = lane & 15, cg = lane >> 4;
+    // XCD-aware decode: the `ntile` column tiles that share one (c-block, modulus) slab of `rot` get consecutive
+    // slots on the same XCD (blocks b and b+8 share an XCD), so the slab is served from that XCD's L2.
+    const int b = blockIdx.x, grp = b / (8 * a.ntile), rem = b % (8 * a.ntile);
+    const int slab = grp * 8 + (rem & 7), tile = rem >> 3;
+    const int nslab = (N / MAC_CL) * a.nl;
+    if (slab >= nslab) return;
+    const int l = a.l0 + slab / (N / MAC_CL), c0 = (slab % (N / MAC_CL)) * MAC_CL;
+    const double q = modc[l].q, qinv = modc[l].qinv;
+    const int n = tile * MAC_COLS + wave * MAC_CG + cg;          // this thread's output column
+    const bool active = n < a.Ncols;
+    const int nn = active ? n : a.Ncols - 1;                       // clamp loads of idle threads
+
+    const size_t rot_k_stride = (size_t)a.R * a.L * N, pt_k_stride = (size_t)a.Ncols * a.L * N;
+    const u64 *rot_base = a.rot + ((size_t)a.r0 * a.L + l) * N + c0;
+    const u64 *pt_ptr = a.pt + ((size_t)nn * a.L + l) * N + c0 + cc;
+
+    double acc[RT][3];
+#pragma unroll
+    for (int r = 0; r < RT; r++) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
+
+    const int nchunk = (a.K + MAC_KC - 1) / MAC_KC;
+    // stage chunk ch into buffer bufi: word e -> (kk, r, c)
+    auto stage = [&](int ch, int bufi) {
+        for (int e = tid; e < MAC_KC * RT * MAC_CL; e += 512) {
+            int kk = e / (RT * MAC_CL), rm = e % (RT * MAC_CL), r = rm / MAC_CL, c = rm % MAC_CL;
+            int k = ch * MAC_KC + kk;
+            u64 w = 0;
+            if (k < a.K && a.r0 + r < a.R) w = rot_base[(size_t)k * rot_k_stride + (size_t)r * a.L * N + c];
+            if (BIG) {
+                lds[bufi][kk][r][c * 2 + 0] = (double)(unsigned)(w & 0x7FFFFFu);
+                lds[bufi][kk][r][c * 2 + 1] = u64_to_f64(w >> 23);
+            } else {
+                lds[bufi][kk][r][c] = u64_to_f64(w);
+            }
+        }
+    };
+    u64 pw[MAC_KC];
+    auto load_pt = [&](int ch) {
+#pragma unroll
+        for (int kk = 0; kk < MAC_KC; kk++) {
+            int k = ch * MAC_KC + kk;
+            pw[kk] = k < a.K ? pt_ptr[(size_t)k * pt_k_stride] : 0ULL;
+        }
+    };
+    stage(0, 0);
+    load_pt(0);
+    __syncthreads();
+    int since_flush = 0;
+    for (int ch = 0; ch < nchunk; ch++) {
+        const int bufi = ch & 1;
+        u64 pcur[MAC_KC];
+#pragma unroll
+        for (int kk = 0; kk < MAC_KC; kk++) pcur[kk] = pw[kk];
+        if (ch + 1 < nchunk) { stage(ch + 1, bufi ^ 1); load_pt(ch + 1); }
+#pragma unroll
+        for (int kk = 0; kk < MAC_KC; kk++) {
+            const u64 p = pcur[kk];
+            if (BIG) {
+                const double p0 = (double)(unsigned)(p & 0x7FFFFFu), p1 = u64_to_f64(p >> 23);
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const double2 rv = *reinterpret_cast<const double2 *>(&lds[bufi][kk][r][cc * 2]);
+                    acc[r][0] = __builtin_fma(rv.x, p0, acc[r][0]);
+                    acc[r][1] = __builtin_fma(rv.x, p1, acc[r][1]);
+                    acc[r][1] = __builtin_fma(rv.y, p0, acc[r][1]);
+                    acc[r][2] = __builtin_fma(rv.y, p1, acc[r][2]);
+                }
+            } else {
+                const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
+                const double p0 = (double)(plo & 0xFFFu), p1 = (double)((plo >> 12) & 0xFFFu);
+                const double p2 = (double)((plo >> 24) | (phi << 8));
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const double rv = lds[bufi][kk][r][cc];
+                    acc[r][0] = __builtin_fma(rv, p0, acc[r][0]);
+                    acc[r][1] = __builtin_fma(rv, p1, acc[r][1]);
+                    acc[r][2] = __builtin_fma(rv, p2, acc[r][2]);
+                }
+            }
+        }
+        since_flush += MAC_KC;
+        if (since_flush >= a.flush) {
+            since_flush = 0;
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                acc[r][0] = pred(acc[r][0], q, qinv); acc[r][1] = pred(acc[r][1], q, qinv); acc[r][2] = pred(acc[r][2], q, qinv);
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    // recombine limbs: value = acc0 + acc1 * 2^S + acc2 * 2^(2S)  (mod q)
+    constexpr double S1 = BIG ? 8388608.0 : 4096.0;
+    const double s1 = S1, s1q = S1 / q;
+    const double s2raw = S1 * S1;                 // 2^46 (big) may exceed q: reduce it first
+    const double s2 = canon(s2raw, q, qinv), s2q = s2 / q;
+    u64 *out = a.out + (((size_t)n * a.R + a.r0) * a.L + l) * N + c0 + cc;
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+        if (a.r0 + r < a.R) {
+            double x = pred(acc[r][0], q, qinv);
+            x += mulmod_lazy(pred(acc[r][1], q, qinv), s1, s1q, q);
+            x += mulmod_lazy(pred(acc[r][2], q, qinv), s2, s2q, q);
+            u64 *o = out + (size_t)r * a.L * N;
+            if (a.accumulate) x += u64_to_f64(*o);
+            *o = f64_to_u64(canon(x, q, qinv));
+        }
+    }
+}
+
+template <bool BIG>
+static int launch_mac_rt(sfg_ctx *ctx, MacArgs a, int rt) {
+    const int nslab = (SFG_N / MAC_CL) * a.nl;
+    a.ntile = (a.Ncols + MAC_COLS - 1) / MAC_COLS;
+    const int ngrp = (nslab + 7) / 8;
+    dim3 grid((unsigned)(ngrp * 8 * a.ntile));
+    if (rt <= 2) hipLaunchKernelGGL((k_mac<BIG, 2>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
+    else if (rt <= 8) hipLaunchKernelGGL((k_mac<BIG, 8>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
+    else if (rt <= 16) hipLaunchKernelGGL((k_mac<BIG, 16>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
+    else hipLaunchKernelGGL((k_mac<BIG, MAC_RMAX>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate) {
+    if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac: L out of range");
+    for (int r0 = 0; r0 < R; r0 += MAC_RMAX) {
+        int rt = R - r0 < MAC_RMAX ? R - r0 : MAC_RMAX;
+        // moduli are handled in runs of equal kind (small / big)
+        int l = 0;
+        while (l < L) {
+            bool big = ctx->q[l] >= (1ULL << 36);
+            if (ctx->q[l] >= (1ULL << 47)) SFG_FAIL(ctx, "sfg_mac: modulus >= 2^47 unsupported by the fp64 limb schedule");
+            int e = l; while (e < L && (ctx->q[e] >= (1ULL << 36)) == big) e++;
+            MacArgs a{rot, pt, out, K, R, Ncols, L, accumulate, r0, l, e - l, 0, 0};
+            // largest exact run: terms are < 2^48 (two per MAC in the big acc01), partial sums must stay < 2^53
+            double maxterm = big ? 2.0 * 16777216.0 * 16777216.0 : (double)ctx->q[l] * 4096.0;
+            for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
+            int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm);
+            f = (f / MAC_KC) * MAC_KC; if (f < MAC_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
+            a.flush = f;
+            SFG_TRY(big ? launch_mac_rt<true>(ctx, a, rt) : launch_mac_rt<false>(ctx, a, rt));
+            l = e;
+        }
+    }
+    return 0;
+}
+
+extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt, uint64_t *out, int K, int R, int Ncols, int L, int accumulate) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    PhaseTimer t(ctx, "mac");
+    int rc = launch_mac(ctx, (const u64 *)rot, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate);
+    t.stop(1);
+    return rc;
+}

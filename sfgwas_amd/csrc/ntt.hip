@@ -1,0 +1,249 @@
+// ntt.hip — negacyclic NTT / inverse NTT over one modulus row of N = 16384 words (lattigo ring.NTT /
+// ring.InvNTT restated; they sit behind EncodeNTT at matmult.go:723 and behind every rotation,
+// crypto/basics.go:201-224).
+//
+// One 512-thread workgroup transforms one row.  A row index j = a*512 + b*16 + c (a,b < 32, c < 16):
+//   phase A: stages with t >= 512  act on `a`  -> thread (b,c) keeps the 32 values of its column in VGPRs
+//   phase B: stages t = 256..16    act on `b`  -> thread (a,c)
+//   phase C: stages t = 8..1       act on `c`  -> thread (a,b), two groups of 16 values
+// The three phases exchange through one 132 KiB LDS image; HBM sees exactly one coalesced read and one
+// coalesced write of the row.  Arithmetic: exact integers in fp64, lazy (values stay in (-2^51, 2^51)),
+// one canonical reduction at the end — the canonical output is representation-independent, so it is
+// bit-identical to lattigo's Montgomery-form butterflies.
+#include "common.hpp"
+#include "kernels.hpp"
+
+constexpr int LDS_ROW = 528;                 // 512 + 16 doubles: keeps (a, a+1) rows 32 banks apart
+constexpr int LDS_DOUBLES = 32 * LDS_ROW;    // 135,168 B
+
+template <int LEN, int H, class TW>
+__device__ __forceinline__ void ct_stage(double (&v)[LEN], double q, TW tw) {
+#pragma unroll
+    for (int g = 0; g < LEN / (2 * H); g++) {
+        double2 w = tw(g);
+#pragma unroll
+        for (int x = 0; x < H; x++) {
+            const int i0 = g * 2 * H + x, i1 = i0 + H;
+            double r = mulmod_lazy(v[i1], w.x, w.y, q);
+            double U = v[i0];
+            v[i0] = U + r; v[i1] = U - r;
+        }
+    }
+}
+template <int LEN, int H, class TW>
+__device__ __forceinline__ void gs_stage(double (&v)[LEN], double q, TW tw) {
+#pragma unroll
+    for (int g = 0; g < LEN / (2 * H); g++) {
+        double2 w = tw(g);
+#pragma unroll
+        for (int x = 0; x < H; x++) {
+            const int i0 = g * 2 * H + x, i1 = i0 + H;
+            double U = v[i0], V = v[i1];
+            v[i0] = U + V;
+            v[i1] = mulmod_lazy(U - V, w.x, w.y, q);
+        }
+    }
+}
+
+// IN_MODE 0: rows of canonical u64; 1: half-coefficient int64 input of a real-slot plaintext
+// (pc[0..N/2): p_c, with p_{N/2} = 0 and p_{N-c} = -p_c, see encode.hip), rows = [plain][L]
+template <int IN_MODE>
+__global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, ModPattern pat, const double2 *tw_all, const ModConst *modc) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, tid = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const int m = pat.m[row % pat.period];
+    const double2 *tw = tw_all + (size_t)m * N;
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    double v[32];
+    // ---- phase A load: j = a*512 + tid
+    if (IN_MODE == 0) {
+        const u64 *in = (const u64 *)in_ + row * N;
+#pragma unroll
+        for (int a = 0; a < 32; a++) v[a] = u64_to_f64(in[a * 512 + tid]);
+    } else {
+        const long long *pc = (const long long *)in_ + (row / pat.period) * (size_t)(N / 2);
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = (double)pc[a * 512 + tid];
+#pragma unroll
+        for (int a = 16; a < 32; a++) {                 // j = N/2 + x, x = (a-16)*512 + tid: p_j = -p_{N/2 - x}, p_{N/2} = 0
+            int x = (a - 16) * 512 + tid;
+            v[a] = x == 0 ? 0.0 : -(double)pc[N / 2 - x];
+        }
+    }
+    ct_stage<32, 16>(v, q, [&](int g) { return tw[1 + g]; });
+    ct_stage<32, 8>(v, q, [&](int g) { return tw[2 + g]; });
+    ct_stage<32, 4>(v, q, [&](int g) { return tw[4 + g]; });
+    ct_stage<32, 2>(v, q, [&](int g) { return tw[8 + g]; });
+    ct_stage<32, 1>(v, q, [&](int g) { return tw[16 + g]; });
+#pragma unroll
+    for (int a = 0; a < 32; a++) lds[a * LDS_ROW + tid] = v[a];
+    __syncthreads();
+    // ---- phase B: thread (a, c), local b
+    {
+        const int a = tid >> 4, c = tid & 15;
+#pragma unroll
+        for (int b = 0; b < 32; b++) v[b] = lds[a * LDS_ROW + b * 16 + c];
+        ct_stage<32, 16>(v, q, [&](int g) { return tw[32 + a + g]; });
+        ct_stage<32, 8>(v, q, [&](int g) { return tw[64 + a * 2 + g]; });
+        ct_stage<32, 4>(v, q, [&](int g) { return tw[128 + a * 4 + g]; });
+        ct_stage<32, 2>(v, q, [&](int g) { return tw[256 + a * 8 + g]; });
+        ct_stage<32, 1>(v, q, [&](int g) { return tw[512 + a * 16 + g]; });
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 32; b++) lds[a * LDS_ROW + c * 33 + b] = v[b];
+    }
+    __syncthreads();
+    // ---- phase C: two (a, b) groups per thread, local c
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = tid + 512 * h, a = p >> 5, b = p & 31;
+        double w[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) w[c] = lds[a * LDS_ROW + c * 33 + b];
+        const int ab = a * 32 + b;
+        ct_stage<16, 8>(w, q, [&](int g) { return tw[1024 + ab + g]; });
+        ct_stage<16, 4>(w, q, [&](int g) { return tw[2048 + ab * 2 + g]; });
+        ct_stage<16, 2>(w, q, [&](int g) { return tw[4096 + ab * 4 + g]; });
+        ct_stage<16, 1>(w, q, [&](int g) { return tw[8192 + ab * 8 + g]; });
+#pragma unroll
+        for (int c = 0; c < 16; c++) v[h * 16 + c] = w[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = tid + 512 * h, a = p >> 5, b = p & 31;
+#pragma unroll
+        for (int c = 0; c < 16; c++) lds[a * LDS_ROW + c * 33 + b] = v[h * 16 + c];
+    }
+    __syncthreads();
+    u64 *out = out_ + row * N;
+    {
+        const int b = tid >> 4, c = tid & 15;
+#pragma unroll
+        for (int a = 0; a < 32; a++) out[a * 512 + tid] = f64_to_u64(canon(lds[a * LDS_ROW + c * 33 + b], q, qinv));
+    }
+}
+
+__global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModPattern pat, const double2 *tw_all, const ModConst *modc) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, tid = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const int m = pat.m[row % pat.period];
+    const double2 *tw = tw_all + (size_t)m * N;
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const u64 *in = in_ + row * N;
+    double v[32];
+    {   // coalesced load into the (a, c*33 + b) image
+        const int b = tid >> 4, c = tid & 15;
+#pragma unroll
+        for (int a = 0; a < 32; a++) lds[a * LDS_ROW + c * 33 + b] = u64_to_f64(in[a * 512 + tid]);
+    }
+    __syncthreads();
+    // ---- phase C': stages t = 1,2,4,8 on c
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = tid + 512 * h, a = p >> 5, b = p & 31;
+        double w[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) w[c] = lds[a * LDS_ROW + c * 33 + b];
+        const int ab = a * 32 + b;
+        gs_stage<16, 1>(w, q, [&](int g) { return tw[8192 + ab * 8 + g]; });
+        gs_stage<16, 2>(w, q, [&](int g) { return tw[4096 + ab * 4 + g]; });
+        gs_stage<16, 4>(w, q, [&](int g) { return tw[2048 + ab * 2 + g]; });
+        gs_stage<16, 8>(w, q, [&](int g) { return tw[1024 + ab + g]; });
+#pragma unroll
+        for (int c = 0; c < 16; c++) v[h * 16 + c] = pred(w[c], q, qinv);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = tid + 512 * h, a = p >> 5, b = p & 31;
+#pragma unroll
+        for (int c = 0; c < 16; c++) lds[a * LDS_ROW + c * 33 + b] = v[h * 16 + c];
+    }
+    __syncthreads();
+    // ---- phase B': stages t = 16..256 on b
+    {
+        const int a = tid >> 4, c = tid & 15;
+#pragma unroll
+        for (int b = 0; b < 32; b++) v[b] = lds[a * LDS_ROW + c * 33 + b];
+        gs_stage<32, 1>(v, q, [&](int g) { return tw[512 + a * 16 + g]; });
+        gs_stage<32, 2>(v, q, [&](int g) { return tw[256 + a * 8 + g]; });
+        gs_stage<32, 4>(v, q, [&](int g) { return tw[128 + a * 4 + g]; });
+        gs_stage<32, 8>(v, q, [&](int g) { return tw[64 + a * 2 + g]; });
+        gs_stage<32, 16>(v, q, [&](int g) { return tw[32 + a + g]; });
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 32; b++) lds[a * LDS_ROW + b * 16 + c] = pred(v[b], q, qinv);
+    }
+    __syncthreads();
+    // ---- phase A': stages t = 512..8192 on a
+#pragma unroll
+    for (int a = 0; a < 32; a++) v[a] = lds[a * LDS_ROW + tid];
+    gs_stage<32, 1>(v, q, [&](int g) { return tw[16 + g]; });
+    gs_stage<32, 2>(v, q, [&](int g) { return tw[8 + g]; });
+    gs_stage<32, 4>(v, q, [&](int g) { return tw[4 + g]; });
+    gs_stage<32, 8>(v, q, [&](int g) { return tw[2 + g]; });
+    gs_stage<32, 16>(v, q, [&](int g) { return tw[1 + g]; });
+    const double ninv = modc[m].ninv, ninv_q = modc[m].ninv_q;
+    u64 *out = out_ + row * N;
+#pragma unroll
+    for (int a = 0; a < 32; a++) {
+        double x = mulmod_lazy(pred(v[a], q, qinv), ninv, ninv_q, q);
+        out[a * 512 + tid] = f64_to_u64(canon(x, q, qinv));
+    }
+}
+
+static int set_lds_attr_once() {
+    static bool done = false;
+    if (done) return 0;
+    hipError_t e = hipFuncSetAttribute((const void *)k_ntt_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
+    done = (e == hipSuccess);
+    return e == hipSuccess ? 0 : 1;
+}
+
+int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) {
+    if (!nrows) return 0;
+    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
+    hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, ctx->tw_fwd, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain, int L) {
+    if (!nplain) return 0;
+    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
+    ModPattern pat; pat.period = L; for (int l = 0; l < L; l++) pat.m[l] = (int8_t)l;
+    hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, ctx->tw_fwd, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) {
+    if (!nrows) return 0;
+    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
+    hipLaunchKernelGGL(k_ntt_inv, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, in, out, pat, ctx->tw_inv, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+static int pattern_from_host(sfg_ctx *ctx, const int *mod_idx, int nrows, ModPattern &pat) {
+    for (int period = 1; period <= 32 && period <= nrows; period++) {
+        bool ok = true;
+        for (int r = 0; r < nrows && ok; r++) ok = mod_idx[r] == mod_idx[r % period];
+        if (ok) { pat.period = period; for (int i = 0; i < period; i++) { if (mod_idx[i] < 0 || mod_idx[i] >= ctx->nmod) SFG_FAIL(ctx, "modulus index out of range"); pat.m[i] = (int8_t)mod_idx[i]; } return 0; }
+    }
+    SFG_FAIL(ctx, "mod_idx must be periodic with period <= 32");
+}
+
+extern "C" int sfg_ntt_rows(sfg_ctx *ctx, uint64_t *rows, int nrows, const int *mod_idx) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    ModPattern pat; SFG_TRY(pattern_from_host(ctx, mod_idx, nrows, pat));
+    return launch_ntt_fwd(ctx, (const u64 *)rows, (u64 *)rows, nrows, pat);
+}
+extern "C" int sfg_intt_rows(sfg_ctx *ctx, uint64_t *rows, int nrows, const int *mod_idx) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    ModPattern pat; SFG_TRY(pattern_from_host(ctx, mod_idx, nrows, pat));
+    return launch_ntt_inv(ctx, (const u64 *)rows, (u64 *)rows, nrows, pat);
+}

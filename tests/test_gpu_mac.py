@@ -1,0 +1,79 @@
+"""GPU parity of the lazy MAC (sfg_mac_dev) against the reference's own arithmetic path restated in the
+oracle: MForm(pt) -> MulCoeffsAndAdd128 -> ReduceAndAddUint128 -> eval.Reduce (matmult.go:247-440). Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+L_ = ol.lib
+
+
+@pytest.fixture(scope="module")
+def env():
+    from sfgwas_amd import capi
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    yield ctx
+    ctx.close()
+
+
+def reference_mac(rot, pt, moduli, out_init=None):
+    K, R, L, N = rot.shape
+    Ncols = pt.shape[1]
+    out = np.zeros((Ncols, R, L, N), dtype=np.uint64)
+    ptm = pt.copy()
+    for l in range(L):
+        for k in range(K):
+            for n in range(Ncols):
+                L_().orc_mform_vec(ol.p64(ptm[k, n, l]), N, moduli[l])          # ToMontgomeryForm, :401-409
+    for n in range(Ncols):
+        for r in range(R):
+            for l in range(L):
+                acc = np.zeros((N, 2), dtype=np.uint64)
+                for k in range(K):
+                    L_().orc_mul_coeffs_and_add128(ol.p64(rot[k, r, l]), ol.p64(ptm[k, n, l]), ol.p64(acc), N)
+                o = np.zeros(N, dtype=np.uint64)
+                L_().orc_reduce_and_add_uint128(ol.p64(acc), ol.p64(o), L_().orc_mred_params(moduli[l]), moduli[l], N)
+                L_().orc_canonical_reduce(ol.p64(o), N, moduli[l])
+                if out_init is not None:
+                    o = (o + out_init[n, r, l]) % np.uint64(moduli[l])
+                out[n, r, l] = o
+    return out
+
+
+def rand_rows(rnd, shape_prefix, L, moduli, N):
+    a = np.zeros(tuple(shape_prefix) + (L, N), dtype=np.uint64)
+    for l in range(L):
+        a[..., l, :] = rnd.integers(0, moduli[l], tuple(shape_prefix) + (N,), dtype=np.uint64)
+    return a
+
+
+@pytest.mark.parametrize("K,R,Ncols,L", [(20, 6, 5, 5), (9, 30, 33, 5), (3, 32, 2, 2), (1, 1, 1, 1), (91, 4, 3, 6)])
+def test_mac_random_bit_exact(env, K, R, Ncols, L):
+    ctx = env
+    rnd = np.random.default_rng(K * 1000 + R)
+    N = ctx.N
+    rot = rand_rows(rnd, (K, R), L, ol.Q_PN14, N)
+    pt = rand_rows(rnd, (K, Ncols), L, ol.Q_PN14, N)
+    got = ctx.mac(rot, pt, L)
+    want = reference_mac(rot, pt, ol.Q_PN14)
+    assert np.array_equal(got, want)
+
+
+def test_mac_worst_case_magnitudes_and_accumulate(env):
+    """all operands q-1 over K=150 terms exercises the exact-run bound and the periodic fold; accumulate adds onto out."""
+    ctx = env
+    K, R, Ncols, L, N = 150, 3, 2, 5, ctx.N
+    rot = np.zeros((K, R, L, N), dtype=np.uint64)
+    pt = np.zeros((K, Ncols, L, N), dtype=np.uint64)
+    for l in range(L):
+        rot[:, :, l, :] = ol.Q_PN14[l] - 1
+        pt[:, :, l, :] = ol.Q_PN14[l] - 1
+    rnd = np.random.default_rng(3)
+    init = rand_rows(rnd, (Ncols, R), L, ol.Q_PN14, N)
+    got = ctx.mac(rot, pt, L, out_init=init)
+    for l in range(L):
+        q = ol.Q_PN14[l]
+        val = (K * (q - 1) * (q - 1)) % q
+        want = (init[:, :, l, :].astype(object) + val) % q
+        assert np.array_equal(got[:, :, l, :].astype(object), want)
