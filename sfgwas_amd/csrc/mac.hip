@@ -21,10 +21,13 @@
 
 constexpr int MAC_CL = 16;        // coefficients per workgroup (lanes 0..15 of each 16-lane group)
 constexpr int MAC_CG = 4;         // column groups per wave
-constexpr int MAC_WAVES = 8;
-constexpr int MAC_COLS = MAC_CG * MAC_WAVES;   // 32 output columns per workgroup
-constexpr int MAC_KC = 8;         // k-steps staged per LDS chunk
-constexpr int MAC_RMAX = 30;      // rows per pass (2 * kp, kp = 15: pca.go:87)
+constexpr int MAC_CT = 3;         // columns per thread
+constexpr int MAC_RGRP = 4;       // row groups (waves that share columns but own different rows)
+constexpr int MAC_WC = 2;         // column waves
+constexpr int MAC_THREADS = 64 * MAC_RGRP * MAC_WC;           // 512 threads = 8 waves = 2 per SIMD (256 VGPRs each)
+constexpr int MAC_COLS = MAC_CG * MAC_CT * MAC_WC;            // 24 output columns per workgroup
+constexpr int MAC_KC = 4;         // k-steps staged per LDS chunk
+constexpr int MAC_RMAX = 32;      // rows per pass (2 * kp = 30 for kp = 15, pca.go:87); 8 per thread
 
 struct MacArgs {
     const u64 *rot; const u64 *pt; u64 *out;
@@ -35,12 +38,18 @@ struct MacArgs {
     int ntile;
 };
 
-template <bool BIG, int RT>
-__global__ void __launch_bounds__(512, 2) k_mac(MacArgs a, const ModConst *modc) {
+// RH = rows per thread (a quarter of the rows of a pass); thread tile = RH rows x 3 columns.
+// LDS image of one chunk: [kk][c][row] with the 2*RH rows of a coefficient contiguous, so a thread pulls its
+// rows with ds_read_b128 (two rows per read; 16 distinct 16-byte words per wave-read at a stride of 2*RH*8 B,
+// which spreads over all 64 banks) and every value read feeds 2 columns x 3..4 FMAs.
+template <bool BIG, int RH>
+__global__ void __launch_bounds__(MAC_THREADS, 2) k_mac(MacArgs a, const ModConst *modc) {
     constexpr int RW = BIG ? 2 : 1;                    // doubles per staged rot word
-    __shared__ double lds[2][MAC_KC][RT][MAC_CL * RW];
+    constexpr int RT = MAC_RGRP * RH;                  // rows per pass
+    constexpr int RP = (RT * RW + 1) & ~1;             // row-vector length in doubles, padded to 16 B
+    __shared__ __attribute__((aligned(16))) double lds[2][MAC_KC][MAC_CL][RP];
     const int N = SFG_N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cc = lane & 15, cg = lane >> 4;
+    const int cc = lane & 15, cg = lane >> 4, rh = wave % MAC_RGRP, wc = wave / MAC_RGRP;
     // XCD-aware decode: the `ntile` column tiles that share one (c-block, modulus) slab of `rot` get consecutive
     // slots on the same XCD (blocks b and b+8 share an XCD), so the slab is served from that XCD's L2.
     const int b = blockIdx.x, grp = b / (8 * a.ntile), rem = b % (8 * a.ntile);
@@ -49,104 +58,123 @@ __global__ void __launch_bounds__(512, 2) k_mac(MacArgs a, const ModConst *modc)
     if (slab >= nslab) return;
     const int l = a.l0 + slab / (N / MAC_CL), c0 = (slab % (N / MAC_CL)) * MAC_CL;
     const double q = modc[l].q, qinv = modc[l].qinv;
-    const int n = tile * MAC_COLS + wave * MAC_CG + cg;          // this thread's output column
-    const bool active = n < a.Ncols;
-    const int nn = active ? n : a.Ncols - 1;                       // clamp loads of idle threads
+    const int n0 = tile * MAC_COLS + (wc * MAC_CG + cg) * MAC_CT;     // this thread's first output column
 
     const size_t rot_k_stride = (size_t)a.R * a.L * N, pt_k_stride = (size_t)a.Ncols * a.L * N;
     const u64 *rot_base = a.rot + ((size_t)a.r0 * a.L + l) * N + c0;
-    const u64 *pt_ptr = a.pt + ((size_t)nn * a.L + l) * N + c0 + cc;
-
-    double acc[RT][3];
+    const u64 *pt_ptr[MAC_CT];          // walks k: advanced by pt_k_stride after every load
 #pragma unroll
-    for (int r = 0; r < RT; r++) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
+    for (int t = 0; t < MAC_CT; t++) { int nn = n0 + t < a.Ncols ? n0 + t : a.Ncols - 1; pt_ptr[t] = a.pt + ((size_t)nn * a.L + l) * N + c0 + cc; }
+    int k_loaded = 0;                    // next k to fetch
+
+    double acc[RH][MAC_CT][3];
+#pragma unroll
+    for (int r = 0; r < RH; r++)
+#pragma unroll
+        for (int t = 0; t < MAC_CT; t++) acc[r][t][0] = acc[r][t][1] = acc[r][t][2] = 0.0;
 
     const int nchunk = (a.K + MAC_KC - 1) / MAC_KC;
-    // stage chunk ch into buffer bufi: word e -> (kk, r, c)
+    // stage chunk ch into buffer bufi: word e -> (kk, r, c); global reads are 128-B segments (16 c of one row)
     auto stage = [&](int ch, int bufi) {
-        for (int e = tid; e < MAC_KC * RT * MAC_CL; e += 512) {
+        for (int e = tid; e < MAC_KC * RT * MAC_CL; e += MAC_THREADS) {
             int kk = e / (RT * MAC_CL), rm = e % (RT * MAC_CL), r = rm / MAC_CL, c = rm % MAC_CL;
             int k = ch * MAC_KC + kk;
             u64 w = 0;
             if (k < a.K && a.r0 + r < a.R) w = rot_base[(size_t)k * rot_k_stride + (size_t)r * a.L * N + c];
             if (BIG) {
-                lds[bufi][kk][r][c * 2 + 0] = (double)(unsigned)(w & 0x7FFFFFu);
-                lds[bufi][kk][r][c * 2 + 1] = u64_to_f64(w >> 23);
+                lds[bufi][kk][c][r * 2 + 0] = (double)(unsigned)(w & 0x7FFFFFu);
+                lds[bufi][kk][c][r * 2 + 1] = u64_to_f64(w >> 23);
             } else {
-                lds[bufi][kk][r][c] = u64_to_f64(w);
+                lds[bufi][kk][c][r] = u64_to_f64(w);
             }
         }
     };
-    u64 pw[MAC_KC];
-    auto load_pt = [&](int ch) {
+    // plaintext words: two-deep register ring, refilled two k-steps ahead.  The k loop is deliberately NOT
+    // unrolled beyond that ring: a fully unrolled chunk lets the scheduler hoist every LDS read of the chunk and
+    // spill the accumulators.
+    u64 pa[MAC_CT], pb[MAC_CT];
+    auto load_p = [&](u64 (&p)[MAC_CT]) {
+        const bool ok = k_loaded < a.K;
 #pragma unroll
-        for (int kk = 0; kk < MAC_KC; kk++) {
-            int k = ch * MAC_KC + kk;
-            pw[kk] = k < a.K ? pt_ptr[(size_t)k * pt_k_stride] : 0ULL;
+        for (int t = 0; t < MAC_CT; t++) { p[t] = ok ? *pt_ptr[t] : 0ULL; pt_ptr[t] += ok ? pt_k_stride : 0; }
+        k_loaded++;
+    };
+    auto kstep = [&](int k, u64 (&p)[MAC_CT]) {
+        const double *rv = &lds[(k / MAC_KC) & 1][k % MAC_KC][cc][rh * RH * RW];
+        double p0[MAC_CT], p1[MAC_CT], p2[MAC_CT];
+#pragma unroll
+        for (int t = 0; t < MAC_CT; t++) {
+            if (BIG) { p0[t] = (double)(unsigned)(p[t] & 0x7FFFFFu); p1[t] = u64_to_f64(p[t] >> 23); p2[t] = 0.0; }
+            else {
+                const unsigned plo = (unsigned)p[t], phi = (unsigned)(p[t] >> 32);
+                p0[t] = (double)(plo & 0xFFFu); p1[t] = (double)((plo >> 12) & 0xFFFu); p2[t] = (double)((plo >> 24) | (phi << 8));
+            }
         }
+        load_p(p);
+#pragma unroll
+        for (int r = 0; r < RH; r++) {
+#pragma unroll
+            for (int t = 0; t < MAC_CT; t++) {
+                if (BIG) {
+                    const double r0 = rv[2 * r], r1 = rv[2 * r + 1];
+                    acc[r][t][0] = __builtin_fma(r0, p0[t], acc[r][t][0]);
+                    acc[r][t][1] = __builtin_fma(r0, p1[t], acc[r][t][1]);
+                    acc[r][t][1] = __builtin_fma(r1, p0[t], acc[r][t][1]);
+                    acc[r][t][2] = __builtin_fma(r1, p1[t], acc[r][t][2]);
+                } else {
+                    const double x = rv[r];
+                    acc[r][t][0] = __builtin_fma(x, p0[t], acc[r][t][0]);
+                    acc[r][t][1] = __builtin_fma(x, p1[t], acc[r][t][1]);
+                    acc[r][t][2] = __builtin_fma(x, p2[t], acc[r][t][2]);
+                }
+            }
+        }
+    };
+    auto flush_all = [&]() {
+#pragma unroll
+        for (int r = 0; r < RH; r++)
+#pragma unroll
+            for (int t = 0; t < MAC_CT; t++) {
+                acc[r][t][0] = pred(acc[r][t][0], q, qinv); acc[r][t][1] = pred(acc[r][t][1], q, qinv); acc[r][t][2] = pred(acc[r][t][2], q, qinv);
+            }
     };
     stage(0, 0);
-    load_pt(0);
+    load_p(pa);
+    load_p(pb);
     __syncthreads();
     int since_flush = 0;
+#pragma unroll 1
     for (int ch = 0; ch < nchunk; ch++) {
-        const int bufi = ch & 1;
-        u64 pcur[MAC_KC];
-#pragma unroll
-        for (int kk = 0; kk < MAC_KC; kk++) pcur[kk] = pw[kk];
-        if (ch + 1 < nchunk) { stage(ch + 1, bufi ^ 1); load_pt(ch + 1); }
-#pragma unroll
-        for (int kk = 0; kk < MAC_KC; kk++) {
-            const u64 p = pcur[kk];
-            if (BIG) {
-                const double p0 = (double)(unsigned)(p & 0x7FFFFFu), p1 = u64_to_f64(p >> 23);
-#pragma unroll
-                for (int r = 0; r < RT; r++) {
-                    const double2 rv = *reinterpret_cast<const double2 *>(&lds[bufi][kk][r][cc * 2]);
-                    acc[r][0] = __builtin_fma(rv.x, p0, acc[r][0]);
-                    acc[r][1] = __builtin_fma(rv.x, p1, acc[r][1]);
-                    acc[r][1] = __builtin_fma(rv.y, p0, acc[r][1]);
-                    acc[r][2] = __builtin_fma(rv.y, p1, acc[r][2]);
-                }
-            } else {
-                const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
-                const double p0 = (double)(plo & 0xFFFu), p1 = (double)((plo >> 12) & 0xFFFu);
-                const double p2 = (double)((plo >> 24) | (phi << 8));
-#pragma unroll
-                for (int r = 0; r < RT; r++) {
-                    const double rv = lds[bufi][kk][r][cc];
-                    acc[r][0] = __builtin_fma(rv, p0, acc[r][0]);
-                    acc[r][1] = __builtin_fma(rv, p1, acc[r][1]);
-                    acc[r][2] = __builtin_fma(rv, p2, acc[r][2]);
-                }
-            }
+        if (ch + 1 < nchunk) stage(ch + 1, (ch + 1) & 1);
+        const int kbase = ch * MAC_KC;
+#pragma unroll 1
+        for (int kk = 0; kk < MAC_KC; kk += 2) {
+            kstep(kbase + kk, pa);
+            kstep(kbase + kk + 1, pb);
         }
         since_flush += MAC_KC;
-        if (since_flush >= a.flush) {
-            since_flush = 0;
-#pragma unroll
-            for (int r = 0; r < RT; r++) {
-                acc[r][0] = pred(acc[r][0], q, qinv); acc[r][1] = pred(acc[r][1], q, qinv); acc[r][2] = pred(acc[r][2], q, qinv);
-            }
-        }
+        if (since_flush >= a.flush) { since_flush = 0; flush_all(); }
         __syncthreads();
     }
-    if (!active) return;
     // recombine limbs: value = acc0 + acc1 * 2^S + acc2 * 2^(2S)  (mod q)
     constexpr double S1 = BIG ? 8388608.0 : 4096.0;
     const double s1 = S1, s1q = S1 / q;
-    const double s2raw = S1 * S1;                 // 2^46 (big) may exceed q: reduce it first
-    const double s2 = canon(s2raw, q, qinv), s2q = s2 / q;
-    u64 *out = a.out + (((size_t)n * a.R + a.r0) * a.L + l) * N + c0 + cc;
+    const double s2 = canon(S1 * S1, q, qinv), s2q = s2 / q;     // 2^46 (big) may exceed q: reduce it first
 #pragma unroll
-    for (int r = 0; r < RT; r++) {
-        if (a.r0 + r < a.R) {
-            double x = pred(acc[r][0], q, qinv);
-            x += mulmod_lazy(pred(acc[r][1], q, qinv), s1, s1q, q);
-            x += mulmod_lazy(pred(acc[r][2], q, qinv), s2, s2q, q);
-            u64 *o = out + (size_t)r * a.L * N;
-            if (a.accumulate) x += u64_to_f64(*o);
-            *o = f64_to_u64(canon(x, q, qinv));
+    for (int t = 0; t < MAC_CT; t++) {
+        const int n = n0 + t;
+        if (n >= a.Ncols) continue;
+#pragma unroll
+        for (int r = 0; r < RH; r++) {
+            const int row = a.r0 + rh * RH + r;
+            if (row < a.R) {
+                double x = pred(acc[r][t][0], q, qinv);
+                x += mulmod_lazy(pred(acc[r][t][1], q, qinv), s1, s1q, q);
+                x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
+                u64 *o = a.out + (((size_t)n * a.R + row) * a.L + l) * N + c0 + cc;
+                if (a.accumulate) x += u64_to_f64(*o);
+                *o = f64_to_u64(canon(x, q, qinv));
+            }
         }
     }
 }
@@ -157,10 +185,9 @@ static int launch_mac_rt(sfg_ctx *ctx, MacArgs a, int rt) {
     a.ntile = (a.Ncols + MAC_COLS - 1) / MAC_COLS;
     const int ngrp = (nslab + 7) / 8;
     dim3 grid((unsigned)(ngrp * 8 * a.ntile));
-    if (rt <= 2) hipLaunchKernelGGL((k_mac<BIG, 2>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
-    else if (rt <= 8) hipLaunchKernelGGL((k_mac<BIG, 8>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
-    else if (rt <= 16) hipLaunchKernelGGL((k_mac<BIG, 16>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
-    else hipLaunchKernelGGL((k_mac<BIG, MAC_RMAX>), grid, dim3(512), 0, ctx->stream, a, ctx->modc);
+    if (rt <= 4) hipLaunchKernelGGL((k_mac<BIG, 1>), grid, dim3(MAC_THREADS), 0, ctx->stream, a, ctx->modc);
+    else if (rt <= 16) hipLaunchKernelGGL((k_mac<BIG, 4>), grid, dim3(MAC_THREADS), 0, ctx->stream, a, ctx->modc);
+    else hipLaunchKernelGGL((k_mac<BIG, MAC_RMAX / MAC_RGRP>), grid, dim3(MAC_THREADS), 0, ctx->stream, a, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
