@@ -185,3 +185,21 @@ def _ctx_mac(self, rot, pt, L, out_init=None):
 
 
 Context.mac = _ctx_mac
+
+
+def _ctx_encode_diags(self, block, shift0, nshift, L, transposed=False):
+    """block: [r][c] int8 host array (<= slots x slots) -> pt [nshift][L][N] uint64."""
+    block = np.ascontiguousarray(block, dtype=np.int8)
+    r, c = block.shape
+    if transposed:
+        r, c = c, r
+    d_blk = self.to_device(block)
+    d_pt = self.malloc(nshift * L * self.N * 8)
+    self.check(lib().sfg_encode_diags_dev(self.h, d_blk, block.shape[1], r, c, int(transposed), shift0, nshift, L, d_pt), "sfg_encode_diags_dev")
+    out = self.to_host(d_pt, (nshift, L, self.N), np.uint64)
+    self.free(d_blk)
+    self.free(d_pt)
+    return out
+
+
+Context.encode_diags = _ctx_encode_diags

@@ -1,4 +1,314 @@
-// encode.hip — placeholder until the encoder lands (defined so the context builds)
+// encode.hip — generalized-diagonal extraction and CKKS encoding of int8 genotype blocks
+// (GetDiag / convertToComplex128WithRot / EncodeDiagWithEncoder -> lattigo EncoderBig.EncodeNTT,
+//  gwas/matmult.go:636-731; called per diagonal at :1024 and :1426).
+//
+// The reference encodes with 256-bit big floats, i.e. it produces the exactly rounded integers
+//     p_c = round(Delta * Re w_c),  p_{c+n} = round(Delta * Im w_c),   w_c = (1/n) sum_t v_t zeta^(-5^t c)
+// (n = N/2 slots, zeta = exp(2 pi i / 2N)).  Here the same real numbers are computed in double-double
+// arithmetic (~2^-104 relative) and rounded half away from zero, which gives the same integers.
+//   * u[(5^t - 1)/4 mod n] = v_t turns the sum into an ordinary length-n DFT times zeta^(-c);
+//   * v is real, so the DFT is done as a length-n/2 complex FFT of z_m = u_2m + i u_2m+1 plus one
+//     recombination pass, and only p_0..p_{n-1} are produced: p_n = 0 and p_{N-c} = -p_c follow from
+//     invariance under X -> X^-1 (the NTT kernel expands them, ntt.hip IN_MODE 1).
+// One 512-thread workgroup encodes one diagonal; the 4096-point FFT lives in a 144 KiB structure-of-arrays
+// LDS image (re.hi, re.lo, im.hi, im.lo) and runs as 4 register passes of 3 radix-2 DIF stages.
 #include "common.hpp"
-int sfg_encoder_init(sfg_ctx *ctx) { return 0; }
-void sfg_encoder_destroy(sfg_ctx *ctx) {}
+#include "kernels.hpp"
+#include <cmath>
+
+// ---------------------------------------------------------------- double-double (host + device)
+struct dd { double hi, lo; };
+__host__ __device__ static inline dd dd_make(double h, double l) { dd r; r.hi = h; r.lo = l; return r; }
+__host__ __device__ static inline dd dd_quick(double a, double b) { double s = a + b; return dd_make(s, b - (s - a)); }
+__host__ __device__ static inline dd dd_two_sum(double a, double b) { double s = a + b, bb = s - a; return dd_make(s, (a - (s - bb)) + (b - bb)); }
+__host__ __device__ static inline dd dd_add(dd a, dd b) { dd s = dd_two_sum(a.hi, b.hi); s.lo += a.lo + b.lo; return dd_quick(s.hi, s.lo); }
+__host__ __device__ static inline dd dd_neg(dd a) { return dd_make(-a.hi, -a.lo); }
+__host__ __device__ static inline dd dd_sub(dd a, dd b) { return dd_add(a, dd_neg(b)); }
+__host__ __device__ static inline dd dd_mul(dd a, dd b) {
+    double p = a.hi * b.hi, e = fma(a.hi, b.hi, -p);
+    e = fma(a.hi, b.lo, e); e = fma(a.lo, b.hi, e);
+    return dd_quick(p, e);
+}
+__host__ __device__ static inline dd dd_mul_d(dd a, double b) {
+    double p = a.hi * b, e = fma(a.hi, b, -p);
+    e = fma(a.lo, b, e);
+    return dd_quick(p, e);
+}
+// accurate host-only add (table construction)
+static inline dd dd_add_acc(dd a, dd b) {
+    dd s = dd_two_sum(a.hi, b.hi), t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi; s = dd_quick(s.hi, s.lo); s.lo += t.lo; return dd_quick(s.hi, s.lo);
+}
+struct cdd { dd re, im; };
+__host__ __device__ static inline cdd cdd_mul(cdd a, cdd b) {
+    cdd r; r.re = dd_sub(dd_mul(a.re, b.re), dd_mul(a.im, b.im)); r.im = dd_add(dd_mul(a.re, b.im), dd_mul(a.im, b.re)); return r;
+}
+
+constexpr int ENC_H = SFG_SLOTS / 2;         // 4096-point complex FFT
+constexpr int ENC_TW = 16384;                // table of zeta^-k, k = 0..16384, zeta = exp(2 pi i / 32768)
+constexpr int ENC_PADN = ENC_H + ENC_H / 8;  // padded index j' = j + (j >> 3)
+
+struct EncTables {
+    double4 *zt = nullptr;        // [ENC_TW + 1] {re.hi, re.lo, im.hi, im.lo} of exp(-2 pi i k / 32768)
+    uint16_t *tinv = nullptr;     // [n] slot index t with (5^t - 1)/4 mod n == m
+    int8_t *skew = nullptr;       // diag-major scratch for one block: [n][n]
+    long long *pc = nullptr;      // half-coefficient scratch [batch][n]
+    size_t pc_cap = 0;
+};
+
+// cos/sin(theta) for small theta by Taylor series in double-double
+static void dd_sincos_small(dd theta, dd &s, dd &c) {
+    dd t2 = dd_mul(theta, theta);
+    dd term = theta; s = theta;
+    for (int k = 1; k < 14; k++) {            // sin: term *= -t2 / ((2k)(2k+1))
+        term = dd_mul(term, t2); term = dd_mul_d(term, -1.0);
+        double den = (double)(2 * k) * (double)(2 * k + 1);
+        // divide by an exactly representable small integer: one Newton-free step via hi/lo correction
+        dd q; q.hi = term.hi / den; double rem = fma(-q.hi, den, term.hi); q.lo = (rem + term.lo) / den; term = dd_quick(q.hi, q.lo);
+        s = dd_add_acc(s, term);
+    }
+    term = dd_make(1.0, 0.0); c = term;
+    for (int k = 1; k < 14; k++) {            // cos: term *= -t2 / ((2k-1)(2k))
+        term = dd_mul(term, t2); term = dd_mul_d(term, -1.0);
+        double den = (double)(2 * k - 1) * (double)(2 * k);
+        dd q; q.hi = term.hi / den; double rem = fma(-q.hi, den, term.hi); q.lo = (rem + term.lo) / den; term = dd_quick(q.hi, q.lo);
+        c = dd_add_acc(c, term);
+    }
+}
+
+int sfg_encoder_init(sfg_ctx *ctx) {
+    EncTables *et = new EncTables();
+    ctx->enc_tables = et;
+    const int n = SFG_SLOTS; const u64 M = 2ULL * SFG_N;
+    // zeta^-1 = exp(-i theta), theta = 2 pi / 32768 = pi * 2^-14 (exact scaling of the dd constant pi)
+    dd pi = dd_make(3.141592653589793116e+00, 1.224646799147353207e-16);
+    dd theta = dd_make(pi.hi / 16384.0, pi.lo / 16384.0);
+    dd s1, c1; dd_sincos_small(theta, s1, c1);
+    std::vector<cdd> z(ENC_TW + 1);
+    z[0].re = dd_make(1, 0); z[0].im = dd_make(0, 0);
+    z[1].re = c1; z[1].im = dd_neg(s1);
+    for (int k = 2; k <= ENC_TW; k++) z[k] = (k & 1) ? cdd_mul(z[k - 1], z[1]) : cdd_mul(z[k / 2], z[k / 2]);
+    // exact values at the octants
+    z[ENC_TW].re = dd_make(-1, 0); z[ENC_TW].im = dd_make(0, 0);                    // k = 16384: exp(-i pi)
+    z[ENC_TW / 2].re = dd_make(0, 0); z[ENC_TW / 2].im = dd_make(-1, 0);            // k = 8192: exp(-i pi/2)
+    std::vector<double4> zt(ENC_TW + 1);
+    for (int k = 0; k <= ENC_TW; k++) zt[k] = make_double4(z[k].re.hi, z[k].re.lo, z[k].im.hi, z[k].im.lo);
+    std::vector<uint16_t> tinv(n);
+    u64 g = 1;
+    for (int t = 0; t < n; t++) { tinv[((g - 1) / 4) % n] = (uint16_t)t; g = (g * 5) % M; }
+    SFG_HIP(ctx, hipMalloc(&et->zt, zt.size() * sizeof(double4)));
+    SFG_HIP(ctx, hipMalloc(&et->tinv, n * sizeof(uint16_t)));
+    SFG_HIP(ctx, hipMemcpy(et->zt, zt.data(), zt.size() * sizeof(double4), hipMemcpyHostToDevice));
+    SFG_HIP(ctx, hipMemcpy(et->tinv, tinv.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return 0;
+}
+void sfg_encoder_destroy(sfg_ctx *ctx) {
+    EncTables *et = (EncTables *)ctx->enc_tables;
+    if (!et) return;
+    (void)hipFree(et->zt); (void)hipFree(et->tinv); (void)hipFree(et->skew); (void)hipFree(et->pc);
+    delete et; ctx->enc_tables = nullptr;
+}
+
+// ---------------------------------------------------------------- diagonal-major copy of one block
+// D[shift][j] = X[(shift + j) mod n][j] inside the r x c block, 0 outside (GetDiag, matmult.go:636-664 with
+// index = -shift).  A diagonal that "does not exist" (GetDiagBool false) is all zero here, which encodes to
+// the zero plaintext — the same contribution as the reference's skipped nil plaintext (matmult.go:392).
+__global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D) {
+    const int n = SFG_SLOTS;
+    const int j = blockIdx.x * 256 + threadIdx.x, shift = blockIdx.y;
+    int i = shift + j; if (i >= n) i -= n;
+    int8_t v = 0;
+    if (i < r && j < c) {
+        v = transposed ? blk[(size_t)j * ld + i] : blk[(size_t)i * ld + j];
+        if (v < 0) v = 0;                    // missing -> 0 (matmult.go:1292-1295)
+        if (square) v = (int8_t)(v * v);     // :1301-1303
+    }
+    D[(size_t)shift * n + j] = v;
+}
+
+// ---------------------------------------------------------------- FFT encode
+__device__ __forceinline__ int padj(int j) { return j + (j >> 3); }
+
+template <int H>   // one radix-2 DIF stage on 8 register-resident points at local distance H (1, 2 or 4)
+__device__ __forceinline__ void dif_stage(dd (&xr)[8], dd (&xi)[8], const double4 *zt, int jbase, int jstride, int half) {
+#pragma unroll
+    for (int g = 0; g < 8 / (2 * H); g++) {
+#pragma unroll
+        for (int x = 0; x < H; x++) {
+            const int i0 = g * 2 * H + x, i1 = i0 + H;
+            const int j = jbase + i0 * jstride;           // global index of the upper element
+            const int k = j & (half - 1);
+            const double4 w = zt[(size_t)k * (ENC_TW / half)];  // exp(-2 pi i k / (2 half)) = zeta^-(k * 16384/half)
+            dd ar = xr[i0], ai = xi[i0], br = xr[i1], bi = xi[i1];
+            xr[i0] = dd_add(ar, br); xi[i0] = dd_add(ai, bi);
+            dd dr = dd_sub(ar, br), di = dd_sub(ai, bi);
+            dd wr = dd_make(w.x, w.y), wi = dd_make(w.z, w.w);
+            xr[i1] = dd_sub(dd_mul(dr, wr), dd_mul(di, wi));
+            xi[i1] = dd_add(dd_mul(dr, wi), dd_mul(di, wr));
+        }
+    }
+}
+
+__device__ __forceinline__ long long dd_round_away(dd x) {
+    double nn = __builtin_rint(x.hi);
+    double diff = (x.hi - nn) + x.lo;
+    if (diff > 0.5 || (diff == 0.5 && nn >= 0)) nn += 1.0;
+    else if (diff < -0.5 || (diff == -0.5 && nn <= 0)) nn -= 1.0;
+    return (long long)nn;
+}
+
+// rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d)
+__global__ void __launch_bounds__(512) k_fft_encode(const int8_t *D, int shift0, const double4 *zt, const uint16_t *tinv,
+                                                   double scale_over_n, long long *pc_out) {
+    extern __shared__ double lds[];
+    double *RH = lds, *RL = lds + ENC_PADN, *IH = lds + 2 * ENC_PADN, *IL = lds + 3 * ENC_PADN;
+    const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
+    const int shift = shift0 + blockIdx.x;
+    const int nrot = SFG_D * (shift / SFG_D);                      // matmult.go:1426: nrot = d * giant
+    const int8_t *row = D + (size_t)shift * n;
+    // stage the 8 KiB row in the (not yet used) tail of LDS
+    int8_t *rowl = reinterpret_cast<int8_t *>(lds + 4 * ENC_PADN);
+    reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
+    __syncthreads();
+    dd xr[8], xi[8];
+    // ---- pass 1: bits a (stages half = 2048, 1024, 512); thread = (b,c,d) = tid, element j = a*512 + tid
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const int m = a * 512 + tid;                               // z_m = u_2m + i u_2m+1, u_mm = v[tinv[mm]] = row[(tinv[mm] - nrot) mod n]
+        int t0 = (int)tinv[2 * m] - nrot, t1 = (int)tinv[2 * m + 1] - nrot;
+        t0 += t0 < 0 ? n : 0; t1 += t1 < 0 ? n : 0;
+        xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0);
+    }
+    dif_stage<4>(xr, xi, zt, tid, 512, 2048);
+    dif_stage<2>(xr, xi, zt, tid, 512, 1024);
+    dif_stage<1>(xr, xi, zt, tid, 512, 512);
+    __syncthreads();                                               // row staging area is dead, image can be written
+#pragma unroll
+    for (int a = 0; a < 8; a++) { const int p = padj(a * 512 + tid); RH[p] = xr[a].hi; RL[p] = xr[a].lo; IH[p] = xi[a].hi; IL[p] = xi[a].lo; }
+    __syncthreads();
+    // ---- pass 2: bits b; thread = (a, c, d): j = a*512 + b*64 + (tid & 63)
+    {
+        const int a = tid >> 6, cd = tid & 63, jb = a * 512 + cd;
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const int p = padj(jb + b * 64); xr[b] = dd_make(RH[p], RL[p]); xi[b] = dd_make(IH[p], IL[p]); }
+        dif_stage<4>(xr, xi, zt, jb, 64, 256);
+        dif_stage<2>(xr, xi, zt, jb, 64, 128);
+        dif_stage<1>(xr, xi, zt, jb, 64, 64);
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const int p = padj(jb + b * 64); RH[p] = xr[b].hi; RL[p] = xr[b].lo; IH[p] = xi[b].hi; IL[p] = xi[b].lo; }
+    }
+    __syncthreads();
+    // ---- pass 3: bits c; thread = (a, b, d): j = ab*64 + c*8 + d
+    {
+        const int ab = tid >> 3, d = tid & 7, jb = ab * 64 + d;
+#pragma unroll
+        for (int c = 0; c < 8; c++) { const int p = padj(jb + c * 8); xr[c] = dd_make(RH[p], RL[p]); xi[c] = dd_make(IH[p], IL[p]); }
+        dif_stage<4>(xr, xi, zt, jb, 8, 32);
+        dif_stage<2>(xr, xi, zt, jb, 8, 16);
+        dif_stage<1>(xr, xi, zt, jb, 8, 8);
+#pragma unroll
+        for (int c = 0; c < 8; c++) { const int p = padj(jb + c * 8); RH[p] = xr[c].hi; RL[p] = xr[c].lo; IH[p] = xi[c].hi; IL[p] = xi[c].lo; }
+    }
+    __syncthreads();
+    // ---- pass 4: bits d; thread = (a, b, c): j = tid*8 + d
+    {
+        const int jb = tid * 8;
+#pragma unroll
+        for (int d = 0; d < 8; d++) { const int p = padj(jb + d); xr[d] = dd_make(RH[p], RL[p]); xi[d] = dd_make(IH[p], IL[p]); }
+        dif_stage<4>(xr, xi, zt, jb, 1, 4);
+        dif_stage<2>(xr, xi, zt, jb, 1, 2);
+        dif_stage<1>(xr, xi, zt, jb, 1, 1);
+#pragma unroll
+        for (int d = 0; d < 8; d++) { const int p = padj(jb + d); RH[p] = xr[d].hi; RL[p] = xr[d].lo; IH[p] = xi[d].hi; IL[p] = xi[d].lo; }
+    }
+    __syncthreads();
+    // ---- recombination: Z_c sits at bit-reversed position.  For c in [0, h/2]:
+    //   A = Z_c, B = conj(Z_{(h-c) mod h});  X = (A+B)/2 (= E_c),  Y = omega^-c * (A-B)/(2i) (= omega^-c O_c)
+    //   W_c = X + Y,  W_{h-c} = conj(X - Y);   w = zeta^-c' W_c' * scale/n;  p_c' = round(Re w), p_{n-c'} = -round(Im w)
+    long long *pc = pc_out + (size_t)blockIdx.x * n;
+    for (int c = tid; c <= h / 2; c += 512) {
+        const int c2 = (h - c) & (h - 1);
+        const int pa = padj((int)(__brev((unsigned)c) >> 20)), pb = padj((int)(__brev((unsigned)c2) >> 20));
+        dd Ar = dd_make(RH[pa], RL[pa]), Ai = dd_make(IH[pa], IL[pa]);
+        dd Br = dd_make(RH[pb], RL[pb]), Bi = dd_neg(dd_make(IH[pb], IL[pb]));
+        dd Xr = dd_mul_d(dd_add(Ar, Br), 0.5), Xi = dd_mul_d(dd_add(Ai, Bi), 0.5);
+        dd Dr = dd_mul_d(dd_sub(Ar, Br), 0.5), Di = dd_mul_d(dd_sub(Ai, Bi), 0.5);
+        dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/(2i) = -i (A-B)/2
+        const double4 wo = zt[4 * c];                               // omega^-c = zeta^-4c
+        dd wor = dd_make(wo.x, wo.y), woi = dd_make(wo.z, wo.w);
+        dd Yr = dd_sub(dd_mul(Or, wor), dd_mul(Oi, woi)), Yi = dd_add(dd_mul(Or, woi), dd_mul(Oi, wor));
+        // W_c
+        {
+            dd Wr = dd_add(Xr, Yr), Wi = dd_add(Xi, Yi);
+            const double4 z = zt[c];
+            dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
+            dd wr = dd_mul_d(dd_sub(dd_mul(Wr, zr), dd_mul(Wi, zi)), scale_over_n);
+            dd wi = dd_mul_d(dd_add(dd_mul(Wr, zi), dd_mul(Wi, zr)), scale_over_n);
+            pc[c] = dd_round_away(wr);
+            if (c > 0) pc[n - c] = -dd_round_away(wi);
+        }
+        // W_{h-c}  (c = 0 gives W_h)
+        if (c < h / 2) {
+            const int cc = h - c;
+            dd Wr = dd_sub(Xr, Yr), Wi = dd_neg(dd_sub(Xi, Yi));
+            const double4 z = zt[cc];
+            dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
+            dd wr = dd_mul_d(dd_sub(dd_mul(Wr, zr), dd_mul(Wi, zi)), scale_over_n);
+            dd wi = dd_mul_d(dd_add(dd_mul(Wr, zi), dd_mul(Wi, zr)), scale_over_n);
+            pc[cc] = dd_round_away(wr);
+            if (cc < h) pc[n - cc] = -dd_round_away(wi);
+        }
+    }
+}
+
+static int enc_scratch(sfg_ctx *ctx, EncTables *et, size_t nplain) {
+    const size_t n = SFG_SLOTS;
+    if (!et->skew) SFG_HIP(ctx, hipMalloc(&et->skew, n * n));
+    if (et->pc_cap < nplain) {
+        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (et->pc) SFG_HIP(ctx, hipFree(et->pc));
+        et->pc = nullptr; et->pc_cap = 0;
+        SFG_HIP(ctx, hipMalloc(&et->pc, nplain * n * sizeof(long long)));
+        et->pc_cap = nplain;
+    }
+    return 0;
+}
+
+int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D) {
+    hipLaunchKernelGGL(k_skew, dim3(SFG_SLOTS / 256, SFG_SLOTS), dim3(256), 0, ctx->stream, blk, ld, r, c, transposed, square, D);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt) {
+    EncTables *et = (EncTables *)ctx->enc_tables;
+    static bool attr = false;
+    const size_t lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
+    if (!attr) { SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr = true; }
+    const int BATCH = 2048;
+    SFG_TRY(enc_scratch(ctx, et, (size_t)(nshift < BATCH ? nshift : BATCH)));
+    for (int s0 = 0; s0 < nshift; s0 += BATCH) {
+        const int nb = nshift - s0 < BATCH ? nshift - s0 : BATCH;
+        {
+            PhaseTimer t(ctx, "encode", false);
+            hipLaunchKernelGGL(k_fft_encode, dim3(nb), dim3(512), lds_bytes, ctx->stream, D, shift0 + s0, et->zt, et->tinv,
+                               ctx->scale / (double)SFG_SLOTS, et->pc);
+            SFG_HIP(ctx, hipGetLastError());
+        }
+        SFG_TRY(launch_ntt_plain(ctx, et->pc, pt + (size_t)s0 * L * SFG_N, nb, L));
+    }
+    return 0;
+}
+
+extern "C" int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block, size_t ld, int r, int c, int transposed,
+                                    int shift0, int nshift, int L, uint64_t *pt) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (r < 1 || c < 1 || r > SFG_SLOTS || c > SFG_SLOTS) SFG_FAIL(ctx, "sfg_encode_diags: block dims out of range");
+    if (shift0 < 0 || nshift < 0 || shift0 + nshift > SFG_SLOTS) SFG_FAIL(ctx, "sfg_encode_diags: shift range out of range");
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_encode_diags: L out of range");
+    EncTables *et = (EncTables *)ctx->enc_tables;
+    SFG_TRY(enc_scratch(ctx, et, 1));
+    SFG_TRY(launch_skew(ctx, block, ld, r, c, transposed, 0, et->skew));
+    return launch_encode_rows(ctx, et->skew, shift0, nshift, L, (u64 *)pt);
+}
