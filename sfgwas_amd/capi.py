@@ -203,3 +203,20 @@ def _ctx_encode_diags(self, block, shift0, nshift, L, transposed=False):
 
 
 Context.encode_diags = _ctx_encode_diags
+
+
+def _ctx_rotate_right(self, cts, level, nrots):
+    """cts: [nct][2][level+1][N] host array; nrots: list of right-rotation amounts."""
+    cts = np.ascontiguousarray(cts, dtype=np.uint64)
+    nct = cts.shape[0]
+    d_in = self.to_device(cts)
+    d_out = self.malloc(cts.nbytes)
+    arr = (C.c_int * nct)(*[int(x) for x in nrots])
+    self.check(lib().sfg_rotate_right_dev(self.h, d_in, d_out, nct, level, arr), "sfg_rotate_right_dev")
+    out = self.to_host(d_out, cts.shape, np.uint64)
+    self.free(d_in)
+    self.free(d_out)
+    return out
+
+
+Context.rotate_right = _ctx_rotate_right

@@ -53,6 +53,7 @@ struct sfg_ctx {
     void *enc_tables = nullptr;
     // rotation keys
     std::map<u64, RotKey> rotkeys;
+    std::map<int, void *> ksw_cache;   // per-level key-switch constants (device), rotate.hip
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
     std::string err;

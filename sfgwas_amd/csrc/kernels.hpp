@@ -3,13 +3,21 @@
 #include "common.hpp"
 
 // row r of a batch uses modulus m[r % period] (ciphertext rows, plaintext rows, key-switch rows are all periodic)
-struct ModPattern { int period; int8_t m[32]; };
+// m < 0 marks a row the kernel must leave untouched
+struct ModPattern { int period; int8_t m[64]; };
+// row r of a launch lives at base + (r / rpg) * gstride + (r % rpg) * N  (strides in words)
+struct RowMap { int rpg; size_t gstride_in, gstride_out; };
 
 // ntt.hip
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain, int L);
+int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
+int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate);
 // encode.hip
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D);
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt);
+// rotate.hip
+int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host);
+int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct, int level);

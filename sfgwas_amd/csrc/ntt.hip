@@ -48,17 +48,19 @@ __device__ __forceinline__ void gs_stage(double (&v)[LEN], double q, TW tw) {
 // IN_MODE 0: rows of canonical u64; 1: half-coefficient int64 input of a real-slot plaintext
 // (pc[0..N/2): p_c, with p_{N/2} = 0 and p_{N-c} = -p_c, see encode.hip), rows = [plain][L]
 template <int IN_MODE>
-__global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, ModPattern pat, const double2 *tw_all, const ModConst *modc) {
+__global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, ModPattern pat, RowMap rm, const double2 *tw_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const int m = pat.m[row % pat.period];
+    if (m < 0) return;                                   // row marked "leave untouched"
+    const size_t grp = row / rm.rpg, gi = row % rm.rpg;
     const double2 *tw = tw_all + (size_t)m * N;
     const double q = modc[m].q, qinv = modc[m].qinv;
     double v[32];
     // ---- phase A load: j = a*512 + tid
     if (IN_MODE == 0) {
-        const u64 *in = (const u64 *)in_ + row * N;
+        const u64 *in = (const u64 *)in_ + grp * rm.gstride_in + gi * N;
 #pragma unroll
         for (int a = 0; a < 32; a++) v[a] = u64_to_f64(in[a * 512 + tid]);
     } else {
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
         for (int c = 0; c < 16; c++) lds[a * LDS_ROW + c * 33 + b] = v[h * 16 + c];
     }
     __syncthreads();
-    u64 *out = out_ + row * N;
+    u64 *out = out_ + grp * rm.gstride_out + gi * N;
     {
         const int b = tid >> 4, c = tid & 15;
 #pragma unroll
@@ -125,14 +127,16 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
     }
 }
 
-__global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModPattern pat, const double2 *tw_all, const ModConst *modc) {
+__global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModPattern pat, RowMap rm, const double2 *tw_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const int m = pat.m[row % pat.period];
+    if (m < 0) return;
+    const size_t grp = row / rm.rpg, gi = row % rm.rpg;
     const double2 *tw = tw_all + (size_t)m * N;
     const double q = modc[m].q, qinv = modc[m].qinv;
-    const u64 *in = in_ + row * N;
+    const u64 *in = in_ + grp * rm.gstride_in + gi * N;
     double v[32];
     {   // coalesced load into the (a, c*33 + b) image
         const int b = tid >> 4, c = tid & 15;
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
     gs_stage<32, 8>(v, q, [&](int g) { return tw[2 + g]; });
     gs_stage<32, 16>(v, q, [&](int g) { return tw[1 + g]; });
     const double ninv = modc[m].ninv, ninv_q = modc[m].ninv_q;
-    u64 *out = out_ + row * N;
+    u64 *out = out_ + grp * rm.gstride_out + gi * N;
 #pragma unroll
     for (int a = 0; a < 32; a++) {
         double x = mulmod_lazy(pred(v[a], q, qinv), ninv, ninv_q, q);
@@ -205,10 +209,13 @@ static int set_lds_attr_once() {
     return e == hipSuccess ? 0 : 1;
 }
 
-int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) {
+static RowMap dense_map() { RowMap rm; rm.rpg = 1; rm.gstride_in = SFG_N; rm.gstride_out = SFG_N; return rm; }
+int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) { return launch_ntt_fwd_map(ctx, in, out, nrows, pat, dense_map()); }
+int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) { return launch_ntt_inv_map(ctx, in, out, nrows, pat, dense_map()); }
+int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, ctx->tw_fwd, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, rm, ctx->tw_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -216,25 +223,25 @@ int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain,
     if (!nplain) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     ModPattern pat; pat.period = L; for (int l = 0; l < L; l++) pat.m[l] = (int8_t)l;
-    hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, ctx->tw_fwd, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, dense_map(), ctx->tw_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
-int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) {
+int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    hipLaunchKernelGGL(k_ntt_inv, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, in, out, pat, ctx->tw_inv, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_inv, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, in, out, pat, rm, ctx->tw_inv, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
 
 static int pattern_from_host(sfg_ctx *ctx, const int *mod_idx, int nrows, ModPattern &pat) {
-    for (int period = 1; period <= 32 && period <= nrows; period++) {
+    for (int period = 1; period <= 64 && period <= nrows; period++) {
         bool ok = true;
         for (int r = 0; r < nrows && ok; r++) ok = mod_idx[r] == mod_idx[r % period];
         if (ok) { pat.period = period; for (int i = 0; i < period; i++) { if (mod_idx[i] < 0 || mod_idx[i] >= ctx->nmod) SFG_FAIL(ctx, "modulus index out of range"); pat.m[i] = (int8_t)mod_idx[i]; } return 0; }
     }
-    SFG_FAIL(ctx, "mod_idx must be periodic with period <= 32");
+    SFG_FAIL(ctx, "mod_idx must be periodic with period <= 64");
 }
 
 extern "C" int sfg_ntt_rows(sfg_ctx *ctx, uint64_t *rows, int nrows, const int *mod_idx) {

@@ -1,0 +1,289 @@
+// rotate.hip — ciphertext slot rotations: crypto.RotateRightWithEvaluator / RotateRight
+// (crypto/basics.go:201-224) -> lattigo ckks.Evaluator.RotateNew = hybrid key switch of c1 with the Galois key,
+// add to c0, NTT-domain automorphism of both polynomials.  Used for the baby-step rotation cache
+// (gwas/matmult.go:1114,1375) and the giant-step alignment (:1207,1476).
+//
+// Batched over ciphertexts (each may use a different key).  Per ciphertext at level l (nl = l+1 moduli,
+// alpha = np special primes per digit, beta = ceil(nl/alpha) digits, nt = nl + np targets):
+//   1. c2 = INTT(c1)                                   nl rows
+//   2. digit i -> exact (float-corrected) basis extension to every target outside the digit     (k_ksw_extend)
+//      (inside the digit the original NTT rows are reused), then NTT of the extended rows         beta*nt rows
+//   3. acc_{0,1}[t] = sum_i ext[i][t] * key[i][{0,1}][t]                                           (k_ksw_inner)
+//   4. ModDown: INTT of the np special-prime rows, basis extension P -> Q, NTT                    (k_moddown_extend)
+//   5. out0 = perm(c0 + (acc0 - ext0) / P), out1 = perm((acc1 - ext1) / P)                        (k_ksw_finish)
+// The float correction v = uint64(sum float64(y_m)/float64(q_m)) is lattigo's (ring.Decomposer /
+// FastBasisExtender); the oracle mirrors it, so results agree bit for bit.
+#include "common.hpp"
+#include "kernels.hpp"
+
+constexpr int KSW_MAXA = 4;       // max primes per digit (= max np)
+constexpr int KSW_MAXDIG = 8;
+
+struct ExtConst {
+    int a;                                        // source moduli in this digit at this level
+    int src[KSW_MAXA];                            // their global modulus indices
+    double qhat_inv[KSW_MAXA], qhat_inv_q[KSW_MAXA];          // (D/q_m)^-1 mod q_m, and that / q_m
+    double qhat_t[SFG_MAXMOD][KSW_MAXA], qhat_t_q[SFG_MAXMOD][KSW_MAXA];   // (D/q_m) mod q_t, / q_t  (t = global modulus index)
+    double D_t[SFG_MAXMOD], D_t_q[SFG_MAXMOD];    // D mod q_t, / q_t
+};
+struct KswConst {
+    int level, nl, np, nt, beta, alpha;
+    int tmod[SFG_MAXMOD];                         // target slot -> global modulus index (Q_0..level then P)
+    int digit_of[SFG_MAXMOD];                     // target slot -> digit that contains it (or -1 for P targets)
+    ExtConst dig[KSW_MAXDIG];
+    ExtConst pq;                                  // special primes -> Q (ModDown)
+    double pinv[SFG_MAXMOD], pinv_q[SFG_MAXMOD];  // P^-1 mod q_t by global modulus index
+};
+
+static void fill_ext(const sfg_ctx *ctx, ExtConst &e, const std::vector<int> &src) {
+    memset(&e, 0, sizeof e);
+    e.a = (int)src.size();
+    for (int m = 0; m < e.a; m++) e.src[m] = src[m];
+    for (int m = 0; m < e.a; m++) {
+        u64 qm = ctx->q[src[m]], h = 1;
+        for (int k = 0; k < e.a; k++) if (k != m) h = h_mulmod(h, ctx->q[src[k]] % qm, qm);
+        u64 hi = h_invmod(h, qm);
+        e.qhat_inv[m] = (double)hi; e.qhat_inv_q[m] = (double)hi / (double)qm;
+    }
+    for (int t = 0; t < ctx->nmod; t++) {
+        u64 qt = ctx->q[t], D = 1 % qt;
+        for (int m = 0; m < e.a; m++) {
+            u64 ht = 1 % qt;
+            for (int k = 0; k < e.a; k++) if (k != m) ht = h_mulmod(ht, ctx->q[src[k]] % qt, qt);
+            e.qhat_t[t][m] = (double)ht; e.qhat_t_q[t][m] = (double)ht / (double)qt;
+            D = h_mulmod(D, ctx->q[src[m]] % qt, qt);
+        }
+        e.D_t[t] = (double)D; e.D_t_q[t] = (double)D / (double)qt;
+    }
+}
+
+
+static int get_ksw(sfg_ctx *ctx, int level, KswConst **dev, KswConst *host) {
+    KswConst kc; memset(&kc, 0, sizeof kc);
+    kc.level = level; kc.nl = level + 1; kc.np = ctx->np; kc.alpha = ctx->np; kc.nt = kc.nl + kc.np;
+    kc.beta = (kc.nl + kc.alpha - 1) / kc.alpha;
+    if (kc.alpha > KSW_MAXA || kc.beta > KSW_MAXDIG) SFG_FAIL(ctx, "key-switch shape unsupported (alpha > 4 or beta > 8)");
+    for (int t = 0; t < kc.nt; t++) { kc.tmod[t] = t < kc.nl ? t : ctx->nq + (t - kc.nl); kc.digit_of[t] = t < kc.nl ? t / kc.alpha : -1; }
+    for (int i = 0; i < kc.beta; i++) {
+        std::vector<int> src;
+        for (int m = i * kc.alpha; m < (i + 1) * kc.alpha && m < kc.nl; m++) src.push_back(m);
+        fill_ext(ctx, kc.dig[i], src);
+    }
+    std::vector<int> ps; for (int p = 0; p < kc.np; p++) ps.push_back(ctx->nq + p);
+    fill_ext(ctx, kc.pq, ps);
+    for (int t = 0; t < kc.nl; t++) {
+        u64 qt = ctx->q[t], P = 1;
+        for (int p = 0; p < kc.np; p++) P = h_mulmod(P, ctx->q[ctx->nq + p] % qt, qt);
+        u64 pi = h_invmod(P, qt);
+        kc.pinv[t] = (double)pi; kc.pinv_q[t] = (double)pi / (double)qt;
+    }
+    *host = kc;
+    auto it = ctx->ksw_cache.find(level);
+    if (it == ctx->ksw_cache.end()) {
+        KswConst *d = nullptr;
+        SFG_HIP(ctx, hipMalloc(&d, sizeof(KswConst)));
+        SFG_HIP(ctx, hipMemcpy(d, &kc, sizeof(KswConst), hipMemcpyHostToDevice));
+        ctx->ksw_cache[level] = d; *dev = d;
+    } else *dev = (KswConst *)it->second;
+    return 0;
+}
+
+// general modular product of two canonical residues held in fp64 (both variable): result in (-q, q)
+__device__ __forceinline__ double mulmod2(double a, double b, double q, double qinv) {
+    double h = a * b;
+    double l = __builtin_fma(a, b, -h);
+    double qh = __builtin_rint(h * qinv);
+    double r = __builtin_fma(-qh, q, h);
+    return r + l;
+}
+
+// y_m, v and the extension to one target modulus (lattigo reconstructRNS + multSum restated)
+__device__ __forceinline__ void ext_prepare(const ExtConst &e, const ModConst *modc, const double (&x)[KSW_MAXA], double (&y)[KSW_MAXA], double &v) {
+    double vf = 0.0;
+#pragma unroll
+    for (int m = 0; m < KSW_MAXA; m++) {
+        if (m < e.a) {
+            const ModConst mc = modc[e.src[m]];
+            y[m] = canon(mulmod_lazy(x[m], e.qhat_inv[m], e.qhat_inv_q[m], mc.q), mc.q, mc.qinv);
+            vf += y[m] / mc.q;                                  // IEEE division, accumulated in modulus order
+        }
+    }
+    v = (double)(u64)vf;
+}
+__device__ __forceinline__ double ext_target(const ExtConst &e, int tg, double qt, double qtinv, const double (&y)[KSW_MAXA], double v) {
+    double acc = -mulmod_lazy(v, e.D_t[tg], e.D_t_q[tg], qt);
+#pragma unroll
+    for (int m = 0; m < KSW_MAXA; m++) if (m < e.a) acc += mulmod_lazy(y[m], e.qhat_t[tg][m], e.qhat_t_q[tg][m], qt);
+    return canon(acc, qt, qtinv);
+}
+
+// grid (N/256, beta, B). c2: [B][nl][N] coefficient-domain c1; cx: original ct (c1 rows at +nl*N); ext: [B][beta][nt][N]
+__global__ void __launch_bounds__(256) k_ksw_extend(const u64 *c2, const u64 *ct_in, u64 *ext, const KswConst *kcp, const ModConst *modc) {
+    const KswConst &kc = *kcp;
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y; const size_t b = blockIdx.z;
+    const ExtConst &e = kc.dig[i];
+    const u64 *c2b = c2 + b * (size_t)kc.nl * N;
+    const u64 *cxb = ct_in + b * (size_t)2 * kc.nl * N + (size_t)kc.nl * N;
+    u64 *eb = ext + (b * kc.beta + i) * (size_t)kc.nt * N;
+    double xs[KSW_MAXA], y[KSW_MAXA], v = 0.0;
+#pragma unroll
+    for (int m = 0; m < KSW_MAXA; m++) xs[m] = m < e.a ? u64_to_f64(c2b[(size_t)e.src[m] * N + x]) : 0.0;
+    if (e.a > 1) ext_prepare(e, modc, xs, y, v);
+    for (int t = 0; t < kc.nt; t++) {
+        const int tg = kc.tmod[t];
+        u64 outv;
+        if (kc.digit_of[t] == i) outv = cxb[(size_t)t * N + x];                       // in-digit: original NTT row
+        else if (e.a == 1) outv = f64_to_u64(canon(xs[0], modc[tg].q, modc[tg].qinv)); // single-prime digit: raw copy mod q_t
+        else outv = f64_to_u64(ext_target(e, tg, modc[tg].q, modc[tg].qinv, y, v));
+        eb[(size_t)t * N + x] = outv;
+    }
+}
+
+// grid (N/256, nt, B). acc: [B][2][nt][N]
+__global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *const *keys, u64 *acc, const KswConst *kcp, const ModConst *modc, int nmod) {
+    const KswConst &kc = *kcp;
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
+    const int tg = kc.tmod[t];
+    const double q = modc[tg].q, qinv = modc[tg].qinv;
+    const u64 *key = keys[b];
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = 0; i < kc.beta; i++) {
+        const double e = u64_to_f64(ext[((b * kc.beta + i) * (size_t)kc.nt + t) * N + x]);
+        const double k0 = u64_to_f64(key[(((size_t)i * 2 + 0) * nmod + tg) * N + x]);
+        const double k1 = u64_to_f64(key[(((size_t)i * 2 + 1) * nmod + tg) * N + x]);
+        a0 += mulmod2(e, k0, q, qinv); a1 += mulmod2(e, k1, q, qinv);
+    }
+    acc[((b * 2 + 0) * (size_t)kc.nt + t) * N + x] = f64_to_u64(canon(a0, q, qinv));
+    acc[((b * 2 + 1) * (size_t)kc.nt + t) * N + x] = f64_to_u64(canon(a1, q, qinv));
+}
+
+// grid (N/256, 2, B): special-prime rows of acc (already INTT'd) -> ext2 [B][2][nl][N] coefficient domain
+__global__ void __launch_bounds__(256) k_moddown_extend(const u64 *acc, u64 *ext2, const KswConst *kcp, const ModConst *modc) {
+    const KswConst &kc = *kcp;
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y; const size_t b = blockIdx.z;
+    const ExtConst &e = kc.pq;
+    const u64 *ap = acc + ((b * 2 + p) * (size_t)kc.nt + kc.nl) * N;
+    double xs[KSW_MAXA], y[KSW_MAXA], v = 0.0;
+#pragma unroll
+    for (int m = 0; m < KSW_MAXA; m++) xs[m] = m < e.a ? u64_to_f64(ap[(size_t)m * N + x]) : 0.0;
+    if (e.a > 1) ext_prepare(e, modc, xs, y, v);
+    for (int t = 0; t < kc.nl; t++) {
+        u64 outv = e.a == 1 ? f64_to_u64(canon(xs[0], modc[t].q, modc[t].qinv)) : f64_to_u64(ext_target(e, t, modc[t].q, modc[t].qinv, y, v));
+        ext2[((b * 2 + p) * (size_t)kc.nl + t) * N + x] = outv;
+    }
+}
+
+// grid (N/256, nl, B): out = perm(c0 + (acc0 - ext0)/P), perm((acc1 - ext1)/P); out[x] = in[index[x]]
+__global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const u64 *acc, const u64 *ext2, const uint16_t *const *index, u64 *ct_out,
+                                                   const KswConst *kcp, const ModConst *modc) {
+    const KswConst &kc = *kcp;
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
+    const double q = modc[t].q, qinv = modc[t].qinv, pinv = kc.pinv[t], pinv_q = kc.pinv_q[t];
+    const int src = index[b][x];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const double a = u64_to_f64(acc[((b * 2 + p) * (size_t)kc.nt + t) * N + src]);
+        const double e = u64_to_f64(ext2[((b * 2 + p) * (size_t)kc.nl + t) * N + src]);
+        double r = mulmod_lazy(a - e, pinv, pinv_q, q);
+        if (p == 0) r += u64_to_f64(ct_in[(b * 2 * (size_t)kc.nl + t) * N + src]);
+        ct_out[((b * 2 + p) * (size_t)kc.nl + t) * N + x] = f64_to_u64(canon(r, q, qinv));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ct_add(const u64 *a, const u64 *b, u64 *out, int nl, const ModConst *modc, size_t total_rows) {
+    const int N = SFG_N; const size_t row = blockIdx.x / (N / 256); const int m = (int)(row % nl);
+    const u64 q = modc[m].qi;
+    const size_t off = row * N + (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    u64 v = a[off] + b[off]; out[off] = v >= q ? v - q : v;
+}
+
+// rotate a batch; nrot_host[j] in RotateRight semantics. in/out: [nct][2][nl][N]
+int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host) {
+    const int N = SFG_N, nl = level + 1;
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "rotate: level out of range");
+    KswConst *kcd; KswConst kc;
+    SFG_TRY(get_ksw(ctx, level, &kcd, &kc));
+    const size_t ctw = (size_t)2 * nl * N;
+    // split into copies and real rotations
+    std::vector<int> rot_idx; std::vector<const u64 *> keyp; std::vector<const uint16_t *> idxp;
+    for (int j = 0; j < nct; j++) {
+        int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
+        if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + j * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
+        u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);                 // basics.go:205: RotateNew(ct, slots - nrot)
+        auto it = ctx->rotkeys.find(g);
+        if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
+        rot_idx.push_back(j); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev);
+    }
+    const int nr = (int)rot_idx.size();
+    if (!nr) return 0;
+    // chunk so that the scratch stays below ~3 GiB
+    const size_t rows_per_ct = (size_t)nl + (size_t)kc.beta * kc.nt + 2 * (size_t)kc.nt + 2 * (size_t)nl + 4 * (size_t)nl; // c2, ext, acc, ext2, gathered in/out
+    int chunk = (int)((3ULL << 30) / (rows_per_ct * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
+    const size_t ptr_bytes = (size_t)chunk * 2 * sizeof(void *);
+    SFG_TRY(sfg_ws_reserve(ctx, rows_per_ct * N * 8 * chunk + ptr_bytes + 256));
+    u64 *gin = (u64 *)ctx->ws, *gout = gin + (size_t)chunk * ctw;
+    u64 *c2 = gout + (size_t)chunk * ctw, *ext = c2 + (size_t)chunk * nl * N;
+    u64 *acc = ext + (size_t)chunk * kc.beta * kc.nt * N, *ext2 = acc + (size_t)chunk * 2 * kc.nt * N;
+    const u64 **keys_d = (const u64 **)(ext2 + (size_t)chunk * 2 * nl * N);
+    const uint16_t **idx_d = (const uint16_t **)(keys_d + chunk);
+    ModPattern pq; pq.period = nl; for (int m = 0; m < nl; m++) pq.m[m] = (int8_t)m;
+    ModPattern pext; pext.period = kc.beta * kc.nt;
+    for (int i = 0; i < kc.beta; i++) for (int t = 0; t < kc.nt; t++) pext.m[i * kc.nt + t] = kc.digit_of[t] == i ? (int8_t)-1 : (int8_t)kc.tmod[t];
+    ModPattern pp; pp.period = kc.np; for (int p = 0; p < kc.np; p++) pp.m[p] = (int8_t)(ctx->nq + p);
+    for (int c0 = 0; c0 < nr; c0 += chunk) {
+        const int nb = nr - c0 < chunk ? nr - c0 : chunk;
+        // gather inputs contiguously (rotations of a batch are usually contiguous already; this keeps the kernels simple)
+        const u64 *bin = nullptr;
+        bool contiguous = true;
+        for (int k = 1; k < nb; k++) if (rot_idx[c0 + k] != rot_idx[c0] + k) contiguous = false;
+        if (contiguous) bin = in + (size_t)rot_idx[c0] * ctw;
+        else { for (int k = 0; k < nb; k++) SFG_HIP(ctx, hipMemcpyAsync(gin + (size_t)k * ctw, in + (size_t)rot_idx[c0 + k] * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); bin = gin; }
+        u64 *bout = contiguous ? out + (size_t)rot_idx[c0] * ctw : gout;
+        SFG_HIP(ctx, hipMemcpyAsync(keys_d, keyp.data() + c0, nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+        SFG_HIP(ctx, hipMemcpyAsync(idx_d, idxp.data() + c0, nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+        // 1. c2 = INTT(c1): row (b, m) reads ct b poly 1
+        RowMap rm1; rm1.rpg = nl; rm1.gstride_in = ctw; rm1.gstride_out = (size_t)nl * N;
+        SFG_TRY(launch_ntt_inv_map(ctx, bin + (size_t)nl * N, c2, (size_t)nb * nl, pq, rm1));
+        // 2. digit extension + NTT (in-digit rows are skipped by the pattern)
+        hipLaunchKernelGGL(k_ksw_extend, dim3(N / 256, kc.beta, nb), dim3(256), 0, ctx->stream, c2, bin, ext, kcd, ctx->modc);
+        SFG_HIP(ctx, hipGetLastError());
+        SFG_TRY(launch_ntt_fwd(ctx, ext, ext, (size_t)nb * kc.beta * kc.nt, pext));
+        // 3. inner product with the key
+        hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, ext, keys_d, acc, kcd, ctx->modc, ctx->nmod);
+        SFG_HIP(ctx, hipGetLastError());
+        // 4. ModDown: INTT special rows in place, extend to Q, NTT
+        RowMap rm4; rm4.rpg = kc.np; rm4.gstride_in = (size_t)kc.nt * N; rm4.gstride_out = (size_t)kc.nt * N;
+        SFG_TRY(launch_ntt_inv_map(ctx, acc + (size_t)nl * N, acc + (size_t)nl * N, (size_t)nb * 2 * kc.np, pp, rm4));
+        hipLaunchKernelGGL(k_moddown_extend, dim3(N / 256, 2, nb), dim3(256), 0, ctx->stream, acc, ext2, kcd, ctx->modc);
+        SFG_HIP(ctx, hipGetLastError());
+        SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2, (size_t)nb * 2 * nl, pq));
+        // 5. finish + automorphism
+        hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, acc, ext2, idx_d, bout, kcd, ctx->modc);
+        SFG_HIP(ctx, hipGetLastError());
+        if (!contiguous) for (int k = 0; k < nb; k++) SFG_HIP(ctx, hipMemcpyAsync(out + (size_t)rot_idx[c0 + k] * ctw, gout + (size_t)k * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        // the pointer arrays are re-used by the next chunk: wait until this chunk's kernels have consumed them
+        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *in, uint64_t *out, int nct, int level, const int *nrot_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (in == out) SFG_FAIL(ctx, "rotate: in and out must not alias");
+    PhaseTimer t(ctx, "rotate");
+    int rc = launch_rotate_right(ctx, (const u64 *)in, (u64 *)out, nct, level, nrot_host);
+    t.stop(1);
+    return rc;
+}
+
+int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct, int level) {
+    const int nl = level + 1; const size_t rows = nct * 2 * nl;
+    if (!rows) return 0;
+    hipLaunchKernelGGL(k_ct_add, dim3((unsigned)(rows * (SFG_N / 256))), dim3(256), 0, ctx->stream, a, b, out, nl, ctx->modc, rows);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+extern "C" int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, int nct, int level) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_ct_add(ctx, (const u64 *)a, (const u64 *)b, (u64 *)out, (size_t)nct, level);
+}

@@ -4,8 +4,6 @@
 #define NOT_YET(ctx, name) do { (ctx)->err = name ": not implemented in this build"; return 2; } while (0)
 extern "C" {
 int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *, int, int64_t *) { NOT_YET(ctx, "sfg_encode_coeffs_host"); }
-int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *, uint64_t *, int, int, const int *) { NOT_YET(ctx, "sfg_rotate_right_dev"); }
-int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *, const uint64_t *, uint64_t *, int, int) { NOT_YET(ctx, "sfg_ct_add_dev"); }
 int sfg_geno_upload(sfg_ctx *ctx, const int8_t *, size_t, size_t, size_t, sfg_geno **) { NOT_YET(ctx, "sfg_geno_upload"); }
 int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *, size_t, size_t, size_t, sfg_geno **) { NOT_YET(ctx, "sfg_geno_from_device"); }
 void sfg_geno_free(sfg_ctx *, sfg_geno *) {}
