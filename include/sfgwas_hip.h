@@ -116,6 +116,17 @@ int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level,
  * [j0, j1) of the output (X: SNP-column blocks) or block rows [b0, b1) of the contraction (X^T) */
 int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,
                                   const sfg_geno *g, unsigned flags, int blk0, int blk1, uint64_t *out_dev);
+/* two-phase form of the same product, for contraction-sharded (X^T) multi-GPU runs.  Key switching is not
+ * bit-linear, so partial sums must be combined BEFORE the giant-step rotations to stay bit-exact with the reference:
+ *   accumulate: acc[(j-j0)][giant < 91][i < s][2][max_level][N] (+)= sum over operand block rows [b0,b1) and baby steps
+ *   (ranks then reduce-scatter / all-reduce acc as uint64 and call sfg_reduce_rows_dev)
+ *   finalize:   out[i][j][2][max_level][N] (+)= sum_{giant in [g0,g1)} RotateRight(acc[j][giant][i], -giant*91)
+ *               (matmult.go:1443-1502); out has ncolb block columns */
+int sfg_matmul_accumulate_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,
+                              const sfg_geno *g, unsigned flags, int b0, int b1, int j0, int j1,
+                              int accumulate, uint64_t *acc_dev);
+int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, int max_level, int ncolb,
+                            int g0, int g1, int accumulate, uint64_t *out_dev);
 /* after an integer all-reduce(sum) of partial outputs across ranks: canonical reduction mod q_l of [rows][L][N] */
 int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows_dev, size_t nrows_of_L, int L);
 

@@ -70,6 +70,7 @@ struct orc_ring {
     int logN, N, nq, np;
     u64 q[ORC_MAXMOD], psi[ORC_MAXMOD], ninv[ORC_MAXMOD];
     u64 *psi_rev[ORC_MAXMOD], *psi_inv_rev[ORC_MAXMOD];
+    u64 *psi_rev_sh[ORC_MAXMOD], *psi_inv_rev_sh[ORC_MAXMOD];   /* floor(w * 2^64 / q): speeds the oracle up, same residues */
 };
 static inline uint32_t brev(uint32_t x, int bits) {
     uint32_t r = 0;
@@ -103,10 +104,12 @@ orc_ring *orc_ring_new(int logN, int nq, int np, const u64 *moduli, const u64 *p
         u64 psi_inv = orc_invmod(r->psi[m], q);
         r->ninv[m] = orc_invmod((u64)N, q);
         r->psi_rev[m] = malloc(sizeof(u64) * N); r->psi_inv_rev[m] = malloc(sizeof(u64) * N);
+        r->psi_rev_sh[m] = malloc(sizeof(u64) * N); r->psi_inv_rev_sh[m] = malloc(sizeof(u64) * N);
         u64 p = 1, pi = 1;
         for (int k = 0; k < N; k++) {
             uint32_t b = brev((uint32_t)k, logN);
             r->psi_rev[m][b] = p; r->psi_inv_rev[m][b] = pi;
+            r->psi_rev_sh[m][b] = (u64)(((u128)p << 64) / q); r->psi_inv_rev_sh[m][b] = (u64)(((u128)pi << 64) / q);
             p = orc_mulmod(p, r->psi[m], q); pi = orc_mulmod(pi, psi_inv, q);
         }
     }
@@ -114,25 +117,32 @@ orc_ring *orc_ring_new(int logN, int nq, int np, const u64 *moduli, const u64 *p
 }
 void orc_ring_free(orc_ring *r) {
     if (!r) return;
-    for (int m = 0; m < ORC_MAXMOD; m++) { free(r->psi_rev[m]); free(r->psi_inv_rev[m]); }
+    for (int m = 0; m < ORC_MAXMOD; m++) { free(r->psi_rev[m]); free(r->psi_inv_rev[m]); free(r->psi_rev_sh[m]); free(r->psi_inv_rev_sh[m]); }
     free(r);
 }
 int orc_ring_N(const orc_ring *r) { return r->N; }
 u64 orc_ring_psi(const orc_ring *r, int mod) { return r->psi[mod]; }
 u64 orc_ring_modulus(const orc_ring *r, int mod) { return r->q[mod]; }
 
+/* a*w mod q with w' = floor(w*2^64/q) (exact: same canonical residue as orc_mulmod, only faster) */
+static inline u64 mulmod_shoup(u64 a, u64 w, u64 wsh, u64 q) {
+    u64 hi = (u64)(((u128)a * wsh) >> 64);
+    u64 r = a * w - hi * q;
+    return r >= q ? r - q : r;
+}
+
 /* lattigo ring.NTT restated: Cooley-Tukey, twiddles psi^brev(m+i), natural in -> bit-reversed out,
  * exact final reduction.  out[i] = p(psi^(2*brev(i)+1)).  Called behind encoder.EncodeNTT
  * (matmult.go:723) and inside every key switch. */
 void orc_ntt(const orc_ring *r, int mod, u64 *a) {
-    int N = r->N; u64 q = r->q[mod]; const u64 *w = r->psi_rev[mod];
+    int N = r->N; u64 q = r->q[mod]; const u64 *w = r->psi_rev[mod], *wsh = r->psi_rev_sh[mod];
     int t = N;
     for (int m = 1; m < N; m <<= 1) {
         t >>= 1;
         for (int i = 0; i < m; i++) {
-            int j1 = 2 * i * t; u64 W = w[m + i];
+            int j1 = 2 * i * t; u64 W = w[m + i], Ws = wsh[m + i];
             for (int j = j1; j < j1 + t; j++) {
-                u64 U = a[j], V = orc_mulmod(a[j + t], W, q);
+                u64 U = a[j], V = mulmod_shoup(a[j + t], W, Ws, q);
                 u64 s = U + V; if (s >= q) s -= q;
                 u64 d = U >= V ? U - V : U + q - V;
                 a[j] = s; a[j + t] = d;
@@ -142,17 +152,17 @@ void orc_ntt(const orc_ring *r, int mod, u64 *a) {
 }
 /* lattigo ring.InvNTT restated: Gentleman-Sande with psi^-brev, then * N^-1 */
 void orc_intt(const orc_ring *r, int mod, u64 *a) {
-    int N = r->N; u64 q = r->q[mod]; const u64 *w = r->psi_inv_rev[mod];
+    int N = r->N; u64 q = r->q[mod]; const u64 *w = r->psi_inv_rev[mod], *wsh = r->psi_inv_rev_sh[mod];
     int t = 1;
     for (int m = N; m > 1; m >>= 1) {
         int j1 = 0, h = m >> 1;
         for (int i = 0; i < h; i++) {
-            u64 W = w[h + i];
+            u64 W = w[h + i], Ws = wsh[h + i];
             for (int j = j1; j < j1 + t; j++) {
                 u64 U = a[j], V = a[j + t];
                 u64 s = U + V; if (s >= q) s -= q;
                 u64 d = U >= V ? U - V : U + q - V;
-                a[j] = s; a[j + t] = orc_mulmod(d, W, q);
+                a[j] = s; a[j + t] = mulmod_shoup(d, W, Ws, q);
             }
             j1 += 2 * t;
         }
@@ -253,23 +263,37 @@ static int64_t dd_round(dd x) { /* half away from zero */
 }
 static int64_t q_round(__float128 x) { return x >= 0 ? (int64_t)floorq(x + 0.5Q) : -(int64_t)floorq(-x + 0.5Q); }
 
+/* twiddle cache: exp(-2 pi i k / M) for k < M in 113-bit precision, built once per M (the trig calls dominate otherwise) */
+static __float128 *g_tw_re = NULL, *g_tw_im = NULL; static u64 g_tw_M = 0;
+static void tw_ensure(u64 M) {
+#pragma omp critical(orc_tw)
+    {
+        if (g_tw_M != M) {
+            free(g_tw_re); free(g_tw_im);
+            g_tw_re = malloc(sizeof(__float128) * M); g_tw_im = malloc(sizeof(__float128) * M);
+            for (u64 k = 0; k < M; k++) { __float128 ang = -2.0Q * M_PIq * (__float128)k / (__float128)M; g_tw_re[k] = cosq(ang); g_tw_im[k] = sinq(ang); }
+            g_tw_M = M;
+        }
+    }
+}
 #define FFT_TMPL(NAME, R, ADD, SUB, MUL, FROMQ)                                              \
-    /* in-place forward DFT (sign -) of size n (power of two) over (re,im) arrays */        \
+    /* in-place forward DFT (sign -) of size n (power of two) over (re,im) arrays; M = 4n table */ \
     static void NAME(R *re, R *im, int n) {                                                  \
         int lg = 0; while ((1 << lg) < n) lg++;                                              \
+        const u64 M = 4ULL * n;                                                              \
         for (int i = 0; i < n; i++) { int j = (int)brev((uint32_t)i, lg);                    \
             if (j > i) { R t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; } } \
         for (int len = 2; len <= n; len <<= 1) {                                             \
             int h = len >> 1;                                                                \
             for (int k = 0; k < h; k++) {                                                    \
-                __float128 ang = -2.0Q * M_PIq * (__float128)k / (__float128)len;            \
-                R wr = FROMQ(cosq(ang)), wi = FROMQ(sinq(ang));                              \
+                const u64 ti = (u64)k * (M / (u64)len);                                      \
+                R wr = FROMQ(g_tw_re[ti]), wi = FROMQ(g_tw_im[ti]);                          \
                 for (int i = k; i < n; i += len) {                                           \
                     int j = i + h;                                                           \
                     R tr = SUB(MUL(re[j], wr), MUL(im[j], wi));                              \
-                    R ti = ADD(MUL(re[j], wi), MUL(im[j], wr));                              \
-                    re[j] = SUB(re[i], tr); im[j] = SUB(im[i], ti);                          \
-                    re[i] = ADD(re[i], tr); im[i] = ADD(im[i], ti);                          \
+                    R ti2 = ADD(MUL(re[j], wi), MUL(im[j], wr));                             \
+                    re[j] = SUB(re[i], tr); im[j] = SUB(im[i], ti2);                         \
+                    re[i] = ADD(re[i], tr); im[i] = ADD(im[i], ti2);                         \
                 }                                                                            \
             }                                                                                \
         }                                                                                    \
@@ -283,6 +307,7 @@ FFT_TMPL(fft_dd, dd, dd_add, dd_sub, dd_mul, dd_from_q)
 
 void orc_encode_coeffs(const orc_ring *r, const double *v, double scale, int64_t *coeffs, int prec) {
     int N = r->N, n = N / 2; u64 M = 2ULL * N;
+    tw_ensure(M);
     int *perm = malloc(sizeof(int) * n);
     u64 g = 1;
     for (int t = 0; t < n; t++) { perm[t] = (int)(((g - 1) / 4) % n); g = (g * 5) % M; }
@@ -291,8 +316,7 @@ void orc_encode_coeffs(const orc_ring *r, const double *v, double scale, int64_t
         for (int t = 0; t < n; t++) re[perm[t]] = (__float128)v[t];
         fft_q(re, im, n);
         for (int c = 0; c < n; c++) {
-            __float128 ang = -2.0Q * M_PIq * (__float128)c / (__float128)M;
-            __float128 zr = cosq(ang), zi = sinq(ang);
+            __float128 zr = g_tw_re[c], zi = g_tw_im[c];
             __float128 wr = (re[c] * zr - im[c] * zi) / (__float128)n, wi = (re[c] * zi + im[c] * zr) / (__float128)n;
             coeffs[c] = q_round(wr * (__float128)scale);
             coeffs[c + n] = q_round(wi * (__float128)scale);
@@ -304,8 +328,7 @@ void orc_encode_coeffs(const orc_ring *r, const double *v, double scale, int64_t
         fft_dd(re, im, n);
         dd sc = dd_from(scale / (double)n); /* n and (in practice) scale are powers of two: exact */
         for (int c = 0; c < n; c++) {
-            __float128 ang = -2.0Q * M_PIq * (__float128)c / (__float128)M;
-            dd zr = dd_from_q(cosq(ang)), zi = dd_from_q(sinq(ang));
+            dd zr = dd_from_q(g_tw_re[c]), zi = dd_from_q(g_tw_im[c]);
             dd wr = dd_mul(dd_sub(dd_mul(re[c], zr), dd_mul(im[c], zi)), sc);
             dd wi = dd_mul(dd_add(dd_mul(re[c], zi), dd_mul(im[c], zr)), sc);
             coeffs[c] = dd_round(wr);

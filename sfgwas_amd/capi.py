@@ -50,6 +50,8 @@ def _sig(L):
         "sfg_matmul_resident_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, vp]),
         "sfg_matmul_stream": (i, [vp, u64p, i, i, i, vp, sz, sz, sz, C.c_uint, u64p, C.POINTER(d), C.POINTER(d)]),
         "sfg_matmul_resident_range_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, vp]),
+        "sfg_matmul_accumulate_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, i, i, i, vp]),
+        "sfg_matmul_finalize_dev": (i, [vp, vp, i, i, i, i, i, i, vp]),
         "sfg_reduce_rows_dev": (i, [vp, vp, sz, i]),
         "sfg_beaver_elem_dev": (i, [vp, i, i, u64p, vp, vp, vp, vp, vp, sz]),
         "sfg_beaver_elem": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, sz]),
@@ -220,3 +222,36 @@ def _ctx_rotate_right(self, cts, level, nrots):
 
 
 Context.rotate_right = _ctx_rotate_right
+
+
+def _ctx_matmul_stream(self, A, in_level, max_level, geno, flags=0, want_sums=False):
+    """MatMult4Stream through the C-ABI with host buffers.
+    A: [s][nbr][2][in_level+1][N] uint64, geno: [nrow][ncol] int8 -> (out [s][m_ct][2][max_level][N], sum, sqsum)"""
+    A = np.ascontiguousarray(A, dtype=np.uint64)
+    geno = np.ascontiguousarray(geno, dtype=np.int8)
+    s = A.shape[0]
+    nrow, ncol = geno.shape
+    lrow, lcol = (ncol, nrow) if flags & SFG_TRANSPOSE else (nrow, ncol)
+    nbr, m_ct = (lrow - 1) // self.slots + 1, (lcol - 1) // self.slots + 1
+    assert A.shape[1] == nbr, (A.shape, nbr)
+    out = np.zeros((s, m_ct, 2, max_level, self.N), dtype=np.uint64)
+    sm = np.zeros(ncol) if want_sums else None
+    sq = np.zeros(ncol) if want_sums else None
+    dp = C.POINTER(C.c_double)
+    self.check(lib().sfg_matmul_stream(self.h, p64(A), s, in_level, max_level, geno.ctypes.data_as(C.c_void_p), nrow, ncol, ncol, flags,
+                                       p64(out), sm.ctypes.data_as(dp) if want_sums else None, sq.ctypes.data_as(dp) if want_sums else None),
+               "sfg_matmul_stream")
+    return out, sm, sq
+
+
+Context.matmul_stream = _ctx_matmul_stream
+
+
+def random_rotkey(ctx_or_ring_moduli, beta, N, seed):
+    """uniform random key words [beta][2][nmod][N] — enough for GPU-vs-oracle parity (which does not need a valid key)"""
+    rnd = np.random.default_rng(seed)
+    mods = ctx_or_ring_moduli
+    k = np.zeros((beta, 2, len(mods), N), dtype=np.uint64)
+    for m, q in enumerate(mods):
+        k[:, :, m, :] = rnd.integers(0, q, (beta, 2, N), dtype=np.uint64)
+    return k

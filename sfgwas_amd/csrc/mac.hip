@@ -31,6 +31,9 @@ constexpr int MAC_RMAX = 32;      // rows per pass (2 * kp = 30 for kp = 15, pca
 
 struct MacArgs {
     const u64 *rot; const u64 *pt; u64 *out;
+    size_t rot_k_stride, rot_r_stride;     // words between consecutive k / consecutive rows of `rot` (row holds >= L modulus rows)
+    size_t pt_k_stride, pt_n_stride;       // words between consecutive k / consecutive columns of `pt`
+    size_t out_n_stride, out_r_stride;     // words between consecutive columns / rows of `out`
     int K, R, Ncols, L, accumulate;
     int r0;            // first row of this pass
     int l0, nl;        // moduli handled by this launch [l0, l0+nl)
@@ -60,11 +63,11 @@ __global__ void __launch_bounds__(MAC_THREADS, 2) k_mac(MacArgs a, const ModCons
     const double q = modc[l].q, qinv = modc[l].qinv;
     const int n0 = tile * MAC_COLS + (wc * MAC_CG + cg) * MAC_CT;     // this thread's first output column
 
-    const size_t rot_k_stride = (size_t)a.R * a.L * N, pt_k_stride = (size_t)a.Ncols * a.L * N;
-    const u64 *rot_base = a.rot + ((size_t)a.r0 * a.L + l) * N + c0;
+    const size_t rot_k_stride = a.rot_k_stride, pt_k_stride = a.pt_k_stride;
+    const u64 *rot_base = a.rot + (size_t)a.r0 * a.rot_r_stride + (size_t)l * N + c0;
     const u64 *pt_ptr[MAC_CT];          // walks k: advanced by pt_k_stride after every load
 #pragma unroll
-    for (int t = 0; t < MAC_CT; t++) { int nn = n0 + t < a.Ncols ? n0 + t : a.Ncols - 1; pt_ptr[t] = a.pt + ((size_t)nn * a.L + l) * N + c0 + cc; }
+    for (int t = 0; t < MAC_CT; t++) { int nn = n0 + t < a.Ncols ? n0 + t : a.Ncols - 1; pt_ptr[t] = a.pt + (size_t)nn * a.pt_n_stride + (size_t)l * N + c0 + cc; }
     int k_loaded = 0;                    // next k to fetch
 
     double acc[RH][MAC_CT][3];
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(MAC_THREADS, 2) k_mac(MacArgs a, const ModCons
             int kk = e / (RT * MAC_CL), rm = e % (RT * MAC_CL), r = rm / MAC_CL, c = rm % MAC_CL;
             int k = ch * MAC_KC + kk;
             u64 w = 0;
-            if (k < a.K && a.r0 + r < a.R) w = rot_base[(size_t)k * rot_k_stride + (size_t)r * a.L * N + c];
+            if (k < a.K && a.r0 + r < a.R) w = rot_base[(size_t)k * rot_k_stride + (size_t)r * a.rot_r_stride + c];
             if (BIG) {
                 lds[bufi][kk][c][r * 2 + 0] = (double)(unsigned)(w & 0x7FFFFFu);
                 lds[bufi][kk][c][r * 2 + 1] = u64_to_f64(w >> 23);
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(MAC_THREADS, 2) k_mac(MacArgs a, const ModCons
                 double x = pred(acc[r][t][0], q, qinv);
                 x += mulmod_lazy(pred(acc[r][t][1], q, qinv), s1, s1q, q);
                 x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
-                u64 *o = a.out + (((size_t)n * a.R + row) * a.L + l) * N + c0 + cc;
+                u64 *o = a.out + (size_t)n * a.out_n_stride + (size_t)row * a.out_r_stride + (size_t)l * N + c0 + cc;
                 if (a.accumulate) x += u64_to_f64(*o);
                 *o = f64_to_u64(canon(x, q, qinv));
             }
@@ -193,6 +196,14 @@ static int launch_mac_rt(sfg_ctx *ctx, MacArgs a, int rt) {
 }
 
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate) {
+    MacStrides st;
+    st.rot_k = (size_t)R * L * SFG_N; st.rot_r = (size_t)L * SFG_N;
+    st.pt_k = (size_t)Ncols * L * SFG_N; st.pt_n = (size_t)L * SFG_N;
+    st.out_n = (size_t)R * L * SFG_N; st.out_r = (size_t)L * SFG_N;
+    return launch_mac_strided(ctx, rot, pt, out, K, R, Ncols, L, accumulate, st);
+}
+
+int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st) {
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac: L out of range");
     for (int r0 = 0; r0 < R; r0 += MAC_RMAX) {
@@ -203,7 +214,7 @@ int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int
             bool big = ctx->q[l] >= (1ULL << 36);
             if (ctx->q[l] >= (1ULL << 47)) SFG_FAIL(ctx, "sfg_mac: modulus >= 2^47 unsupported by the fp64 limb schedule");
             int e = l; while (e < L && (ctx->q[e] >= (1ULL << 36)) == big) e++;
-            MacArgs a{rot, pt, out, K, R, Ncols, L, accumulate, r0, l, e - l, 0, 0};
+            MacArgs a{rot, pt, out, st.rot_k, st.rot_r, st.pt_k, st.pt_n, st.out_n, st.out_r, K, R, Ncols, L, accumulate, r0, l, e - l, 0, 0};
             // largest exact run: terms are < 2^48 (two per MAC in the big acc01), partial sums must stay < 2^53
             double maxterm = big ? 2.0 * 16777216.0 * 16777216.0 : (double)ctx->q[l] * 4096.0;
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;

@@ -1,0 +1,315 @@
+// matmul.hip — orchestration of the encrypted-row-vector x int8 genotype matrix product
+// (MatMult4Stream gwas/matmult.go:1238-1505, MatMult4StreamCompute :1043-1236, MatMult4StreamPreprocess :914-1041).
+//
+// The reference streams one diagonal at a time through s*d*m_ct u128 accumulator polynomials.  On the GPU the
+// same canonical sums are produced block by block:
+//   for every block row bi of the operand:   rotCache[bi] = { RotateRight(A[i][bi], -baby) }      (rotate.hip)
+//   for every 8192x8192 block (bi, j):        P = encode(all 8192 diagonals of the block)           (encode.hip, ntt.hip)
+//                                             acc[j][giant][i] += sum_baby rotCache[bi][baby][i] * P[giant*d + baby]   (mac.hip)
+//   finalize:  out[i][j] = sum_giant RotateRight(acc[j][giant][i], -giant*d)                       (rotate.hip)
+// acc holds canonical residues (8 B per coefficient instead of the reference's 16 B lazy u128), and only for the
+// block columns of the current group, so 100k x 1M fits one GPU's HBM.  The genotype matrix is kept once in HBM
+// as int8 and serves both X and X^T (SFG_TRANSPOSE).  Active baby/giant tables follow matmult.go:1329-1336.
+#include "common.hpp"
+#include "kernels.hpp"
+#include <algorithm>
+
+static inline int ceil_div(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+static inline int diag_bool(int r, int c, int dim, int index) {          // GetDiagBool, matmult.go:627-631
+    index %= dim; if (index < 0) index += dim;
+    return (dim + 1 - r) <= index || index <= c - 1;
+}
+
+struct Shape {
+    size_t nrow, ncol;      // logical operand dims (after optional transpose)
+    int nbr, m_ct;
+    bool transposed;
+    const int8_t *dev; size_t ld;
+    int rows_of(int bi) const { return (int)(std::min((size_t)(bi + 1) * SFG_SLOTS, nrow) - (size_t)bi * SFG_SLOTS); }
+    int cols_of(int bj) const { return (int)(std::min((size_t)(bj + 1) * SFG_SLOTS, ncol) - (size_t)bj * SFG_SLOTS); }
+    // pointer to the stored top-left element of logical block (bi, bj)
+    const int8_t *block(int bi, int bj) const {
+        return transposed ? dev + (size_t)bj * SFG_SLOTS * ld + (size_t)bi * SFG_SLOTS
+                          : dev + (size_t)bi * SFG_SLOTS * ld + (size_t)bj * SFG_SLOTS;
+    }
+};
+static Shape make_shape(const sfg_geno *g, unsigned flags) {
+    Shape sh; sh.transposed = (flags & SFG_TRANSPOSE) != 0;
+    sh.nrow = sh.transposed ? g->ncol : g->nrow; sh.ncol = sh.transposed ? g->nrow : g->ncol;
+    sh.nbr = ceil_div(sh.nrow, SFG_SLOTS); sh.m_ct = ceil_div(sh.ncol, SFG_SLOTS);
+    sh.dev = g->dev; sh.ld = g->ld; return sh;
+}
+
+// ---------------------------------------------------------------- small kernels
+// DropLevel (crypto/basics.go:806-824 at matmult.go:1055,1258): keep the first nl rows of each polynomial
+__global__ void __launch_bounds__(256) k_drop_level(const u64 *in, u64 *out, int nl_in, int nl) {
+    const int N = SFG_N; const size_t row = blockIdx.x / (N / 256);           // output row over [ct][2][nl]
+    const size_t ctp = row / nl, m = row % nl;
+    const size_t x = (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    out[row * N + x] = in[(ctp * nl_in + m) * N + x];
+}
+// out[i][j][p][l][x] (+)= sum over the listed giants of rot[(giant*s + i)][p][l][x]
+__global__ void __launch_bounds__(256) k_sum_giants(const u64 *rot, const int *giants, int ngiant, int s, int L, u64 *out, size_t out_i_stride,
+                                                    int accumulate, const ModConst *modc) {
+    const int N = SFG_N; const size_t row = blockIdx.x / (N / 256);           // row over [i][2][L]
+    const int i = (int)(row / (2 * L)), pl = (int)(row % (2 * L)), l = pl % L;
+    const size_t x = (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    const double q = modc[l].q, qinv = modc[l].qinv;
+    double acc = accumulate ? u64_to_f64(out[(size_t)i * out_i_stride + (size_t)pl * N + x]) : 0.0;
+    for (int g = 0; g < ngiant; g++) {
+        acc += u64_to_f64(rot[(((size_t)giants[g] * s + i) * 2 * L + pl) * N + x]);
+        if ((g & 31) == 31) acc = pred(acc, q, qinv);
+    }
+    out[(size_t)i * out_i_stride + (size_t)pl * N + x] = f64_to_u64(canon(acc, q, qinv));
+}
+__global__ void __launch_bounds__(256) k_reduce_rows(u64 *rows, int L, const ModConst *modc) {
+    const int N = SFG_N; const size_t row = blockIdx.x / (N / 256); const int l = (int)(row % L);
+    const size_t off = row * N + (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    rows[off] = rows[off] % modc[l].qi;
+}
+// P2: per-column sum and sum of squares after missing -> 0 (matmult.go:1292-1300)
+__global__ void __launch_bounds__(256) k_colsums(const int8_t *g, size_t nrow, size_t ncol, size_t ld, double *sum, double *sqsum) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncol) return;
+    unsigned long long s1 = 0, s2 = 0;
+    for (size_t i = 0; i < nrow; i++) { int v = g[i * ld + j]; v = v < 0 ? 0 : v; s1 += v; s2 += (unsigned)(int8_t)(v * v); }
+    if (sum) sum[j] = (double)s1;
+    if (sqsum) sqsum[j] = (double)s2;
+}
+
+// ---------------------------------------------------------------- genotype residency
+extern "C" int sfg_geno_upload(sfg_ctx *ctx, const int8_t *host, size_t nrow, size_t ncol, size_t ld, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!nrow || !ncol || ld < ncol) SFG_FAIL(ctx, "sfg_geno_upload: bad dimensions");
+    int8_t *d = nullptr;
+    SFG_HIP(ctx, hipMalloc(&d, nrow * ncol));
+    SFG_HIP(ctx, hipMemcpy2DAsync(d, ncol, host, ld, ncol, nrow, hipMemcpyHostToDevice, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sfg_geno *g = new sfg_geno(); g->dev = d; g->nrow = nrow; g->ncol = ncol; g->ld = ncol; g->owned = true;
+    *out = g; return 0;
+}
+extern "C" int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *dev, size_t nrow, size_t ncol, size_t ld, sfg_geno **out) {
+    if (!nrow || !ncol || ld < ncol) SFG_FAIL(ctx, "sfg_geno_from_device: bad dimensions");
+    sfg_geno *g = new sfg_geno(); g->dev = dev; g->nrow = nrow; g->ncol = ncol; g->ld = ld; g->owned = false;
+    *out = g; return 0;
+}
+extern "C" void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g) {
+    if (!g) return;
+    if (g->owned) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); (void)hipFree((void *)g->dev); }
+    delete g;
+}
+extern "C" int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *sqsum_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(sfg_ws_reserve(ctx, g->ncol * 16));
+    double *ds = (double *)ctx->ws, *dq = ds + g->ncol;
+    hipLaunchKernelGGL(k_colsums, dim3((unsigned)((g->ncol + 255) / 256)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, ds, dq);
+    SFG_HIP(ctx, hipGetLastError());
+    if (sum_host) SFG_HIP(ctx, hipMemcpyAsync(sum_host, ds, g->ncol * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (sqsum_host) SFG_HIP(ctx, hipMemcpyAsync(sqsum_host, dq, g->ncol * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows, size_t nrows_of_L, int L) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rows_total = nrows_of_L * L;
+    if (!rows_total) return 0;
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(rows_total * (SFG_N / 256))), dim3(256), 0, ctx->stream, (u64 *)rows, L, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- phase 1: accumulate
+// acc_dev: [(j - j0)][giant < d][i < s][2][L][N] canonical residues (zero-initialised here unless accumulate != 0)
+// for operand block rows [b0, b1) and block columns [j0, j1).
+static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, const Shape &sh, unsigned flags,
+                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc) {
+    const int N = SFG_N, d = SFG_D, L = max_level;
+    const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "matmul: max_level out of range");
+    if (nl < L) SFG_FAIL(ctx, "matmul: input level %d has fewer than max_level = %d moduli", in_level, max_level);
+    if (b0 < 0 || b1 > sh.nbr || b0 > b1 || j0 < 0 || j1 > sh.m_ct || j0 > j1) SFG_FAIL(ctx, "matmul: block range out of bounds");
+    const size_t ctw = (size_t)2 * nl * N, accw = (size_t)s * 2 * L * N;
+    const int ncolb = j1 - j0;
+    if (!accumulate) SFG_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ncolb * d * accw * 8, ctx->stream));
+    if (b0 == b1 || j0 == j1) return 0;
+    // scratch: level-dropped inputs of one block row, rotation cache of one block row, plaintext panel of one block
+    const size_t nplain = (size_t)d * d;                         // 8281 >= 8192: the tail stays zero
+    u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr;
+    SFG_HIP(ctx, hipMalloc(&a_row, (size_t)s * ctw * 8));
+    SFG_HIP(ctx, hipMalloc(&rotc, (size_t)d * s * ctw * 8));
+    SFG_HIP(ctx, hipMalloc(&pt, nplain * L * N * 8));
+    auto cleanup = [&]() { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(a_row); (void)hipFree(rotc); (void)hipFree(pt); };
+    int8_t *skew = nullptr;
+    if (hipMalloc(&skew, (size_t)SFG_SLOTS * SFG_SLOTS) != hipSuccess) { cleanup(); SFG_FAIL(ctx, "matmul: out of device memory (skew)"); }
+    int rc = 0;
+    std::vector<int> nrot((size_t)d * s);
+    for (int bi = b0; bi < b1 && !rc; bi++) {
+        const int nr = sh.rows_of(bi);
+        // active tables (matmult.go:1326-1336), union over ALL block columns of the operand as in the reference
+        std::vector<uint8_t> baby_t(d, 0), giant_t(d, 0);
+        for (int shift = 0; shift < SFG_SLOTS; shift++) {
+            bool any = false;
+            for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
+            if (any) { baby_t[shift % d] = 1; giant_t[shift / d] = 1; }
+        }
+        // A[i][bi] at the dropped level, contiguous over i
+        for (int i = 0; i < s && !rc; i++) {
+            const u64 *src = A + ((size_t)i * sh.nbr + bi) * 2 * nl_in * N;
+            if (nl == nl_in) { if (hipMemcpyAsync(a_row + (size_t)i * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = 1; }
+            else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_row + (size_t)i * ctw, nl_in, nl);
+        }
+        if (rc) { ctx->err = "matmul: staging of A failed"; break; }
+        // rotation cache: rotc[baby][i] = RotateRight(A[i][bi], -baby) (matmult.go:1373-1377); inactive babies are never read
+        {
+            PhaseTimer t(ctx, "rotate");
+            // one batch over (baby, i): every baby re-uses the decomposition of the same s inputs
+            std::vector<int> nrv((size_t)d * s, 0), inv((size_t)d * s, 0);
+            for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) { nrv[(size_t)baby * s + i] = baby_t[baby] ? -baby : 0; inv[(size_t)baby * s + i] = i; }
+            rc = launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data());
+            t.stop(1);
+        }
+        if (rc) break;
+        for (int bj = j0; bj < j1 && !rc; bj++) {
+            const int nc = sh.cols_of(bj);
+            {
+                PhaseTimer t(ctx, "skew");
+                rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
+                t.stop(1);
+            }
+            if (rc) break;
+            // existing diagonals of this block form at most two runs of shifts: [0, nr) and (n - nc, n)  (GetDiagBool)
+            int runs[2][2]; int nruns = 0;
+            if (nr >= SFG_SLOTS || nc >= SFG_SLOTS || nr + nc > SFG_SLOTS) { runs[0][0] = 0; runs[0][1] = SFG_SLOTS; nruns = 1; }
+            else { runs[0][0] = 0; runs[0][1] = nr; runs[1][0] = SFG_SLOTS - nc + 1; runs[1][1] = SFG_SLOTS; nruns = 2; if (runs[1][0] >= runs[1][1]) nruns = 1; }
+            if (nruns == 2 || runs[0][1] - runs[0][0] < SFG_SLOTS) SFG_HIP(ctx, hipMemsetAsync(pt, 0, nplain * L * N * 8, ctx->stream));
+            else SFG_HIP(ctx, hipMemsetAsync(pt + (size_t)SFG_SLOTS * L * N, 0, (nplain - SFG_SLOTS) * L * N * 8, ctx->stream));
+            {
+                PhaseTimer t(ctx, "encode");
+                for (int r = 0; r < nruns && !rc; r++)
+                    rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * L * N);
+                t.stop(nruns);
+            }
+            if (rc) break;
+            {
+                PhaseTimer t(ctx, "mac");
+                MacStrides st;
+                st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
+                st.pt_k = (size_t)L * N; st.pt_n = (size_t)d * L * N;           // pt[giant*d + baby]
+                st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
+                rc = launch_mac_strided(ctx, rotc, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
+                t.stop(1);
+            }
+        }
+    }
+    cleanup(); (void)hipFree(skew);
+    return rc;
+}
+
+// ---------------------------------------------------------------- phase 2: finalize
+// out[i][j][2][L][N] (+)= sum_{giant in [g0,g1)} RotateRight(acc[j][giant][i], -giant*d)   (matmult.go:1443-1502)
+static int matmul_finalize(sfg_ctx *ctx, const u64 *acc, int s, int max_level, int ncolb, int m_ct_out, int jout0, int g0, int g1,
+                           const std::vector<uint8_t> *giant_active, int accumulate, u64 *out) {
+    const int N = SFG_N, d = SFG_D, L = max_level;
+    const size_t accw = (size_t)s * 2 * L * N, ctw = (size_t)2 * L * N;
+    if (g0 < 0 || g1 > d || g0 > g1) SFG_FAIL(ctx, "finalize: giant range out of bounds");
+    u64 *rot = nullptr; int *giants_d = nullptr;
+    SFG_HIP(ctx, hipMalloc(&rot, (size_t)d * accw * 8));
+    SFG_HIP(ctx, hipMalloc(&giants_d, d * sizeof(int)));
+    int rc = 0;
+    for (int jb = 0; jb < ncolb && !rc; jb++) {
+        const u64 *accj = acc + (size_t)jb * d * accw;
+        std::vector<int> glist;
+        for (int g = g0; g < g1; g++) if (!giant_active || (*giant_active)[g]) glist.push_back(g);
+        {   // one batch over all d*s accumulator ciphertexts of this block column (inactive giants: plain copies of zeros)
+            std::vector<int> nrv((size_t)d * s, 0);
+            for (size_t k = 0; k < glist.size(); k++) for (int i = 0; i < s; i++) nrv[(size_t)glist[k] * s + i] = -glist[k] * d;
+            PhaseTimer t(ctx, "rotate");
+            rc = launch_rotate_right(ctx, accj, rot, d * s, L - 1, nrv.data());
+            t.stop(1);
+        }
+        if (rc) break;
+        if (hipMemcpyAsync(giants_d, glist.data(), glist.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = 1; ctx->err = "finalize: copy failed"; break; }
+        u64 *o = out + (size_t)(jout0 + jb) * ctw;
+        hipLaunchKernelGGL(k_sum_giants, dim3((unsigned)((size_t)s * 2 * L * (N / 256))), dim3(256), 0, ctx->stream, rot, giants_d, (int)glist.size(), s, L,
+                           o, (size_t)m_ct_out * ctw, accumulate, ctx->modc);
+        if (hipGetLastError() != hipSuccess) { rc = 1; ctx->err = "finalize: k_sum_giants launch failed"; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = 1; ctx->err = "finalize: sync failed"; }
+    }
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rot); (void)hipFree(giants_d);
+    return rc;
+}
+
+static void giant_table(const Shape &sh, std::vector<uint8_t> &giant_t) {
+    giant_t.assign(SFG_D, 0);
+    for (int bi = 0; bi < sh.nbr; bi++) {
+        const int nr = sh.rows_of(bi);
+        for (int shift = 0; shift < SFG_SLOTS; shift++) {
+            if (giant_t[shift / SFG_D]) { shift = (shift / SFG_D + 1) * SFG_D - 1; continue; }
+            bool any = false;
+            for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
+            if (any) giant_t[shift / SFG_D] = 1;
+        }
+    }
+}
+
+extern "C" int sfg_matmul_accumulate_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
+                                         int b0, int b1, int j0, int j1, int accumulate, uint64_t *acc) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    Shape sh = make_shape(g, flags);
+    return matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, j0, j1, accumulate, (u64 *)acc);
+}
+extern "C" int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc, int s, int max_level, int ncolb, int g0, int g1, int accumulate, uint64_t *out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    return matmul_finalize(ctx, (const u64 *)acc, s, max_level, ncolb, ncolb, 0, g0, g1, nullptr, accumulate, (u64 *)out);
+}
+
+// SNP-block range [blk0, blk1) over the block columns of the STORED matrix: output columns for X, contraction rows for X^T
+extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
+                                             int blk0, int blk1, uint64_t *out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->phases.clear();
+    Shape sh = make_shape(g, flags);
+    const int d = SFG_D, L = max_level, N = SFG_N;
+    const size_t accw = (size_t)s * 2 * L * N;
+    std::vector<uint8_t> giant_t; giant_table(sh, giant_t);
+    int b0 = 0, b1 = sh.nbr, j0 = 0, j1 = sh.m_ct;
+    if (sh.transposed) { b0 = blk0; b1 = blk1; } else { j0 = blk0; j1 = blk1; }
+    if (b0 < 0 || b1 > sh.nbr || j0 < 0 || j1 > sh.m_ct || b0 > b1 || j0 > j1) SFG_FAIL(ctx, "matmul: SNP-block range out of bounds");
+    const int m_out = j1 - j0;
+    // column groups bounded by an accumulator budget (default 24 GiB)
+    size_t budget = 24ULL << 30;
+    int jg = (int)(budget / ((size_t)d * accw * 8)); if (jg < 1) jg = 1;
+    for (int ja = j0; ja < j1; ja += jg) {
+        const int jb = std::min(j1, ja + jg);
+        u64 *acc = nullptr;
+        SFG_HIP(ctx, hipMalloc(&acc, (size_t)(jb - ja) * d * accw * 8));
+        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc);
+        if (!rc) rc = matmul_finalize(ctx, acc, s, max_level, jb - ja, m_out, ja - j0, 0, d, &giant_t, 0, (u64 *)out);
+        (void)hipStreamSynchronize(ctx->stream); (void)hipFree(acc);
+        if (rc) return rc;
+    }
+    return 0;
+}
+extern "C" int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, uint64_t *out) {
+    const size_t nb = (g->ncol + SFG_SLOTS - 1) / SFG_SLOTS;    // SNP blocks = block columns of the stored matrix
+    return sfg_matmul_resident_range_dev(ctx, A, s, in_level, max_level, g, flags, 0, (int)nb, out);
+}
+
+// MatMult4Stream(cps, A, gfs, maxLevel, computeSquaredSum, square, nproc) with host buffers (matmult.go:1238)
+extern "C" int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level, int max_level,
+                                 const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, unsigned flags,
+                                 uint64_t *out_host, double *sum_host, double *sqsum_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    sfg_geno *g = nullptr;
+    SFG_TRY(sfg_geno_upload(ctx, geno_host, nrow, ncol, ld, &g));
+    Shape sh = make_shape(g, flags);
+    const size_t a_words = (size_t)s * sh.nbr * 2 * (in_level + 1) * SFG_N, o_words = (size_t)s * sh.m_ct * 2 * max_level * SFG_N;
+    u64 *dA = nullptr, *dO = nullptr; int rc = 0;
+    if (hipMalloc(&dA, a_words * 8) != hipSuccess || hipMalloc(&dO, o_words * 8) != hipSuccess) { rc = 1; ctx->err = "matmul_stream: out of device memory"; }
+    if (!rc && hipMemcpy(dA, A_host, a_words * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = 1; ctx->err = "matmul_stream: upload failed"; }
+    if (!rc && (sum_host || sqsum_host)) rc = sfg_geno_colsums(ctx, g, sum_host, sqsum_host);   // sums are taken before squaring (:1297-1303)
+    if (!rc) rc = sfg_matmul_resident_dev(ctx, (const uint64_t *)dA, s, in_level, max_level, g, flags, (uint64_t *)dO);
+    if (!rc && hipMemcpy(out_host, dO, o_words * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = 1; ctx->err = "matmul_stream: download failed"; }
+    (void)hipFree(dA); (void)hipFree(dO); sfg_geno_free(ctx, g);
+    return rc;
+}

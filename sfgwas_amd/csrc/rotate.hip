@@ -139,16 +139,17 @@ __global__ void __launch_bounds__(256) k_ksw_extend(const u64 *c2, const u64 *ct
     }
 }
 
-// grid (N/256, nt, B). acc: [B][2][nt][N]
-__global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *const *keys, u64 *acc, const KswConst *kcp, const ModConst *modc, int nmod) {
+// grid (N/256, nt, B). acc: [B][2][nt][N]; inidx[b] = which decomposed input feeds output b
+__global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *const *keys, const int *inidx, u64 *acc, const KswConst *kcp, const ModConst *modc, int nmod) {
     const KswConst &kc = *kcp;
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
     const int tg = kc.tmod[t];
     const double q = modc[tg].q, qinv = modc[tg].qinv;
     const u64 *key = keys[b];
+    const size_t bi = (size_t)inidx[b];
     double a0 = 0.0, a1 = 0.0;
     for (int i = 0; i < kc.beta; i++) {
-        const double e = u64_to_f64(ext[((b * kc.beta + i) * (size_t)kc.nt + t) * N + x]);
+        const double e = u64_to_f64(ext[((bi * kc.beta + i) * (size_t)kc.nt + t) * N + x]);
         const double k0 = u64_to_f64(key[(((size_t)i * 2 + 0) * nmod + tg) * N + x]);
         const double k1 = u64_to_f64(key[(((size_t)i * 2 + 1) * nmod + tg) * N + x]);
         a0 += mulmod2(e, k0, q, qinv); a1 += mulmod2(e, k1, q, qinv);
@@ -174,8 +175,8 @@ __global__ void __launch_bounds__(256) k_moddown_extend(const u64 *acc, u64 *ext
 }
 
 // grid (N/256, nl, B): out = perm(c0 + (acc0 - ext0)/P), perm((acc1 - ext1)/P); out[x] = in[index[x]]
-__global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const u64 *acc, const u64 *ext2, const uint16_t *const *index, u64 *ct_out,
-                                                   const KswConst *kcp, const ModConst *modc) {
+__global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const int *inidx, const u64 *acc, const u64 *ext2, const uint16_t *const *index,
+                                                   u64 *const *ct_out, const KswConst *kcp, const ModConst *modc) {
     const KswConst &kc = *kcp;
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
     const double q = modc[t].q, qinv = modc[t].qinv, pinv = kc.pinv[t], pinv_q = kc.pinv_q[t];
@@ -185,8 +186,8 @@ __global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const u64 
         const double a = u64_to_f64(acc[((b * 2 + p) * (size_t)kc.nt + t) * N + src]);
         const double e = u64_to_f64(ext2[((b * 2 + p) * (size_t)kc.nl + t) * N + src]);
         double r = mulmod_lazy(a - e, pinv, pinv_q, q);
-        if (p == 0) r += u64_to_f64(ct_in[(b * 2 * (size_t)kc.nl + t) * N + src]);
-        ct_out[((b * 2 + p) * (size_t)kc.nl + t) * N + x] = f64_to_u64(canon(r, q, qinv));
+        if (p == 0) r += u64_to_f64(ct_in[((size_t)inidx[b] * 2 * (size_t)kc.nl + t) * N + src]);
+        ct_out[b][((size_t)p * kc.nl + t) * N + x] = f64_to_u64(canon(r, q, qinv));
     }
 }
 
@@ -197,74 +198,86 @@ __global__ void __launch_bounds__(256) k_ct_add(const u64 *a, const u64 *b, u64 
     u64 v = a[off] + b[off]; out[off] = v >= q ? v - q : v;
 }
 
-// rotate a batch; nrot_host[j] in RotateRight semantics. in/out: [nct][2][nl][N]
-int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host) {
+// Rotate a batch.  `in` holds nin ciphertexts [nin][2][nl][N]; output j = RotateRight(in[in_index[j]], nrot[j])
+// (RotateRightWithEvaluator semantics) written to out + j*ct words.  in_index == nullptr means identity (nin == nct).
+// Decomposition (steps 1-2) is done once per INPUT and shared by all its rotations ("hoisting"): the per-key work is
+// only the inner product, ModDown and the automorphism.  Same arithmetic, same bits.
+int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index) {
     const int N = SFG_N, nl = level + 1;
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "rotate: level out of range");
     KswConst *kcd; KswConst kc;
     SFG_TRY(get_ksw(ctx, level, &kcd, &kc));
     const size_t ctw = (size_t)2 * nl * N;
-    // split into copies and real rotations
-    std::vector<int> rot_idx; std::vector<const u64 *> keyp; std::vector<const uint16_t *> idxp;
+    std::vector<int> job_in; std::vector<const u64 *> keyp; std::vector<const uint16_t *> idxp; std::vector<u64 *> outp;
     for (int j = 0; j < nct; j++) {
         int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
-        if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + j * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
+        const int src = in_index ? in_index[j] : j;
+        if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
+        if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + (size_t)src * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
         u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);                 // basics.go:205: RotateNew(ct, slots - nrot)
         auto it = ctx->rotkeys.find(g);
         if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
-        rot_idx.push_back(j); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev);
+        job_in.push_back(src); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev); outp.push_back(out + j * ctw);
     }
-    const int nr = (int)rot_idx.size();
+    const int nr = (int)job_in.size();
     if (!nr) return 0;
-    // chunk so that the scratch stays below ~3 GiB
-    const size_t rows_per_ct = (size_t)nl + (size_t)kc.beta * kc.nt + 2 * (size_t)kc.nt + 2 * (size_t)nl + 4 * (size_t)nl; // c2, ext, acc, ext2, gathered in/out
-    int chunk = (int)((3ULL << 30) / (rows_per_ct * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
-    const size_t ptr_bytes = (size_t)chunk * 2 * sizeof(void *);
-    SFG_TRY(sfg_ws_reserve(ctx, rows_per_ct * N * 8 * chunk + ptr_bytes + 256));
-    u64 *gin = (u64 *)ctx->ws, *gout = gin + (size_t)chunk * ctw;
-    u64 *c2 = gout + (size_t)chunk * ctw, *ext = c2 + (size_t)chunk * nl * N;
-    u64 *acc = ext + (size_t)chunk * kc.beta * kc.nt * N, *ext2 = acc + (size_t)chunk * 2 * kc.nt * N;
+    // inputs are processed in groups whose decomposition fits ~1.5 GiB; jobs of a group in chunks whose acc/ext2 fit ~1.5 GiB
+    const size_t in_rows = (size_t)nl + (size_t)kc.beta * kc.nt, job_rows = 2 * (size_t)kc.nt + 2 * (size_t)nl;
+    int in_grp = (int)((3ULL << 29) / (in_rows * N * 8)); if (in_grp < 1) in_grp = 1; if (in_grp > nin) in_grp = nin;
+    int chunk = (int)((3ULL << 29) / (job_rows * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
+    const size_t ptr_bytes = (size_t)chunk * (3 * sizeof(void *) + sizeof(int)) + 256;
+    SFG_TRY(sfg_ws_reserve(ctx, (in_rows * in_grp + job_rows * chunk) * N * 8 + ptr_bytes));
+    u64 *c2 = (u64 *)ctx->ws, *ext = c2 + (size_t)in_grp * nl * N;
+    u64 *acc = ext + (size_t)in_grp * kc.beta * kc.nt * N, *ext2 = acc + (size_t)chunk * 2 * kc.nt * N;
     const u64 **keys_d = (const u64 **)(ext2 + (size_t)chunk * 2 * nl * N);
     const uint16_t **idx_d = (const uint16_t **)(keys_d + chunk);
+    u64 **out_d = (u64 **)(idx_d + chunk);
+    int *inidx_d = (int *)(out_d + chunk);
     ModPattern pq; pq.period = nl; for (int m = 0; m < nl; m++) pq.m[m] = (int8_t)m;
     ModPattern pext; pext.period = kc.beta * kc.nt;
     for (int i = 0; i < kc.beta; i++) for (int t = 0; t < kc.nt; t++) pext.m[i * kc.nt + t] = kc.digit_of[t] == i ? (int8_t)-1 : (int8_t)kc.tmod[t];
     ModPattern pp; pp.period = kc.np; for (int p = 0; p < kc.np; p++) pp.m[p] = (int8_t)(ctx->nq + p);
-    for (int c0 = 0; c0 < nr; c0 += chunk) {
-        const int nb = nr - c0 < chunk ? nr - c0 : chunk;
-        // gather inputs contiguously (rotations of a batch are usually contiguous already; this keeps the kernels simple)
-        const u64 *bin = nullptr;
-        bool contiguous = true;
-        for (int k = 1; k < nb; k++) if (rot_idx[c0 + k] != rot_idx[c0] + k) contiguous = false;
-        if (contiguous) bin = in + (size_t)rot_idx[c0] * ctw;
-        else { for (int k = 0; k < nb; k++) SFG_HIP(ctx, hipMemcpyAsync(gin + (size_t)k * ctw, in + (size_t)rot_idx[c0 + k] * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); bin = gin; }
-        u64 *bout = contiguous ? out + (size_t)rot_idx[c0] * ctw : gout;
-        SFG_HIP(ctx, hipMemcpyAsync(keys_d, keyp.data() + c0, nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-        SFG_HIP(ctx, hipMemcpyAsync(idx_d, idxp.data() + c0, nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-        // 1. c2 = INTT(c1): row (b, m) reads ct b poly 1
+    for (int i0 = 0; i0 < nin; i0 += in_grp) {
+        const int ni = nin - i0 < in_grp ? nin - i0 : in_grp;
+        std::vector<int> jobs;
+        for (int k = 0; k < nr; k++) if (job_in[k] >= i0 && job_in[k] < i0 + ni) jobs.push_back(k);
+        if (jobs.empty()) continue;
+        const u64 *bin = in + (size_t)i0 * ctw;
+        // 1. c2 = INTT(c1) for every input of the group
         RowMap rm1; rm1.rpg = nl; rm1.gstride_in = ctw; rm1.gstride_out = (size_t)nl * N;
-        SFG_TRY(launch_ntt_inv_map(ctx, bin + (size_t)nl * N, c2, (size_t)nb * nl, pq, rm1));
+        SFG_TRY(launch_ntt_inv_map(ctx, bin + (size_t)nl * N, c2, (size_t)ni * nl, pq, rm1));
         // 2. digit extension + NTT (in-digit rows are skipped by the pattern)
-        hipLaunchKernelGGL(k_ksw_extend, dim3(N / 256, kc.beta, nb), dim3(256), 0, ctx->stream, c2, bin, ext, kcd, ctx->modc);
+        hipLaunchKernelGGL(k_ksw_extend, dim3(N / 256, kc.beta, ni), dim3(256), 0, ctx->stream, c2, bin, ext, kcd, ctx->modc);
         SFG_HIP(ctx, hipGetLastError());
-        SFG_TRY(launch_ntt_fwd(ctx, ext, ext, (size_t)nb * kc.beta * kc.nt, pext));
-        // 3. inner product with the key
-        hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, ext, keys_d, acc, kcd, ctx->modc, ctx->nmod);
-        SFG_HIP(ctx, hipGetLastError());
-        // 4. ModDown: INTT special rows in place, extend to Q, NTT
-        RowMap rm4; rm4.rpg = kc.np; rm4.gstride_in = (size_t)kc.nt * N; rm4.gstride_out = (size_t)kc.nt * N;
-        SFG_TRY(launch_ntt_inv_map(ctx, acc + (size_t)nl * N, acc + (size_t)nl * N, (size_t)nb * 2 * kc.np, pp, rm4));
-        hipLaunchKernelGGL(k_moddown_extend, dim3(N / 256, 2, nb), dim3(256), 0, ctx->stream, acc, ext2, kcd, ctx->modc);
-        SFG_HIP(ctx, hipGetLastError());
-        SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2, (size_t)nb * 2 * nl, pq));
-        // 5. finish + automorphism
-        hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, acc, ext2, idx_d, bout, kcd, ctx->modc);
-        SFG_HIP(ctx, hipGetLastError());
-        if (!contiguous) for (int k = 0; k < nb; k++) SFG_HIP(ctx, hipMemcpyAsync(out + (size_t)rot_idx[c0 + k] * ctw, gout + (size_t)k * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        // the pointer arrays are re-used by the next chunk: wait until this chunk's kernels have consumed them
-        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SFG_TRY(launch_ntt_fwd(ctx, ext, ext, (size_t)ni * kc.beta * kc.nt, pext));
+        for (size_t c0 = 0; c0 < jobs.size(); c0 += chunk) {
+            const int nb = (int)(jobs.size() - c0 < (size_t)chunk ? jobs.size() - c0 : (size_t)chunk);
+            std::vector<const u64 *> kp(nb); std::vector<const uint16_t *> ip(nb); std::vector<u64 *> op(nb); std::vector<int> ii(nb);
+            for (int k = 0; k < nb; k++) { int jb = jobs[c0 + k]; kp[k] = keyp[jb]; ip[k] = idxp[jb]; op[k] = outp[jb]; ii[k] = job_in[jb] - i0; }
+            SFG_HIP(ctx, hipMemcpyAsync(keys_d, kp.data(), nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+            SFG_HIP(ctx, hipMemcpyAsync(idx_d, ip.data(), nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+            SFG_HIP(ctx, hipMemcpyAsync(out_d, op.data(), nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+            SFG_HIP(ctx, hipMemcpyAsync(inidx_d, ii.data(), nb * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            // 3. inner product with the key
+            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, ext, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
+            SFG_HIP(ctx, hipGetLastError());
+            // 4. ModDown: INTT special rows in place, extend to Q, NTT
+            RowMap rm4; rm4.rpg = kc.np; rm4.gstride_in = (size_t)kc.nt * N; rm4.gstride_out = (size_t)kc.nt * N;
+            SFG_TRY(launch_ntt_inv_map(ctx, acc + (size_t)nl * N, acc + (size_t)nl * N, (size_t)nb * 2 * kc.np, pp, rm4));
+            hipLaunchKernelGGL(k_moddown_extend, dim3(N / 256, 2, nb), dim3(256), 0, ctx->stream, acc, ext2, kcd, ctx->modc);
+            SFG_HIP(ctx, hipGetLastError());
+            SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2, (size_t)nb * 2 * nl, pq));
+            // 5. finish + automorphism
+            hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2, idx_d, out_d, kcd, ctx->modc);
+            SFG_HIP(ctx, hipGetLastError());
+            // the host vectors and device pointer arrays are re-used by the next chunk
+            SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     return 0;
+}
+int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host) {
+    return launch_rotate_right_indexed(ctx, in, nct, out, nct, level, nrot_host, nullptr);
 }
 
 extern "C" int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *in, uint64_t *out, int nct, int level, const int *nrot_host) {

@@ -4,14 +4,6 @@
 #define NOT_YET(ctx, name) do { (ctx)->err = name ": not implemented in this build"; return 2; } while (0)
 extern "C" {
 int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *, int, int64_t *) { NOT_YET(ctx, "sfg_encode_coeffs_host"); }
-int sfg_geno_upload(sfg_ctx *ctx, const int8_t *, size_t, size_t, size_t, sfg_geno **) { NOT_YET(ctx, "sfg_geno_upload"); }
-int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *, size_t, size_t, size_t, sfg_geno **) { NOT_YET(ctx, "sfg_geno_from_device"); }
-void sfg_geno_free(sfg_ctx *, sfg_geno *) {}
-int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *, double *, double *) { NOT_YET(ctx, "sfg_geno_colsums"); }
-int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *, int, int, int, const sfg_geno *, unsigned, uint64_t *) { NOT_YET(ctx, "sfg_matmul_resident_dev"); }
-int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *, int, int, int, const int8_t *, size_t, size_t, size_t, unsigned, uint64_t *, double *, double *) { NOT_YET(ctx, "sfg_matmul_stream"); }
-int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *, int, int, int, const sfg_geno *, unsigned, int, int, uint64_t *) { NOT_YET(ctx, "sfg_matmul_resident_range_dev"); }
-int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *, size_t, int) { NOT_YET(ctx, "sfg_reduce_rows_dev"); }
 int sfg_beaver_elem_dev(sfg_ctx *ctx, int, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *, size_t) { NOT_YET(ctx, "sfg_beaver_elem_dev"); }
 int sfg_beaver_elem(sfg_ctx *ctx, int, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *, size_t) { NOT_YET(ctx, "sfg_beaver_elem"); }
 int sfg_beaver_matmul(sfg_ctx *ctx, int, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *, int, int, int) { NOT_YET(ctx, "sfg_beaver_matmul"); }
