@@ -152,7 +152,8 @@ int sfg_fill_geno_dev(sfg_ctx *ctx, int8_t *geno_dev, size_t nrow, size_t ncol, 
 int sfg_fill_rotkeys_synthetic(sfg_ctx *ctx, const int *rot_left, int nrot, uint64_t seed);
 
 /* last kernel timing hooks for bench.py: milliseconds spent (HIP events on the ctx stream) in the named phase
- * of the most recent matmul call: "encode", "ntt", "mac", "rotate", "skew" ; returns <0 if unknown */
+ * of the most recent matmul call: "encode" (diagonal FFT + plaintext NTT), "mac", "mac_small"/"mac_big" (the two k_mac instances), "rotate", "skew" ; returns <0 if unknown */
+int sfg_ctx_clear_phases(sfg_ctx *ctx);
 double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase);
 int sfg_last_phase_launches(const sfg_ctx *ctx, const char *phase);
 

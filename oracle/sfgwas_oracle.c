@@ -749,3 +749,34 @@ void orc_sketch(const int8_t *X, size_t nrow, size_t ncol, const int32_t *bucket
         x2sum[j] += (u64)(int64_t)(int8_t)(x * x);
     }
 }
+
+/* ------------------------------------------------------------------ cpu_baseline timing leg (bench.py)
+ * The reference's hot loop exactly as it runs on the CPU: worker goroutines each take a diagonal and do
+ * CPMultAccWithoutMRedV2(rotCache[i][baby], plainVec, accCache[i][giant]) for i < s (matmult.go:1158-1166).
+ * Every thread owns one (rotated-ciphertext set, plaintext, accumulator set) and repeats that call until
+ * `seconds` have elapsed.  Returns ring-MACs per second over all threads ("CPU restatement, not the Go binary"). */
+#include <omp.h>
+double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long long *macs_done) {
+    long long total = 0;
+    double t_begin = omp_get_wtime(), t_end = t_begin;
+#pragma omp parallel num_threads(nthreads) reduction(+ : total)
+    {
+        size_t rw = (size_t)s * 2 * L * N;
+        u64 *rot = malloc(rw * 8), *pt = malloc((size_t)L * N * 8), *acc = calloc(rw * 2, 8);
+        u64 st = 0x1234 + 77 * (u64)omp_get_thread_num();
+        for (size_t i = 0; i < rw; i++) rot[i] = orc_splitmix64(&st) >> 18;
+        for (size_t i = 0; i < (size_t)L * N; i++) pt[i] = orc_splitmix64(&st) >> 18;
+#pragma omp barrier
+        double t0 = omp_get_wtime();
+        long long mine = 0;
+        while (omp_get_wtime() - t0 < seconds) { orc_cpmult_acc_v2(rot, pt, acc, s, L, N); mine += (long long)s * 2 * L * N; }
+        total += mine;
+        if (acc[1] == 0x5555) fprintf(stderr, " ");
+        free(rot); free(pt); free(acc);
+#pragma omp barrier
+#pragma omp master
+        t_end = omp_get_wtime();
+    }
+    if (macs_done) *macs_done = total;
+    return (double)total / (t_end - t_begin);
+}

@@ -113,6 +113,9 @@ int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
  * rot: [s][2][L][N] rotated ct (one baby), pt: [L][N] Montgomery-form plaintext, acc: [s][2][L][N]{hi,lo} */
 void orc_cpmult_acc_v2(const uint64_t *rot, const uint64_t *pt_mont, uint64_t *acc_hilo, int s, int L, int N);
 
+/* cpu_baseline leg of bench.py: the reference's MAC loop on nthreads host threads for ~seconds; returns MAC/s */
+double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long long *macs_done);
+
 /* ---- DiagCache file format (gwas/filestream.go:19-282) ---- */
 /* payload byte order for coefficients: big-endian u64 (lattigo ring.WriteCoeffsTo, unverified — see header) */
 typedef struct orc_diagcache orc_diagcache;

@@ -60,6 +60,7 @@ def _sig(L):
         "sfg_fill_uniform_ct_dev": (i, [vp, vp, i, i, u64]),
         "sfg_fill_geno_dev": (i, [vp, vp, sz, sz, u64]),
         "sfg_fill_rotkeys_synthetic": (i, [vp, C.POINTER(i), i, u64]),
+        "sfg_ctx_clear_phases": (i, [vp]),
         "sfg_last_phase_ms": (d, [vp, C.c_char_p]),
         "sfg_last_phase_launches": (i, [vp, C.c_char_p]),
     }

@@ -103,6 +103,7 @@ extern "C" int sfg_memcpy_d2h(sfg_ctx *ctx, void *d, const void *s, size_t n) {
     SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
 }
 
+extern "C" int sfg_ctx_clear_phases(sfg_ctx *ctx) { ctx->phases.clear(); return 0; }
 extern "C" double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase) {
     auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1.0 : it->second.ms;
 }

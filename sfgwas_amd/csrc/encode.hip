@@ -157,18 +157,21 @@ __device__ __forceinline__ long long dd_round_away(dd x) {
     return (long long)nn;
 }
 
-// rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d)
-__global__ void __launch_bounds__(512) k_fft_encode(const int8_t *D, int shift0, const double4 *zt, const uint16_t *tinv,
+// rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
+// F64IN: rows are n doubles (arbitrary real slot vectors, no rotation) — the Mask / EncodeFloatVector use.
+template <bool F64IN>
+__global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, const double4 *zt, const uint16_t *tinv,
                                                    double scale_over_n, long long *pc_out) {
     extern __shared__ double lds[];
     double *RH = lds, *RL = lds + ENC_PADN, *IH = lds + 2 * ENC_PADN, *IL = lds + 3 * ENC_PADN;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
     const int shift = shift0 + blockIdx.x;
-    const int nrot = SFG_D * (shift / SFG_D);                      // matmult.go:1426: nrot = d * giant
-    const int8_t *row = D + (size_t)shift * n;
+    const int nrot = F64IN ? 0 : SFG_D * (shift / SFG_D);          // matmult.go:1426: nrot = d * giant
+    const int8_t *row = (const int8_t *)Dv + (size_t)shift * n;
+    const double *rowd = (const double *)Dv + (size_t)shift * n;
     // stage the 8 KiB row in the (not yet used) tail of LDS
     int8_t *rowl = reinterpret_cast<int8_t *>(lds + 4 * ENC_PADN);
-    reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
+    if (!F64IN) reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
     __syncthreads();
     dd xr[8], xi[8];
     // ---- pass 1: bits a (stages half = 2048, 1024, 512); thread = (b,c,d) = tid, element j = a*512 + tid
@@ -177,7 +180,8 @@ __global__ void __launch_bounds__(512) k_fft_encode(const int8_t *D, int shift0,
         const int m = a * 512 + tid;                               // z_m = u_2m + i u_2m+1, u_mm = v[tinv[mm]] = row[(tinv[mm] - nrot) mod n]
         int t0 = (int)tinv[2 * m] - nrot, t1 = (int)tinv[2 * m + 1] - nrot;
         t0 += t0 < 0 ? n : 0; t1 += t1 < 0 ? n : 0;
-        xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0);
+        if (F64IN) { xr[a] = dd_make(rowd[t0], 0.0); xi[a] = dd_make(rowd[t1], 0.0); }
+        else { xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0); }
     }
     dif_stage<4>(xr, xi, zt, tid, 512, 2048);
     dif_stage<2>(xr, xi, zt, tid, 512, 1024);
@@ -285,14 +289,18 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
     EncTables *et = (EncTables *)ctx->enc_tables;
     static bool attr = false;
     const size_t lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
-    if (!attr) { SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr = true; }
+    if (!attr) {
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr = true;
+    }
     const int BATCH = 2048;
     SFG_TRY(enc_scratch(ctx, et, (size_t)(nshift < BATCH ? nshift : BATCH)));
     for (int s0 = 0; s0 < nshift; s0 += BATCH) {
         const int nb = nshift - s0 < BATCH ? nshift - s0 : BATCH;
         {
             PhaseTimer t(ctx, "encode", false);
-            hipLaunchKernelGGL(k_fft_encode, dim3(nb), dim3(512), lds_bytes, ctx->stream, D, shift0 + s0, et->zt, et->tinv,
+            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->zt, et->tinv,
                                ctx->scale / (double)SFG_SLOTS, et->pc);
             SFG_HIP(ctx, hipGetLastError());
         }
@@ -311,4 +319,34 @@ extern "C" int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block, size_t ld
     SFG_TRY(enc_scratch(ctx, et, 1));
     SFG_TRY(launch_skew(ctx, block, ld, r, c, transposed, 0, et->skew));
     return launch_encode_rows(ctx, et->skew, shift0, nshift, L, (u64 *)pt);
+}
+
+// EncodeFloatVector-style host helper (crypto.go:398-420 behind Mask/MaskTrunc, basics.go:110-172): real slot
+// vectors -> coefficient-domain integers of the scaled inverse embedding (exactly rounded, like EncoderBig).
+extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, int64_t *coeffs_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (nvec <= 0) return 0;
+    EncTables *et = (EncTables *)ctx->enc_tables;
+    const size_t n = SFG_SLOTS, lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    double *dv = nullptr; long long *dpc = nullptr;
+    SFG_HIP(ctx, hipMalloc(&dv, (size_t)nvec * n * 8));
+    if (hipMalloc(&dpc, (size_t)nvec * n * 8) != hipSuccess) { (void)hipFree(dv); SFG_FAIL(ctx, "encode_coeffs: out of device memory"); }
+    std::vector<long long> pc((size_t)nvec * n);
+    int rc = 0;
+    if (hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
+    if (!rc) {
+        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc);
+        if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    if (!rc && hipMemcpyAsync(pc.data(), dpc, (size_t)nvec * n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(dv); (void)hipFree(dpc);
+    if (rc) SFG_FAIL(ctx, "encode_coeffs: device operation failed");
+    for (int v = 0; v < nvec; v++) {                       // expand p_n = 0, p_{n+c} = -p_{n-c}
+        const long long *h = pc.data() + (size_t)v * n; int64_t *o = coeffs_host + (size_t)v * SFG_N;
+        for (size_t c = 0; c < n; c++) o[c] = h[c];
+        o[n] = 0;
+        for (size_t c = 1; c < n; c++) o[n + c] = -h[n - c];
+    }
+    return 0;
 }

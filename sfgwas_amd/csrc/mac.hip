@@ -221,7 +221,12 @@ int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, in
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm);
             f = (f / MAC_KC) * MAC_KC; if (f < MAC_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
             a.flush = f;
-            SFG_TRY(big ? launch_mac_rt<true>(ctx, a, rt) : launch_mac_rt<false>(ctx, a, rt));
+            {
+                PhaseTimer t(ctx, big ? "mac_big" : "mac_small");      // HIP events on the launch stream around this kernel
+                int rc = big ? launch_mac_rt<true>(ctx, a, rt) : launch_mac_rt<false>(ctx, a, rt);
+                t.stop(1);
+                if (rc) return rc;
+            }
             l = e;
         }
     }

@@ -1,0 +1,117 @@
+"""GPU parity of the remaining hot-path rows: Beaver local products (B1-B3), count-sketch + moments (P1),
+column sums (P2), float-vector encode (Mask path), synthetic generators. All against the oracle / big ints."""
+import ctypes as C
+import random
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sfgwas_amd import capi
+    c = capi.Context(ol.Q_PN14, ol.P_PN14)
+    yield c
+    c.close()
+
+
+def _limbs(x, n):
+    return [(x >> (64 * i)) & ((1 << 64) - 1) for i in range(n)]
+
+
+@pytest.mark.parametrize("limbs,p", [(2, (1 << 127) - 1), (4, (1 << 255) - 19), (2, (1 << 128) - 159)])
+@pytest.mark.parametrize("pid", [0, 1, 2])
+def test_beaver_elem_matches_oracle_and_bigint(ctx, limbs, p, pid):
+    from sfgwas_amd import capi
+    rnd = random.Random(limbs * 10 + pid)
+    n = 3000
+    vals = [[rnd.randrange(p) for _ in range(n)] for _ in range(4)]
+    for v in vals:                       # edge values
+        v[0], v[1], v[2] = 0, p - 1, 1
+    arrs = [np.array([_limbs(x, limbs) for x in v], dtype=np.uint64) for v in vals]
+    mod = np.array(_limbs(p, limbs), dtype=np.uint64)
+    got = np.zeros((n, limbs), dtype=np.uint64)
+    ctx.check(capi.lib().sfg_beaver_elem(ctx.h, pid, limbs, capi.p64(mod), *[capi.p64(a) for a in arrs], capi.p64(got), n), "beaver_elem")
+    want = np.zeros((n, limbs), dtype=np.uint64)
+    ol.lib().orc_beaver_elem(pid, limbs, ol.p64(mod), *[ol.p64(a) for a in arrs], ol.p64(want), n)
+    assert np.array_equal(got, want)
+    ar, am, br, bm = vals
+    for i in range(0, n, 97):            # and directly against Python integers (beavermult.go:94-106)
+        e = am[i] * bm[i] % p if pid == 0 else (ar[i] * bm[i] + br[i] * am[i] + (ar[i] * br[i] if pid == 1 else 0)) % p
+        assert sum(int(got[i, k]) << (64 * k) for k in range(limbs)) == e
+
+
+@pytest.mark.parametrize("pid", [0, 1, 2])
+def test_beaver_matmul(ctx, pid):
+    from sfgwas_amd import capi
+    limbs, p = 4, (1 << 255) - 19
+    rnd = random.Random(pid)
+    m, k, n = 15, 15, 7
+    mk = lambda cnt: np.array([_limbs(rnd.randrange(p), limbs) for _ in range(cnt)], dtype=np.uint64)
+    ar, am, br, bm = mk(m * k), mk(m * k), mk(k * n), mk(k * n)
+    mod = np.array(_limbs(p, limbs), dtype=np.uint64)
+    got = np.zeros((m * n, limbs), dtype=np.uint64)
+    ctx.check(capi.lib().sfg_beaver_matmul(ctx.h, pid, limbs, capi.p64(mod), capi.p64(ar), capi.p64(am), capi.p64(br), capi.p64(bm), capi.p64(got), m, k, n), "beaver_matmul")
+    want = np.zeros((m * n, limbs), dtype=np.uint64)
+    ol.lib().orc_beaver_matmul(pid, limbs, ol.p64(mod), ol.p64(ar), ol.p64(am), ol.p64(br), ol.p64(bm), ol.p64(want), m, k, n)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("nrow,ncol", [(1000, 777), (64, 256), (130, 5), (1, 1)])
+def test_sketch_and_moments(ctx, nrow, ncol):
+    from sfgwas_amd import capi
+    rnd = np.random.default_rng(nrow + ncol)
+    X = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+    kp = 15
+    bucket = rnd.integers(0, kp, nrow).astype(np.int32)
+    sgn = (rnd.integers(0, 2, nrow) * 2 - 1).astype(np.int8)
+    gh = C.c_void_p()
+    ctx.check(capi.lib().sfg_geno_upload(ctx.h, X.ctypes.data_as(C.c_void_p), nrow, ncol, ncol, C.byref(gh)), "geno_upload")
+    sk = np.zeros((kp, ncol)); xs = np.zeros(ncol, dtype=np.uint64); x2 = np.zeros(ncol, dtype=np.uint64)
+    ctx.check(capi.lib().sfg_sketch(ctx.h, gh, bucket.ctypes.data_as(C.POINTER(C.c_int32)), sgn.ctypes.data_as(C.POINTER(C.c_int8)), kp,
+                                    sk.ctypes.data_as(C.POINTER(C.c_double)), capi.p64(xs), capi.p64(x2)), "sketch")
+    wsk = np.zeros((kp, ncol)); wxs = np.zeros(ncol, dtype=np.uint64); wx2 = np.zeros(ncol, dtype=np.uint64)
+    ol.lib().orc_sketch(ol.pi8(X), nrow, ncol, bucket.ctypes.data_as(C.POINTER(C.c_int32)), ol.pi8(sgn), kp, ol.pd(wsk), ol.p64(wxs), ol.p64(wx2))
+    assert np.array_equal(sk, wsk) and np.array_equal(xs, wxs) and np.array_equal(x2, wx2)
+    # P2 column sums (missing -> 0)
+    sm = np.zeros(ncol); sq = np.zeros(ncol)
+    ctx.check(capi.lib().sfg_geno_colsums(ctx.h, gh, sm.ctypes.data_as(C.POINTER(C.c_double)), sq.ctypes.data_as(C.POINTER(C.c_double))), "colsums")
+    g0 = np.where(X < 0, 0, X).astype(np.float64)
+    assert np.array_equal(sm, g0.sum(0)) and np.array_equal(sq, (g0 * g0).sum(0))
+    capi.lib().sfg_geno_free(ctx.h, gh)
+
+
+def test_encode_float_vectors_match_oracle(ctx):
+    from sfgwas_amd import capi
+    ring = ol.Ring(14, ol.Q_PN14[:2], ol.P_PN14)
+    rnd = np.random.default_rng(3)
+    vecs = np.stack([np.r_[np.ones(100), np.zeros(8192 - 100)],          # MaskTrunc-style 0/1 mask (basics.go:110-127)
+                     rnd.normal(size=8192), np.zeros(8192)])
+    out = np.zeros((3, 16384), dtype=np.int64)
+    ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, vecs.ctypes.data_as(C.POINTER(C.c_double)), 3, out.ctypes.data_as(C.POINTER(C.c_int64))), "encode_coeffs")
+    for k in range(3):
+        assert np.array_equal(out[k], ring.encode_coeffs(vecs[k], 2.0 ** 34, prec=0))
+
+
+def test_device_generators_match_host_definitions(ctx):
+    from sfgwas_amd import capi
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    level, nct = 5, 3
+    d = ctx.malloc(nct * 2 * (level + 1) * ring.N * 8)
+    ctx.check(capi.lib().sfg_fill_uniform_ct_dev(ctx.h, d, nct, level, 4242), "fill_uniform")
+    got = ctx.to_host(d, (nct, 2, level + 1, ring.N), np.uint64)
+    ctx.free(d)
+    for j in range(nct):
+        assert np.array_equal(got[j], ring.fill_uniform(level, 4242 + j))
+    nrow, ncol = 300, 1000
+    g = ctx.malloc(nrow * ncol)
+    ctx.check(capi.lib().sfg_fill_geno_dev(ctx.h, g, nrow, ncol, 99), "fill_geno")
+    X = ctx.to_host(g, (nrow, ncol), np.int8)
+    ctx.free(g)
+    assert set(np.unique(X)) <= {-1, 0, 1, 2}
+    assert 0.003 < (X == -1).mean() < 0.02                     # ~1/128 missing
+    maf = np.where(X < 0, 0, X).mean(0) / 2
+    assert 0.03 < maf.min() and maf.max() < 0.6                # p_j ~ U(0.05, 0.5)
