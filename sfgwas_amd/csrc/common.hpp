@@ -56,6 +56,7 @@ struct sfg_ctx {
     std::map<int, void *> ksw_cache;   // per-level key-switch constants (device), rotate.hip
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
+    void *zeros_dev = nullptr;           // 256 B of zeros (DMA source for padded k-steps)
     std::string err;
     std::map<std::string, PhaseStat> phases;
 };

@@ -70,7 +70,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     for (auto &kv : ctx->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
     sfg_encoder_destroy(ctx);
-    (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws);
+    (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws); (void)hipFree(ctx->zeros_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

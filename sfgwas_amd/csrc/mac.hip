@@ -233,10 +233,33 @@ int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, in
     return 0;
 }
 
+// SFG_MAC_IMPL=reg selects the register-staged kernel of this file; default is the LDS-DMA kernel (mac_dma.hip)
+bool mac_use_dma() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SFG_MAC_IMPL"); v = (e && !strcmp(e, "reg")) ? 0 : 1; }
+    return v == 1;
+}
+
 extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt, uint64_t *out, int K, int R, int Ncols, int L, int accumulate) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac: L out of range");
     PhaseTimer t(ctx, "mac");
-    int rc = launch_mac(ctx, (const u64 *)rot, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate);
+    int rc;
+    if (!mac_use_dma()) rc = launch_mac(ctx, (const u64 *)rot, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate);
+    else {
+        std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+        if (nplanes < 0) return 1;
+        double *rotf = nullptr;
+        const size_t rows = (size_t)K * R;                       // rot is [K][R][L][N]
+        SFG_HIP(ctx, hipMalloc(&rotf, rows * (size_t)nplanes * SFG_N * 8));
+        rc = launch_rot_to_f64(ctx, (const u64 *)rot, rows, L, L, rotf);
+        MacStrides st;
+        st.rot_k = (size_t)R * L * SFG_N; st.rot_r = (size_t)L * SFG_N;
+        st.pt_k = (size_t)Ncols * L * SFG_N; st.pt_n = (size_t)L * SFG_N;
+        st.out_n = (size_t)R * L * SFG_N; st.out_r = (size_t)L * SFG_N;
+        if (!rc) rc = launch_mac_dma(ctx, rotf, (size_t)R, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate, st);
+        (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rotf);
+    }
     t.stop(1);
     return rc;
 }

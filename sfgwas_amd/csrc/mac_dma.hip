@@ -1,0 +1,265 @@
+// mac_dma.hip — LDS-DMA form of the lazy-MAC batched modular GEMM (see mac.hip for the algebra and the
+// reference lines it replaces: gwas/matmult.go:247-399).
+//
+// What changed relative to mac.hip's register-staged kernel: both operands now reach the CU through
+// `global_load_lds_dwordx4` (async global -> LDS, no VGPR destination) into a ring of chunk slots, so the only
+// per-thread state is the accumulator tile.  A chunk = 4 k-steps of (32 rot rows + 24 pt columns) x 16
+// coefficients; up to 3 chunks are in flight per workgroup behind a counted `s_waitcnt vmcnt(N)` and ONE raw
+// `s_barrier` per chunk (a __syncthreads() would drain the DMA queue).  The rotation cache is handed over already
+// converted to fp64 (small moduli: one double per word; the 46-bit modulus: {low 23 bits, high bits} pairs), so
+// a staged word is an FMA operand without any per-use conversion.
+//
+// Workgroup = 512 threads = 8 waves: wave = (row group rh < 4, column wave wc < 2); lane = (column group cg < 4,
+// coefficient cc < 16); thread tile = 8 rows x 3 columns x 3 fp64 limb accumulators (144 VGPRs).
+#include "common.hpp"
+#include "kernels.hpp"
+
+constexpr int DM_CL = 16, DM_CT = 3, DM_CG = 4, DM_WC = 2, DM_RG = 4, DM_RH = 8;
+constexpr int DM_ROWS = DM_RG * DM_RH;                 // 32 rows per pass
+constexpr int DM_COLS = DM_CG * DM_CT * DM_WC;         // 24 columns per workgroup
+constexpr int DM_KC = 4;
+constexpr int DM_THREADS = 512;
+
+struct DmaArgs {
+    const double *rotf;          // fp64 rotation cache, see k_rot_to_f64
+    const u64 *pt; u64 *out;
+    const u64 *zeros;            // >= 128 B of zeros: plaintext source of the padded k-steps of the last chunk
+    size_t rotf_k_stride, rotf_r_stride;     // doubles
+    size_t pt_k_stride, pt_n_stride;         // words
+    size_t out_n_stride, out_r_stride;       // words
+    int K, R, Ncols, L, accumulate, r0, l0, nl, flush, ntile;
+    int plane0;                  // fp64 plane index of modulus l0 inside a rotf row
+};
+
+// one 16-byte-per-lane LDS-DMA; lds_base must be wave-uniform (it goes to M0)
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
+template <bool BIG>
+__global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModConst *modc) {
+    constexpr int RW = BIG ? 2 : 1;                                  // doubles per rot word
+    constexpr int R_BYTES = DM_KC * DM_ROWS * DM_CL * 8 * RW;        // 16 KiB / 32 KiB
+    constexpr int P_BYTES = DM_KC * DM_COLS * DM_CL * 8;             // 12 KiB
+    constexpr int R_JOBS = R_BYTES / 1024, P_JOBS = P_BYTES / 1024;  // 1 KiB per wave-instruction
+    constexpr int JOBS = R_JOBS + P_JOBS;                            // 28 / 44
+    constexpr int A = (JOBS + 7) / 8;                                // DMA instructions per wave per chunk: 4 / 6
+    constexpr int SLOT = A * 8 * 1024;                               // slot incl. dummy jobs: 32 / 48 KiB
+    constexpr int DEPTH = BIG ? 3 : 4;                               // ring slots: 144 / 128 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int N = SFG_N, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cc = lane & 15, cg = lane >> 4, rh = wave & 3, wc = wave >> 2;
+    const int b = blockIdx.x, grp = b / (8 * a.ntile), rem = b % (8 * a.ntile);
+    const int slab = grp * 8 + (rem & 7), tile = rem >> 3;
+    const int nslab = (N / DM_CL) * a.nl;
+    if (slab >= nslab) return;
+    const int li = slab / (N / DM_CL), l = a.l0 + li, c0 = (slab % (N / DM_CL)) * DM_CL;
+    const double q = modc[l].q, qinv = modc[l].qinv;
+    const int n0 = tile * DM_COLS + (wc * DM_CG + cg) * DM_CT;
+    const int nchunk = (a.K + DM_KC - 1) / DM_KC;
+
+    // ---- DMA source addressing.  Job j of a chunk moves 8 (k, row|col) pairs x 128 B; lane = (pair & 7, 16-B piece)
+    const int pair_in_job = lane >> 3, piece = lane & 7;
+    const double *rot_src = a.rotf + (size_t)a.r0 * a.rotf_r_stride + (size_t)(a.plane0 + li * RW) * N + (size_t)(c0 + piece * 2) * 1;
+    // BIG rows are stored {lo,hi} interleaved per coefficient: 16 B = one coefficient, 128 B = 8 coefficients -> two jobs per 16 c
+    auto issue_chunk = [&](int ch) {
+        unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
+#pragma unroll
+        for (int t = 0; t < A; t++) {
+            const int job = wave * A + t;                                  // wave-uniform
+            unsigned char *dst = slot + job * 1024;
+            const void *src;
+            if (job < R_JOBS) {
+                int pr, cpart = 0;
+                if (BIG) { pr = job * 4 + (pair_in_job >> 1); cpart = pair_in_job & 1; }   // 256 B per (k,row): 2 halves of 8 coefficients
+                else pr = job * 8 + pair_in_job;
+                const int kk = pr / DM_ROWS, r = pr % DM_ROWS;
+                int k = ch * DM_KC + kk; k = k < a.K ? k : a.K - 1;
+                int row = a.r0 + r < a.R ? r : a.R - 1 - a.r0;
+                if (BIG) src = a.rotf + (size_t)k * a.rotf_k_stride + (size_t)(a.r0 + row) * a.rotf_r_stride + (size_t)(a.plane0 + li * 2) * N + (size_t)(c0 + cpart * 8 + piece) * 2;
+                else src = rot_src + (size_t)k * a.rotf_k_stride + (size_t)row * a.rotf_r_stride;
+            } else if (job < JOBS) {
+                const int pr = (job - R_JOBS) * 8 + pair_in_job;
+                const int kk = pr / DM_COLS, col = pr % DM_COLS;
+                const int k = ch * DM_KC + kk;
+                int n = tile * DM_COLS + col; n = n < a.Ncols ? n : a.Ncols - 1;
+                src = k < a.K ? (const void *)(a.pt + (size_t)k * a.pt_k_stride + (size_t)n * a.pt_n_stride + (size_t)l * N + c0 + piece * 2)
+                              : (const void *)(a.zeros + piece * 2);        // k >= K contributes nothing
+            } else {
+                src = a.zeros + piece * 2;                                 // dummy job: keeps the per-wave DMA count uniform
+            }
+            dma16(src, dst);
+        }
+    };
+
+    double acc[DM_RH][DM_CT][3];
+#pragma unroll
+    for (int r = 0; r < DM_RH; r++)
+#pragma unroll
+        for (int t = 0; t < DM_CT; t++) acc[r][t][0] = acc[r][t][1] = acc[r][t][2] = 0.0;
+
+    // prologue: DEPTH-1 chunks in flight
+#pragma unroll
+    for (int ch = 0; ch < DEPTH - 1; ch++) if (ch < nchunk) issue_chunk(ch);
+
+    int since_flush = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < nchunk; ch++) {
+        // chunk ch has landed once at most `ahead` younger chunks of this wave are still outstanding
+        const int ahead = (nchunk - 1 - ch) < (DEPTH - 2) ? (nchunk - 1 - ch) : (DEPTH - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's pieces of chunk ch are in LDS; everyone is done with chunk ch-1
+        if (ch + DEPTH - 1 < nchunk) issue_chunk(ch + DEPTH - 1);      // refill the slot chunk ch-1 just vacated
+        const unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
+        const double *rbase = reinterpret_cast<const double *>(slot);
+        const u64 *pbase = reinterpret_cast<const u64 *>(slot + R_BYTES);
+#pragma unroll 2
+        for (int kk = 0; kk < DM_KC; kk++) {
+            double p0[DM_CT], p1[DM_CT], p2[DM_CT];
+#pragma unroll
+            for (int t = 0; t < DM_CT; t++) {
+                const int colw = (wc * DM_CG + cg) * DM_CT + t;
+                const u64 p = pbase[(size_t)(kk * DM_COLS + colw) * DM_CL + cc];
+                if (BIG) { p0[t] = (double)(unsigned)(p & 0x7FFFFFu); p1[t] = u64_to_f64(p >> 23); p2[t] = 0.0; }
+                else {
+                    const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
+                    p0[t] = (double)(plo & 0xFFFu); p1[t] = (double)((plo >> 12) & 0xFFFu); p2[t] = (double)((plo >> 24) | (phi << 8));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < DM_RH; r++) {
+                const int row = rh * DM_RH + r;
+                if (BIG) {
+                    const double2 rv = *reinterpret_cast<const double2 *>(rbase + ((size_t)(kk * DM_ROWS + row) * DM_CL + cc) * 2);
+#pragma unroll
+                    for (int t = 0; t < DM_CT; t++) {
+                        acc[r][t][0] = __builtin_fma(rv.x, p0[t], acc[r][t][0]);
+                        acc[r][t][1] = __builtin_fma(rv.x, p1[t], acc[r][t][1]);
+                        acc[r][t][1] = __builtin_fma(rv.y, p0[t], acc[r][t][1]);
+                        acc[r][t][2] = __builtin_fma(rv.y, p1[t], acc[r][t][2]);
+                    }
+                } else {
+                    const double x = rbase[(size_t)(kk * DM_ROWS + row) * DM_CL + cc];
+#pragma unroll
+                    for (int t = 0; t < DM_CT; t++) {
+                        acc[r][t][0] = __builtin_fma(x, p0[t], acc[r][t][0]);
+                        acc[r][t][1] = __builtin_fma(x, p1[t], acc[r][t][1]);
+                        acc[r][t][2] = __builtin_fma(x, p2[t], acc[r][t][2]);
+                    }
+                }
+            }
+        }
+        since_flush += DM_KC;
+        if (since_flush >= a.flush) {
+            since_flush = 0;
+#pragma unroll
+            for (int r = 0; r < DM_RH; r++)
+#pragma unroll
+                for (int t = 0; t < DM_CT; t++) {
+                    acc[r][t][0] = pred(acc[r][t][0], q, qinv); acc[r][t][1] = pred(acc[r][t][1], q, qinv); acc[r][t][2] = pred(acc[r][t][2], q, qinv);
+                }
+        }
+    }
+    constexpr double S1 = BIG ? 8388608.0 : 4096.0;
+    const double s1 = S1, s1q = S1 / q;
+    const double s2 = canon(S1 * S1, q, qinv), s2q = s2 / q;
+#pragma unroll
+    for (int t = 0; t < DM_CT; t++) {
+        const int n = n0 + t;
+        if (n >= a.Ncols) continue;
+#pragma unroll
+        for (int r = 0; r < DM_RH; r++) {
+            const int row = a.r0 + rh * DM_RH + r;
+            if (row < a.R) {
+                double x = pred(acc[r][t][0], q, qinv);
+                x += mulmod_lazy(pred(acc[r][t][1], q, qinv), s1, s1q, q);
+                x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
+                u64 *o = a.out + (size_t)n * a.out_n_stride + (size_t)row * a.out_r_stride + (size_t)l * N + c0 + cc;
+                if (a.accumulate) x += u64_to_f64(*o);
+                *o = f64_to_u64(canon(x, q, qinv));
+            }
+        }
+    }
+}
+
+// rotation cache -> fp64 operand form.  in: [nct][2][nl][N] u64 ciphertext rows; out row (ct, poly) holds the
+// planes of moduli 0..L-1: a "big" modulus (>= 2^36) takes 2N doubles {low 23 bits, high bits} interleaved per
+// coefficient, a small one N doubles.
+__global__ void __launch_bounds__(256) k_rot_to_f64(const u64 *in, double *out, int nl, int L, size_t out_row_stride, const int *plane_of, const int *is_big) {
+    const int N = SFG_N; const size_t rowl = blockIdx.x / (N / 256);         // over [ct*2][L]
+    const size_t ctp = rowl / L; const int l = (int)(rowl % L);
+    const size_t x = (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    const u64 w = in[(ctp * nl + l) * N + x];
+    double *o = out + ctp * out_row_stride + (size_t)plane_of[l] * N;
+    if (is_big[l]) { o[2 * x] = (double)(unsigned)(w & 0x7FFFFFu); o[2 * x + 1] = u64_to_f64(w >> 23); }
+    else o[x] = u64_to_f64(w);
+}
+
+static bool g_dma_attr = false;
+
+int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<int> &is_big) {
+    plane_of.assign(L, 0); is_big.assign(L, 0); int nplanes = 0;
+    for (int l = 0; l < L; l++) {
+        if (ctx->q[l] >= (1ULL << 47)) { ctx->err = "sfg_mac: modulus >= 2^47 unsupported by the fp64 limb schedule"; return -1; }
+        is_big[l] = ctx->q[l] >= (1ULL << 36); plane_of[l] = nplanes; nplanes += is_big[l] ? 2 : 1;
+    }
+    return nplanes;
+}
+
+// convert nrows polynomial rows [nrows][nl_rot][N] (ciphertexts are two consecutive rows) to the fp64 operand form rotf[nrows][nplanes*N]
+int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, int L, double *rotf) {
+    const int N = SFG_N;
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) return 1;
+    int *d_tab = nullptr;
+    SFG_HIP(ctx, hipMalloc(&d_tab, 2 * L * sizeof(int)));
+    SFG_HIP(ctx, hipMemcpy(d_tab, plane_of.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    SFG_HIP(ctx, hipMemcpy(d_tab + L, is_big.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rot_to_f64, dim3((unsigned)(nrows * L * (N / 256))), dim3(256), 0, ctx->stream, rot, rotf, nl_rot, L, (size_t)nplanes * N, d_tab, d_tab + L);
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFG_HIP(ctx, hipFree(d_tab));
+    return 0;
+}
+
+// rotf: fp64 rotation cache with row stride nplanes*N doubles; rows_per_k = rows (ct, poly) between consecutive k.
+int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate,
+                   const MacStrides &st) {
+    const int N = SFG_N;
+    if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
+    if (!g_dma_attr) {
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 1024));
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 48 * 1024));
+        g_dma_attr = true;
+    }
+    if (!ctx->zeros_dev) { SFG_HIP(ctx, hipMalloc(&ctx->zeros_dev, 256)); SFG_HIP(ctx, hipMemset(ctx->zeros_dev, 0, 256)); }
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) return 1;
+    const size_t rowf = (size_t)nplanes * N;
+    for (int r0 = 0; r0 < R; r0 += DM_ROWS) {
+        int l = 0;
+        while (l < L) {
+            const bool big = is_big[l]; int e = l; while (e < L && is_big[e] == (int)big) e++;
+            DmaArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev;
+            a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
+            a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
+            a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
+            double maxterm = big ? 2.0 * 16777216.0 * 16777216.0 : 0.0;
+            for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
+            int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / DM_KC) * DM_KC;
+            if (f < DM_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
+            a.flush = f; a.ntile = (Ncols + DM_COLS - 1) / DM_COLS;
+            const int nslab = (N / DM_CL) * a.nl, ngrp = (nslab + 7) / 8;
+            dim3 grid((unsigned)(ngrp * 8 * a.ntile));
+            PhaseTimer t(ctx, big ? "mac_big" : "mac_small");
+            if (big) hipLaunchKernelGGL(k_mac_dma<true>, grid, dim3(DM_THREADS), 3 * 48 * 1024, ctx->stream, a, ctx->modc);
+            else hipLaunchKernelGGL(k_mac_dma<false>, grid, dim3(DM_THREADS), 4 * 32 * 1024, ctx->stream, a, ctx->modc);
+            SFG_HIP(ctx, hipGetLastError());
+            t.stop(1);
+            l = e;
+        }
+    }
+    return 0;
+}

@@ -141,6 +141,14 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     auto cleanup = [&]() { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(a_row); (void)hipFree(rotc); (void)hipFree(pt); };
     int8_t *skew = nullptr;
     if (hipMalloc(&skew, (size_t)SFG_SLOTS * SFG_SLOTS) != hipSuccess) { cleanup(); SFG_FAIL(ctx, "matmul: out of device memory (skew)"); }
+    // fp64 operand form of the rotation cache for the LDS-DMA MAC kernel
+    double *rotf = nullptr; size_t rowf = 0;
+    if (mac_use_dma()) {
+        std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+        if (nplanes < 0) { cleanup(); (void)hipFree(skew); return 1; }
+        rowf = (size_t)nplanes * N;
+        if (hipMalloc(&rotf, (size_t)d * s * 2 * rowf * 8) != hipSuccess) { cleanup(); (void)hipFree(skew); SFG_FAIL(ctx, "matmul: out of device memory (rotf)"); }
+    }
     int rc = 0;
     std::vector<int> nrot((size_t)d * s);
     for (int bi = b0; bi < b1 && !rc; bi++) {
@@ -169,6 +177,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             t.stop(1);
         }
         if (rc) break;
+        if (rotf) { rc = launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf); if (rc) break; }
         for (int bj = j0; bj < j1 && !rc; bj++) {
             const int nc = sh.cols_of(bj);
             {
@@ -196,12 +205,13 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
                 st.pt_k = (size_t)L * N; st.pt_n = (size_t)d * L * N;           // pt[giant*d + baby]
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
-                rc = launch_mac_strided(ctx, rotc, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
+                if (rotf) rc = launch_mac_dma(ctx, rotf, (size_t)s * 2, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
+                else rc = launch_mac_strided(ctx, rotc, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
                 t.stop(1);
             }
         }
     }
-    cleanup(); (void)hipFree(skew);
+    cleanup(); (void)hipFree(skew); (void)hipFree(rotf);
     return rc;
 }
 
