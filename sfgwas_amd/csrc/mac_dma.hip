@@ -58,37 +58,46 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
     const int n0 = tile * DM_COLS + (wc * DM_CG + cg) * DM_CT;
     const int nchunk = (a.K + DM_KC - 1) / DM_KC;
 
-    // ---- DMA source addressing.  Job j of a chunk moves 8 (k, row|col) pairs x 128 B; lane = (pair & 7, 16-B piece)
+    // ---- DMA source addressing.  Job j of a chunk moves 8 (k, row|col) pairs x 128 B; lane = (pair & 7, 16-B piece).
+    // A wave always issues the same A jobs, so each lane's source pointer for chunk 0 is computed once and then only
+    // advanced by a constant per chunk; only the ragged last chunk (K % 4 != 0) recomputes with k clamped / zeroed.
     const int pair_in_job = lane >> 3, piece = lane & 7;
-    const double *rot_src = a.rotf + (size_t)a.r0 * a.rotf_r_stride + (size_t)(a.plane0 + li * RW) * N + (size_t)(c0 + piece * 2) * 1;
-    // BIG rows are stored {lo,hi} interleaved per coefficient: 16 B = one coefficient, 128 B = 8 coefficients -> two jobs per 16 c
+    const unsigned char *src0[A]; size_t step[A]; int kk_of[A]; int kind[A];   // kind: 0 = rot, 1 = pt, 2 = dummy
+#pragma unroll
+    for (int t = 0; t < A; t++) {
+        const int job = wave * A + t;
+        if (job < R_JOBS) {
+            int pr, cpart = 0;
+            if (BIG) { pr = job * 4 + (pair_in_job >> 1); cpart = pair_in_job & 1; }   // 256 B per (k,row): 2 halves of 8 coefficients
+            else pr = job * 8 + pair_in_job;
+            const int kk = pr / DM_ROWS, r = pr % DM_ROWS;
+            const int row = a.r0 + r < a.R ? a.r0 + r : a.R - 1;
+            const double *ptr = a.rotf + (size_t)kk * a.rotf_k_stride + (size_t)row * a.rotf_r_stride + (size_t)(a.plane0 + li * RW) * N
+                                + (BIG ? (size_t)(c0 + cpart * 8 + piece) * 2 : (size_t)(c0 + piece * 2));
+            src0[t] = (const unsigned char *)ptr; step[t] = (size_t)DM_KC * a.rotf_k_stride * 8; kk_of[t] = kk; kind[t] = 0;
+        } else if (job < JOBS) {
+            const int pr = (job - R_JOBS) * 8 + pair_in_job;
+            const int kk = pr / DM_COLS, col = pr % DM_COLS;
+            int n = tile * DM_COLS + col; n = n < a.Ncols ? n : a.Ncols - 1;
+            const u64 *ptr = a.pt + (size_t)kk * a.pt_k_stride + (size_t)n * a.pt_n_stride + (size_t)l * N + c0 + piece * 2;
+            src0[t] = (const unsigned char *)ptr; step[t] = (size_t)DM_KC * a.pt_k_stride * 8; kk_of[t] = kk; kind[t] = 1;
+        } else {
+            src0[t] = (const unsigned char *)(a.zeros + piece * 2); step[t] = 0; kk_of[t] = 0; kind[t] = 2;
+        }
+    }
+    const unsigned char *zsrc = (const unsigned char *)(a.zeros + piece * 2);
+    const int nchunk_full = a.K / DM_KC;                              // chunks whose 4 k-steps all exist
     auto issue_chunk = [&](int ch) {
         unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
+        const bool ragged = ch >= nchunk_full;                        // wave-uniform
 #pragma unroll
         for (int t = 0; t < A; t++) {
-            const int job = wave * A + t;                                  // wave-uniform
-            unsigned char *dst = slot + job * 1024;
-            const void *src;
-            if (job < R_JOBS) {
-                int pr, cpart = 0;
-                if (BIG) { pr = job * 4 + (pair_in_job >> 1); cpart = pair_in_job & 1; }   // 256 B per (k,row): 2 halves of 8 coefficients
-                else pr = job * 8 + pair_in_job;
-                const int kk = pr / DM_ROWS, r = pr % DM_ROWS;
-                int k = ch * DM_KC + kk; k = k < a.K ? k : a.K - 1;
-                int row = a.r0 + r < a.R ? r : a.R - 1 - a.r0;
-                if (BIG) src = a.rotf + (size_t)k * a.rotf_k_stride + (size_t)(a.r0 + row) * a.rotf_r_stride + (size_t)(a.plane0 + li * 2) * N + (size_t)(c0 + cpart * 8 + piece) * 2;
-                else src = rot_src + (size_t)k * a.rotf_k_stride + (size_t)row * a.rotf_r_stride;
-            } else if (job < JOBS) {
-                const int pr = (job - R_JOBS) * 8 + pair_in_job;
-                const int kk = pr / DM_COLS, col = pr % DM_COLS;
-                const int k = ch * DM_KC + kk;
-                int n = tile * DM_COLS + col; n = n < a.Ncols ? n : a.Ncols - 1;
-                src = k < a.K ? (const void *)(a.pt + (size_t)k * a.pt_k_stride + (size_t)n * a.pt_n_stride + (size_t)l * N + c0 + piece * 2)
-                              : (const void *)(a.zeros + piece * 2);        // k >= K contributes nothing
-            } else {
-                src = a.zeros + piece * 2;                                 // dummy job: keeps the per-wave DMA count uniform
+            const unsigned char *src = src0[t] + (size_t)ch * step[t];
+            if (ragged && kind[t] != 2) {
+                const int k = ch * DM_KC + kk_of[t];
+                if (k >= a.K) src = kind[t] == 1 ? zsrc : src0[t] - (size_t)kk_of[t] * a.rotf_k_stride * 8;   // padded k-step: zero plaintext; rot row of k = 0
             }
-            dma16(src, dst);
+            dma16(src, slot + (wave * A + t) * 1024);
         }
     };
 
@@ -245,6 +254,9 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             DmaArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev;
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
+            if (getenv("SFG_MAC_DEBUG_CONTIG")) {   // timing experiment only (wrong results): pretend both operands are stored blocked
+                a.pt_n_stride = 16; a.pt_k_stride = (size_t)Ncols * 16; a.rotf_r_stride = 16 * (big ? 2 : 1); a.rotf_k_stride = (size_t)rows_per_k * a.rotf_r_stride;
+            }
             a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
             double maxterm = big ? 2.0 * 16777216.0 * 16777216.0 : 0.0;
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
