@@ -71,8 +71,8 @@ def main():
     n_ind, m_snp = CONFIGS[args.config]
     nbr_x, mct_x = ceil_div(n_ind, SLOTS), ceil_div(m_snp, SLOTS)          # block rows / cols of X
     # SNP-block shard of this rank
-    blk0, blk1 = (mct_x * rank) // world, (mct_x * (rank + 1)) // world
-    c0, c1 = blk0 * SLOTS, min(blk1 * SLOTS, m_snp)
+    from sfgwas_amd.sharding import snp_block_range, giant_range
+    blk0, blk1, c0, c1 = snp_block_range(m_snp, rank, world)
     m_loc, nblk_loc = c1 - c0, blk1 - blk0
 
     ctx = capi.Context(ol.Q_PN14, ol.P_PN14, device=local_rank)
@@ -124,7 +124,7 @@ def main():
         if world > 1:
             dist.all_reduce(acc2)                                           # < 8 * 2^46: no uint64 overflow
             chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(acc2.data_ptr()), nbr_x * D * KP * 2, L), "reduce acc")
-        g0, g1 = (D * rank) // world, (D * (rank + 1)) // world
+        g0, g1 = giant_range(rank, world)
         chk(lib.sfg_matmul_finalize_dev(ctx.h, C.c_void_p(acc2.data_ptr()), KP, L, nbr_x, g0, g1, 0, C.c_void_p(out2.data_ptr())), "finalize")
         if world > 1:
             dist.all_reduce(out2)
@@ -173,7 +173,7 @@ def main():
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "k_mac<false,8>", "avg_launch_ms": avg_ms, "launches": n_small,
+                               "kernel": "k_mac_dma<false>", "avg_launch_ms": avg_ms, "launches": n_small,
                                "alg_bytes_per_launch": per_launch,
                                "macs_per_s_in_kernel": D * D * 2 * KP * nl_small * N / (avg_ms * 1e-3)}
         res["phases_ms_per_step"] = {k: v[0] / args.steps for k, v in phase_tot.items()}

@@ -543,11 +543,15 @@ void orc_fill_uniform(const orc_ring *r, int level, u64 seed, u64 *ct) {
 }
 
 /* ------------------------------------------------------------------ MatMult4Stream (matmult.go:1238-1505) */
-int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
-                       const u64 *A, int s, int in_level, int max_level,
-                       const int8_t *geno_in, size_t nrow, size_t ncol,
-                       int compute_sqsum, int square, int enc_prec,
-                       u64 *out, double *sum, double *sqsum) {
+/* Phase 1 (matmult.go:1280-1439 + the REDC half of :1472): for operand block rows [b0,b1), build the rotation cache,
+ * encode every existing diagonal, accumulate lazily in u128 exactly as the reference, then ModularReduceV2 each
+ * accumulator to canonical residues.  acc_out: [m_ct][d][s][2][L][N] (zero where the giant step never became active),
+ * giant_active[d] (may be NULL).  Canonical partial accumulators of disjoint block-row ranges add up (mod q) to the
+ * accumulator of the union — that is the contract the multi-GPU contraction sharding relies on. */
+int orc_matmult_accumulate(const orc_ring *r, const orc_rotkeys *keys, double scale,
+                           const u64 *A, int s, int in_level, int max_level,
+                           const int8_t *geno_in, size_t nrow, size_t ncol, int square, int enc_prec,
+                           int b0, int b1, u64 *acc_out, uint8_t *giant_active) {
     int N = r->N, slots = N / 2;
     int d = (int)ceil(sqrt((double)slots));                                   /* :1249 */
     int m_ct = (int)((ncol - 1) / slots) + 1, nbr = (int)((nrow - 1) / slots) + 1; /* :1253-1254 */
@@ -556,17 +560,12 @@ int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
     int nl_in = in_level + 1, nl = lev + 1;
     size_t ctw_in = (size_t)2 * nl_in * N, ctw = (size_t)2 * nl * N, outw = (size_t)2 * L * N;
     int rc = 0;
+    if (nl < L || b0 < 0 || b1 > nbr || b0 > b1) return -2;
 
-    /* working copy of genotypes: missing -> 0, sums, optional squaring (:1291-1304) */
+    /* working copy of genotypes: missing -> 0, optional squaring (:1291-1304) */
     int8_t *geno = malloc(nrow * ncol);
     memcpy(geno, geno_in, nrow * ncol);
-    if (compute_sqsum) { memset(sum, 0, 8 * ncol); memset(sqsum, 0, 8 * ncol); }
-    for (size_t i = 0; i < nrow; i++) for (size_t j = 0; j < ncol; j++) {
-        int8_t *x = &geno[i * ncol + j];
-        if (*x < 0) *x = 0;
-        if (compute_sqsum) { sqsum[j] += (double)(int8_t)(*x * *x); sum[j] += (double)*x; }
-        if (square) *x = (int8_t)(*x * *x);
-    }
+    for (size_t i = 0; i < nrow * ncol; i++) { if (geno[i] < 0) geno[i] = 0; if (square) geno[i] = (int8_t)(geno[i] * geno[i]); }
 
     u64 ***acc = calloc(s, sizeof *acc);              /* accCache[i][giant] -> m_ct*2*L*N {hi,lo} */
     for (int i = 0; i < s; i++) acc[i] = calloc(d, sizeof **acc);
@@ -576,7 +575,7 @@ int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
     uint8_t *baby_t = malloc(d), *giant_t = malloc(d), *shift_t = malloc(slots);
     u64 qinv[ORC_MAXMOD]; for (int l = 0; l < L; l++) qinv[l] = orc_mred_params(r->q[l]);
 
-    for (int bi = 0; bi < nbr && !rc; bi++) {
+    for (int bi = b0; bi < b1 && !rc; bi++) {
         int nr = (int)(((size_t)(bi + 1) * slots < nrow ? (size_t)(bi + 1) * slots : nrow) - (size_t)bi * slots);
         memset(baby_t, 0, d); memset(giant_t, 0, d); memset(shift_t, 0, slots);
         for (int shift = 0; shift < slots; shift++) {           /* :1329-1336 */
@@ -618,33 +617,72 @@ int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
             }
         }
     }
-    /* post-processing (:1443-1502): ModularReduceV2, giant alignment, aggregation */
+    /* ModularReduceV2 (:343-366): REDC each u128 accumulator, then eval.Reduce -> canonical residues */
     if (!rc) {
-        memset(out, 0, 8 * (size_t)s * m_ct * outw);
-        u64 *cv = malloc(8 * outw), *cvr = malloc(8 * outw);
-        for (int i = 0; i < s && !rc; i++) for (int g = 0; g < d && !rc; g++) if (acc[i][g]) {
+        memset(acc_out, 0, 8 * (size_t)m_ct * d * s * outw);
+        if (giant_active) memset(giant_active, 0, d);
+        for (int i = 0; i < s; i++) for (int g = 0; g < d; g++) if (acc[i][g]) {
+            if (giant_active) giant_active[g] = 1;
             for (int bj = 0; bj < m_ct; bj++) {
-                memset(cv, 0, 8 * outw);
                 const u64 *a = acc[i][g] + (size_t)bj * outw * 2;
+                u64 *o = acc_out + (((size_t)bj * d + g) * s + i) * outw;
                 for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* matmult.go:351-359 */
-                    u64 *o = cv + ((size_t)p * L + l) * N;
-                    orc_reduce_and_add_uint128(a + (((size_t)p * L + l) * N) * 2, o, qinv[l], r->q[l], N);
-                    orc_canonical_reduce(o, N, r->q[l]);
-                }
-                const u64 *src = cv;
-                if (g > 0) { if (orc_rotate_right(r, keys, L - 1, cv, -g * d, cvr)) { rc = -1; break; } src = cvr; } /* :1474-1478 */
-                u64 *o = out + ((size_t)i * m_ct + bj) * outw;
-                for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* eva.Add :1494 */
-                    u64 q = r->q[l]; size_t off = ((size_t)p * L + l) * N;
-                    for (int x = 0; x < N; x++) { u64 v = o[off + x] + src[off + x]; if (v >= q) v -= q; o[off + x] = v; }
+                    u64 *row = o + ((size_t)p * L + l) * N;
+                    orc_reduce_and_add_uint128(a + (((size_t)p * L + l) * N) * 2, row, qinv[l], r->q[l], N);
+                    orc_canonical_reduce(row, N, r->q[l]);
                 }
             }
         }
-        free(cv); free(cvr);
     }
     for (int i = 0; i < s; i++) { for (int g = 0; g < d; g++) free(acc[i][g]); free(acc[i]); }
     for (size_t k = 0; k < (size_t)s * d; k++) free(rot[k]);
     free(acc); free(rot); free(diag); free(diagr); free(pt); free(ct_lvl); free(baby_t); free(giant_t); free(shift_t); free(geno);
+    return rc;
+}
+
+/* Phase 2 (matmult.go:1443-1502): giant-step alignment RotateRight(cv, -l*d) for l > 0 and aggregation.
+ * acc: [m_ct][d][s][2][L][N] canonical; giants in [g0,g1) that are active (giant_active NULL = all) contribute;
+ * out: [s][m_ct][2][L][N], overwritten unless accumulate. */
+int orc_matmult_finalize(const orc_ring *r, const orc_rotkeys *keys, int max_level, int s, int m_ct,
+                         const u64 *acc, const uint8_t *giant_active, int g0, int g1, int accumulate, u64 *out) {
+    int N = r->N, slots = N / 2, L = max_level, d = (int)ceil(sqrt((double)slots));
+    size_t outw = (size_t)2 * L * N; int rc = 0;
+    if (!accumulate) memset(out, 0, 8 * (size_t)s * m_ct * outw);
+    u64 *cvr = malloc(8 * outw);
+    for (int i = 0; i < s && !rc; i++) for (int g = g0; g < g1 && !rc; g++) if (!giant_active || giant_active[g]) {
+        for (int bj = 0; bj < m_ct; bj++) {
+            const u64 *cv = acc + (((size_t)bj * d + g) * s + i) * outw;
+            const u64 *src = cv;
+            if (g > 0) { if (orc_rotate_right(r, keys, L - 1, cv, -g * d, cvr)) { rc = -1; break; } src = cvr; } /* :1474-1478 */
+            u64 *o = out + ((size_t)i * m_ct + bj) * outw;
+            for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* eva.Add :1494 */
+                u64 q = r->q[l]; size_t off = ((size_t)p * L + l) * N;
+                for (int x = 0; x < N; x++) { u64 v = o[off + x] + src[off + x]; if (v >= q) v -= q; o[off + x] = v; }
+            }
+        }
+    }
+    free(cvr);
+    return rc;
+}
+
+int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
+                       const u64 *A, int s, int in_level, int max_level,
+                       const int8_t *geno_in, size_t nrow, size_t ncol,
+                       int compute_sqsum, int square, int enc_prec,
+                       u64 *out, double *sum, double *sqsum) {
+    int N = r->N, slots = N / 2, d = (int)ceil(sqrt((double)slots));
+    int m_ct = (int)((ncol - 1) / slots) + 1, nbr = (int)((nrow - 1) / slots) + 1, L = max_level;
+    if (compute_sqsum) {                                  /* sums before squaring, after missing -> 0 (:1292-1300) */
+        memset(sum, 0, 8 * ncol); memset(sqsum, 0, 8 * ncol);
+        for (size_t i = 0; i < nrow; i++) for (size_t j = 0; j < ncol; j++) {
+            int8_t x = geno_in[i * ncol + j]; if (x < 0) x = 0;
+            sqsum[j] += (double)(int8_t)(x * x); sum[j] += (double)x;
+        }
+    }
+    u64 *acc = malloc(8 * (size_t)m_ct * d * s * 2 * L * N); uint8_t *ga = malloc(d);
+    int rc = orc_matmult_accumulate(r, keys, scale, A, s, in_level, max_level, geno_in, nrow, ncol, square, enc_prec, 0, nbr, acc, ga);
+    if (!rc) rc = orc_matmult_finalize(r, keys, max_level, s, m_ct, acc, ga, 0, d, 0, out);
+    free(acc); free(ga);
     return rc;
 }
 

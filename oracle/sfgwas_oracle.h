@@ -109,6 +109,13 @@ int orc_matmult4stream(const orc_ring *r, const orc_rotkeys *keys, double scale,
                        int compute_sqsum, int square, int enc_prec,
                        uint64_t *out, double *sum, double *sqsum);
 
+/* the same product in two phases (what a contraction-sharded multi-GPU run combines between the phases) */
+int orc_matmult_accumulate(const orc_ring *r, const orc_rotkeys *keys, double scale, const uint64_t *A, int s, int in_level, int max_level,
+                           const int8_t *geno, size_t nrow, size_t ncol, int square, int enc_prec, int b0, int b1,
+                           uint64_t *acc_out /*[m_ct][d][s][2][L][N]*/, uint8_t *giant_active /*[d] or NULL*/);
+int orc_matmult_finalize(const orc_ring *r, const orc_rotkeys *keys, int max_level, int s, int m_ct, const uint64_t *acc,
+                         const uint8_t *giant_active, int g0, int g1, int accumulate, uint64_t *out);
+
 /* MAC-only inner loop for cpu_baseline timing: reference loop order, u128 accumulators.
  * rot: [s][2][L][N] rotated ct (one baby), pt: [L][N] Montgomery-form plaintext, acc: [s][2][L][N]{hi,lo} */
 void orc_cpmult_acc_v2(const uint64_t *rot, const uint64_t *pt_mont, uint64_t *acc_hilo, int s, int L, int N);

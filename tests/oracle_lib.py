@@ -76,6 +76,11 @@ def lib():
                                          C.POINTER(C.c_int8), C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                          u64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_cpmult_acc_v2.argtypes = [u64p, u64p, u64p, C.c_int, C.c_int, C.c_int]
+        L.orc_matmult_accumulate.restype = C.c_int
+        L.orc_matmult_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_double, u64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int8), C.c_size_t, C.c_size_t,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_uint8)]
+        L.orc_matmult_finalize.restype = C.c_int
+        L.orc_matmult_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, u64p]
         L.orc_bench_mac.restype = C.c_double
         L.orc_bench_mac.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong)]
         L.orc_diagcache_create.restype = C.c_void_p
