@@ -45,8 +45,10 @@ struct sfg_ctx {
     u64 q[SFG_MAXMOD] = {0}, psi[SFG_MAXMOD] = {0};
     hipStream_t own_stream = nullptr, stream = nullptr;
     // device tables
-    double2 *tw_fwd = nullptr;   // [nmod][N] {w, w/q}, index m+i as in the CT loop (psi^bitrev)
-    double2 *tw_inv = nullptr;   // [nmod][N] {w, w/q} for psi^-bitrev
+    double *tw_fwd = nullptr;    // [nmod][N] w, index m+i as in the CT loop (psi^bitrev)
+    double *tw_inv = nullptr;    // [nmod][N] w for psi^-bitrev
+    double2 *pack_fwd = nullptr; // [nmod][256][8][64] late-stage (t <= 8) twiddles packed for coalesced per-wave loads
+    double2 *pack_inv = nullptr;
     ModConst *modc = nullptr;    // [nmod]
     ModConst modc_host[SFG_MAXMOD];
     // encoder tables (double-double twiddles), see encode.hip

@@ -34,7 +34,7 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     ctx->stream = ctx->own_stream;
     const int N = SFG_N;
-    std::vector<double2> twf((size_t)ctx->nmod * N), twi((size_t)ctx->nmod * N);
+    std::vector<double> twf((size_t)ctx->nmod * N), twi((size_t)ctx->nmod * N);
     for (int m = 0; m < ctx->nmod; m++) {
         u64 q = moduli[m];
         if (q >= (1ULL << 50) || (q - 1) % (2ULL * N)) return fail("modulus must be < 2^50 and == 1 mod 2N");
@@ -44,8 +44,8 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
         u64 psi_inv = h_invmod(ctx->psi[m], q), p = 1, pi = 1;
         for (int k = 0; k < N; k++) {
             uint32_t b = h_brev((uint32_t)k, logN);
-            twf[(size_t)m * N + b] = make_double2((double)p, (double)p / (double)q);
-            twi[(size_t)m * N + b] = make_double2((double)pi, (double)pi / (double)q);
+            twf[(size_t)m * N + b] = (double)p;
+            twi[(size_t)m * N + b] = (double)pi;
             p = h_mulmod(p, ctx->psi[m], q); pi = h_mulmod(pi, psi_inv, q);
         }
         ModConst &mc = ctx->modc_host[m];
@@ -53,10 +53,31 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
         u64 ninv = h_invmod((u64)N, q);
         mc.ninv = (double)ninv; mc.ninv_q = (double)ninv / (double)q;
     }
-    if (hipMalloc(&ctx->tw_fwd, twf.size() * sizeof(double2)) != hipSuccess || hipMalloc(&ctx->tw_inv, twi.size() * sizeof(double2)) != hipSuccess ||
+    // late-stage twiddles (t = 8,4,2,1) of group p = j / 16: [T8, T4_0, T4_1, T2_0..3, T1_0..7, pad] laid out as
+    // pack[p / 64][i < 8][p % 64] = {entry 2i, entry 2i+1}, so that a wave's 8 loads are 8 contiguous KiB
+    auto build_pack = [&](const std::vector<double> &tw, std::vector<double2> &pk) {
+        pk.assign((size_t)ctx->nmod * (N / 2), make_double2(0, 0));
+        for (int m = 0; m < ctx->nmod; m++) {
+            const double *t = tw.data() + (size_t)m * N;
+            for (int p = 0; p < N / 16; p++) {
+                double e[16]; int k = 0;
+                e[k++] = t[1024 + p];
+                for (int g = 0; g < 2; g++) e[k++] = t[2048 + 2 * p + g];
+                for (int g = 0; g < 4; g++) e[k++] = t[4096 + 4 * p + g];
+                for (int g = 0; g < 8; g++) e[k++] = t[8192 + 8 * p + g];
+                e[k++] = 0.0;
+                for (int i = 0; i < 8; i++) pk[(size_t)m * (N / 2) + (size_t)(p >> 6) * 512 + (size_t)i * 64 + (p & 63)] = make_double2(e[2 * i], e[2 * i + 1]);
+            }
+        }
+    };
+    std::vector<double2> pkf, pki; build_pack(twf, pkf); build_pack(twi, pki);
+    if (hipMalloc(&ctx->tw_fwd, twf.size() * sizeof(double)) != hipSuccess || hipMalloc(&ctx->tw_inv, twi.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->pack_fwd, pkf.size() * sizeof(double2)) != hipSuccess || hipMalloc(&ctx->pack_inv, pki.size() * sizeof(double2)) != hipSuccess ||
         hipMalloc(&ctx->modc, sizeof(ModConst) * SFG_MAXMOD) != hipSuccess) return fail("hipMalloc of tables failed");
-    if (hipMemcpy(ctx->tw_fwd, twf.data(), twf.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->tw_inv, twi.data(), twi.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(ctx->tw_fwd, twf.data(), twf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->tw_inv, twi.data(), twi.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->pack_fwd, pkf.data(), pkf.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->pack_inv, pki.data(), pki.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->modc, ctx->modc_host, sizeof(ModConst) * SFG_MAXMOD, hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
     if (sfg_encoder_init(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
     *out = ctx;
@@ -70,7 +91,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     for (auto &kv : ctx->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
     sfg_encoder_destroy(ctx);
-    (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws); (void)hipFree(ctx->zeros_dev);
+    (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->pack_fwd); (void)hipFree(ctx->pack_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws); (void)hipFree(ctx->zeros_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

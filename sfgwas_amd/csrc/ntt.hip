@@ -16,31 +16,33 @@
 constexpr int LDS_ROW = 528;                 // 512 + 16 doubles: keeps (a, a+1) rows 32 banks apart
 constexpr int LDS_DOUBLES = 32 * LDS_ROW;    // 135,168 B
 
+// twiddles are stored as w only; w/q is recovered with one multiply (its rounding only moves the quotient
+// estimate of mulmod_lazy by << 1, the remainder stays exact)
 template <int LEN, int H, class TW>
-__device__ __forceinline__ void ct_stage(double (&v)[LEN], double q, TW tw) {
+__device__ __forceinline__ void ct_stage(double (&v)[LEN], double q, double qinv, TW tw) {
 #pragma unroll
     for (int g = 0; g < LEN / (2 * H); g++) {
-        double2 w = tw(g);
+        const double w = tw(g), wq = w * qinv;
 #pragma unroll
         for (int x = 0; x < H; x++) {
             const int i0 = g * 2 * H + x, i1 = i0 + H;
-            double r = mulmod_lazy(v[i1], w.x, w.y, q);
+            double r = mulmod_lazy(v[i1], w, wq, q);
             double U = v[i0];
             v[i0] = U + r; v[i1] = U - r;
         }
     }
 }
 template <int LEN, int H, class TW>
-__device__ __forceinline__ void gs_stage(double (&v)[LEN], double q, TW tw) {
+__device__ __forceinline__ void gs_stage(double (&v)[LEN], double q, double qinv, TW tw) {
 #pragma unroll
     for (int g = 0; g < LEN / (2 * H); g++) {
-        double2 w = tw(g);
+        const double w = tw(g), wq = w * qinv;
 #pragma unroll
         for (int x = 0; x < H; x++) {
             const int i0 = g * 2 * H + x, i1 = i0 + H;
             double U = v[i0], V = v[i1];
             v[i0] = U + V;
-            v[i1] = mulmod_lazy(U - V, w.x, w.y, q);
+            v[i1] = mulmod_lazy(U - V, w, wq, q);
         }
     }
 }
@@ -48,14 +50,15 @@ __device__ __forceinline__ void gs_stage(double (&v)[LEN], double q, TW tw) {
 // IN_MODE 0: rows of canonical u64; 1: half-coefficient int64 input of a real-slot plaintext
 // (pc[0..N/2): p_c, with p_{N/2} = 0 and p_{N-c} = -p_c, see encode.hip), rows = [plain][L]
 template <int IN_MODE>
-__global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, ModPattern pat, RowMap rm, const double2 *tw_all, const ModConst *modc) {
+__global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, ModPattern pat, RowMap rm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const int m = pat.m[row % pat.period];
     if (m < 0) return;                                   // row marked "leave untouched"
     const size_t grp = row / rm.rpg, gi = row % rm.rpg;
-    const double2 *tw = tw_all + (size_t)m * N;
+    const double *tw = tw_all + (size_t)m * N;
+    const double2 *pack = pack_all + (size_t)m * (N / 2);      // late-stage twiddles, see build_pack() in ctx.hip
     const double q = modc[m].q, qinv = modc[m].qinv;
     double v[32];
     // ---- phase A load: j = a*512 + tid
@@ -73,11 +76,11 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
             v[a] = x == 0 ? 0.0 : -(double)pc[N / 2 - x];
         }
     }
-    ct_stage<32, 16>(v, q, [&](int g) { return tw[1 + g]; });
-    ct_stage<32, 8>(v, q, [&](int g) { return tw[2 + g]; });
-    ct_stage<32, 4>(v, q, [&](int g) { return tw[4 + g]; });
-    ct_stage<32, 2>(v, q, [&](int g) { return tw[8 + g]; });
-    ct_stage<32, 1>(v, q, [&](int g) { return tw[16 + g]; });
+    ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[1 + g]; });
+    ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[2 + g]; });
+    ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[4 + g]; });
+    ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[8 + g]; });
+    ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[16 + g]; });
 #pragma unroll
     for (int a = 0; a < 32; a++) lds[a * LDS_ROW + tid] = v[a];
     __syncthreads();
@@ -86,11 +89,11 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
         const int a = tid >> 4, c = tid & 15;
 #pragma unroll
         for (int b = 0; b < 32; b++) v[b] = lds[a * LDS_ROW + b * 16 + c];
-        ct_stage<32, 16>(v, q, [&](int g) { return tw[32 + a + g]; });
-        ct_stage<32, 8>(v, q, [&](int g) { return tw[64 + a * 2 + g]; });
-        ct_stage<32, 4>(v, q, [&](int g) { return tw[128 + a * 4 + g]; });
-        ct_stage<32, 2>(v, q, [&](int g) { return tw[256 + a * 8 + g]; });
-        ct_stage<32, 1>(v, q, [&](int g) { return tw[512 + a * 16 + g]; });
+        ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + a + g]; });
+        ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + a * 2 + g]; });
+        ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + a * 4 + g]; });
+        ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + a * 8 + g]; });
+        ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + a * 16 + g]; });
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < 32; b++) lds[a * LDS_ROW + c * 33 + b] = v[b];
@@ -103,11 +106,18 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
         double w[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) w[c] = lds[a * LDS_ROW + c * 33 + b];
-        const int ab = a * 32 + b;
-        ct_stage<16, 8>(w, q, [&](int g) { return tw[1024 + ab + g]; });
-        ct_stage<16, 4>(w, q, [&](int g) { return tw[2048 + ab * 2 + g]; });
-        ct_stage<16, 2>(w, q, [&](int g) { return tw[4096 + ab * 4 + g]; });
-        ct_stage<16, 1>(w, q, [&](int g) { return tw[8192 + ab * 8 + g]; });
+        // the 15 twiddles of group ab = p (1 + 2 + 4 + 8) come from 8 fully coalesced 16-byte loads:
+        // pack[(p / 64)][i][lane] holds entries {2i, 2i+1} of the list [T8, T4_0, T4_1, T2_0..3, T1_0..7, pad]
+        double tl[16];
+        {
+            const double2 *pk = pack + (size_t)(p >> 6) * 512 + (p & 63);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
+        }
+        ct_stage<16, 8>(w, q, qinv, [&](int g) { return tl[0 + g]; });
+        ct_stage<16, 4>(w, q, qinv, [&](int g) { return tl[1 + g]; });
+        ct_stage<16, 2>(w, q, qinv, [&](int g) { return tl[3 + g]; });
+        ct_stage<16, 1>(w, q, qinv, [&](int g) { return tl[7 + g]; });
 #pragma unroll
         for (int c = 0; c < 16; c++) v[h * 16 + c] = w[c];
     }
@@ -127,14 +137,15 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
     }
 }
 
-__global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModPattern pat, RowMap rm, const double2 *tw_all, const ModConst *modc) {
+__global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModPattern pat, RowMap rm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const int m = pat.m[row % pat.period];
     if (m < 0) return;
     const size_t grp = row / rm.rpg, gi = row % rm.rpg;
-    const double2 *tw = tw_all + (size_t)m * N;
+    const double *tw = tw_all + (size_t)m * N;
+    const double2 *pack = pack_all + (size_t)m * (N / 2);      // late-stage twiddles, see build_pack() in ctx.hip
     const double q = modc[m].q, qinv = modc[m].qinv;
     const u64 *in = in_ + grp * rm.gstride_in + gi * N;
     double v[32];
@@ -151,11 +162,16 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
         double w[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) w[c] = lds[a * LDS_ROW + c * 33 + b];
-        const int ab = a * 32 + b;
-        gs_stage<16, 1>(w, q, [&](int g) { return tw[8192 + ab * 8 + g]; });
-        gs_stage<16, 2>(w, q, [&](int g) { return tw[4096 + ab * 4 + g]; });
-        gs_stage<16, 4>(w, q, [&](int g) { return tw[2048 + ab * 2 + g]; });
-        gs_stage<16, 8>(w, q, [&](int g) { return tw[1024 + ab + g]; });
+        double tl[16];
+        {
+            const double2 *pk = pack + (size_t)(p >> 6) * 512 + (p & 63);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
+        }
+        gs_stage<16, 1>(w, q, qinv, [&](int g) { return tl[7 + g]; });
+        gs_stage<16, 2>(w, q, qinv, [&](int g) { return tl[3 + g]; });
+        gs_stage<16, 4>(w, q, qinv, [&](int g) { return tl[1 + g]; });
+        gs_stage<16, 8>(w, q, qinv, [&](int g) { return tl[0 + g]; });
 #pragma unroll
         for (int c = 0; c < 16; c++) v[h * 16 + c] = pred(w[c], q, qinv);
     }
@@ -172,11 +188,11 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
         const int a = tid >> 4, c = tid & 15;
 #pragma unroll
         for (int b = 0; b < 32; b++) v[b] = lds[a * LDS_ROW + c * 33 + b];
-        gs_stage<32, 1>(v, q, [&](int g) { return tw[512 + a * 16 + g]; });
-        gs_stage<32, 2>(v, q, [&](int g) { return tw[256 + a * 8 + g]; });
-        gs_stage<32, 4>(v, q, [&](int g) { return tw[128 + a * 4 + g]; });
-        gs_stage<32, 8>(v, q, [&](int g) { return tw[64 + a * 2 + g]; });
-        gs_stage<32, 16>(v, q, [&](int g) { return tw[32 + a + g]; });
+        gs_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + a * 16 + g]; });
+        gs_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + a * 8 + g]; });
+        gs_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + a * 4 + g]; });
+        gs_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + a * 2 + g]; });
+        gs_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + a + g]; });
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < 32; b++) lds[a * LDS_ROW + b * 16 + c] = pred(v[b], q, qinv);
@@ -185,11 +201,11 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
     // ---- phase A': stages t = 512..8192 on a
 #pragma unroll
     for (int a = 0; a < 32; a++) v[a] = lds[a * LDS_ROW + tid];
-    gs_stage<32, 1>(v, q, [&](int g) { return tw[16 + g]; });
-    gs_stage<32, 2>(v, q, [&](int g) { return tw[8 + g]; });
-    gs_stage<32, 4>(v, q, [&](int g) { return tw[4 + g]; });
-    gs_stage<32, 8>(v, q, [&](int g) { return tw[2 + g]; });
-    gs_stage<32, 16>(v, q, [&](int g) { return tw[1 + g]; });
+    gs_stage<32, 1>(v, q, qinv, [&](int g) { return tw[16 + g]; });
+    gs_stage<32, 2>(v, q, qinv, [&](int g) { return tw[8 + g]; });
+    gs_stage<32, 4>(v, q, qinv, [&](int g) { return tw[4 + g]; });
+    gs_stage<32, 8>(v, q, qinv, [&](int g) { return tw[2 + g]; });
+    gs_stage<32, 16>(v, q, qinv, [&](int g) { return tw[1 + g]; });
     const double ninv = modc[m].ninv, ninv_q = modc[m].ninv_q;
     u64 *out = out_ + grp * rm.gstride_out + gi * N;
 #pragma unroll
@@ -215,7 +231,7 @@ int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const Mo
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, rm, ctx->tw_fwd, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, rm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -223,14 +239,14 @@ int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain,
     if (!nplain) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     ModPattern pat; pat.period = L; for (int l = 0; l < L; l++) pat.m[l] = (int8_t)l;
-    hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, dense_map(), ctx->tw_fwd, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, dense_map(), ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    hipLaunchKernelGGL(k_ntt_inv, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, in, out, pat, rm, ctx->tw_inv, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_inv, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, in, out, pat, rm, ctx->tw_inv, ctx->pack_inv, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
