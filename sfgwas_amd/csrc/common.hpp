@@ -31,6 +31,7 @@ struct RotKey {
 };
 
 struct PhaseStat { double ms = 0; int launches = 0; };
+struct PendingEvent { hipEvent_t e0, e1; std::string name; int launches; };
 
 struct sfg_geno {
     const int8_t *dev = nullptr;
@@ -58,6 +59,8 @@ struct sfg_ctx {
     std::map<int, void *> ksw_cache;   // per-level key-switch constants (device), rotate.hip
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
+    std::map<std::string, std::pair<void *, size_t>> pool;   // named grow-only device scratch (sfg_scratch), freed with the context
+    std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
     void *zeros_dev = nullptr;           // 256 B of zeros (DMA source for padded k-steps)
     std::string err;
     std::map<std::string, PhaseStat> phases;
@@ -79,7 +82,12 @@ static inline u64 h_powmod(u64 a, u64 e, u64 q) { u64 r = 1 % q; a %= q; while (
 static inline u64 h_invmod(u64 a, u64 q) { return h_powmod(a, q - 2, q); }
 static inline uint32_t h_brev(uint32_t x, int bits) { uint32_t r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 
-// phase timing helper: records HIP events around a region on the ctx stream
+// named grow-only scratch buffers owned by the context (avoids hipMalloc/hipFree of multi-GB buffers per call)
+int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out);
+// reads back all pending phase events (one stream sync); called by the phase query functions and at API exits
+void sfg_phases_resolve(sfg_ctx *ctx);
+
+// phase timing helper: HIP events around a region on the ctx stream, WITHOUT a host sync (resolved lazily)
 struct PhaseTimer {
     sfg_ctx *ctx; const char *name; hipEvent_t e0, e1; bool on;
     PhaseTimer(sfg_ctx *c, const char *n, bool enable = true) : ctx(c), name(n), on(enable) {
@@ -87,10 +95,10 @@ struct PhaseTimer {
     }
     void stop(int launches = 1) {
         if (!on) return;
-        (void)hipEventRecord(e1, ctx->stream); (void)hipEventSynchronize(e1);
-        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        auto &p = ctx->phases[name]; p.ms += ms; p.launches += launches;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); on = false;
+        (void)hipEventRecord(e1, ctx->stream);
+        ctx->pending.push_back(PendingEvent{e0, e1, name, launches});
+        on = false;
+        if (ctx->pending.size() > 4096) sfg_phases_resolve(ctx);
     }
     ~PhaseTimer() { stop(0); }
 };

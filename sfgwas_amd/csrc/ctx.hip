@@ -89,7 +89,9 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (auto &kv : ctx->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
+    sfg_phases_resolve(ctx);
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
     sfg_encoder_destroy(ctx);
     (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->pack_fwd); (void)hipFree(ctx->pack_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws); (void)hipFree(ctx->zeros_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -124,11 +126,35 @@ extern "C" int sfg_memcpy_d2h(sfg_ctx *ctx, void *d, const void *s, size_t n) {
     SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
 }
 
-extern "C" int sfg_ctx_clear_phases(sfg_ctx *ctx) { ctx->phases.clear(); return 0; }
+void sfg_phases_resolve(sfg_ctx *ctx) {
+    if (ctx->pending.empty()) return;
+    (void)hipEventSynchronize(ctx->pending.back().e1);
+    for (auto &p : ctx->pending) {
+        float ms = 0; (void)hipEventSynchronize(p.e1); (void)hipEventElapsedTime(&ms, p.e0, p.e1);
+        auto &st = ctx->phases[p.name]; st.ms += ms; st.launches += p.launches;
+        (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    ctx->pending.clear();
+}
+int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out) {
+    auto &e = ctx->pool[name];
+    if (e.second < bytes) {
+        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (e.first) SFG_HIP(ctx, hipFree(e.first));
+        e.first = nullptr; e.second = 0;
+        SFG_HIP(ctx, hipMalloc(&e.first, bytes));
+        e.second = bytes;
+    }
+    *out = e.first;
+    return 0;
+}
+extern "C" int sfg_ctx_clear_phases(sfg_ctx *ctx) { sfg_phases_resolve(ctx); ctx->phases.clear(); return 0; }
 extern "C" double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase) {
+    sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));
     auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1.0 : it->second.ms;
 }
 extern "C" int sfg_last_phase_launches(const sfg_ctx *ctx, const char *phase) {
+    sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));
     auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1 : it->second.launches;
 }
 

@@ -135,19 +135,19 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // scratch: level-dropped inputs of one block row, rotation cache of one block row, plaintext panel of one block
     const size_t nplain = (size_t)d * d;                         // 8281 >= 8192: the tail stays zero
     u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr;
-    SFG_HIP(ctx, hipMalloc(&a_row, (size_t)s * ctw * 8));
-    SFG_HIP(ctx, hipMalloc(&rotc, (size_t)d * s * ctw * 8));
-    SFG_HIP(ctx, hipMalloc(&pt, nplain * L * N * 8));
-    auto cleanup = [&]() { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(a_row); (void)hipFree(rotc); (void)hipFree(pt); };
+    SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
+    SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
+    SFG_TRY(sfg_scratch(ctx, "mm.pt", nplain * L * N * 8, (void **)&pt));
+    auto cleanup = [&]() {};
     int8_t *skew = nullptr;
-    if (hipMalloc(&skew, (size_t)SFG_SLOTS * SFG_SLOTS) != hipSuccess) { cleanup(); SFG_FAIL(ctx, "matmul: out of device memory (skew)"); }
+    SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
     // fp64 operand form of the rotation cache for the LDS-DMA MAC kernel
     double *rotf = nullptr; size_t rowf = 0;
     if (mac_use_dma()) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
-        if (nplanes < 0) { cleanup(); (void)hipFree(skew); return 1; }
+        if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
-        if (hipMalloc(&rotf, (size_t)d * s * 2 * rowf * 8) != hipSuccess) { cleanup(); (void)hipFree(skew); SFG_FAIL(ctx, "matmul: out of device memory (rotf)"); }
+        SFG_TRY(sfg_scratch(ctx, "mm.rotf", (size_t)d * s * 2 * rowf * 8, (void **)&rotf));
     }
     int rc = 0;
     std::vector<int> nrot((size_t)d * s);
@@ -211,7 +211,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             }
         }
     }
-    cleanup(); (void)hipFree(skew); (void)hipFree(rotf);
+    cleanup();
     return rc;
 }
 
@@ -223,8 +223,8 @@ static int matmul_finalize(sfg_ctx *ctx, const u64 *acc, int s, int max_level, i
     const size_t accw = (size_t)s * 2 * L * N, ctw = (size_t)2 * L * N;
     if (g0 < 0 || g1 > d || g0 > g1) SFG_FAIL(ctx, "finalize: giant range out of bounds");
     u64 *rot = nullptr; int *giants_d = nullptr;
-    SFG_HIP(ctx, hipMalloc(&rot, (size_t)d * accw * 8));
-    SFG_HIP(ctx, hipMalloc(&giants_d, d * sizeof(int)));
+    SFG_TRY(sfg_scratch(ctx, "mm.fin_rot", (size_t)d * accw * 8, (void **)&rot));
+    SFG_TRY(sfg_scratch(ctx, "mm.giants", (size_t)ncolb * d * sizeof(int) + 256, (void **)&giants_d));
     int rc = 0;
     for (int jb = 0; jb < ncolb && !rc; jb++) {
         const u64 *accj = acc + (size_t)jb * d * accw;
@@ -238,14 +238,13 @@ static int matmul_finalize(sfg_ctx *ctx, const u64 *acc, int s, int max_level, i
             t.stop(1);
         }
         if (rc) break;
-        if (hipMemcpyAsync(giants_d, glist.data(), glist.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = 1; ctx->err = "finalize: copy failed"; break; }
+        int *gd = giants_d + (size_t)jb * d;     // one list per block column: no host sync needed between columns
+        if (hipMemcpy(gd, glist.data(), glist.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = 1; ctx->err = "finalize: copy failed"; break; }
         u64 *o = out + (size_t)(jout0 + jb) * ctw;
-        hipLaunchKernelGGL(k_sum_giants, dim3((unsigned)((size_t)s * 2 * L * (N / 256))), dim3(256), 0, ctx->stream, rot, giants_d, (int)glist.size(), s, L,
+        hipLaunchKernelGGL(k_sum_giants, dim3((unsigned)((size_t)s * 2 * L * (N / 256))), dim3(256), 0, ctx->stream, rot, gd, (int)glist.size(), s, L,
                            o, (size_t)m_ct_out * ctw, accumulate, ctx->modc);
         if (hipGetLastError() != hipSuccess) { rc = 1; ctx->err = "finalize: k_sum_giants launch failed"; }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = 1; ctx->err = "finalize: sync failed"; }
     }
-    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rot); (void)hipFree(giants_d);
     return rc;
 }
 
@@ -292,10 +291,9 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     for (int ja = j0; ja < j1; ja += jg) {
         const int jb = std::min(j1, ja + jg);
         u64 *acc = nullptr;
-        SFG_HIP(ctx, hipMalloc(&acc, (size_t)(jb - ja) * d * accw * 8));
+        SFG_TRY(sfg_scratch(ctx, "mm.acc", (size_t)(jb - ja) * d * accw * 8, (void **)&acc));
         int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc);
         if (!rc) rc = matmul_finalize(ctx, acc, s, max_level, jb - ja, m_out, ja - j0, 0, d, &giant_t, 0, (u64 *)out);
-        (void)hipStreamSynchronize(ctx->stream); (void)hipFree(acc);
         if (rc) return rc;
     }
     return 0;
@@ -319,7 +317,9 @@ extern "C" int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, in
     if (!rc && hipMemcpy(dA, A_host, a_words * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = 1; ctx->err = "matmul_stream: upload failed"; }
     if (!rc && (sum_host || sqsum_host)) rc = sfg_geno_colsums(ctx, g, sum_host, sqsum_host);   // sums are taken before squaring (:1297-1303)
     if (!rc) rc = sfg_matmul_resident_dev(ctx, (const uint64_t *)dA, s, in_level, max_level, g, flags, (uint64_t *)dO);
-    if (!rc && hipMemcpy(out_host, dO, o_words * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = 1; ctx->err = "matmul_stream: download failed"; }
+    if (!rc && (hipMemcpyAsync(out_host, dO, o_words * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)) { rc = 1; ctx->err = "matmul_stream: download failed"; }
+    (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dA); (void)hipFree(dO); sfg_geno_free(ctx, g);
     return rc;
 }

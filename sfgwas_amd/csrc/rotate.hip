@@ -225,14 +225,14 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
     const size_t in_rows = (size_t)nl + (size_t)kc.beta * kc.nt, job_rows = 2 * (size_t)kc.nt + 2 * (size_t)nl;
     int in_grp = (int)((3ULL << 29) / (in_rows * N * 8)); if (in_grp < 1) in_grp = 1; if (in_grp > nin) in_grp = nin;
     int chunk = (int)((3ULL << 29) / (job_rows * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
-    const size_t ptr_bytes = (size_t)chunk * (3 * sizeof(void *) + sizeof(int)) + 256;
+    const size_t ptr_bytes = (size_t)nr * (3 * sizeof(void *) + sizeof(int)) + 256;     // pointer tables for every job of a group
     SFG_TRY(sfg_ws_reserve(ctx, (in_rows * in_grp + job_rows * chunk) * N * 8 + ptr_bytes));
     u64 *c2 = (u64 *)ctx->ws, *ext = c2 + (size_t)in_grp * nl * N;
     u64 *acc = ext + (size_t)in_grp * kc.beta * kc.nt * N, *ext2 = acc + (size_t)chunk * 2 * kc.nt * N;
-    const u64 **keys_d = (const u64 **)(ext2 + (size_t)chunk * 2 * nl * N);
-    const uint16_t **idx_d = (const uint16_t **)(keys_d + chunk);
-    u64 **out_d = (u64 **)(idx_d + chunk);
-    int *inidx_d = (int *)(out_d + chunk);
+    const u64 **keys_all = (const u64 **)(ext2 + (size_t)chunk * 2 * nl * N);
+    const uint16_t **idx_all = (const uint16_t **)(keys_all + nr);
+    u64 **out_all = (u64 **)(idx_all + nr);
+    int *inidx_all = (int *)(out_all + nr);
     ModPattern pq; pq.period = nl; for (int m = 0; m < nl; m++) pq.m[m] = (int8_t)m;
     ModPattern pext; pext.period = kc.beta * kc.nt;
     for (int i = 0; i < kc.beta; i++) for (int t = 0; t < kc.nt; t++) pext.m[i * kc.nt + t] = kc.digit_of[t] == i ? (int8_t)-1 : (int8_t)kc.tmod[t];
@@ -250,14 +250,21 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
         hipLaunchKernelGGL(k_ksw_extend, dim3(N / 256, kc.beta, ni), dim3(256), 0, ctx->stream, c2, bin, ext, kcd, ctx->modc);
         SFG_HIP(ctx, hipGetLastError());
         SFG_TRY(launch_ntt_fwd(ctx, ext, ext, (size_t)ni * kc.beta * kc.nt, pext));
+        // pointer tables of the whole group, uploaded once with blocking copies (the host vectors die with this scope;
+        // earlier kernels that read the tables are ordered before the copy by the stream sync)
+        {
+            const size_t nj = jobs.size();
+            std::vector<const u64 *> kp(nj); std::vector<const uint16_t *> ip(nj); std::vector<u64 *> op(nj); std::vector<int> ii(nj);
+            for (size_t k = 0; k < nj; k++) { int jb = jobs[k]; kp[k] = keyp[jb]; ip[k] = idxp[jb]; op[k] = outp[jb]; ii[k] = job_in[jb] - i0; }
+            SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SFG_HIP(ctx, hipMemcpy(keys_all, kp.data(), nj * sizeof(void *), hipMemcpyHostToDevice));
+            SFG_HIP(ctx, hipMemcpy(idx_all, ip.data(), nj * sizeof(void *), hipMemcpyHostToDevice));
+            SFG_HIP(ctx, hipMemcpy(out_all, op.data(), nj * sizeof(void *), hipMemcpyHostToDevice));
+            SFG_HIP(ctx, hipMemcpy(inidx_all, ii.data(), nj * sizeof(int), hipMemcpyHostToDevice));
+        }
         for (size_t c0 = 0; c0 < jobs.size(); c0 += chunk) {
             const int nb = (int)(jobs.size() - c0 < (size_t)chunk ? jobs.size() - c0 : (size_t)chunk);
-            std::vector<const u64 *> kp(nb); std::vector<const uint16_t *> ip(nb); std::vector<u64 *> op(nb); std::vector<int> ii(nb);
-            for (int k = 0; k < nb; k++) { int jb = jobs[c0 + k]; kp[k] = keyp[jb]; ip[k] = idxp[jb]; op[k] = outp[jb]; ii[k] = job_in[jb] - i0; }
-            SFG_HIP(ctx, hipMemcpyAsync(keys_d, kp.data(), nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-            SFG_HIP(ctx, hipMemcpyAsync(idx_d, ip.data(), nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-            SFG_HIP(ctx, hipMemcpyAsync(out_d, op.data(), nb * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-            SFG_HIP(ctx, hipMemcpyAsync(inidx_d, ii.data(), nb * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            const u64 **keys_d = keys_all + c0; const uint16_t **idx_d = idx_all + c0; u64 **out_d = out_all + c0; int *inidx_d = inidx_all + c0;
             // 3. inner product with the key
             hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, ext, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
             SFG_HIP(ctx, hipGetLastError());
@@ -270,8 +277,6 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
             // 5. finish + automorphism
             hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2, idx_d, out_d, kcd, ctx->modc);
             SFG_HIP(ctx, hipGetLastError());
-            // the host vectors and device pointer arrays are re-used by the next chunk
-            SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
     return 0;
