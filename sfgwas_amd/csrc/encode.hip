@@ -285,7 +285,7 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 }
 
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt) {
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows) {
     EncTables *et = (EncTables *)ctx->enc_tables;
     static bool attr = false;
     const size_t lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
@@ -304,7 +304,8 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
                                ctx->scale / (double)SFG_SLOTS, et->pc);
             SFG_HIP(ctx, hipGetLastError());
         }
-        SFG_TRY(launch_ntt_plain(ctx, et->pc, pt + (size_t)s0 * L * SFG_N, nb, L));
+        if (half_rows) SFG_TRY(launch_ntt_plain_half(ctx, et->pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L));
+        else SFG_TRY(launch_ntt_plain(ctx, et->pc, pt + (size_t)s0 * L * SFG_N, nb, L));
     }
     return 0;
 }
@@ -318,7 +319,10 @@ extern "C" int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block, size_t ld
     EncTables *et = (EncTables *)ctx->enc_tables;
     SFG_TRY(enc_scratch(ctx, et, 1));
     SFG_TRY(launch_skew(ctx, block, ld, r, c, transposed, 0, et->skew));
-    return launch_encode_rows(ctx, et->skew, shift0, nshift, L, (u64 *)pt);
+    u64 *half = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "enc.half", (size_t)nshift * L * (SFG_N / 2) * 8, (void **)&half));
+    SFG_TRY(launch_encode_rows(ctx, et->skew, shift0, nshift, L, half, true));
+    return launch_expand_half(ctx, half, (u64 *)pt, (size_t)nshift * L);
 }
 
 // EncodeFloatVector-style host helper (crypto.go:398-420 behind Mask/MaskTrunc, basics.go:110-172): real slot

@@ -12,15 +12,17 @@ struct RowMap { int rpg; size_t gstride_in, gstride_out; };
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain, int L);
+int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L);
+int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 // mac.hip
-struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; };   // in words
+struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; };   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate);
 int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
 // encode.hip
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D);
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt);
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false);
 // rotate.hip
 int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host);
 int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index);

@@ -29,6 +29,8 @@ struct DmaArgs {
     size_t out_n_stride, out_r_stride;       // words
     int K, R, Ncols, L, accumulate, r0, l0, nl, flush, ntile;
     int plane0;                  // fp64 plane index of modulus l0 inside a rotf row
+    int pt_half;                 // pt rows hold N/2 words: P[N-1-c] = P[c] (plaintexts of real slot vectors)
+    size_t pt_l_stride;          // words between consecutive modulus rows of one plaintext (N or N/2)
 };
 
 // one 16-byte-per-lane LDS-DMA; lds_base must be wave-uniform (it goes to M0)
@@ -49,13 +51,30 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int N = SFG_N, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cc = lane & 15, cg = lane >> 4, rh = wave & 3, wc = wave >> 2;
-    const int b = blockIdx.x, grp = b / (8 * a.ntile), rem = b % (8 * a.ntile);
-    const int slab = grp * 8 + (rem & 7), tile = rem >> 3;
-    const int nslab = (N / DM_CL) * a.nl;
-    if (slab >= nslab) return;
-    const int li = slab / (N / DM_CL), l = a.l0 + li, c0 = (slab % (N / DM_CL)) * DM_CL;
+    // Block decode.  Column tiles that share one (c-block, modulus) slab of `rot` get consecutive slots on the same
+    // XCD (blocks b and b+8 share an XCD).  With half-row plaintexts a c-block and its mirror (1023 - cblk) read
+    // the same plaintext bytes, so the pair is placed back to back on one XCD and the second read is an L2 hit.
+    int li, c0, tile; bool mirrored = false;
+    {
+        const int b = blockIdx.x;
+        if (!a.pt_half) {
+            const int grp = b / (8 * a.ntile), rem = b % (8 * a.ntile);
+            const int slab = grp * 8 + (rem & 7); tile = rem >> 3;
+            if (slab >= (N / DM_CL) * a.nl) return;
+            li = slab / (N / DM_CL); c0 = (slab % (N / DM_CL)) * DM_CL;
+        } else {
+            const int per = 16 * a.ntile, grp = b / per, rem = b % per, idx = rem >> 3;
+            const int sup = grp * 8 + (rem & 7); tile = idx % a.ntile; mirrored = idx >= a.ntile;
+            if (sup >= (N / DM_CL / 2) * a.nl) return;
+            li = sup / (N / DM_CL / 2);
+            const int sb = sup % (N / DM_CL / 2);
+            c0 = (mirrored ? (N / DM_CL - 1 - sb) : sb) * DM_CL;
+        }
+    }
+    const int l = a.l0 + li;
     const double q = modc[l].q, qinv = modc[l].qinv;
     const int n0 = tile * DM_COLS + (wc * DM_CG + cg) * DM_CT;
+    const int pcc = mirrored ? DM_CL - 1 - cc : cc;                     // P[N-1-c] = P[c]
     const int nchunk = (a.K + DM_KC - 1) / DM_KC;
 
     // ---- DMA source addressing.  Job j of a chunk moves 8 (k, row|col) pairs x 128 B; lane = (pair & 7, 16-B piece).
@@ -79,7 +98,8 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
             const int pr = (job - R_JOBS) * 8 + pair_in_job;
             const int kk = pr / DM_COLS, col = pr % DM_COLS;
             int n = tile * DM_COLS + col; n = n < a.Ncols ? n : a.Ncols - 1;
-            const u64 *ptr = a.pt + (size_t)kk * a.pt_k_stride + (size_t)n * a.pt_n_stride + (size_t)l * N + c0 + piece * 2;
+            const int cp0 = mirrored ? N - DM_CL - c0 : c0;                    // mirror block start inside the half row
+            const u64 *ptr = a.pt + (size_t)kk * a.pt_k_stride + (size_t)n * a.pt_n_stride + (size_t)l * a.pt_l_stride + cp0 + piece * 2;
             src0[t] = (const unsigned char *)ptr; step[t] = (size_t)DM_KC * a.pt_k_stride * 8; kk_of[t] = kk; kind[t] = 1;
         } else {
             src0[t] = (const unsigned char *)(a.zeros + piece * 2); step[t] = 0; kk_of[t] = 0; kind[t] = 2;
@@ -130,7 +150,7 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
 #pragma unroll
             for (int t = 0; t < DM_CT; t++) {
                 const int colw = (wc * DM_CG + cg) * DM_CT + t;
-                const u64 p = pbase[(size_t)(kk * DM_COLS + colw) * DM_CL + cc];
+                const u64 p = pbase[(size_t)(kk * DM_COLS + colw) * DM_CL + pcc];
                 if (BIG) { p0[t] = (double)(unsigned)(p & 0x7FFFFFu); p1[t] = u64_to_f64(p >> 23); p2[t] = 0.0; }
                 else {
                     const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
@@ -258,13 +278,14 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
                 a.pt_n_stride = 16; a.pt_k_stride = (size_t)Ncols * 16; a.rotf_r_stride = 16 * (big ? 2 : 1); a.rotf_k_stride = (size_t)rows_per_k * a.rotf_r_stride;
             }
             a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
+            a.pt_half = st.pt_half ? 1 : 0; a.pt_l_stride = st.pt_half ? N / 2 : N;
             double maxterm = big ? 2.0 * 16777216.0 * 16777216.0 : 0.0;
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / DM_KC) * DM_KC;
             if (f < DM_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
             a.flush = f; a.ntile = (Ncols + DM_COLS - 1) / DM_COLS;
-            const int nslab = (N / DM_CL) * a.nl, ngrp = (nslab + 7) / 8;
-            dim3 grid((unsigned)(ngrp * 8 * a.ntile));
+            const int nslab = (st.pt_half ? N / DM_CL / 2 : N / DM_CL) * a.nl, ngrp = (nslab + 7) / 8;
+            dim3 grid((unsigned)(ngrp * 8 * a.ntile * (st.pt_half ? 2 : 1)));
             PhaseTimer t(ctx, big ? "mac_big" : "mac_small");
             if (big) hipLaunchKernelGGL(k_mac_dma<true>, grid, dim3(DM_THREADS), 3 * 48 * 1024, ctx->stream, a, ctx->modc);
             else hipLaunchKernelGGL(k_mac_dma<false>, grid, dim3(DM_THREADS), 4 * 32 * 1024, ctx->stream, a, ctx->modc);

@@ -137,7 +137,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
-    SFG_TRY(sfg_scratch(ctx, "mm.pt", nplain * L * N * 8, (void **)&pt));
+    const bool half = mac_use_dma();                       // half-row plaintext panel (P[N-1-c] = P[c]); the register-staged kernel wants full rows
+    const size_t prow = half ? (size_t)N / 2 : (size_t)N;    // words per plaintext modulus row
+    SFG_TRY(sfg_scratch(ctx, "mm.pt", nplain * L * prow * 8, (void **)&pt));
     auto cleanup = [&]() {};
     int8_t *skew = nullptr;
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
@@ -190,12 +192,12 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             int runs[2][2]; int nruns = 0;
             if (nr >= SFG_SLOTS || nc >= SFG_SLOTS || nr + nc > SFG_SLOTS) { runs[0][0] = 0; runs[0][1] = SFG_SLOTS; nruns = 1; }
             else { runs[0][0] = 0; runs[0][1] = nr; runs[1][0] = SFG_SLOTS - nc + 1; runs[1][1] = SFG_SLOTS; nruns = 2; if (runs[1][0] >= runs[1][1]) nruns = 1; }
-            if (nruns == 2 || runs[0][1] - runs[0][0] < SFG_SLOTS) SFG_HIP(ctx, hipMemsetAsync(pt, 0, nplain * L * N * 8, ctx->stream));
-            else SFG_HIP(ctx, hipMemsetAsync(pt + (size_t)SFG_SLOTS * L * N, 0, (nplain - SFG_SLOTS) * L * N * 8, ctx->stream));
+            if (nruns == 2 || runs[0][1] - runs[0][0] < SFG_SLOTS) SFG_HIP(ctx, hipMemsetAsync(pt, 0, nplain * L * prow * 8, ctx->stream));
+            else SFG_HIP(ctx, hipMemsetAsync(pt + (size_t)SFG_SLOTS * L * prow, 0, (nplain - SFG_SLOTS) * L * prow * 8, ctx->stream));
             {
                 PhaseTimer t(ctx, "encode");
                 for (int r = 0; r < nruns && !rc; r++)
-                    rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * L * N);
+                    rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * L * prow, half);
                 t.stop(nruns);
             }
             if (rc) break;
@@ -203,7 +205,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = (size_t)L * N; st.pt_n = (size_t)d * L * N;           // pt[giant*d + baby]
+                st.pt_k = (size_t)L * prow; st.pt_n = (size_t)d * L * prow; st.pt_half = half;   // pt[giant*d + baby]
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 if (rotf) rc = launch_mac_dma(ctx, rotf, (size_t)s * 2, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
                 else rc = launch_mac_strided(ctx, rotc, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);

@@ -215,12 +215,109 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Half-size forward NTT for plaintexts of REAL slot vectors.  Such a polynomial is invariant under X -> X^-1
+// (p_{N-c} = -p_c), hence P[N-1-i] = P[i] in lattigo's output order, and the whole "minus" branch of the first
+// Cooley-Tukey stage is redundant.  This kernel computes r_j = p_j + W p_{n+j} = p_j - W p_{n-j} (W = psi^(N/2),
+// r_0 = p_0) and runs stages 2..14 on those n = N/2 values only: half the butterflies, half the LDS (two
+// workgroups per CU), and it emits half rows P[0..n).  256 threads, j = a*512 + b*16 + c with a < 16.
+constexpr int HLDS_DOUBLES = 16 * LDS_ROW;   // 67,584 B
+__global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *out_, int L, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, n = N / 2, tid = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const int m = (int)(row % L);
+    const double *tw = tw_all + (size_t)m * N;
+    const double2 *pack = pack_all + (size_t)m * (N / 2);
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const long long *pc = pc_all + (row / L) * (size_t)n;
+    const double W = tw[1], Wq = W * qinv;
+    double v[32];
+    // ---- phase A: two (b,c) columns per thread, 16 values of a each; stages t = 4096, 2048, 1024, 512
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int pp = tid + 256 * h;
+        double w[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            const int j = a * 512 + pp;
+            const double lo = (double)pc[j];
+            const double hi = j == 0 ? 0.0 : (double)pc[n - j];          // p_{n+j} = -p_{n-j}
+            w[a] = lo - mulmod_lazy(hi, W, Wq, q);
+        }
+        ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + g]; });
+        ct_stage<16, 4>(w, q, qinv, [&](int g) { return tw[4 + g]; });
+        ct_stage<16, 2>(w, q, qinv, [&](int g) { return tw[8 + g]; });
+        ct_stage<16, 1>(w, q, qinv, [&](int g) { return tw[16 + g]; });
+#pragma unroll
+        for (int a = 0; a < 16; a++) lds[a * LDS_ROW + pp] = w[a];
+    }
+    __syncthreads();
+    // ---- phase B: thread (a, c), 32 values of b; stages t = 256 .. 16
+    {
+        const int a = tid >> 4, c = tid & 15;
+#pragma unroll
+        for (int b = 0; b < 32; b++) v[b] = lds[a * LDS_ROW + b * 16 + c];
+        ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + a + g]; });
+        ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + a * 2 + g]; });
+        ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + a * 4 + g]; });
+        ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + a * 8 + g]; });
+        ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + a * 16 + g]; });
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 32; b++) lds[a * LDS_ROW + c * 33 + b] = v[b];
+    }
+    __syncthreads();
+    // ---- phase C: two (a, b) groups per thread, 16 values of c; stages t = 8 .. 1 with the packed twiddles
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = tid + 256 * h, a = p >> 5, b = p & 31;
+        double w[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) w[c] = lds[a * LDS_ROW + c * 33 + b];
+        double tl[16];
+        {
+            const double2 *pk = pack + (size_t)(p >> 6) * 512 + (p & 63);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
+        }
+        ct_stage<16, 8>(w, q, qinv, [&](int g) { return tl[0 + g]; });
+        ct_stage<16, 4>(w, q, qinv, [&](int g) { return tl[1 + g]; });
+        ct_stage<16, 2>(w, q, qinv, [&](int g) { return tl[3 + g]; });
+        ct_stage<16, 1>(w, q, qinv, [&](int g) { return tl[7 + g]; });
+#pragma unroll
+        for (int c = 0; c < 16; c++) v[h * 16 + c] = w[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = tid + 256 * h, a = p >> 5, b = p & 31;
+#pragma unroll
+        for (int c = 0; c < 16; c++) lds[a * LDS_ROW + c * 33 + b] = v[h * 16 + c];
+    }
+    __syncthreads();
+    u64 *out = out_ + row * (size_t)n;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int j = k * 256 + tid, a = j >> 9, x = j & 511, b = x >> 4, c = x & 15;
+        out[j] = f64_to_u64(canon(lds[a * LDS_ROW + c * 33 + b], q, qinv));
+    }
+}
+// full rows from half rows: out[i] = out[N-1-i] = half[i]
+__global__ void __launch_bounds__(256) k_expand_half(const u64 *half, u64 *full) {
+    const int N = SFG_N, n = N / 2; const size_t row = blockIdx.x / (n / 256);
+    const int i = (int)(blockIdx.x % (n / 256)) * 256 + threadIdx.x;
+    const u64 v = half[row * n + i];
+    full[row * N + i] = v; full[row * N + (N - 1 - i)] = v;
+}
+
 static int set_lds_attr_once() {
     static bool done = false;
     if (done) return 0;
     hipError_t e = hipFuncSetAttribute((const void *)k_ntt_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
     done = (e == hipSuccess);
     return e == hipSuccess ? 0 : 1;
 }
@@ -240,6 +337,20 @@ int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain,
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     ModPattern pat; pat.period = L; for (int l = 0; l < L; l++) pat.m[l] = (int8_t)l;
     hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, dense_map(), ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// half rows [nplain][L][N/2] from half-coefficient plaintexts
+int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L) {
+    if (!nplain) return 0;
+    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
+    hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows) {
+    if (!nrows) return 0;
+    hipLaunchKernelGGL(k_expand_half, dim3((unsigned)(nrows * (SFG_N / 2 / 256))), dim3(256), 0, ctx->stream, half, full);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
