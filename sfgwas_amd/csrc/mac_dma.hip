@@ -144,13 +144,23 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
         const unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
         const double *rbase = reinterpret_cast<const double *>(slot);
         const u64 *pbase = reinterpret_cast<const u64 *>(slot + R_BYTES);
-#pragma unroll 2
-        for (int kk = 0; kk < DM_KC; kk++) {
+        // software pipeline: the LDS words of k-step kk+1 are requested before the FMAs of k-step kk run
+        double rcur[DM_RH * RW], rnxt[DM_RH * RW]; u64 pcur[DM_CT], pnxt[DM_CT];
+        auto fetch = [&](int kk, double (&rr)[DM_RH * RW], u64 (&pp)[DM_CT]) {
+#pragma unroll
+            for (int t = 0; t < DM_CT; t++) pp[t] = pbase[(size_t)(kk * DM_COLS + (wc * DM_CG + cg) * DM_CT + t) * DM_CL + pcc];
+#pragma unroll
+            for (int r = 0; r < DM_RH; r++) {
+                const int row = rh * DM_RH + r;
+                if (BIG) { const double2 v2 = *reinterpret_cast<const double2 *>(rbase + ((size_t)(kk * DM_ROWS + row) * DM_CL + cc) * 2); rr[2 * r] = v2.x; rr[2 * r + 1] = v2.y; }
+                else rr[r] = rbase[(size_t)(kk * DM_ROWS + row) * DM_CL + cc];
+            }
+        };
+        auto fmas = [&](const double (&rr)[DM_RH * RW], const u64 (&pp)[DM_CT]) {
             double p0[DM_CT], p1[DM_CT], p2[DM_CT];
 #pragma unroll
             for (int t = 0; t < DM_CT; t++) {
-                const int colw = (wc * DM_CG + cg) * DM_CT + t;
-                const u64 p = pbase[(size_t)(kk * DM_COLS + colw) * DM_CL + pcc];
+                const u64 p = pp[t];
                 if (BIG) { p0[t] = (double)(unsigned)(p & 0x7FFFFFu); p1[t] = u64_to_f64(p >> 23); p2[t] = 0.0; }
                 else {
                     const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
@@ -159,27 +169,27 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
             }
 #pragma unroll
             for (int r = 0; r < DM_RH; r++) {
-                const int row = rh * DM_RH + r;
-                if (BIG) {
-                    const double2 rv = *reinterpret_cast<const double2 *>(rbase + ((size_t)(kk * DM_ROWS + row) * DM_CL + cc) * 2);
 #pragma unroll
-                    for (int t = 0; t < DM_CT; t++) {
-                        acc[r][t][0] = __builtin_fma(rv.x, p0[t], acc[r][t][0]);
-                        acc[r][t][1] = __builtin_fma(rv.x, p1[t], acc[r][t][1]);
-                        acc[r][t][1] = __builtin_fma(rv.y, p0[t], acc[r][t][1]);
-                        acc[r][t][2] = __builtin_fma(rv.y, p1[t], acc[r][t][2]);
-                    }
-                } else {
-                    const double x = rbase[(size_t)(kk * DM_ROWS + row) * DM_CL + cc];
-#pragma unroll
-                    for (int t = 0; t < DM_CT; t++) {
-                        acc[r][t][0] = __builtin_fma(x, p0[t], acc[r][t][0]);
-                        acc[r][t][1] = __builtin_fma(x, p1[t], acc[r][t][1]);
-                        acc[r][t][2] = __builtin_fma(x, p2[t], acc[r][t][2]);
+                for (int t = 0; t < DM_CT; t++) {
+                    if (BIG) {
+                        acc[r][t][0] = __builtin_fma(rr[2 * r], p0[t], acc[r][t][0]);
+                        acc[r][t][1] = __builtin_fma(rr[2 * r], p1[t], acc[r][t][1]);
+                        acc[r][t][1] = __builtin_fma(rr[2 * r + 1], p0[t], acc[r][t][1]);
+                        acc[r][t][2] = __builtin_fma(rr[2 * r + 1], p1[t], acc[r][t][2]);
+                    } else {
+                        acc[r][t][0] = __builtin_fma(rr[r], p0[t], acc[r][t][0]);
+                        acc[r][t][1] = __builtin_fma(rr[r], p1[t], acc[r][t][1]);
+                        acc[r][t][2] = __builtin_fma(rr[r], p2[t], acc[r][t][2]);
                     }
                 }
             }
-        }
+        };
+        fetch(0, rcur, pcur);
+        fetch(1, rnxt, pnxt); fmas(rcur, pcur);
+        fetch(2, rcur, pcur); fmas(rnxt, pnxt);
+        fetch(3, rnxt, pnxt); fmas(rcur, pcur);
+        fmas(rnxt, pnxt);
+        static_assert(DM_KC == 4, "the pipeline above is written for 4 k-steps per chunk");
         since_flush += DM_KC;
         if (since_flush >= a.flush) {
             since_flush = 0;
@@ -194,21 +204,31 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
     constexpr double S1 = BIG ? 8388608.0 : 4096.0;
     const double s1 = S1, s1q = S1 / q;
     const double s2 = canon(S1 * S1, q, qinv), s2q = s2 / q;
+    // epilogue: all previous-value loads are issued first (one wait), then the tile is reduced and stored;
+    // a load->add->store chain per element would serialize 24 HBM round trips per thread
+    u64 oldv[DM_RH][DM_CT];
+#pragma unroll
+    for (int t = 0; t < DM_CT; t++)
+#pragma unroll
+        for (int r = 0; r < DM_RH; r++) {
+            // unconditional loads from clamped (always valid) addresses: a branch per element would put a
+            // vmcnt(0) behind every load (24 serialized HBM round trips per thread)
+            const int n = n0 + t < a.Ncols ? n0 + t : a.Ncols - 1;
+            const int row = a.r0 + rh * DM_RH + r < a.R ? a.r0 + rh * DM_RH + r : a.R - 1;
+            oldv[r][t] = a.out[(size_t)n * a.out_n_stride + (size_t)row * a.out_r_stride + (size_t)l * N + c0 + cc];
+        }
 #pragma unroll
     for (int t = 0; t < DM_CT; t++) {
         const int n = n0 + t;
-        if (n >= a.Ncols) continue;
 #pragma unroll
         for (int r = 0; r < DM_RH; r++) {
             const int row = a.r0 + rh * DM_RH + r;
-            if (row < a.R) {
-                double x = pred(acc[r][t][0], q, qinv);
-                x += mulmod_lazy(pred(acc[r][t][1], q, qinv), s1, s1q, q);
-                x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
-                u64 *o = a.out + (size_t)n * a.out_n_stride + (size_t)row * a.out_r_stride + (size_t)l * N + c0 + cc;
-                if (a.accumulate) x += u64_to_f64(*o);
-                *o = f64_to_u64(canon(x, q, qinv));
-            }
+            double x = pred(acc[r][t][0], q, qinv);
+            x += mulmod_lazy(pred(acc[r][t][1], q, qinv), s1, s1q, q);
+            x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
+            x += a.accumulate ? u64_to_f64(oldv[r][t] & 0x000FFFFFFFFFFFFFULL) : 0.0;
+            if (n < a.Ncols && row < a.R)
+                a.out[(size_t)n * a.out_n_stride + (size_t)row * a.out_r_stride + (size_t)l * N + c0 + cc] = f64_to_u64(canon(x, q, qinv));
         }
     }
 }
