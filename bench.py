@@ -64,7 +64,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SFG_BENCH_FORCE_COLLECTIVES=1 runs the RCCL collectives even at world size 1 (used to exercise the N > 1 code path
+    # on a single-GPU box under torch.distributed.run)
+    force_coll = os.environ.get("SFG_BENCH_FORCE_COLLECTIVES") == "1"
+    use_dist = world > 1 or (force_coll and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
@@ -121,18 +125,18 @@ def main():
         lib.sfg_ctx_clear_phases(ctx.h)
         chk(lib.sfg_matmul_accumulate_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP, LEVEL, L, gh, capi.SFG_TRANSPOSE,
                                           0, nblk_loc, 0, nbr_x, 0, C.c_void_p(acc2.data_ptr())), "Q'*X^T accumulate")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(acc2)                                           # < 8 * 2^46: no uint64 overflow
             chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(acc2.data_ptr()), nbr_x * D * KP * 2, L), "reduce acc")
         g0, g1 = giant_range(rank, world)
         chk(lib.sfg_matmul_finalize_dev(ctx.h, C.c_void_p(acc2.data_ptr()), KP, L, nbr_x, g0, g1, 0, C.c_void_p(out2.data_ptr())), "finalize")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(out2)
             chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(out2.data_ptr()), KP * nbr_x * 2, L), "reduce out")
         add_phases()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +149,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -188,7 +192,7 @@ def main():
         print(json.dumps(res), flush=True)
     lib.sfg_geno_free(ctx.h, gh)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
