@@ -172,11 +172,19 @@ def main():
         ms_small, n_small = phase_tot.get("mac_small", [0.0, 0])
         if n_small:
             nl_small = L - 1                                               # moduli 1..4 are the 35/36-bit primes
-            per_launch = (D * 2 * KP + D * D + 2 * D * 2 * KP) * nl_small * N * 8   # rot + pt + acc(read+write)
+            # algorithmic bytes of one launch (one 8192^2 block, K = 91 baby steps, 30 rows, 91 giant columns):
+            # fp64 rot operand + half-row plaintexts (P[N-1-c] = P[c]) + accumulators read and written
+            per_launch = (D * 2 * KP * N + D * D * (N // 2) + 2 * D * 2 * KP * N) * nl_small * 8
             avg_ms = ms_small / n_small
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:        # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_launch.json")))
+                traffic = pm["void k_mac_dma<false>"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "k_mac_dma<false>", "avg_launch_ms": avg_ms, "launches": n_small,
                                "alg_bytes_per_launch": per_launch,
                                "macs_per_s_in_kernel": D * D * 2 * KP * nl_small * N / (avg_ms * 1e-3)}
