@@ -1,0 +1,310 @@
+// gwas.hpp — host-side mirror (C++17, header-only) of the reference's Go interface for the hot path, written on
+// top of the C-ABI (include/sfgwas_hip.h).  Go is not available in this image, so this is what stands in for the
+// cgo shim of INTEGRATION.md: same names, same argument meaning, same error behaviour (the reference panics on this
+// path — matmult.go:361, filestream.go:60,334 — here: std::runtime_error).
+//
+//   crypto::CryptoParams / Ciphertext / CipherVector / CipherMatrix      crypto/crypto.go:32-60
+//   crypto::RotateRight, RotateRightWithEvaluator                        crypto/basics.go:201-224
+//   gwas::GenoFileStream                                                 gwas/filestream.go:284-494
+//   gwas::DiagCacheStream (reader + writer, reference byte format)       gwas/filestream.go:19-282
+//   gwas::MatMult4Stream / MatMult4StreamPreprocess / MatMult4StreamCompute   gwas/matmult.go:914,1043,1238
+//   mpc::BeaverMultElemVec / BeaverMultMat                               mpc/beavermult.go:108-147
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "../../include/sfgwas_hip.h"
+
+namespace crypto {
+
+struct Ciphertext {               // ckks.Ciphertext of degree 1: Value()[k].Coeffs[m][:] flattened as [2][level+1][N]
+    int level = 0;
+    double scale = 0;
+    std::vector<uint64_t> data;
+    int Level() const { return level; }
+    double Scale() const { return scale; }
+};
+using CipherVector = std::vector<Ciphertext>;
+using CipherMatrix = std::vector<CipherVector>;
+
+struct CryptoParams {             // crypto.go:32-60 (the parts the hot path touches)
+    sfg_ctx *ctx = nullptr;
+    int logN = 14, nq = 0, np = 0;
+    double scale = 0;
+    int N() const { return 1 << logN; }
+    int GetSlots() const { return N() / 2; }                         // crypto.go:282-284
+    ~CryptoParams() { if (ctx) sfg_ctx_destroy(ctx); }
+    void check(int rc, const char *what) const {
+        if (rc) throw std::runtime_error(std::string(what) + ": " + sfg_last_error(ctx));
+    }
+};
+
+// after CollectiveInit (gwas.go:212): ring moduli Q then P, lattigo's 2N-th roots (or nullptr), params.Scale()
+inline std::unique_ptr<CryptoParams> NewCryptoParams(int device, int logN, const std::vector<uint64_t> &qi, const std::vector<uint64_t> &pi,
+                                                     const uint64_t *psi, double scale) {
+    auto cps = std::make_unique<CryptoParams>();
+    std::vector<uint64_t> mod(qi); mod.insert(mod.end(), pi.begin(), pi.end());
+    if (sfg_ctx_create(&cps->ctx, device, logN, (int)qi.size(), (int)pi.size(), mod.data(), psi, scale))
+        throw std::runtime_error(std::string("sfg_ctx_create: ") + sfg_last_error(nullptr));
+    cps->logN = logN; cps->nq = (int)qi.size(); cps->np = (int)pi.size(); cps->scale = scale;
+    return cps;
+}
+// cryptoParams.RotKs (crypto.go:50): one switching key per Galois element, [beta][2][nq+np][N]
+inline void LoadRotationKey(CryptoParams *cps, uint64_t galoisEl, const std::vector<uint64_t> &key, bool montgomeryForm) {
+    cps->check(sfg_ctx_load_rotkey(cps->ctx, galoisEl, key.data(), montgomeryForm ? 1 : 0), "LoadRotationKey");
+}
+
+inline int Mod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+// crypto/basics.go:201-210 (the evaluator argument of the Go signature has no counterpart: the context owns the keys)
+inline Ciphertext RotateRightWithEvaluator(CryptoParams *cps, const Ciphertext &ct, int nrot) {
+    const size_t words = ct.data.size();
+    void *din = nullptr, *dout = nullptr;
+    cps->check(sfg_malloc(cps->ctx, &din, words * 8), "RotateRight"); cps->check(sfg_malloc(cps->ctx, &dout, words * 8), "RotateRight");
+    cps->check(sfg_memcpy_h2d(cps->ctx, din, ct.data.data(), words * 8), "RotateRight");
+    int rc = sfg_rotate_right_dev(cps->ctx, (const uint64_t *)din, (uint64_t *)dout, 1, ct.level, &nrot);
+    Ciphertext out; out.level = ct.level; out.scale = ct.scale; out.data.resize(words);
+    if (!rc) rc = sfg_memcpy_d2h(cps->ctx, out.data.data(), dout, words * 8);
+    sfg_free(cps->ctx, din); sfg_free(cps->ctx, dout);
+    cps->check(rc, "RotateRight");
+    return out;
+}
+inline Ciphertext RotateRight(CryptoParams *cps, const Ciphertext &ct, int nrot) { return RotateRightWithEvaluator(cps, ct, nrot); }  // :212-224
+
+}  // namespace crypto
+
+namespace gwas {
+
+// ---------------------------------------------------------------- GenoFileStream (filestream.go:284-494)
+class GenoFileStream {
+    std::string filename; FILE *file = nullptr;
+    uint64_t numRows, numCols, lineCount = 0;
+    std::vector<uint8_t> buf;
+    std::vector<bool> filtRows, filtCols; bool hasRowFilt = false, hasColFilt = false;
+    uint64_t filtNumRow = 0, filtNumCol = 0;
+    bool replaceMissing;
+    std::vector<int8_t> readRow() {                                  // :327-360
+        if (CheckEOF()) return {};
+        if (fread(buf.data(), 1, numCols, file) != numCols) throw std::runtime_error("GenoFileStream: short read");   // panic(err)
+        std::vector<int8_t> out; out.reserve(hasColFilt ? filtNumCol : numCols);
+        for (uint64_t i = 0; i < numCols; i++) if (!hasColFilt || filtCols[i]) {
+            int8_t v = (int8_t)buf[i];
+            if (replaceMissing && v < 0) v = 0;                     // :352-354
+            out.push_back(v);
+        }
+        lineCount++;
+        return out;
+    }
+public:
+    GenoFileStream(const std::string &fn, uint64_t numRow, uint64_t numCol, bool replaceMissing_)   // NewGenoFileStream :302-325
+        : filename(fn), numRows(numRow), numCols(numCol), buf(numCol), replaceMissing(replaceMissing_) {
+        file = fopen(fn.c_str(), "rb");
+        if (!file) throw std::runtime_error("NewGenoFileStream: cannot open " + fn);
+    }
+    ~GenoFileStream() { if (file) fclose(file); }
+    void Reset() {                                                   // :362-376
+        if (!file) file = fopen(filename.c_str(), "rb"); else fseek(file, 0, SEEK_SET);
+        if (!file) throw std::runtime_error("GenoFileStream.Reset: cannot open " + filename);
+        lineCount = 0;
+    }
+    uint64_t NumRows() const { return numRows; }
+    uint64_t NumCols() const { return numCols; }
+    uint64_t NumRowsToKeep() const { return hasRowFilt ? filtNumRow : numRows; }   // :386-391
+    uint64_t NumColsToKeep() const { return hasColFilt ? filtNumCol : numCols; }   // :393-398
+    bool CheckEOF() {                                                // :400-412
+        if (lineCount >= numRows) { if (file) fclose(file); file = nullptr; return true; }
+        return false;
+    }
+    std::vector<int8_t> NextRow() {                                  // :414-426
+        if (CheckEOF()) return {};
+        if (hasRowFilt) while (lineCount < filtRows.size() && !filtRows[lineCount]) readRow();
+        return readRow();
+    }
+    int UpdateRowFilt(const std::vector<bool> &a) {                  // :428-454
+        if (a.size() != NumRowsToKeep()) throw std::runtime_error("Invalid length of input array");
+        if (!hasRowFilt) { filtRows.assign(numRows, true); hasRowFilt = true; }
+        int sum = 0; size_t idx = 0;
+        for (size_t i = 0; i < filtRows.size(); i++) if (filtRows[i]) { filtRows[i] = a[idx++]; if (filtRows[i]) sum++; }
+        filtNumRow = sum; return sum;
+    }
+    int UpdateColFilt(const std::vector<bool> &a) {                  // :456-482
+        if (a.size() != NumColsToKeep()) throw std::runtime_error("Invalid length of input array");
+        if (!hasColFilt) { filtCols.assign(numCols, true); hasColFilt = true; }
+        int sum = 0; size_t idx = 0;
+        for (size_t i = 0; i < filtCols.size(); i++) if (filtCols[i]) { filtCols[i] = a[idx++]; if (filtCols[i]) sum++; }
+        filtNumCol = sum; return sum;
+    }
+    uint64_t LineCount() const { return lineCount; }
+};
+
+// ---------------------------------------------------------------- DiagCacheStream (filestream.go:19-282)
+// header: 6 x u64 LE {vectorLen, level, scale bits, n, numModuli, rowSize}, d baby flags, d giant flags;
+// record: u64 LE length, u32 LE shift, per plaintext u8 isEmpty + numModuli*n coefficients (big-endian u64,
+// lattigo ring.WriteCoeffsTo — unverified).  Plaintexts are NTT + Montgomery form in the file.
+struct PlainVector { std::vector<std::vector<uint64_t>> pt; std::vector<bool> empty; };
+class DiagCacheStream {
+    FILE *file = nullptr; bool isWrite, atHead = true; int d;
+    std::vector<uint8_t> buf;
+public:
+    uint64_t vectorLen = 0, level = 0, n = 0, numModuli = 0, rowSize = 0; double scale = 0;
+    std::vector<bool> babyTable, giantTable;
+    static std::string FileName(const std::string &prefix, int blockRowIndex) { return prefix + "_" + std::to_string(blockRowIndex) + ".bin"; }   // :43
+    // second result of NewDiagCacheStream: true when a write was requested but the file already exists (:48-54)
+    DiagCacheStream(const std::string &prefix, int blockRowIndex, bool isWrite_, int slots, bool *existed = nullptr) : isWrite(isWrite_) {
+        d = (int)std::ceil(std::sqrt((double)slots));
+        const std::string fn = FileName(prefix, blockRowIndex);
+        if (existed) *existed = false;
+        if (isWrite) {
+            if (FILE *t = fopen(fn.c_str(), "rb")) { fclose(t); if (existed) *existed = true; return; }
+            file = fopen(fn.c_str(), "wb");
+        } else file = fopen(fn.c_str(), "rb");
+        if (!file) throw std::runtime_error("NewDiagCacheStream: cannot open " + fn);
+        if (!isWrite) {
+            uint8_t h[48];
+            if (fread(h, 1, 48, file) != 48) throw std::runtime_error("DiagCacheStream: short header");
+            auto le = [&](int k) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)h[8 * k + i] << (8 * i); return v; };
+            vectorLen = le(0); level = le(1); uint64_t sb = le(2); memcpy(&scale, &sb, 8); n = le(3); numModuli = le(4); rowSize = le(5);
+            std::vector<uint8_t> tb(2 * d);
+            if (fread(tb.data(), 1, 2 * d, file) != (size_t)(2 * d)) throw std::runtime_error("DiagCacheStream: short tables");
+            babyTable.resize(d); giantTable.resize(d);
+            for (int i = 0; i < d; i++) { babyTable[i] = tb[i] != 0; giantTable[i] = tb[d + i] != 0; }
+            buf.resize(rowSize);
+        }
+    }
+    ~DiagCacheStream() { Close(); }
+    void SetIndexTables(const std::vector<bool> &b, const std::vector<bool> &g) { babyTable = b; giantTable = g; }   // :134-137
+    void WriteDiag(const PlainVector &pv, uint32_t shift, uint64_t level_, double scale_, uint64_t n_, uint64_t numModuli_) {   // :144-231
+        if (atHead) {
+            vectorLen = pv.pt.size(); level = level_; scale = scale_; n = n_; numModuli = numModuli_;
+            rowSize = 4 + (1 + n * numModuli * 8) * vectorLen;
+            if (babyTable.empty() || giantTable.empty()) throw std::runtime_error("babyTable or giantTable not set before attempting to write diag cache header");
+            uint8_t h[48]; uint64_t sb; memcpy(&sb, &scale, 8);
+            uint64_t f[6] = {vectorLen, level, sb, n, numModuli, rowSize};
+            for (int k = 0; k < 6; k++) for (int i = 0; i < 8; i++) h[8 * k + i] = (uint8_t)(f[k] >> (8 * i));
+            fwrite(h, 1, 48, file);
+            for (bool v : babyTable) fputc(v ? 1 : 0, file);
+            for (bool v : giantTable) fputc(v ? 1 : 0, file);
+            buf.resize(rowSize); atHead = false;
+        }
+        size_t ptr = 0;
+        for (int i = 0; i < 4; i++) buf[ptr++] = (uint8_t)(shift >> (8 * i));
+        for (size_t i = 0; i < pv.pt.size(); i++) {
+            buf[ptr++] = pv.empty[i] ? 1 : 0;
+            if (!pv.empty[i]) for (uint64_t w : pv.pt[i]) for (int b = 7; b >= 0; b--) buf[ptr++] = (uint8_t)(w >> (8 * b));
+        }
+        uint8_t l8[8]; for (int i = 0; i < 8; i++) l8[i] = (uint8_t)((uint64_t)ptr >> (8 * i));
+        fwrite(l8, 1, 8, file); fwrite(buf.data(), 1, ptr, file);
+    }
+    bool ReadDiag(PlainVector &pv, int &shift) {                     // :247-282; false at EOF (the Go version returns nil)
+        uint8_t l8[8];
+        if (!file || fread(l8, 1, 8, file) != 8) return false;
+        uint64_t len = 0; for (int i = 0; i < 8; i++) len |= (uint64_t)l8[i] << (8 * i);
+        if (len > rowSize || fread(buf.data(), 1, len, file) != len) return false;
+        shift = (int)((uint32_t)buf[0] | (uint32_t)buf[1] << 8 | (uint32_t)buf[2] << 16 | (uint32_t)buf[3] << 24);
+        size_t ptr = 4; pv.pt.assign(vectorLen, {}); pv.empty.assign(vectorLen, false);
+        for (uint64_t i = 0; i < vectorLen; i++) {
+            pv.empty[i] = buf[ptr++] == 1;
+            if (!pv.empty[i]) { pv.pt[i].resize(numModuli * n); for (auto &w : pv.pt[i]) { w = 0; for (int b = 0; b < 8; b++) w = (w << 8) | buf[ptr++]; } }
+        }
+        return true;
+    }
+    void Close() { if (file) { fclose(file); file = nullptr; } }
+};
+
+// ---------------------------------------------------------------- the products
+inline std::vector<uint64_t> flattenCipherMatrix(const crypto::CipherMatrix &A) {
+    std::vector<uint64_t> f;
+    for (auto &row : A) for (auto &ct : row) f.insert(f.end(), ct.data.begin(), ct.data.end());
+    return f;
+}
+inline crypto::CipherMatrix unflatten(const std::vector<uint64_t> &f, int s, int m_ct, int level, double scale, int N) {
+    crypto::CipherMatrix out(s, crypto::CipherVector(m_ct));
+    const size_t w = (size_t)2 * (level + 1) * N;
+    for (int i = 0; i < s; i++) for (int j = 0; j < m_ct; j++) {
+        auto &ct = out[i][j]; ct.level = level; ct.scale = scale;
+        ct.data.assign(f.begin() + ((size_t)i * m_ct + j) * w, f.begin() + ((size_t)i * m_ct + j + 1) * w);
+    }
+    return out;
+}
+inline std::vector<int8_t> readAllRows(GenoFileStream *gfs, uint64_t &nrow, uint64_t &ncol) {
+    gfs->Reset();                                                    // matmult.go:1239
+    nrow = gfs->NumRowsToKeep(); ncol = gfs->NumColsToKeep();
+    std::vector<int8_t> geno(nrow * ncol);
+    for (uint64_t r = 0; r < nrow; r++) { auto row = gfs->NextRow(); if (row.size() != ncol) throw std::runtime_error("GenoFileStream: unexpected row length"); memcpy(&geno[r * ncol], row.data(), ncol); }
+    return geno;
+}
+
+// matmult.go:1238.  Returns (out, sum, sqSum); sum/sqSum are empty unless computeSquaredSum.  The returned
+// ciphertexts are the deterministic product; the reference adds them onto CZeroMat (a fresh encryption of zero).
+inline std::tuple<crypto::CipherMatrix, std::vector<double>, std::vector<double>>
+MatMult4Stream(crypto::CryptoParams *cps, const crypto::CipherMatrix &A, GenoFileStream *gfs, int maxLevel, bool computeSquaredSum, bool square, int /*nproc*/) {
+    uint64_t nrow, ncol;
+    std::vector<int8_t> geno = readAllRows(gfs, nrow, ncol);
+    const int s = (int)A.size(), inLevel = A[0][0].Level(), slots = cps->GetSlots();
+    const double outScale = A[0][0].Scale() * cps->scale;            // :1247
+    const int m_ct = (int)((ncol - 1) / slots) + 1, numBlockRows = (int)((nrow - 1) / slots) + 1;   // :1253-1254
+    if ((int)A[0].size() != numBlockRows) throw std::runtime_error("MatMult4Stream: A has the wrong number of block rows");
+    std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());
+    std::vector<double> sum, sq;
+    if (computeSquaredSum) { sum.assign(ncol, 0); sq.assign(ncol, 0); }
+    cps->check(sfg_matmul_stream(cps->ctx, a.data(), s, inLevel, maxLevel, geno.data(), nrow, ncol, ncol, square ? SFG_SQUARE : 0u, o.data(),
+                                 computeSquaredSum ? sum.data() : nullptr, computeSquaredSum ? sq.data() : nullptr), "MatMult4Stream");
+    return {unflatten(o, s, m_ct, maxLevel - 1, outScale, cps->N()), sum, sq};
+}
+
+// matmult.go:914 / :1043.  The DiagCache files of the reference become an HBM-resident int8 matrix keyed by the
+// same cacheFilePrefix; `transposeOf` registers a prefix as the transpose of an already resident matrix, which is how
+// pca.go:112-113 (X cache, X^T cache) maps onto ONE resident copy.
+struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; };
+inline std::map<std::string, ResidentGeno> &residentTable() { static std::map<std::string, ResidentGeno> t; return t; }
+inline void MatMult4StreamPreprocess(crypto::CryptoParams *cps, GenoFileStream *gfs, int /*maxLevel*/, const std::string &cacheFilePrefix,
+                                     const std::string &transposeOf = "") {
+    auto &tab = residentTable();
+    if (tab.count(cacheFilePrefix)) return;                          // "Found cache file" (filestream.go:52-54): skip
+    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE}; return; }
+    uint64_t nrow, ncol; std::vector<int8_t> geno = readAllRows(gfs, nrow, ncol);
+    ResidentGeno r; cps->check(sfg_geno_upload(cps->ctx, geno.data(), nrow, ncol, ncol, &r.g), "MatMult4StreamPreprocess");
+    tab[cacheFilePrefix] = r;
+}
+inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, const crypto::CipherMatrix &A, int maxLevel, const std::string &cacheFilePrefix,
+                                                  int m_ct) {
+    auto it = residentTable().find(cacheFilePrefix);
+    if (it == residentTable().end()) throw std::runtime_error("MatMult4StreamCompute: no resident matrix for prefix " + cacheFilePrefix);   // os.Open panics (filestream.go:59-61)
+    const int s = (int)A.size(), inLevel = A[0][0].Level();
+    std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());
+    void *dA = nullptr, *dO = nullptr;
+    cps->check(sfg_malloc(cps->ctx, &dA, a.size() * 8), "MatMult4StreamCompute"); cps->check(sfg_malloc(cps->ctx, &dO, o.size() * 8), "MatMult4StreamCompute");
+    cps->check(sfg_memcpy_h2d(cps->ctx, dA, a.data(), a.size() * 8), "MatMult4StreamCompute");
+    int rc = sfg_matmul_resident_dev(cps->ctx, (const uint64_t *)dA, s, inLevel, maxLevel, it->second.g, it->second.flags, (uint64_t *)dO);
+    if (!rc) rc = sfg_memcpy_d2h(cps->ctx, o.data(), dO, o.size() * 8);
+    sfg_free(cps->ctx, dA); sfg_free(cps->ctx, dO);
+    cps->check(rc, "MatMult4StreamCompute");
+    return unflatten(o, s, m_ct, maxLevel - 1, A[0][0].Scale() * cps->scale, cps->N());
+}
+
+}  // namespace gwas
+
+namespace mpc {
+// mpc_core.RVec flattened: `limbs` little-endian 64-bit words per element (2 = LElem128, 4 = LElem256)
+struct RVec { int limbs = 2; std::vector<uint64_t> w; size_t size() const { return w.size() / limbs; } };
+struct MPC { crypto::CryptoParams *cps; int pid; std::vector<uint64_t> modulus; };
+// mpc/beavermult.go:108-133
+inline RVec BeaverMultElemVec(MPC *m, const RVec &ar, const RVec &am, const RVec &br, const RVec &bm) {
+    RVec out; out.limbs = am.limbs; out.w.resize(am.w.size());
+    m->cps->check(sfg_beaver_elem(m->cps->ctx, m->pid, am.limbs, m->modulus.data(), ar.w.data(), am.w.data(), br.w.data(), bm.w.data(), out.w.data(), am.size()), "BeaverMultElemVec");
+    return out;
+}
+// mpc/beavermult.go:135-147: (m x k) * (k x n)
+inline RVec BeaverMultMat(MPC *m, const RVec &ar, const RVec &am, const RVec &br, const RVec &bm, int rows, int inner, int cols) {
+    RVec out; out.limbs = am.limbs; out.w.resize((size_t)rows * cols * am.limbs);
+    m->cps->check(sfg_beaver_matmul(m->cps->ctx, m->pid, am.limbs, m->modulus.data(), ar.w.data(), am.w.data(), br.w.data(), bm.w.data(), out.w.data(), rows, inner, cols), "BeaverMultMat");
+    return out;
+}
+}  // namespace mpc

@@ -1,0 +1,98 @@
+"""The C++ host mirror of the reference's Go interface (sfgwas_amd/host/gwas.hpp): CPU logic tests for
+GenoFileStream / DiagCacheStream, and a GPU end-to-end test that calls MatMult4Stream, MatMult4StreamPreprocess,
+MatMult4StreamCompute and RotateRight the way the Go callers do."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "sfgwas_amd", "lib")
+
+
+def build(name):
+    src = os.path.join(ROOT, "tests", "host", name + ".cpp")
+    exe = os.path.join(ROOT, "tests", "host", "_build_" + name)
+    hdr = os.path.join(ROOT, "sfgwas_amd", "host", "gwas.hpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, src, "-L" + LIBDIR, "-lsfgwas_hip", "-Wl,-rpath," + LIBDIR,
+                               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_host_logic_and_diagcache_cross_read(tmp_path):
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_logic_test")
+    # a DiagCache file written by the ORACLE must decode identically through the mirror's reader
+    L = ol.lib()
+    d, n, nmod, vlen = 4, 8, 3, 2
+    path = str(tmp_path / "orc_0.bin").encode()
+    dc = L.orc_diagcache_create(path, d)
+    baby = np.array([1, 1, 0, 0], dtype=np.uint8); giant = np.array([1, 0, 0, 1], dtype=np.uint8)
+    L.orc_diagcache_set_tables(dc, baby.ctypes.data_as(C.POINTER(C.c_uint8)), giant.ctypes.data_as(C.POINTER(C.c_uint8)))
+    rnd = np.random.default_rng(4)
+    digest = (vlen * 1000 + 5 * 100 + nmod) & ((1 << 64) - 1)
+    for shift in [1, 5, 12]:
+        pv = [rnd.integers(0, 1 << 45, (nmod, n), dtype=np.uint64), None if shift == 5 else rnd.integers(0, 1 << 45, (nmod, n), dtype=np.uint64)]
+        arr = (ol.u64p * vlen)(*[ol.p64(p) if p is not None else None for p in pv])
+        L.orc_diagcache_write(dc, arr, vlen, 5, 2.0 ** 34, n, nmod, shift)
+        digest = (digest * 31 + shift) & ((1 << 64) - 1)
+        for p in pv:
+            if p is not None:
+                for w in p.reshape(-1):
+                    digest = (digest * 1099511628211 + int(w)) & ((1 << 64) - 1)
+    L.orc_diagcache_close(dc)
+    out = subprocess.run([exe, str(tmp_path), str(tmp_path / "orc")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "OK" in out.stdout
+    assert f"DIGEST {digest}" in out.stdout
+
+
+@pytest.mark.gpu
+def test_host_mirror_matmul_end_to_end(tmp_path):
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_gpu_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rnd = np.random.default_rng(21)
+    nrow, ncol, s, level, L, square = 45, 33, 2, 5, 5, 0
+    geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+    geno.tofile(tmp_path / "geno.bin")
+    slots, d = 8192, 91
+    steps = set()
+    for (r, c) in [(nrow, ncol), (ncol, nrow)]:
+        for sh in list(range(r)) + list(range(slots - c + 1, slots)):
+            if sh % d:
+                steps.add(sh % d)
+            if sh // d:
+                steps.add((sh // d) * d)
+    steps.add(slots - 1)                                   # RotateRight(ct, 1) = RotateNew(ct, slots - 1)
+    blob = [np.array([len(steps)], dtype=np.uint64)]
+    for k in sorted(steps):
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 300 + k)
+        keys.add(g, key)
+        blob += [np.array([g], dtype=np.uint64), key.reshape(-1)]
+    np.concatenate(blob).tofile(tmp_path / "keys.bin")
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    A = np.stack([np.stack([ring.fill_uniform(level, 50 + i)]) for i in range(s)])
+    AT = np.stack([np.stack([ring.fill_uniform(level, 70 + i)]) for i in range(s)])
+    A.tofile(tmp_path / "A.bin"); AT.tofile(tmp_path / "AT.bin")
+    (tmp_path / "case.txt").write_text(f"{nrow} {ncol} {s} {level} {L} {square}\n")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr
+    want, wsm, wsq = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, L, geno, compute_sqsum=True)
+    got = np.fromfile(tmp_path / "out_stream.bin", dtype=np.uint64).reshape(want.shape)
+    assert np.array_equal(got, want)
+    sums = np.fromfile(tmp_path / "sums.bin", dtype=np.float64)
+    assert np.array_equal(sums[:ncol], wsm) and np.array_equal(sums[ncol:], wsq)
+    want_t, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, AT, level, L, np.ascontiguousarray(geno.T))
+    got_t = np.fromfile(tmp_path / "out_xt.bin", dtype=np.uint64).reshape(want_t.shape)
+    assert np.array_equal(got_t, want_t)
+    rot = np.fromfile(tmp_path / "rot.bin", dtype=np.uint64).reshape(A[0, 0].shape)
+    assert np.array_equal(rot, ol.rotate_right(ring, keys, level, A[0, 0], 1))
