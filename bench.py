@@ -113,9 +113,10 @@ def main():
             ms = ctx.phase_ms(ph)
             if ms >= 0:
                 n = lib.sfg_last_phase_launches(ctx.h, ph.encode())
-                a = phase_tot.setdefault(ph, [0.0, 0])
+                a = phase_tot.setdefault(ph, [0.0, 0, 0.0])
                 a[0] += ms
                 a[1] += n
+                a[2] += max(lib.sfg_last_phase_bytes(ctx.h, ph.encode()), 0.0)
 
     def step():
         # (1) Q * X : output block columns of this rank
@@ -169,25 +170,28 @@ def main():
     }
     if rank == 0:
         # ---- roofline of the dominant kernel (k_mac, small-modulus instance): algorithmic bytes per launch / avg duration
-        ms_small, n_small = phase_tot.get("mac_small", [0.0, 0])
+        ms_small, n_small, by_small = phase_tot.get("mac_small", [0.0, 0, 0.0])
         if n_small:
-            nl_small = L - 1                                               # moduli 1..4 are the 35/36-bit primes
-            # algorithmic bytes of one launch (one 8192^2 block, K = 91 baby steps, 30 rows, 91 giant columns):
-            # fp64 rot operand + half-row plaintexts (P[N-1-c] = P[c]) + accumulators read and written
-            per_launch = (D * 2 * KP * N + D * D * (N // 2) + 2 * D * 2 * KP * N) * nl_small * 8
+            # dominant kernel = k_mac_dma<false> (the four 35/36-bit moduli).  Algorithmic bytes are reported by the library
+            # per launch (fp64 rot operand + half-row plaintexts + accumulators); a launch covers up to 8 block
+            # rows x 1 block column, so bytes and duration are averaged over the launches of the timed region.
             avg_ms = ms_small / n_small
-            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            per_launch = by_small / n_small
+            achieved = by_small / (ms_small * 1e-3) / 1e9
             traffic = None
-            try:        # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+            try:        # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_launch.json")))
-                traffic = pm["void k_mac_dma<false>"]["hbm_bytes_per_launch"]
+                if pm.get("_config") == args.config:
+                    traffic = pm["void k_mac_dma<false>"]["hbm_bytes_per_launch"]
             except Exception:
                 pass
+            nl_small = L - 1
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "k_mac_dma<false>", "avg_launch_ms": avg_ms, "launches": n_small,
                                "alg_bytes_per_launch": per_launch,
-                               "macs_per_s_in_kernel": D * D * 2 * KP * nl_small * N / (avg_ms * 1e-3)}
+                               "padded_ring_macs_per_s_in_kernel": 2 * ceil_div(n_ind, SLOTS) * ceil_div(m_snp, SLOTS) * D * D * 2 * KP * nl_small * N
+                                                                   * args.steps / (ms_small * 1e-3)}
         res["phases_ms_per_step"] = {k: v[0] / args.steps for k, v in phase_tot.items()}
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

@@ -156,6 +156,8 @@ int sfg_fill_rotkeys_synthetic(sfg_ctx *ctx, const int *rot_left, int nrot, uint
 int sfg_ctx_clear_phases(sfg_ctx *ctx);
 double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase);
 int sfg_last_phase_launches(const sfg_ctx *ctx, const char *phase);
+/* algorithmic bytes (operands read once + results written once, as laid out in HBM) credited to the phase's launches */
+double sfg_last_phase_bytes(const sfg_ctx *ctx, const char *phase);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ def _sig(L):
         "sfg_ctx_clear_phases": (i, [vp]),
         "sfg_last_phase_ms": (d, [vp, C.c_char_p]),
         "sfg_last_phase_launches": (i, [vp, C.c_char_p]),
+        "sfg_last_phase_bytes": (d, [vp, C.c_char_p]),
     }
     for name, (res, args) in S.items():
         fn = getattr(L, name)         # AttributeError here = the library does not export a declared symbol

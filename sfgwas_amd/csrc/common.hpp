@@ -30,8 +30,8 @@ struct RotKey {
     uint16_t *index_dev = nullptr; // automorphism index map (N entries)
 };
 
-struct PhaseStat { double ms = 0; int launches = 0; };
-struct PendingEvent { hipEvent_t e0, e1; std::string name; int launches; };
+struct PhaseStat { double ms = 0; int launches = 0; double bytes = 0; };   // bytes = algorithmic bytes credited to the phase
+struct PendingEvent { hipEvent_t e0, e1; std::string name; int launches; double bytes; };
 
 struct sfg_geno {
     const int8_t *dev = nullptr;
@@ -93,10 +93,10 @@ struct PhaseTimer {
     PhaseTimer(sfg_ctx *c, const char *n, bool enable = true) : ctx(c), name(n), on(enable) {
         if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, ctx->stream); }
     }
-    void stop(int launches = 1) {
+    void stop(int launches = 1, double bytes = 0) {
         if (!on) return;
         (void)hipEventRecord(e1, ctx->stream);
-        ctx->pending.push_back(PendingEvent{e0, e1, name, launches});
+        ctx->pending.push_back(PendingEvent{e0, e1, name, launches, bytes});
         on = false;
         if (ctx->pending.size() > 4096) sfg_phases_resolve(ctx);
     }

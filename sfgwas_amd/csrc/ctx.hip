@@ -131,7 +131,7 @@ void sfg_phases_resolve(sfg_ctx *ctx) {
     (void)hipEventSynchronize(ctx->pending.back().e1);
     for (auto &p : ctx->pending) {
         float ms = 0; (void)hipEventSynchronize(p.e1); (void)hipEventElapsedTime(&ms, p.e0, p.e1);
-        auto &st = ctx->phases[p.name]; st.ms += ms; st.launches += p.launches;
+        auto &st = ctx->phases[p.name]; st.ms += ms; st.launches += p.launches; st.bytes += p.bytes;
         (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
     }
     ctx->pending.clear();
@@ -152,6 +152,10 @@ extern "C" int sfg_ctx_clear_phases(sfg_ctx *ctx) { sfg_phases_resolve(ctx); ctx
 extern "C" double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase) {
     sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));
     auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1.0 : it->second.ms;
+}
+extern "C" double sfg_last_phase_bytes(const sfg_ctx *ctx, const char *phase) {
+    sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));
+    auto it = ctx->phases.find(phase); return it == ctx->phases.end() ? -1.0 : it->second.bytes;
 }
 extern "C" int sfg_last_phase_launches(const sfg_ctx *ctx, const char *phase) {
     sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));

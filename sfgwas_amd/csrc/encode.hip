@@ -285,7 +285,8 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 }
 
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows) {
+// half_rows + G > 0: `pt` is the base of a grouped panel and rows are scattered by PanelMap (half rows only)
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g) {
     EncTables *et = (EncTables *)ctx->enc_tables;
     static bool attr = false;
     const size_t lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
@@ -304,7 +305,8 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
                                ctx->scale / (double)SFG_SLOTS, et->pc);
             SFG_HIP(ctx, hipGetLastError());
         }
-        if (half_rows) SFG_TRY(launch_ntt_plain_half(ctx, et->pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L));
+        if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0}; SFG_TRY(launch_ntt_plain_half(ctx, et->pc, pt, nb, L, pm)); }
+        else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, et->pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, et->pc, pt + (size_t)s0 * L * SFG_N, nb, L));
     }
     return 0;

@@ -7,12 +7,16 @@
 struct ModPattern { int period; int8_t m[64]; };
 // row r of a launch lives at base + (r / rpg) * gstride + (r % rpg) * N  (strides in words)
 struct RowMap { int rpg; size_t gstride_in, gstride_out; };
+// where the plaintext of diagonal `shift` (= shift0 + index in the batch) of block row g lands inside a panel that holds G
+// block rows: slot ((shift / 91) * G + g) * 91 + shift % 91, i.e. [giant][g][baby] so that k = g*91 + baby is contiguous.
+// G == 0: dense (slot = index in the batch)
+struct PanelMap { int G, g, shift0; };
 
 // ntt.hip
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain, int L);
-int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L);
+int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L, PanelMap pm);
 int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
@@ -22,7 +26,7 @@ int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int
 int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
 // encode.hip
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D);
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false);
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0);
 // rotate.hip
 int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host);
 int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index);

@@ -310,7 +310,11 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             if (big) hipLaunchKernelGGL(k_mac_dma<true>, grid, dim3(DM_THREADS), 3 * 48 * 1024, ctx->stream, a, ctx->modc);
             else hipLaunchKernelGGL(k_mac_dma<false>, grid, dim3(DM_THREADS), 4 * 32 * 1024, ctx->stream, a, ctx->modc);
             SFG_HIP(ctx, hipGetLastError());
-            t.stop(1);
+            {   // algorithmic bytes of this launch: fp64 rot operand + plaintext words + accumulators written (and read when accumulating)
+                const double nlm = (double)(e - l), rw = big ? 2.0 : 1.0, pw = st.pt_half ? 0.5 : 1.0;
+                const double bytes = ((double)K * R * rw + (double)K * Ncols * pw + (double)Ncols * R * (accumulate ? 2.0 : 1.0)) * nlm * N * 8.0;
+                t.stop(1, bytes);
+            }
             l = e;
         }
     }

@@ -130,90 +130,104 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     if (b0 < 0 || b1 > sh.nbr || b0 > b1 || j0 < 0 || j1 > sh.m_ct || j0 > j1) SFG_FAIL(ctx, "matmul: block range out of bounds");
     const size_t ctw = (size_t)2 * nl * N, accw = (size_t)s * 2 * L * N;
     const int ncolb = j1 - j0;
-    if (!accumulate) SFG_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ncolb * d * accw * 8, ctx->stream));
-    if (b0 == b1 || j0 == j1) return 0;
-    // scratch: level-dropped inputs of one block row, rotation cache of one block row, plaintext panel of one block
-    const size_t nplain = (size_t)d * d;                         // 8281 >= 8192: the tail stays zero
-    u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr;
+    if (b0 == b1 || j0 == j1) { if (!accumulate) SFG_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ncolb * d * accw * 8, ctx->stream)); return 0; }
+    const bool dma = mac_use_dma();                          // LDS-DMA MAC: half-row plaintexts, fp64 rot operand, block-row groups
+    const size_t prow = dma ? (size_t)N / 2 : (size_t)N;     // words per plaintext modulus row
+    // G block rows share one MAC launch (K = G*91): accumulators are written once per group instead of
+    // read-modify-written per block.  Bounded by scratch: ~4.9 GB per block row at s = 15.
+    int G = 1;
+    if (dma) { const char *e = getenv("SFG_MM_GROUP"); G = e ? atoi(e) : 8; if (G < 1) G = 1; if (G > b1 - b0) G = b1 - b0; }
+    const size_t nplain = (size_t)d * d;                     // 8281 >= 8192 slots per block row: the tail stays zero
+    u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr; size_t rowf = 0;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
-    const bool half = mac_use_dma();                       // half-row plaintext panel (P[N-1-c] = P[c]); the register-staged kernel wants full rows
-    const size_t prow = half ? (size_t)N / 2 : (size_t)N;    // words per plaintext modulus row
-    SFG_TRY(sfg_scratch(ctx, "mm.pt", nplain * L * prow * 8, (void **)&pt));
-    auto cleanup = [&]() {};
-    int8_t *skew = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "mm.pt", (size_t)G * nplain * L * prow * 8, (void **)&pt));
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
-    // fp64 operand form of the rotation cache for the LDS-DMA MAC kernel
-    double *rotf = nullptr; size_t rowf = 0;
-    if (mac_use_dma()) {
+    if (dma) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
-        SFG_TRY(sfg_scratch(ctx, "mm.rotf", (size_t)d * s * 2 * rowf * 8, (void **)&rotf));
+        SFG_TRY(sfg_scratch(ctx, "mm.rotf", (size_t)G * d * s * 2 * rowf * 8, (void **)&rotf));
     }
+    const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
-    std::vector<int> nrot((size_t)d * s);
-    for (int bi = b0; bi < b1 && !rc; bi++) {
-        const int nr = sh.rows_of(bi);
-        // active tables (matmult.go:1326-1336), union over ALL block columns of the operand as in the reference
-        std::vector<uint8_t> baby_t(d, 0), giant_t(d, 0);
-        for (int shift = 0; shift < SFG_SLOTS; shift++) {
-            bool any = false;
-            for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
-            if (any) { baby_t[shift % d] = 1; giant_t[shift / d] = 1; }
-        }
-        // A[i][bi] at the dropped level, contiguous over i
-        for (int i = 0; i < s && !rc; i++) {
-            const u64 *src = A + ((size_t)i * sh.nbr + bi) * 2 * nl_in * N;
-            if (nl == nl_in) { if (hipMemcpyAsync(a_row + (size_t)i * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = 1; }
-            else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_row + (size_t)i * ctw, nl_in, nl);
-        }
-        if (rc) { ctx->err = "matmul: staging of A failed"; break; }
-        // rotation cache: rotc[baby][i] = RotateRight(A[i][bi], -baby) (matmult.go:1373-1377); inactive babies are never read
-        {
-            PhaseTimer t(ctx, "rotate");
-            // one batch over (baby, i): every baby re-uses the decomposition of the same s inputs
-            std::vector<int> nrv((size_t)d * s, 0), inv((size_t)d * s, 0);
-            for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) { nrv[(size_t)baby * s + i] = baby_t[baby] ? -baby : 0; inv[(size_t)baby * s + i] = i; }
-            rc = launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data());
-            t.stop(1);
-        }
-        if (rc) break;
-        if (rotf) { rc = launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf); if (rc) break; }
-        for (int bj = j0; bj < j1 && !rc; bj++) {
-            const int nc = sh.cols_of(bj);
-            {
-                PhaseTimer t(ctx, "skew");
-                rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
+    bool first_group = true;
+    for (int bg = b0; bg < b1 && !rc; bg += G) {
+        const int ng = std::min(G, b1 - bg);
+        // ---- rotation caches of the group's block rows
+        for (int g = 0; g < ng && !rc; g++) {
+            const int bi = bg + g, nr = sh.rows_of(bi);
+            // active baby steps (matmult.go:1326-1336), union over ALL block columns of the operand as in the reference
+            std::vector<uint8_t> baby_t(d, 0);
+            for (int shift = 0; shift < SFG_SLOTS; shift++) {
+                if (baby_t[shift % d]) continue;
+                bool any = false;
+                for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
+                if (any) baby_t[shift % d] = 1;
+            }
+            for (int i = 0; i < s && !rc; i++) {                  // A[i][bi] at the dropped level, contiguous over i
+                const u64 *src = A + ((size_t)i * sh.nbr + bi) * 2 * nl_in * N;
+                if (nl == nl_in) { if (hipMemcpyAsync(a_row + (size_t)i * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = 1; }
+                else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_row + (size_t)i * ctw, nl_in, nl);
+            }
+            if (rc) { ctx->err = "matmul: staging of A failed"; break; }
+            {   // rotc[baby][i] = RotateRight(A[i][bi], -baby) (matmult.go:1373-1377); one batch, decomposition shared per input
+                PhaseTimer t(ctx, "rotate");
+                std::vector<int> nrv((size_t)d * s, 0), inv((size_t)d * s, 0);
+                for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) { nrv[(size_t)baby * s + i] = baby_t[baby] ? -baby : 0; inv[(size_t)baby * s + i] = i; }
+                rc = launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data());
                 t.stop(1);
             }
             if (rc) break;
-            // existing diagonals of this block form at most two runs of shifts: [0, nr) and (n - nc, n)  (GetDiagBool)
-            int runs[2][2]; int nruns = 0;
-            if (nr >= SFG_SLOTS || nc >= SFG_SLOTS || nr + nc > SFG_SLOTS) { runs[0][0] = 0; runs[0][1] = SFG_SLOTS; nruns = 1; }
-            else { runs[0][0] = 0; runs[0][1] = nr; runs[1][0] = SFG_SLOTS - nc + 1; runs[1][1] = SFG_SLOTS; nruns = 2; if (runs[1][0] >= runs[1][1]) nruns = 1; }
-            if (nruns == 2 || runs[0][1] - runs[0][0] < SFG_SLOTS) SFG_HIP(ctx, hipMemsetAsync(pt, 0, nplain * L * prow * 8, ctx->stream));
-            else SFG_HIP(ctx, hipMemsetAsync(pt + (size_t)SFG_SLOTS * L * prow, 0, (nplain - SFG_SLOTS) * L * prow * 8, ctx->stream));
-            {
-                PhaseTimer t(ctx, "encode");
-                for (int r = 0; r < nruns && !rc; r++)
-                    rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * L * prow, half);
-                t.stop(nruns);
+            if (dma) rc = launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf + (size_t)g * d * s * 2 * rowf);
+        }
+        if (rc) break;
+        for (int bj = j0; bj < j1 && !rc; bj++) {
+            const int nc = sh.cols_of(bj);
+            for (int g = 0; g < ng && !rc; g++) {
+                const int bi = bg + g, nr = sh.rows_of(bi);
+                {
+                    PhaseTimer t(ctx, "skew");
+                    rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
+                    t.stop(1);
+                }
+                if (rc) break;
+                // existing diagonals of this block form at most two runs of shifts: [0, nr) and (n - nc, n)  (GetDiagBool)
+                int runs[2][2]; int nruns = 0;
+                if (nr + nc > SFG_SLOTS) { runs[0][0] = 0; runs[0][1] = SFG_SLOTS; nruns = 1; }
+                else { runs[0][0] = 0; runs[0][1] = nr; runs[1][0] = SFG_SLOTS - nc + 1; runs[1][1] = SFG_SLOTS; nruns = runs[1][0] < runs[1][1] ? 2 : 1; }
+                const bool full = nruns == 1 && runs[0][1] - runs[0][0] == SFG_SLOTS;
+                // zero what the encoder will not write: plaintext slot of (giant, g, baby) is ((giant*ng + g)*91 + baby)
+                if (full) {        // only the 89 slots past shift 8191 (giant 90, baby 2..90)
+                    SFG_HIP(ctx, hipMemsetAsync(pt + (((size_t)(d - 1) * ng + g) * d + (SFG_SLOTS - (d - 1) * d)) * plw, 0, (nplain - SFG_SLOTS) * plw * 8, ctx->stream));
+                } else {           // ragged block: all 91 x 91 slots of this block row
+                    SFG_HIP(ctx, hipMemset2DAsync(pt + (size_t)g * d * plw, (size_t)ng * d * plw * 8, 0, (size_t)d * plw * 8, d, ctx->stream));
+                }
+                {
+                    PhaseTimer t(ctx, "encode");
+                    for (int r = 0; r < nruns && !rc; r++) {
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g);
+                        else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
+                    }
+                    t.stop(nruns);
+                }
             }
             if (rc) break;
             {
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = (size_t)L * prow; st.pt_n = (size_t)d * L * prow; st.pt_half = half;   // pt[giant*d + baby]
+                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
-                if (rotf) rc = launch_mac_dma(ctx, rotf, (size_t)s * 2, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
-                else rc = launch_mac_strided(ctx, rotc, pt, acc + (size_t)(bj - j0) * d * accw, d, 2 * s, d, L, 1, st);
+                const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
+                u64 *accj = acc + (size_t)(bj - j0) * d * accw;
+                if (dma) rc = launch_mac_dma(ctx, rotf, (size_t)s * 2, pt, accj, ng * d, 2 * s, d, L, acc_flag, st);
+                else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
                 t.stop(1);
             }
         }
+        first_group = false;
     }
-    cleanup();
     return rc;
 }
 

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
 // r_0 = p_0) and runs stages 2..14 on those n = N/2 values only: half the butterflies, half the LDS (two
 // workgroups per CU), and it emits half rows P[0..n).  256 threads, j = a*512 + b*16 + c with a < 16.
 constexpr int HLDS_DOUBLES = 16 * LDS_ROW;   // 67,584 B
-__global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *out_, int L, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+__global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     const size_t row = blockIdx.x;
@@ -296,7 +296,10 @@ __global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *
         for (int c = 0; c < 16; c++) lds[a * LDS_ROW + c * 33 + b] = v[h * 16 + c];
     }
     __syncthreads();
-    u64 *out = out_ + row * (size_t)n;
+    // destination plaintext slot inside a (possibly multi-block-row) panel: see PanelMap
+    const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
+    const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
+    u64 *out = out_ + (dst * L + m) * (size_t)n;
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         const int j = k * 256 + tid, a = j >> 9, x = j & 511, b = x >> 4, c = x & 15;
@@ -341,10 +344,10 @@ int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain,
     return 0;
 }
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
-int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L) {
+int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L, PanelMap pm) {
     if (!nplain) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
