@@ -1,0 +1,158 @@
+"""Size-independent properties of the GPU product at multi-block sizes (several full 8192 x 8192 blocks), where
+the CPU oracle would take hours.  All checks are bit-exact self-consistency of the HIP path:
+  * block-row grouping (K fusion) does not change any output word;
+  * the LDS-DMA and the register-staged MAC kernels agree;
+  * computing block-column ranges separately and concatenating equals the full product (output sharding);
+  * accumulate over block-row ranges, summed mod q, then finalize equals the one-shot product (contraction sharding);
+  * an all-zero / all-missing genotype matrix gives the zero ciphertext;
+  * X^T through SFG_TRANSPOSE equals the product with an explicitly transposed upload."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SLOTS, D, N, L, LEVEL = 8192, 91, 16384, 5, 5
+
+
+class Env:
+    def __init__(self):
+        from sfgwas_amd import capi
+        self.capi = capi
+        self.ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+        self.lib = capi.lib()
+        rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < SLOTS]
+        arr = (C.c_int * len(rots))(*rots)
+        self.ctx.check(self.lib.sfg_fill_rotkeys_synthetic(self.ctx.h, arr, len(rots), 0xBEEF), "keys")
+
+    def geno(self, nrow, ncol, seed, host=None):
+        gh = C.c_void_p()
+        if host is not None:
+            host = np.ascontiguousarray(host, dtype=np.int8)
+            self.ctx.check(self.lib.sfg_geno_upload(self.ctx.h, host.ctypes.data_as(C.c_void_p), nrow, ncol, ncol, C.byref(gh)), "upload")
+            return gh, None
+        d = self.ctx.malloc(nrow * ncol)
+        self.ctx.check(self.lib.sfg_fill_geno_dev(self.ctx.h, d, nrow, ncol, seed), "fill")
+        self.ctx.check(self.lib.sfg_geno_from_device(self.ctx.h, d, nrow, ncol, ncol, C.byref(gh)), "geno")
+        return gh, d
+
+    def cts(self, n, seed):
+        d = self.ctx.malloc(n * 2 * (LEVEL + 1) * N * 8)
+        self.ctx.check(self.lib.sfg_fill_uniform_ct_dev(self.ctx.h, d, n, LEVEL, seed), "fill ct")
+        return d
+
+    def product(self, A, s, gh, flags, m_out, blk=None):
+        out = self.ctx.malloc(s * m_out * 2 * L * N * 8)
+        if blk is None:
+            self.ctx.check(self.lib.sfg_matmul_resident_dev(self.ctx.h, A, s, LEVEL, L, gh, flags, out), "matmul")
+        else:
+            self.ctx.check(self.lib.sfg_matmul_resident_range_dev(self.ctx.h, A, s, LEVEL, L, gh, flags, blk[0], blk[1], out), "range")
+        h = self.ctx.to_host(out, (s, m_out, 2, L, N), np.uint64)
+        self.ctx.free(out)
+        return h
+
+
+@pytest.fixture(scope="module")
+def env():
+    e = Env()
+    yield e
+    e.ctx.close()
+
+
+def test_range_concat_and_accumulate_finalize(env):
+    s, nrow, ncol = 2, 2 * SLOTS + 100, 2 * SLOTS            # 3 block rows x 2 block cols
+    gh, gd = env.geno(nrow, ncol, 5)
+    nbr, m_ct = 3, 2
+    A = env.cts(s * nbr, 11)
+    full = env.product(A, s, gh, 0, m_ct)
+    # output sharding: block columns computed separately
+    parts = [env.product(A, s, gh, 0, 1, blk=(j, j + 1)) for j in range(m_ct)]
+    assert np.array_equal(np.concatenate(parts, axis=1), full)
+    # contraction sharding: accumulate two block-row ranges separately, add mod q, finalize
+    accw = m_ct * D * s * 2 * L * N
+    acc = [env.ctx.malloc(accw * 8) for _ in range(2)]
+    for k, (b0, b1) in enumerate([(0, 1), (1, 3)]):
+        env.ctx.check(env.lib.sfg_matmul_accumulate_dev(env.ctx.h, A, s, LEVEL, L, gh, 0, b0, b1, 0, m_ct, 0, acc[k]), "acc")
+    h = [env.ctx.to_host(a, (m_ct, D, s, 2, L, N), np.uint64) for a in acc]
+    tot = h[0] + h[1]                                          # < 2^47: no overflow
+    for l in range(L):
+        tot[..., l, :] %= np.uint64(ol.Q_PN14[l])
+    env.ctx.check(env.lib.sfg_memcpy_h2d(env.ctx.h, acc[0], tot.ctypes.data_as(C.c_void_p), tot.nbytes), "h2d")
+    out = env.ctx.malloc(s * m_ct * 2 * L * N * 8)
+    env.ctx.check(env.lib.sfg_matmul_finalize_dev(env.ctx.h, acc[0], s, L, m_ct, 0, D, 0, out), "fin")
+    two_phase = env.ctx.to_host(out, (s, m_ct, 2, L, N), np.uint64)
+    assert np.array_equal(two_phase, full)
+    # also: summing un-reduced accumulators on the device and reducing there
+    env.ctx.check(env.lib.sfg_memcpy_h2d(env.ctx.h, acc[1], (h[0] + h[1]).ctypes.data_as(C.c_void_p), tot.nbytes), "h2d")
+    env.ctx.check(env.lib.sfg_reduce_rows_dev(env.ctx.h, acc[1], m_ct * D * s * 2, L), "reduce")
+    assert np.array_equal(env.ctx.to_host(acc[1], tot.shape, np.uint64), tot)
+    for p in acc + [out, A]:
+        env.ctx.free(p)
+    env.lib.sfg_geno_free(env.ctx.h, gh)
+    env.ctx.free(gd)
+
+
+def test_transpose_flag_equals_explicit_transpose(env):
+    rnd = np.random.default_rng(9)
+    X = rnd.integers(-1, 3, (SLOTS + 37, 300)).astype(np.int8)
+    s = 1
+    gh, _ = env.geno(X.shape[0], X.shape[1], 0, host=X)
+    ght, _ = env.geno(X.shape[1], X.shape[0], 0, host=X.T)
+    A = env.cts(s * 1, 3)                                     # operand X^T: 300 rows -> 1 block row
+    a = env.product(A, s, gh, env.capi.SFG_TRANSPOSE, 2)
+    b = env.product(A, s, ght, 0, 2)
+    assert np.array_equal(a, b)
+    env.ctx.free(A)
+    env.lib.sfg_geno_free(env.ctx.h, gh)
+    env.lib.sfg_geno_free(env.ctx.h, ght)
+
+
+def test_zero_and_all_missing_matrix_give_zero(env):
+    s = 2
+    for fill in (0, -1):
+        X = np.full((700, SLOTS + 5), fill, dtype=np.int8)
+        gh, _ = env.geno(X.shape[0], X.shape[1], 0, host=X)
+        A = env.cts(s, 17)
+        out = env.product(A, s, gh, 0, 2)
+        assert not out.any()
+        env.ctx.free(A)
+        env.lib.sfg_geno_free(env.ctx.h, gh)
+
+
+_CHILD = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as ol
+from sfgwas_amd import capi
+ctx = capi.Context(ol.Q_PN14, ol.P_PN14); lib = capi.lib()
+D, N, L, LEVEL = 91, 16384, 5, 5
+rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < 8192]
+ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(rots))(*rots), len(rots), 0xBEEF), 'keys')
+nrow, ncol, s = 3 * 8192 - 11, 8192 + 9, 2
+g = ctx.malloc(nrow * ncol); ctx.check(lib.sfg_fill_geno_dev(ctx.h, g, nrow, ncol, 77), 'g')
+gh = C.c_void_p(); ctx.check(lib.sfg_geno_from_device(ctx.h, g, nrow, ncol, ncol, C.byref(gh)), 'gh')
+A = ctx.malloc(s * 3 * 2 * 6 * N * 8); ctx.check(lib.sfg_fill_uniform_ct_dev(ctx.h, A, s * 3, LEVEL, 5), 'A')
+out = ctx.malloc(s * 2 * 2 * L * N * 8)
+ctx.check(lib.sfg_matmul_resident_dev(ctx.h, A, s, LEVEL, L, gh, 0, out), 'mm')
+h = ctx.to_host(out, (s, 2, 2, L, N), np.uint64)
+np.save(sys.argv[1], h)
+"""
+
+
+def test_group_size_and_mac_kernel_invariance(tmp_path):
+    """the same product in three separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8 and the register-staged MAC"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"})]:
+        f = str(tmp_path / (name + ".npy"))
+        e = dict(os.environ); e.update(envv)
+        r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1]), "block-row grouping changed the result"
+    assert np.array_equal(outs[0], outs[2]), "LDS-DMA and register-staged MAC kernels disagree"
+    assert outs[0].any()
