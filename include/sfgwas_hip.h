@@ -87,6 +87,26 @@ int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *ct_in_dev, uint64_t *ct_o
                          const int *nrot_host);
 /* C4: element-wise ciphertext add (eval.Add, basics.go:174, matmult.go:1225,1494): out = a + b */
 int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
+/* C4: eval.Sub (crypto.CSub, basics.go:575-590): out = a - b */
+int sfg_ct_sub_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
+
+/* ---- C3: ciphertext products (crypto.CMult / CPMult / Mask, basics.go:110-172, 386-470) ----
+ * The relinearisation key (cryptoParams.Rlk, crypto.go:47) has the same layout as a rotation key:
+ * [beta][2][nq+np][N], montgomery != 0 if in lattigo's stored Montgomery form. */
+int sfg_ctx_load_relinkey(sfg_ctx *ctx, const uint64_t *key_host, int montgomery);
+/* eval.MulRelinNew(a, b): degree-2 tensor product + relinearisation, batch of nct pairs; level unchanged, scale = product.
+ * No rescale (call sfg_ct_rescale_dev, as CMult does at basics.go:394). out may alias neither input. */
+int sfg_ct_mulrelin_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
+/* eval.MulRelinNew(plaintext, ct): both polynomials times an NTT-domain plaintext [level+1][N]; ct j uses
+ * pt_dev + j*pt_stride words (pt_stride 0 = one plaintext for all, e.g. a Mask). out may alias ct. */
+int sfg_ct_mul_plain_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *pt_dev, size_t pt_stride, uint64_t *out_dev,
+                         int nct, int level);
+/* one step of eval.Rescale = ring.DivRoundByLastModulusNTT on both polynomials: in [nct][2][level+1][N] ->
+ * out [nct][2][level][N] (level-1); the caller divides the scale by q_level. Fails at level 0 like lattigo. */
+int sfg_ct_rescale_dev(sfg_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int nct, int level);
+/* C2: crypto.InnerSumAll (basics.go:278-292): sum of the nct ciphertexts and of all their slots, in every slot of the one
+ * output ciphertext. Needs the rotation keys for left rotations by 1,2,4,..,slots/2. */
+int sfg_ct_innersum_dev(sfg_ctx *ctx, const uint64_t *in_dev, int nct, int level, uint64_t *out_dev);
 
 /* ---- F1 + A11: genotype matrix residency (replaces GenoFileStream reads + the DiagCache of
  * MatMult4StreamPreprocess, matmult.go:914-1041; filestream.go:284-494).

@@ -473,6 +473,99 @@ int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, cons
     return orc_rotate_left(r, keys, level, ct, nrot ? n - nrot : 0, out);
 }
 
+/* ------------------------------------------------------------------ remaining crypto/basics.go evaluator ops (C2-C4)
+ * lattigo ckks.Evaluator restated.  ct layout [2][level+1][N], NTT domain, canonical. */
+/* eval.Add / eval.Sub (basics.go:174,568,580; matmult.go:56) */
+void orc_ct_addsub(const orc_ring *r, int level, const u64 *a, const u64 *b, int sub, u64 *out) {
+    int N = r->N, nl = level + 1;
+    for (int p = 0; p < 2; p++) for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m]; size_t off = ((size_t)p * nl + m) * N;
+        for (int x = 0; x < N; x++) { u64 v = sub ? (a[off + x] >= b[off + x] ? a[off + x] - b[off + x] : a[off + x] + q - b[off + x]) : a[off + x] + b[off + x]; if (v >= q) v -= q; out[off + x] = v; }
+    }
+}
+/* eval.MulRelinNew(ct0, ct1) (basics.go:229,393,439): degree-2 tensor product, then relinearisation = key switch of the
+ * c2 term with the relinearisation key (s^2 -> s), added onto (c0, c1).  No rescale here. */
+void orc_mulrelin(const orc_ring *r, int level, const u64 *a, const u64 *b, const u64 *rlk, u64 *out) {
+    int N = r->N, nl = level + 1; size_t pw = (size_t)nl * N;
+    u64 *c2 = malloc(8 * pw), *d0 = malloc(8 * pw), *d1 = malloc(8 * pw);
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m];
+        for (int x = 0; x < N; x++) {
+            size_t i = (size_t)m * N + x;
+            u64 a0 = a[i], a1 = a[pw + i], b0 = b[i], b1 = b[pw + i];
+            out[i] = orc_mulmod(a0, b0, q);
+            out[pw + i] = (orc_mulmod(a0, b1, q) + orc_mulmod(a1, b0, q)) % q;
+            c2[i] = orc_mulmod(a1, b1, q);
+        }
+    }
+    orc_keyswitch(r, level, c2, rlk, d0, d1);
+    for (int m = 0; m < nl; m++) { u64 q = r->q[m]; for (int x = 0; x < N; x++) { size_t i = (size_t)m * N + x; out[i] = (out[i] + d0[i]) % q; out[pw + i] = (out[pw + i] + d1[i]) % q; } }
+    free(c2); free(d0); free(d1);
+}
+/* ct x NTT-domain plaintext (eval.MulRelinNew(mask, ct) with a Plaintext operand, basics.go:122,142,165): both polys times pt */
+void orc_mul_plain(const orc_ring *r, int level, const u64 *ct, const u64 *pt, u64 *out) {
+    int N = r->N, nl = level + 1;
+    for (int p = 0; p < 2; p++) for (int m = 0; m < nl; m++) { u64 q = r->q[m]; for (int x = 0; x < N; x++) { size_t i = ((size_t)p * nl + m) * N + x; out[i] = orc_mulmod(ct[i], pt[(size_t)m * N + x], q); } }
+}
+/* one step of eval.Rescale (basics.go:123,394): lattigo ring.DivRoundByLastModulusNTT on both polynomials:
+ * x -> floor((x + (q_L-1)/2) / q_L) in the remaining moduli.  in: level, out: level-1 ([2][level][N]) */
+void orc_rescale(const orc_ring *r, int level, const u64 *ct, u64 *out) {
+    int N = r->N, nl = level + 1; u64 qL = r->q[level], half = (qL - 1) >> 1;
+    u64 *t = malloc(8 * N), *tmp = malloc(8 * N);
+    for (int p = 0; p < 2; p++) {
+        memcpy(t, ct + ((size_t)p * nl + level) * N, 8 * N);
+        orc_intt(r, level, t);
+        for (int x = 0; x < N; x++) { u64 v = t[x] + half; if (v >= qL) v -= qL; t[x] = v; }
+        for (int m = 0; m < level; m++) {
+            u64 q = r->q[m], hneg = q - (half % q), qLinv = orc_invmod(qL % q, q);
+            for (int x = 0; x < N; x++) tmp[x] = ((t[x] % q) + hneg) % q;
+            orc_ntt(r, m, tmp);
+            const u64 *src = ct + ((size_t)p * nl + m) * N; u64 *dst = out + ((size_t)p * level + m) * N;
+            for (int x = 0; x < N; x++) { u64 dlt = src[x] >= tmp[x] ? src[x] - tmp[x] : src[x] + q - tmp[x]; dst[x] = orc_mulmod(dlt, qLinv, q); }
+        }
+    }
+    free(t); free(tmp);
+}
+/* crypto.InnerSumAll (basics.go:278-292): add the nct ciphertexts, then RotateAndAdd over rotate = 1,2,4,..,slots/2 (left) */
+int orc_innersum_all(const orc_ring *r, const orc_rotkeys *keys, int level, const u64 *cts, int nct, u64 *out) {
+    int N = r->N, nl = level + 1; size_t ctw = (size_t)2 * nl * N;
+    u64 *rt = malloc(8 * ctw);
+    memcpy(out, cts, 8 * ctw);
+    for (int i = 1; i < nct; i++) orc_ct_addsub(r, level, cts + (size_t)i * ctw, out, 0, out);
+    for (int rot = 1; rot < N / 2; rot *= 2) {
+        if (orc_rotate_left(r, keys, level, out, rot, rt)) { free(rt); return -1; }
+        orc_ct_addsub(r, level, rt, out, 0, out);
+    }
+    free(rt); return 0;
+}
+/* relinearisation key for tests: digit i = (b_i, a_i), b_i = -a_i*s + e_i + P*g_i*s^2 */
+void orc_gen_rlk(const orc_ring *r, const int8_t *s, u64 seed, u64 *key) {
+    int N = r->N, nq = r->nq, np = r->np, nmod = nq + np, beta = orc_rotkeys_beta(r);
+    u64 *s_ntt = malloc(8 * N), *e_ntt = malloc(8 * N); int8_t *e = malloc(N);
+    u64 st = seed;
+    for (int i = 0; i < beta; i++) {
+        for (int x = 0; x < N; x++) e[x] = (int8_t)((int)uniform_mod(&st, 7) - 3);
+        for (int m = 0; m < nmod; m++) {
+            u64 q = r->q[m]; u64 *b = key + (((size_t)i * 2 + 0) * nmod + m) * N, *a = key + (((size_t)i * 2 + 1) * nmod + m) * N;
+            for (int x = 0; x < N; x++) s_ntt[x] = s[x] < 0 ? q - (u64)(-s[x]) : (u64)s[x];
+            orc_ntt(r, m, s_ntt);
+            for (int x = 0; x < N; x++) e_ntt[x] = e[x] < 0 ? q - (u64)(-e[x]) : (u64)e[x];
+            orc_ntt(r, m, e_ntt);
+            u64 st_a = seed ^ (0x5151ULL + 733ULL * (u64)(i * nmod + m));
+            u64 Pg = 0;
+            if (m < nq && m / np == i) { Pg = 1; for (int p = 0; p < np; p++) Pg = orc_mulmod(Pg, r->q[nq + p] % q, q); }
+            for (int x = 0; x < N; x++) {
+                a[x] = uniform_mod(&st_a, q);
+                u64 v = (q - orc_mulmod(a[x], s_ntt[x], q)) % q;
+                v = (v + e_ntt[x]) % q;
+                v = (v + orc_mulmod(Pg, orc_mulmod(s_ntt[x], s_ntt[x], q), q)) % q;
+                b[x] = v;
+            }
+        }
+    }
+    free(s_ntt); free(e_ntt); free(e);
+}
+
 /* ------------------------------------------------------------------ test-side CKKS helpers */
 void orc_gen_secret(const orc_ring *r, u64 seed, int8_t *s) {
     u64 st = seed; for (int i = 0; i < r->N; i++) s[i] = (int8_t)((int)uniform_mod(&st, 3) - 1);

@@ -90,6 +90,14 @@ int orc_rotate_left(const orc_ring *r, const orc_rotkeys *keys, int level, const
 /* crypto.RotateRightWithEvaluator semantics (basics.go:201-210) */
 int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *ct_in, int nrot, uint64_t *ct_out);
 
+/* ---- remaining evaluator ops of crypto/basics.go used between the matmuls (C2-C4) ---- */
+void orc_ct_addsub(const orc_ring *r, int level, const uint64_t *a, const uint64_t *b, int sub, uint64_t *out);
+void orc_mulrelin(const orc_ring *r, int level, const uint64_t *a, const uint64_t *b, const uint64_t *rlk, uint64_t *out);
+void orc_mul_plain(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *pt, uint64_t *out);
+void orc_rescale(const orc_ring *r, int level, const uint64_t *ct, uint64_t *out /*[2][level][N]*/);
+int orc_innersum_all(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *cts, int nct, uint64_t *out);
+void orc_gen_rlk(const orc_ring *r, const int8_t *s_coeff, uint64_t seed, uint64_t *key_out);
+
 /* ---- test-side CKKS helpers (not on the reference hot path; used to build inputs / check outputs) ---- */
 void orc_gen_secret(const orc_ring *r, uint64_t seed, int8_t *s_coeff /*N, ternary*/);
 void orc_gen_rotkey(const orc_ring *r, const int8_t *s_coeff, uint64_t galois_el, uint64_t seed, uint64_t *key_out);

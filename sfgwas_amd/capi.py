@@ -43,6 +43,12 @@ def _sig(L):
         "sfg_encode_coeffs_host": (i, [vp, C.POINTER(d), i, C.POINTER(C.c_int64)]),
         "sfg_rotate_right_dev": (i, [vp, vp, vp, i, i, C.POINTER(i)]),
         "sfg_ct_add_dev": (i, [vp, vp, vp, vp, i, i]),
+        "sfg_ct_sub_dev": (i, [vp, vp, vp, vp, i, i]),
+        "sfg_ctx_load_relinkey": (i, [vp, u64p, i]),
+        "sfg_ct_mulrelin_dev": (i, [vp, vp, vp, vp, i, i]),
+        "sfg_ct_mul_plain_dev": (i, [vp, vp, vp, sz, vp, i, i]),
+        "sfg_ct_rescale_dev": (i, [vp, vp, vp, i, i]),
+        "sfg_ct_innersum_dev": (i, [vp, vp, i, i, vp]),
         "sfg_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_from_device": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_free": (None, [vp, vp]),
@@ -257,3 +263,42 @@ def random_rotkey(ctx_or_ring_moduli, beta, N, seed):
     for m, q in enumerate(mods):
         k[:, :, m, :] = rnd.integers(0, q, (beta, 2, N), dtype=np.uint64)
     return k
+
+
+def _ctx_evalop(self, name, level, *arrays, out_level=None, extra=()):
+    """run one of the batched evaluator ops (host arrays in, host array out): test plumbing"""
+    devs = [self.to_device(np.ascontiguousarray(a, dtype=np.uint64)) for a in arrays]
+    nct = arrays[0].shape[0]
+    ol_ = level if out_level is None else out_level
+    out = self.malloc(nct * 2 * (ol_ + 1) * self.N * 8)
+    fn = getattr(lib(), name)
+    if name == "sfg_ct_mul_plain_dev":
+        self.check(fn(self.h, devs[0], devs[1], extra[0], out, nct, level), name)
+    elif name == "sfg_ct_rescale_dev":
+        self.check(fn(self.h, devs[0], out, nct, level), name)
+    else:
+        self.check(fn(self.h, devs[0], devs[1], out, nct, level), name)
+    res = self.to_host(out, (nct, 2, ol_ + 1, self.N), np.uint64)
+    for d_ in devs + [out]:
+        self.free(d_)
+    return res
+
+
+def _ctx_innersum(self, cts, level):
+    cts = np.ascontiguousarray(cts, dtype=np.uint64)
+    d_in = self.to_device(cts)
+    out = self.malloc(2 * (level + 1) * self.N * 8)
+    self.check(lib().sfg_ct_innersum_dev(self.h, d_in, cts.shape[0], level, out), "innersum")
+    res = self.to_host(out, (2, level + 1, self.N), np.uint64)
+    self.free(d_in); self.free(out)
+    return res
+
+
+def _ctx_load_relinkey(self, key, montgomery=False):
+    key = np.ascontiguousarray(key, dtype=np.uint64)
+    self.check(lib().sfg_ctx_load_relinkey(self.h, p64(key), int(montgomery)), "load_relinkey")
+
+
+Context.evalop = _ctx_evalop
+Context.innersum = _ctx_innersum
+Context.load_relinkey = _ctx_load_relinkey

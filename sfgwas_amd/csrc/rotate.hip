@@ -175,8 +175,9 @@ __global__ void __launch_bounds__(256) k_moddown_extend(const u64 *acc, u64 *ext
 }
 
 // grid (N/256, nl, B): out = perm(c0 + (acc0 - ext0)/P), perm((acc1 - ext1)/P); out[x] = in[index[x]]
+// add1 (nullable): [nin][nl][N] rows added to polynomial 1 (relinearisation: the degree-1 term of the tensor product)
 __global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const int *inidx, const u64 *acc, const u64 *ext2, const uint16_t *const *index,
-                                                   u64 *const *ct_out, const KswConst *kcp, const ModConst *modc) {
+                                                   u64 *const *ct_out, const KswConst *kcp, const ModConst *modc, const u64 *add1) {
     const KswConst &kc = *kcp;
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
     const double q = modc[t].q, qinv = modc[t].qinv, pinv = kc.pinv[t], pinv_q = kc.pinv_q[t];
@@ -187,6 +188,7 @@ __global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const int 
         const double e = u64_to_f64(ext2[((b * 2 + p) * (size_t)kc.nl + t) * N + src]);
         double r = mulmod_lazy(a - e, pinv, pinv_q, q);
         if (p == 0) r += u64_to_f64(ct_in[((size_t)inidx[b] * 2 * (size_t)kc.nl + t) * N + src]);
+        else if (add1) r += u64_to_f64(add1[((size_t)inidx[b] * (size_t)kc.nl + t) * N + src]);
         ct_out[b][((size_t)p * kc.nl + t) * N + x] = f64_to_u64(canon(r, q, qinv));
     }
 }
@@ -198,27 +200,17 @@ __global__ void __launch_bounds__(256) k_ct_add(const u64 *a, const u64 *b, u64 
     u64 v = a[off] + b[off]; out[off] = v >= q ? v - q : v;
 }
 
-// Rotate a batch.  `in` holds nin ciphertexts [nin][2][nl][N]; output j = RotateRight(in[in_index[j]], nrot[j])
-// (RotateRightWithEvaluator semantics) written to out + j*ct words.  in_index == nullptr means identity (nin == nct).
-// Decomposition (steps 1-2) is done once per INPUT and shared by all its rotations ("hoisting"): the per-key work is
+// Key-switch a batch of jobs.  `in` holds nin ciphertext-shaped inputs [nin][2][nl][N] whose polynomial 1 is switched;
+// job k reads input job_in[k], uses key keyp[k] and automorphism table idxp[k], and writes
+//   out0 = perm(in.p0 + d0), out1 = perm(d1 [+ add1[in]])            to outp[k].
+// Decomposition (steps 1-2) is done once per INPUT and shared by all its jobs ("hoisting"): the per-key work is
 // only the inner product, ModDown and the automorphism.  Same arithmetic, same bits.
-int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index) {
+static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level, const std::vector<int> &job_in, const std::vector<const u64 *> &keyp,
+                                 const std::vector<const uint16_t *> &idxp, const std::vector<u64 *> &outp, const u64 *add1) {
     const int N = SFG_N, nl = level + 1;
-    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "rotate: level out of range");
     KswConst *kcd; KswConst kc;
     SFG_TRY(get_ksw(ctx, level, &kcd, &kc));
     const size_t ctw = (size_t)2 * nl * N;
-    std::vector<int> job_in; std::vector<const u64 *> keyp; std::vector<const uint16_t *> idxp; std::vector<u64 *> outp;
-    for (int j = 0; j < nct; j++) {
-        int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
-        const int src = in_index ? in_index[j] : j;
-        if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
-        if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + (size_t)src * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
-        u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);                 // basics.go:205: RotateNew(ct, slots - nrot)
-        auto it = ctx->rotkeys.find(g);
-        if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
-        job_in.push_back(src); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev); outp.push_back(out + j * ctw);
-    }
     const int nr = (int)job_in.size();
     if (!nr) return 0;
     // inputs are processed in groups whose decomposition fits ~1.5 GiB; jobs of a group in chunks whose acc/ext2 fit ~1.5 GiB
@@ -275,11 +267,40 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
             SFG_HIP(ctx, hipGetLastError());
             SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2, (size_t)nb * 2 * nl, pq));
             // 5. finish + automorphism
-            hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2, idx_d, out_d, kcd, ctx->modc);
+            hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2, idx_d, out_d, kcd, ctx->modc,
+                               add1 ? add1 + (size_t)i0 * nl * N : nullptr);
             SFG_HIP(ctx, hipGetLastError());
         }
     }
     return 0;
+}
+// Rotate a batch.  `in` holds nin ciphertexts [nin][2][nl][N]; output j = RotateRight(in[in_index[j]], nrot[j])
+// (RotateRightWithEvaluator semantics) written to out + j*ct words.  in_index == nullptr means identity (nin == nct).
+int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index) {
+    const int N = SFG_N, nl = level + 1;
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "rotate: level out of range");
+    const size_t ctw = (size_t)2 * nl * N;
+    std::vector<int> job_in; std::vector<const u64 *> keyp; std::vector<const uint16_t *> idxp; std::vector<u64 *> outp;
+    for (int j = 0; j < nct; j++) {
+        int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
+        const int src = in_index ? in_index[j] : j;
+        if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
+        if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + (size_t)src * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
+        u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);                 // basics.go:205: RotateNew(ct, slots - nrot)
+        auto it = ctx->rotkeys.find(g);
+        if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
+        job_in.push_back(src); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev); outp.push_back(out + j * ctw);
+    }
+    return launch_keyswitch_jobs(ctx, in, nin, level, job_in, keyp, idxp, outp, nullptr);
+}
+// relinearisation: out[i] = (tmp[i].p0 + d0, mid[i] + d1) with (d0, d1) = key switch of tmp[i].p1 under the key stored at Galois element 1
+int launch_relinearize(sfg_ctx *ctx, const u64 *tmp, int nct, int level, const u64 *mid, u64 *out) {
+    auto it = ctx->rotkeys.find(1);
+    if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "relinearize: no relinearisation key loaded");
+    const size_t ctw = (size_t)2 * (level + 1) * SFG_N;
+    std::vector<int> job_in(nct); std::vector<const u64 *> keyp(nct, it->second.key_dev); std::vector<const uint16_t *> idxp(nct, it->second.index_dev); std::vector<u64 *> outp(nct);
+    for (int j = 0; j < nct; j++) { job_in[j] = j; outp[j] = out + (size_t)j * ctw; }
+    return launch_keyswitch_jobs(ctx, tmp, nct, level, job_in, keyp, idxp, outp, mid);
 }
 int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host) {
     return launch_rotate_right_indexed(ctx, in, nct, out, nct, level, nrot_host, nullptr);

@@ -5,11 +5,13 @@
 //
 //   crypto::CryptoParams / Ciphertext / CipherVector / CipherMatrix      crypto/crypto.go:32-60
 //   crypto::RotateRight, RotateRightWithEvaluator                        crypto/basics.go:201-224
+//   crypto::Mult, CMult, CPMult, CAdd, CSub, CRescale, InnerSumAll       crypto/basics.go:226-292, 386-470, 568-590, 707-720
 //   gwas::GenoFileStream                                                 gwas/filestream.go:284-494
 //   gwas::DiagCacheStream (reader + writer, reference byte format)       gwas/filestream.go:19-282
 //   gwas::MatMult4Stream / MatMult4StreamPreprocess / MatMult4StreamCompute   gwas/matmult.go:914,1043,1238
 //   mpc::BeaverMultElemVec / BeaverMultMat                               mpc/beavermult.go:108-147
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -77,6 +79,103 @@ inline Ciphertext RotateRightWithEvaluator(CryptoParams *cps, const Ciphertext &
     return out;
 }
 inline Ciphertext RotateRight(CryptoParams *cps, const Ciphertext &ct, int nrot) { return RotateRightWithEvaluator(cps, ct, nrot); }  // :212-224
+
+// ---- batched evaluator ops (basics.go:226-292, 386-470, 568-590, 707-720)
+struct Plaintext { int level = 0; double scale = 0; std::vector<uint64_t> data; };          // NTT domain, [level+1][N]
+using PlainVector = std::vector<Plaintext>;
+inline void LoadRelinKey(CryptoParams *cps, const std::vector<uint64_t> &key, bool montgomeryForm) {       // cryptoParams.Rlk, crypto.go:47
+    cps->check(sfg_ctx_load_relinkey(cps->ctx, key.data(), montgomeryForm ? 1 : 0), "LoadRelinKey");
+}
+namespace detail {
+struct DevBuf {                                                   // device buffer that frees itself
+    CryptoParams *cps; void *p = nullptr;
+    DevBuf(CryptoParams *c, size_t bytes) : cps(c) { cps->check(sfg_malloc(c->ctx, &p, bytes ? bytes : 8), "sfg_malloc"); }
+    ~DevBuf() { if (p) sfg_free(cps->ctx, p); }
+    uint64_t *u() const { return (uint64_t *)p; }
+};
+inline size_t ctWords(const CryptoParams *cps, int level) { return (size_t)2 * (level + 1) * cps->N(); }
+inline void upload(CryptoParams *cps, const CipherVector &X, int level, DevBuf &d, bool broadcast, size_t n) {
+    const size_t w = ctWords(cps, level);
+    for (size_t i = 0; i < n; i++) {
+        const Ciphertext &c = X[broadcast ? 0 : i];
+        if (c.level != level || c.data.size() != w) throw std::runtime_error("evaluator op: operand levels differ");   // lattigo panics on mixed levels here too
+        cps->check(sfg_memcpy_h2d(cps->ctx, d.u() + i * w, c.data.data(), w * 8), "h2d");
+    }
+}
+inline CipherVector download(CryptoParams *cps, const DevBuf &d, size_t n, int level, double scale) {
+    const size_t w = ctWords(cps, level);
+    CipherVector out(n);
+    for (size_t i = 0; i < n; i++) { out[i].level = level; out[i].scale = scale; out[i].data.resize(w); cps->check(sfg_memcpy_d2h(cps->ctx, out[i].data.data(), d.u() + i * w, w * 8), "d2h"); }
+    return out;
+}
+// eval.Rescale(ct, threshold, ct): divide by the last modulus while scale >= threshold * q_level / 2 (lattigo ckks evaluator)
+inline CipherVector rescaleOnDevice(CryptoParams *cps, DevBuf &d, size_t n, int level, double scale, double threshold, const std::vector<uint64_t> &qi) {
+    if (level == 0) throw std::runtime_error("cannot Rescale: input Ciphertext already at level 0");
+    DevBuf t(cps, n * ctWords(cps, level) * 8);
+    DevBuf *cur = &d, *nxt = &t;
+    while (level != 0 && scale >= threshold * (double)qi[level] / 2) {
+        cps->check(sfg_ct_rescale_dev(cps->ctx, cur->u(), nxt->u(), (int)n, level), "Rescale");
+        scale /= (double)qi[level]; level--; std::swap(cur, nxt);
+    }
+    return download(cps, *cur, n, level, scale);
+}
+}  // namespace detail
+
+// basics.go:226-234: MulRelinNew without rescale
+inline Ciphertext Mult(CryptoParams *cps, const Ciphertext &a, const Ciphertext &b) {
+    detail::DevBuf da(cps, a.data.size() * 8), db(cps, a.data.size() * 8), dout(cps, a.data.size() * 8);
+    detail::upload(cps, {a}, a.level, da, false, 1); detail::upload(cps, {b}, a.level, db, false, 1);
+    cps->check(sfg_ct_mulrelin_dev(cps->ctx, da.u(), db.u(), dout.u(), 1, a.level), "Mult");
+    return detail::download(cps, dout, 1, a.level, a.scale * b.scale)[0];
+}
+// basics.go:386-427: element-wise MulRelin + Rescale; a length-1 operand is broadcast. qi = params.Qi()
+inline CipherVector CMult(CryptoParams *cps, const CipherVector &X, const CipherVector &Y, const std::vector<uint64_t> &qi) {
+    const size_t n = std::max(X.size(), Y.size()); const int level = X[0].level; const size_t w = detail::ctWords(cps, level);
+    detail::DevBuf dx(cps, n * w * 8), dy(cps, n * w * 8), dout(cps, n * w * 8);
+    detail::upload(cps, X, level, dx, X.size() == 1, n); detail::upload(cps, Y, level, dy, Y.size() == 1 && X.size() != 1, n);
+    cps->check(sfg_ct_mulrelin_dev(cps->ctx, dx.u(), dy.u(), dout.u(), (int)n, level), "CMult");
+    return detail::rescaleOnDevice(cps, dout, n, level, X[0].scale * Y[0].scale, cps->scale, qi);
+}
+// basics.go:429-470: ciphertext x plaintext + Rescale, same broadcast rule
+inline CipherVector CPMult(CryptoParams *cps, const CipherVector &X, const PlainVector &Y, const std::vector<uint64_t> &qi) {
+    const size_t n = std::max(X.size(), Y.size()); const int level = X[0].level; const size_t w = detail::ctWords(cps, level), pw = w / 2;
+    detail::DevBuf dx(cps, n * w * 8), dp(cps, Y.size() * pw * 8), dout(cps, n * w * 8);
+    detail::upload(cps, X, level, dx, X.size() == 1, n);
+    for (size_t i = 0; i < Y.size(); i++) {
+        if (Y[i].level != level) throw std::runtime_error("CPMult: operand levels differ");
+        cps->check(sfg_memcpy_h2d(cps->ctx, dp.u() + i * pw, Y[i].data.data(), pw * 8), "h2d");
+    }
+    cps->check(sfg_ct_mul_plain_dev(cps->ctx, dx.u(), dp.u(), Y.size() == 1 ? 0 : pw, dout.u(), (int)n, level), "CPMult");
+    return detail::rescaleOnDevice(cps, dout, n, level, X[0].scale * Y[0].scale, cps->scale, qi);
+}
+inline CipherVector addSub(CryptoParams *cps, const CipherVector &X, const CipherVector &Y, bool sub) {
+    const size_t n = X.size(); const int level = X[0].level; const size_t w = detail::ctWords(cps, level);
+    if (Y.size() != n) throw std::runtime_error("CAdd/CSub: vector lengths differ");                   // index out of range panic in Go
+    detail::DevBuf dx(cps, n * w * 8), dy(cps, n * w * 8);
+    detail::upload(cps, X, level, dx, false, n); detail::upload(cps, Y, level, dy, false, n);
+    cps->check((sub ? sfg_ct_sub_dev : sfg_ct_add_dev)(cps->ctx, dx.u(), dy.u(), dx.u(), (int)n, level), "CAdd/CSub");
+    return detail::download(cps, dx, n, level, X[0].scale);
+}
+inline CipherVector CAdd(CryptoParams *cps, const CipherVector &X, const CipherVector &Y) { return addSub(cps, X, Y, false); }   // :568-578
+inline CipherVector CSub(CryptoParams *cps, const CipherVector &X, const CipherVector &Y) { return addSub(cps, X, Y, true); }    // :580-590
+// basics.go:707-720
+inline CipherVector CRescale(CryptoParams *cps, const CipherVector &X, const std::vector<uint64_t> &qi) {
+    const size_t n = X.size(); const int level = X[0].level;
+    detail::DevBuf dx(cps, n * detail::ctWords(cps, level) * 8);
+    detail::upload(cps, X, level, dx, false, n);
+    return detail::rescaleOnDevice(cps, dx, n, level, X[0].scale, cps->scale, qi);
+}
+// basics.go:278-292
+inline Ciphertext InnerSumAll(CryptoParams *cps, const CipherVector &X) {
+    const size_t n = X.size(); const int level = X[0].level; const size_t w = detail::ctWords(cps, level);
+    detail::DevBuf dx(cps, n * w * 8), dout(cps, w * 8);
+    detail::upload(cps, X, level, dx, false, n);
+    cps->check(sfg_ct_innersum_dev(cps->ctx, dx.u(), (int)n, level, dout.u()), "InnerSumAll");
+    return detail::download(cps, dout, 1, level, X[0].scale)[0];
+}
+inline Ciphertext InnerProd(CryptoParams *cps, const CipherVector &X, const CipherVector &Y, const std::vector<uint64_t> &qi) {   // :274-276
+    return InnerSumAll(cps, CMult(cps, X, Y, qi));
+}
 
 }  // namespace crypto
 

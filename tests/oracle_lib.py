@@ -81,6 +81,13 @@ def lib():
                                              C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_uint8)]
         L.orc_matmult_finalize.restype = C.c_int
         L.orc_matmult_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, u64p]
+        L.orc_ct_addsub.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_int, u64p]
+        L.orc_mulrelin.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p]
+        L.orc_mul_plain.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
+        L.orc_rescale.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
+        L.orc_innersum_all.restype = C.c_int
+        L.orc_innersum_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_int, u64p]
+        L.orc_gen_rlk.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_uint64, u64p]
         L.orc_bench_mac.restype = C.c_double
         L.orc_bench_mac.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong)]
         L.orc_diagcache_create.restype = C.c_void_p

@@ -83,6 +83,8 @@ def test_host_mirror_matmul_end_to_end(tmp_path):
     A = np.stack([np.stack([ring.fill_uniform(level, 50 + i)]) for i in range(s)])
     AT = np.stack([np.stack([ring.fill_uniform(level, 70 + i)]) for i in range(s)])
     A.tofile(tmp_path / "A.bin"); AT.tofile(tmp_path / "AT.bin")
+    rlk = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 999)
+    rlk.tofile(tmp_path / "rlk.bin")
     (tmp_path / "case.txt").write_text(f"{nrow} {ncol} {s} {level} {L} {square}\n")
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr
@@ -96,3 +98,13 @@ def test_host_mirror_matmul_end_to_end(tmp_path):
     assert np.array_equal(got_t, want_t)
     rot = np.fromfile(tmp_path / "rot.bin", dtype=np.uint64).reshape(A[0, 0].shape)
     assert np.array_equal(rot, ol.rotate_right(ring, keys, level, A[0, 0], 1))
+    # CMult = MulRelin + one Rescale step at scale 2^68 (basics.go:386-427); CSub (basics.go:580)
+    a0, a1 = np.ascontiguousarray(A[0, 0]), np.ascontiguousarray(A[1, 0])
+    mr = np.zeros_like(a0)
+    ol.lib().orc_mulrelin(ring.h, level, ol.p64(a0), ol.p64(a1), ol.p64(rlk), ol.p64(mr))
+    rs = np.zeros((2, level, ring.N), dtype=np.uint64)
+    ol.lib().orc_rescale(ring.h, level, ol.p64(mr), ol.p64(rs))
+    assert np.array_equal(np.fromfile(tmp_path / "cmult.bin", dtype=np.uint64).reshape(rs.shape), rs)
+    df = np.zeros_like(a0)
+    ol.lib().orc_ct_addsub(ring.h, level, ol.p64(a0), ol.p64(a1), 1, ol.p64(df))
+    assert np.array_equal(np.fromfile(tmp_path / "csub.bin", dtype=np.uint64).reshape(df.shape), df)

@@ -354,3 +354,43 @@ def test_sketch_and_moments():
     assert np.array_equal(sk, want)
     assert np.array_equal(xs, X.astype(np.int64).sum(0).astype(np.uint64))
     assert np.array_equal(x2, (X.astype(np.int64) ** 2).sum(0).astype(np.uint64))
+
+
+# ---------------------------------------------------------------- evaluator ops between the matmuls (C2-C4)
+def test_mulrelin_rescale_mulplain_innersum_decrypt_correctly():
+    ring = small_ring(6)
+    s = ring.gen_secret(31)
+    rlk = np.zeros((ring.beta, 2, len(ring.moduli), ring.N), dtype=np.uint64)
+    L().orc_gen_rlk(ring.h, ol.pi8(s), 5, ol.p64(rlk))
+    keys = ol.RotKeys(ring)
+    keys.gen_for_rotations(s, [1 << k for k in range(ring.logN - 1)])
+    rnd = np.random.default_rng(13)
+    level, scale = 5, 2.0 ** 34
+    u, v = rnd.normal(size=ring.slots), rnd.normal(size=ring.slots)
+    cu, cv = _encode_encrypt(ring, s, level, u, scale, 1), _encode_encrypt(ring, s, level, v, scale, 2)
+    # MulRelin + one Rescale step (CMult, basics.go:386-427)
+    prod = np.zeros_like(cu)
+    L().orc_mulrelin(ring.h, level, ol.p64(cu), ol.p64(cv), ol.p64(rlk), ol.p64(prod))
+    got = _decrypt_decode(ring, s, level, prod, scale * scale, nmod=3)
+    assert np.max(np.abs(got.real - u * v)) < 1e-3
+    res = np.zeros((2, level, ring.N), dtype=np.uint64)
+    L().orc_rescale(ring.h, level, ol.p64(prod), ol.p64(res))
+    got = _decrypt_decode(ring, s, level - 1, res, scale * scale / ring.moduli[level], nmod=2)
+    assert np.max(np.abs(got.real - u * v)) < 1e-3
+    # ct x plaintext (Mask path, basics.go:110-172): 0/1 mask
+    mask = (np.arange(ring.slots) < 5).astype(np.float64)
+    pt = ring.encode_ntt(mask, scale, level + 1)
+    mp = np.zeros_like(cu)
+    L().orc_mul_plain(ring.h, level, ol.p64(cu), ol.p64(pt), ol.p64(mp))
+    got = _decrypt_decode(ring, s, level, mp, scale * scale, nmod=3)
+    assert np.max(np.abs(got.real - u * mask)) < 1e-3
+    # Sub and InnerSumAll (basics.go:278-292): every slot holds the total
+    df = np.zeros_like(cu)
+    L().orc_ct_addsub(ring.h, level, ol.p64(cu), ol.p64(cv), 1, ol.p64(df))
+    got = _decrypt_decode(ring, s, level, df, scale)
+    assert np.max(np.abs(got.real - (u - v))) < 1e-4
+    both = np.ascontiguousarray(np.stack([cu, cv]))
+    tot = np.zeros_like(cu)
+    assert L().orc_innersum_all(ring.h, keys.h, level, ol.p64(both), 2, ol.p64(tot)) == 0
+    got = _decrypt_decode(ring, s, level, tot, scale)
+    assert np.max(np.abs(got.real - (u.sum() + v.sum()))) < 1e-3
