@@ -115,6 +115,20 @@ int sfg_ct_innersum_dev(sfg_ctx *ctx, const uint64_t *in_dev, int nct, int level
 int sfg_geno_upload(sfg_ctx *ctx, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
 int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *geno_dev, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
 void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g);
+/* Input pipeline on the device (replaces the per-batch shell-outs of assoc.go:389 to the Python converters under scripts/):
+ * scripts/plinkBedToBinary.py + filterMatrix.py: `bed_host` is a whole SNP-major PLINK .bed image (3 magic bytes +
+ * ceil(num_sample/4) bytes per SNP; codes 00->2, 01->-1, 10->1, 11->0); rows (samples) / columns (SNPs) whose filter
+ * byte is zero are dropped (nullptr = keep all). Result: resident sample-major int8 matrix. Fails on a size mismatch
+ * (the script's assert) or wrong magic. */
+int sfg_geno_from_bed(sfg_ctx *ctx, const uint8_t *bed_host, size_t bed_bytes, size_t num_sample, size_t num_snp,
+                      const uint8_t *row_filter, const uint8_t *col_filter, sfg_geno **out);
+int sfg_geno_dims(const sfg_geno *g, size_t *nrow, size_t *ncol);
+/* host [nrow][ncol] copy of a resident matrix (interoperability with CPU-only parties, tests) */
+int sfg_geno_download(sfg_ctx *ctx, const sfg_geno *g, int8_t *host);
+/* scripts/transposeMatrix.py as a materialised copy (the products themselves use SFG_TRANSPOSE on the one copy) */
+int sfg_geno_transpose(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out);
+/* scripts/mergeMatrices.py: column-wise concatenation of k resident matrices with equal row counts */
+int sfg_geno_concat_cols(sfg_ctx *ctx, const sfg_geno *const *parts, int k, sfg_geno **out);
 /* P2: per-column sum / sum of squares after missing->0 (matmult.go:1292-1300); either may be NULL */
 int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *sqsum_host);
 

@@ -473,6 +473,24 @@ int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, cons
     return orc_rotate_left(r, keys, level, ct, nrot ? n - nrot : 0, out);
 }
 
+/* ------------------------------------------------------------------ input formats (scripts/*.py; pinned by tests/golden/input_formats.npz,
+ * which holds outputs of the reference's own converters) */
+/* scripts/plinkBedToBinary.py:14-27: skip the 3 magic bytes; SNP-major, ceil(ns/4) bytes per SNP, sample 4b+k in bits 2k..2k+1;
+ * code 0 -> 2, 1 -> -1 (missing), 2 -> 1, 3 -> 0; output sample-major [num_sample][num_snp] */
+int orc_bed_decode(const uint8_t *bed, size_t bed_bytes, size_t num_sample, size_t num_snp, int8_t *out) {
+    static const int8_t map[4] = {2, -1, 1, 0};
+    size_t bps = (num_sample + 3) / 4;
+    if (bed_bytes != 3 + num_snp * bps) return -1;                    /* the script's assert */
+    for (size_t j = 0; j < num_snp; j++) for (size_t i = 0; i < num_sample; i++)
+        out[i * num_snp + j] = map[(bed[3 + j * bps + i / 4] >> (2 * (i % 4))) & 3];
+    return 0;
+}
+/* scripts/filterMatrix.py:26-37: keep rows / columns whose filter byte is non-zero */
+void orc_filter_matrix(const int8_t *in, size_t nrows, size_t ncols, const uint8_t *rf, const uint8_t *cf, int8_t *out) {
+    size_t o = 0;
+    for (size_t r = 0; r < nrows; r++) if (rf[r]) for (size_t c = 0; c < ncols; c++) if (cf[c]) out[o++] = in[r * ncols + c];
+}
+
 /* ------------------------------------------------------------------ remaining crypto/basics.go evaluator ops (C2-C4)
  * lattigo ckks.Evaluator restated.  ct layout [2][level+1][N], NTT domain, canonical. */
 /* eval.Add / eval.Sub (basics.go:174,568,580; matmult.go:56) */

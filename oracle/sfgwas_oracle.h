@@ -90,6 +90,10 @@ int orc_rotate_left(const orc_ring *r, const orc_rotkeys *keys, int level, const
 /* crypto.RotateRightWithEvaluator semantics (basics.go:201-210) */
 int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *ct_in, int nrot, uint64_t *ct_out);
 
+/* ---- input formats (scripts/plinkBedToBinary.py, filterMatrix.py) ---- */
+int orc_bed_decode(const uint8_t *bed, size_t bed_bytes, size_t num_sample, size_t num_snp, int8_t *out);
+void orc_filter_matrix(const int8_t *in, size_t nrows, size_t ncols, const uint8_t *rf, const uint8_t *cf, int8_t *out);
+
 /* ---- remaining evaluator ops of crypto/basics.go used between the matmuls (C2-C4) ---- */
 void orc_ct_addsub(const orc_ring *r, int level, const uint64_t *a, const uint64_t *b, int sub, uint64_t *out);
 void orc_mulrelin(const orc_ring *r, int level, const uint64_t *a, const uint64_t *b, const uint64_t *rlk, uint64_t *out);

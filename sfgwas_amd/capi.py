@@ -52,6 +52,11 @@ def _sig(L):
         "sfg_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_from_device": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_free": (None, [vp, vp]),
+        "sfg_geno_from_bed": (i, [vp, vp, sz, sz, sz, vp, vp, C.POINTER(vp)]),
+        "sfg_geno_dims": (i, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_geno_download": (i, [vp, vp, vp]),
+        "sfg_geno_transpose": (i, [vp, vp, C.POINTER(vp)]),
+        "sfg_geno_concat_cols": (i, [vp, C.POINTER(vp), i, C.POINTER(vp)]),
         "sfg_geno_colsums": (i, [vp, vp, C.POINTER(d), C.POINTER(d)]),
         "sfg_matmul_resident_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, vp]),
         "sfg_matmul_stream": (i, [vp, u64p, i, i, i, vp, sz, sz, sz, C.c_uint, u64p, C.POINTER(d), C.POINTER(d)]),
@@ -302,3 +307,26 @@ def _ctx_load_relinkey(self, key, montgomery=False):
 Context.evalop = _ctx_evalop
 Context.innersum = _ctx_innersum
 Context.load_relinkey = _ctx_load_relinkey
+
+
+def _ctx_geno_to_host(self, g):
+    nr, nc = C.c_size_t(), C.c_size_t()
+    lib().sfg_geno_dims(g, C.byref(nr), C.byref(nc))
+    out = np.empty((nr.value, nc.value), dtype=np.int8)
+    self.check(lib().sfg_geno_download(self.h, g, out.ctypes.data_as(C.c_void_p)), "geno_download")
+    return out
+
+
+def _ctx_geno_from_bed(self, bed, num_sample, num_snp, row_filter=None, col_filter=None):
+    bed = np.ascontiguousarray(bed, dtype=np.uint8)
+    rf = None if row_filter is None else np.ascontiguousarray(row_filter, dtype=np.uint8)
+    cf = None if col_filter is None else np.ascontiguousarray(col_filter, dtype=np.uint8)
+    g = C.c_void_p()
+    self.check(lib().sfg_geno_from_bed(self.h, bed.ctypes.data_as(C.c_void_p), bed.size, num_sample, num_snp,
+                                       None if rf is None else rf.ctypes.data_as(C.c_void_p),
+                                       None if cf is None else cf.ctypes.data_as(C.c_void_p), C.byref(g)), "geno_from_bed")
+    return g
+
+
+Context.geno_to_host = _ctx_geno_to_host
+Context.geno_from_bed = _ctx_geno_from_bed

@@ -1,0 +1,117 @@
+// genoio.hip — genotype input pipeline on the device (SURVEY §8b "Python callers/harness", §8f-3):
+//   scripts/plinkBedToBinary.py  PLINK .bed (SNP-major 2-bit codes) -> sample-major int8 {00->2, 01->-1, 10->1, 11->0}
+//   scripts/filterMatrix.py      keep rows / columns by byte filters           (fused into the decode)
+//   scripts/transposeMatrix.py   [nrows x ncols] -> [ncols x nrows]
+//   scripts/mergeMatrices.py     column-wise concatenation
+// The packed image crosses PCIe (4x less than int8) and is expanded in HBM; results are resident sfg_geno handles.
+#include "common.hpp"
+#include "kernels.hpp"
+
+// tile = 64 SNPs x 64 bytes (256 samples). grid (ceil(bps/64), ceil(num_snp/64)), 256 threads
+__global__ void __launch_bounds__(256) k_bed_decode(const uint8_t *bed, size_t bps, size_t num_sample, size_t num_snp,
+                                                    const int32_t *row_map, const int32_t *col_map, int8_t *out, size_t ld) {
+    __shared__ int8_t tile[256][65];                          // [sample][snp], padded
+    const size_t b0 = (size_t)blockIdx.x * 64, j0 = (size_t)blockIdx.y * 64;
+    const int t = threadIdx.x;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {                          // coalesced along the bytes of one SNP
+        const int idx = it * 256 + t, snp = idx >> 6, byte = idx & 63;
+        uint32_t v = 0;
+        if (j0 + snp < num_snp && b0 + byte < bps) v = bed[(j0 + snp) * bps + b0 + byte];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tile[byte * 4 + k][snp] = (int8_t)(0x0001FF02u >> (8 * ((v >> (2 * k)) & 3)));
+    }
+    __syncthreads();
+    for (int it = 0; it < 64; it++) {                          // 64 consecutive SNPs of one sample per wave
+        const int idx = it * 256 + t, s = idx >> 6, snp = idx & 63;
+        const size_t gs = b0 * 4 + s, gj = j0 + snp;
+        if (gs < num_sample && gj < num_snp) {
+            const long r = row_map ? row_map[gs] : (long)gs, c = col_map ? col_map[gj] : (long)gj;
+            if (r >= 0 && c >= 0) out[(size_t)r * ld + (size_t)c] = tile[s][snp];
+        }
+    }
+}
+// 64 x 64 tiles. grid (ceil(ncol/64), ceil(nrow/64)), 256 threads
+__global__ void __launch_bounds__(256) k_geno_transpose(const int8_t *in, size_t nrow, size_t ncol, size_t ld, int8_t *out) {
+    __shared__ int8_t tile[64][65];
+    const size_t c0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 64;
+    const int t = threadIdx.x;
+    for (int it = 0; it < 16; it++) { const int idx = it * 256 + t, r = idx >> 6, c = idx & 63; if (r0 + r < nrow && c0 + c < ncol) tile[r][c] = in[(r0 + r) * ld + c0 + c]; }
+    __syncthreads();
+    for (int it = 0; it < 16; it++) { const int idx = it * 256 + t, c = idx >> 6, r = idx & 63; if (r0 + r < nrow && c0 + c < ncol) out[(c0 + c) * nrow + r0 + r] = tile[r][c]; }
+}
+
+static int make_map(sfg_ctx *ctx, const uint8_t *filt, size_t n, int32_t **dev, size_t *kept) {
+    *dev = nullptr; *kept = n;
+    if (!filt) return 0;
+    std::vector<int32_t> m(n); size_t k = 0;
+    for (size_t i = 0; i < n; i++) m[i] = filt[i] ? (int32_t)k++ : -1;
+    *kept = k;
+    SFG_HIP(ctx, hipMalloc(dev, n * sizeof(int32_t)));
+    SFG_HIP(ctx, hipMemcpy(*dev, m.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int sfg_geno_from_bed(sfg_ctx *ctx, const uint8_t *bed_host, size_t bed_bytes, size_t num_sample, size_t num_snp,
+                                 const uint8_t *row_filter, const uint8_t *col_filter, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bps = (num_sample + 3) / 4;
+    if (!num_sample || !num_snp) SFG_FAIL(ctx, "sfg_geno_from_bed: bad dimensions");
+    if (bed_bytes != 3 + num_snp * bps) SFG_FAIL(ctx, "sfg_geno_from_bed: file holds %zu bytes, expected 3 + %zu x %zu", bed_bytes, num_snp, bps);  // the script's assert
+    if (bed_host[0] != 0x6C || bed_host[1] != 0x1B || bed_host[2] != 0x01) SFG_FAIL(ctx, "sfg_geno_from_bed: not a SNP-major PLINK .bed (magic %02x %02x %02x)", bed_host[0], bed_host[1], bed_host[2]);
+    if (num_sample >= (1ULL << 31) || num_snp >= (1ULL << 31)) SFG_FAIL(ctx, "sfg_geno_from_bed: dimension too large");
+    int32_t *rmap = nullptr, *cmap = nullptr; size_t nr, nc;
+    SFG_TRY(make_map(ctx, row_filter, num_sample, &rmap, &nr));
+    SFG_TRY(make_map(ctx, col_filter, num_snp, &cmap, &nc));
+    if (!nr || !nc) { (void)hipFree(rmap); (void)hipFree(cmap); SFG_FAIL(ctx, "sfg_geno_from_bed: filters keep nothing"); }
+    uint8_t *dbed = nullptr; int8_t *d = nullptr;
+    SFG_HIP(ctx, hipMalloc(&dbed, num_snp * bps));
+    SFG_HIP(ctx, hipMalloc(&d, nr * nc));
+    SFG_HIP(ctx, hipMemcpyAsync(dbed, bed_host + 3, num_snp * bps, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((bps + 63) / 64), (unsigned)((num_snp + 63) / 64)), dim3(256), 0, ctx->stream,
+                       dbed, bps, num_sample, num_snp, rmap, cmap, d, nc);
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dbed); (void)hipFree(rmap); (void)hipFree(cmap);
+    sfg_geno *g = new sfg_geno(); g->dev = d; g->nrow = nr; g->ncol = nc; g->ld = nc; g->owned = true;
+    *out = g; return 0;
+}
+
+extern "C" int sfg_geno_dims(const sfg_geno *g, size_t *nrow, size_t *ncol) {
+    if (!g) return 1;
+    if (nrow) *nrow = g->nrow;
+    if (ncol) *ncol = g->ncol;
+    return 0;
+}
+extern "C" int sfg_geno_download(sfg_ctx *ctx, const sfg_geno *g, int8_t *host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_HIP(ctx, hipMemcpy2DAsync(host, g->ncol, g->dev, g->ld, g->ncol, g->nrow, hipMemcpyDeviceToHost, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int sfg_geno_transpose(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    int8_t *d = nullptr;
+    SFG_HIP(ctx, hipMalloc(&d, g->nrow * g->ncol));
+    hipLaunchKernelGGL(k_geno_transpose, dim3((unsigned)((g->ncol + 63) / 64), (unsigned)((g->nrow + 63) / 64)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, d);
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sfg_geno *t = new sfg_geno(); t->dev = d; t->nrow = g->ncol; t->ncol = g->nrow; t->ld = g->nrow; t->owned = true;
+    *out = t; return 0;
+}
+extern "C" int sfg_geno_concat_cols(sfg_ctx *ctx, const sfg_geno *const *parts, int k, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (k < 1) SFG_FAIL(ctx, "sfg_geno_concat_cols: nothing to merge");
+    size_t nrow = parts[0]->nrow, ncol = 0;
+    for (int i = 0; i < k; i++) { if (parts[i]->nrow != nrow) SFG_FAIL(ctx, "sfg_geno_concat_cols: part %d has %zu rows, expected %zu", i, parts[i]->nrow, nrow); ncol += parts[i]->ncol; }
+    int8_t *d = nullptr;
+    SFG_HIP(ctx, hipMalloc(&d, nrow * ncol));
+    size_t c0 = 0;
+    for (int i = 0; i < k; i++) {
+        SFG_HIP(ctx, hipMemcpy2DAsync(d + c0, ncol, parts[i]->dev, parts[i]->ld, parts[i]->ncol, nrow, hipMemcpyDeviceToDevice, ctx->stream));
+        c0 += parts[i]->ncol;
+    }
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sfg_geno *g = new sfg_geno(); g->dev = d; g->nrow = nrow; g->ncol = ncol; g->ld = ncol; g->owned = true;
+    *out = g; return 0;
+}

@@ -81,6 +81,9 @@ def lib():
                                              C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_uint8)]
         L.orc_matmult_finalize.restype = C.c_int
         L.orc_matmult_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, u64p]
+        L.orc_bed_decode.restype = C.c_int
+        L.orc_bed_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.orc_filter_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ct_addsub.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_int, u64p]
         L.orc_mulrelin.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p]
         L.orc_mul_plain.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]

@@ -4,7 +4,7 @@ reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Both 
 import csv, glob, json, sys, collections
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     tot = collections.defaultdict(float); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
