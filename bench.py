@@ -43,7 +43,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("SFG_BENCH_CONFIG", "c4"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (seconds of wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

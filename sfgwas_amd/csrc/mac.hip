@@ -251,7 +251,9 @@ extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt
         if (nplanes < 0) return 1;
         double *rotf = nullptr;
         const size_t rows = (size_t)K * R;                       // rot is [K][R][L][N]
-        SFG_HIP(ctx, hipMalloc(&rotf, rows * (size_t)nplanes * SFG_N * 8));
+        const size_t pad_rows = (size_t)((4 - K % 4) % 4) * R;       // k-slices read (against zero plaintexts) by the ragged last chunk
+        SFG_HIP(ctx, hipMalloc(&rotf, (rows + pad_rows) * (size_t)nplanes * SFG_N * 8));
+        if (pad_rows) SFG_HIP(ctx, hipMemsetAsync(rotf + rows * (size_t)nplanes * SFG_N, 0, pad_rows * (size_t)nplanes * SFG_N * 8, ctx->stream));
         rc = launch_rot_to_f64(ctx, (const u64 *)rot, rows, L, L, rotf);
         MacStrides st;
         st.rot_k = (size_t)R * L * SFG_N; st.rot_r = (size_t)L * SFG_N;

@@ -107,16 +107,17 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
     }
     const unsigned char *zsrc = (const unsigned char *)(a.zeros + piece * 2);
     const int nchunk_full = a.K / DM_KC;                              // chunks whose 4 k-steps all exist
+    // Chunks are issued in order, so each job keeps one running source pointer.  In the ragged last chunk (K % 4 != 0)
+    // the padded k-steps take a zero plaintext; the rot operand is read as is - the caller guarantees that the
+    // (up to 3) k-slices after the last hold finite doubles (launch_mac_dma contract), and x * 0 adds nothing.
     auto issue_chunk = [&](int ch) {
         unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
         const bool ragged = ch >= nchunk_full;                        // wave-uniform
 #pragma unroll
         for (int t = 0; t < A; t++) {
-            const unsigned char *src = src0[t] + (size_t)ch * step[t];
-            if (ragged && kind[t] != 2) {
-                const int k = ch * DM_KC + kk_of[t];
-                if (k >= a.K) src = kind[t] == 1 ? zsrc : src0[t] - (size_t)kk_of[t] * a.rotf_k_stride * 8;   // padded k-step: zero plaintext; rot row of k = 0
-            }
+            const unsigned char *src = src0[t];
+            src0[t] += step[t];
+            if (ragged && kind[t] == 1 && ch * DM_KC + kk_of[t] >= a.K) src = zsrc;
             dma16(src, slot + (wave * A + t) * 1024);
         }
     };
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
 #pragma unroll
             for (int t = 0; t < DM_CT; t++) {
                 const u64 p = pp[t];
-                if (BIG) { p0[t] = (double)(unsigned)(p & 0x7FFFFFu); p1[t] = u64_to_f64(p >> 23); p2[t] = 0.0; }
+                if (BIG) { p0[t] = (double)(unsigned)(p & 0x7FFFFFu); p1[t] = (double)(unsigned)(p >> 23); p2[t] = p0[t] + p1[t]; }   // Karatsuba: p2 = p_lo + p_hi
                 else {
                     const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
                     p0[t] = (double)(plo & 0xFFFu); p1[t] = (double)((plo >> 12) & 0xFFFu); p2[t] = (double)((plo >> 24) | (phi << 8));
@@ -172,10 +173,10 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
 #pragma unroll
                 for (int t = 0; t < DM_CT; t++) {
                     if (BIG) {
+                        // 3 products per MAC: lo*lo, hi*hi and (lo+hi)*(lo+hi); the middle limb is recovered in the epilogue
                         acc[r][t][0] = __builtin_fma(rr[2 * r], p0[t], acc[r][t][0]);
-                        acc[r][t][1] = __builtin_fma(rr[2 * r], p1[t], acc[r][t][1]);
-                        acc[r][t][1] = __builtin_fma(rr[2 * r + 1], p0[t], acc[r][t][1]);
                         acc[r][t][2] = __builtin_fma(rr[2 * r + 1], p1[t], acc[r][t][2]);
+                        acc[r][t][1] = __builtin_fma(rr[2 * r] + rr[2 * r + 1], p2[t], acc[r][t][1]);
                     } else {
                         acc[r][t][0] = __builtin_fma(rr[r], p0[t], acc[r][t][0]);
                         acc[r][t][1] = __builtin_fma(rr[r], p1[t], acc[r][t][1]);
@@ -224,7 +225,8 @@ __global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModC
         for (int r = 0; r < DM_RH; r++) {
             const int row = a.r0 + rh * DM_RH + r;
             double x = pred(acc[r][t][0], q, qinv);
-            x += mulmod_lazy(pred(acc[r][t][1], q, qinv), s1, s1q, q);
+            const double mid = BIG ? pred(acc[r][t][1], q, qinv) - pred(acc[r][t][0], q, qinv) - pred(acc[r][t][2], q, qinv) : pred(acc[r][t][1], q, qinv);
+            x += mulmod_lazy(mid, s1, s1q, q);
             x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
             x += a.accumulate ? u64_to_f64(oldv[r][t] & 0x000FFFFFFFFFFFFFULL) : 0.0;
             if (n < a.Ncols && row < a.R)
@@ -262,18 +264,22 @@ int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, in
     const int N = SFG_N;
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) return 1;
-    int *d_tab = nullptr;
-    SFG_HIP(ctx, hipMalloc(&d_tab, 2 * L * sizeof(int)));
-    SFG_HIP(ctx, hipMemcpy(d_tab, plane_of.data(), L * sizeof(int), hipMemcpyHostToDevice));
-    SFG_HIP(ctx, hipMemcpy(d_tab + L, is_big.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    // plane tables live in the context scratch pool (one small blocking upload per call would drain the stream)
+    int *d_tab = nullptr; char name[32]; snprintf(name, sizeof name, "mac.planes.%d", L);
+    const bool fresh = ctx->pool.find(name) == ctx->pool.end();
+    SFG_TRY(sfg_scratch(ctx, name, 2 * L * sizeof(int), (void **)&d_tab));
+    if (fresh) {
+        SFG_HIP(ctx, hipMemcpy(d_tab, plane_of.data(), L * sizeof(int), hipMemcpyHostToDevice));
+        SFG_HIP(ctx, hipMemcpy(d_tab + L, is_big.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    }
     hipLaunchKernelGGL(k_rot_to_f64, dim3((unsigned)(nrows * L * (N / 256))), dim3(256), 0, ctx->stream, rot, rotf, nl_rot, L, (size_t)nplanes * N, d_tab, d_tab + L);
     SFG_HIP(ctx, hipGetLastError());
-    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SFG_HIP(ctx, hipFree(d_tab));
     return 0;
 }
 
 // rotf: fp64 rotation cache with row stride nplanes*N doubles; rows_per_k = rows (ct, poly) between consecutive k.
+// Contract: when K % 4 != 0 the buffer must extend over the k-slices K .. 4*ceil(K/4)-1 and hold finite doubles there
+// (they are multiplied by zero plaintexts).
 int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate,
                    const MacStrides &st) {
     const int N = SFG_N;
@@ -299,7 +305,7 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             }
             a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
             a.pt_half = st.pt_half ? 1 : 0; a.pt_l_stride = st.pt_half ? N / 2 : N;
-            double maxterm = big ? 2.0 * 16777216.0 * 16777216.0 : 0.0;
+            double maxterm = big ? 16777216.0 * 16777216.0 : 0.0;            // (lo+hi)*(lo+hi) < 2^48
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / DM_KC) * DM_KC;
             if (f < DM_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");

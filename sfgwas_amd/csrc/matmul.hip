@@ -147,7 +147,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
-        SFG_TRY(sfg_scratch(ctx, "mm.rotf", (size_t)G * d * s * 2 * rowf * 8, (void **)&rotf));
+        SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)G * d + 3) * s * 2 * rowf * 8, (void **)&rotf));      // + 3 k-slices: see launch_mac_dma
     }
     const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
@@ -182,6 +182,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             if (dma) rc = launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf + (size_t)g * d * s * 2 * rowf);
         }
         if (rc) break;
+        if (dma && (ng * d) % 4) {        // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
+            if (hipMemsetAsync(rotf + (size_t)ng * d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream) != hipSuccess) { ctx->err = "matmul: memset failed"; rc = 1; break; }
+        }
         for (int bj = j0; bj < j1 && !rc; bj++) {
             const int nc = sh.cols_of(bj);
             for (int g = 0; g < ng && !rc; g++) {
