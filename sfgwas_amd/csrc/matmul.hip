@@ -118,11 +118,43 @@ extern "C" int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows, size_t nrows_of
     return 0;
 }
 
+// ---------------------------------------------------------------- rotation cache of one operand block row
+// rotc[baby][i] = RotateRight(A[i][bi], -baby) (matmult.go:1373-1377) for the active baby steps, then (LDS-DMA MAC) the fp64
+// operand form into rotf_dst.  a_row / rotc are scratch of s resp. d*s ciphertexts.
+static int build_rot_row(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int nl, int lev, int L, const Shape &sh, int bi, u64 *a_row, u64 *rotc,
+                         bool dma, double *rotf_dst) {
+    const int N = SFG_N, d = SFG_D; const size_t ctw = (size_t)2 * nl * N;
+    const int nr = sh.rows_of(bi);
+    // active baby steps (matmult.go:1326-1336), union over ALL block columns of the operand as in the reference
+    std::vector<uint8_t> baby_t(d, 0);
+    for (int shift = 0; shift < SFG_SLOTS; shift++) {
+        if (baby_t[shift % d]) continue;
+        bool any = false;
+        for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
+        if (any) baby_t[shift % d] = 1;
+    }
+    for (int i = 0; i < s; i++) {                  // A[i][bi] at the dropped level, contiguous over i
+        const u64 *src = A + ((size_t)i * sh.nbr + bi) * 2 * nl_in * N;
+        if (nl == nl_in) SFG_HIP(ctx, hipMemcpyAsync(a_row + (size_t)i * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_row + (size_t)i * ctw, nl_in, nl);
+    }
+    SFG_HIP(ctx, hipGetLastError());
+    {
+        PhaseTimer t(ctx, "rotate");
+        std::vector<int> nrv((size_t)d * s, 0), inv((size_t)d * s, 0);
+        for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) { nrv[(size_t)baby * s + i] = baby_t[baby] ? -baby : 0; inv[(size_t)baby * s + i] = i; }
+        SFG_TRY(launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data()));
+        t.stop(1);
+    }
+    if (dma) SFG_TRY(launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf_dst));
+    return 0;
+}
+
 // ---------------------------------------------------------------- phase 1: accumulate
 // acc_dev: [(j - j0)][giant < d][i < s][2][L][N] canonical residues (zero-initialised here unless accumulate != 0)
 // for operand block rows [b0, b1) and block columns [j0, j1).
 static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, const Shape &sh, unsigned flags,
-                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc) {
+                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc, const double *rotf_pre = nullptr) {
     const int N = SFG_N, d = SFG_D, L = max_level;
     const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "matmul: max_level out of range");
@@ -147,43 +179,22 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
-        SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)G * d + 3) * s * 2 * rowf * 8, (void **)&rotf));      // + 3 k-slices: see launch_mac_dma
+        if (!rotf_pre) SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)G * d + 3) * s * 2 * rowf * 8, (void **)&rotf));      // + 3 k-slices: see launch_mac_dma
     }
     const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
     bool first_group = true;
     for (int bg = b0; bg < b1 && !rc; bg += G) {
         const int ng = std::min(G, b1 - bg);
-        // ---- rotation caches of the group's block rows
-        for (int g = 0; g < ng && !rc; g++) {
-            const int bi = bg + g, nr = sh.rows_of(bi);
-            // active baby steps (matmult.go:1326-1336), union over ALL block columns of the operand as in the reference
-            std::vector<uint8_t> baby_t(d, 0);
-            for (int shift = 0; shift < SFG_SLOTS; shift++) {
-                if (baby_t[shift % d]) continue;
-                bool any = false;
-                for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
-                if (any) baby_t[shift % d] = 1;
-            }
-            for (int i = 0; i < s && !rc; i++) {                  // A[i][bi] at the dropped level, contiguous over i
-                const u64 *src = A + ((size_t)i * sh.nbr + bi) * 2 * nl_in * N;
-                if (nl == nl_in) { if (hipMemcpyAsync(a_row + (size_t)i * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = 1; }
-                else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_row + (size_t)i * ctw, nl_in, nl);
-            }
-            if (rc) { ctx->err = "matmul: staging of A failed"; break; }
-            {   // rotc[baby][i] = RotateRight(A[i][bi], -baby) (matmult.go:1373-1377); one batch, decomposition shared per input
-                PhaseTimer t(ctx, "rotate");
-                std::vector<int> nrv((size_t)d * s, 0), inv((size_t)d * s, 0);
-                for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) { nrv[(size_t)baby * s + i] = baby_t[baby] ? -baby : 0; inv[(size_t)baby * s + i] = i; }
-                rc = launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data());
-                t.stop(1);
-            }
+        // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
+        const double *rotf_grp = rotf;
+        if (rotf_pre) rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf;
+        else {
+            for (int g = 0; g < ng && !rc; g++) rc = build_rot_row(ctx, A, s, nl_in, nl, lev, L, sh, bg + g, a_row, rotc, dma, dma ? rotf + (size_t)g * d * s * 2 * rowf : nullptr);
             if (rc) break;
-            if (dma) rc = launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf + (size_t)g * d * s * 2 * rowf);
-        }
-        if (rc) break;
-        if (dma && (ng * d) % 4) {        // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
-            if (hipMemsetAsync(rotf + (size_t)ng * d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream) != hipSuccess) { ctx->err = "matmul: memset failed"; rc = 1; break; }
+            if (dma && (ng * d) % 4) {    // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
+                if (hipMemsetAsync(rotf + (size_t)ng * d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream) != hipSuccess) { ctx->err = "matmul: memset failed"; rc = 1; break; }
+            }
         }
         for (int bj = j0; bj < j1 && !rc; bj++) {
             const int nc = sh.cols_of(bj);
@@ -224,7 +235,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
-                if (dma) rc = launch_mac_dma(ctx, rotf, (size_t)s * 2, pt, accj, ng * d, 2 * s, d, L, acc_flag, st);
+                if (dma) rc = launch_mac_dma(ctx, rotf_grp, (size_t)s * 2, pt, accj, ng * d, 2 * s, d, L, acc_flag, st);
                 else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
                 t.stop(1);
             }
@@ -306,12 +317,32 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     const int m_out = j1 - j0;
     // column groups bounded by an accumulator budget (default 24 GiB)
     size_t budget = 24ULL << 30;
+    if (const char *e = getenv("SFG_MM_ACC_BUDGET_MB")) budget = (size_t)atoll(e) << 20;
     int jg = (int)(budget / ((size_t)d * accw * 8)); if (jg < 1) jg = 1;
+    // Several column groups would each rebuild the rotation cache of every block row (91 key switches per input
+    // ciphertext).  When the whole cache fits (48 GiB; Q*X at 100k x 1M: 13 block rows = 28 GB) it is built once here.
+    const double *rotf_all = nullptr;
+    if (mac_use_dma() && j1 - j0 > jg && b1 > b0) {
+        std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+        if (nplanes < 0) return 1;
+        const size_t rowf = (size_t)nplanes * N, per_row = (size_t)d * s * 2 * rowf;       // doubles per block row
+        const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1;
+        if (nl >= L && ((size_t)(b1 - b0) * per_row + 3 * (size_t)s * 2 * rowf) * 8 <= (48ULL << 30)) {
+            double *buf = nullptr; u64 *a_row = nullptr, *rotc = nullptr;
+            const size_t ctw = (size_t)2 * nl * N;
+            SFG_TRY(sfg_scratch(ctx, "mm.rotf_all", ((size_t)(b1 - b0) * per_row + 3 * (size_t)s * 2 * rowf) * 8, (void **)&buf));
+            SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
+            SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
+            for (int bi = b0; bi < b1; bi++) SFG_TRY(build_rot_row(ctx, (const u64 *)A, s, in_level + 1, nl, lev, L, sh, bi, a_row, rotc, true, buf + (size_t)(bi - b0) * per_row));
+            SFG_HIP(ctx, hipMemsetAsync(buf + (size_t)(b1 - b0) * per_row, 0, 3 * (size_t)s * 2 * rowf * 8, ctx->stream));   // k-slices read by a ragged last chunk
+            rotf_all = buf;
+        }
+    }
     for (int ja = j0; ja < j1; ja += jg) {
         const int jb = std::min(j1, ja + jg);
         u64 *acc = nullptr;
         SFG_TRY(sfg_scratch(ctx, "mm.acc", (size_t)(jb - ja) * d * accw * 8, (void **)&acc));
-        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc);
+        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc, rotf_all);
         if (!rc) rc = matmul_finalize(ctx, acc, s, max_level, jb - ja, m_out, ja - j0, 0, d, &giant_t, 0, (u64 *)out);
         if (rc) return rc;
     }

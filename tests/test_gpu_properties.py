@@ -144,10 +144,12 @@ np.save(sys.argv[1], h)
 
 
 def test_group_size_and_mac_kernel_invariance(tmp_path):
-    """the same product in three separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8 and the register-staged MAC"""
+    """the same product in separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8, the register-staged MAC, and a small
+    accumulator budget (one block column per pass -> the product-wide rotation cache is built once and reused)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"})]:
+    for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"}),
+                       ("budget", {"SFG_MM_ACC_BUDGET_MB": "300"}), ("budget_g1", {"SFG_MM_ACC_BUDGET_MB": "300", "SFG_MM_GROUP": "1"})]:
         f = str(tmp_path / (name + ".npy"))
         e = dict(os.environ); e.update(envv)
         r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
@@ -155,4 +157,5 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1]), "block-row grouping changed the result"
     assert np.array_equal(outs[0], outs[2]), "LDS-DMA and register-staged MAC kernels disagree"
+    assert np.array_equal(outs[0], outs[3]) and np.array_equal(outs[0], outs[4]), "column passes / shared rotation cache changed the result"
     assert outs[0].any()
