@@ -113,17 +113,58 @@ void sfg_encoder_destroy(sfg_ctx *ctx) {
 // D[shift][j] = X[(shift + j) mod n][j] inside the r x c block, 0 outside (GetDiag, matmult.go:636-664 with
 // index = -shift).  A diagonal that "does not exist" (GetDiagBool false) is all zero here, which encodes to
 // the zero plaintext — the same contribution as the reference's skipped nil plaintext (matmult.go:392).
+// Tiled: a workgroup produces 128 shifts x 128 columns.  The X elements it needs, X[(S0+J0+u) mod n][J0+jj] with
+// u = s + jj < 255, are 255 row segments of 128 contiguous bytes (for the transposed operand: 128 rows of 255
+// contiguous bytes), staged through LDS so that both the HBM reads and the D writes are contiguous runs.
+constexpr int SK_T = 128, SK_U = 2 * SK_T - 1, SK_PITCH = 132;
 __global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D) {
-    const int n = SFG_SLOTS;
-    const int j = blockIdx.x * 256 + threadIdx.x, shift = blockIdx.y;
-    int i = shift + j; if (i >= n) i -= n;
-    int8_t v = 0;
-    if (i < r && j < c) {
-        v = transposed ? blk[(size_t)j * ld + i] : blk[(size_t)i * ld + j];
-        if (v < 0) v = 0;                    // missing -> 0 (matmult.go:1292-1295)
-        if (square) v = (int8_t)(v * v);     // :1301-1303
+    __shared__ int8_t tile[SK_U * SK_PITCH];                 // tile[u][jj]
+    const int n = SFG_SLOTS, tid = threadIdx.x;
+    const int J0 = blockIdx.x * SK_T, S0 = blockIdx.y * SK_T;
+    // 4 consecutive bytes along the contiguous axis: one dword load when the run is inside the block and 4-byte aligned
+    auto load4 = [&](const int8_t *src, int nvalid) -> unsigned {
+        if (nvalid >= 4 && ((uintptr_t)src & 3) == 0) return *reinterpret_cast<const unsigned *>(src);
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k < nvalid) w |= (unsigned)(uint8_t)src[k] << (8 * k);
+        return w;
+    };
+    if (!transposed) {
+        // rows u (255) x 128 bytes: thread = (row-in-pass tid >> 5, dword tid & 31)
+        const int q = tid & 31;
+        for (int u = tid >> 5; u < SK_U; u += 8) {
+            int i = S0 + J0 + u; if (i >= n) i -= n;
+            const int j = J0 + 4 * q;
+            const unsigned w = i < r ? load4(blk + (size_t)i * ld + j, c - j) : 0u;
+            *reinterpret_cast<unsigned *>(tile + u * SK_PITCH + 4 * q) = w;
+        }
+    } else {
+        // element (i, j) lives at blk[j*ld + i]: rows jj (128) x 256 contiguous bytes along u (S0 + J0 and the wrap
+        // point are multiples of 128, so a dword never straddles the wrap)
+        for (int idx = tid; idx < SK_T * 64; idx += 256) {
+            const int jj = idx >> 6, u = (idx & 63) * 4;
+            int i = S0 + J0 + u; if (i >= n) i -= n;
+            const int j = J0 + jj;
+            const unsigned w = j < c ? load4(blk + (size_t)j * ld + i, r - i) : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (u + k < SK_U) tile[(u + k) * SK_PITCH + jj] = (int8_t)(w >> (8 * k));
+        }
     }
-    D[(size_t)shift * n + j] = v;
+    __syncthreads();
+    // D[S0+s][J0 + 4q .. 4q+3] = tile[s + jj][jj]
+    const int q = tid & 31;
+    for (int s = tid >> 5; s < SK_T; s += 8) {
+        unsigned packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int jj = 4 * q + k;
+            int v = tile[(s + jj) * SK_PITCH + jj];
+            if (v < 0) v = 0;                    // missing -> 0 (matmult.go:1292-1295)
+            if (square) v = v * v;               // :1301-1303
+            packed |= (unsigned)(v & 0xFF) << (8 * k);
+        }
+        *reinterpret_cast<unsigned *>(D + (size_t)(S0 + s) * n + J0 + 4 * q) = packed;
+    }
 }
 
 // ---------------------------------------------------------------- FFT encode
@@ -279,7 +320,7 @@ static int enc_scratch(sfg_ctx *ctx, EncTables *et, size_t nplain) {
 }
 
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D) {
-    hipLaunchKernelGGL(k_skew, dim3(SFG_SLOTS / 256, SFG_SLOTS), dim3(256), 0, ctx->stream, blk, ld, r, c, transposed, square, D);
+    hipLaunchKernelGGL(k_skew, dim3(SFG_SLOTS / SK_T, SFG_SLOTS / SK_T), dim3(256), 0, ctx->stream, blk, ld, r, c, transposed, square, D);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
