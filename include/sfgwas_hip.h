@@ -79,6 +79,10 @@ int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block_dev, size_t ld, int r
 /* coefficient-domain result of the encoder for arbitrary real slot vectors (host convenience used by
  * Mask/MaskTrunc-style callers, basics.go:110-172): values_host[nvec][slots] -> coeffs_host[nvec][N] int64 */
 int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, int64_t *coeffs_host);
+/* crypto.EncodeFloatVector (crypto.go:398-420; behind Mask / MaskTrunc / MaskWithScaling, basics.go:110-172, and
+ * CPMult operands): nvec real slot vectors [nvec][slots] (host) -> NTT-domain plaintexts pt_dev[nvec][level+1][N]
+ * at the context's default scale. The reference encodes at MaxLevel; a product at a lower level reads the first rows. */
+int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, int nvec, int level, uint64_t *pt_dev);
 
 /* ---- C1/A8: rotations (crypto/basics.go:201-224 -> ckks.Evaluator.RotateNew) ----
  * batch of nct ciphertexts at `level`, each [2][level+1][N]; ct j is rotated RIGHT by nrot_host[j]

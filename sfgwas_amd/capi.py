@@ -41,6 +41,7 @@ def _sig(L):
         "sfg_mac_dev": (i, [vp, vp, vp, vp, i, i, i, i, i]),
         "sfg_encode_diags_dev": (i, [vp, vp, sz, i, i, i, i, i, i, vp]),
         "sfg_encode_coeffs_host": (i, [vp, C.POINTER(d), i, C.POINTER(C.c_int64)]),
+        "sfg_encode_vectors_dev": (i, [vp, C.POINTER(d), i, i, vp]),
         "sfg_rotate_right_dev": (i, [vp, vp, vp, i, i, C.POINTER(i)]),
         "sfg_ct_add_dev": (i, [vp, vp, vp, vp, i, i]),
         "sfg_ct_sub_dev": (i, [vp, vp, vp, vp, i, i]),
@@ -330,3 +331,16 @@ def _ctx_geno_from_bed(self, bed, num_sample, num_snp, row_filter=None, col_filt
 
 Context.geno_to_host = _ctx_geno_to_host
 Context.geno_from_bed = _ctx_geno_from_bed
+
+
+def _ctx_encode_vectors(self, values, level):
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    nvec = values.shape[0]
+    out = self.malloc(nvec * (level + 1) * self.N * 8)
+    self.check(lib().sfg_encode_vectors_dev(self.h, values.ctypes.data_as(C.POINTER(C.c_double)), nvec, level, out), "encode_vectors")
+    res = self.to_host(out, (nvec, level + 1, self.N), np.uint64)
+    self.free(out)
+    return res
+
+
+Context.encode_vectors = _ctx_encode_vectors

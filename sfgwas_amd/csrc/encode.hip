@@ -397,3 +397,23 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     }
     return 0;
 }
+
+// crypto.EncodeFloatVector (crypto.go:398-420 -> encoder.EncodeNTT at `level`, default scale): nvec real slot vectors
+// -> NTT-domain plaintexts pt_dev[nvec][level+1][N] (canonical residues).  Feeds Mask / MaskTrunc / CPMult.
+extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, int nvec, int level, uint64_t *pt_dev) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (nvec <= 0) return 0;
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "encode_vectors: level out of range");
+    EncTables *et = (EncTables *)ctx->enc_tables;
+    const size_t n = SFG_SLOTS, lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    void *p = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
+    double *dv = (double *)p; long long *dpc = (long long *)(dv + (size_t)nvec * n);
+    SFG_HIP(ctx, hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc);
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_TRY(launch_ntt_plain(ctx, dpc, (u64 *)pt_dev, (size_t)nvec, level + 1));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // values_host may be reused by the caller
+    return 0;
+}

@@ -6,6 +6,7 @@
 //   crypto::CryptoParams / Ciphertext / CipherVector / CipherMatrix      crypto/crypto.go:32-60
 //   crypto::RotateRight, RotateRightWithEvaluator                        crypto/basics.go:201-224
 //   crypto::Mult, CMult, CPMult, CAdd, CSub, CRescale, InnerSumAll       crypto/basics.go:226-292, 386-470, 568-590, 707-720
+//   crypto::EncodeFloatVector, Mask, MaskTrunc, MaskWithScaling, CMask   crypto/crypto.go:398-420, basics.go:110-172, 673-693
 //   gwas::GenoFileStream                                                 gwas/filestream.go:284-494
 //   gwas::DiagCacheStream (reader + writer, reference byte format)       gwas/filestream.go:19-282
 //   gwas::MatMult4Stream / MatMult4StreamPreprocess / MatMult4StreamCompute   gwas/matmult.go:914,1043,1238
@@ -147,6 +148,38 @@ inline CipherVector CPMult(CryptoParams *cps, const CipherVector &X, const Plain
     }
     cps->check(sfg_ct_mul_plain_dev(cps->ctx, dx.u(), dp.u(), Y.size() == 1 ? 0 : pw, dout.u(), (int)n, level), "CPMult");
     return detail::rescaleOnDevice(cps, dout, n, level, X[0].scale * Y[0].scale, cps->scale, qi);
+}
+// crypto.go:398-420 EncodeFloatVector: packs f into ceil(len/slots) plaintexts at `level` (the reference uses MaxLevel), default scale
+inline PlainVector EncodeFloatVector(CryptoParams *cps, const std::vector<double> &f, int level) {
+    const size_t slots = (size_t)cps->GetSlots(), nvec = (f.size() + slots - 1) / slots, pw = (size_t)(level + 1) * cps->N();
+    std::vector<double> padded(nvec * slots, 0.0);
+    std::copy(f.begin(), f.end(), padded.begin());
+    detail::DevBuf d(cps, nvec * pw * 8);
+    cps->check(sfg_encode_vectors_dev(cps->ctx, padded.data(), (int)nvec, level, d.u()), "EncodeFloatVector");
+    PlainVector out(nvec);
+    for (size_t i = 0; i < nvec; i++) { out[i].level = level; out[i].scale = cps->scale; out[i].data.resize(pw); cps->check(sfg_memcpy_d2h(cps->ctx, out[i].data.data(), d.u() + i * pw, pw * 8), "d2h"); }
+    return out;
+}
+// basics.go:129-148: keep ? every slot but `ind` : only slot `ind`, times scalingFactor; MulRelinNew(mask, ct) + Rescale
+inline Ciphertext MaskWithScaling(CryptoParams *cps, const Ciphertext &ct, int ind, bool keep, double scalingFactor, const std::vector<uint64_t> &qi) {
+    std::vector<double> m(cps->GetSlots(), keep ? scalingFactor : 0.0);
+    m[ind] = keep ? 0.0 : scalingFactor;
+    return CPMult(cps, {ct}, EncodeFloatVector(cps, m, ct.level), qi)[0];
+}
+inline Ciphertext Mask(CryptoParams *cps, const Ciphertext &ct, int index, bool keepRest, const std::vector<uint64_t> &qi) {   // :150-172
+    return MaskWithScaling(cps, ct, index, keepRest, 1.0, qi);
+}
+inline Ciphertext MaskTrunc(CryptoParams *cps, const Ciphertext &ct, int N, const std::vector<uint64_t> &qi) {                  // :110-127
+    if (N == cps->GetSlots()) return ct;
+    std::vector<double> m(cps->GetSlots(), 0.0);
+    for (int i = 0; i < N; i++) m[i] = 1.0;
+    return CPMult(cps, {ct}, EncodeFloatVector(cps, m, ct.level), qi)[0];
+}
+inline CipherVector CMask(CryptoParams *cps, const CipherVector &cv, int index, bool keepRest, const std::vector<uint64_t> &qi) {   // :673-693
+    if (cv.empty()) return cv;
+    std::vector<double> m((size_t)cps->GetSlots() * cv.size(), keepRest ? 1.0 : 0.0);     // one mask over the whole vector: every
+    m[index] = keepRest ? 0.0 : 1.0;                                                      // ciphertext is multiplied and rescaled
+    return CPMult(cps, cv, EncodeFloatVector(cps, m, cv[0].level), qi);
 }
 inline CipherVector addSub(CryptoParams *cps, const CipherVector &X, const CipherVector &Y, bool sub) {
     const size_t n = X.size(); const int level = X[0].level; const size_t w = detail::ctWords(cps, level);

@@ -1,7 +1,7 @@
 // GPU check of the host mirror: MatMult4Stream / MatMult4StreamPreprocess+Compute / RotateRight called exactly the
 // way the Go callers call them (assoc.go:395, pca.go:112-113,344,352), on files prepared by tests/test_host_mirror.py.
 // Usage: host_gpu_test <casedir>.  Inputs (little-endian): moduli.bin (nq, np, u64...), keys.bin (count, then per key:
-// galois, words...), A.bin, geno.bin + dims in case.txt.  rlk.bin.  Outputs: out_stream.bin, sums.bin, out_xt.bin, rot.bin, cmult.bin, csub.bin.
+// galois, words...), A.bin, geno.bin + dims in case.txt.  rlk.bin.  Outputs: out_stream.bin, sums.bin, out_xt.bin, rot.bin, cmult.bin, csub.bin, masktrunc.bin.
 #include "../../sfgwas_amd/host/gwas.hpp"
 #include <fstream>
 #include <iostream>
@@ -50,6 +50,10 @@ int main(int argc, char **argv) {
         if (prod[0].level != level - 1) throw std::runtime_error("CMult must rescale exactly once at scale 2^68");
         writeU64(dir + "/cmult.bin", prod[0].data);
         writeU64(dir + "/csub.bin", crypto::CSub(cps.get(), A[0], A[1])[0].data);
+        // --- crypto.MaskTrunc (basics.go:110) as QXLazyNormStream applies it to the tail ciphertext (matmult.go:62-70)
+        auto mt = crypto::MaskTrunc(cps.get(), A[0][0], 1000, qi);
+        if (mt.level != level - 1) throw std::runtime_error("MaskTrunc must consume one level");
+        writeU64(dir + "/masktrunc.bin", mt.data);
         bool threw = false; try { gwas::MatMult4StreamCompute(cps.get(), A, maxLevel, dir + "/no_such_cache", m_ct); } catch (const std::runtime_error &) { threw = true; }
         if (!threw) throw std::runtime_error("missing cache prefix must fail loudly");
         std::cout << "OK" << std::endl;

@@ -68,6 +68,19 @@ def test_mul_plain_and_sub_bit_exact(env):
         assert np.array_equal(got[j], want)
 
 
+def test_encode_float_vectors_bit_exact(env):
+    """crypto.EncodeFloatVector on the device (behind Mask / MaskTrunc / CPMult operands): arbitrary real vectors, MaxLevel"""
+    ctx, ring, s, rlk = env
+    rnd = np.random.default_rng(8)
+    vals = np.stack([rnd.normal(size=ring.slots) * 3.0, (rnd.random(ring.slots) < 0.5).astype(np.float64), np.zeros(ring.slots)])
+    vals[2, 17] = 1.0
+    got = ctx.encode_vectors(vals, 9)
+    for k in range(3):
+        assert np.array_equal(got[k], ring.encode_ntt(vals[k], 2.0 ** 34, 10)), f"vector {k}"
+    got3 = ctx.encode_vectors(vals[:1], 3)
+    assert np.array_equal(got3[0], got[0][:4])                 # a lower level is a prefix of the rows
+
+
 def test_innersum_all_bit_exact_and_decrypts_to_total(env):
     ctx, ring, s, rlk = env
     import pyref

@@ -108,3 +108,10 @@ def test_host_mirror_matmul_end_to_end(tmp_path):
     df = np.zeros_like(a0)
     ol.lib().orc_ct_addsub(ring.h, level, ol.p64(a0), ol.p64(a1), 1, ol.p64(df))
     assert np.array_equal(np.fromfile(tmp_path / "csub.bin", dtype=np.uint64).reshape(df.shape), df)
+    # MaskTrunc(ct, 1000) = encode(1 on the first 1000 slots) x ct, rescaled once
+    mvec = np.zeros(ring.slots); mvec[:1000] = 1.0
+    mpt = ring.encode_ntt(mvec, 2.0 ** 34, level + 1)
+    mp = np.zeros_like(a0)
+    ol.lib().orc_mul_plain(ring.h, level, ol.p64(a0), ol.p64(mpt), ol.p64(mp))
+    ol.lib().orc_rescale(ring.h, level, ol.p64(mp), ol.p64(rs))
+    assert np.array_equal(np.fromfile(tmp_path / "masktrunc.bin", dtype=np.uint64).reshape(rs.shape), rs)
