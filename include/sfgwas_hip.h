@@ -94,6 +94,14 @@ int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, u
 /* C4: eval.Sub (crypto.CSub, basics.go:575-590): out = a - b */
 int sfg_ct_sub_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
 
+/* C4: eval.MultByConst / AddConst / AddNew(ct, plaintext) behind crypto.CMultConst, CMultConstRescale, AddConst, CAddConst,
+ * AddPlain, CPAdd (basics.go:183-199, 472-497, 533-551, 592-611). scalars_host[level+1]: one canonical residue per modulus
+ * (lattigo scaleUpExact(constant, scale, q_m); the host side owns that rule and the scale bookkeeping). out may alias ct. */
+int sfg_ct_mul_scalar_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *scalars_host, uint64_t *out_dev, int nct, int level);
+int sfg_ct_add_scalar_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *scalars_host, uint64_t *out_dev, int nct, int level);
+int sfg_ct_add_plain_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *pt_dev, size_t pt_stride, uint64_t *out_dev,
+                         int nct, int level);
+
 /* ---- C3: ciphertext products (crypto.CMult / CPMult / Mask, basics.go:110-172, 386-470) ----
  * The relinearisation key (cryptoParams.Rlk, crypto.go:47) has the same layout as a rotation key:
  * [beta][2][nq+np][N], montgomery != 0 if in lattigo's stored Montgomery form. */

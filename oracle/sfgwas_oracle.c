@@ -556,6 +556,44 @@ int orc_innersum_all(const orc_ring *r, const orc_rotkeys *keys, int level, cons
     }
     free(rt); return 0;
 }
+/* lattigo ckks scaleUpExact(value, n, q) restated: round(|n*value|) mod q with the sign folded back; the product and the
+ * +0.5 are taken in float64 (big.NewFloat has 53 bits of precision), the truncation is toward zero. */
+u64 orc_scale_up_exact(double value, double n, u64 q) {
+    int neg = value < 0;
+    double x = neg ? -n * value : n * value;
+    x = floor(x + 0.5);
+    u64 res = (u64)fmod(x, (double)q);                 /* fmod is exact */
+    return neg ? q - res : res;                        /* lattigo returns q (not 0) for a negative value that rounds to 0 */
+}
+/* eval.MultByConst(ct, constant float64) (behind CMultConst / CMultConstRescale, basics.go:480-497,533-551): if the constant has a
+ * fractional part it is scaled by q_level (the caller multiplies the ciphertext scale by *scale_mult), then every coefficient
+ * of both polynomials is multiplied by the scaled constant mod q_m. */
+void orc_mul_const(const orc_ring *r, int level, const u64 *ct, double constant, u64 *out, double *scale_mult) {
+    int N = r->N, nl = level + 1; double scale = 1.0;
+    if (constant != 0 && constant - (double)(long long)constant != 0) scale = (double)r->q[level];
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m], c = constant != 0 ? orc_scale_up_exact(constant, scale, q) % q : 0;
+        for (int p = 0; p < 2; p++) for (int x = 0; x < N; x++) { size_t i = ((size_t)p * nl + m) * N + x; out[i] = orc_mulmod(ct[i], c, q); }
+    }
+    *scale_mult = scale;
+}
+/* eval.AddConst(ct, constant float64) (basics.go:192-199, 604-611): adds round(constant * ct_scale) to every NTT coefficient of c0 */
+void orc_add_const(const orc_ring *r, int level, const u64 *ct, double constant, double ct_scale, u64 *out) {
+    int N = r->N, nl = level + 1;
+    memcpy(out, ct, (size_t)2 * nl * N * 8);
+    if (constant == 0) return;
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m], c = orc_scale_up_exact(constant, ct_scale, q) % q;
+        for (int x = 0; x < N; x++) { size_t i = (size_t)m * N + x; u64 v = ct[i] + c; out[i] = v >= q ? v - q : v; }
+    }
+}
+/* eval.AddNew(ct, plaintext) (AddPlain / CPAdd, basics.go:183-190, 592-602): c0 += pt */
+void orc_add_plain(const orc_ring *r, int level, const u64 *ct, const u64 *pt, u64 *out) {
+    int N = r->N, nl = level + 1;
+    memcpy(out, ct, (size_t)2 * nl * N * 8);
+    for (int m = 0; m < nl; m++) { u64 q = r->q[m]; for (int x = 0; x < N; x++) { size_t i = (size_t)m * N + x; u64 v = ct[i] + pt[i]; out[i] = v >= q ? v - q : v; } }
+}
+
 /* relinearisation key for tests: digit i = (b_i, a_i), b_i = -a_i*s + e_i + P*g_i*s^2 */
 void orc_gen_rlk(const orc_ring *r, const int8_t *s, u64 seed, u64 *key) {
     int N = r->N, nq = r->nq, np = r->np, nmod = nq + np, beta = orc_rotkeys_beta(r);

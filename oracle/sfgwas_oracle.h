@@ -100,6 +100,10 @@ void orc_mulrelin(const orc_ring *r, int level, const uint64_t *a, const uint64_
 void orc_mul_plain(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *pt, uint64_t *out);
 void orc_rescale(const orc_ring *r, int level, const uint64_t *ct, uint64_t *out /*[2][level][N]*/);
 int orc_innersum_all(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *cts, int nct, uint64_t *out);
+uint64_t orc_scale_up_exact(double value, double n, uint64_t q);
+void orc_mul_const(const orc_ring *r, int level, const uint64_t *ct, double constant, uint64_t *out, double *scale_mult);
+void orc_add_const(const orc_ring *r, int level, const uint64_t *ct, double constant, double ct_scale, uint64_t *out);
+void orc_add_plain(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *pt, uint64_t *out);
 void orc_gen_rlk(const orc_ring *r, const int8_t *s_coeff, uint64_t seed, uint64_t *key_out);
 
 /* ---- test-side CKKS helpers (not on the reference hot path; used to build inputs / check outputs) ---- */

@@ -45,6 +45,9 @@ def _sig(L):
         "sfg_rotate_right_dev": (i, [vp, vp, vp, i, i, C.POINTER(i)]),
         "sfg_ct_add_dev": (i, [vp, vp, vp, vp, i, i]),
         "sfg_ct_sub_dev": (i, [vp, vp, vp, vp, i, i]),
+        "sfg_ct_mul_scalar_dev": (i, [vp, vp, u64p, vp, i, i]),
+        "sfg_ct_add_scalar_dev": (i, [vp, vp, u64p, vp, i, i]),
+        "sfg_ct_add_plain_dev": (i, [vp, vp, vp, sz, vp, i, i]),
         "sfg_ctx_load_relinkey": (i, [vp, u64p, i]),
         "sfg_ct_mulrelin_dev": (i, [vp, vp, vp, vp, i, i]),
         "sfg_ct_mul_plain_dev": (i, [vp, vp, vp, sz, vp, i, i]),
@@ -278,8 +281,10 @@ def _ctx_evalop(self, name, level, *arrays, out_level=None, extra=()):
     ol_ = level if out_level is None else out_level
     out = self.malloc(nct * 2 * (ol_ + 1) * self.N * 8)
     fn = getattr(lib(), name)
-    if name == "sfg_ct_mul_plain_dev":
+    if name in ("sfg_ct_mul_plain_dev", "sfg_ct_add_plain_dev"):
         self.check(fn(self.h, devs[0], devs[1], extra[0], out, nct, level), name)
+    elif name in ("sfg_ct_mul_scalar_dev", "sfg_ct_add_scalar_dev"):
+        self.check(fn(self.h, devs[0], p64(np.ascontiguousarray(extra[0], dtype=np.uint64)), out, nct, level), name)
     elif name == "sfg_ct_rescale_dev":
         self.check(fn(self.h, devs[0], out, nct, level), name)
     else:

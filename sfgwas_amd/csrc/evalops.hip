@@ -57,6 +57,24 @@ __global__ void __launch_bounds__(256) k_rescale_fin(const u64 *ct, const u64 *t
     out[(pb * level + m) * N + x] = f64_to_u64(canon(mulmod_lazy(d, rc.qLinv[m], rc.qLinv_q[m], q), q, qinv));
 }
 
+struct ScalarRow { u64 c[SFG_MAXMOD]; };
+// grid (N/256, 2*nl, nct): out = ct * c[m]  (MultByConst)
+__global__ void __launch_bounds__(256) k_mul_scalar(const u64 *ct, ScalarRow sc, u64 *out, int nl, const ModConst *modc) {
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, m = row % nl; const size_t c = blockIdx.z;
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const size_t i = (c * 2 * nl + row) * N + x;
+    out[i] = f64_to_u64(mm2(u64_to_f64(ct[i]), u64_to_f64(sc.c[m]), q, qinv));
+}
+// grid (N/256, 2*nl, nct): out = ct, with c[m] (AddConst) or pt[m][x] (AddNew(ct, plaintext)) added to polynomial 0
+__global__ void __launch_bounds__(256) k_add_c0(const u64 *ct, ScalarRow sc, const u64 *pt, size_t pt_stride, u64 *out, int nl, const ModConst *modc) {
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, m = row % nl; const size_t c = blockIdx.z;
+    const u64 q = modc[m].qi;
+    const size_t i = (c * 2 * nl + row) * N + x;
+    u64 v = ct[i];
+    if (row < nl) { v += pt ? pt[c * pt_stride + (size_t)m * N + x] : sc.c[m]; if (v >= q) v -= q; }
+    out[i] = v;
+}
+
 static int check_level(sfg_ctx *ctx, int level, int nct) {
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "evaluator op: level %d out of range", level);
     if (nct < 0) SFG_FAIL(ctx, "evaluator op: negative ciphertext count");
@@ -152,5 +170,42 @@ extern "C" int sfg_ct_innersum_dev(sfg_ctx *ctx, const uint64_t *in, int nct, in
         SFG_TRY(launch_ct_add(ctx, rt, o, o, 1, level));
     }
     t.stop(1);
+    return 0;
+}
+
+// eval.MultByConst: both polynomials times one residue per modulus (scalars_host[level+1], canonical; see crypto::CMultConst in
+// the host mirror for lattigo's scaleUpExact rule that produces them and the scale bookkeeping)
+extern "C" int sfg_ct_mul_scalar_dev(sfg_ctx *ctx, const uint64_t *ct, const uint64_t *scalars_host, uint64_t *out, int nct, int level) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(check_level(ctx, level, nct));
+    if (!nct) return 0;
+    const int N = SFG_N, nl = level + 1;
+    ScalarRow sc; memset(&sc, 0, sizeof sc);
+    for (int m = 0; m < nl; m++) { if (scalars_host[m] >= ctx->q[m]) SFG_FAIL(ctx, "mul_scalar: residue %d not canonical", m); sc.c[m] = scalars_host[m]; }
+    hipLaunchKernelGGL(k_mul_scalar, dim3(N / 256, 2 * nl, nct), dim3(256), 0, ctx->stream, (const u64 *)ct, sc, (u64 *)out, nl, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// eval.AddConst: one residue per modulus added to every NTT coefficient of polynomial 0
+extern "C" int sfg_ct_add_scalar_dev(sfg_ctx *ctx, const uint64_t *ct, const uint64_t *scalars_host, uint64_t *out, int nct, int level) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(check_level(ctx, level, nct));
+    if (!nct) return 0;
+    const int N = SFG_N, nl = level + 1;
+    ScalarRow sc; memset(&sc, 0, sizeof sc);
+    for (int m = 0; m < nl; m++) { if (scalars_host[m] >= ctx->q[m]) SFG_FAIL(ctx, "add_scalar: residue %d not canonical", m); sc.c[m] = scalars_host[m]; }
+    hipLaunchKernelGGL(k_add_c0, dim3(N / 256, 2 * nl, nct), dim3(256), 0, ctx->stream, (const u64 *)ct, sc, (const u64 *)nullptr, (size_t)0, (u64 *)out, nl, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// eval.AddNew(ct, plaintext): polynomial 0 += pt (NTT domain, [level+1][N]; pt_stride words between plaintexts, 0 = shared)
+extern "C" int sfg_ct_add_plain_dev(sfg_ctx *ctx, const uint64_t *ct, const uint64_t *pt, size_t pt_stride, uint64_t *out, int nct, int level) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(check_level(ctx, level, nct));
+    if (!nct) return 0;
+    const int N = SFG_N, nl = level + 1;
+    ScalarRow sc; memset(&sc, 0, sizeof sc);
+    hipLaunchKernelGGL(k_add_c0, dim3(N / 256, 2 * nl, nct), dim3(256), 0, ctx->stream, (const u64 *)ct, sc, (const u64 *)pt, pt_stride, (u64 *)out, nl, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -6,6 +6,7 @@
 //   crypto::CryptoParams / Ciphertext / CipherVector / CipherMatrix      crypto/crypto.go:32-60
 //   crypto::RotateRight, RotateRightWithEvaluator                        crypto/basics.go:201-224
 //   crypto::Mult, CMult, CPMult, CAdd, CSub, CRescale, InnerSumAll       crypto/basics.go:226-292, 386-470, 568-590, 707-720
+//   crypto::CMultConst(Rescale/Mat), CAddConst, AddConst, CPAdd, AddPlain  crypto/basics.go:183-199, 472-497, 533-551, 592-611
 //   crypto::EncodeFloatVector, Mask, MaskTrunc, MaskWithScaling, CMask   crypto/crypto.go:398-420, basics.go:110-172, 673-693
 //   gwas::GenoFileStream                                                 gwas/filestream.go:284-494
 //   gwas::DiagCacheStream (reader + writer, reference byte format)       gwas/filestream.go:19-282
@@ -198,6 +199,61 @@ inline CipherVector CRescale(CryptoParams *cps, const CipherVector &X, const std
     detail::upload(cps, X, level, dx, false, n);
     return detail::rescaleOnDevice(cps, dx, n, level, X[0].scale, cps->scale, qi);
 }
+// ---- constants and plaintext addends (basics.go:183-199, 472-497, 533-551, 592-611)
+// lattigo ckks scaleUpExact: round(|n * value|) mod q, sign folded back; float64 product and +0.5 (53-bit big.Float), truncation
+inline uint64_t scaleUpExact(double value, double n, uint64_t q) {
+    const bool neg = value < 0;
+    double x = std::floor((neg ? -n * value : n * value) + 0.5);
+    const uint64_t res = (uint64_t)std::fmod(x, (double)q);
+    return (neg ? q - res : res) % q;
+}
+// eval.MultByConst with a float64 constant: a fractional constant is scaled by q_level and the ciphertext scale grows by it
+inline CipherVector CMultConst(CryptoParams *cps, const CipherVector &X, double constant, const std::vector<uint64_t> &qi) {   // :480-497
+    const size_t n = X.size(); if (!n) return X;
+    const int level = X[0].level; const size_t w = detail::ctWords(cps, level);
+    double scale = 1.0;
+    if (constant != 0 && constant - (double)(long long)constant != 0) scale = (double)qi[level];
+    std::vector<uint64_t> sc(level + 1, 0);
+    for (int m = 0; m <= level; m++) sc[m] = constant != 0 ? scaleUpExact(constant, scale, qi[m]) : 0;
+    detail::DevBuf dx(cps, n * w * 8);
+    detail::upload(cps, X, level, dx, false, n);
+    cps->check(sfg_ct_mul_scalar_dev(cps->ctx, dx.u(), sc.data(), dx.u(), (int)n, level), "CMultConst");
+    return detail::download(cps, dx, n, level, X[0].scale * scale);
+}
+inline CipherVector CMultConstRescale(CryptoParams *cps, const CipherVector &X, double constant, const std::vector<uint64_t> &qi) {   // :533-551
+    return CRescale(cps, CMultConst(cps, X, constant, qi), qi);
+}
+inline CipherMatrix CMultConstMat(CryptoParams *cps, const CipherMatrix &X, double constant, const std::vector<uint64_t> &qi) {       // :472-478
+    CipherMatrix res(X.size());
+    for (size_t i = 0; i < X.size(); i++) res[i] = CMultConst(cps, X[i], constant, qi);
+    return res;
+}
+// eval.AddConst: round(constant * ct.Scale()) mod q_m on every NTT coefficient of c0
+inline CipherVector CAddConst(CryptoParams *cps, const CipherVector &X, double constant, const std::vector<uint64_t> &qi) {            // :604-611
+    const size_t n = X.size(); if (!n) return X;
+    const int level = X[0].level; const size_t w = detail::ctWords(cps, level);
+    std::vector<uint64_t> sc(level + 1, 0);
+    for (int m = 0; m <= level; m++) sc[m] = constant != 0 ? scaleUpExact(constant, X[0].scale, qi[m]) : 0;
+    detail::DevBuf dx(cps, n * w * 8);
+    detail::upload(cps, X, level, dx, false, n);
+    cps->check(sfg_ct_add_scalar_dev(cps->ctx, dx.u(), sc.data(), dx.u(), (int)n, level), "CAddConst");
+    return detail::download(cps, dx, n, level, X[0].scale);
+}
+inline Ciphertext AddConst(CryptoParams *cps, const Ciphertext &ct, double constant, const std::vector<uint64_t> &qi) { return CAddConst(cps, {ct}, constant, qi)[0]; }   // :192-199
+// eval.AddNew(ct, plaintext)
+inline CipherVector CPAdd(CryptoParams *cps, const CipherVector &X, const PlainVector &Y) {                                               // :592-602
+    const size_t n = Y.size(); if (!n) return {};
+    const int level = X[0].level; const size_t w = detail::ctWords(cps, level), pw = w / 2;
+    detail::DevBuf dx(cps, n * w * 8), dp(cps, n * pw * 8);
+    detail::upload(cps, X, level, dx, false, n);
+    for (size_t i = 0; i < n; i++) {
+        if (Y[i].level < level) throw std::runtime_error("CPAdd: plaintext level below the ciphertext level");
+        cps->check(sfg_memcpy_h2d(cps->ctx, dp.u() + i * pw, Y[i].data.data(), pw * 8), "h2d");     // first level+1 rows
+    }
+    cps->check(sfg_ct_add_plain_dev(cps->ctx, dx.u(), dp.u(), pw, dx.u(), (int)n, level), "CPAdd");
+    return detail::download(cps, dx, n, level, X[0].scale);
+}
+inline Ciphertext AddPlain(CryptoParams *cps, const Ciphertext &ct, const Plaintext &pt) { return CPAdd(cps, {ct}, {pt})[0]; }             // :183-190
 // basics.go:278-292
 inline Ciphertext InnerSumAll(CryptoParams *cps, const CipherVector &X) {
     const size_t n = X.size(); const int level = X[0].level; const size_t w = detail::ctWords(cps, level);

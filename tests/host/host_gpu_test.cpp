@@ -1,7 +1,7 @@
 // GPU check of the host mirror: MatMult4Stream / MatMult4StreamPreprocess+Compute / RotateRight called exactly the
 // way the Go callers call them (assoc.go:395, pca.go:112-113,344,352), on files prepared by tests/test_host_mirror.py.
 // Usage: host_gpu_test <casedir>.  Inputs (little-endian): moduli.bin (nq, np, u64...), keys.bin (count, then per key:
-// galois, words...), A.bin, geno.bin + dims in case.txt.  rlk.bin.  Outputs: out_stream.bin, sums.bin, out_xt.bin, rot.bin, cmult.bin, csub.bin, masktrunc.bin.
+// galois, words...), A.bin, geno.bin + dims in case.txt.  rlk.bin.  Outputs: out_stream.bin, sums.bin, out_xt.bin, rot.bin, cmult.bin, csub.bin, masktrunc.bin, cmultconst.bin.
 #include "../../sfgwas_amd/host/gwas.hpp"
 #include <fstream>
 #include <iostream>
@@ -50,6 +50,10 @@ int main(int argc, char **argv) {
         if (prod[0].level != level - 1) throw std::runtime_error("CMult must rescale exactly once at scale 2^68");
         writeU64(dir + "/cmult.bin", prod[0].data);
         writeU64(dir + "/csub.bin", crypto::CSub(cps.get(), A[0], A[1])[0].data);
+        // --- crypto.CMultConstRescale (basics.go:533; pca.go / qrfact.go scale by 1/n style constants)
+        auto cm = crypto::CMultConstRescale(cps.get(), A[0], 1.0 / 8192.0, qi);
+        if (cm[0].level != level - 1) throw std::runtime_error("CMultConstRescale must consume one level for a fractional constant");
+        writeU64(dir + "/cmultconst.bin", cm[0].data);
         // --- crypto.MaskTrunc (basics.go:110) as QXLazyNormStream applies it to the tail ciphertext (matmult.go:62-70)
         auto mt = crypto::MaskTrunc(cps.get(), A[0][0], 1000, qi);
         if (mt.level != level - 1) throw std::runtime_error("MaskTrunc must consume one level");

@@ -84,6 +84,11 @@ def lib():
         L.orc_bed_decode.restype = C.c_int
         L.orc_bed_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_filter_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scale_up_exact.restype = C.c_uint64
+        L.orc_scale_up_exact.argtypes = [C.c_double, C.c_double, C.c_uint64]
+        L.orc_mul_const.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, u64p, C.POINTER(C.c_double)]
+        L.orc_add_const.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, C.c_double, u64p]
+        L.orc_add_plain.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
         L.orc_ct_addsub.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_int, u64p]
         L.orc_mulrelin.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p]
         L.orc_mul_plain.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]

@@ -68,6 +68,31 @@ def test_mul_plain_and_sub_bit_exact(env):
         assert np.array_equal(got[j], want)
 
 
+def test_const_and_plain_linear_ops_bit_exact(env):
+    """MultByConst / AddConst / AddNew(ct, pt): device kernels fed with lattigo's scaleUpExact residues vs the oracle"""
+    import ctypes as C
+    ctx, ring, s, rlk = env
+    level, n, scale = 5, 2, 2.0 ** 34
+    a = np.stack([ring.fill_uniform(level, 300 + j) for j in range(n)])
+    for const in [0.125, -3.0, -1.0 / 8192]:
+        sm = C.c_double(); want = np.zeros_like(a[0])
+        L().orc_mul_const(ring.h, level, ol.p64(a[0]), const, ol.p64(want), C.byref(sm))
+        sc = [L().orc_scale_up_exact(const, sm.value, q) % q for q in ring.moduli[:level + 1]]
+        got = ctx.evalop("sfg_ct_mul_scalar_dev", level, a, extra=(sc,))
+        assert np.array_equal(got[0], want), const
+        L().orc_add_const(ring.h, level, ol.p64(a[1]), const, scale, ol.p64(want))
+        sc = [L().orc_scale_up_exact(const, scale, q) % q for q in ring.moduli[:level + 1]]
+        got = ctx.evalop("sfg_ct_add_scalar_dev", level, a, extra=(sc,))
+        assert np.array_equal(got[1], want), const
+    rnd = np.random.default_rng(6)
+    pts = np.stack([ring.encode_ntt(rnd.normal(size=ring.slots), scale, level + 1) for _ in range(n)])
+    got = ctx.evalop("sfg_ct_add_plain_dev", level, a, pts, extra=((level + 1) * ring.N,))
+    for j in range(n):
+        want = np.zeros_like(a[j])
+        L().orc_add_plain(ring.h, level, ol.p64(a[j]), ol.p64(pts[j]), ol.p64(want))
+        assert np.array_equal(got[j], want)
+
+
 def test_encode_float_vectors_bit_exact(env):
     """crypto.EncodeFloatVector on the device (behind Mask / MaskTrunc / CPMult operands): arbitrary real vectors, MaxLevel"""
     ctx, ring, s, rlk = env

@@ -115,3 +115,10 @@ def test_host_mirror_matmul_end_to_end(tmp_path):
     ol.lib().orc_mul_plain(ring.h, level, ol.p64(a0), ol.p64(mpt), ol.p64(mp))
     ol.lib().orc_rescale(ring.h, level, ol.p64(mp), ol.p64(rs))
     assert np.array_equal(np.fromfile(tmp_path / "masktrunc.bin", dtype=np.uint64).reshape(rs.shape), rs)
+    # CMultConstRescale(X, 1/8192): scaled by q_level, multiplied, rescaled once (scale 2^34 * q5 >= 2^34 * q5 / 2)
+    import ctypes as C
+    mc = np.zeros_like(a0); sm = C.c_double()
+    ol.lib().orc_mul_const(ring.h, level, ol.p64(a0), 1.0 / 8192.0, ol.p64(mc), C.byref(sm))
+    assert sm.value == float(ring.moduli[level])
+    ol.lib().orc_rescale(ring.h, level, ol.p64(mc), ol.p64(rs))
+    assert np.array_equal(np.fromfile(tmp_path / "cmultconst.bin", dtype=np.uint64).reshape(rs.shape), rs)

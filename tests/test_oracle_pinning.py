@@ -394,3 +394,36 @@ def test_mulrelin_rescale_mulplain_innersum_decrypt_correctly():
     assert L().orc_innersum_all(ring.h, keys.h, level, ol.p64(both), 2, ol.p64(tot)) == 0
     got = _decrypt_decode(ring, s, level, tot, scale)
     assert np.max(np.abs(got.real - (u.sum() + v.sum()))) < 1e-3
+
+
+def test_mul_const_add_const_add_plain_decrypt_correctly():
+    """MultByConst / AddConst / AddNew(ct, pt) restated (basics.go:183-199, 480-497, 604-611): decrypted semantics and the
+    scaleUpExact rule against Python integers"""
+    ring = small_ring(6)
+    s = ring.gen_secret(3)
+    rnd = np.random.default_rng(17)
+    level, scale = 4, 2.0 ** 34
+    u = rnd.normal(size=ring.slots)
+    cu = _encode_encrypt(ring, s, level, u, scale, 5)
+    for const in [3.0, -2.0, 0.125, -1.0 / 8192, 0.0]:
+        out = np.zeros_like(cu); sm = C.c_double()
+        L().orc_mul_const(ring.h, level, ol.p64(cu), const, ol.p64(out), C.byref(sm))
+        frac = const != int(const)
+        assert sm.value == (float(ring.moduli[level]) if frac else 1.0)
+        got = _decrypt_decode(ring, s, level, out, scale * sm.value, nmod=3)
+        assert np.max(np.abs(got.real - const * u)) < 1e-3
+        out = np.zeros_like(cu)
+        L().orc_add_const(ring.h, level, ol.p64(cu), const, scale, ol.p64(out))
+        got = _decrypt_decode(ring, s, level, out, scale)
+        assert np.max(np.abs(got.real - (u + const))) < 1e-4
+    for q in ring.moduli[:3]:
+        for v, n in [(0.3, 2.0 ** 34), (-0.3, 2.0 ** 34), (7.0, 1.0), (-7.0, 1.0), (1 / 8192, float(q)), (-1e-30, 1.0)]:
+            want = int(abs(n * v) + 0.5) % q
+            want = (q - want) % q if v < 0 else want
+            assert L().orc_scale_up_exact(v, n, q) % q == want
+    v = rnd.normal(size=ring.slots)
+    pt = ring.encode_ntt(v, scale, level + 1)
+    out = np.zeros_like(cu)
+    L().orc_add_plain(ring.h, level, ol.p64(cu), ol.p64(pt), ol.p64(out))
+    got = _decrypt_decode(ring, s, level, out, scale)
+    assert np.max(np.abs(got.real - (u + v))) < 1e-4
