@@ -45,6 +45,11 @@ struct sfg_ctx {
     double scale = 0;
     u64 q[SFG_MAXMOD] = {0}, psi[SFG_MAXMOD] = {0};
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC
+    // pinned host ring for small stream-ordered uploads (pointer tables): no blocking copies on the launch path
+    unsigned char *pin = nullptr; size_t pin_bytes = 0, pin_head = 0;
+    hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // [0,1]: rotation cache of group parity ready; [2,3]: finalize of column pass parity done
+    std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;     // ordering events (no timing), reused round-robin
     // device tables
     double *tw_fwd = nullptr;    // [nmod][N] w, index m+i as in the CT loop (psi^bitrev)
     double *tw_inv = nullptr;    // [nmod][N] w for psi^-bitrev
@@ -82,6 +87,16 @@ static inline u64 h_powmod(u64 a, u64 e, u64 q) { u64 r = 1 % q; a %= q; while (
 static inline u64 h_invmod(u64 a, u64 q) { return h_powmod(a, q - 2, q); }
 static inline uint32_t h_brev(uint32_t x, int bits) { uint32_t r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 
+// stream-ordered upload of a small host table: staged in the pinned ring, copied with hipMemcpyAsync on ctx->stream
+int sfg_upload_small(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+// run the enclosed launches on the auxiliary stream (everything launches on ctx->stream)
+struct AuxScope {
+    sfg_ctx *c; hipStream_t saved;
+    explicit AuxScope(sfg_ctx *c_, bool on = true) : c(c_), saved(c_->stream) { if (on) c->stream = c->aux_stream; }
+    ~AuxScope() { c->stream = saved; }
+};
+// order `waiter` after everything enqueued so far on `signaller` (no host wait)
+int sfg_stream_after(sfg_ctx *ctx, hipStream_t waiter, hipStream_t signaller);
 // named grow-only scratch buffers owned by the context (avoids hipMalloc/hipFree of multi-GB buffers per call)
 int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out);
 // reads back all pending phase events (one stream sync); called by the phase query functions and at API exits

@@ -33,6 +33,13 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     ctx->stream = ctx->own_stream;
+    {   // the auxiliary queue yields to the main one: its element-wise key-switch kernels fill gaps, they must not displace MAC workgroups
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) return fail("hipStreamCreate failed");
+    }
+    for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    ctx->pin_bytes = 64u << 20;
+    if (hipHostMalloc((void **)&ctx->pin, ctx->pin_bytes, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
     const int N = SFG_N;
     std::vector<double> twf((size_t)ctx->nmod * N), twi((size_t)ctx->nmod * N);
     for (int m = 0; m < ctx->nmod; m++) {
@@ -88,6 +95,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     for (auto &kv : ctx->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
     sfg_phases_resolve(ctx);
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
@@ -95,6 +103,10 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     sfg_encoder_destroy(ctx);
     (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->pack_fwd); (void)hipFree(ctx->pack_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws); (void)hipFree(ctx->zeros_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; i++) if (ctx->ev_pipe[i]) (void)hipEventDestroy(ctx->ev_pipe[i]);
     delete ctx;
 }
 
@@ -106,6 +118,34 @@ extern "C" int sfg_ctx_synchronize(sfg_ctx *ctx) {
     return 0;
 }
 extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) { ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return 0; }
+
+int sfg_upload_small(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!bytes) return 0;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ctx->pin_bytes / 4) {                       // not "small": plain blocking copy, ordered after the stream
+        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SFG_HIP(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
+    if (ctx->pin_head + need > ctx->pin_bytes) {           // wrap: earlier staged copies must have executed before their slots are reused
+        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->aux_stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+        if (ctx->own_stream && ctx->own_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+        ctx->pin_head = 0;
+    }
+    unsigned char *slot = ctx->pin + ctx->pin_head; ctx->pin_head += need;
+    memcpy(slot, src_host, bytes);
+    SFG_HIP(ctx, hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+int sfg_stream_after(sfg_ctx *ctx, hipStream_t waiter, hipStream_t signaller) {
+    if (waiter == signaller) return 0;
+    if (ctx->ev_pool.size() < 64) { hipEvent_t e; SFG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_pool.push_back(e); ctx->ev_next = ctx->ev_pool.size() - 1; }
+    hipEvent_t e = ctx->ev_pool[ctx->ev_next]; ctx->ev_next = (ctx->ev_next + 1) % ctx->ev_pool.size();
+    SFG_HIP(ctx, hipEventRecord(e, signaller));            // a wait captures the record made here; re-recording later does not disturb it
+    SFG_HIP(ctx, hipStreamWaitEvent(waiter, e, 0));
+    return 0;
+}
 
 int sfg_ws_reserve(sfg_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return 0;

@@ -171,6 +171,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     if (dma) { const char *e = getenv("SFG_MM_GROUP"); G = e ? atoi(e) : 8; if (G < 1) G = 1; if (G > b1 - b0) G = b1 - b0; }
     const size_t nplain = (size_t)d * d;                     // 8281 >= 8192 slots per block row: the tail stays zero
     u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr; size_t rowf = 0;
+    const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
+    const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !getenv("SFG_MM_NO_OVERLAP");
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
     SFG_TRY(sfg_scratch(ctx, "mm.pt", (size_t)G * nplain * L * prow * 8, (void **)&pt));
@@ -179,22 +181,45 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
-        if (!rotf_pre) SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)G * d + 3) * s * 2 * rowf * 8, (void **)&rotf));      // + 3 k-slices: see launch_mac_dma
+        if (!rotf_pre) SFG_TRY(sfg_scratch(ctx, "mm.rotf", grp_slices * s * 2 * rowf * 8 * (pipelined ? 2 : 1), (void **)&rotf));
     }
     const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
     bool first_group = true;
-    for (int bg = b0; bg < b1 && !rc; bg += G) {
+    // rotation cache of one group into half `buf` of mm.rotf (on whatever stream is current)
+    auto build_group = [&](int bg, int buf) -> int {
+        const int ng = std::min(G, b1 - bg);
+        double *dst = rotf + (size_t)buf * grp_slices * s * 2 * rowf;
+        for (int g = 0; g < ng; g++) SFG_TRY(build_rot_row(ctx, A, s, nl_in, nl, lev, L, sh, bg + g, a_row, rotc, dma, dma ? dst + (size_t)g * d * s * 2 * rowf : nullptr));
+        if (dma && (ng * d) % 4)          // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
+            SFG_HIP(ctx, hipMemsetAsync(dst + (size_t)ng * d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream));
+        return 0;
+    };
+    // With several groups the key switching of group k+1 runs on the auxiliary stream beside the encode + MAC of group k
+    // (those kernels leave registers and wave slots free; the MAC does not, so nothing overlaps it).
+    hipStream_t main_stream = ctx->stream;
+    if (pipelined) {
+        SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));            // inputs and scratch as the main stream left them
+        { AuxScope aux(ctx); SFG_TRY(build_group(b0, 0)); }
+        SFG_HIP(ctx, hipEventRecord(ctx->ev_pipe[0], ctx->aux_stream));
+    }
+    int gi = 0;
+    for (int bg = b0; bg < b1 && !rc; bg += G, gi++) {
         const int ng = std::min(G, b1 - bg);
         // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
         const double *rotf_grp = rotf;
         if (rotf_pre) rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf;
-        else {
-            for (int g = 0; g < ng && !rc; g++) rc = build_rot_row(ctx, A, s, nl_in, nl, lev, L, sh, bg + g, a_row, rotc, dma, dma ? rotf + (size_t)g * d * s * 2 * rowf : nullptr);
-            if (rc) break;
-            if (dma && (ng * d) % 4) {    // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
-                if (hipMemsetAsync(rotf + (size_t)ng * d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream) != hipSuccess) { ctx->err = "matmul: memset failed"; rc = 1; break; }
+        else if (pipelined) {
+            if (bg + G < b1) {                                                   // next group: its half was last read by group gi-1
+                SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));
+                { AuxScope aux(ctx); SFG_TRY(build_group(bg + G, (gi + 1) & 1)); }
+                SFG_HIP(ctx, hipEventRecord(ctx->ev_pipe[(gi + 1) & 1], ctx->aux_stream));
             }
+            SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pipe[gi & 1], 0));
+            rotf_grp = rotf + (size_t)(gi & 1) * grp_slices * s * 2 * rowf;
+        } else {
+            rc = build_group(bg, 0);
+            if (rc) break;
         }
         for (int bj = j0; bj < j1 && !rc; bj++) {
             const int nc = sh.cols_of(bj);
@@ -269,7 +294,7 @@ static int matmul_finalize(sfg_ctx *ctx, const u64 *acc, int s, int max_level, i
         }
         if (rc) break;
         int *gd = giants_d + (size_t)jb * d;     // one list per block column: no host sync needed between columns
-        if (hipMemcpy(gd, glist.data(), glist.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = 1; ctx->err = "finalize: copy failed"; break; }
+        if (sfg_upload_small(ctx, gd, glist.data(), glist.size() * sizeof(int))) { rc = 1; break; }
         u64 *o = out + (size_t)(jout0 + jb) * ctw;
         hipLaunchKernelGGL(k_sum_giants, dim3((unsigned)((size_t)s * 2 * L * (N / 256))), dim3(256), 0, ctx->stream, rot, gd, (int)glist.size(), s, L,
                            o, (size_t)m_ct_out * ctw, accumulate, ctx->modc);
@@ -330,7 +355,7 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
         if (nl >= L && ((size_t)(b1 - b0) * per_row + 3 * (size_t)s * 2 * rowf) * 8 <= (48ULL << 30)) {
             double *buf = nullptr; u64 *a_row = nullptr, *rotc = nullptr;
             const size_t ctw = (size_t)2 * nl * N;
-            SFG_TRY(sfg_scratch(ctx, "mm.rotf_all", ((size_t)(b1 - b0) * per_row + 3 * (size_t)s * 2 * rowf) * 8, (void **)&buf));
+            SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)(b1 - b0) * per_row + 3 * (size_t)s * 2 * rowf) * 8, (void **)&buf));
             SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
             SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
             for (int bi = b0; bi < b1; bi++) SFG_TRY(build_rot_row(ctx, (const u64 *)A, s, in_level + 1, nl, lev, L, sh, bi, a_row, rotc, true, buf + (size_t)(bi - b0) * per_row));
@@ -338,14 +363,33 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
             rotf_all = buf;
         }
     }
-    for (int ja = j0; ja < j1; ja += jg) {
+    // With the product-wide cache the accumulate passes do no key switching, so the giant-step alignment of pass k runs on the
+    // auxiliary stream beside the encode + MAC of pass k+1 (two accumulator buffers of half the budget each).
+    const bool overlap = rotf_all && !getenv("SFG_MM_NO_OVERLAP");
+    if (overlap) { jg = (jg + 1) / 2; }
+    hipStream_t main_stream = ctx->stream;
+    int k = 0;
+    for (int ja = j0; ja < j1; ja += jg, k++) {
         const int jb = std::min(j1, ja + jg);
         u64 *acc = nullptr;
-        SFG_TRY(sfg_scratch(ctx, "mm.acc", (size_t)(jb - ja) * d * accw * 8, (void **)&acc));
+        SFG_TRY(sfg_scratch(ctx, "mm.acc", (size_t)jg * d * accw * 8 * (overlap ? 2 : 1), (void **)&acc));
+        if (overlap) {
+            acc += (size_t)(k & 1) * jg * d * accw;
+            if (k >= 2) SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pipe[2 + (k & 1)], 0));    // pass k-2 has been aligned out of this buffer
+        }
         int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc, rotf_all);
-        if (!rc) rc = matmul_finalize(ctx, acc, s, max_level, jb - ja, m_out, ja - j0, 0, d, &giant_t, 0, (u64 *)out);
         if (rc) return rc;
+        if (overlap) {
+            SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));
+            { AuxScope aux(ctx); rc = matmul_finalize(ctx, acc, s, max_level, jb - ja, m_out, ja - j0, 0, d, &giant_t, 0, (u64 *)out); }
+            if (rc) return rc;
+            SFG_HIP(ctx, hipEventRecord(ctx->ev_pipe[2 + (k & 1)], ctx->aux_stream));
+        } else {
+            rc = matmul_finalize(ctx, acc, s, max_level, jb - ja, m_out, ja - j0, 0, d, &giant_t, 0, (u64 *)out);
+            if (rc) return rc;
+        }
     }
+    if (overlap) SFG_TRY(sfg_stream_after(ctx, main_stream, ctx->aux_stream));      // outputs are complete in main-stream order
     return 0;
 }
 extern "C" int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, uint64_t *out) {

@@ -242,17 +242,15 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
         hipLaunchKernelGGL(k_ksw_extend, dim3(N / 256, kc.beta, ni), dim3(256), 0, ctx->stream, c2, bin, ext, kcd, ctx->modc);
         SFG_HIP(ctx, hipGetLastError());
         SFG_TRY(launch_ntt_fwd(ctx, ext, ext, (size_t)ni * kc.beta * kc.nt, pext));
-        // pointer tables of the whole group, uploaded once with blocking copies (the host vectors die with this scope;
-        // earlier kernels that read the tables are ordered before the copy by the stream sync)
+        // pointer tables of the whole group: staged in the pinned ring, stream-ordered (no host wait on the launch path)
         {
             const size_t nj = jobs.size();
             std::vector<const u64 *> kp(nj); std::vector<const uint16_t *> ip(nj); std::vector<u64 *> op(nj); std::vector<int> ii(nj);
             for (size_t k = 0; k < nj; k++) { int jb = jobs[k]; kp[k] = keyp[jb]; ip[k] = idxp[jb]; op[k] = outp[jb]; ii[k] = job_in[jb] - i0; }
-            SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            SFG_HIP(ctx, hipMemcpy(keys_all, kp.data(), nj * sizeof(void *), hipMemcpyHostToDevice));
-            SFG_HIP(ctx, hipMemcpy(idx_all, ip.data(), nj * sizeof(void *), hipMemcpyHostToDevice));
-            SFG_HIP(ctx, hipMemcpy(out_all, op.data(), nj * sizeof(void *), hipMemcpyHostToDevice));
-            SFG_HIP(ctx, hipMemcpy(inidx_all, ii.data(), nj * sizeof(int), hipMemcpyHostToDevice));
+            SFG_TRY(sfg_upload_small(ctx, keys_all, kp.data(), nj * sizeof(void *)));
+            SFG_TRY(sfg_upload_small(ctx, idx_all, ip.data(), nj * sizeof(void *)));
+            SFG_TRY(sfg_upload_small(ctx, out_all, op.data(), nj * sizeof(void *)));
+            SFG_TRY(sfg_upload_small(ctx, inidx_all, ii.data(), nj * sizeof(int)));
         }
         for (size_t c0 = 0; c0 < jobs.size(); c0 += chunk) {
             const int nb = (int)(jobs.size() - c0 < (size_t)chunk ? jobs.size() - c0 : (size_t)chunk);
