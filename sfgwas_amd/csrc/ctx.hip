@@ -122,7 +122,8 @@ extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) { ctx->stream = s ? (hi
 int sfg_upload_small(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!bytes) return 0;
     const size_t need = (bytes + 255) & ~(size_t)255;
-    if (need > ctx->pin_bytes / 4) {                       // not "small": plain blocking copy, ordered after the stream
+    static const bool blocking = getenv("SFG_UPLOAD_BLOCKING") != nullptr;       // diagnostic switch
+    if (blocking || need > ctx->pin_bytes / 4) {           // not "small": plain blocking copy, ordered after the stream
         SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         SFG_HIP(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
         return 0;

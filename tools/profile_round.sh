@@ -4,9 +4,9 @@ mkdir -p $R/gpurun_out/r01f
 cd $R
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01f/stats -o stats -- python3 bench.py > gpurun_out/r01f/bench_stats.log 2>&1
 grep '^{"metric"' gpurun_out/r01f/bench_stats.log > gpurun_out/r01f/benchline.json
-timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r01f/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 > gpurun_out/r01f/pmc_fetch.log 2>&1
-timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r01f/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 > gpurun_out/r01f/pmc_write.log 2>&1
-python3 tools/pmc_traffic.py gpurun_out/r01f/pmc_fetch gpurun_out/r01f/pmc_write gpurun_out/r01f/traffic.json > gpurun_out/r01f/traffic.txt 2>&1
+
+
+
 # keep only the small summaries
 find gpurun_out/r01f -name "*kernel_trace.csv" -delete; find gpurun_out/r01f -name "*counter_collection.csv" -delete; find gpurun_out/r01f -name "*.db" -delete
 find gpurun_out/r01f -type f | head -40
