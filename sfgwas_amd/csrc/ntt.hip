@@ -306,6 +306,101 @@ __global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *
         out[j] = f64_to_u64(canon(lds[a * LDS_ROW + c * 33 + b], q, qinv));
     }
 }
+// Same transform with every exchange split in two rounds through a HALF image (33 KiB instead of 66 KiB): three
+// workgroups (12 waves) fit a CU instead of two.  Round structure:
+//   A->B  by column half h (pp = tid + 256 h  <=>  b < 16 or b >= 16): everyone writes its column h, (a, c) readers take 16 b's
+//   B->C  by row half (a < 8 or a >= 8): the 128 producers of the half write 32 b's each, everyone reads the group p = tid + 256 r
+//   C->out by row half: everyone writes its group r, then 4096 words are stored coalesced
+constexpr int H3_ROWA = 264;                  // 256 + 8 doubles per `a` row of the A->B half image
+constexpr int H3_DOUBLES = 16 * H3_ROWA;
+constexpr int H3_LDS_BYTES = (H3_DOUBLES > 8 * LDS_ROW ? H3_DOUBLES : 8 * LDS_ROW) * 8;      // 33,792 B (the B->C / C->out half image needs 8 * LDS_ROW = 4224 doubles as well)
+__global__ void __launch_bounds__(256) k_ntt_half3(const long long *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, n = N / 2, tid = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const int m = (int)(row % L);
+    const double *tw = tw_all + (size_t)m * N;
+    const double2 *pack = pack_all + (size_t)m * (N / 2);
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const long long *pc = pc_all + (row / L) * (size_t)n;
+    const double W = tw[1], Wq = W * qinv;
+    double v[32];
+    const int a_b = tid >> 4, c_b = tid & 15;                  // phase B identity
+    // ---- phase A (two columns) interleaved with the two A->B rounds
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int pp = tid + 256 * h;
+        double w[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            const int j = a * 512 + pp;
+            const double lo = (double)pc[j];
+            const double hi = j == 0 ? 0.0 : (double)pc[n - j];          // p_{n+j} = -p_{n-j}
+            w[a] = lo - mulmod_lazy(hi, W, Wq, q);
+        }
+        ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + g]; });
+        ct_stage<16, 4>(w, q, qinv, [&](int g) { return tw[4 + g]; });
+        ct_stage<16, 2>(w, q, qinv, [&](int g) { return tw[8 + g]; });
+        ct_stage<16, 1>(w, q, qinv, [&](int g) { return tw[16 + g]; });
+        if (h) __syncthreads();                                           // round-0 readers are done with the image
+#pragma unroll
+        for (int a = 0; a < 16; a++) lds[a * H3_ROWA + tid] = w[a];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; b++) v[h * 16 + b] = lds[a_b * H3_ROWA + b * 16 + c_b];
+    }
+    // ---- phase B: thread (a, c), 32 values of b; stages t = 256 .. 16
+    ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + a_b + g]; });
+    ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + a_b * 2 + g]; });
+    ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + a_b * 4 + g]; });
+    ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + a_b * 8 + g]; });
+    ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + a_b * 16 + g]; });
+    // ---- B->C rounds by row half, phase C per group
+    double wc[2][16];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        __syncthreads();                                                  // previous readers are done
+        if ((a_b >> 3) == r) {
+#pragma unroll
+            for (int b = 0; b < 32; b++) lds[(a_b & 7) * LDS_ROW + c_b * 33 + b] = v[b];
+        }
+        __syncthreads();
+        const int p = tid + 256 * r, a = p >> 5, b = p & 31;
+#pragma unroll
+        for (int c = 0; c < 16; c++) wc[r][c] = lds[(a & 7) * LDS_ROW + c * 33 + b];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int p = tid + 256 * r;
+        double tl[16];
+        {
+            const double2 *pk = pack + (size_t)(p >> 6) * 512 + (p & 63);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
+        }
+        ct_stage<16, 8>(wc[r], q, qinv, [&](int g) { return tl[0 + g]; });
+        ct_stage<16, 4>(wc[r], q, qinv, [&](int g) { return tl[1 + g]; });
+        ct_stage<16, 2>(wc[r], q, qinv, [&](int g) { return tl[3 + g]; });
+        ct_stage<16, 1>(wc[r], q, qinv, [&](int g) { return tl[7 + g]; });
+    }
+    // ---- C->out rounds by row half
+    const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
+    const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
+    u64 *out = out_ + (dst * L + m) * (size_t)n;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int p = tid + 256 * r, a = p >> 5, b = p & 31;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; c++) lds[(a & 7) * LDS_ROW + c * 33 + b] = wc[r][c];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
+            out[r * 4096 + jj] = f64_to_u64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
+        }
+    }
+}
 // full rows from half rows: out[i] = out[N-1-i] = half[i]
 __global__ void __launch_bounds__(256) k_expand_half(const u64 *half, u64 *full) {
     const int N = SFG_N, n = N / 2; const size_t row = blockIdx.x / (n / 256);
@@ -321,6 +416,7 @@ static int set_lds_attr_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     done = (e == hipSuccess);
     return e == hipSuccess ? 0 : 1;
 }
@@ -347,7 +443,9 @@ int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain,
 int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L, PanelMap pm) {
     if (!nplain) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    static const bool full_image = getenv("SFG_NTT_HALF_IMPL") && !strcmp(getenv("SFG_NTT_HALF_IMPL"), "full");      // A/B switch
+    if (full_image) hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    else hipLaunchKernelGGL(k_ntt_half3, dim3((unsigned)(nplain * L)), dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
