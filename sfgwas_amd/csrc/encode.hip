@@ -170,22 +170,72 @@ __global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int 
 // ---------------------------------------------------------------- FFT encode
 __device__ __forceinline__ int padj(int j) { return j + (j >> 3); }
 
-template <int H>   // one radix-2 DIF stage on 8 register-resident points at local distance H (1, 2 or 4)
-__device__ __forceinline__ void dif_stage(dd (&xr)[8], dd (&xi)[8], const double4 *zt, int jbase, int jstride, int half) {
+// (ar + i ai) * (wr + i wi) with each component as ONE double-double dot product (two products share the final
+// renormalisation): 19 flops per component instead of 2 dd_mul + 1 dd_add = 25.
+__device__ __forceinline__ dd dd_dot2(dd a, dd w, dd b, dd x, double sgn) {          // a*w + sgn*b*x, sgn = +-1
+    const double p1 = a.hi * w.hi, e1 = fma(a.hi, w.hi, -p1);
+    const double bh = sgn * b.hi, bl = sgn * b.lo;
+    const double p2 = bh * x.hi, e2 = fma(bh, x.hi, -p2);
+    dd s = dd_two_sum(p1, p2);
+    double lo = e1 + e2;
+    lo = fma(a.hi, w.lo, lo); lo = fma(a.lo, w.hi, lo);
+    lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
+    return dd_quick(s.hi, s.lo + lo);
+}
+__device__ __forceinline__ void cdd_mul_ip(dd &re, dd &im, dd wr, dd wi) {
+    const dd r = dd_dot2(re, wr, im, wi, -1.0), i = dd_dot2(re, wi, im, wr, 1.0);
+    re = r; im = i;
+}
+// zeta^-idx for idx in [0, 32768): the table covers [0, 16384], the rest is the negated first half
+__device__ __forceinline__ void tw_at(const double4 *zt, int idx, dd &wr, dd &wi) {
+    const bool neg = idx > ENC_TW;
+    const double4 w = zt[neg ? idx - ENC_TW : idx];
+    const double sg = neg ? -1.0 : 1.0;
+    wr = dd_make(sg * w.x, sg * w.y); wi = dd_make(sg * w.z, sg * w.w);
+}
+// One radix-8 DIF pass on 8 register-resident points at stride S of a sub-transform of length 8S: identical to three
+// radix-2 DIF stages (pairs (i,i+4), (i,i+2), (i,i+1)) with the twiddles regrouped - the 12 twiddle products of the
+// radix-2 form become 7 output products W^(e t), e = bitrev(r), plus two rotations by 1/8 turn; t = j mod S.
+template <int S>
+__device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const double4 *zt, int t) {
+    const dd rs = dd_make(7.071067811865475727e-01, -4.833646656726456726e-17);      // 1/sqrt(2) in double-double
+    dd ur[4], ui[4], dr[4], di[4];
 #pragma unroll
-    for (int g = 0; g < 8 / (2 * H); g++) {
+    for (int i = 0; i < 4; i++) {
+        ur[i] = dd_add(xr[i], xr[i + 4]); ui[i] = dd_add(xi[i], xi[i + 4]);
+        dr[i] = dd_sub(xr[i], xr[i + 4]); di[i] = dd_sub(xi[i], xi[i + 4]);
+    }
+    {   // d1 *= W8 = (1 - i)/sqrt2: (a + bi) -> ((a + b) + (b - a) i)/sqrt2
+        dd a = dr[1], b = di[1];
+        dr[1] = dd_mul(dd_add(a, b), rs); di[1] = dd_mul(dd_sub(b, a), rs);
+    }
+    {   // d2 *= -i: (a + bi) -> (b - ai)
+        dd a = dr[2]; dr[2] = di[2]; di[2] = dd_neg(a);
+    }
+    {   // d3 *= W8^3 = (-1 - i)/sqrt2: (a + bi) -> ((b - a) - (a + b) i)/sqrt2
+        dd a = dr[3], b = di[3];
+        dr[3] = dd_mul(dd_sub(b, a), rs); di[3] = dd_neg(dd_mul(dd_add(a, b), rs));
+    }
+    auto quad = [&](dd (&hr)[4], dd (&hi)[4], int o) {
+        dd p0r = dd_add(hr[0], hr[2]), p0i = dd_add(hi[0], hi[2]);
+        dd p1r = dd_add(hr[1], hr[3]), p1i = dd_add(hi[1], hi[3]);
+        dd q0r = dd_sub(hr[0], hr[2]), q0i = dd_sub(hi[0], hi[2]);
+        dd t1r = dd_sub(hr[1], hr[3]), t1i = dd_sub(hi[1], hi[3]);
+        dd q1r = t1i, q1i = dd_neg(t1r);                                               // * -i
+        xr[o + 0] = dd_add(p0r, p1r); xi[o + 0] = dd_add(p0i, p1i);
+        xr[o + 1] = dd_sub(p0r, p1r); xi[o + 1] = dd_sub(p0i, p1i);
+        xr[o + 2] = dd_add(q0r, q1r); xi[o + 2] = dd_add(q0i, q1i);
+        xr[o + 3] = dd_sub(q0r, q1r); xi[o + 3] = dd_sub(q0i, q1i);
+    };
+    quad(ur, ui, 0);
+    quad(dr, di, 4);
+    if (S > 1) {                                                                       // S == 1: t = 0, every output twiddle is 1
+        constexpr int STEP = 4096 / S;                                                 // W_{8S} = zeta^-(32768 / 8S)
+        constexpr int E[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 #pragma unroll
-        for (int x = 0; x < H; x++) {
-            const int i0 = g * 2 * H + x, i1 = i0 + H;
-            const int j = jbase + i0 * jstride;           // global index of the upper element
-            const int k = j & (half - 1);
-            const double4 w = zt[(size_t)k * (ENC_TW / half)];  // exp(-2 pi i k / (2 half)) = zeta^-(k * 16384/half)
-            dd ar = xr[i0], ai = xi[i0], br = xr[i1], bi = xi[i1];
-            xr[i0] = dd_add(ar, br); xi[i0] = dd_add(ai, bi);
-            dd dr = dd_sub(ar, br), di = dd_sub(ai, bi);
-            dd wr = dd_make(w.x, w.y), wi = dd_make(w.z, w.w);
-            xr[i1] = dd_sub(dd_mul(dr, wr), dd_mul(di, wi));
-            xi[i1] = dd_add(dd_mul(dr, wi), dd_mul(di, wr));
+        for (int r = 1; r < 8; r++) {
+            dd wr, wi; tw_at(zt, E[r] * t * STEP, wr, wi);
+            cdd_mul_ip(xr[r], xi[r], wr, wi);
         }
     }
 }
@@ -224,9 +274,7 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
         if (F64IN) { xr[a] = dd_make(rowd[t0], 0.0); xi[a] = dd_make(rowd[t1], 0.0); }
         else { xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0); }
     }
-    dif_stage<4>(xr, xi, zt, tid, 512, 2048);
-    dif_stage<2>(xr, xi, zt, tid, 512, 1024);
-    dif_stage<1>(xr, xi, zt, tid, 512, 512);
+    dif_radix8<512>(xr, xi, zt, tid);
     __syncthreads();                                               // row staging area is dead, image can be written
 #pragma unroll
     for (int a = 0; a < 8; a++) { const int p = padj(a * 512 + tid); RH[p] = xr[a].hi; RL[p] = xr[a].lo; IH[p] = xi[a].hi; IL[p] = xi[a].lo; }
@@ -236,9 +284,7 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
         const int a = tid >> 6, cd = tid & 63, jb = a * 512 + cd;
 #pragma unroll
         for (int b = 0; b < 8; b++) { const int p = padj(jb + b * 64); xr[b] = dd_make(RH[p], RL[p]); xi[b] = dd_make(IH[p], IL[p]); }
-        dif_stage<4>(xr, xi, zt, jb, 64, 256);
-        dif_stage<2>(xr, xi, zt, jb, 64, 128);
-        dif_stage<1>(xr, xi, zt, jb, 64, 64);
+        dif_radix8<64>(xr, xi, zt, cd);
 #pragma unroll
         for (int b = 0; b < 8; b++) { const int p = padj(jb + b * 64); RH[p] = xr[b].hi; RL[p] = xr[b].lo; IH[p] = xi[b].hi; IL[p] = xi[b].lo; }
     }
@@ -248,9 +294,7 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
         const int ab = tid >> 3, d = tid & 7, jb = ab * 64 + d;
 #pragma unroll
         for (int c = 0; c < 8; c++) { const int p = padj(jb + c * 8); xr[c] = dd_make(RH[p], RL[p]); xi[c] = dd_make(IH[p], IL[p]); }
-        dif_stage<4>(xr, xi, zt, jb, 8, 32);
-        dif_stage<2>(xr, xi, zt, jb, 8, 16);
-        dif_stage<1>(xr, xi, zt, jb, 8, 8);
+        dif_radix8<8>(xr, xi, zt, d);
 #pragma unroll
         for (int c = 0; c < 8; c++) { const int p = padj(jb + c * 8); RH[p] = xr[c].hi; RL[p] = xr[c].lo; IH[p] = xi[c].hi; IL[p] = xi[c].lo; }
     }
@@ -260,9 +304,7 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
         const int jb = tid * 8;
 #pragma unroll
         for (int d = 0; d < 8; d++) { const int p = padj(jb + d); xr[d] = dd_make(RH[p], RL[p]); xi[d] = dd_make(IH[p], IL[p]); }
-        dif_stage<4>(xr, xi, zt, jb, 1, 4);
-        dif_stage<2>(xr, xi, zt, jb, 1, 2);
-        dif_stage<1>(xr, xi, zt, jb, 1, 1);
+        dif_radix8<1>(xr, xi, zt, 0);
 #pragma unroll
         for (int d = 0; d < 8; d++) { const int p = padj(jb + d); RH[p] = xr[d].hi; RL[p] = xr[d].lo; IH[p] = xi[d].hi; IL[p] = xi[d].lo; }
     }
@@ -281,14 +323,14 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
         dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/(2i) = -i (A-B)/2
         const double4 wo = zt[4 * c];                               // omega^-c = zeta^-4c
         dd wor = dd_make(wo.x, wo.y), woi = dd_make(wo.z, wo.w);
-        dd Yr = dd_sub(dd_mul(Or, wor), dd_mul(Oi, woi)), Yi = dd_add(dd_mul(Or, woi), dd_mul(Oi, wor));
+        dd Yr = dd_dot2(Or, wor, Oi, woi, -1.0), Yi = dd_dot2(Or, woi, Oi, wor, 1.0);
         // W_c
         {
             dd Wr = dd_add(Xr, Yr), Wi = dd_add(Xi, Yi);
             const double4 z = zt[c];
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
-            dd wr = dd_mul_d(dd_sub(dd_mul(Wr, zr), dd_mul(Wi, zi)), scale_over_n);
-            dd wi = dd_mul_d(dd_add(dd_mul(Wr, zi), dd_mul(Wi, zr)), scale_over_n);
+            dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
+            dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
             pc[c] = dd_round_away(wr);
             if (c > 0) pc[n - c] = -dd_round_away(wi);
         }
@@ -298,8 +340,8 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
             dd Wr = dd_sub(Xr, Yr), Wi = dd_neg(dd_sub(Xi, Yi));
             const double4 z = zt[cc];
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
-            dd wr = dd_mul_d(dd_sub(dd_mul(Wr, zr), dd_mul(Wi, zi)), scale_over_n);
-            dd wi = dd_mul_d(dd_add(dd_mul(Wr, zi), dd_mul(Wi, zr)), scale_over_n);
+            dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
+            dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
             pc[cc] = dd_round_away(wr);
             if (cc < h) pc[n - cc] = -dd_round_away(wi);
         }
