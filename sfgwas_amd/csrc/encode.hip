@@ -250,22 +250,31 @@ __device__ __forceinline__ long long dd_round_away(dd x) {
 
 // rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
 // F64IN: rows are n doubles (arbitrary real slot vectors, no rotation) — the Mask / EncodeFloatVector use.
+constexpr int ENC_HALF = ENC_H / 2;                 // the exchange image holds half of the points (2048) at a time
+constexpr int ENC_HPAD = ENC_HALF + ENC_HALF / 8;  // padded
+constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 73,728 B: two workgroups per CU
+// After the first radix-8 pass the transform splits into 8 independent 512-point sub-transforms (one per `a`), and the
+// final recombination pairs Z_c with Z_{h-c}, whose bit-reversed positions share the top bit (= parity of c).  So every
+// exchange can go through an image of HALF the points: the sub-transforms a < 4 (threads 0..255) and a >= 4 (threads
+// 256..511) take turns, data stays in registers meanwhile.  16 waves per CU instead of 8.
 template <bool F64IN>
-__global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, const double4 *zt, const uint16_t *tinv,
-                                                   double scale_over_n, long long *pc_out) {
+__global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *zt, const uint16_t *tinv,
+                                                      double scale_over_n, long long *pc_out) {
     extern __shared__ double lds[];
-    double *RH = lds, *RL = lds + ENC_PADN, *IH = lds + 2 * ENC_PADN, *IL = lds + 3 * ENC_PADN;
+    double *RH = lds, *RL = lds + ENC_HPAD, *IH = lds + 2 * ENC_HPAD, *IL = lds + 3 * ENC_HPAD;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
     const int shift = shift0 + blockIdx.x;
     const int nrot = F64IN ? 0 : SFG_D * (shift / SFG_D);          // matmult.go:1426: nrot = d * giant
     const int8_t *row = (const int8_t *)Dv + (size_t)shift * n;
     const double *rowd = (const double *)Dv + (size_t)shift * n;
-    // stage the 8 KiB row in the (not yet used) tail of LDS
-    int8_t *rowl = reinterpret_cast<int8_t *>(lds + 4 * ENC_PADN);
+    // stage the 8 KiB row at the start of LDS (the image is first written after pass 1)
+    int8_t *rowl = reinterpret_cast<int8_t *>(lds);
     if (!F64IN) reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
     __syncthreads();
     dd xr[8], xi[8];
-    // ---- pass 1: bits a (stages half = 2048, 1024, 512); thread = (b,c,d) = tid, element j = a*512 + tid
+    auto put = [&](int p, dd re, dd im) { RH[p] = re.hi; RL[p] = re.lo; IH[p] = im.hi; IL[p] = im.lo; };
+    auto get = [&](int p, dd &re, dd &im) { re = dd_make(RH[p], RL[p]); im = dd_make(IH[p], IL[p]); };
+    // ---- pass 1: bits a; thread = (b,c,d) = tid, element j = a*512 + tid
 #pragma unroll
     for (int a = 0; a < 8; a++) {
         const int m = a * 512 + tid;                               // z_m = u_2m + i u_2m+1, u_mm = v[tinv[mm]] = row[(tinv[mm] - nrot) mod n]
@@ -275,47 +284,67 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
         else { xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0); }
     }
     dif_radix8<512>(xr, xi, zt, tid);
-    __syncthreads();                                               // row staging area is dead, image can be written
-#pragma unroll
-    for (int a = 0; a < 8; a++) { const int p = padj(a * 512 + tid); RH[p] = xr[a].hi; RL[p] = xr[a].lo; IH[p] = xi[a].hi; IL[p] = xi[a].lo; }
-    __syncthreads();
-    // ---- pass 2: bits b; thread = (a, c, d): j = a*512 + b*64 + (tid & 63)
+    // Every exchange runs in two rounds through the half image.  Round r moves the points whose split bit equals r: the
+    // threads that own them write all 8 of their values, then EVERY thread reads the 4 values of that round it needs
+    // (unconditional reads keep the register live ranges short).
+    dd yr[8], yi[8];
     {
-        const int a = tid >> 6, cd = tid & 63, jb = a * 512 + cd;
+        // ---- exchange 1 -> 2, split on b >> 2.  Writer tid = (b, cd) holds a = 0..7; reader (a, cd) needs b = 0..7 of j = a*512 + b*64 + cd
+        const int bw = tid >> 6, cd = tid & 63, ar = tid >> 6;
 #pragma unroll
-        for (int b = 0; b < 8; b++) { const int p = padj(jb + b * 64); xr[b] = dd_make(RH[p], RL[p]); xi[b] = dd_make(IH[p], IL[p]); }
-        dif_radix8<64>(xr, xi, zt, cd);
+        for (int r = 0; r < 2; r++) {
+            __syncthreads();                                       // r = 0: row staging area is dead; r = 1: round-0 readers are done
+            if ((bw >> 2) == r) {
 #pragma unroll
-        for (int b = 0; b < 8; b++) { const int p = padj(jb + b * 64); RH[p] = xr[b].hi; RL[p] = xr[b].lo; IH[p] = xi[b].hi; IL[p] = xi[b].lo; }
-    }
-    __syncthreads();
-    // ---- pass 3: bits c; thread = (a, b, d): j = ab*64 + c*8 + d
-    {
-        const int ab = tid >> 3, d = tid & 7, jb = ab * 64 + d;
+                for (int a = 0; a < 8; a++) put(padj(a * 256 + (bw & 3) * 64 + cd), xr[a], xi[a]);
+            }
+            __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 8; c++) { const int p = padj(jb + c * 8); xr[c] = dd_make(RH[p], RL[p]); xi[c] = dd_make(IH[p], IL[p]); }
+            for (int b = 0; b < 4; b++) get(padj(ar * 256 + b * 64 + cd), yr[4 * r + b], yi[4 * r + b]);
+        }
+        dif_radix8<64>(yr, yi, zt, cd);
+        // ---- exchange 2 -> 3, split on c >> 2.  Writer (a, c, d) holds b = 0..7; reader (ab, d) needs c = 0..7 of j = ab*64 + c*8 + d
+        const int cw = (tid >> 3) & 7, d = tid & 7, ab = tid >> 3;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            __syncthreads();
+            if ((cw >> 2) == r) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) put(padj((ar * 8 + b) * 32 + (cw & 3) * 8 + d), yr[b], yi[b]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 4; c++) get(padj(ab * 32 + c * 8 + d), xr[4 * r + c], xi[4 * r + c]);
+        }
         dif_radix8<8>(xr, xi, zt, d);
+        // ---- exchange 3 -> 4, split on d >> 2.  Writer (ab, d) holds c = 0..7; reader tid = abc needs d = 0..7 of j = tid*8 + d
 #pragma unroll
-        for (int c = 0; c < 8; c++) { const int p = padj(jb + c * 8); RH[p] = xr[c].hi; RL[p] = xr[c].lo; IH[p] = xi[c].hi; IL[p] = xi[c].lo; }
+        for (int r = 0; r < 2; r++) {
+            __syncthreads();
+            if ((d >> 2) == r) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) put(padj((ab * 8 + c) * 4 + (d & 3)), xr[c], xi[c]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int d4 = 0; d4 < 4; d4++) get(padj(tid * 4 + d4), yr[4 * r + d4], yi[4 * r + d4]);
+        }
+        dif_radix8<1>(yr, yi, zt, 0);
     }
-    __syncthreads();
-    // ---- pass 4: bits d; thread = (a, b, c): j = tid*8 + d
-    {
-        const int jb = tid * 8;
-#pragma unroll
-        for (int d = 0; d < 8; d++) { const int p = padj(jb + d); xr[d] = dd_make(RH[p], RL[p]); xi[d] = dd_make(IH[p], IL[p]); }
-        dif_radix8<1>(xr, xi, zt, 0);
-#pragma unroll
-        for (int d = 0; d < 8; d++) { const int p = padj(jb + d); RH[p] = xr[d].hi; RL[p] = xr[d].lo; IH[p] = xi[d].hi; IL[p] = xi[d].lo; }
-    }
-    __syncthreads();
-    // ---- recombination: Z_c sits at bit-reversed position.  For c in [0, h/2]:
-    //   A = Z_c, B = conj(Z_{(h-c) mod h});  X = (A+B)/2 (= E_c),  Y = omega^-c * (A-B)/(2i) (= omega^-c O_c)
-    //   W_c = X + Y,  W_{h-c} = conj(X - Y);   w = zeta^-c' W_c' * scale/n;  p_c' = round(Re w), p_{n-c'} = -round(Im w)
+    const int my_half = tid >> 8, tl = tid & 255;                   // result position j = tid*8 + d: top bit = tid >> 8
+    // Round r handles the c of parity r: Z_c and Z_{h-c} then sit in half r of the (bit-reversed) result.
     long long *pc = pc_out + (size_t)blockIdx.x * n;
-    for (int c = tid; c <= h / 2; c += 512) {
+#pragma unroll 1
+    for (int r = 0; r < 2; r++) {
+    __syncthreads();
+    if (my_half == r) {
+#pragma unroll
+        for (int dd_ = 0; dd_ < 8; dd_++) put(padj(tl * 8 + dd_), yr[dd_], yi[dd_]);
+    }
+    __syncthreads();
+    for (int c = 2 * tid + r; c <= h / 2; c += 1024) {
         const int c2 = (h - c) & (h - 1);
-        const int pa = padj((int)(__brev((unsigned)c) >> 20)), pb = padj((int)(__brev((unsigned)c2) >> 20));
+        const int pa = padj((int)(__brev((unsigned)c) >> 20) & (ENC_HALF - 1)), pb = padj((int)(__brev((unsigned)c2) >> 20) & (ENC_HALF - 1));
         dd Ar = dd_make(RH[pa], RL[pa]), Ai = dd_make(IH[pa], IL[pa]);
         dd Br = dd_make(RH[pb], RL[pb]), Bi = dd_neg(dd_make(IH[pb], IL[pb]));
         dd Xr = dd_mul_d(dd_add(Ar, Br), 0.5), Xi = dd_mul_d(dd_add(Ai, Bi), 0.5);
@@ -346,6 +375,7 @@ __global__ void __launch_bounds__(512) k_fft_encode(const void *Dv, int shift0, 
             if (cc < h) pc[n - cc] = -dd_round_away(wi);
         }
     }
+    }
 }
 
 static int enc_scratch(sfg_ctx *ctx, EncTables *et, size_t nplain) {
@@ -372,7 +402,7 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g) {
     EncTables *et = (EncTables *)ctx->enc_tables;
     static bool attr = false;
-    const size_t lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
+    const size_t lds_bytes = ENC_LDS_BYTES;
     if (!attr) {
         SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -416,7 +446,7 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (nvec <= 0) return 0;
     EncTables *et = (EncTables *)ctx->enc_tables;
-    const size_t n = SFG_SLOTS, lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
+    const size_t n = SFG_SLOTS, lds_bytes = ENC_LDS_BYTES;
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     double *dv = nullptr; long long *dpc = nullptr;
     SFG_HIP(ctx, hipMalloc(&dv, (size_t)nvec * n * 8));
@@ -447,7 +477,7 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     if (nvec <= 0) return 0;
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "encode_vectors: level out of range");
     EncTables *et = (EncTables *)ctx->enc_tables;
-    const size_t n = SFG_SLOTS, lds_bytes = (size_t)(4 * ENC_PADN) * 8 + 8192;
+    const size_t n = SFG_SLOTS, lds_bytes = ENC_LDS_BYTES;
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     void *p = nullptr;
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
