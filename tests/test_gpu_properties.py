@@ -159,3 +159,47 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     assert np.array_equal(outs[0], outs[2]), "LDS-DMA and register-staged MAC kernels disagree"
     assert np.array_equal(outs[0], outs[3]) and np.array_equal(outs[0], outs[4]), "column passes / shared rotation cache changed the result"
     assert outs[0].any()
+
+
+_CHILD_LARGE = r"""
+import sys, ctypes as C, hashlib, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as ol
+from sfgwas_amd import capi
+ctx = capi.Context(ol.Q_PN14, ol.P_PN14); lib = capi.lib()
+D, N, L, LEVEL, SLOTS = 91, 16384, 5, 5, 8192
+rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < SLOTS]
+ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(rots))(*rots), len(rots), 0xBEEF), 'keys')
+nrow, ncol, s = 50000, 131077, 15               # BASELINE c3 rows (7 block rows, ragged), 17 block columns (ragged), kp = 15
+nbr, mct = -(-nrow // SLOTS), -(-ncol // SLOTS)
+g = ctx.malloc(nrow * ncol); ctx.check(lib.sfg_fill_geno_dev(ctx.h, g, nrow, ncol, 0x5F6A), 'g')
+gh = C.c_void_p(); ctx.check(lib.sfg_geno_from_device(ctx.h, g, nrow, ncol, ncol, C.byref(gh)), 'gh')
+h = hashlib.sha256()
+for flags, nin, nout in ((0, nbr, mct), (capi.SFG_TRANSPOSE, mct, nbr)):       # Q*X and Q'*X^T
+    A = ctx.malloc(s * nin * 2 * (LEVEL + 1) * N * 8); ctx.check(lib.sfg_fill_uniform_ct_dev(ctx.h, A, s * nin, LEVEL, 0xC1F3 + flags), 'A')
+    out = ctx.malloc(s * nout * 2 * L * N * 8)
+    ctx.check(lib.sfg_matmul_resident_dev(ctx.h, A, s, LEVEL, L, gh, flags, out), 'mm')
+    res = ctx.to_host(out, (s, nout, 2, L, N), np.uint64)
+    assert res.any() and int(res.max()) < max(ol.Q_PN14[:L])
+    h.update(res.tobytes())
+    ctx.free(A); ctx.free(out)
+open(sys.argv[1], 'w').write(h.hexdigest())
+"""
+
+
+def test_schedule_invariance_at_kp15_multi_pass_size(tmp_path):
+    """Both products of a power iteration at kp = 15 on a 50 000 x 131 077 matrix (7 ragged block rows x 17 block
+    columns: several block-row groups, two column passes at the default accumulator budget, the shared rotation cache
+    and the two-queue overlap all engage).  The digest of every output word must not depend on the schedule: default vs single queue + groups of 3 +
+    a 3-column accumulator budget + the register-staged MAC kernel for the third run."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for name, envv in [("default", {}),
+                       ("serial", {"SFG_MM_NO_OVERLAP": "1", "SFG_MM_GROUP": "3", "SFG_MM_ACC_BUDGET_MB": "6000", "SFG_UPLOAD_BLOCKING": "1"}),
+                       ("full_ntt", {"SFG_NTT_HALF_IMPL": "full", "SFG_MM_GROUP": "5"})]:
+        f = str(tmp_path / (name + ".txt"))
+        e = dict(os.environ); e.update(envv)
+        r = subprocess.run([sys.executable, "-c", _CHILD_LARGE, f], cwd=root, env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(open(f).read())
+    assert digests[0] == digests[1] == digests[2], digests
