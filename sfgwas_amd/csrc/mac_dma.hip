@@ -300,9 +300,6 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             DmaArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev;
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
-            if (getenv("SFG_MAC_DEBUG_CONTIG")) {   // timing experiment only (wrong results): pretend both operands are stored blocked
-                a.pt_n_stride = 16; a.pt_k_stride = (size_t)Ncols * 16; a.rotf_r_stride = 16 * (big ? 2 : 1); a.rotf_k_stride = (size_t)rows_per_k * a.rotf_r_stride;
-            }
             a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
             a.pt_half = st.pt_half ? 1 : 0; a.pt_l_stride = st.pt_half ? N / 2 : N;
             double maxterm = big ? 16777216.0 * 16777216.0 : 0.0;            // (lo+hi)*(lo+hi) < 2^48
