@@ -38,19 +38,32 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 
-template <bool BIG>
-__global__ void __launch_bounds__(DM_THREADS, 2) k_mac_dma(DmaArgs a, const ModConst *modc) {
+// WC = column waves per workgroup.  WC = 2: one 8-wave workgroup per CU (24 columns).  WC = 1: 4-wave workgroups of 12 columns,
+// TWO per CU with a ring each: their barriers and DMA waits are not synchronised, so one computes while the other waits.
+template <bool BIG, int WC_> struct MacRing {
+    // slot bytes: WC 2: 32 / 48 KiB, WC 1: 24 / 40 KiB
+    static constexpr int RW = BIG ? 2 : 1, JOBS = (DM_KC * DM_ROWS * DM_CL * 8 * RW + DM_KC * DM_CG * DM_CT * WC_ * DM_CL * 8) / 1024;
+    static constexpr int NW = 4 * WC_, A = (JOBS + NW - 1) / NW, SLOT = A * NW * 1024;
+    static constexpr int DEPTH = WC_ == 2 ? (BIG ? 3 : 4) : (BIG ? 2 : 3);
+    static constexpr int LDS = DEPTH * SLOT;
+};
+template <int WC_> struct MacGeom {
+    static constexpr int WAVES = 4 * WC_, THREADS = 64 * WAVES, COLS = DM_CG * DM_CT * WC_;
+};
+template <bool BIG, int WC_>
+__global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const ModConst *modc) {
+    constexpr int DM_COLS = MacGeom<WC_>::COLS, NWAVE = MacGeom<WC_>::WAVES;      // shadow the file-scope 2-wave-column geometry
     constexpr int RW = BIG ? 2 : 1;                                  // doubles per rot word
     constexpr int R_BYTES = DM_KC * DM_ROWS * DM_CL * 8 * RW;        // 16 KiB / 32 KiB
-    constexpr int P_BYTES = DM_KC * DM_COLS * DM_CL * 8;             // 12 KiB
+    constexpr int P_BYTES = DM_KC * DM_COLS * DM_CL * 8;             // 12 KiB (6 KiB for WC = 1)
     constexpr int R_JOBS = R_BYTES / 1024, P_JOBS = P_BYTES / 1024;  // 1 KiB per wave-instruction
-    constexpr int JOBS = R_JOBS + P_JOBS;                            // 28 / 44
-    constexpr int A = (JOBS + 7) / 8;                                // DMA instructions per wave per chunk: 4 / 6
-    constexpr int SLOT = A * 8 * 1024;                               // slot incl. dummy jobs: 32 / 48 KiB
-    constexpr int DEPTH = BIG ? 3 : 4;                               // ring slots: 144 / 128 KiB
+    constexpr int JOBS = R_JOBS + P_JOBS;                            // 28 / 44 (22 / 38)
+    constexpr int A = (JOBS + NWAVE - 1) / NWAVE;                    // DMA instructions per wave per chunk
+    constexpr int SLOT = A * NWAVE * 1024;                           // slot incl. dummy jobs
+    constexpr int DEPTH = MacRing<BIG, WC_>::DEPTH;                  // ring slots
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int N = SFG_N, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cc = lane & 15, cg = lane >> 4, rh = wave & 3, wc = wave >> 2;
+    const int cc = lane & 15, cg = lane >> 4, rh = wave & 3, wc = wave >> 2;                  // wc == 0 when WC_ == 1
     // Block decode.  Column tiles that share one (c-block, modulus) slab of `rot` get consecutive slots on the same
     // XCD (blocks b and b+8 share an XCD).  With half-row plaintexts a c-block and its mirror (1023 - cblk) read
     // the same plaintext bytes, so the pair is placed back to back on one XCD and the second read is an L2 hit.
@@ -285,8 +298,11 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
     const int N = SFG_N;
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
     if (!g_dma_attr) {
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 1024));
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 48 * 1024));
+        constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
+        auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s2));
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b2));
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s1));
         g_dma_attr = true;
     }
     if (!ctx->zeros_dev) { SFG_HIP(ctx, hipMalloc(&ctx->zeros_dev, 256)); SFG_HIP(ctx, hipMemset(ctx->zeros_dev, 0, 256)); }
@@ -306,12 +322,18 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / DM_KC) * DM_KC;
             if (f < DM_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
-            a.flush = f; a.ntile = (Ncols + DM_COLS - 1) / DM_COLS;
+            static const int wc_small = getenv("SFG_MAC_WC") ? atoi(getenv("SFG_MAC_WC")) : 1;       // column waves per workgroup for the small moduli
+            const int wcs = big ? 2 : (wc_small == 2 ? 2 : 1);
+            const int cols_wg = DM_CG * DM_CT * wcs;
+            a.flush = f; a.ntile = (Ncols + cols_wg - 1) / cols_wg;
             const int nslab = (st.pt_half ? N / DM_CL / 2 : N / DM_CL) * a.nl, ngrp = (nslab + 7) / 8;
             dim3 grid((unsigned)(ngrp * 8 * a.ntile * (st.pt_half ? 2 : 1)));
             PhaseTimer t(ctx, big ? "mac_big" : "mac_small");
-            if (big) hipLaunchKernelGGL(k_mac_dma<true>, grid, dim3(DM_THREADS), 3 * 48 * 1024, ctx->stream, a, ctx->modc);
-            else hipLaunchKernelGGL(k_mac_dma<false>, grid, dim3(DM_THREADS), 4 * 32 * 1024, ctx->stream, a, ctx->modc);
+            constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
+            auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
+            if (big) hipLaunchKernelGGL(kb2, grid, dim3(512), lds_b2, ctx->stream, a, ctx->modc);
+            else if (wcs == 2) hipLaunchKernelGGL(ks2, grid, dim3(512), lds_s2, ctx->stream, a, ctx->modc);
+            else hipLaunchKernelGGL(ks1, grid, dim3(256), lds_s1, ctx->stream, a, ctx->modc);
             SFG_HIP(ctx, hipGetLastError());
             {   // algorithmic bytes of this launch: fp64 rot operand + plaintext words + accumulators written (and read when accumulating)
                 const double nlm = (double)(e - l), rw = big ? 2.0 : 1.0, pw = st.pt_half ? 0.5 : 1.0;

@@ -149,7 +149,8 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"}),
-                       ("budget", {"SFG_MM_ACC_BUDGET_MB": "300"}), ("budget_g1", {"SFG_MM_ACC_BUDGET_MB": "300", "SFG_MM_GROUP": "1"})]:
+                       ("budget", {"SFG_MM_ACC_BUDGET_MB": "300"}), ("budget_g1", {"SFG_MM_ACC_BUDGET_MB": "300", "SFG_MM_GROUP": "1"}),
+                       ("wc2", {"SFG_MAC_WC": "2"})]:
         f = str(tmp_path / (name + ".npy"))
         e = dict(os.environ); e.update(envv)
         r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
@@ -158,6 +159,7 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     assert np.array_equal(outs[0], outs[1]), "block-row grouping changed the result"
     assert np.array_equal(outs[0], outs[2]), "LDS-DMA and register-staged MAC kernels disagree"
     assert np.array_equal(outs[0], outs[3]) and np.array_equal(outs[0], outs[4]), "column passes / shared rotation cache changed the result"
+    assert np.array_equal(outs[0], outs[5]), "8-wave and 4-wave MAC workgroups disagree"
     assert outs[0].any()
 
 
