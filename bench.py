@@ -127,7 +127,8 @@ def main():
         chk(lib.sfg_matmul_accumulate_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP, LEVEL, L, gh, capi.SFG_TRANSPOSE,
                                           0, nblk_loc, 0, nbr_x, 0, C.c_void_p(acc2.data_ptr())), "Q'*X^T accumulate")
         if use_dist:
-            dist.all_reduce(acc2)                                           # < 8 * 2^46: no uint64 overflow
+            for j in range(nbr_x):                                          # one collective per output block column: 1.8 GB each,
+                dist.all_reduce(acc2[j])                                    # element counts stay below 2^31; sums < 8 * 2^46, no overflow
             chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(acc2.data_ptr()), nbr_x * D * KP * 2, L), "reduce acc")
         g0, g1 = giant_range(rank, world)
         chk(lib.sfg_matmul_finalize_dev(ctx.h, C.c_void_p(acc2.data_ptr()), KP, L, nbr_x, g0, g1, 0, C.c_void_p(out2.data_ptr())), "finalize")
