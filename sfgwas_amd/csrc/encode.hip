@@ -52,7 +52,7 @@ struct EncTables {
     double4 *zt = nullptr;        // [ENC_TW + 1] {re.hi, re.lo, im.hi, im.lo} of exp(-2 pi i k / 32768)
     uint16_t *tinv = nullptr;     // [n] slot index t with (5^t - 1)/4 mod n == m
     int8_t *skew = nullptr;       // diag-major scratch for one block: [n][n]
-    long long *pc = nullptr;      // half-coefficient scratch [batch][n]
+    double *pc = nullptr;         // half-coefficient scratch [batch][n]: the rounded integers, held as doubles (|p| < 2^53)
     size_t pc_cap = 0;
 };
 
@@ -240,12 +240,12 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
     }
 }
 
-__device__ __forceinline__ long long dd_round_away(dd x) {
+__device__ __forceinline__ double dd_round_away(dd x) {                // integer-valued double
     double nn = __builtin_rint(x.hi);
     double diff = (x.hi - nn) + x.lo;
     if (diff > 0.5 || (diff == 0.5 && nn >= 0)) nn += 1.0;
     else if (diff < -0.5 || (diff == -0.5 && nn <= 0)) nn -= 1.0;
-    return (long long)nn;
+    return nn;
 }
 
 // rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
@@ -259,7 +259,7 @@ constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 73,728 B: two
 // 256..511) take turns, data stays in registers meanwhile.  16 waves per CU instead of 8.
 template <bool F64IN>
 __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *zt, const uint16_t *tinv,
-                                                      double scale_over_n, long long *pc_out) {
+                                                      double scale_over_n, double *pc_out) {
     extern __shared__ double lds[];
     double *RH = lds, *RL = lds + ENC_HPAD, *IH = lds + 2 * ENC_HPAD, *IL = lds + 3 * ENC_HPAD;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     }
     const int my_half = tid >> 8, tl = tid & 255;                   // result position j = tid*8 + d: top bit = tid >> 8
     // Round r handles the c of parity r: Z_c and Z_{h-c} then sit in half r of the (bit-reversed) result.
-    long long *pc = pc_out + (size_t)blockIdx.x * n;
+    double *pc = pc_out + (size_t)blockIdx.x * n;
 #pragma unroll 1
     for (int r = 0; r < 2; r++) {
     __syncthreads();
@@ -385,7 +385,7 @@ static int enc_scratch(sfg_ctx *ctx, EncTables *et, size_t nplain) {
         SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (et->pc) SFG_HIP(ctx, hipFree(et->pc));
         et->pc = nullptr; et->pc_cap = 0;
-        SFG_HIP(ctx, hipMalloc(&et->pc, nplain * n * sizeof(long long)));
+        SFG_HIP(ctx, hipMalloc(&et->pc, nplain * n * sizeof(double)));
         et->pc_cap = nplain;
     }
     return 0;
@@ -448,10 +448,10 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     EncTables *et = (EncTables *)ctx->enc_tables;
     const size_t n = SFG_SLOTS, lds_bytes = ENC_LDS_BYTES;
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    double *dv = nullptr; long long *dpc = nullptr;
+    double *dv = nullptr; double *dpc = nullptr;
     SFG_HIP(ctx, hipMalloc(&dv, (size_t)nvec * n * 8));
     if (hipMalloc(&dpc, (size_t)nvec * n * 8) != hipSuccess) { (void)hipFree(dv); SFG_FAIL(ctx, "encode_coeffs: out of device memory"); }
-    std::vector<long long> pc((size_t)nvec * n);
+    std::vector<double> pc((size_t)nvec * n);
     int rc = 0;
     if (hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
     if (!rc) {
@@ -462,10 +462,10 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     (void)hipStreamSynchronize(ctx->stream); (void)hipFree(dv); (void)hipFree(dpc);
     if (rc) SFG_FAIL(ctx, "encode_coeffs: device operation failed");
     for (int v = 0; v < nvec; v++) {                       // expand p_n = 0, p_{n+c} = -p_{n-c}
-        const long long *h = pc.data() + (size_t)v * n; int64_t *o = coeffs_host + (size_t)v * SFG_N;
-        for (size_t c = 0; c < n; c++) o[c] = h[c];
+        const double *h = pc.data() + (size_t)v * n; int64_t *o = coeffs_host + (size_t)v * SFG_N;
+        for (size_t c = 0; c < n; c++) o[c] = (int64_t)h[c];
         o[n] = 0;
-        for (size_t c = 1; c < n; c++) o[n + c] = -h[n - c];
+        for (size_t c = 1; c < n; c++) o[n + c] = -(int64_t)h[n - c];
     }
     return 0;
 }
@@ -481,7 +481,7 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     void *p = nullptr;
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
-    double *dv = (double *)p; long long *dpc = (long long *)(dv + (size_t)nvec * n);
+    double *dv = (double *)p; double *dpc = dv + (size_t)nvec * n;
     SFG_HIP(ctx, hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc);
     SFG_HIP(ctx, hipGetLastError());

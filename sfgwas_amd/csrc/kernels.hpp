@@ -15,8 +15,8 @@ struct PanelMap { int G, g, shift0; };
 // ntt.hip
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
-int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain, int L);
-int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L, PanelMap pm);
+int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, int L);
+int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm);
 int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);

@@ -14,7 +14,7 @@
 #include "kernels.hpp"
 #include "ntt_core.hpp"
 
-// IN_MODE 0: rows of canonical u64; 1: half-coefficient int64 input of a real-slot plaintext
+// IN_MODE 0: rows of canonical u64; 1: half-coefficient input (integer-valued doubles) of a real-slot plaintext
 // (pc[0..N/2): p_c, with p_{N/2} = 0 and p_{N-c} = -p_c, see encode.hip), rows = [plain][L]
 template <int IN_MODE>
 __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, ModPattern pat, RowMap rm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
@@ -34,13 +34,13 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
 #pragma unroll
         for (int a = 0; a < 32; a++) v[a] = u64_to_f64(in[a * 512 + tid]);
     } else {
-        const long long *pc = (const long long *)in_ + (row / pat.period) * (size_t)(N / 2);
+        const double *pc = (const double *)in_ + (row / pat.period) * (size_t)(N / 2);
 #pragma unroll
-        for (int a = 0; a < 16; a++) v[a] = (double)pc[a * 512 + tid];
+        for (int a = 0; a < 16; a++) v[a] = pc[a * 512 + tid];
 #pragma unroll
         for (int a = 16; a < 32; a++) {                 // j = N/2 + x, x = (a-16)*512 + tid: p_j = -p_{N/2 - x}, p_{N/2} = 0
             int x = (a - 16) * 512 + tid;
-            v[a] = x == 0 ? 0.0 : -(double)pc[N / 2 - x];
+            v[a] = x == 0 ? 0.0 : -pc[N / 2 - x];
         }
     }
     ntt_fwd_phases(v, lds, tw, pack, q, qinv, tid);
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
 // r_0 = p_0) and runs stages 2..14 on those n = N/2 values only: half the butterflies, half the LDS (two
 // workgroups per CU), and it emits half rows P[0..n).  256 threads, j = a*512 + b*16 + c with a < 16.
 constexpr int HLDS_DOUBLES = 16 * LDS_ROW;   // 67,584 B
-__global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+__global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     const size_t row = blockIdx.x;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *
     const double *tw = tw_all + (size_t)m * N;
     const double2 *pack = pack_all + (size_t)m * (N / 2);
     const double q = modc[m].q, qinv = modc[m].qinv;
-    const long long *pc = pc_all + (row / L) * (size_t)n;
+    const double *pc = pc_all + (row / L) * (size_t)n;
     const double W = tw[1], Wq = W * qinv;
     double v[32];
     // ---- phase A: two (b,c) columns per thread, 16 values of a each; stages t = 4096, 2048, 1024, 512
@@ -156,8 +156,8 @@ __global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *
 #pragma unroll
         for (int a = 0; a < 16; a++) {
             const int j = a * 512 + pp;
-            const double lo = (double)pc[j];
-            const double hi = j == 0 ? 0.0 : (double)pc[n - j];          // p_{n+j} = -p_{n-j}
+            const double lo = pc[j];
+            const double hi = j == 0 ? 0.0 : pc[n - j];          // p_{n+j} = -p_{n-j}
             w[a] = lo - mulmod_lazy(hi, W, Wq, q);
         }
         ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + g]; });
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_ntt_half(const long long *pc_all, u64 *
 constexpr int H3_ROWA = 264;                  // 256 + 8 doubles per `a` row of the A->B half image
 constexpr int H3_DOUBLES = 16 * H3_ROWA;
 constexpr int H3_LDS_BYTES = (H3_DOUBLES > 8 * LDS_ROW ? H3_DOUBLES : 8 * LDS_ROW) * 8;      // 33,792 B (the B->C / C->out half image needs 8 * LDS_ROW = 4224 doubles as well)
-__global__ void __launch_bounds__(256) k_ntt_half3(const long long *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+__global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     const size_t row = blockIdx.x;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const long long *pc_all, u64 
     const double *tw = tw_all + (size_t)m * N;
     const double2 *pack = pack_all + (size_t)m * (N / 2);
     const double q = modc[m].q, qinv = modc[m].qinv;
-    const long long *pc = pc_all + (row / L) * (size_t)n;
+    const double *pc = pc_all + (row / L) * (size_t)n;
     const double W = tw[1], Wq = W * qinv;
     double v[32];
     const int a_b = tid >> 4, c_b = tid & 15;                  // phase B identity
@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const long long *pc_all, u64 
 #pragma unroll
         for (int a = 0; a < 16; a++) {
             const int j = a * 512 + pp;
-            const double lo = (double)pc[j];
-            const double hi = j == 0 ? 0.0 : (double)pc[n - j];          // p_{n+j} = -p_{n-j}
+            const double lo = pc[j];
+            const double hi = j == 0 ? 0.0 : pc[n - j];          // p_{n+j} = -p_{n-j}
             w[a] = lo - mulmod_lazy(hi, W, Wq, q);
         }
         ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + g]; });
@@ -346,7 +346,7 @@ int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, cons
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
-int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain, int L) {
+int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, int L) {
     if (!nplain) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     ModPattern pat; pat.period = L; for (int l = 0; l < L; l++) pat.m[l] = (int8_t)l;
@@ -355,7 +355,7 @@ int launch_ntt_plain(sfg_ctx *ctx, const long long *pc, u64 *out, size_t nplain,
     return 0;
 }
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
-int launch_ntt_plain_half(sfg_ctx *ctx, const long long *pc, u64 *out_half, size_t nplain, int L, PanelMap pm) {
+int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm) {
     if (!nplain) return 0;
     if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     static const bool full_image = getenv("SFG_NTT_HALF_IMPL") && !strcmp(getenv("SFG_NTT_HALF_IMPL"), "full");      // A/B switch
