@@ -23,6 +23,12 @@ __host__ __device__ static inline dd dd_quick(double a, double b) { double s = a
 __host__ __device__ static inline dd dd_two_sum(double a, double b) { double s = a + b, bb = s - a; return dd_make(s, (a - (s - bb)) + (b - bb)); }
 __host__ __device__ static inline dd dd_add(dd a, dd b) { dd s = dd_two_sum(a.hi, b.hi); s.lo += a.lo + b.lo; return dd_quick(s.hi, s.lo); }
 __host__ __device__ static inline dd dd_neg(dd a) { return dd_make(-a.hi, -a.lo); }
+// sum without the final renormalisation (8 flops instead of 11): the high parts are added exactly, the low part may grow to a
+// few ulps of the high part.  Every consumer below (two_sum on the high parts, dd_mul / dd_dot2 cross terms) is exact or
+// first-order correct for such pairs, so a chain of k lazy sums costs log2(k) of the ~106 bits; results are renormalised by the
+// next product or by the recombination.
+__host__ __device__ static inline dd dd_add_lazy(dd a, dd b) { dd s = dd_two_sum(a.hi, b.hi); s.lo += a.lo + b.lo; return s; }
+__host__ __device__ static inline dd dd_sub_lazy(dd a, dd b) { dd s = dd_two_sum(a.hi, -b.hi); s.lo += a.lo - b.lo; return s; }
 __host__ __device__ static inline dd dd_sub(dd a, dd b) { return dd_add(a, dd_neg(b)); }
 __host__ __device__ static inline dd dd_mul(dd a, dd b) {
     double p = a.hi * b.hi, e = fma(a.hi, b.hi, -p);
@@ -202,30 +208,30 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
     dd ur[4], ui[4], dr[4], di[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        ur[i] = dd_add(xr[i], xr[i + 4]); ui[i] = dd_add(xi[i], xi[i + 4]);
-        dr[i] = dd_sub(xr[i], xr[i + 4]); di[i] = dd_sub(xi[i], xi[i + 4]);
+        ur[i] = dd_add_lazy(xr[i], xr[i + 4]); ui[i] = dd_add_lazy(xi[i], xi[i + 4]);
+        dr[i] = dd_sub_lazy(xr[i], xr[i + 4]); di[i] = dd_sub_lazy(xi[i], xi[i + 4]);
     }
     {   // d1 *= W8 = (1 - i)/sqrt2: (a + bi) -> ((a + b) + (b - a) i)/sqrt2
         dd a = dr[1], b = di[1];
-        dr[1] = dd_mul(dd_add(a, b), rs); di[1] = dd_mul(dd_sub(b, a), rs);
+        dr[1] = dd_mul(dd_add_lazy(a, b), rs); di[1] = dd_mul(dd_sub_lazy(b, a), rs);
     }
     {   // d2 *= -i: (a + bi) -> (b - ai)
         dd a = dr[2]; dr[2] = di[2]; di[2] = dd_neg(a);
     }
     {   // d3 *= W8^3 = (-1 - i)/sqrt2: (a + bi) -> ((b - a) - (a + b) i)/sqrt2
         dd a = dr[3], b = di[3];
-        dr[3] = dd_mul(dd_sub(b, a), rs); di[3] = dd_neg(dd_mul(dd_add(a, b), rs));
+        dr[3] = dd_mul(dd_sub_lazy(b, a), rs); di[3] = dd_neg(dd_mul(dd_add_lazy(a, b), rs));
     }
     auto quad = [&](dd (&hr)[4], dd (&hi)[4], int o) {
-        dd p0r = dd_add(hr[0], hr[2]), p0i = dd_add(hi[0], hi[2]);
-        dd p1r = dd_add(hr[1], hr[3]), p1i = dd_add(hi[1], hi[3]);
-        dd q0r = dd_sub(hr[0], hr[2]), q0i = dd_sub(hi[0], hi[2]);
-        dd t1r = dd_sub(hr[1], hr[3]), t1i = dd_sub(hi[1], hi[3]);
+        dd p0r = dd_add_lazy(hr[0], hr[2]), p0i = dd_add_lazy(hi[0], hi[2]);
+        dd p1r = dd_add_lazy(hr[1], hr[3]), p1i = dd_add_lazy(hi[1], hi[3]);
+        dd q0r = dd_sub_lazy(hr[0], hr[2]), q0i = dd_sub_lazy(hi[0], hi[2]);
+        dd t1r = dd_sub_lazy(hr[1], hr[3]), t1i = dd_sub_lazy(hi[1], hi[3]);
         dd q1r = t1i, q1i = dd_neg(t1r);                                               // * -i
-        xr[o + 0] = dd_add(p0r, p1r); xi[o + 0] = dd_add(p0i, p1i);
-        xr[o + 1] = dd_sub(p0r, p1r); xi[o + 1] = dd_sub(p0i, p1i);
-        xr[o + 2] = dd_add(q0r, q1r); xi[o + 2] = dd_add(q0i, q1i);
-        xr[o + 3] = dd_sub(q0r, q1r); xi[o + 3] = dd_sub(q0i, q1i);
+        xr[o + 0] = dd_add_lazy(p0r, p1r); xi[o + 0] = dd_add_lazy(p0i, p1i);
+        xr[o + 1] = dd_sub_lazy(p0r, p1r); xi[o + 1] = dd_sub_lazy(p0i, p1i);
+        xr[o + 2] = dd_add_lazy(q0r, q1r); xi[o + 2] = dd_add_lazy(q0i, q1i);
+        xr[o + 3] = dd_sub_lazy(q0r, q1r); xi[o + 3] = dd_sub_lazy(q0i, q1i);
     };
     quad(ur, ui, 0);
     quad(dr, di, 4);
