@@ -16,8 +16,11 @@
  *    (row[i] = p(psi^(2*bitrev(i)+1))); a ciphertext at level l is [2][l+1][N]
  *    (= ct.Value()[k].Coeffs[m][:] flattened, crypto.go:32-60).
  *  - "_dev" pointers are device (HBM) addresses on the context's GPU; "_host" are host pointers.
- *  - A context is re-entrant across threads only through separate contexts or external locking
- *    (the Go evaluator pool has the same exclusivity rule, crypto.go:311-316).
+ *  - Threading: one host thread drives a context at a time - the exclusivity rule of the Go evaluator
+ *    pool (crypto.go:311-316).  Concurrent callers (assoc.go:360-408 runs assoc_num_blocks_parallel MatMult4Stream
+ *    calls at once) each take a fork (sfg_ctx_fork): forks share the immutable ring tables and key material of their
+ *    parent and own their HIP queues, scratch, staging ring, timers and error string.  The library keeps no
+ *    process-global state and reads the environment only inside sfg_ctx_create.
  */
 #ifndef SFGWAS_HIP_H
 #define SFGWAS_HIP_H
@@ -36,6 +39,9 @@ typedef struct sfg_geno sfg_geno;
  * derived from the smallest primitive root exactly as lattigo derives it. */
 int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int np,
                    const uint64_t *moduli, const uint64_t *psi, double scale);
+/* a second caller on the same keys: replaces checking a private evaluator out of the pool (crypto.go:287-316,
+ * ckks.NewEvaluator per goroutine at matmult.go:1110,1200,1371).  Load keys before forks run concurrently. */
+int sfg_ctx_fork(sfg_ctx *parent, sfg_ctx **out);
 void sfg_ctx_destroy(sfg_ctx *ctx);
 const char *sfg_last_error(const sfg_ctx *ctx);     /* ctx may be NULL: error of a failed sfg_ctx_create */
 int sfg_ctx_synchronize(sfg_ctx *ctx);

@@ -25,6 +25,7 @@ def _sig(L):
     vp, i, u64, d, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_size_t
     S = {
         "sfg_ctx_create": (i, [C.POINTER(vp), i, i, i, i, u64p, u64p, d]),
+        "sfg_ctx_fork": (i, [vp, C.POINTER(vp)]),
         "sfg_ctx_destroy": (None, [vp]),
         "sfg_last_error": (C.c_char_p, [vp]),
         "sfg_ctx_synchronize": (i, [vp]),

@@ -39,37 +39,78 @@ struct sfg_geno {
     bool owned = false;
 };
 
-struct sfg_ctx {
+// A/B and diagnostic switches: read ONCE from the environment by sfg_ctx_create (never on the launch path)
+struct SfgConfig {
+    bool mac_reg = false;          // SFG_MAC_IMPL=reg      register-staged MAC kernel (mac.hip)
+    int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
+    int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
+    size_t acc_budget = 24ULL << 30;   // SFG_MM_ACC_BUDGET_MB
+    bool no_overlap = false;       // SFG_MM_NO_OVERLAP     single queue
+    bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
+    bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
+    bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)
+};
+
+// Immutable after setup, shared by a context and its forks (sfg_ctx_fork): ring tables, encoder tables, key material.
+struct SfgShared {
     int device = 0;
     int logN = SFG_LOGN, N = SFG_N, nq = 0, np = 0, nmod = 0, beta = 0;
     double scale = 0;
     u64 q[SFG_MAXMOD] = {0}, psi[SFG_MAXMOD] = {0};
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC
-    // pinned host ring for small stream-ordered uploads (pointer tables): no blocking copies on the launch path
-    unsigned char *pin = nullptr; size_t pin_bytes = 0, pin_head = 0;
-    hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // [0,1]: rotation cache of group parity ready; [2,3]: finalize of column pass parity done
-    std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;     // ordering events (no timing), reused round-robin
-    // device tables
     double *tw_fwd = nullptr;    // [nmod][N] w, index m+i as in the CT loop (psi^bitrev)
     double *tw_inv = nullptr;    // [nmod][N] w for psi^-bitrev
     double2 *pack_fwd = nullptr; // [nmod][256][8][64] late-stage (t <= 8) twiddles packed for coalesced per-wave loads
     double2 *pack_inv = nullptr;
     ModConst *modc = nullptr;    // [nmod]
     ModConst modc_host[SFG_MAXMOD];
-    // encoder tables (double-double twiddles), see encode.hip
-    void *enc_tables = nullptr;
-    // rotation keys
-    std::map<u64, RotKey> rotkeys;
+    void *enc_tables = nullptr;  // encoder tables (double-double twiddles), see encode.hip
+    void *zeros_dev = nullptr;   // 256 B of zeros (DMA source for padded k-steps)
+    std::map<u64, RotKey> rotkeys;      // written only by sfg_ctx_load_rotkey / _relinkey (setup time), read by every fork
+    SfgConfig cfg;
+    int refs = 1;                // the creating context + live forks
+};
+
+// A context = the shared part + ONE caller's execution state (streams, scratch, staging ring, timers, error string).
+// Concurrent callers (assoc.go:360-408 runs assoc_num_blocks_parallel MatMult4Stream calls at once) each use their own
+// fork; nothing below is touched by another thread.
+struct sfg_ctx {
+    SfgShared *sh = nullptr;
+    bool is_fork = false;
+    // mirrors of the shared scalars / table pointers (read-only; filled by ctx_bind_shared)
+    int device = 0;
+    int logN = SFG_LOGN, N = SFG_N, nq = 0, np = 0, nmod = 0, beta = 0;
+    double scale = 0;
+    u64 q[SFG_MAXMOD] = {0}, psi[SFG_MAXMOD] = {0};
+    double *tw_fwd = nullptr, *tw_inv = nullptr;
+    double2 *pack_fwd = nullptr, *pack_inv = nullptr;
+    ModConst *modc = nullptr;
+    ModConst modc_host[SFG_MAXMOD];
+    SfgConfig cfg;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t user_stream = nullptr;   // installed by sfg_ctx_set_stream (nullptr = own_stream is the main queue)
+    hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC
+    // pinned host ring for small stream-ordered uploads (pointer tables): no blocking copies on the launch path
+    unsigned char *pin = nullptr; size_t pin_bytes = 0, pin_head = 0;
+    hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // [0,1]: rotation cache of group parity ready; [2,3]: finalize of column pass parity done
+    std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;     // ordering events (no timing), reused round-robin
     std::map<int, void *> ksw_cache;   // per-level key-switch constants (device), rotate.hip
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
     std::map<std::string, std::pair<void *, size_t>> pool;   // named grow-only device scratch (sfg_scratch), freed with the context
     std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
-    void *zeros_dev = nullptr;           // 256 B of zeros (DMA source for padded k-steps)
     std::string err;
     std::map<std::string, PhaseStat> phases;
+    unsigned long long enc_near_ties = 0;   // encoder coefficients within 2^-40 of a rounding tie, recomputed in triple-double (encode.hip)
+    void *tie_count_dev = nullptr;
+    hipStream_t main_stream() const { return user_stream ? user_stream : own_stream; }
+    std::map<u64, RotKey> &rotkeys() { return sh->rotkeys; }
+    const std::map<u64, RotKey> &rotkeys() const { return sh->rotkeys; }
+    void *enc_tables() const { return sh->enc_tables; }
+    void *zeros_dev() const { return sh->zeros_dev; }
 };
+
+// synchronise every queue of the context (before freeing / reusing memory either queue may still read)
+int sfg_sync_all(sfg_ctx *ctx);
 
 extern thread_local std::string g_create_error;
 

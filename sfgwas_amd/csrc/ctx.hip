@@ -16,8 +16,47 @@ static u64 derive_psi(u64 q, int logN) {
     }
 }
 
-int sfg_encoder_init(sfg_ctx *ctx);      // encode.hip
-void sfg_encoder_destroy(sfg_ctx *ctx);
+int sfg_encoder_init(sfg_ctx *ctx);      // encode.hip (tables into ctx->sh)
+void sfg_encoder_destroy(SfgShared *sh);
+int sfg_kernel_attrs_init(sfg_ctx *ctx);  // raises the dynamic-LDS limits of every big-LDS kernel on ctx->device (mac_dma/ntt/encode)
+int mac_dma_set_attrs(sfg_ctx *ctx);
+int ntt_set_attrs(sfg_ctx *ctx);
+int encode_set_attrs(sfg_ctx *ctx);
+
+static void read_config(SfgConfig &c) {
+    auto env = [](const char *n) { return getenv(n); };
+    if (const char *e = env("SFG_MAC_IMPL")) c.mac_reg = !strcmp(e, "reg");
+    if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
+    if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; }
+    if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
+    c.no_overlap = env("SFG_MM_NO_OVERLAP") != nullptr;
+    if (const char *e = env("SFG_NTT_HALF_IMPL")) c.ntt_half_full = !strcmp(e, "full");
+    c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
+    if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
+}
+
+// copy the shared scalars / table pointers into the context (read-only mirrors: the launch code reads ctx->q, ctx->modc, ...)
+static void ctx_bind_shared(sfg_ctx *ctx, SfgShared *sh) {
+    ctx->sh = sh; ctx->device = sh->device; ctx->logN = sh->logN; ctx->N = sh->N; ctx->nq = sh->nq; ctx->np = sh->np; ctx->nmod = sh->nmod;
+    ctx->beta = sh->beta; ctx->scale = sh->scale; ctx->cfg = sh->cfg;
+    memcpy(ctx->q, sh->q, sizeof sh->q); memcpy(ctx->psi, sh->psi, sizeof sh->psi); memcpy(ctx->modc_host, sh->modc_host, sizeof sh->modc_host);
+    ctx->tw_fwd = sh->tw_fwd; ctx->tw_inv = sh->tw_inv; ctx->pack_fwd = sh->pack_fwd; ctx->pack_inv = sh->pack_inv; ctx->modc = sh->modc;
+}
+// per-caller execution state: two queues, ordering events, the pinned staging ring
+static const char *ctx_exec_init(sfg_ctx *ctx) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return "hipSetDevice failed";
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+    ctx->stream = ctx->own_stream;
+    {   // the auxiliary queue yields to the main one: its element-wise key-switch kernels fill gaps, they must not displace MAC workgroups
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) return "hipStreamCreate failed";
+    }
+    for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    ctx->pin_bytes = 64u << 20;
+    if (hipHostMalloc((void **)&ctx->pin, ctx->pin_bytes, hipHostMallocDefault) != hipSuccess) return "hipHostMalloc failed";
+    if (hipMalloc(&ctx->tie_count_dev, 8) != hipSuccess || hipMemset(ctx->tie_count_dev, 0, 8) != hipSuccess) return "hipMalloc failed";
+    return nullptr;
+}
 
 extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int np,
                               const uint64_t *moduli, const uint64_t *psi, double scale) {
@@ -28,34 +67,28 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device: libsfgwas_hip has no CPU fallback"; return 1; }
     if (device < 0 || device >= ndev) { g_create_error = "bad device index"; return 1; }
     sfg_ctx *ctx = new sfg_ctx();
-    ctx->device = device; ctx->nq = nq; ctx->np = np; ctx->nmod = nq + np; ctx->beta = (nq + np - 1) / np; ctx->scale = scale;
-    auto fail = [&](const char *m) { g_create_error = m; sfg_ctx_destroy(ctx); return 1; };
-    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    ctx->stream = ctx->own_stream;
-    {   // the auxiliary queue yields to the main one: its element-wise key-switch kernels fill gaps, they must not displace MAC workgroups
-        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) return fail("hipStreamCreate failed");
-    }
-    for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
-    ctx->pin_bytes = 64u << 20;
-    if (hipHostMalloc((void **)&ctx->pin, ctx->pin_bytes, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+    SfgShared *sh = new SfgShared();
+    ctx->sh = sh; ctx->device = device;
+    sh->device = device; sh->nq = nq; sh->np = np; sh->nmod = nq + np; sh->beta = (nq + np - 1) / np; sh->scale = scale;
+    read_config(sh->cfg);
+    auto fail = [&](const char *m) { std::string msg = m; sfg_ctx_destroy(ctx); g_create_error = msg; return 1; };
+    if (const char *e = ctx_exec_init(ctx)) return fail(e);
     const int N = SFG_N;
-    std::vector<double> twf((size_t)ctx->nmod * N), twi((size_t)ctx->nmod * N);
-    for (int m = 0; m < ctx->nmod; m++) {
+    std::vector<double> twf((size_t)sh->nmod * N), twi((size_t)sh->nmod * N);
+    for (int m = 0; m < sh->nmod; m++) {
         u64 q = moduli[m];
         if (q >= (1ULL << 50) || (q - 1) % (2ULL * N)) return fail("modulus must be < 2^50 and == 1 mod 2N");
-        ctx->q[m] = q;
-        ctx->psi[m] = psi ? psi[m] : derive_psi(q, logN);
-        if (h_powmod(ctx->psi[m], N, q) != q - 1) return fail("psi is not a primitive 2N-th root of unity");
-        u64 psi_inv = h_invmod(ctx->psi[m], q), p = 1, pi = 1;
+        sh->q[m] = q;
+        sh->psi[m] = psi ? psi[m] : derive_psi(q, logN);
+        if (h_powmod(sh->psi[m], N, q) != q - 1) return fail("psi is not a primitive 2N-th root of unity");
+        u64 psi_inv = h_invmod(sh->psi[m], q), p = 1, pi = 1;
         for (int k = 0; k < N; k++) {
             uint32_t b = h_brev((uint32_t)k, logN);
             twf[(size_t)m * N + b] = (double)p;
             twi[(size_t)m * N + b] = (double)pi;
-            p = h_mulmod(p, ctx->psi[m], q); pi = h_mulmod(pi, psi_inv, q);
+            p = h_mulmod(p, sh->psi[m], q); pi = h_mulmod(pi, psi_inv, q);
         }
-        ModConst &mc = ctx->modc_host[m];
+        ModConst &mc = sh->modc_host[m];
         mc.q = (double)q; mc.qinv = 1.0 / (double)q; mc.qi = q;
         u64 ninv = h_invmod((u64)N, q);
         mc.ninv = (double)ninv; mc.ninv_q = (double)ninv / (double)q;
@@ -63,8 +96,8 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     // late-stage twiddles (t = 8,4,2,1) of group p = j / 16: [T8, T4_0, T4_1, T2_0..3, T1_0..7, pad] laid out as
     // pack[p / 64][i < 8][p % 64] = {entry 2i, entry 2i+1}, so that a wave's 8 loads are 8 contiguous KiB
     auto build_pack = [&](const std::vector<double> &tw, std::vector<double2> &pk) {
-        pk.assign((size_t)ctx->nmod * (N / 2), make_double2(0, 0));
-        for (int m = 0; m < ctx->nmod; m++) {
+        pk.assign((size_t)sh->nmod * (N / 2), make_double2(0, 0));
+        for (int m = 0; m < sh->nmod; m++) {
             const double *t = tw.data() + (size_t)m * N;
             for (int p = 0; p < N / 16; p++) {
                 double e[16]; int k = 0;
@@ -78,15 +111,34 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
         }
     };
     std::vector<double2> pkf, pki; build_pack(twf, pkf); build_pack(twi, pki);
-    if (hipMalloc(&ctx->tw_fwd, twf.size() * sizeof(double)) != hipSuccess || hipMalloc(&ctx->tw_inv, twi.size() * sizeof(double)) != hipSuccess ||
-        hipMalloc(&ctx->pack_fwd, pkf.size() * sizeof(double2)) != hipSuccess || hipMalloc(&ctx->pack_inv, pki.size() * sizeof(double2)) != hipSuccess ||
-        hipMalloc(&ctx->modc, sizeof(ModConst) * SFG_MAXMOD) != hipSuccess) return fail("hipMalloc of tables failed");
-    if (hipMemcpy(ctx->tw_fwd, twf.data(), twf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->tw_inv, twi.data(), twi.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->pack_fwd, pkf.data(), pkf.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->pack_inv, pki.data(), pki.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->modc, ctx->modc_host, sizeof(ModConst) * SFG_MAXMOD, hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
+    if (hipMalloc(&sh->tw_fwd, twf.size() * sizeof(double)) != hipSuccess || hipMalloc(&sh->tw_inv, twi.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc(&sh->pack_fwd, pkf.size() * sizeof(double2)) != hipSuccess || hipMalloc(&sh->pack_inv, pki.size() * sizeof(double2)) != hipSuccess ||
+        hipMalloc(&sh->modc, sizeof(ModConst) * SFG_MAXMOD) != hipSuccess || hipMalloc(&sh->zeros_dev, 256) != hipSuccess) return fail("hipMalloc of tables failed");
+    if (hipMemcpy(sh->tw_fwd, twf.data(), twf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(sh->tw_inv, twi.data(), twi.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(sh->pack_fwd, pkf.data(), pkf.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(sh->pack_inv, pki.data(), pki.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(sh->modc, sh->modc_host, sizeof(ModConst) * SFG_MAXMOD, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(sh->zeros_dev, 0, 256) != hipSuccess) return fail("table upload failed");
+    ctx_bind_shared(ctx, sh);
     if (sfg_encoder_init(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
+    // dynamic-LDS limits are per (function, device): set here for this context's device, not behind process-wide flags
+    if (mac_dma_set_attrs(ctx) || ntt_set_attrs(ctx) || encode_set_attrs(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
+    *out = ctx;
+    return 0;
+}
+
+// A second caller on the same key set: shares the immutable tables and keys, owns its queues / scratch / timers.
+// Forks may run concurrently with each other and with the parent (one host thread per context at a time).  Keys must be
+// loaded before concurrent use begins; destroy forks before (or after) the parent in any order - the shared part is
+// released with the last of them.
+extern "C" int sfg_ctx_fork(sfg_ctx *parent, sfg_ctx **out) {
+    *out = nullptr;
+    sfg_ctx *ctx = new sfg_ctx();
+    ctx->is_fork = true;
+    ctx_bind_shared(ctx, parent->sh);
+    __atomic_add_fetch(&parent->sh->refs, 1, __ATOMIC_ACQ_REL);
+    if (const char *e = ctx_exec_init(ctx)) { parent->err = std::string("sfg_ctx_fork: ") + e; sfg_ctx_destroy(ctx); return 1; }
     *out = ctx;
     return 0;
 }
@@ -96,17 +148,23 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
-    for (auto &kv : ctx->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
+    if (ctx->user_stream) (void)hipStreamSynchronize(ctx->user_stream);
     sfg_phases_resolve(ctx);
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
-    sfg_encoder_destroy(ctx);
-    (void)hipFree(ctx->tw_fwd); (void)hipFree(ctx->tw_inv); (void)hipFree(ctx->pack_fwd); (void)hipFree(ctx->pack_inv); (void)hipFree(ctx->modc); (void)hipFree(ctx->ws); (void)hipFree(ctx->zeros_dev);
+    (void)hipFree(ctx->ws); (void)hipFree(ctx->tie_count_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; i++) if (ctx->ev_pipe[i]) (void)hipEventDestroy(ctx->ev_pipe[i]);
+    SfgShared *sh = ctx->sh;
+    if (sh && __atomic_sub_fetch(&sh->refs, 1, __ATOMIC_ACQ_REL) == 0) {
+        for (auto &kv : sh->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
+        sfg_encoder_destroy(sh);
+        (void)hipFree(sh->tw_fwd); (void)hipFree(sh->tw_inv); (void)hipFree(sh->pack_fwd); (void)hipFree(sh->pack_inv); (void)hipFree(sh->modc); (void)hipFree(sh->zeros_dev);
+        delete sh;
+    }
     delete ctx;
 }
 
@@ -117,21 +175,25 @@ extern "C" int sfg_ctx_synchronize(sfg_ctx *ctx) {
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
-extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) { ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return 0; }
+extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) { ctx->user_stream = (hipStream_t)s; ctx->stream = ctx->main_stream(); return 0; }
+int sfg_sync_all(sfg_ctx *ctx) {
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->user_stream && ctx->user_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->user_stream));
+    if (ctx->own_stream && ctx->own_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+    if (ctx->aux_stream && ctx->aux_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+    return 0;
+}
 
 int sfg_upload_small(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!bytes) return 0;
     const size_t need = (bytes + 255) & ~(size_t)255;
-    static const bool blocking = getenv("SFG_UPLOAD_BLOCKING") != nullptr;       // diagnostic switch
-    if (blocking || need > ctx->pin_bytes / 4) {           // not "small": plain blocking copy, ordered after the stream
+    if (ctx->cfg.upload_blocking || need > ctx->pin_bytes / 4) {           // not "small": plain blocking copy, ordered after the stream
         SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         SFG_HIP(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
         return 0;
     }
     if (ctx->pin_head + need > ctx->pin_bytes) {           // wrap: earlier staged copies must have executed before their slots are reused
-        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->aux_stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
-        if (ctx->own_stream && ctx->own_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+        SFG_TRY(sfg_sync_all(ctx));                        // both queues (and an installed external main stream) may hold staged copies
         ctx->pin_head = 0;
     }
     unsigned char *slot = ctx->pin + ctx->pin_head; ctx->pin_head += need;
@@ -150,7 +212,7 @@ int sfg_stream_after(sfg_ctx *ctx, hipStream_t waiter, hipStream_t signaller) {
 
 int sfg_ws_reserve(sfg_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return 0;
-    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFG_TRY(sfg_sync_all(ctx));
     if (ctx->ws) SFG_HIP(ctx, hipFree(ctx->ws));
     ctx->ws = nullptr; ctx->ws_bytes = 0;
     SFG_HIP(ctx, hipMalloc(&ctx->ws, bytes));
@@ -180,7 +242,7 @@ void sfg_phases_resolve(sfg_ctx *ctx) {
 int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out) {
     auto &e = ctx->pool[name];
     if (e.second < bytes) {
-        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SFG_TRY(sfg_sync_all(ctx));
         if (e.first) SFG_HIP(ctx, hipFree(e.first));
         e.first = nullptr; e.second = 0;
         SFG_HIP(ctx, hipMalloc(&e.first, bytes));
@@ -208,7 +270,7 @@ extern "C" uint64_t sfg_galois_for_rotation(const sfg_ctx *ctx, int k) {
     const u64 M = 2ULL * SFG_N; int n = SFG_SLOTS; k %= n; if (k < 0) k += n;
     u64 g = 1; for (int i = 0; i < k; i++) g = (g * 5) % M; return g;
 }
-extern "C" int sfg_ctx_has_rotkey(const sfg_ctx *ctx, uint64_t g) { return ctx->rotkeys.count(g) ? 1 : 0; }
+extern "C" int sfg_ctx_has_rotkey(const sfg_ctx *ctx, uint64_t g) { return ctx->rotkeys().count(g) ? 1 : 0; }
 
 // lattigo ring.InvMForm: x * 2^-64 mod q, applied when the caller hands keys in Montgomery form
 __global__ void k_from_montgomery(u64 *rows, int nmod, const ModConst *modc, size_t total_rows) {
@@ -231,8 +293,8 @@ extern "C" int sfg_ctx_load_rotkey(sfg_ctx *ctx, uint64_t g, const uint64_t *key
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     const int N = SFG_N; size_t words = (size_t)ctx->beta * 2 * ctx->nmod * N;
     RotKey rk;
-    auto it = ctx->rotkeys.find(g);
-    if (it != ctx->rotkeys.end()) rk = it->second;
+    auto it = ctx->rotkeys().find(g);
+    if (it != ctx->rotkeys().end()) rk = it->second;
     else { SFG_HIP(ctx, hipMalloc(&rk.key_dev, words * 8)); SFG_HIP(ctx, hipMalloc(&rk.index_dev, N * sizeof(uint16_t))); }
     SFG_HIP(ctx, hipMemcpyAsync(rk.key_dev, key_host, words * 8, hipMemcpyHostToDevice, ctx->stream));
     if (mont) {
@@ -244,6 +306,6 @@ extern "C" int sfg_ctx_load_rotkey(sfg_ctx *ctx, uint64_t g, const uint64_t *key
     for (int i = 0; i < N; i++) { u64 t1 = 2ULL * h_brev((uint32_t)i, SFG_LOGN) + 1; u64 t2 = ((g * t1 & mask) - 1) >> 1; idx[i] = (uint16_t)h_brev((uint32_t)t2, SFG_LOGN); }
     SFG_HIP(ctx, hipMemcpyAsync(rk.index_dev, idx.data(), N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->rotkeys[g] = rk;
+    ctx->rotkeys()[g] = rk;
     return 0;
 }

@@ -54,13 +54,12 @@ constexpr int ENC_H = SFG_SLOTS / 2;         // 4096-point complex FFT
 constexpr int ENC_TW = 16384;                // table of zeta^-k, k = 0..16384, zeta = exp(2 pi i / 32768)
 constexpr int ENC_PADN = ENC_H + ENC_H / 8;  // padded index j' = j + (j >> 3)
 
-struct EncTables {
+struct EncTables {                // immutable, shared by a context and its forks
     double4 *zt = nullptr;        // [ENC_TW + 1] {re.hi, re.lo, im.hi, im.lo} of exp(-2 pi i k / 32768)
     uint16_t *tinv = nullptr;     // [n] slot index t with (5^t - 1)/4 mod n == m
-    int8_t *skew = nullptr;       // diag-major scratch for one block: [n][n]
-    double *pc = nullptr;         // half-coefficient scratch [batch][n]: the rounded integers, held as doubles (|p| < 2^53)
-    size_t pc_cap = 0;
 };
+// per-context scratch (sfg_scratch pool): "enc.skew" diag-major copy of one block [n][n] int8;
+// "enc.pc" half-coefficient rows [batch][n]: the rounded integers, held as doubles (|p| < 2^53)
 
 // cos/sin(theta) for small theta by Taylor series in double-double
 static void dd_sincos_small(dd theta, dd &s, dd &c) {
@@ -84,7 +83,7 @@ static void dd_sincos_small(dd theta, dd &s, dd &c) {
 
 int sfg_encoder_init(sfg_ctx *ctx) {
     EncTables *et = new EncTables();
-    ctx->enc_tables = et;
+    ctx->sh->enc_tables = et;
     const int n = SFG_SLOTS; const u64 M = 2ULL * SFG_N;
     // zeta^-1 = exp(-i theta), theta = 2 pi / 32768 = pi * 2^-14 (exact scaling of the dd constant pi)
     dd pi = dd_make(3.141592653589793116e+00, 1.224646799147353207e-16);
@@ -108,11 +107,11 @@ int sfg_encoder_init(sfg_ctx *ctx) {
     SFG_HIP(ctx, hipMemcpy(et->tinv, tinv.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
     return 0;
 }
-void sfg_encoder_destroy(sfg_ctx *ctx) {
-    EncTables *et = (EncTables *)ctx->enc_tables;
+void sfg_encoder_destroy(SfgShared *sh) {
+    EncTables *et = (EncTables *)sh->enc_tables;
     if (!et) return;
-    (void)hipFree(et->zt); (void)hipFree(et->tinv); (void)hipFree(et->skew); (void)hipFree(et->pc);
-    delete et; ctx->enc_tables = nullptr;
+    (void)hipFree(et->zt); (void)hipFree(et->tinv);
+    delete et; sh->enc_tables = nullptr;
 }
 
 // ---------------------------------------------------------------- diagonal-major copy of one block
@@ -384,16 +383,12 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     }
 }
 
-static int enc_scratch(sfg_ctx *ctx, EncTables *et, size_t nplain) {
-    const size_t n = SFG_SLOTS;
-    if (!et->skew) SFG_HIP(ctx, hipMalloc(&et->skew, n * n));
-    if (et->pc_cap < nplain) {
-        SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (et->pc) SFG_HIP(ctx, hipFree(et->pc));
-        et->pc = nullptr; et->pc_cap = 0;
-        SFG_HIP(ctx, hipMalloc(&et->pc, nplain * n * sizeof(double)));
-        et->pc_cap = nplain;
-    }
+static int enc_pc_scratch(sfg_ctx *ctx, size_t nplain, double **pc) {
+    return sfg_scratch(ctx, "enc.pc", nplain * SFG_SLOTS * sizeof(double), (void **)pc);
+}
+int encode_set_attrs(sfg_ctx *ctx) {
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ENC_LDS_BYTES));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ENC_LDS_BYTES));
     return 0;
 }
 
@@ -406,27 +401,22 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
 // half_rows + G > 0: `pt` is the base of a grouped panel and rows are scattered by PanelMap (half rows only)
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g) {
-    EncTables *et = (EncTables *)ctx->enc_tables;
-    static bool attr = false;
+    EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
-    if (!attr) {
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr = true;
-    }
     const int BATCH = 2048;
-    SFG_TRY(enc_scratch(ctx, et, (size_t)(nshift < BATCH ? nshift : BATCH)));
+    double *pc = nullptr;
+    SFG_TRY(enc_pc_scratch(ctx, (size_t)(nshift < BATCH ? nshift : BATCH), &pc));
     for (int s0 = 0; s0 < nshift; s0 += BATCH) {
         const int nb = nshift - s0 < BATCH ? nshift - s0 : BATCH;
         {
             PhaseTimer t(ctx, "encode", false);
             hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->zt, et->tinv,
-                               ctx->scale / (double)SFG_SLOTS, et->pc);
+                               ctx->scale / (double)SFG_SLOTS, pc);
             SFG_HIP(ctx, hipGetLastError());
         }
-        if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0}; SFG_TRY(launch_ntt_plain_half(ctx, et->pc, pt, nb, L, pm)); }
-        else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, et->pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
-        else SFG_TRY(launch_ntt_plain(ctx, et->pc, pt + (size_t)s0 * L * SFG_N, nb, L));
+        if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
+        else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
+        else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));
     }
     return 0;
 }
@@ -437,12 +427,12 @@ extern "C" int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block, size_t ld
     if (r < 1 || c < 1 || r > SFG_SLOTS || c > SFG_SLOTS) SFG_FAIL(ctx, "sfg_encode_diags: block dims out of range");
     if (shift0 < 0 || nshift < 0 || shift0 + nshift > SFG_SLOTS) SFG_FAIL(ctx, "sfg_encode_diags: shift range out of range");
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_encode_diags: L out of range");
-    EncTables *et = (EncTables *)ctx->enc_tables;
-    SFG_TRY(enc_scratch(ctx, et, 1));
-    SFG_TRY(launch_skew(ctx, block, ld, r, c, transposed, 0, et->skew));
+    int8_t *skew = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "enc.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
+    SFG_TRY(launch_skew(ctx, block, ld, r, c, transposed, 0, skew));
     u64 *half = nullptr;
     SFG_TRY(sfg_scratch(ctx, "enc.half", (size_t)nshift * L * (SFG_N / 2) * 8, (void **)&half));
-    SFG_TRY(launch_encode_rows(ctx, et->skew, shift0, nshift, L, half, true));
+    SFG_TRY(launch_encode_rows(ctx, skew, shift0, nshift, L, half, true));
     return launch_expand_half(ctx, half, (u64 *)pt, (size_t)nshift * L);
 }
 
@@ -451,9 +441,8 @@ extern "C" int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block, size_t ld
 extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, int64_t *coeffs_host) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (nvec <= 0) return 0;
-    EncTables *et = (EncTables *)ctx->enc_tables;
+    EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t n = SFG_SLOTS, lds_bytes = ENC_LDS_BYTES;
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     double *dv = nullptr; double *dpc = nullptr;
     SFG_HIP(ctx, hipMalloc(&dv, (size_t)nvec * n * 8));
     if (hipMalloc(&dpc, (size_t)nvec * n * 8) != hipSuccess) { (void)hipFree(dv); SFG_FAIL(ctx, "encode_coeffs: out of device memory"); }
@@ -482,9 +471,8 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (nvec <= 0) return 0;
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "encode_vectors: level out of range");
-    EncTables *et = (EncTables *)ctx->enc_tables;
+    EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t n = SFG_SLOTS, lds_bytes = ENC_LDS_BYTES;
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     void *p = nullptr;
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
     double *dv = (double *)p; double *dpc = dv + (size_t)nvec * n;

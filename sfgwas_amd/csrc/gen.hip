@@ -65,7 +65,7 @@ extern "C" int sfg_fill_rotkeys_synthetic(sfg_ctx *ctx, const int *rot_left, int
     const int N = SFG_N; const size_t rows = (size_t)ctx->beta * 2 * ctx->nmod, words = rows * N;
     for (int k = 0; k < nrot; k++) {
         const u64 g = sfg_galois_for_rotation(ctx, rot_left[k]);
-        if (ctx->rotkeys.count(g)) continue;
+        if (ctx->rotkeys().count(g)) continue;
         RotKey rk;
         SFG_HIP(ctx, hipMalloc(&rk.key_dev, words * 8));
         SFG_HIP(ctx, hipMalloc(&rk.index_dev, N * sizeof(uint16_t)));
@@ -75,7 +75,7 @@ extern "C" int sfg_fill_rotkeys_synthetic(sfg_ctx *ctx, const int *rot_left, int
         for (int i = 0; i < N; i++) { u64 t1 = 2ULL * h_brev((uint32_t)i, SFG_LOGN) + 1; u64 t2 = ((g * t1 & mask) - 1) >> 1; idx[i] = (uint16_t)h_brev((uint32_t)t2, SFG_LOGN); }
         SFG_HIP(ctx, hipMemcpyAsync(rk.index_dev, idx.data(), N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
         SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->rotkeys[g] = rk;
+        ctx->rotkeys()[g] = rk;
     }
     return 0;
 }

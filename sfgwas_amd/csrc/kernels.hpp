@@ -4,7 +4,8 @@
 
 // row r of a batch uses modulus m[r % period] (ciphertext rows, plaintext rows, key-switch rows are all periodic)
 // m < 0 marks a row the kernel must leave untouched
-struct ModPattern { int period; int8_t m[64]; };
+constexpr int SFG_MAXPATTERN = 128;   // >= KSW_MAXDIG * SFG_MAXMOD
+struct ModPattern { int period; int8_t m[SFG_MAXPATTERN]; };
 // row r of a launch lives at base + (r / rpg) * gstride + (r % rpg) * N  (strides in words)
 struct RowMap { int rpg; size_t gstride_in, gstride_out; };
 // where the plaintext of diagonal `shift` (= shift0 + index in the batch) of block row g lands inside a panel that holds G
@@ -36,4 +37,4 @@ int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct
 int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<int> &is_big);
 int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, int L, double *rotf);
 int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
-bool mac_use_dma();
+bool mac_use_dma(const sfg_ctx *ctx);

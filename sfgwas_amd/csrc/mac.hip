@@ -234,18 +234,14 @@ int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, in
 }
 
 // SFG_MAC_IMPL=reg selects the register-staged kernel of this file; default is the LDS-DMA kernel (mac_dma.hip)
-bool mac_use_dma() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SFG_MAC_IMPL"); v = (e && !strcmp(e, "reg")) ? 0 : 1; }
-    return v == 1;
-}
+bool mac_use_dma(const sfg_ctx *ctx) { return !ctx->cfg.mac_reg; }
 
 extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt, uint64_t *out, int K, int R, int Ncols, int L, int accumulate) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac: L out of range");
     PhaseTimer t(ctx, "mac");
     int rc;
-    if (!mac_use_dma()) rc = launch_mac(ctx, (const u64 *)rot, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate);
+    if (!mac_use_dma(ctx)) rc = launch_mac(ctx, (const u64 *)rot, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate);
     else {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;

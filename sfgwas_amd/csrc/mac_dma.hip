@@ -261,7 +261,14 @@ __global__ void __launch_bounds__(256) k_rot_to_f64(const u64 *in, double *out, 
     else o[x] = u64_to_f64(w);
 }
 
-static bool g_dma_attr = false;
+int mac_dma_set_attrs(sfg_ctx *ctx) {
+    constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
+    auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s2));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b2));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s1));
+    return 0;
+}
 
 int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<int> &is_big) {
     plane_of.assign(L, 0); is_big.assign(L, 0); int nplanes = 0;
@@ -297,15 +304,6 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
                    const MacStrides &st) {
     const int N = SFG_N;
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
-    if (!g_dma_attr) {
-        constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
-        auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s2));
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b2));
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s1));
-        g_dma_attr = true;
-    }
-    if (!ctx->zeros_dev) { SFG_HIP(ctx, hipMalloc(&ctx->zeros_dev, 256)); SFG_HIP(ctx, hipMemset(ctx->zeros_dev, 0, 256)); }
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) return 1;
     const size_t rowf = (size_t)nplanes * N;
@@ -313,17 +311,19 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
         int l = 0;
         while (l < L) {
             const bool big = is_big[l]; int e = l; while (e < L && is_big[e] == (int)big) e++;
-            DmaArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev;
+            DmaArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev();
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
             a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
             a.pt_half = st.pt_half ? 1 : 0; a.pt_l_stride = st.pt_half ? N / 2 : N;
-            double maxterm = big ? 16777216.0 * 16777216.0 : 0.0;            // (lo+hi)*(lo+hi) < 2^48
+            // largest single term of a run: small moduli q * 2^12; big ones the Karatsuba middle term (r_lo + r_hi) * (p_lo + p_hi) with
+            // lo < 2^23 and hi = w >> 23 <= q >> 23, i.e. < 2^48 only for q < 2^46 and up to 2.25 * 2^48 for a 47-bit modulus
+            double maxterm = 0.0;
+            for (int t = l; t < e; t++) if (big) { const double hs = 8388608.0 + (double)((ctx->q[t] >> 23) + 1); if (hs * hs > maxterm) maxterm = hs * hs; }
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / DM_KC) * DM_KC;
             if (f < DM_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
-            static const int wc_small = getenv("SFG_MAC_WC") ? atoi(getenv("SFG_MAC_WC")) : 1;       // column waves per workgroup for the small moduli
-            const int wcs = big ? 2 : (wc_small == 2 ? 2 : 1);
+            const int wcs = big ? 2 : ctx->cfg.mac_wc;       // column waves per workgroup for the small moduli
             const int cols_wg = DM_CG * DM_CT * wcs;
             a.flush = f; a.ntile = (Ncols + cols_wg - 1) / cols_wg;
             const int nslab = (st.pt_half ? N / DM_CL / 2 : N / DM_CL) * a.nl, ngrp = (nslab + 7) / 8;

@@ -48,8 +48,8 @@ __global__ void __launch_bounds__(256) k_drop_level(const u64 *in, u64 *out, int
     const size_t x = (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
     out[row * N + x] = in[(ctp * nl_in + m) * N + x];
 }
-// out[i][j][p][l][x] (+)= sum over the listed giants of rot[(giant*s + i)][p][l][x]
-__global__ void __launch_bounds__(256) k_sum_giants(const u64 *rot, const int *giants, int ngiant, int s, int L, u64 *out, size_t out_i_stride,
+// out[i][j][p][l][x] (+)= sum_{k < ngiant} rot[(k*s + i)][p][l][x]   (rot holds only the aligned giants, compactly)
+__global__ void __launch_bounds__(256) k_sum_giants(const u64 *rot, int ngiant, int s, int L, u64 *out, size_t out_i_stride,
                                                     int accumulate, const ModConst *modc) {
     const int N = SFG_N; const size_t row = blockIdx.x / (N / 256);           // row over [i][2][L]
     const int i = (int)(row / (2 * L)), pl = (int)(row % (2 * L)), l = pl % L;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_sum_giants(const u64 *rot, const int *g
     const double q = modc[l].q, qinv = modc[l].qinv;
     double acc = accumulate ? u64_to_f64(out[(size_t)i * out_i_stride + (size_t)pl * N + x]) : 0.0;
     for (int g = 0; g < ngiant; g++) {
-        acc += u64_to_f64(rot[(((size_t)giants[g] * s + i) * 2 * L + pl) * N + x]);
+        acc += u64_to_f64(rot[(((size_t)g * s + i) * 2 * L + pl) * N + x]);
         if ((g & 31) == 31) acc = pred(acc, q, qinv);
     }
     out[(size_t)i * out_i_stride + (size_t)pl * N + x] = f64_to_u64(canon(acc, q, qinv));
@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(256) k_reduce_rows(u64 *rows, int L, const Mod
 __global__ void __launch_bounds__(256) k_colsums(const int8_t *g, size_t nrow, size_t ncol, size_t ld, double *sum, double *sqsum) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= ncol) return;
-    unsigned long long s1 = 0, s2 = 0;
-    for (size_t i = 0; i < nrow; i++) { int v = g[i * ld + j]; v = v < 0 ? 0 : v; s1 += v; s2 += (unsigned)(int8_t)(v * v); }
+    long long s1 = 0, s2 = 0;
+    for (size_t i = 0; i < nrow; i++) { int v = g[i * ld + j]; v = v < 0 ? 0 : v; s1 += v; s2 += (long long)(int8_t)(v * v); }   // Go: float64(int8(x*x)), wraps for |x| >= 12
     if (sum) sum[j] = (double)s1;
     if (sqsum) sqsum[j] = (double)s2;
 }
@@ -163,16 +163,16 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     const size_t ctw = (size_t)2 * nl * N, accw = (size_t)s * 2 * L * N;
     const int ncolb = j1 - j0;
     if (b0 == b1 || j0 == j1) { if (!accumulate) SFG_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ncolb * d * accw * 8, ctx->stream)); return 0; }
-    const bool dma = mac_use_dma();                          // LDS-DMA MAC: half-row plaintexts, fp64 rot operand, block-row groups
+    const bool dma = mac_use_dma(ctx);                          // LDS-DMA MAC: half-row plaintexts, fp64 rot operand, block-row groups
     const size_t prow = dma ? (size_t)N / 2 : (size_t)N;     // words per plaintext modulus row
     // G block rows share one MAC launch (K = G*91): accumulators are written once per group instead of
     // read-modify-written per block.  Bounded by scratch: ~4.9 GB per block row at s = 15.
     int G = 1;
-    if (dma) { const char *e = getenv("SFG_MM_GROUP"); G = e ? atoi(e) : 8; if (G < 1) G = 1; if (G > b1 - b0) G = b1 - b0; }
+    if (dma) { G = ctx->cfg.mm_group; if (G > b1 - b0) G = b1 - b0; }
     const size_t nplain = (size_t)d * d;                     // 8281 >= 8192 slots per block row: the tail stays zero
     u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr; size_t rowf = 0;
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
-    const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !getenv("SFG_MM_NO_OVERLAP");
+    const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
     SFG_TRY(sfg_scratch(ctx, "mm.pt", (size_t)G * nplain * L * prow * 8, (void **)&pt));
@@ -277,26 +277,26 @@ static int matmul_finalize(sfg_ctx *ctx, const u64 *acc, int s, int max_level, i
     const int N = SFG_N, d = SFG_D, L = max_level;
     const size_t accw = (size_t)s * 2 * L * N, ctw = (size_t)2 * L * N;
     if (g0 < 0 || g1 > d || g0 > g1) SFG_FAIL(ctx, "finalize: giant range out of bounds");
-    u64 *rot = nullptr; int *giants_d = nullptr;
+    u64 *rot = nullptr;
     SFG_TRY(sfg_scratch(ctx, "mm.fin_rot", (size_t)d * accw * 8, (void **)&rot));
-    SFG_TRY(sfg_scratch(ctx, "mm.giants", (size_t)ncolb * d * sizeof(int) + 256, (void **)&giants_d));
+    std::vector<int> glist;
+    for (int g = g0; g < g1; g++) if (!giant_active || (*giant_active)[g]) glist.push_back(g);
+    const int ng = (int)glist.size();
+    // only the listed giants are aligned (a rank of a giant-sharded finalize owns ~91/world of them): job (k, i) reads
+    // accumulator ciphertext glist[k]*s + i and lands compactly at k*s + i
+    std::vector<int> nrv((size_t)ng * s), inv((size_t)ng * s);
+    for (int k = 0; k < ng; k++) for (int i = 0; i < s; i++) { nrv[(size_t)k * s + i] = -glist[k] * d; inv[(size_t)k * s + i] = glist[k] * s + i; }
     int rc = 0;
     for (int jb = 0; jb < ncolb && !rc; jb++) {
         const u64 *accj = acc + (size_t)jb * d * accw;
-        std::vector<int> glist;
-        for (int g = g0; g < g1; g++) if (!giant_active || (*giant_active)[g]) glist.push_back(g);
-        {   // one batch over all d*s accumulator ciphertexts of this block column (inactive giants: plain copies of zeros)
-            std::vector<int> nrv((size_t)d * s, 0);
-            for (size_t k = 0; k < glist.size(); k++) for (int i = 0; i < s; i++) nrv[(size_t)glist[k] * s + i] = -glist[k] * d;
-            PhaseTimer t(ctx, "rotate");
-            rc = launch_rotate_right(ctx, accj, rot, d * s, L - 1, nrv.data());
-            t.stop(1);
-        }
-        if (rc) break;
-        int *gd = giants_d + (size_t)jb * d;     // one list per block column: no host sync needed between columns
-        if (sfg_upload_small(ctx, gd, glist.data(), glist.size() * sizeof(int))) { rc = 1; break; }
         u64 *o = out + (size_t)(jout0 + jb) * ctw;
-        hipLaunchKernelGGL(k_sum_giants, dim3((unsigned)((size_t)s * 2 * L * (N / 256))), dim3(256), 0, ctx->stream, rot, gd, (int)glist.size(), s, L,
+        if (ng) {
+            PhaseTimer t(ctx, "rotate");
+            rc = launch_rotate_right_indexed(ctx, accj, d * s, rot, ng * s, L - 1, nrv.data(), inv.data());
+            t.stop(1);
+            if (rc) break;
+        }
+        hipLaunchKernelGGL(k_sum_giants, dim3((unsigned)((size_t)s * 2 * L * (N / 256))), dim3(256), 0, ctx->stream, rot, ng, s, L,
                            o, (size_t)m_ct_out * ctw, accumulate, ctx->modc);
         if (hipGetLastError() != hipSuccess) { rc = 1; ctx->err = "finalize: k_sum_giants launch failed"; }
     }
@@ -341,13 +341,12 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     if (b0 < 0 || b1 > sh.nbr || j0 < 0 || j1 > sh.m_ct || b0 > b1 || j0 > j1) SFG_FAIL(ctx, "matmul: SNP-block range out of bounds");
     const int m_out = j1 - j0;
     // column groups bounded by an accumulator budget (default 24 GiB)
-    size_t budget = 24ULL << 30;
-    if (const char *e = getenv("SFG_MM_ACC_BUDGET_MB")) budget = (size_t)atoll(e) << 20;
+    const size_t budget = ctx->cfg.acc_budget;
     int jg = (int)(budget / ((size_t)d * accw * 8)); if (jg < 1) jg = 1;
     // Several column groups would each rebuild the rotation cache of every block row (91 key switches per input
     // ciphertext).  When the whole cache fits (48 GiB; Q*X at 100k x 1M: 13 block rows = 28 GB) it is built once here.
     const double *rotf_all = nullptr;
-    if (mac_use_dma() && j1 - j0 > jg && b1 > b0) {
+    if (mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         const size_t rowf = (size_t)nplanes * N, per_row = (size_t)d * s * 2 * rowf;       // doubles per block row
@@ -365,7 +364,7 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     }
     // With the product-wide cache the accumulate passes do no key switching, so the giant-step alignment of pass k runs on the
     // auxiliary stream beside the encode + MAC of pass k+1 (two accumulator buffers of half the budget each).
-    const bool overlap = rotf_all && !getenv("SFG_MM_NO_OVERLAP");
+    const bool overlap = rotf_all && !ctx->cfg.no_overlap;
     if (overlap) { jg = (jg + 1) / 2; }
     hipStream_t main_stream = ctx->stream;
     int k = 0;

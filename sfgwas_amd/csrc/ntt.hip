@@ -324,16 +324,14 @@ __global__ void __launch_bounds__(256) k_expand_half(const u64 *half, u64 *full)
     full[row * N + i] = v; full[row * N + (N - 1 - i)] = v;
 }
 
-static int set_lds_attr_once() {
-    static bool done = false;
-    if (done) return 0;
+int ntt_set_attrs(sfg_ctx *ctx) {
     hipError_t e = hipFuncSetAttribute((const void *)k_ntt_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
-    done = (e == hipSuccess);
-    return e == hipSuccess ? 0 : 1;
+    if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
+    return 0;
 }
 
 static RowMap dense_map() { RowMap rm; rm.rpg = 1; rm.gstride_in = SFG_N; rm.gstride_out = SFG_N; return rm; }
@@ -341,14 +339,12 @@ int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const Mo
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) { return launch_ntt_inv_map(ctx, in, out, nrows, pat, dense_map()); }
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
-    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, rm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
 int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, int L) {
     if (!nplain) return 0;
-    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     ModPattern pat; pat.period = L; for (int l = 0; l < L; l++) pat.m[l] = (int8_t)l;
     hipLaunchKernelGGL(k_ntt_fwd<1>, dim3((unsigned)(nplain * L)), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)pc, out, pat, dense_map(), ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
@@ -357,9 +353,7 @@ int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, in
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
 int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm) {
     if (!nplain) return 0;
-    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
-    static const bool full_image = getenv("SFG_NTT_HALF_IMPL") && !strcmp(getenv("SFG_NTT_HALF_IMPL"), "full");      // A/B switch
-    if (full_image) hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    if (ctx->cfg.ntt_half_full) hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)(nplain * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     else hipLaunchKernelGGL(k_ntt_half3, dim3((unsigned)(nplain * L)), dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
@@ -372,7 +366,6 @@ int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows) {
 }
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
-    if (set_lds_attr_once()) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     hipLaunchKernelGGL(k_ntt_inv, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, in, out, pat, rm, ctx->tw_inv, ctx->pack_inv, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;

@@ -63,6 +63,7 @@ static int get_ksw(sfg_ctx *ctx, int level, KswConst **dev, KswConst *host) {
     kc.level = level; kc.nl = level + 1; kc.np = ctx->np; kc.alpha = ctx->np; kc.nt = kc.nl + kc.np;
     kc.beta = (kc.nl + kc.alpha - 1) / kc.alpha;
     if (kc.alpha > KSW_MAXA || kc.beta > KSW_MAXDIG) SFG_FAIL(ctx, "key-switch shape unsupported (alpha > 4 or beta > 8)");
+    if (kc.beta * kc.nt > SFG_MAXPATTERN) SFG_FAIL(ctx, "key-switch shape unsupported (beta * (level + 1 + np) = %d rows exceed the modulus pattern table)", kc.beta * kc.nt);
     for (int t = 0; t < kc.nt; t++) { kc.tmod[t] = t < kc.nl ? t : ctx->nq + (t - kc.nl); kc.digit_of[t] = t < kc.nl ? t / kc.alpha : -1; }
     for (int i = 0; i < kc.beta; i++) {
         std::vector<int> src;
@@ -285,16 +286,16 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
         if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
         if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + (size_t)src * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
         u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);                 // basics.go:205: RotateNew(ct, slots - nrot)
-        auto it = ctx->rotkeys.find(g);
-        if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
+        auto it = ctx->rotkeys().find(g);
+        if (it == ctx->rotkeys().end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
         job_in.push_back(src); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev); outp.push_back(out + j * ctw);
     }
     return launch_keyswitch_jobs(ctx, in, nin, level, job_in, keyp, idxp, outp, nullptr);
 }
 // relinearisation: out[i] = (tmp[i].p0 + d0, mid[i] + d1) with (d0, d1) = key switch of tmp[i].p1 under the key stored at Galois element 1
 int launch_relinearize(sfg_ctx *ctx, const u64 *tmp, int nct, int level, const u64 *mid, u64 *out) {
-    auto it = ctx->rotkeys.find(1);
-    if (it == ctx->rotkeys.end()) SFG_FAIL(ctx, "relinearize: no relinearisation key loaded");
+    auto it = ctx->rotkeys().find(1);
+    if (it == ctx->rotkeys().end()) SFG_FAIL(ctx, "relinearize: no relinearisation key loaded");
     const size_t ctw = (size_t)2 * (level + 1) * SFG_N;
     std::vector<int> job_in(nct); std::vector<const u64 *> keyp(nct, it->second.key_dev); std::vector<const uint16_t *> idxp(nct, it->second.index_dev); std::vector<u64 *> outp(nct);
     for (int j = 0; j < nct; j++) { job_in[j] = j; outp[j] = out + (size_t)j * ctw; }
