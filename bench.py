@@ -8,22 +8,29 @@ on synthetic data, through the C-ABI of libsfgwas_hip.so, one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Sharding (strong scaling, total work fixed): the genotype matrix is split by SNP block (8192 columns of X) across
-ranks.  Q*X is output-sharded (no collective).  Q'*X^T is contraction-sharded: ranks all-reduce the uint64
-accumulators over RCCL BEFORE the giant-step rotations (key switching is not bit-linear), each rank then aligns its
-share of the giant steps and the aligned outputs are all-reduced again (256 MB at 100k x 1M).
+ranks; every rank generates exactly the window of the SAME global matrix it owns, so any world size multiplies the same
+matrix and the output digests in the JSON line are comparable between N = 1 and N > 1.
+  Q*X    : output-sharded, no data-path collective.
+  Q'*X^T : contraction-sharded.  Key switching is not bit-linear, so partial sums are combined BEFORE the giant-step
+           rotations: reduce-scatter of the uint64 accumulators over the giant axis (RCCL), each rank aligns its giant
+           steps, and the aligned partial outputs (256 MB at 100k x 1M) are all-reduced.
+
+Before timing, rank 0 pushes a reduced problem (1 block row x 2 block columns, all 8192 diagonals, s = 2) through the
+CPU oracle and compares every output word with the HIP path ("parity_gate" in the JSON line; --no-check skips it).
 
 Prints ONE JSON line (rank 0).  PyTorch is plumbing here: device tensors, streams and torch.distributed.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CONFIGS = {          # n_ind, m_snp  (BASELINE.md §2)
     "c4": (100_000, 1_000_000),
@@ -31,12 +38,80 @@ CONFIGS = {          # n_ind, m_snp  
     "c2": (10_000, 100_000),
     "tiny": (8_192, 24_576),
 }
-SLOTS, D, N, L, LEVEL, KP = 8192, 91, 16384, 5, 5, 15
+KP = 15                    # num_pcs_to_remove + num_oversampling (pca.go:87)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_VALU_SPEC_FMA_S = 256 * 4 * 16 * 2.4e9          # 3.93e13: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz (78.6 TFLOP/s spec)
+UBENCH_FILE = "profiles/r01_ubench_instruction_rates.txt"      # committed microbenchmark: v_fma_f64 at 16 waves/CU
+UBENCH_FMA_S = 3.217e13
 
 
 def ceil_div(a, b):
     return (a + b - 1) // b
+
+
+def oracle_lib():
+    """the CPU oracle: checker (parity gate) and timed CPU baseline only"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    return ol
+
+
+def parity_gate(ctx, capi, P):
+    """SURVEY §8d 'Parity check during measurement': 8192 x 16384 genotypes (1 block row x 2 block columns, every one of the
+    8192 diagonals of both blocks), s = 2, on the bench context's own (synthetic) keys; every output word vs the oracle."""
+    import numpy as np
+    ol = oracle_lib()
+    t0 = time.perf_counter()
+    ring = ol.Ring(P.LOGN, P.Q_PN14, P.P_PN14)
+    keys = ol.RotKeys(ring)
+    for k in P.rotations_for_matmul():
+        g = ring.galois(k)
+        keys.add(g, ctx.export_rotkey(g))
+    s, nrow, ncol = 2, P.SLOTS, 2 * P.SLOTS
+    gd, gh = ctx.fill_geno(nrow, ncol, 0x6A7E)
+    geno = gd.host()
+    A = ctx.fill_uniform_cts(s, P.MAX_LEVEL, 0x6A7F)
+    out = ctx.matmul_resident(A, s, P.MAX_LEVEL, P.MAX_LEVEL, gh)
+    got = out.host()
+    Ah = A.host().reshape(s, 1, 2, P.MAX_LEVEL + 1, P.N)
+    bad = 0
+    for j in range(2):
+        sub = np.ascontiguousarray(geno[:, j * P.SLOTS:(j + 1) * P.SLOTS])
+        want, _, _ = ol.matmult4stream(ring, keys, P.DEFAULT_SCALE, Ah, P.MAX_LEVEL, P.MAX_LEVEL, sub, enc_prec=1)
+        bad += int(np.count_nonzero(got[:, j] != want[:, 0]))
+    for d in (gd, A, out):
+        d.free()
+    ctx.geno_free(gh)
+    return {"status": "ok" if bad == 0 else "FAILED", "mismatching_words": bad, "words": int(got.size),
+            "problem": f"{nrow} x {ncol} int8 (1 block row x 2 block columns, all 8192 diagonals), s={s}, vs oracle/sfgwas_oracle.c",
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds, L, N, D):
+    """the reference's MAC loop (matmult.go:247-289,380-399) restated in C, built -O3 -march=native ON this host, with the
+    reference's data layout (shared rotCache[i][baby], u128 accCache[i][giant]), all host threads; encode excluded"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle_native.so"))
+    lib.orc_bench_mac_ref_layout.restype = C.c_double
+    lib.orc_bench_mac_ref_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong)]
+    cores = os.cpu_count() or 1
+    n_done = C.c_longlong()
+    rate = lib.orc_bench_mac_ref_layout(KP, L, N, D, cores, float(seconds), C.byref(n_done))
+    return {"value": rate, "unit": "ring-MAC/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "build": "gcc -O3 -march=native -fopenmp (oracle/Makefile: native)",
+            "sample": f"reference MAC loop CPMultAccWithoutMRedV2 (u128 lazy accumulation, s={KP}, L={L}, N={N}) in the reference's layout: shared "
+                      f"rotCache[i][baby] ({KP * D} cts), accCache[i][giant] of one block column, one plaintext per diagonal; {cores} threads x "
+                      f"{seconds:.0f} s = {n_done.value:.3e} MACs; cached-diagonal mode (encode excluded); CPU restatement, not the Go binary"}
 
 
 def main():
@@ -47,14 +122,18 @@ def main():
     ap.add_argument("--config", default=os.environ.get("SFG_BENCH_CONFIG", "c4"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (seconds of wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle parity gate")
+    ap.add_argument("--no-digest", action="store_true", help="skip the SHA-256 digests of the outputs")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from sfgwas_amd import capi
-    import oracle_lib as ol
+    from sfgwas_amd import params as P
+    from sfgwas_amd.sharding import snp_block_range, giant_slots
 
+    SLOTS, D, N, L, LEVEL = P.SLOTS, P.D, P.N, P.MAX_LEVEL, P.MAX_LEVEL
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,12 +153,10 @@ def main():
 
     n_ind, m_snp = CONFIGS[args.config]
     nbr_x, mct_x = ceil_div(n_ind, SLOTS), ceil_div(m_snp, SLOTS)          # block rows / cols of X
-    # SNP-block shard of this rank
-    from sfgwas_amd.sharding import snp_block_range, giant_range
-    blk0, blk1, c0, c1 = snp_block_range(m_snp, rank, world)
+    blk0, blk1, c0, c1 = snp_block_range(m_snp, rank, world)                # SNP-block shard of this rank
     m_loc, nblk_loc = c1 - c0, blk1 - blk0
 
-    ctx = capi.Context(ol.Q_PN14, ol.P_PN14, device=local_rank)
+    ctx = capi.Context(P.Q_PN14, P.P_PN14, device=local_rank)
     lib = capi.lib()
     stream = torch.cuda.current_stream()
     lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream))
@@ -87,23 +164,31 @@ def main():
     def chk(rc, what):
         ctx.check(rc, what)
 
-    # ---- synthetic inputs, generated on the device (seeds: BASELINE.md §2)
+    rots = P.rotations_for_matmul()
+    arr = (C.c_int * len(rots))(*rots)
+    chk(lib.sfg_fill_rotkeys_synthetic(ctx.h, arr, len(rots), 0xBEEF), "fill rotkeys")
+
+    gate = None
+    if rank == 0 and not args.no_check:
+        gate = parity_gate(ctx, capi, P)
+    # ---- synthetic inputs, generated on the device (seeds: BASELINE.md §2); windows of ONE global matrix / ciphertext grid
     geno = torch.empty((n_ind, m_loc), dtype=torch.int8, device=dev)
-    chk(lib.sfg_fill_geno_dev(ctx.h, C.c_void_p(geno.data_ptr()), n_ind, m_loc, 0x5F6A + 131 * rank), "fill_geno")
+    chk(lib.sfg_fill_geno_window_dev(ctx.h, C.c_void_p(geno.data_ptr()), n_ind, m_loc, m_loc, c0, m_snp, 0x5F6A), "fill_geno")
     gh = C.c_void_p()
     chk(lib.sfg_geno_from_device(ctx.h, C.c_void_p(geno.data_ptr()), n_ind, m_loc, m_loc, C.byref(gh)), "geno_from_device")
     ctw = 2 * (LEVEL + 1) * N
-    A1 = torch.empty((KP, nbr_x, ctw), dtype=torch.int64, device=dev)       # Q   : kp x n_ind
+    A1 = torch.empty((KP, nbr_x, ctw), dtype=torch.int64, device=dev)       # Q   : kp x n_ind (replicated)
     A2 = torch.empty((KP, nblk_loc, ctw), dtype=torch.int64, device=dev)    # Q'  : kp x m_snp, this rank's SNP blocks
     chk(lib.sfg_fill_uniform_ct_dev(ctx.h, C.c_void_p(A1.data_ptr()), KP * nbr_x, LEVEL, 0xC1F3), "fill A1")
-    chk(lib.sfg_fill_uniform_ct_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP * nblk_loc, LEVEL, 0xC1F3 + 7919 * (rank + 1)), "fill A2")
-    rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < SLOTS]
-    arr = (C.c_int * len(rots))(*rots)
-    chk(lib.sfg_fill_rotkeys_synthetic(ctx.h, arr, len(rots), 0xBEEF), "fill rotkeys")
+    for i in range(KP):                                                     # ciphertext (i, global block b) has seed base + i*mct_x + b
+        chk(lib.sfg_fill_uniform_ct_dev(ctx.h, C.c_void_p(A2[i].data_ptr()), nblk_loc, LEVEL, 0xD2A7_0000 + i * mct_x + blk0), "fill A2")
     outw = 2 * L * N
     out1 = torch.empty((KP, nblk_loc, outw), dtype=torch.int64, device=dev)
     out2 = torch.empty((KP, nbr_x, outw), dtype=torch.int64, device=dev)
-    acc2 = torch.empty((nbr_x, D, KP, outw), dtype=torch.int64, device=dev)
+    # accumulators [j][giant][i]; + slots so that the last block column's reduce-scatter window (world * gpr giants) stays in bounds
+    gpr, g_lo, g_hi = giant_slots(rank, world)                              # giants per rank (padded), this rank's giant range
+    acc2 = torch.zeros((nbr_x * D + (world * gpr - D)) * KP * outw, dtype=torch.int64, device=dev)
+    acc_mine = torch.empty((nbr_x, gpr, KP, outw), dtype=torch.int64, device=dev) if use_dist else None
     ctx.sync()
 
     phase_tot = {}
@@ -127,14 +212,16 @@ def main():
         chk(lib.sfg_matmul_accumulate_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP, LEVEL, L, gh, capi.SFG_TRANSPOSE,
                                           0, nblk_loc, 0, nbr_x, 0, C.c_void_p(acc2.data_ptr())), "Q'*X^T accumulate")
         if use_dist:
-            for j in range(nbr_x):                                          # one collective per output block column: 1.8 GB each,
-                dist.all_reduce(acc2[j])                                    # element counts stay below 2^31; sums < 8 * 2^46, no overflow
-            chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(acc2.data_ptr()), nbr_x * D * KP * 2, L), "reduce acc")
-        g0, g1 = giant_range(rank, world)
-        chk(lib.sfg_matmul_finalize_dev(ctx.h, C.c_void_p(acc2.data_ptr()), KP, L, nbr_x, g0, g1, 0, C.c_void_p(out2.data_ptr())), "finalize")
-        if use_dist:
-            dist.all_reduce(out2)
+            col = D * KP * outw
+            for j in range(nbr_x):                      # one reduce-scatter per output block column over the (padded) giant axis: sums < 8 * 2^46
+                dist.reduce_scatter_tensor(acc_mine[j].view(-1), acc2[j * col: j * col + world * gpr * KP * outw])
+            chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(acc_mine.data_ptr()), nbr_x * gpr * KP * 2, L), "reduce acc")
+            chk(lib.sfg_matmul_finalize_slots_dev(ctx.h, C.c_void_p(acc_mine.data_ptr()), KP, L, nbr_x, gpr, g_lo, 0, gpr, 0,
+                                                  C.c_void_p(out2.data_ptr())), "finalize")
+            dist.all_reduce(out2)                       # aligned partial outputs of the ranks' giant shards
             chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(out2.data_ptr()), KP * nbr_x * 2, L), "reduce out")
+        else:
+            chk(lib.sfg_matmul_finalize_dev(ctx.h, C.c_void_p(acc2.data_ptr()), KP, L, nbr_x, 0, D, 0, C.c_void_p(out2.data_ptr())), "finalize")
         add_phases()
 
     def barrier():
@@ -156,6 +243,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- output digests, outside the timed region: SHA-256 over the per-ciphertext SHA-256s in global [i][j] order
+    digests = None
+    if not args.no_digest:
+        def ct_hashes(t):                                   # t: [KP][ncols][outw] on the device -> bytes [KP][ncols][32]
+            h = t.cpu().numpy()
+            return np.frombuffer(b"".join(hashlib.sha256(h[i, j].tobytes()).digest() for i in range(h.shape[0]) for j in range(h.shape[1])),
+                                 dtype=np.uint8).reshape(h.shape[0], h.shape[1], 32)
+        mine = ct_hashes(out1)
+        if use_dist and world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, (blk0, mine))
+            parts.sort(key=lambda p: p[0])
+            mine = np.concatenate([p[1] for p in parts], axis=1)
+        if rank == 0:
+            digests = {"out1_sha256": hashlib.sha256(mine.tobytes()).hexdigest(),
+                       "out2_sha256": hashlib.sha256(ct_hashes(out2).tobytes()).hexdigest(),
+                       "of": "SHA-256 over the per-ciphertext SHA-256s in [i][j] order: Q*X (kp x m_ct) and Q'*X^T (kp x nbr); equal for every world size"}
+
     # ---- work accounting: useful ring-MACs = nrow*ncol*s*2 polys*L*(N/slots) per product
     macs_per_product = n_ind * m_snp * KP * 2 * L * (N // SLOTS)
     macs_per_step = 2 * macs_per_product
@@ -170,45 +275,60 @@ def main():
                    "parallelism": f"snp-block x{world}", "power_iter_wall_s": dt / args.steps},
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_mac, small-modulus instance): algorithmic bytes per launch / avg duration
+        if gate is not None:
+            res["parity_gate"] = gate
+        if digests is not None:
+            res["digests"] = digests
+        # ---- roofline of the dominant kernel (k_mac_dma, small-modulus instance)
         ms_small, n_small, by_small = phase_tot.get("mac_small", [0.0, 0, 0.0])
         if n_small:
-            # dominant kernel = k_mac_dma<false> (the four 35/36-bit moduli).  Algorithmic bytes are reported by the library
-            # per launch (fp64 rot operand + half-row plaintexts + accumulators); a launch covers up to 8 block
-            # rows x 1 block column, so bytes and duration are averaged over the launches of the timed region.
+            nl_small = L - 1
             avg_ms = ms_small / n_small
-            per_launch = by_small / n_small
             achieved = by_small / (ms_small * 1e-3) / 1e9
-            traffic = None
-            try:        # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_launch.json")))
-                if pm.get("_config") == args.config:
-                    ks = [k for k in pm if k.startswith("void k_mac_dma<false")]          # the small-modulus instance the default build launches
-                    best = max(ks, key=lambda k: pm[k]["launches"])
-                    traffic = pm[best]["hbm_bytes_per_launch"]
+            padded_macs_s = 2 * nbr_x * mct_x * D * D * 2 * KP * nl_small * N * args.steps / world / (ms_small * 1e-3)   # this rank's share
+            fma_s = 3.0 * padded_macs_s
+            # SURVEY §8d algorithmic bytes of the whole step: int8 genotypes read once per product + ciphertexts in + out
+            alg_step = 2 * n_ind * m_snp + (KP * nbr_x + KP * mct_x) * ctw * 8 + (KP * mct_x + KP * nbr_x) * outw * 8
+            hbm_alg = alg_step * args.steps / dt / 1e9
+            traffic, traffic_src = None, None
+            try:        # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_pmc.sh), committed file
+                for name in ("r02_pmc_traffic_per_launch.json", "r01_pmc_traffic_per_launch.json"):
+                    path = os.path.join(ROOT, "profiles", name)
+                    if not os.path.exists(path):
+                        continue
+                    pm = json.load(open(path))
+                    if pm.get("_config") == args.config:
+                        ks = [k for k in pm if k.startswith("void k_mac_dma<false")]
+                        best = max(ks, key=lambda k: pm[k]["launches"])
+                        traffic, traffic_src = pm[best]["hbm_bytes_per_launch"], f"profiles/{name} (static: separate --pmc passes, not measured in this run)"
+                        break
             except Exception:
                 pass
-            nl_small = L - 1
-            res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_mac_dma<false, 1>", "avg_launch_ms": avg_ms, "launches": n_small,
-                               "alg_bytes_per_launch": per_launch,
-                               "padded_ring_macs_per_s_in_kernel": 2 * ceil_div(n_ind, SLOTS) * ceil_div(m_snp, SLOTS) * D * D * 2 * KP * nl_small * N
-                                                                   * args.steps / (ms_small * 1e-3)}
+            res["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "k_mac_dma<false, 1>", "avg_launch_ms": avg_ms, "launches": n_small,
+                "bytes_kind": "kernel operands: fp64 rotation-cache slab + half-row plaintext panel + accumulator tile, each counted once "
+                              "(DESIGN.md §4); these are intermediates the encode / key-switch kernels wrote, not SURVEY §8(d)'s input/output bytes",
+                "alg_bytes_per_launch": by_small / n_small,
+                "hbm_algorithmic": {"bytes_per_step": alg_step, "achieved_GBps": hbm_alg, "frac": hbm_alg / HBM_PEAK_GBS,
+                                    "what": "SURVEY §8(d): int8 genotypes once per product + ciphertexts in/out, divided by the WHOLE step time"},
+                "alu": {"what": "the roofline that binds (SURVEY §8d): fp64 FMA issue of the dominant kernel; 3 v_fma_f64 per ring-MAC "
+                                "(36-bit modulus: plaintext word split into 3 x 12-bit limbs, products < 2^48 summed exactly)",
+                        "fma_per_mac": 3, "padded_ring_macs_per_s_in_kernel": padded_macs_s, "fma_per_s_in_kernel": fma_s,
+                        "frac_of_spec": fma_s / FP64_VALU_SPEC_FMA_S, "spec_fma_per_s": FP64_VALU_SPEC_FMA_S,
+                        "frac_of_measured_peak": fma_s / UBENCH_FMA_S, "measured_peak_fma_per_s": UBENCH_FMA_S, "measured_peak_source": UBENCH_FILE,
+                        "useful_fma_per_s_whole_step": 3.0 * value / world, "useful_frac_of_spec_whole_step": 3.0 * value / world / FP64_VALU_SPEC_FMA_S}}
         res["phases_ms_per_step"] = {k: v[0] / args.steps for k, v in phase_tot.items()}
-        if not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            n_done = C.c_longlong()
-            rate = ol.lib().orc_bench_mac(KP, L, N, cores, float(args.cpu_seconds), C.byref(n_done))
-            res["cpu_baseline"] = {"value": rate, "unit": "ring-MAC/s", "cores": cores, "kind": "port",
-                                   "sample": f"reference MAC loop (CPMultAccWithoutMRedV2, s={KP}, L={L}, N={N}) restated in C, "
-                                             f"{cores} threads x {args.cpu_seconds:.0f} s = {n_done.value:.3e} MACs; cached-diagonal mode "
-                                             f"(encode excluded); CPU restatement, not the Go binary"}
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L, N, D)
         print(json.dumps(res), flush=True)
     lib.sfg_geno_free(ctx.h, gh)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if gate is not None and gate["status"] != "ok":
+        raise SystemExit("parity gate FAILED: the HIP path differs from the oracle")
 
 
 if __name__ == "__main__":

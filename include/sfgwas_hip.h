@@ -53,6 +53,9 @@ int sfg_ctx_set_stream(sfg_ctx *ctx, void *hip_stream);
  * lattigo's Montgomery representation (they are in lattigo's SwitchingKey) */
 int sfg_ctx_load_rotkey(sfg_ctx *ctx, uint64_t galois_el, const uint64_t *key_host, int montgomery_form);
 int sfg_ctx_has_rotkey(const sfg_ctx *ctx, uint64_t galois_el);
+/* copy a loaded key back to the host in normal (non-Montgomery) form, [beta][2][nq+np][N]: lets a CPU checker (bench.py's parity
+ * gate) or a CPU-only party work with exactly the key material resident on the device */
+int sfg_ctx_export_rotkey(sfg_ctx *ctx, uint64_t galois_el, uint64_t *key_host);
 uint64_t sfg_galois_for_rotation(const sfg_ctx *ctx, int k_left);
 
 /* ---- device memory (so ciphertexts / genotypes stay resident across calls) ---- */
@@ -179,6 +182,11 @@ int sfg_matmul_accumulate_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in
                               int accumulate, uint64_t *acc_dev);
 int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, int max_level, int ncolb,
                             int g0, int g1, int accumulate, uint64_t *out_dev);
+/* finalize for a rank of a giant-sharded run: acc_dev is [ncolb][acc_giants][s][2][max_level][N] and slot g of a block column holds
+ * giant step giant_base + g (what a reduce-scatter over the giant axis leaves on each rank); slots [g0, g1) are aligned, giant steps
+ * >= 91 ignored */
+int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, int max_level, int ncolb, int acc_giants, int giant_base,
+                                  int g0, int g1, int accumulate, uint64_t *out_dev);
 /* after an integer all-reduce(sum) of partial outputs across ranks: canonical reduction mod q_l of [rows][L][N] */
 int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows_dev, size_t nrows_of_L, int L);
 
@@ -201,6 +209,9 @@ int sfg_sketch(sfg_ctx *ctx, const sfg_geno *g, const int32_t *bucket_host, cons
 /* ---- synthetic data generators used by bench.py / tests (counter-mode splitmix64) ---- */
 int sfg_fill_uniform_ct_dev(sfg_ctx *ctx, uint64_t *ct_dev, int nct, int level, uint64_t seed);
 int sfg_fill_geno_dev(sfg_ctx *ctx, int8_t *geno_dev, size_t nrow, size_t ncol, uint64_t seed);
+/* the column window [col0, col0+ncol) of the same global nrow x ncol_global matrix (row stride ld): SNP-sharded ranks hold
+ * exactly the bytes the single-GPU run holds in that window, so outputs are comparable across world sizes */
+int sfg_fill_geno_window_dev(sfg_ctx *ctx, int8_t *geno_dev, size_t nrow, size_t ncol, size_t ld, size_t col0, size_t ncol_global, uint64_t seed);
 int sfg_fill_rotkeys_synthetic(sfg_ctx *ctx, const int *rot_left, int nrot, uint64_t seed);
 
 /* last kernel timing hooks for bench.py: milliseconds spent (HIP events on the ctx stream) in the named phase

@@ -719,10 +719,9 @@ int orc_matmult_accumulate(const orc_ring *r, const orc_rotkeys *keys, double sc
     u64 ***acc = calloc(s, sizeof *acc);              /* accCache[i][giant] -> m_ct*2*L*N {hi,lo} */
     for (int i = 0; i < s; i++) acc[i] = calloc(d, sizeof **acc);
     u64 **rot = calloc((size_t)s * d, sizeof *rot);   /* rotCache[i][baby] */
-    double *diag = malloc(8 * slots), *diagr = malloc(8 * slots);
-    u64 *pt = malloc(8 * (size_t)L * N), *ct_lvl = malloc(8 * ctw);
     uint8_t *baby_t = malloc(d), *giant_t = malloc(d), *shift_t = malloc(slots);
     u64 qinv[ORC_MAXMOD]; for (int l = 0; l < L; l++) qinv[l] = orc_mred_params(r->q[l]);
+    tw_ensure(2ULL * N);                                  /* encoder twiddles: built once, before the parallel regions */
 
     for (int bi = b0; bi < b1 && !rc; bi++) {
         int nr = (int)(((size_t)(bi + 1) * slots < nrow ? (size_t)(bi + 1) * slots : nrow) - (size_t)bi * slots);
@@ -735,43 +734,62 @@ int orc_matmult_accumulate(const orc_ring *r, const orc_rotkeys *keys, double sc
             }
             if (any) { baby_t[shift % d] = 1; giant_t[shift / d] = 1; shift_t[shift] = 1; }
         }
-        /* rotation cache (:1373-1377): rotCache[i][baby] = RotateRight(A[i][bi], -baby) at the dropped level */
-        for (int baby = 0; baby < d && !rc; baby++) if (baby_t[baby]) for (int i = 0; i < s; i++) {
+        /* rotation cache (:1373-1377): rotCache[i][baby] = RotateRight(A[i][bi], -baby) at the dropped level.
+         * The reference builds it with nproc goroutines and private evaluators; here: OpenMP over (baby, i). */
+#pragma omp parallel for collapse(2) schedule(dynamic)
+        for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) {
+            if (!baby_t[baby]) continue;
             const u64 *a_in = A + ((size_t)i * nbr + bi) * ctw_in;
+            u64 *ct_lvl = malloc(8 * ctw);
             for (int p = 0; p < 2; p++) memcpy(ct_lvl + (size_t)p * nl * N, a_in + (size_t)p * nl_in * N, 8 * (size_t)nl * N);
             u64 **slot = &rot[(size_t)i * d + baby];
             if (!*slot) *slot = malloc(8 * ctw);
-            if (orc_rotate_right(r, keys, lev, ct_lvl, -baby, *slot)) { rc = -1; break; }
+            if (orc_rotate_right(r, keys, lev, ct_lvl, -baby, *slot)) {
+#pragma omp atomic write
+                rc = -1;
+            }
+            free(ct_lvl);
         }
         if (rc) break;
         for (int g = 0; g < d; g++) if (giant_t[g]) for (int i = 0; i < s; i++)
             if (!acc[i][g]) acc[i][g] = calloc((size_t)m_ct * outw * 2, 8);             /* :1382-1390 */
-        for (int shift = 0; shift < slots; shift++) if (shift_t[shift]) {               /* :1423-1435 */
-            int baby = shift % d, giant = shift / d;
-            for (int bj = 0; bj < m_ct; bj++) {
-                int nc = (int)(((size_t)(bj + 1) * slots < ncol ? (size_t)(bj + 1) * slots : ncol) - (size_t)bj * slots);
-                const int8_t *X = geno + (size_t)bi * slots * ncol + (size_t)bj * slots;
-                if (!orc_get_diag(diag, X, ncol, nr, nc, slots, -shift)) continue;     /* nil plaintext, skipped at :392 */
-                orc_rot_right(diag, diagr, slots, d * giant);                           /* :723 nrot = d*giant */
-                orc_encode_ntt(r, diagr, scale, L, pt, enc_prec);                       /* level maxLevel has L+1 moduli; only L are used */
-                for (int l = 0; l < L; l++) orc_mform_vec(pt + (size_t)l * N, N, r->q[l]); /* :1428 ToMontgomeryForm */
-                for (int i = 0; i < s; i++) {                                           /* :1430-1434 */
-                    const u64 *rc_ct = rot[(size_t)i * d + baby];
-                    u64 *a = acc[i][giant] + (size_t)bj * outw * 2;
-                    for (int l = 0; l < L; l++) {
-                        orc_mul_coeffs_and_add128(rc_ct + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
-                        orc_mul_coeffs_and_add128(rc_ct + (size_t)(nl + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
+        /* :1395-1438 worker pool.  The reference shards diagonals over goroutines and locks accCacheMux[i][giant]; here every
+         * giant step is owned by one thread (its accumulators are private to it), u128 sums commute, so the bits are the same. */
+#pragma omp parallel
+        {
+            double *diag = malloc(8 * slots), *diagr = malloc(8 * slots);
+            u64 *pt = malloc(8 * (size_t)L * N);
+#pragma omp for schedule(dynamic)
+            for (int giant = 0; giant < d; giant++) for (int baby = 0; baby < d; baby++) {
+                int shift = giant * d + baby;
+                if (shift >= slots || !shift_t[shift]) continue;                        /* :1423-1435 */
+                for (int bj = 0; bj < m_ct; bj++) {
+                    int nc = (int)(((size_t)(bj + 1) * slots < ncol ? (size_t)(bj + 1) * slots : ncol) - (size_t)bj * slots);
+                    const int8_t *X = geno + (size_t)bi * slots * ncol + (size_t)bj * slots;
+                    if (!orc_get_diag(diag, X, ncol, nr, nc, slots, -shift)) continue;     /* nil plaintext, skipped at :392 */
+                    orc_rot_right(diag, diagr, slots, d * giant);                           /* :723 nrot = d*giant */
+                    orc_encode_ntt(r, diagr, scale, L, pt, enc_prec);                       /* level maxLevel has L+1 moduli; only L are used */
+                    for (int l = 0; l < L; l++) orc_mform_vec(pt + (size_t)l * N, N, r->q[l]); /* :1428 ToMontgomeryForm */
+                    for (int i = 0; i < s; i++) {                                           /* :1430-1434 */
+                        const u64 *rc_ct = rot[(size_t)i * d + baby];
+                        u64 *a = acc[i][giant] + (size_t)bj * outw * 2;
+                        for (int l = 0; l < L; l++) {
+                            orc_mul_coeffs_and_add128(rc_ct + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
+                            orc_mul_coeffs_and_add128(rc_ct + (size_t)(nl + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
+                        }
                     }
                 }
             }
+            free(diag); free(diagr); free(pt);
         }
     }
     /* ModularReduceV2 (:343-366): REDC each u128 accumulator, then eval.Reduce -> canonical residues */
     if (!rc) {
         memset(acc_out, 0, 8 * (size_t)m_ct * d * s * outw);
         if (giant_active) memset(giant_active, 0, d);
+        for (int i = 0; i < s; i++) for (int g = 0; g < d; g++) if (acc[i][g] && giant_active) giant_active[g] = 1;
+#pragma omp parallel for collapse(2) schedule(dynamic)
         for (int i = 0; i < s; i++) for (int g = 0; g < d; g++) if (acc[i][g]) {
-            if (giant_active) giant_active[g] = 1;
             for (int bj = 0; bj < m_ct; bj++) {
                 const u64 *a = acc[i][g] + (size_t)bj * outw * 2;
                 u64 *o = acc_out + (((size_t)bj * d + g) * s + i) * outw;
@@ -785,7 +803,7 @@ int orc_matmult_accumulate(const orc_ring *r, const orc_rotkeys *keys, double sc
     }
     for (int i = 0; i < s; i++) { for (int g = 0; g < d; g++) free(acc[i][g]); free(acc[i]); }
     for (size_t k = 0; k < (size_t)s * d; k++) free(rot[k]);
-    free(acc); free(rot); free(diag); free(diagr); free(pt); free(ct_lvl); free(baby_t); free(giant_t); free(shift_t); free(geno);
+    free(acc); free(rot); free(baby_t); free(giant_t); free(shift_t); free(geno);
     return rc;
 }
 
@@ -797,20 +815,39 @@ int orc_matmult_finalize(const orc_ring *r, const orc_rotkeys *keys, int max_lev
     int N = r->N, slots = N / 2, L = max_level, d = (int)ceil(sqrt((double)slots));
     size_t outw = (size_t)2 * L * N; int rc = 0;
     if (!accumulate) memset(out, 0, 8 * (size_t)s * m_ct * outw);
-    u64 *cvr = malloc(8 * outw);
-    for (int i = 0; i < s && !rc; i++) for (int g = g0; g < g1 && !rc; g++) if (!giant_active || giant_active[g]) {
-        for (int bj = 0; bj < m_ct; bj++) {
-            const u64 *cv = acc + (((size_t)bj * d + g) * s + i) * outw;
-            const u64 *src = cv;
-            if (g > 0) { if (orc_rotate_right(r, keys, L - 1, cv, -g * d, cvr)) { rc = -1; break; } src = cvr; } /* :1474-1478 */
-            u64 *o = out + ((size_t)i * m_ct + bj) * outw;
-            for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* eva.Add :1494 */
-                u64 q = r->q[l]; size_t off = ((size_t)p * L + l) * N;
-                for (int x = 0; x < N; x++) { u64 v = o[off + x] + src[off + x]; if (v >= q) v -= q; o[off + x] = v; }
+    /* the reference aligns giant steps with nproc goroutines (:1456-1482) and adds under a per-row lock; here each thread sums
+     * its share of the giants privately and the partial sums are added mod q (commutative): same bits */
+    for (int i = 0; i < s && !rc; i++) for (int bj = 0; bj < m_ct && !rc; bj++) {
+        u64 *o = out + ((size_t)i * m_ct + bj) * outw;
+#pragma omp parallel
+        {
+            u64 *cvr = malloc(8 * outw), *part = calloc(outw, 8);
+#pragma omp for schedule(dynamic)
+            for (int g = g0; g < g1; g++) {
+                if (giant_active && !giant_active[g]) continue;
+                const u64 *cv = acc + (((size_t)bj * d + g) * s + i) * outw;
+                const u64 *src = cv;
+                if (g > 0) {                                                             /* :1474-1478 */
+                    if (orc_rotate_right(r, keys, L - 1, cv, -g * d, cvr)) {
+#pragma omp atomic write
+                        rc = -1;
+                        continue;
+                    }
+                    src = cvr;
+                }
+                for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {               /* eva.Add :1494 */
+                    u64 q = r->q[l]; size_t off = ((size_t)p * L + l) * N;
+                    for (int x = 0; x < N; x++) { u64 v = part[off + x] + src[off + x]; if (v >= q) v -= q; part[off + x] = v; }
+                }
             }
+#pragma omp critical(orc_fin)
+            for (int p = 0; p < 2; p++) for (int l = 0; l < L; l++) {
+                u64 q = r->q[l]; size_t off = ((size_t)p * L + l) * N;
+                for (int x = 0; x < N; x++) { u64 v = o[off + x] + part[off + x]; if (v >= q) v -= q; o[off + x] = v; }
+            }
+            free(cvr); free(part);
         }
     }
-    free(cvr);
     return rc;
 }
 
@@ -964,6 +1001,58 @@ double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long lon
 #pragma omp master
         t_end = omp_get_wtime();
     }
+    if (macs_done) *macs_done = total;
+    return (double)total / (t_end - t_begin);
+}
+
+/* cpu_baseline with the REFERENCE's data layout (matmult.go:1065-1068,1121-1129,1154-1168): one shared rotCache[i][baby]
+ * (s*d ciphertexts), lazily reduced u128 accumulators accCache[i][giant] for ONE output block column (m_ct = 1), one plaintext per
+ * diagonal, workers that take whole diagonals.  A giant step is owned by one thread (the reference locks accCacheMux[i][giant]
+ * instead; ownership costs no lock traffic, so this flatters the CPU slightly).  Encode is excluded (cached-diagonal mode,
+ * MatMult4StreamCompute): the plaintext words are random.  Returns u128 MACs per second over all threads. */
+double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double seconds, long long *macs_done) {
+    size_t ctw = (size_t)2 * (L + 1) * N, accw = (size_t)2 * L * N * 2;
+    u64 **rot = malloc(sizeof(u64 *) * (size_t)s * d), **acc = malloc(sizeof(u64 *) * (size_t)s * d);
+    for (size_t k = 0; k < (size_t)s * d; k++) { rot[k] = malloc(ctw * 8); acc[k] = NULL; }
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int k = 0; k < s * d; k++) {
+        u64 st = 0x9876 + 131 * (u64)k;
+        for (size_t x = 0; x < ctw; x++) rot[k][x] = orc_splitmix64(&st) >> 18;
+        acc[k] = calloc(accw, 8);
+    }
+    long long total = 0; int stop = 0;
+    double t_begin = omp_get_wtime(), t_end;
+#pragma omp parallel num_threads(nthreads) reduction(+ : total)
+    {
+        u64 *pt = malloc((size_t)(L + 1) * N * 8);
+        u64 st = 0x1234 + 77 * (u64)omp_get_thread_num();
+        for (size_t x = 0; x < (size_t)(L + 1) * N; x++) pt[x] = orc_splitmix64(&st) >> 18;
+        long long mine = 0;
+        while (!stop) {
+#pragma omp for schedule(dynamic) nowait
+            for (int giant = 0; giant < d; giant++) {
+                for (int baby = 0; baby < d && !stop; baby++) {
+                    for (int i = 0; i < s; i++) {                       /* CPMultAccWithoutMRedV2(rotCache[i][baby], plainVec, accCache[i][giant]) */
+                        const u64 *rc = rot[(size_t)i * d + baby]; u64 *a = acc[(size_t)i * d + giant];
+                        for (int l = 0; l < L; l++) {
+                            orc_mul_coeffs_and_add128(rc + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
+                            orc_mul_coeffs_and_add128(rc + (size_t)(L + 1 + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
+                        }
+                    }
+                    mine += (long long)s * 2 * L * N;
+                    if (omp_get_wtime() - t_begin >= seconds) {
+#pragma omp atomic write
+                        stop = 1;
+                    }
+                }
+            }
+        }
+        total += mine;
+        free(pt);
+    }
+    t_end = omp_get_wtime();
+    for (size_t k = 0; k < (size_t)s * d; k++) { free(rot[k]); free(acc[k]); }
+    free(rot); free(acc);
     if (macs_done) *macs_done = total;
     return (double)total / (t_end - t_begin);
 }

@@ -139,6 +139,10 @@ void orc_cpmult_acc_v2(const uint64_t *rot, const uint64_t *pt_mont, uint64_t *a
 /* cpu_baseline leg of bench.py: the reference's MAC loop on nthreads host threads for ~seconds; returns MAC/s */
 double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long long *macs_done);
 
+/* the same MAC loop on the reference's data layout: shared rotCache[i][baby], u128 accCache[i][giant] of one block column,
+ * workers taking whole diagonals (matmult.go:1065-1068,1121-1168) */
+double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double seconds, long long *macs_done);
+
 /* ---- DiagCache file format (gwas/filestream.go:19-282) ---- */
 /* payload byte order for coefficients: big-endian u64 (lattigo ring.WriteCoeffsTo, unverified — see header) */
 typedef struct orc_diagcache orc_diagcache;

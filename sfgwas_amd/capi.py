@@ -32,6 +32,7 @@ def _sig(L):
         "sfg_ctx_set_stream": (i, [vp, vp]),
         "sfg_ctx_load_rotkey": (i, [vp, u64, u64p, i]),
         "sfg_ctx_has_rotkey": (i, [vp, u64]),
+        "sfg_ctx_export_rotkey": (i, [vp, u64, u64p]),
         "sfg_galois_for_rotation": (u64, [vp, i]),
         "sfg_malloc": (i, [vp, C.POINTER(vp), sz]),
         "sfg_free": (i, [vp, vp]),
@@ -68,6 +69,7 @@ def _sig(L):
         "sfg_matmul_resident_range_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, vp]),
         "sfg_matmul_accumulate_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, i, i, i, vp]),
         "sfg_matmul_finalize_dev": (i, [vp, vp, i, i, i, i, i, i, vp]),
+        "sfg_matmul_finalize_slots_dev": (i, [vp, vp, i, i, i, i, i, i, i, i, vp]),
         "sfg_reduce_rows_dev": (i, [vp, vp, sz, i]),
         "sfg_beaver_elem_dev": (i, [vp, i, i, u64p, vp, vp, vp, vp, vp, sz]),
         "sfg_beaver_elem": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, sz]),
@@ -75,6 +77,7 @@ def _sig(L):
         "sfg_sketch": (i, [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int8), i, C.POINTER(d), u64p, u64p]),
         "sfg_fill_uniform_ct_dev": (i, [vp, vp, i, i, u64]),
         "sfg_fill_geno_dev": (i, [vp, vp, sz, sz, u64]),
+        "sfg_fill_geno_window_dev": (i, [vp, vp, sz, sz, sz, sz, sz, u64]),
         "sfg_fill_rotkeys_synthetic": (i, [vp, C.POINTER(i), i, u64]),
         "sfg_ctx_clear_phases": (i, [vp]),
         "sfg_last_phase_ms": (d, [vp, C.c_char_p]),
@@ -177,6 +180,20 @@ class Context:
     def load_rotkey(self, galois, key, montgomery=False):
         key = np.ascontiguousarray(key, dtype=np.uint64)
         self.check(lib().sfg_ctx_load_rotkey(self.h, int(galois), p64(key), int(montgomery)), "load_rotkey")
+
+    def export_rotkey(self, galois):
+        key = np.zeros((self.beta, 2, self.nq + self.np_, self.N), dtype=np.uint64)
+        self.check(lib().sfg_ctx_export_rotkey(self.h, int(galois), p64(key)), "export_rotkey")
+        return key
+
+    def fork(self):
+        """a second caller on the same tables and keys (sfg_ctx_fork): own queues, scratch and timers"""
+        h = C.c_void_p()
+        self.check(lib().sfg_ctx_fork(self.h, C.byref(h)), "sfg_ctx_fork")
+        child = Context.__new__(Context)
+        child.__dict__.update({k: v for k, v in self.__dict__.items()})
+        child.h = h
+        return child
 
     def galois(self, k):
         return lib().sfg_galois_for_rotation(self.h, k)
@@ -350,3 +367,107 @@ def _ctx_encode_vectors(self, values, level):
 
 
 Context.encode_vectors = _ctx_encode_vectors
+
+
+# ---- resident products (device-level plumbing for the tests and bench.py)
+class DevArray:
+    """a device buffer with a numpy-like shape (uint64 words unless dtype says otherwise); freed with .free()"""
+
+    def __init__(self, ctx, shape, dtype=np.uint64):
+        self.ctx, self.shape, self.dtype = ctx, tuple(int(x) for x in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.p = ctx.malloc(max(self.nbytes, 8))
+
+    @classmethod
+    def from_host(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        d = cls(ctx, arr.shape, arr.dtype)
+        ctx.check(lib().sfg_memcpy_h2d(ctx.h, d.p, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+        return d
+
+    def host(self):
+        return self.ctx.to_host(self.p, self.shape, self.dtype)
+
+    def host_slice(self, index):
+        """download self[index] for a leading-axis integer index (or tuple of leading indices)"""
+        index = index if isinstance(index, tuple) else (index,)
+        sub = self.shape[len(index):]
+        off = 0
+        for k, i in enumerate(index):
+            off += int(i) * int(np.prod(self.shape[k + 1:]))
+        out = np.empty(sub, dtype=self.dtype)
+        src = C.c_void_p(self.p.value + off * self.dtype.itemsize)
+        self.ctx.check(lib().sfg_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), src, out.nbytes), "d2h")
+        return out
+
+    def free(self):
+        if self.p is not None:
+            self.ctx.free(self.p)
+            self.p = None
+
+
+def _ctx_geno_upload(self, geno):
+    geno = np.ascontiguousarray(geno, dtype=np.int8)
+    g = C.c_void_p()
+    self.check(lib().sfg_geno_upload(self.h, geno.ctypes.data_as(C.c_void_p), geno.shape[0], geno.shape[1], geno.shape[1], C.byref(g)), "geno_upload")
+    return g
+
+
+def _ctx_geno_free(self, g):
+    lib().sfg_geno_free(self.h, g)
+
+
+def _ctx_fill_uniform_cts(self, nct, level, seed):
+    d = DevArray(self, (nct, 2, level + 1, self.N))
+    self.check(lib().sfg_fill_uniform_ct_dev(self.h, d.p, nct, level, seed), "fill_uniform_ct")
+    return d
+
+
+def _ctx_fill_geno(self, nrow, ncol, seed):
+    d = DevArray(self, (nrow, ncol), np.int8)
+    self.check(lib().sfg_fill_geno_dev(self.h, d.p, nrow, ncol, seed), "fill_geno")
+    g = C.c_void_p()
+    self.check(lib().sfg_geno_from_device(self.h, d.p, nrow, ncol, ncol, C.byref(g)), "geno_from_device")
+    return d, g
+
+
+def _ctx_matmul_resident(self, A_dev, s, in_level, max_level, g, flags=0, blk=None):
+    """A_dev: DevArray [s][nbr][2][in_level+1][N]; returns DevArray out [s][m_out][2][max_level][N]"""
+    nr, nc = C.c_size_t(), C.c_size_t()
+    lib().sfg_geno_dims(g, C.byref(nr), C.byref(nc))
+    lcol = nr.value if flags & SFG_TRANSPOSE else nc.value
+    m_ct = (lcol - 1) // self.slots + 1
+    if blk is None:
+        out = DevArray(self, (s, m_ct, 2, max_level, self.N))
+        self.check(lib().sfg_matmul_resident_dev(self.h, A_dev.p, s, in_level, max_level, g, flags, out.p), "matmul_resident")
+    else:
+        m_out = m_ct if flags & SFG_TRANSPOSE else blk[1] - blk[0]
+        out = DevArray(self, (s, m_out, 2, max_level, self.N))
+        self.check(lib().sfg_matmul_resident_range_dev(self.h, A_dev.p, s, in_level, max_level, g, flags, blk[0], blk[1], out.p), "matmul_resident_range")
+    return out
+
+
+def _ctx_matmul_accumulate(self, A_dev, s, in_level, max_level, g, flags, b0, b1, j0, j1, acc=None):
+    d = 91
+    accumulate = acc is not None
+    if acc is None:
+        acc = DevArray(self, (j1 - j0, d, s, 2, max_level, self.N))
+    self.check(lib().sfg_matmul_accumulate_dev(self.h, A_dev.p, s, in_level, max_level, g, flags, b0, b1, j0, j1, int(accumulate), acc.p), "matmul_accumulate")
+    return acc
+
+
+def _ctx_matmul_finalize(self, acc, s, max_level, ncolb, g0, g1, out=None):
+    accumulate = out is not None
+    if out is None:
+        out = DevArray(self, (s, ncolb, 2, max_level, self.N))
+    self.check(lib().sfg_matmul_finalize_dev(self.h, acc.p, s, max_level, ncolb, g0, g1, int(accumulate), out.p), "matmul_finalize")
+    return out
+
+
+Context.geno_upload = _ctx_geno_upload
+Context.geno_free = _ctx_geno_free
+Context.fill_uniform_cts = _ctx_fill_uniform_cts
+Context.fill_geno = _ctx_fill_geno
+Context.matmul_resident = _ctx_matmul_resident
+Context.matmul_accumulate = _ctx_matmul_accumulate
+Context.matmul_finalize = _ctx_matmul_finalize

@@ -272,6 +272,16 @@ extern "C" uint64_t sfg_galois_for_rotation(const sfg_ctx *ctx, int k) {
 }
 extern "C" int sfg_ctx_has_rotkey(const sfg_ctx *ctx, uint64_t g) { return ctx->rotkeys().count(g) ? 1 : 0; }
 
+extern "C" int sfg_ctx_export_rotkey(sfg_ctx *ctx, uint64_t g, uint64_t *key_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    auto it = ctx->rotkeys().find(g);
+    if (it == ctx->rotkeys().end()) SFG_FAIL(ctx, "export_rotkey: no key loaded for galois element %llu", (unsigned long long)g);
+    const size_t words = (size_t)ctx->beta * 2 * ctx->nmod * SFG_N;
+    SFG_HIP(ctx, hipMemcpyAsync(key_host, it->second.key_dev, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // lattigo ring.InvMForm: x * 2^-64 mod q, applied when the caller hands keys in Montgomery form
 __global__ void k_from_montgomery(u64 *rows, int nmod, const ModConst *modc, size_t total_rows) {
     size_t row = blockIdx.y; int m = (int)(row % nmod); u64 q = modc[m].qi;

@@ -31,26 +31,33 @@ __device__ __host__ static inline unsigned geno_pj24(u64 h) {            // p_j 
     const unsigned lo = 838861u, span = 7549747u;                         // 0.05 * 2^24, 0.45 * 2^24
     return lo + (unsigned)(((h >> 40) * (u64)span) >> 24);
 }
-__global__ void __launch_bounds__(256) k_fill_geno(int8_t *g, size_t row0, size_t ncol, u64 seed) {
+// element (i, jg) of the GLOBAL nrow x ncol_global matrix, written for the column window [col0, col0 + ncol) at g[i*ld + (jg - col0)]:
+// a rank that owns a SNP-column window of X holds exactly the bytes the single-GPU run holds there
+__global__ void __launch_bounds__(256) k_fill_geno(int8_t *g, size_t row0, size_t ncol, size_t ld, size_t col0, size_t ncol_global, u64 seed) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x, i = row0 + blockIdx.y;
     if (j >= ncol) return;
-    const unsigned pj = geno_pj24(splitmix_at(seed ^ 0xC01C01ULL, j));
-    const u64 h = splitmix_at(seed, i * ncol + j);
+    const size_t jg = col0 + j;
+    const unsigned pj = geno_pj24(splitmix_at(seed ^ 0xC01C01ULL, jg));
+    const u64 h = splitmix_at(seed, i * ncol_global + jg);
     const unsigned u0 = (unsigned)(h & 0xFFFFFF), u1 = (unsigned)((h >> 24) & 0xFFFFFF), um = (unsigned)(h >> 57);
     int8_t v = (int8_t)((u0 < pj) + (u1 < pj));
     if (um == 0) v = -1;
-    g[i * ncol + j] = v;
+    g[i * ld + j] = v;
 }
-extern "C" int sfg_fill_geno_dev(sfg_ctx *ctx, int8_t *geno, size_t nrow, size_t ncol, uint64_t seed) {
+extern "C" int sfg_fill_geno_window_dev(sfg_ctx *ctx, int8_t *geno, size_t nrow, size_t ncol, size_t ld, size_t col0, size_t ncol_global, uint64_t seed) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (!nrow || !ncol) return 0;
     if (nrow > 2147483647ULL) SFG_FAIL(ctx, "sfg_fill_geno: too many rows");
+    if (ld < ncol || col0 + ncol > ncol_global) SFG_FAIL(ctx, "sfg_fill_geno: bad column window");
     for (size_t r0 = 0; r0 < nrow; r0 += 65535) {          // grid.y is limited to 65535: row bands
         const size_t nr = nrow - r0 < 65535 ? nrow - r0 : 65535;
-        hipLaunchKernelGGL(k_fill_geno, dim3((unsigned)((ncol + 255) / 256), (unsigned)nr), dim3(256), 0, ctx->stream, geno, r0, ncol, (u64)seed);
+        hipLaunchKernelGGL(k_fill_geno, dim3((unsigned)((ncol + 255) / 256), (unsigned)nr), dim3(256), 0, ctx->stream, geno, r0, ncol, ld, col0, ncol_global, (u64)seed);
         SFG_HIP(ctx, hipGetLastError());
     }
     return 0;
+}
+extern "C" int sfg_fill_geno_dev(sfg_ctx *ctx, int8_t *geno, size_t nrow, size_t ncol, uint64_t seed) {
+    return sfg_fill_geno_window_dev(ctx, geno, nrow, ncol, ncol, 0, ncol, seed);
 }
 
 // rotation keys with uniform random words (timing-equivalent to real keys)

@@ -272,27 +272,28 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
 
 // ---------------------------------------------------------------- phase 2: finalize
 // out[i][j][2][L][N] (+)= sum_{giant in [g0,g1)} RotateRight(acc[j][giant][i], -giant*d)   (matmult.go:1443-1502)
+// acc: [ncolb][acc_giants][s][2][L][N]; slot g of a block column holds giant step giant_base + g
 static int matmul_finalize(sfg_ctx *ctx, const u64 *acc, int s, int max_level, int ncolb, int m_ct_out, int jout0, int g0, int g1,
-                           const std::vector<uint8_t> *giant_active, int accumulate, u64 *out) {
+                           const std::vector<uint8_t> *giant_active, int accumulate, u64 *out, int acc_giants = SFG_D, int giant_base = 0) {
     const int N = SFG_N, d = SFG_D, L = max_level;
     const size_t accw = (size_t)s * 2 * L * N, ctw = (size_t)2 * L * N;
-    if (g0 < 0 || g1 > d || g0 > g1) SFG_FAIL(ctx, "finalize: giant range out of bounds");
+    if (g0 < 0 || g1 > acc_giants || g0 > g1 || giant_base < 0) SFG_FAIL(ctx, "finalize: giant range out of bounds");
     u64 *rot = nullptr;
     SFG_TRY(sfg_scratch(ctx, "mm.fin_rot", (size_t)d * accw * 8, (void **)&rot));
     std::vector<int> glist;
-    for (int g = g0; g < g1; g++) if (!giant_active || (*giant_active)[g]) glist.push_back(g);
+    for (int g = g0; g < g1; g++) if (giant_base + g < d && (!giant_active || (*giant_active)[giant_base + g])) glist.push_back(g);
     const int ng = (int)glist.size();
     // only the listed giants are aligned (a rank of a giant-sharded finalize owns ~91/world of them): job (k, i) reads
     // accumulator ciphertext glist[k]*s + i and lands compactly at k*s + i
     std::vector<int> nrv((size_t)ng * s), inv((size_t)ng * s);
-    for (int k = 0; k < ng; k++) for (int i = 0; i < s; i++) { nrv[(size_t)k * s + i] = -glist[k] * d; inv[(size_t)k * s + i] = glist[k] * s + i; }
+    for (int k = 0; k < ng; k++) for (int i = 0; i < s; i++) { nrv[(size_t)k * s + i] = -(giant_base + glist[k]) * d; inv[(size_t)k * s + i] = glist[k] * s + i; }
     int rc = 0;
     for (int jb = 0; jb < ncolb && !rc; jb++) {
-        const u64 *accj = acc + (size_t)jb * d * accw;
+        const u64 *accj = acc + (size_t)jb * acc_giants * accw;
         u64 *o = out + (size_t)(jout0 + jb) * ctw;
         if (ng) {
             PhaseTimer t(ctx, "rotate");
-            rc = launch_rotate_right_indexed(ctx, accj, d * s, rot, ng * s, L - 1, nrv.data(), inv.data());
+            rc = launch_rotate_right_indexed(ctx, accj, acc_giants * s, rot, ng * s, L - 1, nrv.data(), inv.data());
             t.stop(1);
             if (rc) break;
         }
@@ -325,6 +326,15 @@ extern "C" int sfg_matmul_accumulate_dev(sfg_ctx *ctx, const uint64_t *A, int s,
 extern "C" int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc, int s, int max_level, int ncolb, int g0, int g1, int accumulate, uint64_t *out) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     return matmul_finalize(ctx, (const u64 *)acc, s, max_level, ncolb, ncolb, 0, g0, g1, nullptr, accumulate, (u64 *)out);
+}
+
+// the same with the accumulator slots of a giant-sharded rank: acc [ncolb][acc_giants][s][2][L][N] where slot g holds giant step
+// giant_base + g (what a reduce-scatter over giant steps leaves on each rank); slots whose giant step is >= 91 are ignored
+extern "C" int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc, int s, int max_level, int ncolb, int acc_giants, int giant_base,
+                                             int g0, int g1, int accumulate, uint64_t *out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (acc_giants < 1) SFG_FAIL(ctx, "finalize: acc_giants must be positive");
+    return matmul_finalize(ctx, (const u64 *)acc, s, max_level, ncolb, ncolb, 0, g0, g1, nullptr, accumulate, (u64 *)out, acc_giants, giant_base);
 }
 
 // SNP-block range [blk0, blk1) over the block columns of the STORED matrix: output columns for X, contraction rows for X^T

@@ -98,6 +98,8 @@ def lib():
         L.orc_gen_rlk.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_uint64, u64p]
         L.orc_bench_mac.restype = C.c_double
         L.orc_bench_mac.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong)]
+        L.orc_bench_mac_ref_layout.restype = C.c_double
+        L.orc_bench_mac_ref_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong)]
         L.orc_diagcache_create.restype = C.c_void_p
         L.orc_diagcache_create.argtypes = [C.c_char_p, C.c_int]
         L.orc_diagcache_set_tables.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
@@ -131,12 +133,8 @@ def pi8(a):
     return a.ctypes.data_as(C.POINTER(C.c_int8))
 
 
-# PN14QP438-shaped modulus chain: q0 is the 46-bit prime the preset is known to start with; the other
-# primes are NTT-friendly primes (== 1 mod 2^15) of the preset's sizes (the exact values are taken from
-# the host at run time in the real integration).
-Q_PN14 = [0x200000440001, 0x7fff80001, 0x800280001, 0x7ffd80001, 0x7ffc80001,
-          0x7ff9c0001, 0x800008001, 0x7fffb0001, 0x8000f8001, 0x800250001]
-P_PN14 = [0x80000050001, 0x7fffffd8001]
+# PN14QP438-shaped modulus chain: defined once, in the product package (sfgwas_amd/params.py)
+from sfgwas_amd.params import Q_PN14, P_PN14  # noqa: E402,F401
 
 
 def small_primes(logN, bits, count, skip=0):

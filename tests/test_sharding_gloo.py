@@ -1,9 +1,11 @@
 """World-size-2 (gloo, CPU) check of the multi-GPU contract bench.py implements over RCCL:
   * SNP-block ranges partition the matrix;
   * Q*X     : concatenating the ranks' output block columns gives the unsharded product;
-  * Q'*X^T  : summing the ranks' canonical accumulators (all-reduce, then mod q) BEFORE the giant-step rotations,
-              then letting each rank align its share of the giant steps and all-reducing again, gives the unsharded
-              product bit for bit — whereas summing rotated partial outputs does not (key switching is not bit-linear).
+  * Q'*X^T  : summing the ranks' canonical accumulators (reduce-scatter over the padded giant axis, then mod q) BEFORE the
+              giant-step rotations, then letting each rank align its giant steps and all-reducing the aligned partial
+              outputs, gives the unsharded product bit for bit — whereas summing rotated partial outputs does not (key
+              switching is not bit-linear).  The window arithmetic is bench.py's; gloo has no reduce-scatter, so the
+              collective is emulated by all-reduce + slice (same sums).
 Runs the oracle at a small ring (N = 32) so that 2 processes finish in seconds."""
 import os
 import sys
@@ -16,7 +18,7 @@ import torch.multiprocessing as mp
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from sfgwas_amd.sharding import snp_block_range, giant_range, ceil_div  # noqa: E402
+from sfgwas_amd.sharding import snp_block_range, giant_range, giant_slots, ceil_div  # noqa: E402
 
 
 def test_snp_block_ranges_partition():
@@ -32,6 +34,11 @@ def test_snp_block_ranges_partition():
     for world in [1, 2, 4, 8]:
         g = [giant_range(r, world) for r in range(world)]
         assert g[0][0] == 0 and g[-1][1] == 91 and all(g[i][1] == g[i + 1][0] for i in range(world - 1))
+    for world in [1, 2, 3, 4, 8]:
+        sl = [giant_slots(r, world) for r in range(world)]
+        assert all(x[0] == sl[0][0] for x in sl) and sl[0][0] * world >= 91
+        owned = [gi for (gpr, lo, hi) in sl for gi in range(lo, hi)]
+        assert owned == list(range(91))
 
 
 def _worker(rank, world, port, q):
@@ -80,14 +87,26 @@ def _worker(rank, world, port, q):
     wrong_sum = tw.numpy().view(np.uint64)
     for l in range(L):
         wrong_sum[:, :, :, l, :] %= np.uint64(qs[l])
-    # the bit-exact way: all-reduce accumulators, reduce mod q, finalize a share of the giants, all-reduce outputs
-    ta = torch.from_numpy(acc.view(np.int64))
-    dist.all_reduce(ta)
+    # the bit-exact way (bench.py's scheme): per output block column, reduce-scatter the accumulators over the giant axis padded
+    # to world * gpr slots (the window of the last real column runs into zero padding, the others into the next column: those
+    # slots are ignored), reduce mod q, align this rank's giants, all-reduce the aligned partial outputs
+    gpr, g_lo, g_hi = giant_slots(rank, world, d)
+    kw = s * 2 * L * ring.N                               # words per giant slot of one block column
+    col = d * kw
+    flat = np.zeros(m_ct * col + (world * gpr - d) * kw, dtype=np.uint64)
+    flat[:m_ct * col] = acc.reshape(-1)
+    mine = np.zeros((m_ct, d, s, 2, L, ring.N), dtype=np.uint64)     # this rank's slots, placed at their giant index
+    for j in range(m_ct):
+        win = torch.from_numpy(flat[j * col: j * col + world * gpr * kw].view(np.int64).copy())
+        dist.all_reduce(win)                                # gloo stand-in for reduce_scatter_tensor: same sums, then take my chunk
+        chunk = win.numpy().view(np.uint64)[rank * gpr * kw:(rank + 1) * gpr * kw].reshape(gpr, s, 2, L, ring.N)
+        for gslot in range(gpr):
+            if g_lo + gslot < d:
+                mine[j, g_lo + gslot] = chunk[gslot]
     for l in range(L):
-        acc[:, :, :, :, l, :] %= np.uint64(qs[l])
-    g0, g1 = giant_range(rank, world, d)
+        mine[:, :, :, :, l, :] %= np.uint64(qs[l])
     part = np.zeros((s, m_ct, 2, L, ring.N), dtype=np.uint64)
-    ol.lib().orc_matmult_finalize(ring.h, keys.h, L, s, m_ct, ol.p64(acc), None, g0, g1, 0, ol.p64(part))
+    ol.lib().orc_matmult_finalize(ring.h, keys.h, L, s, m_ct, ol.p64(mine), None, g_lo, g_hi, 0, ol.p64(part))
     tp = torch.from_numpy(part.view(np.int64))
     dist.all_reduce(tp)
     for l in range(L):
@@ -98,13 +117,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_is_bit_exact():
+@pytest.mark.parametrize("world", [2, 3])          # 3: the giant axis (d = 4 at this ring size) needs padding
+def test_multi_rank_sharding_is_bit_exact(world):
     import oracle_lib as ol
     ol.build_oracle()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
