@@ -159,7 +159,12 @@ struct PhaseTimer {
     ~PhaseTimer() { stop(0); }
 };
 
+// packed-limb plaintext word of a canonical residue w < 2^36 (see mac_dma.hip): three 16-bit fields 0xB000 | 12-bit limb
+constexpr u64 PACKED_ZERO = 0x0000B000B000B000ULL;
 #ifdef __HIPCC__
+__device__ __host__ __forceinline__ u64 pack_limbs(u64 w) {
+    return (0xB000ULL | (w & 0xFFF)) | ((0xB000ULL | ((w >> 12) & 0xFFF)) << 16) | ((0xB000ULL | (w >> 24)) << 32);
+}
 // ---------------------------------------------------------------- device arithmetic
 // All ring arithmetic on the device is done on exact integers held in fp64 registers (|x| < 2^53):
 // measured on gfx950 v_fma_f64 and v_mad_u64_u32 issue at the same rate (profiles/r01_ubench_*.txt),

@@ -113,13 +113,17 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     std::vector<double2> pkf, pki; build_pack(twf, pkf); build_pack(twi, pki);
     if (hipMalloc(&sh->tw_fwd, twf.size() * sizeof(double)) != hipSuccess || hipMalloc(&sh->tw_inv, twi.size() * sizeof(double)) != hipSuccess ||
         hipMalloc(&sh->pack_fwd, pkf.size() * sizeof(double2)) != hipSuccess || hipMalloc(&sh->pack_inv, pki.size() * sizeof(double2)) != hipSuccess ||
-        hipMalloc(&sh->modc, sizeof(ModConst) * SFG_MAXMOD) != hipSuccess || hipMalloc(&sh->zeros_dev, 256) != hipSuccess) return fail("hipMalloc of tables failed");
+        hipMalloc(&sh->modc, sizeof(ModConst) * SFG_MAXMOD) != hipSuccess || hipMalloc(&sh->zeros_dev, 512) != hipSuccess) return fail("hipMalloc of tables failed");
     if (hipMemcpy(sh->tw_fwd, twf.data(), twf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(sh->tw_inv, twi.data(), twi.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(sh->pack_fwd, pkf.data(), pkf.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(sh->pack_inv, pki.data(), pki.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(sh->modc, sh->modc_host, sizeof(ModConst) * SFG_MAXMOD, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(sh->zeros_dev, 0, 256) != hipSuccess) return fail("table upload failed");
+        hipMemset(sh->zeros_dev, 0, 512) != hipSuccess) return fail("table upload failed");
+    {   // second 256 B: zero plaintext words in the packed-limb format (mac_dma.hip PACKED_ZERO)
+        u64 pz[32]; for (int i = 0; i < 32; i++) pz[i] = 0x0000B000B000B000ULL;
+        if (hipMemcpy((char *)sh->zeros_dev + 256, pz, 256, hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
+    }
     ctx_bind_shared(ctx, sh);
     if (sfg_encoder_init(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
     // dynamic-LDS limits are per (function, device): set here for this context's device, not behind process-wide flags

@@ -400,7 +400,7 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
 // half_rows + G > 0: `pt` is the base of a grouped panel and rows are scattered by PanelMap (half rows only)
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g) {
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask) {
     EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
     const int BATCH = 2048;
@@ -414,7 +414,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
                                ctx->scale / (double)SFG_SLOTS, pc);
             SFG_HIP(ctx, hipGetLastError());
         }
-        if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
+        if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
         else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));
     }

@@ -11,7 +11,7 @@ struct RowMap { int rpg; size_t gstride_in, gstride_out; };
 // where the plaintext of diagonal `shift` (= shift0 + index in the batch) of block row g lands inside a panel that holds G
 // block rows: slot ((shift / 91) * G + g) * 91 + shift % 91, i.e. [giant][g][baby] so that k = g*91 + baby is contiguous.
 // G == 0: dense (slot = index in the batch)
-struct PanelMap { int G, g, shift0; };
+struct PanelMap { int G, g, shift0; unsigned packed_mask = 0; };   // packed_mask bit l: rows of modulus l are written as packed-limb words (mac_dma.hip)
 
 // ntt.hip
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
@@ -22,12 +22,12 @@ int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 // mac.hip
-struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; };   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
+struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; };   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate);
 int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
 // encode.hip
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D);
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0);
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0, unsigned packed_mask = 0);
 // rotate.hip
 int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host);
 int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index);
@@ -36,5 +36,9 @@ int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct
 // mac_dma.hip
 int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<int> &is_big);
 int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, int L, double *rotf);
-int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
+int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st,
+                   const double *rotsum = nullptr);
+int launch_rot_sum(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, int K, int L, double *rotsum);
+int launch_pack_pt(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, size_t words_per_row, int L, unsigned packed_mask);
+unsigned mac_dma_packed_mask(sfg_ctx *ctx, int L);
 bool mac_use_dma(const sfg_ctx *ctx);

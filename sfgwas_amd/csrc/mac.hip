@@ -255,8 +255,18 @@ extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt
         st.rot_k = (size_t)R * L * SFG_N; st.rot_r = (size_t)L * SFG_N;
         st.pt_k = (size_t)Ncols * L * SFG_N; st.pt_n = (size_t)L * SFG_N;
         st.out_n = (size_t)R * L * SFG_N; st.out_r = (size_t)L * SFG_N;
-        if (!rc) rc = launch_mac_dma(ctx, rotf, (size_t)R, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate, st);
-        (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rotf);
+        // default build: the small-modulus plaintext rows go through the packed-limb format the product path uses (SFG_MAC_PT=plain: as given)
+        const unsigned pmask = mac_dma_packed_mask(ctx, L);
+        u64 *ptp = nullptr; double *rsum = nullptr;
+        if (!rc && pmask) {
+            const size_t prows = (size_t)K * Ncols * L;
+            if (hipMalloc(&ptp, prows * SFG_N * 8) != hipSuccess || hipMalloc(&rsum, (size_t)R * nplanes * SFG_N * 8) != hipSuccess) { rc = 1; ctx->err = "sfg_mac: out of device memory"; }
+            if (!rc) rc = launch_pack_pt(ctx, (const u64 *)pt, ptp, prows, SFG_N, L, pmask);
+            if (!rc) rc = launch_rot_sum(ctx, rotf, (size_t)R, K, L, rsum);
+            st.pt_packed = true;
+        }
+        if (!rc) rc = launch_mac_dma(ctx, rotf, (size_t)R, pmask ? ptp : (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate, st, rsum);
+        (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rotf); (void)hipFree(ptp); (void)hipFree(rsum);
     }
     t.stop(1);
     return rc;

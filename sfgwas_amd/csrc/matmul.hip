@@ -67,6 +67,24 @@ __global__ void __launch_bounds__(256) k_reduce_rows(u64 *rows, int L, const Mod
     const size_t off = row * N + (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
     rows[off] = rows[off] % modc[l].qi;
 }
+// zero plaintexts for the panel slots the encoder does not write: nseg segments of seg_words words, pitch_words apart; a word of
+// modulus row l (= (index / prow) % L inside a segment, segments start on a plaintext boundary) is PACKED_ZERO when packed_mask has bit l
+__global__ void __launch_bounds__(256) k_pt_zero(u64 *pt, size_t pitch_words, size_t seg_words, int L, size_t prow, unsigned packed_mask) {
+    const size_t seg = blockIdx.y, x = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= seg_words) return;
+    const int l = (int)((x / prow) % L);
+    pt[seg * pitch_words + x] = ((packed_mask >> l) & 1u) ? PACKED_ZERO : 0ULL;
+}
+static int launch_pt_zero(sfg_ctx *ctx, u64 *pt, size_t pitch_words, size_t seg_words, int nseg, int L, size_t prow, unsigned packed_mask) {
+    if (!packed_mask) {
+        if (nseg == 1) SFG_HIP(ctx, hipMemsetAsync(pt, 0, seg_words * 8, ctx->stream));
+        else SFG_HIP(ctx, hipMemset2DAsync(pt, pitch_words * 8, 0, seg_words * 8, nseg, ctx->stream));
+        return 0;
+    }
+    hipLaunchKernelGGL(k_pt_zero, dim3((unsigned)((seg_words + 255) / 256), (unsigned)nseg), dim3(256), 0, ctx->stream, pt, pitch_words, seg_words, L, prow, packed_mask);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
 // P2: per-column sum and sum of squares after missing -> 0 (matmult.go:1292-1300)
 __global__ void __launch_bounds__(256) k_colsums(const int8_t *g, size_t nrow, size_t ncol, size_t ld, double *sum, double *sqsum) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -154,7 +172,7 @@ static int build_rot_row(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int nl, i
 // acc_dev: [(j - j0)][giant < d][i < s][2][L][N] canonical residues (zero-initialised here unless accumulate != 0)
 // for operand block rows [b0, b1) and block columns [j0, j1).
 static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, const Shape &sh, unsigned flags,
-                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc, const double *rotf_pre = nullptr) {
+                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc, const double *rotf_pre = nullptr, const double *rotsum_pre = nullptr) {
     const int N = SFG_N, d = SFG_D, L = max_level;
     const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "matmul: max_level out of range");
@@ -170,7 +188,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     int G = 1;
     if (dma) { G = ctx->cfg.mm_group; if (G > b1 - b0) G = b1 - b0; }
     const size_t nplain = (size_t)d * d;                     // 8281 >= 8192 slots per block row: the tail stays zero
-    u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr; size_t rowf = 0;
+    u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr, *rotsum = nullptr; size_t rowf = 0;
+    const unsigned packed_mask = dma ? mac_dma_packed_mask(ctx, L) : 0u;      // small-modulus plaintext rows in the packed-limb format
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
     const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
@@ -182,6 +201,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
         if (!rotf_pre) SFG_TRY(sfg_scratch(ctx, "mm.rotf", grp_slices * s * 2 * rowf * 8 * (pipelined ? 2 : 1), (void **)&rotf));
+        if (!rotf_pre && packed_mask) SFG_TRY(sfg_scratch(ctx, "mm.rotsum", (size_t)2 * s * 2 * rowf * 8, (void **)&rotsum));     // one per ring half
     }
     const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
@@ -193,6 +213,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         for (int g = 0; g < ng; g++) SFG_TRY(build_rot_row(ctx, A, s, nl_in, nl, lev, L, sh, bg + g, a_row, rotc, dma, dma ? dst + (size_t)g * d * s * 2 * rowf : nullptr));
         if (dma && (ng * d) % 4)          // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
             SFG_HIP(ctx, hipMemsetAsync(dst + (size_t)ng * d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream));
+        if (packed_mask) SFG_TRY(launch_rot_sum(ctx, dst, (size_t)s * 2, ng * d, L, rotsum + (size_t)buf * s * 2 * rowf));
         return 0;
     };
     // With several groups the key switching of group k+1 runs on the auxiliary stream beside the encode + MAC of group k
@@ -207,8 +228,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     for (int bg = b0; bg < b1 && !rc; bg += G, gi++) {
         const int ng = std::min(G, b1 - bg);
         // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
-        const double *rotf_grp = rotf;
-        if (rotf_pre) rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf;
+        const double *rotf_grp = rotf, *rotsum_grp = rotsum;
+        if (rotf_pre) { rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf; rotsum_grp = rotsum_pre ? rotsum_pre + (size_t)gi * s * 2 * rowf : nullptr; }
         else if (pipelined) {
             if (bg + G < b1) {                                                   // next group: its half was last read by group gi-1
                 SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));
@@ -217,6 +238,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             }
             SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pipe[gi & 1], 0));
             rotf_grp = rotf + (size_t)(gi & 1) * grp_slices * s * 2 * rowf;
+            if (rotsum) rotsum_grp = rotsum + (size_t)(gi & 1) * s * 2 * rowf;
         } else {
             rc = build_group(bg, 0);
             if (rc) break;
@@ -238,14 +260,15 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 const bool full = nruns == 1 && runs[0][1] - runs[0][0] == SFG_SLOTS;
                 // zero what the encoder will not write: plaintext slot of (giant, g, baby) is ((giant*ng + g)*91 + baby)
                 if (full) {        // only the 89 slots past shift 8191 (giant 90, baby 2..90)
-                    SFG_HIP(ctx, hipMemsetAsync(pt + (((size_t)(d - 1) * ng + g) * d + (SFG_SLOTS - (d - 1) * d)) * plw, 0, (nplain - SFG_SLOTS) * plw * 8, ctx->stream));
+                    rc = launch_pt_zero(ctx, pt + (((size_t)(d - 1) * ng + g) * d + (SFG_SLOTS - (d - 1) * d)) * plw, 0, (nplain - SFG_SLOTS) * plw, 1, L, prow, packed_mask);
                 } else {           // ragged block: all 91 x 91 slots of this block row
-                    SFG_HIP(ctx, hipMemset2DAsync(pt + (size_t)g * d * plw, (size_t)ng * d * plw * 8, 0, (size_t)d * plw * 8, d, ctx->stream));
+                    rc = launch_pt_zero(ctx, pt + (size_t)g * d * plw, (size_t)ng * d * plw, (size_t)d * plw, d, L, prow, packed_mask);
                 }
+                if (rc) break;
                 {
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g);
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
                     t.stop(nruns);
@@ -256,11 +279,11 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma;   // pt[giant][g][baby]: k = g*91 + baby
+                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
-                if (dma) rc = launch_mac_dma(ctx, rotf_grp, (size_t)s * 2, pt, accj, ng * d, 2 * s, d, L, acc_flag, st);
+                if (dma) rc = launch_mac_dma(ctx, rotf_grp, (size_t)s * 2, pt, accj, ng * d, 2 * s, d, L, acc_flag, st, rotsum_grp);
                 else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
                 t.stop(1);
             }
@@ -355,7 +378,7 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     int jg = (int)(budget / ((size_t)d * accw * 8)); if (jg < 1) jg = 1;
     // Several column groups would each rebuild the rotation cache of every block row (91 key switches per input
     // ciphertext).  When the whole cache fits (48 GiB; Q*X at 100k x 1M: 13 block rows = 28 GB) it is built once here.
-    const double *rotf_all = nullptr;
+    const double *rotf_all = nullptr, *rotsum_all = nullptr;
     if (mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
@@ -370,6 +393,16 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
             for (int bi = b0; bi < b1; bi++) SFG_TRY(build_rot_row(ctx, (const u64 *)A, s, in_level + 1, nl, lev, L, sh, bi, a_row, rotc, true, buf + (size_t)(bi - b0) * per_row));
             SFG_HIP(ctx, hipMemsetAsync(buf + (size_t)(b1 - b0) * per_row, 0, 3 * (size_t)s * 2 * rowf * 8, ctx->stream));   // k-slices read by a ragged last chunk
             rotf_all = buf;
+            if (mac_dma_packed_mask(ctx, L)) {             // per MAC group (as matmul_accumulate forms them): sum of its k-slices
+                const int G = std::min(ctx->cfg.mm_group, b1 - b0), ngrp = (b1 - b0 + G - 1) / G;
+                double *rs = nullptr;
+                SFG_TRY(sfg_scratch(ctx, "mm.rotsum_all", (size_t)ngrp * s * 2 * rowf * 8, (void **)&rs));
+                for (int gi = 0; gi < ngrp; gi++) {
+                    const int ng = std::min(G, b1 - b0 - gi * G);
+                    SFG_TRY(launch_rot_sum(ctx, buf + (size_t)gi * G * per_row, (size_t)s * 2, ng * d, L, rs + (size_t)gi * s * 2 * rowf));
+                }
+                rotsum_all = rs;
+            }
         }
     }
     // With the product-wide cache the accumulate passes do no key switching, so the giant-step alignment of pass k runs on the
@@ -386,7 +419,7 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
             acc += (size_t)(k & 1) * jg * d * accw;
             if (k >= 2) SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pipe[2 + (k & 1)], 0));    // pass k-2 has been aligned out of this buffer
         }
-        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc, rotf_all);
+        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc, rotf_all, rotsum_all);
         if (rc) return rc;
         if (overlap) {
             SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));

@@ -215,10 +215,12 @@ __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out
     const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
     const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
     u64 *out = out_ + (dst * L + m) * (size_t)n;
+    const bool packed = (pm.packed_mask >> m) & 1u;
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         const int j = k * 256 + tid, a = j >> 9, x = j & 511, b = x >> 4, c = x & 15;
-        out[j] = f64_to_u64(canon(lds[a * LDS_ROW + c * 33 + b], q, qinv));
+        const u64 w = f64_to_u64(canon(lds[a * LDS_ROW + c * 33 + b], q, qinv));
+        out[j] = packed ? pack_limbs(w) : w;
     }
 }
 // Same transform with every exchange split in two rounds through a HALF image (33 KiB instead of 66 KiB): three
@@ -302,6 +304,7 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
     const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
     const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
     u64 *out = out_ + (dst * L + m) * (size_t)n;
+    const bool packed = (pm.packed_mask >> m) & 1u;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int p = tid + 256 * r, a = p >> 5, b = p & 31;
@@ -312,7 +315,8 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
-            out[r * 4096 + jj] = f64_to_u64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
+            const u64 w = f64_to_u64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
+            out[r * 4096 + jj] = packed ? pack_limbs(w) : w;
         }
     }
 }

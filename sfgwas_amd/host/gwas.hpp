@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -38,15 +39,34 @@ struct Ciphertext {               // ckks.Ciphertext of degree 1: Value()[k].Coe
 using CipherVector = std::vector<Ciphertext>;
 using CipherMatrix = std::vector<CipherVector>;
 
+// HBM-resident genotype matrices keyed by the reference's cacheFilePrefix (see gwas::MatMult4StreamPreprocess); owned by the
+// CryptoParams that created them and shared with its forks - no process-global table
+struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; bool owner = false; };
+struct ResidentTable { std::mutex mu; std::map<std::string, ResidentGeno> tab; };
+
 struct CryptoParams {             // crypto.go:32-60 (the parts the hot path touches)
     sfg_ctx *ctx = nullptr;
     int logN = 14, nq = 0, np = 0;
     double scale = 0;
+    std::shared_ptr<ResidentTable> resident = std::make_shared<ResidentTable>();
     int N() const { return 1 << logN; }
     int GetSlots() const { return N() / 2; }                         // crypto.go:282-284
-    ~CryptoParams() { if (ctx) sfg_ctx_destroy(ctx); }
+    ~CryptoParams() {
+        if (!ctx) return;
+        if (resident.use_count() == 1) for (auto &kv : resident->tab) if (kv.second.owner) sfg_geno_free(ctx, kv.second.g);
+        sfg_ctx_destroy(ctx);
+    }
     void check(int rc, const char *what) const {
         if (rc) throw std::runtime_error(std::string(what) + ": " + sfg_last_error(ctx));
+    }
+    // One CryptoParams per concurrent caller, the way the reference checks a private evaluator out of its pool
+    // (crypto.go:287-316; ckks.NewEvaluator per goroutine, matmult.go:1110,1200,1371): shares tables, keys and resident
+    // matrices with this object, owns its HIP queues and scratch.  Destroy forks before the object that loaded the keys.
+    std::unique_ptr<CryptoParams> Fork() {
+        auto c = std::make_unique<CryptoParams>();
+        check(sfg_ctx_fork(ctx, &c->ctx), "sfg_ctx_fork");
+        c->logN = logN; c->nq = nq; c->np = np; c->scale = scale; c->resident = resident;
+        return c;
     }
 };
 
@@ -450,27 +470,32 @@ MatMult4Stream(crypto::CryptoParams *cps, const crypto::CipherMatrix &A, GenoFil
 // matmult.go:914 / :1043.  The DiagCache files of the reference become an HBM-resident int8 matrix keyed by the
 // same cacheFilePrefix; `transposeOf` registers a prefix as the transpose of an already resident matrix, which is how
 // pca.go:112-113 (X cache, X^T cache) maps onto ONE resident copy.
-struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; };
-inline std::map<std::string, ResidentGeno> &residentTable() { static std::map<std::string, ResidentGeno> t; return t; }
 inline void MatMult4StreamPreprocess(crypto::CryptoParams *cps, GenoFileStream *gfs, int /*maxLevel*/, const std::string &cacheFilePrefix,
                                      const std::string &transposeOf = "") {
-    auto &tab = residentTable();
+    std::lock_guard<std::mutex> lk(cps->resident->mu);
+    auto &tab = cps->resident->tab;
     if (tab.count(cacheFilePrefix)) return;                          // "Found cache file" (filestream.go:52-54): skip
-    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE}; return; }
+    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE, false}; return; }
     uint64_t nrow, ncol; std::vector<int8_t> geno = readAllRows(gfs, nrow, ncol);
-    ResidentGeno r; cps->check(sfg_geno_upload(cps->ctx, geno.data(), nrow, ncol, ncol, &r.g), "MatMult4StreamPreprocess");
+    crypto::ResidentGeno r; cps->check(sfg_geno_upload(cps->ctx, geno.data(), nrow, ncol, ncol, &r.g), "MatMult4StreamPreprocess");
+    r.owner = true;
     tab[cacheFilePrefix] = r;
 }
 inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, const crypto::CipherMatrix &A, int maxLevel, const std::string &cacheFilePrefix,
                                                   int m_ct) {
-    auto it = residentTable().find(cacheFilePrefix);
-    if (it == residentTable().end()) throw std::runtime_error("MatMult4StreamCompute: no resident matrix for prefix " + cacheFilePrefix);   // os.Open panics (filestream.go:59-61)
+    crypto::ResidentGeno rg;
+    {
+        std::lock_guard<std::mutex> lk(cps->resident->mu);
+        auto it = cps->resident->tab.find(cacheFilePrefix);
+        if (it == cps->resident->tab.end()) throw std::runtime_error("MatMult4StreamCompute: no resident matrix for prefix " + cacheFilePrefix);   // os.Open panics (filestream.go:59-61)
+        rg = it->second;
+    }
     const int s = (int)A.size(), inLevel = A[0][0].Level();
     std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());
     void *dA = nullptr, *dO = nullptr;
     cps->check(sfg_malloc(cps->ctx, &dA, a.size() * 8), "MatMult4StreamCompute"); cps->check(sfg_malloc(cps->ctx, &dO, o.size() * 8), "MatMult4StreamCompute");
     cps->check(sfg_memcpy_h2d(cps->ctx, dA, a.data(), a.size() * 8), "MatMult4StreamCompute");
-    int rc = sfg_matmul_resident_dev(cps->ctx, (const uint64_t *)dA, s, inLevel, maxLevel, it->second.g, it->second.flags, (uint64_t *)dO);
+    int rc = sfg_matmul_resident_dev(cps->ctx, (const uint64_t *)dA, s, inLevel, maxLevel, rg.g, rg.flags, (uint64_t *)dO);
     if (!rc) rc = sfg_memcpy_d2h(cps->ctx, o.data(), dO, o.size() * 8);
     sfg_free(cps->ctx, dA); sfg_free(cps->ctx, dO);
     cps->check(rc, "MatMult4StreamCompute");

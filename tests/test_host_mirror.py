@@ -18,7 +18,7 @@ def build(name):
     exe = os.path.join(ROOT, "tests", "host", "_build_" + name)
     hdr = os.path.join(ROOT, "sfgwas_amd", "host", "gwas.hpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, src, "-L" + LIBDIR, "-lsfgwas_hip", "-Wl,-rpath," + LIBDIR,
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe, src, "-L" + LIBDIR, "-lsfgwas_hip", "-Wl,-rpath," + LIBDIR,
                                "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
@@ -122,3 +122,48 @@ def test_host_mirror_matmul_end_to_end(tmp_path):
     assert sm.value == float(ring.moduli[level])
     ol.lib().orc_rescale(ring.h, level, ol.p64(mc), ol.p64(rs))
     assert np.array_equal(np.fromfile(tmp_path / "cmultconst.bin", dtype=np.uint64).reshape(rs.shape), rs)
+
+
+@pytest.mark.gpu
+def test_two_host_threads_share_one_key_set(tmp_path):
+    """SURVEY §8b threading: assoc.go:360-408 issues concurrent MatMult4Stream calls; here two host threads, each on its own
+    fork of the context (sfg_ctx_fork), run different products at the same time for several rounds — every word vs the oracle"""
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_concurrent_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rnd = np.random.default_rng(31)
+    slots, d, level, L = 8192, 91, 5, 5
+    cases = [(70, 40, 2, 0), (30, slots + 20, 1, 1)]            # (nrow, ncol, s, square): one block vs two block columns, squared
+    steps = set()
+    for (r, c, _, _) in cases:
+        for c_blk in ([c] if c <= slots else [slots, c - slots]):
+            shifts = range(slots) if r + c_blk > slots else list(range(r)) + list(range(slots - c_blk + 1, slots))
+            for sh in shifts:
+                if sh % d:
+                    steps.add(sh % d)
+                if sh // d:
+                    steps.add((sh // d) * d)
+    blob = [np.array([len(steps)], dtype=np.uint64)]
+    for k in sorted(steps):
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 300 + k)
+        keys.add(g, key)
+        blob += [np.array([g], dtype=np.uint64), key.reshape(-1)]
+    np.concatenate(blob).tofile(tmp_path / "keys.bin")
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    inputs = []
+    for t, (nrow, ncol, s, square) in enumerate(cases):
+        geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+        geno.tofile(tmp_path / f"geno{t}.bin")
+        A = np.stack([np.stack([ring.fill_uniform(level, 500 + 10 * t + i)]) for i in range(s)])
+        A.tofile(tmp_path / f"A{t}.bin")
+        (tmp_path / f"case{t}.txt").write_text(f"{nrow} {ncol} {s} {level} {L} {square}\n")
+        inputs.append((geno, A, square))
+    out = subprocess.run([exe, str(tmp_path), str(len(cases)), "3"], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr
+    for t, (geno, A, square) in enumerate(inputs):
+        want, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, L, geno, square=bool(square), enc_prec=1)
+        got = np.fromfile(tmp_path / f"out_thr{t}.bin", dtype=np.uint64).reshape(want.shape)
+        assert np.array_equal(got, want), f"thread {t}"
