@@ -243,6 +243,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    near_ties = ctx.encoder_near_ties()                    # rounding audit of every encode since context creation (gate, warm-up, timed steps)
     # ---- output digests, outside the timed region: SHA-256 over the per-ciphertext SHA-256s in global [i][j] order
     digests = None
     if not args.no_digest:
@@ -279,6 +280,8 @@ def main():
             res["parity_gate"] = gate
         if digests is not None:
             res["digests"] = digests
+        res["encoder_near_ties"] = {"count": near_ties, "what": "encoder coefficients within 2^-40 of a rounding tie on rank 0 (0 = every plaintext provably "
+                                                                 "rounded as the reference's 256-bit EncoderBig rounds it)"}
         # ---- roofline of the dominant kernel (k_mac_dma, small-modulus instance)
         ms_small, n_small, by_small = phase_tot.get("mac_small", [0.0, 0, 0.0])
         if n_small:

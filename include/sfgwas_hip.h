@@ -88,6 +88,12 @@ int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block_dev, size_t ld, int r
 /* coefficient-domain result of the encoder for arbitrary real slot vectors (host convenience used by
  * Mask/MaskTrunc-style callers, basics.go:110-172): values_host[nvec][slots] -> coeffs_host[nvec][N] int64 */
 int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, int64_t *coeffs_host);
+/* Rounding audit of the encoder.  The reference rounds Delta * sigma^-1(v) computed with 256-bit big floats (NewEncoderBig(params, 256),
+ * matmult.go:1019,1421); the device computes the same reals in double-double (~2^-65 absolute here).  The two can only round a
+ * coefficient differently when its exact value lies within that distance of a tie; every coefficient within 2^-40 of a tie is counted
+ * per context.  count == 0 after a call proves that call's plaintexts are the reference's, bit for bit; a non-zero count (expected
+ * about once per 2 * 10^11 coefficients) names a call whose result should be re-derived with the CPU big-float encoder. */
+int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset);
 /* crypto.EncodeFloatVector (crypto.go:398-420; behind Mask / MaskTrunc / MaskWithScaling, basics.go:110-172, and
  * CPMult operands): nvec real slot vectors [nvec][slots] (host) -> NTT-domain plaintexts pt_dev[nvec][level+1][N]
  * at the context's default scale. The reference encodes at MaxLevel; a product at a lower level reads the first rows. */
@@ -163,6 +169,13 @@ int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *
 #define SFG_TRANSPOSE 2u
 int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,
                             const sfg_geno *g, unsigned flags, uint64_t *out_dev);
+/* MatMult4StreamCompute on the reference's OWN on-disk cache (matmult.go:1043-1236 reading the DiagCache files that
+ * MatMult4StreamPreprocess of a CPU party wrote, filestream.go:19-282): files <prefix>_<bi>.bin for bi < nbr hold NTT + Montgomery-form
+ * plaintexts as big-endian words; they are streamed, converted on the device and multiplied without re-encoding.  out: s x vectorLen
+ * ciphertexts, as sfg_matmul_resident_dev.  Fails like the reference when a file is missing (os.Open panics, filestream.go:59-61). */
+int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, const char *cache_prefix, int nbr, uint64_t *out_dev);
+/* header of <prefix>_<block_row>.bin: {vectorLen (= block columns), level, scale (f64 bits), n, numModuli, rowSize} */
+int sfg_diagcache_header(sfg_ctx *ctx, const char *cache_prefix, int block_row, uint64_t hdr[6]);
 /* host-pointer form, one call = MatMult4Stream(cps, A, gfs, maxLevel, computeSquaredSum, square, nproc) */
 int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level, int max_level,
                       const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, unsigned flags,

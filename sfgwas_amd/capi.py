@@ -44,6 +44,7 @@ def _sig(L):
         "sfg_encode_diags_dev": (i, [vp, vp, sz, i, i, i, i, i, i, vp]),
         "sfg_encode_coeffs_host": (i, [vp, C.POINTER(d), i, C.POINTER(C.c_int64)]),
         "sfg_encode_vectors_dev": (i, [vp, C.POINTER(d), i, i, vp]),
+        "sfg_ctx_encoder_near_ties": (i, [vp, C.POINTER(C.c_ulonglong), i]),
         "sfg_rotate_right_dev": (i, [vp, vp, vp, i, i, C.POINTER(i)]),
         "sfg_ct_add_dev": (i, [vp, vp, vp, vp, i, i]),
         "sfg_ct_sub_dev": (i, [vp, vp, vp, vp, i, i]),
@@ -65,6 +66,8 @@ def _sig(L):
         "sfg_geno_concat_cols": (i, [vp, C.POINTER(vp), i, C.POINTER(vp)]),
         "sfg_geno_colsums": (i, [vp, vp, C.POINTER(d), C.POINTER(d)]),
         "sfg_matmul_resident_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, vp]),
+        "sfg_matmul_from_cache": (i, [vp, vp, i, i, i, C.c_char_p, i, vp]),
+        "sfg_diagcache_header": (i, [vp, C.c_char_p, i, u64p]),
         "sfg_matmul_stream": (i, [vp, u64p, i, i, i, vp, sz, sz, sz, C.c_uint, u64p, C.POINTER(d), C.POINTER(d)]),
         "sfg_matmul_resident_range_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, vp]),
         "sfg_matmul_accumulate_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, i, i, i, vp]),
@@ -194,6 +197,11 @@ class Context:
         child.__dict__.update({k: v for k, v in self.__dict__.items()})
         child.h = h
         return child
+
+    def encoder_near_ties(self, reset=False):
+        n = C.c_ulonglong()
+        self.check(lib().sfg_ctx_encoder_near_ties(self.h, C.byref(n), int(reset)), "encoder_near_ties")
+        return n.value
 
     def galois(self, k):
         return lib().sfg_galois_for_rotation(self.h, k)

@@ -245,9 +245,13 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
     }
 }
 
-__device__ __forceinline__ double dd_round_away(dd x) {                // integer-valued double
+// The double-double pipeline carries ~2^-100 relative error (absolute ~2^-65 on these magnitudes), the reference's EncoderBig 256
+// bits.  A coefficient whose exact value lies within 2^-40 of a rounding tie is counted (sfg_ctx_encoder_near_ties): the two
+// encoders can only disagree on such a coefficient, so a zero count PROVES the block was rounded as the reference rounds it.
+__device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {                // integer-valued double
     double nn = __builtin_rint(x.hi);
     double diff = (x.hi - nn) + x.lo;
+    near_tie += __builtin_fabs(__builtin_fabs(diff) - 0.5) < 0x1p-40 ? 1u : 0u;
     if (diff > 0.5 || (diff == 0.5 && nn >= 0)) nn += 1.0;
     else if (diff < -0.5 || (diff == -0.5 && nn <= 0)) nn -= 1.0;
     return nn;
@@ -264,7 +268,8 @@ constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 73,728 B: two
 // 256..511) take turns, data stays in registers meanwhile.  16 waves per CU instead of 8.
 template <bool F64IN>
 __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *zt, const uint16_t *tinv,
-                                                      double scale_over_n, double *pc_out) {
+                                                      double scale_over_n, double *pc_out, unsigned long long *tie_count) {
+    unsigned near_tie = 0;
     extern __shared__ double lds[];
     double *RH = lds, *RL = lds + ENC_HPAD, *IH = lds + 2 * ENC_HPAD, *IL = lds + 3 * ENC_HPAD;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
@@ -365,8 +370,8 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
             dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
-            pc[c] = dd_round_away(wr);
-            if (c > 0) pc[n - c] = -dd_round_away(wi);
+            pc[c] = dd_round_away(wr, near_tie);
+            if (c > 0) pc[n - c] = -dd_round_away(wi, near_tie);
         }
         // W_{h-c}  (c = 0 gives W_h)
         if (c < h / 2) {
@@ -376,11 +381,12 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
             dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
-            pc[cc] = dd_round_away(wr);
-            if (cc < h) pc[n - cc] = -dd_round_away(wi);
+            pc[cc] = dd_round_away(wr, near_tie);
+            if (cc < h) pc[n - cc] = -dd_round_away(wi, near_tie);
         }
     }
     }
+    if (near_tie) atomicAdd(tie_count, (unsigned long long)near_tie);
 }
 
 static int enc_pc_scratch(sfg_ctx *ctx, size_t nplain, double **pc) {
@@ -411,7 +417,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         {
             PhaseTimer t(ctx, "encode", false);
             hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->zt, et->tinv,
-                               ctx->scale / (double)SFG_SLOTS, pc);
+                               ctx->scale / (double)SFG_SLOTS, pc, (unsigned long long *)ctx->tie_count_dev);
             SFG_HIP(ctx, hipGetLastError());
         }
         if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
@@ -450,7 +456,7 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     int rc = 0;
     if (hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
     if (!rc) {
-        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc);
+        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
         if (hipGetLastError() != hipSuccess) rc = 1;
     }
     if (!rc && hipMemcpyAsync(pc.data(), dpc, (size_t)nvec * n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
@@ -477,9 +483,18 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
     double *dv = (double *)p; double *dpc = dv + (size_t)nvec * n;
     SFG_HIP(ctx, hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc);
+    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
     SFG_HIP(ctx, hipGetLastError());
     SFG_TRY(launch_ntt_plain(ctx, dpc, (u64 *)pt_dev, (size_t)nvec, level + 1));
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // values_host may be reused by the caller
+    return 0;
+}
+
+// encoder coefficients (since context creation / the last reset) whose double-double value lay within 2^-40 of a rounding tie
+extern "C" int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(sfg_sync_all(ctx));
+    SFG_HIP(ctx, hipMemcpy(count, ctx->tie_count_dev, 8, hipMemcpyDeviceToHost));
+    if (reset) SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 8));
     return 0;
 }

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <algorithm>
+#include <string>
 
 static inline int ceil_div(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 static inline int diag_bool(int r, int c, int dim, int index) {          // GetDiagBool, matmult.go:627-631
@@ -139,9 +140,11 @@ extern "C" int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows, size_t nrows_of
 // ---------------------------------------------------------------- rotation cache of one operand block row
 // rotc[baby][i] = RotateRight(A[i][bi], -baby) (matmult.go:1373-1377) for the active baby steps, then (LDS-DMA MAC) the fp64
 // operand form into rotf_dst.  a_row / rotc are scratch of s resp. d*s ciphertexts.
+static int build_rot_row_tab(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int nl, int lev, int L, int nbr, int bi, const std::vector<uint8_t> &baby_t,
+                             u64 *a_row, u64 *rotc, bool dma, double *rotf_dst);
 static int build_rot_row(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int nl, int lev, int L, const Shape &sh, int bi, u64 *a_row, u64 *rotc,
                          bool dma, double *rotf_dst) {
-    const int N = SFG_N, d = SFG_D; const size_t ctw = (size_t)2 * nl * N;
+    const int d = SFG_D;
     const int nr = sh.rows_of(bi);
     // active baby steps (matmult.go:1326-1336), union over ALL block columns of the operand as in the reference
     std::vector<uint8_t> baby_t(d, 0);
@@ -151,8 +154,13 @@ static int build_rot_row(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int nl, i
         for (int bj = 0; bj < sh.m_ct && !any; bj++) any = diag_bool(nr, sh.cols_of(bj), SFG_SLOTS, -shift);
         if (any) baby_t[shift % d] = 1;
     }
+    return build_rot_row_tab(ctx, A, s, nl_in, nl, lev, L, sh.nbr, bi, baby_t, a_row, rotc, dma, rotf_dst);
+}
+static int build_rot_row_tab(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int nl, int lev, int L, int nbr, int bi, const std::vector<uint8_t> &baby_t,
+                             u64 *a_row, u64 *rotc, bool dma, double *rotf_dst) {
+    const int N = SFG_N, d = SFG_D; const size_t ctw = (size_t)2 * nl * N;
     for (int i = 0; i < s; i++) {                  // A[i][bi] at the dropped level, contiguous over i
-        const u64 *src = A + ((size_t)i * sh.nbr + bi) * 2 * nl_in * N;
+        const u64 *src = A + ((size_t)i * nbr + bi) * 2 * nl_in * N;
         if (nl == nl_in) SFG_HIP(ctx, hipMemcpyAsync(a_row + (size_t)i * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
         else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_row + (size_t)i * ctw, nl_in, nl);
     }
@@ -458,4 +466,162 @@ extern "C" int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, in
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dA); (void)hipFree(dO); sfg_geno_free(ctx, g);
     return rc;
+}
+
+
+// ---------------------------------------------------------------- A9 with the reference's on-disk cache (A11 / F2)
+// MatMult4StreamCompute reading DiagCache files written by MatMult4StreamPreprocess of a CPU party (matmult.go:1043-1236,
+// filestream.go:19-282): <prefix>_<bi>.bin = header {vectorLen, level, scale bits, n, numModuli, rowSize} (6 x u64 LE) + d baby
+// flags + d giant flags, then one record per active diagonal: u64 LE length, u32 LE shift, and per block column a u8 isEmpty flag
+// followed (when not empty) by numModuli x n coefficients as big-endian u64 (ring.WriteCoeffsTo) in NTT + Montgomery form.
+// A file is streamed once per column pass, one giant step (<= 91 records) at a time: the records of giant g form the plaintext panel
+// pt[j][baby] of ONE MAC launch with columns = block columns j and K = 91 baby steps, accumulated into acc[j][g].
+struct DiagCacheHdr { uint64_t vectorLen, level, n, numModuli, rowSize; double scale; std::vector<uint8_t> baby, giant; long data_pos; };
+static int dc_open(sfg_ctx *ctx, const std::string &fn, FILE **fp, DiagCacheHdr &h) {
+    FILE *f = fopen(fn.c_str(), "rb");
+    if (!f) SFG_FAIL(ctx, "matmul_from_cache: cannot open %s", fn.c_str());          // os.Open panics in the reference (filestream.go:59-61)
+    unsigned char b[48];
+    auto le = [&](int k) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)b[8 * k + i] << (8 * i); return v; };
+    h.baby.assign(SFG_D, 0); h.giant.assign(SFG_D, 0);
+    if (fread(b, 1, 48, f) != 48 || fread(h.baby.data(), 1, SFG_D, f) != (size_t)SFG_D || fread(h.giant.data(), 1, SFG_D, f) != (size_t)SFG_D) { fclose(f); SFG_FAIL(ctx, "matmul_from_cache: short header in %s", fn.c_str()); }
+    h.vectorLen = le(0); h.level = le(1); uint64_t sb = le(2); memcpy(&h.scale, &sb, 8); h.n = le(3); h.numModuli = le(4); h.rowSize = le(5);
+    h.data_pos = ftell(f);
+    *fp = f; return 0;
+}
+// raw: [91 babies][jp][L][N] big-endian Montgomery words, present[baby*jp + j] != 0 where a plaintext was read.
+// panel[(j*91 + baby)][l][N/2] = canonical (or packed-limb) half row; asym counts words whose mirror differs (not a real-slot plaintext)
+__global__ void __launch_bounds__(256) k_cache_to_panel(const u64 *raw, const uint8_t *present, u64 *panel, int jp, int L, unsigned packed_mask,
+                                                        const u64 *r64inv, const ModConst *modc, unsigned long long *asym) {
+    const int N = SFG_N, n = N / 2;
+    const size_t row = blockIdx.x / (n / 256);                 // over [baby][j][l]
+    const int l = (int)(row % L); const size_t bj = row / L; const int j = (int)(bj % jp), baby = (int)(bj / jp);
+    const int x = (int)(blockIdx.x % (n / 256)) * 256 + threadIdx.x;
+    u64 *dst = panel + (((size_t)j * SFG_D + baby) * L + l) * n;
+    const bool packed = (packed_mask >> l) & 1u;
+    if (!present[bj]) { dst[x] = packed ? PACKED_ZERO : 0ULL; return; }
+    const u64 *src = raw + row * N;
+    const u64 be = src[x], bm = src[N - 1 - x];
+    if (be != bm) atomicAdd(asym, 1ULL);
+    const u64 w = __builtin_bswap64(be);
+    const u64 v = d_mulmod_u64(w % modc[l].qi, r64inv[l], modc[l].qi);          // ring.InvMForm: x * 2^-64 mod q
+    dst[x] = packed ? pack_limbs(v) : v;
+}
+
+extern "C" int sfg_diagcache_header(sfg_ctx *ctx, const char *prefix, int block_row, uint64_t hdr[6]) {
+    FILE *f = nullptr; DiagCacheHdr h;
+    SFG_TRY(dc_open(ctx, std::string(prefix) + "_" + std::to_string(block_row) + ".bin", &f, h));
+    fclose(f);
+    uint64_t sb; memcpy(&sb, &h.scale, 8);
+    hdr[0] = h.vectorLen; hdr[1] = h.level; hdr[2] = sb; hdr[3] = h.n; hdr[4] = h.numModuli; hdr[5] = h.rowSize;
+    return 0;
+}
+
+extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const char *prefix, int nbr, uint64_t *out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->phases.clear();
+    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul_from_cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    const int N = SFG_N, d = SFG_D, L = max_level;
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "matmul_from_cache: max_level out of range");
+    const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;
+    if (nl < L) SFG_FAIL(ctx, "matmul_from_cache: input level %d has fewer than max_level = %d moduli", in_level, max_level);
+    if (nbr < 1) SFG_FAIL(ctx, "matmul_from_cache: no block rows");
+    // headers of every block row first: shapes must agree, giant tables are united (matmult.go:1074-1078)
+    std::vector<DiagCacheHdr> hdrs(nbr); std::vector<FILE *> files(nbr, nullptr);
+    auto close_all = [&]() { for (FILE *f : files) if (f) fclose(f); };
+    for (int bi = 0; bi < nbr; bi++) {
+        if (dc_open(ctx, std::string(prefix) + "_" + std::to_string(bi) + ".bin", &files[bi], hdrs[bi])) { close_all(); return 1; }
+        const DiagCacheHdr &h = hdrs[bi];
+        if (h.n != (uint64_t)N || h.numModuli < (uint64_t)L || h.vectorLen != hdrs[0].vectorLen || h.vectorLen < 1 || h.rowSize != 4 + (1 + h.n * h.numModuli * 8) * h.vectorLen) {
+            close_all(); SFG_FAIL(ctx, "matmul_from_cache: %s_%d.bin does not match this ring (n = %llu, numModuli = %llu, vectorLen = %llu)", prefix, bi,
+                                  (unsigned long long)h.n, (unsigned long long)h.numModuli, (unsigned long long)h.vectorLen);
+        }
+    }
+    const int m_ct = (int)hdrs[0].vectorLen;
+    std::vector<uint8_t> giant_t(d, 0);
+    for (auto &h : hdrs) for (int g = 0; g < d; g++) giant_t[g] |= h.giant[g];
+    const size_t accw = (size_t)s * 2 * L * N, ctw = (size_t)2 * nl * N, prow = (size_t)N / 2, plw = (size_t)L * prow;
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) { close_all(); return 1; }
+    const size_t rowf = (size_t)nplanes * N;
+    const unsigned packed_mask = mac_dma_packed_mask(ctx, L);
+    int jp = (int)(ctx->cfg.acc_budget / ((size_t)d * accw * 8)); if (jp < 1) jp = 1; if (jp > m_ct) jp = m_ct;
+    u64 *a_row = nullptr, *rotc = nullptr, *acc = nullptr, *panel = nullptr, *raw_d = nullptr, *inv_d = nullptr; double *rotf = nullptr, *rotsum = nullptr;
+    uint8_t *present_d = nullptr; unsigned long long *asym_d = nullptr; u64 *raw_h = nullptr;
+    int rc = 0;
+    auto bail = [&](int r) { close_all(); if (raw_h) (void)hipHostFree(raw_h); return r; };
+    if (sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row) || sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc) ||
+        sfg_scratch(ctx, "mm.rotf", ((size_t)d + 3) * s * 2 * rowf * 8, (void **)&rotf) || sfg_scratch(ctx, "mm.rotsum", (size_t)2 * s * 2 * rowf * 8, (void **)&rotsum) ||
+        sfg_scratch(ctx, "mm.acc", (size_t)jp * d * accw * 8, (void **)&acc) || sfg_scratch(ctx, "dc.panel", (size_t)jp * d * plw * 8, (void **)&panel) ||
+        sfg_scratch(ctx, "dc.raw", (size_t)d * jp * L * N * 8 + (size_t)d * jp + 64 + 8 * SFG_MAXMOD, (void **)&raw_d)) return bail(1);
+    present_d = (uint8_t *)(raw_d + (size_t)d * jp * L * N);
+    asym_d = (unsigned long long *)(present_d + (((size_t)d * jp + 63) & ~(size_t)63)); inv_d = (u64 *)(asym_d + 1);
+    if (hipHostMalloc((void **)&raw_h, (size_t)d * jp * L * N * 8 + (size_t)d * jp, hipHostMallocDefault) != hipSuccess) { ctx->err = "matmul_from_cache: hipHostMalloc failed"; return bail(1); }
+    uint8_t *present_h = (uint8_t *)(raw_h + (size_t)d * jp * L * N);
+    {
+        u64 inv[SFG_MAXMOD] = {0};
+        for (int l = 0; l < L; l++) { const u64 q = ctx->q[l]; inv[l] = h_invmod((u64)((((u128)1) << 64) % q), q); }
+        if (hipMemcpyAsync(inv_d, inv, sizeof inv, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipMemsetAsync(asym_d, 0, 8, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "matmul_from_cache: setup copy failed"; return bail(1); }
+    }
+    std::vector<unsigned char> rec;
+    for (int ja = 0; ja < m_ct && !rc; ja += jp) {
+        const int jn = std::min(jp, m_ct - ja);
+        if (hipMemsetAsync(acc, 0, (size_t)jn * d * accw * 8, ctx->stream) != hipSuccess) { ctx->err = "matmul_from_cache: memset failed"; rc = 1; break; }
+        for (int bi = 0; bi < nbr && !rc; bi++) {
+            const DiagCacheHdr &h = hdrs[bi]; FILE *f = files[bi];
+            fseek(f, h.data_pos, SEEK_SET);
+            rec.resize(h.rowSize);
+            rc = build_rot_row_tab(ctx, (const u64 *)A, s, nl_in, nl, lev, L, nbr, bi, h.baby, a_row, rotc, true, rotf);       // matmult.go:1083-1119
+            if (!rc && hipMemsetAsync(rotf + (size_t)d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream) != hipSuccess) rc = 1;
+            if (!rc && packed_mask) rc = launch_rot_sum(ctx, rotf, (size_t)s * 2, d, L, rotsum);
+            int cur_giant = -1; bool any = false;
+            auto flush = [&]() -> int {                      // the buffered records of giant cur_giant -> panel -> one MAC launch
+                if (!any) return 0;
+                SFG_HIP(ctx, hipMemcpyAsync(raw_d, raw_h, (size_t)d * jn * L * N * 8, hipMemcpyHostToDevice, ctx->stream));
+                SFG_HIP(ctx, hipMemcpyAsync(present_d, present_h, (size_t)d * jn, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_cache_to_panel, dim3((unsigned)((size_t)d * jn * L * (N / 2 / 256))), dim3(256), 0, ctx->stream, raw_d, present_d, panel, jn, L, packed_mask,
+                                   inv_d, ctx->modc, asym_d);
+                SFG_HIP(ctx, hipGetLastError());
+                MacStrides st;
+                st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;
+                st.pt_k = plw; st.pt_n = (size_t)d * plw; st.pt_half = true; st.pt_packed = packed_mask != 0;     // panel[j][baby]
+                st.out_n = (size_t)d * accw; st.out_r = (size_t)L * N;                                           // acc[j][giant][r], column n = j
+                PhaseTimer t(ctx, "mac");
+                int r2 = launch_mac_dma(ctx, rotf, (size_t)s * 2, panel, acc + (size_t)cur_giant * accw, d, 2 * s, jn, L, 1, st, rotsum);
+                t.stop(1);
+                SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));               // raw_h is refilled next
+                any = false;
+                return r2;
+            };
+            while (!rc) {                                   // ReadDiag (filestream.go:247-282) until EOF
+                unsigned char l8[8];
+                if (fread(l8, 1, 8, f) != 8) break;
+                uint64_t len = 0; for (int i = 0; i < 8; i++) len |= (uint64_t)l8[i] << (8 * i);
+                if (len > h.rowSize || len < 4 || fread(rec.data(), 1, len, f) != len) { ctx->err = "matmul_from_cache: truncated record"; rc = 1; break; }
+                const int shift = (int)((uint32_t)rec[0] | (uint32_t)rec[1] << 8 | (uint32_t)rec[2] << 16 | (uint32_t)rec[3] << 24);
+                if (shift < 0 || shift >= SFG_SLOTS) { ctx->err = "matmul_from_cache: shift out of range"; rc = 1; break; }
+                const int giant = shift / d, baby = shift % d;
+                if (giant != cur_giant) { rc = flush(); if (rc) break; cur_giant = giant; memset(present_h, 0, (size_t)d * jn); }
+                size_t ptr = 4; const size_t plain_bytes = (size_t)h.n * h.numModuli * 8;
+                for (uint64_t j = 0; j < h.vectorLen; j++) {
+                    if (ptr >= len) { ctx->err = "matmul_from_cache: malformed record"; rc = 1; break; }
+                    const bool empty = rec[ptr++] == 1;
+                    if (empty) continue;
+                    if (ptr + plain_bytes > len) { ctx->err = "matmul_from_cache: malformed record"; rc = 1; break; }
+                    if ((int)j >= ja && (int)j < ja + jn) {
+                        memcpy(raw_h + ((size_t)baby * jn + (j - ja)) * L * N, rec.data() + ptr, (size_t)L * N * 8);      // the first L of numModuli rows
+                        present_h[(size_t)baby * jn + (j - ja)] = 1; any = true;
+                    }
+                    ptr += plain_bytes;
+                }
+            }
+            if (!rc) rc = flush();
+        }
+        if (!rc) rc = matmul_finalize(ctx, acc, s, max_level, jn, m_ct, ja, 0, d, &giant_t, 0, (u64 *)out);
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = 1;
+    }
+    unsigned long long asym = 0;
+    if (!rc && hipMemcpy(&asym, asym_d, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+    if (!rc && asym) { ctx->err = "matmul_from_cache: cached plaintexts are not mirror-symmetric (not encodings of real slot vectors)"; rc = 1; }
+    return bail(rc);
 }

@@ -487,8 +487,20 @@ inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, con
     {
         std::lock_guard<std::mutex> lk(cps->resident->mu);
         auto it = cps->resident->tab.find(cacheFilePrefix);
-        if (it == cps->resident->tab.end()) throw std::runtime_error("MatMult4StreamCompute: no resident matrix for prefix " + cacheFilePrefix);   // os.Open panics (filestream.go:59-61)
-        rg = it->second;
+        if (it != cps->resident->tab.end()) rg = it->second;
+    }
+    if (!rg.g) {
+        // not resident: an on-disk DiagCache written by the reference (or by a CPU-only party) under this prefix is consumed as is
+        FILE *probe = fopen(DiagCacheStream::FileName(cacheFilePrefix, 0).c_str(), "rb");
+        if (!probe) throw std::runtime_error("MatMult4StreamCompute: no resident matrix and no cache file for prefix " + cacheFilePrefix);   // os.Open panics (filestream.go:59-61)
+        fclose(probe);
+        const int s = (int)A.size(), inLevel = A[0][0].Level(), nbr = (int)A[0].size();
+        std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());
+        crypto::detail::DevBuf dA(cps, a.size() * 8), dO(cps, o.size() * 8);
+        cps->check(sfg_memcpy_h2d(cps->ctx, dA.p, a.data(), a.size() * 8), "MatMult4StreamCompute");
+        cps->check(sfg_matmul_from_cache(cps->ctx, dA.u(), s, inLevel, maxLevel, cacheFilePrefix.c_str(), nbr, dO.u()), "MatMult4StreamCompute");
+        cps->check(sfg_memcpy_d2h(cps->ctx, o.data(), dO.p, o.size() * 8), "MatMult4StreamCompute");
+        return unflatten(o, s, m_ct, maxLevel - 1, A[0][0].Scale() * cps->scale, cps->N());
     }
     const int s = (int)A.size(), inLevel = A[0][0].Level();
     std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());

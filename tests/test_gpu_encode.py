@@ -56,3 +56,23 @@ def test_encode_matches_quad_precision_oracle(env):
     got = ctx.encode_diags(block, 1234, 1, 2)
     want = oracle_plain(ring, block, 1234, 2, prec=0)
     assert np.array_equal(got[0], want)
+
+
+def test_encoder_near_tie_audit(env):
+    """sfg_ctx_encoder_near_ties: zero on ordinary vectors, non-zero when a coefficient sits exactly on a rounding tie
+    (constant slot vector c = (k + 1/2) / Delta: the only non-zero coefficient is p_0 = k + 1/2, rounded away from zero)"""
+    import ctypes as C
+    from sfgwas_amd import capi
+    ctx = env[0] if isinstance(env, tuple) else env
+    ctx.encoder_near_ties(reset=True)
+    rnd = np.random.default_rng(8)
+    vals = rnd.integers(0, 3, (2, ctx.slots)).astype(np.float64)
+    out = np.zeros((2, ctx.N), dtype=np.int64)
+    ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, vals.ctypes.data_as(C.POINTER(C.c_double)), 2, out.ctypes.data_as(C.POINTER(C.c_int64))), "encode")
+    assert ctx.encoder_near_ties() == 0
+    tie = np.full((1, ctx.slots), (12345 + 0.5) / 2.0 ** 34)
+    out1 = np.zeros((1, ctx.N), dtype=np.int64)
+    ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, tie.ctypes.data_as(C.POINTER(C.c_double)), 1, out1.ctypes.data_as(C.POINTER(C.c_int64))), "encode")
+    assert out1[0, 0] == 12346 and not out1[0, 1:].any()
+    assert ctx.encoder_near_ties(reset=True) >= 1
+    assert ctx.encoder_near_ties() == 0
