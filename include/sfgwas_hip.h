@@ -63,6 +63,7 @@ int sfg_malloc(sfg_ctx *ctx, void **dev_ptr, size_t bytes);
 int sfg_free(sfg_ctx *ctx, void *dev_ptr);
 int sfg_memcpy_h2d(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int sfg_memcpy_d2h(sfg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int sfg_memcpy_d2d(sfg_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);      /* stream-ordered */
 
 /* ---- ring substrate (lattigo ring.NTT / ring.InvNTT behind crypto/basics.go) ----
  * rows: nrows device rows of N words; mod_idx[r] selects the modulus (0..nq+np-1) of row r (host array) */
@@ -108,6 +109,10 @@ int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *ct_in_dev, uint64_t *ct_o
 int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
 /* C4: eval.Sub (crypto.CSub, basics.go:575-590): out = a - b */
 int sfg_ct_sub_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
+
+/* C6: crypto.DropLevel -> eval.DropLevelNew (basics.go:806-824; FlattenLevels :514-531 drops a matrix to its minimum level):
+ * in [nct][2][level_in+1][N] -> out [nct][2][level_out+1][N].  level_out == level_in copies (CopyNew); level_out > level_in fails. */
+int sfg_ct_drop_level_dev(sfg_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int nct, int level_in, int level_out);
 
 /* C4: eval.MultByConst / AddConst / AddNew(ct, plaintext) behind crypto.CMultConst, CMultConstRescale, AddConst, CAddConst,
  * AddPlain, CPAdd (basics.go:183-199, 472-497, 533-551, 592-611). scalars_host[level+1]: one canonical residue per modulus

@@ -38,6 +38,8 @@ def _sig(L):
         "sfg_free": (i, [vp, vp]),
         "sfg_memcpy_h2d": (i, [vp, vp, vp, sz]),
         "sfg_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "sfg_memcpy_d2d": (i, [vp, vp, vp, sz]),
+        "sfg_ct_drop_level_dev": (i, [vp, vp, vp, i, i, i]),
         "sfg_ntt_rows": (i, [vp, vp, i, C.POINTER(i)]),
         "sfg_intt_rows": (i, [vp, vp, i, C.POINTER(i)]),
         "sfg_mac_dev": (i, [vp, vp, vp, vp, i, i, i, i, i]),

@@ -96,6 +96,25 @@ __global__ void __launch_bounds__(256) k_colsums(const int8_t *g, size_t nrow, s
     if (sqsum) sqsum[j] = (double)s2;
 }
 
+// C6: crypto.DropLevel / eval.DropLevelNew (basics.go:806-824): keep the first level_out+1 moduli rows of each polynomial.
+// level_out == level_in is the CopyNew branch; level_out > level_in fails like the reference (log.Fatalf).
+extern "C" int sfg_ct_drop_level_dev(sfg_ctx *ctx, const uint64_t *in, uint64_t *out, int nct, int level_in, int level_out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (level_out > level_in) SFG_FAIL(ctx, "DropLevel: requested level %d when input is %d", level_out, level_in);
+    if (level_out < 0 || level_in >= ctx->nq || nct < 0) SFG_FAIL(ctx, "DropLevel: level out of range");
+    if (!nct) return 0;
+    const int nl = level_out + 1, nl_in = level_in + 1;
+    if (nl == nl_in) { SFG_HIP(ctx, hipMemcpyAsync(out, in, (size_t)nct * 2 * nl * SFG_N * 8, hipMemcpyDeviceToDevice, ctx->stream)); return 0; }
+    hipLaunchKernelGGL(k_drop_level, dim3((unsigned)((size_t)nct * 2 * nl * (SFG_N / 256))), dim3(256), 0, ctx->stream, (const u64 *)in, (u64 *)out, nl_in, nl);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+extern "C" int sfg_memcpy_d2d(sfg_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
 // ---------------------------------------------------------------- genotype residency
 extern "C" int sfg_geno_upload(sfg_ctx *ctx, const int8_t *host, size_t nrow, size_t ncol, size_t ld, sfg_geno **out) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));

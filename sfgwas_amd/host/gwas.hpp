@@ -286,6 +286,118 @@ inline Ciphertext InnerProd(CryptoParams *cps, const CipherVector &X, const Ciph
     return InnerSumAll(cps, CMult(cps, X, Y, qi));
 }
 
+
+// ================================================================ device-resident ciphertext vectors / matrices
+// The functions above move every operand over PCIe per call (they mirror the Go signatures one to one).  The types below keep
+// ciphertexts in HBM between operations, so that the code AROUND the two hot products of a power iteration - lazy
+// standardisation (matmult.go:27-116), A * (A^T B) (matmult.go:121-194), InnerProd / Mask chains of the QR - runs without host
+// traffic between ops.  A DevCipherVector is n ciphertexts of one level, contiguous: [n][2][level+1][N].
+struct DevCipherVector {
+    CryptoParams *cps = nullptr;
+    std::shared_ptr<detail::DevBuf> buf; size_t off = 0;      // word offset into buf (views of a matrix row share the buffer)
+    size_t n = 0; int level = 0; double scale = 0;
+    uint64_t *ptr(size_t i = 0) const { return buf->u() + off + i * detail::ctWords(cps, level); }
+    size_t size() const { return n; }
+};
+inline DevCipherVector NewDevCipherVector(CryptoParams *cps, size_t n, int level, double scale) {
+    DevCipherVector v; v.cps = cps; v.n = n; v.level = level; v.scale = scale;
+    v.buf = std::make_shared<detail::DevBuf>(cps, n * detail::ctWords(cps, level) * 8);
+    return v;
+}
+inline DevCipherVector ToDevice(CryptoParams *cps, const CipherVector &X) {
+    DevCipherVector v = NewDevCipherVector(cps, X.size(), X[0].level, X[0].scale);
+    detail::upload(cps, X, X[0].level, *v.buf, false, X.size());
+    return v;
+}
+inline CipherVector ToHost(const DevCipherVector &v) {
+    CipherVector out(v.n); const size_t w = detail::ctWords(v.cps, v.level);
+    for (size_t i = 0; i < v.n; i++) { out[i].level = v.level; out[i].scale = v.scale; out[i].data.resize(w); v.cps->check(sfg_memcpy_d2h(v.cps->ctx, out[i].data.data(), v.ptr(i), w * 8), "d2h"); }
+    return out;
+}
+// s x ncols ciphertexts, one buffer [s][ncols][2][level+1][N]: exactly the layout the product entry points take and return
+struct DevCipherMatrix {
+    CryptoParams *cps = nullptr; std::shared_ptr<detail::DevBuf> buf; size_t rows = 0, cols = 0; int level = 0; double scale = 0;
+    DevCipherVector row(size_t i) const { DevCipherVector v; v.cps = cps; v.buf = buf; v.off = i * cols * detail::ctWords(cps, level); v.n = cols; v.level = level; v.scale = scale; return v; }
+};
+inline DevCipherMatrix NewDevCipherMatrix(CryptoParams *cps, size_t rows, size_t cols, int level, double scale) {
+    DevCipherMatrix m; m.cps = cps; m.rows = rows; m.cols = cols; m.level = level; m.scale = scale;
+    m.buf = std::make_shared<detail::DevBuf>(cps, rows * cols * detail::ctWords(cps, level) * 8);
+    return m;
+}
+inline DevCipherMatrix ToDevice(CryptoParams *cps, const CipherMatrix &A) {
+    DevCipherMatrix m = NewDevCipherMatrix(cps, A.size(), A[0].size(), A[0][0].level, A[0][0].scale);
+    for (size_t i = 0; i < A.size(); i++) { DevCipherVector r = m.row(i); const size_t w = detail::ctWords(cps, m.level);
+        for (size_t j = 0; j < A[i].size(); j++) { if (A[i][j].level != m.level) throw std::runtime_error("ToDevice: mixed levels (FlattenLevels first)"); cps->check(sfg_memcpy_h2d(cps->ctx, r.ptr(j), A[i][j].data.data(), w * 8), "h2d"); } }
+    return m;
+}
+inline CipherMatrix ToHost(const DevCipherMatrix &m) { CipherMatrix out(m.rows); for (size_t i = 0; i < m.rows; i++) out[i] = ToHost(m.row(i)); return out; }
+
+// crypto.DropLevel on device (basics.go:806-824)
+inline DevCipherVector DropLevelDev(const DevCipherVector &X, int outLevel) {
+    DevCipherVector o = NewDevCipherVector(X.cps, X.n, outLevel, X.scale);
+    X.cps->check(sfg_ct_drop_level_dev(X.cps->ctx, X.ptr(), o.ptr(), (int)X.n, X.level, outLevel), "DropLevel");
+    return o;
+}
+namespace detail {
+// n copies of one ciphertext (the length-1 broadcast of CMult / CSub), device to device
+inline DevCipherVector broadcast(const DevCipherVector &x, size_t n) {
+    if (x.n == n) return x;
+    if (x.n != 1) throw std::runtime_error("evaluator op: vector lengths differ");
+    DevCipherVector o = NewDevCipherVector(x.cps, n, x.level, x.scale); const size_t w = ctWords(x.cps, x.level);
+    for (size_t i = 0; i < n; i++) x.cps->check(sfg_memcpy_d2d(x.cps->ctx, o.ptr(i), x.ptr(), w * 8), "d2d");
+    return o;
+}
+// eval.Rescale(ct, params.Scale(), ct) on a device vector: while scale >= threshold * q_level / 2 divide by the last modulus
+inline DevCipherVector rescaleDev(DevCipherVector x, double threshold, const std::vector<uint64_t> &qi) {
+    if (x.level == 0) throw std::runtime_error("cannot Rescale: input Ciphertext already at level 0");
+    while (x.level != 0 && x.scale >= threshold * (double)qi[x.level] / 2) {
+        DevCipherVector o = NewDevCipherVector(x.cps, x.n, x.level - 1, x.scale / (double)qi[x.level]);
+        x.cps->check(sfg_ct_rescale_dev(x.cps->ctx, x.ptr(), o.ptr(), (int)x.n, x.level), "Rescale");
+        x = o;
+    }
+    return x;
+}
+}  // namespace detail
+// lattigo binary ops work at the smaller of the two levels
+inline void alignLevels(DevCipherVector &a, DevCipherVector &b) {
+    const int l = std::min(a.level, b.level);
+    if (a.level != l) a = DropLevelDev(a, l);
+    if (b.level != l) b = DropLevelDev(b, l);
+}
+inline DevCipherVector CMultDev(CryptoParams *cps, DevCipherVector X, DevCipherVector Y, const std::vector<uint64_t> &qi) {     // basics.go:386-427
+    const size_t n = std::max(X.n, Y.n);
+    alignLevels(X, Y);
+    X = detail::broadcast(X, n); Y = detail::broadcast(Y, n);
+    DevCipherVector o = NewDevCipherVector(cps, n, X.level, X.scale * Y.scale);
+    cps->check(sfg_ct_mulrelin_dev(cps->ctx, X.ptr(), Y.ptr(), o.ptr(), (int)n, X.level), "CMult");
+    return detail::rescaleDev(o, cps->scale, qi);
+}
+inline DevCipherVector CMultScalarDev(CryptoParams *cps, const DevCipherVector &X, const DevCipherVector &ct, const std::vector<uint64_t> &qi) { return CMultDev(cps, X, ct, qi); }   // :553-566
+inline DevCipherVector CAddSubDev(CryptoParams *cps, DevCipherVector X, DevCipherVector Y, bool sub) {                               // :568-590, eval.Sub with a broadcast operand
+    const size_t n = std::max(X.n, Y.n);
+    alignLevels(X, Y);
+    X = detail::broadcast(X, n); Y = detail::broadcast(Y, n);
+    DevCipherVector o = NewDevCipherVector(cps, n, X.level, X.scale);
+    cps->check((sub ? sfg_ct_sub_dev : sfg_ct_add_dev)(cps->ctx, X.ptr(), Y.ptr(), o.ptr(), (int)n, X.level), "CAdd/CSub");
+    return o;
+}
+inline DevCipherVector InnerSumAllDev(CryptoParams *cps, const DevCipherVector &X) {                                             // :278-292
+    DevCipherVector o = NewDevCipherVector(cps, 1, X.level, X.scale);
+    cps->check(sfg_ct_innersum_dev(cps->ctx, X.ptr(), (int)X.n, X.level, o.ptr()), "InnerSumAll");
+    return o;
+}
+inline DevCipherVector InnerProdDev(CryptoParams *cps, const DevCipherVector &X, const DevCipherVector &Y, const std::vector<uint64_t> &qi) { return InnerSumAllDev(cps, CMultDev(cps, X, Y, qi)); }   // :274-276
+// MaskTrunc on one resident ciphertext (basics.go:110-127): the 0/1 mask is encoded on the device at the ciphertext's level
+inline DevCipherVector MaskTruncDev(CryptoParams *cps, const DevCipherVector &ct, int Nkeep, const std::vector<uint64_t> &qi) {
+    if (Nkeep == cps->GetSlots()) return ct;
+    std::vector<double> m(cps->GetSlots(), 0.0);
+    for (int i = 0; i < Nkeep; i++) m[i] = 1.0;
+    detail::DevBuf pt(cps, (size_t)(ct.level + 1) * cps->N() * 8);
+    cps->check(sfg_encode_vectors_dev(cps->ctx, m.data(), 1, ct.level, pt.u()), "MaskTrunc");
+    DevCipherVector o = NewDevCipherVector(cps, ct.n, ct.level, ct.scale * cps->scale);
+    cps->check(sfg_ct_mul_plain_dev(cps->ctx, ct.ptr(), pt.u(), 0, o.ptr(), (int)ct.n, ct.level), "MaskTrunc");
+    return detail::rescaleDev(o, cps->scale, qi);
+}
 }  // namespace crypto
 
 namespace gwas {
@@ -514,6 +626,89 @@ inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, con
     return unflatten(o, s, m_ct, maxLevel - 1, A[0][0].Scale() * cps->scale, cps->N());
 }
 
+
+// ---------------------------------------------------------------- device-resident forms of the product and of its wrappers
+// MatMult4StreamCompute on a resident matrix (matmult.go:1043): A [s][nbr] resident, result [s][m_ct] resident at level maxLevel-1
+inline crypto::DevCipherMatrix MatMult4StreamComputeDev(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &A, int maxLevel, const std::string &cacheFilePrefix, int m_ct) {
+    crypto::ResidentGeno rg;
+    { std::lock_guard<std::mutex> lk(cps->resident->mu); auto it = cps->resident->tab.find(cacheFilePrefix);
+      if (it == cps->resident->tab.end()) throw std::runtime_error("MatMult4StreamCompute: no resident matrix for prefix " + cacheFilePrefix); rg = it->second; }
+    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, A.rows, (size_t)m_ct, maxLevel - 1, A.scale * cps->scale);
+    cps->check(sfg_matmul_resident_dev(cps->ctx, A.buf->u(), (int)A.rows, A.level, maxLevel, rg.g, rg.flags, out.buf->u()), "MatMult4StreamCompute");
+    return out;
+}
+// QXLazyNormStream (matmult.go:27-77) = local part 1, BootstrapMatAll (network, stays in Go), local part 2.
+//   part 1: QS[i] = CMult(Q[i], XStdInv);  out = MatMult4StreamCompute(QS, 5, Xcache)                         (:36-42)
+//   part 2: QSm[i] = InnerProd(QS[i], XMean);  out[i][j] = MaskTrunc(out[i][j] - QSm[i], N_j)                 (:47-71)
+struct QXLazyNormState { crypto::DevCipherMatrix QS; };
+inline crypto::DevCipherMatrix QXLazyNormStreamLocal1(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &Q, const std::string &Xcachefile, int m_ct,
+                                                      const crypto::DevCipherVector &XStdInv, const std::vector<uint64_t> &qi, QXLazyNormState &st) {
+    crypto::DevCipherVector first = crypto::CMultDev(cps, Q.row(0), XStdInv, qi);
+    st.QS = crypto::NewDevCipherMatrix(cps, Q.rows, Q.cols, first.level, first.scale);
+    const size_t roww = Q.cols * crypto::detail::ctWords(cps, first.level);
+    for (size_t i = 0; i < Q.rows; i++) {
+        crypto::DevCipherVector r = i ? crypto::CMultDev(cps, Q.row(i), XStdInv, qi) : first;
+        cps->check(sfg_memcpy_d2d(cps->ctx, st.QS.row(i).ptr(), r.ptr(), roww * 8), "d2d");
+    }
+    return MatMult4StreamComputeDev(cps, st.QS, 5, Xcachefile, m_ct);
+}
+inline crypto::DevCipherMatrix QXLazyNormStreamLocal2(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &outBootstrapped, const QXLazyNormState &st,
+                                                      const crypto::DevCipherVector &XMean, int numInd, const std::vector<uint64_t> &qi) {
+    const int slots = cps->GetSlots();
+    std::vector<std::vector<crypto::DevCipherVector>> cells(outBootstrapped.rows);
+    int outLevel = -1; double outScale = 0;
+    for (size_t i = 0; i < outBootstrapped.rows; i++) {
+        crypto::DevCipherVector QSm = crypto::InnerProdDev(cps, st.QS.row(i), XMean, qi);                     // value in all slots
+        crypto::DevCipherVector d = crypto::CAddSubDev(cps, outBootstrapped.row(i), QSm, true);              // eval.Sub(out[i][j], QSm[i], out[i][j])
+        for (size_t j = 0; j < d.n; j++) {
+            const int Nk = j + 1 < d.n ? slots : ((numInd - 1) % slots) + 1;
+            crypto::DevCipherVector one = d; one.off = d.off + j * crypto::detail::ctWords(cps, d.level); one.n = 1;
+            cells[i].push_back(crypto::MaskTruncDev(cps, one, Nk, qi));
+            if (j + 1 == d.n) { outLevel = cells[i].back().level; outScale = cells[i].back().scale; }
+        }
+    }
+    // MaskTrunc returns full-slot ciphertexts unchanged (one level higher than the masked tail, as in the reference): gather at the
+    // common (lowest) level only when the caller asks for a flat matrix
+    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, outBootstrapped.rows, outBootstrapped.cols, outLevel, outScale);
+    for (size_t i = 0; i < out.rows; i++) for (size_t j = 0; j < out.cols; j++) {
+        crypto::DevCipherVector c = cells[i][j];
+        if (c.level != outLevel) c = crypto::DropLevelDev(c, outLevel);
+        cps->check(sfg_memcpy_d2d(cps->ctx, out.row(i).ptr(j), c.ptr(), crypto::detail::ctWords(cps, outLevel) * 8), "d2d");
+    }
+    return out;
+}
+// QXtLazyNormStream (matmult.go:83-116): part 1 = the product (:91), part 2 after the bootstrap (:95-111):
+//   out[i][j] = CMult(out[i][j] - CMultScalar(XMean, InnerSumAll(Q[i]))[j], XStdInv[j])
+inline crypto::DevCipherMatrix QXtLazyNormStreamLocal2(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &outBootstrapped, const crypto::DevCipherMatrix &Q,
+                                                       const crypto::DevCipherVector &XMean, const crypto::DevCipherVector &XStdInv, const std::vector<uint64_t> &qi) {
+    std::vector<crypto::DevCipherVector> rows;
+    for (size_t i = 0; i < outBootstrapped.rows; i++) {
+        crypto::DevCipherVector rowSum = crypto::InnerSumAllDev(cps, Q.row(i));
+        crypto::DevCipherVector Q1m = crypto::CMultScalarDev(cps, XMean, rowSum, qi);
+        crypto::DevCipherVector d = crypto::CAddSubDev(cps, outBootstrapped.row(i), Q1m, true);
+        rows.push_back(crypto::CMultDev(cps, d, XStdInv, qi));
+    }
+    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, rows.size(), rows[0].n, rows[0].level, rows[0].scale);
+    for (size_t i = 0; i < rows.size(); i++) cps->check(sfg_memcpy_d2d(cps->ctx, out.row(i).ptr(), rows[i].ptr(), rows[i].n * crypto::detail::ctWords(cps, rows[i].level) * 8), "d2d");
+    return out;
+}
+// DCMatMulAAtB (matmult.go:121-156), column c of A: local part 1 = cTQloc[j] = InnerSumAll(innerFn(A[c], B, j)) with innerFn = CMult
+// (the inner function qrfact.go / assoc.go pass), AggregateCVec (network, stays in Go), local part 2 = out[j] += CMult(A[c], {cTQ[j]})
+inline crypto::DevCipherVector DCMatMulAAtBLocal1(crypto::CryptoParams *cps, const crypto::DevCipherVector &Ac, const crypto::DevCipherMatrix &B, const std::vector<uint64_t> &qi) {
+    std::vector<crypto::DevCipherVector> parts;
+    for (size_t j = 0; j < B.rows; j++) parts.push_back(crypto::InnerSumAllDev(cps, crypto::CMultDev(cps, Ac, B.row(j), qi)));
+    crypto::DevCipherVector out = crypto::NewDevCipherVector(cps, parts.size(), parts[0].level, parts[0].scale);
+    for (size_t j = 0; j < parts.size(); j++) cps->check(sfg_memcpy_d2d(cps->ctx, out.ptr(j), parts[j].ptr(), crypto::detail::ctWords(cps, out.level) * 8), "d2d");
+    return out;
+}
+inline void DCMatMulAAtBLocal2(crypto::CryptoParams *cps, const crypto::DevCipherVector &Ac, const crypto::DevCipherVector &cTQ, std::vector<crypto::DevCipherVector> &out,
+                               const std::vector<uint64_t> &qi) {
+    for (size_t j = 0; j < cTQ.n; j++) {
+        crypto::DevCipherVector one = cTQ; one.off = cTQ.off + j * crypto::detail::ctWords(cps, cTQ.level); one.n = 1;
+        crypto::DevCipherVector ccTQ = crypto::CMultDev(cps, Ac, one, qi);
+        out[j] = out[j].n ? crypto::CAddSubDev(cps, out[j], ccTQ, false) : ccTQ;                             // out starts as CZeroMat (fresh zero encryptions, added by the Go side)
+    }
+}
 }  // namespace gwas
 
 namespace mpc {

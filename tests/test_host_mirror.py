@@ -167,3 +167,122 @@ def test_two_host_threads_share_one_key_set(tmp_path):
         want, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, L, geno, square=bool(square), enc_prec=1)
         got = np.fromfile(tmp_path / f"out_thr{t}.bin", dtype=np.uint64).reshape(want.shape)
         assert np.array_equal(got, want), f"thread {t}"
+
+
+# ------------------------------------------------------------------------------------------------ A12 / A13 compositions
+def _orc_cmult(ring, level, scale, a, b, rlk, thr=2.0 ** 34):
+    """crypto.CMult on two ciphertexts: MulRelinNew + eval.Rescale(ct, params.Scale(), ct); returns (ct, level, scale)"""
+    mr = np.zeros_like(a)
+    ol.lib().orc_mulrelin(ring.h, level, ol.p64(np.ascontiguousarray(a)), ol.p64(np.ascontiguousarray(b)), ol.p64(rlk), ol.p64(mr))
+    return _orc_rescale_loop(ring, mr, level, scale, thr)
+
+
+def _orc_rescale_loop(ring, ct, level, scale, thr=2.0 ** 34):
+    while level != 0 and scale >= thr * float(ring.moduli[level]) / 2:
+        rs = np.zeros((2, level, ring.N), dtype=np.uint64)
+        ol.lib().orc_rescale(ring.h, level, ol.p64(np.ascontiguousarray(ct)), ol.p64(rs))
+        scale /= float(ring.moduli[level]); level -= 1; ct = rs
+    return ct, level, scale
+
+
+def _orc_innersum(ring, keys, level, cts):
+    out = np.zeros((2, level + 1, ring.N), dtype=np.uint64)
+    cts = np.ascontiguousarray(np.stack(cts))
+    assert ol.lib().orc_innersum_all(ring.h, keys.h, level, ol.p64(cts), cts.shape[0], ol.p64(out)) == 0
+    return out
+
+
+def _orc_sub(ring, level, a, b):
+    out = np.zeros((2, level + 1, ring.N), dtype=np.uint64)
+    ol.lib().orc_ct_addsub(ring.h, level, ol.p64(np.ascontiguousarray(a)), ol.p64(np.ascontiguousarray(b)), 1, ol.p64(out))
+    return out
+
+
+def _drop(ct, level):
+    return np.ascontiguousarray(ct[:, :level + 1])
+
+
+@pytest.mark.gpu
+def test_lazy_norm_and_aatb_compositions_stay_on_device_and_match_the_oracle(tmp_path):
+    """QXLazyNormStream / QXtLazyNormStream (matmult.go:27-116) and a DCMatMulAAtB column step (matmult.go:121-156) composed from
+    device-resident ops in the host mirror, against the same compositions of oracle functions"""
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_lazynorm_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rnd = np.random.default_rng(77)
+    nrow, ncol, s, qlevel, slots, d, SC = 45, 33, 2, 7, 8192, 91, 2.0 ** 34
+    geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+    geno.tofile(tmp_path / "geno.bin")
+    steps = set()
+    for (r, c) in [(nrow, ncol), (ncol, nrow)]:
+        for sh in list(range(r)) + list(range(slots - c + 1, slots)):
+            if sh % d:
+                steps.add(sh % d)
+            if sh // d:
+                steps.add((sh // d) * d)
+    k = 1
+    while k < slots:                                          # InnerSumAll: left rotations by 1, 2, 4, .. (basics.go:236-246)
+        steps.add(k); k *= 2
+    blob = [np.array([len(steps)], dtype=np.uint64)]
+    for k in sorted(steps):
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 300 + k)
+        keys.add(g, key)
+        blob += [np.array([g], dtype=np.uint64), key.reshape(-1)]
+    np.concatenate(blob).tofile(tmp_path / "keys.bin")
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    rlk = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 999)
+    rlk.tofile(tmp_path / "rlk.bin")
+    Q = np.stack([np.stack([ring.fill_uniform(qlevel, 50 + i)]) for i in range(s)])          # [s][nbr=1]
+    Q2 = np.stack([np.stack([ring.fill_uniform(qlevel, 60 + i)]) for i in range(s)])         # [s][m_ct=1]
+    XStdInv, XMean = ring.fill_uniform(qlevel, 70), ring.fill_uniform(qlevel - 1, 71)
+    XMean2, XStdInv2 = ring.fill_uniform(qlevel, 72), ring.fill_uniform(qlevel, 73)
+    for name, a in [("Q", Q), ("Q2", Q2), ("XStdInv", XStdInv), ("XMean", XMean), ("XMean2", XMean2), ("XStdInv2", XStdInv2)]:
+        a.tofile(tmp_path / (name + ".bin"))
+    (tmp_path / "case.txt").write_text(f"{nrow} {ncol} {s} {qlevel}\n")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr
+    # ---- oracle: QXLazyNormStream
+    QS = [_orc_cmult(ring, qlevel, SC * SC, Q[i, 0], XStdInv, rlk) for i in range(s)]
+    lvl, sc = QS[0][1], QS[0][2]
+    assert lvl == qlevel - 1
+    QSm = np.stack([np.stack([q[0]]) for q in QS])
+    prod, _, _ = ol.matmult4stream(ring, keys, SC, QSm, lvl, 5, geno, enc_prec=1)
+    got1 = np.fromfile(tmp_path / "qx_part1.bin", dtype=np.uint64).reshape(prod.shape)
+    assert np.array_equal(got1, prod)
+    mask = np.zeros(ring.slots); mask[:((ncol - 1) % slots) + 1] = 1.0
+    fin = []
+    for i in range(s):
+        cm, l2, s2 = _orc_cmult(ring, lvl, sc * SC, QS[i][0], XMean, rlk)
+        qsm = _orc_innersum(ring, keys, l2, [cm])
+        dct = _orc_sub(ring, 4, prod[i, 0], _drop(qsm, 4))
+        mp = np.zeros_like(dct)
+        mpt = ring.encode_ntt(mask, SC, 5)
+        ol.lib().orc_mul_plain(ring.h, 4, ol.p64(dct), ol.p64(mpt), ol.p64(mp))
+        fin.append(_orc_rescale_loop(ring, mp, 4, sc * SC * SC)[0])
+    want = np.stack(fin)
+    got = np.fromfile(tmp_path / "qx_final.bin", dtype=np.uint64).reshape(want.shape)
+    assert np.array_equal(got, want), "QXLazyNormStream local composition"
+    # ---- oracle: QXtLazyNormStream
+    prod2, _, _ = ol.matmult4stream(ring, keys, SC, Q2, qlevel, 5, np.ascontiguousarray(geno.T), enc_prec=1)
+    fin2 = []
+    for i in range(s):
+        row_sum = _orc_innersum(ring, keys, qlevel, [Q2[i, 0]])
+        q1m, l3, s3 = _orc_cmult(ring, qlevel, SC * SC, XMean2, row_sum, rlk)
+        dct = _orc_sub(ring, 4, prod2[i, 0], _drop(q1m, 4))
+        fin2.append(_orc_cmult(ring, 4, SC * SC * SC, dct, _drop(XStdInv2, 4), rlk)[0])
+    want2 = np.stack(fin2)
+    got2 = np.fromfile(tmp_path / "qxt_final.bin", dtype=np.uint64).reshape(want2.shape)
+    assert np.array_equal(got2, want2), "QXtLazyNormStream local composition"
+    # ---- oracle: DCMatMulAAtB column step, innerFn = CMult(A[c], B[j])
+    ctq = []
+    for j in range(s):
+        cm, l4, s4 = _orc_cmult(ring, qlevel, SC * SC, Q[0, 0], Q[j, 0], rlk)
+        ctq.append(_orc_innersum(ring, keys, l4, [cm]))
+    got_ctq = np.fromfile(tmp_path / "aatb_ctq.bin", dtype=np.uint64).reshape(np.stack(ctq).shape)
+    assert np.array_equal(got_ctq, np.stack(ctq)), "DCMatMulAAtB: cTQloc"
+    outs = [_orc_cmult(ring, l4, SC * s4, _drop(Q[0, 0], l4), ctq[j], rlk)[0] for j in range(s)]
+    got_out = np.fromfile(tmp_path / "aatb_out.bin", dtype=np.uint64).reshape(np.stack(outs).shape)
+    assert np.array_equal(got_out, np.stack(outs)), "DCMatMulAAtB: out[j] += CMult(A[c], cTQ[j])"
