@@ -398,6 +398,26 @@ inline DevCipherVector MaskTruncDev(CryptoParams *cps, const DevCipherVector &ct
     cps->check(sfg_ct_mul_plain_dev(cps->ctx, ct.ptr(), pt.u(), 0, o.ptr(), (int)ct.n, ct.level), "MaskTrunc");
     return detail::rescaleDev(o, cps->scale, qi);
 }
+// ct x plaintext mask built from real slot values (one vector of `slots` doubles per ciphertext, or a single one for all):
+// MulRelinNew(mask, ct) + Rescale - the shared tail of Mask / CMask / CPMult (basics.go:110-172, 429-470, 673-693)
+inline DevCipherVector mulByRealVectorsDev(CryptoParams *cps, const DevCipherVector &X, const std::vector<double> &vals, const std::vector<uint64_t> &qi) {
+    const size_t slots = (size_t)cps->GetSlots(), nvec = vals.size() / slots, pw = (size_t)(X.level + 1) * cps->N();
+    if (nvec != 1 && nvec != X.n) throw std::runtime_error("CPMult: plaintext / ciphertext vector lengths differ");
+    detail::DevBuf pt(cps, nvec * pw * 8);
+    cps->check(sfg_encode_vectors_dev(cps->ctx, vals.data(), (int)nvec, X.level, pt.u()), "EncodeFloatVector");
+    DevCipherVector o = NewDevCipherVector(cps, X.n, X.level, X.scale * cps->scale);
+    cps->check(sfg_ct_mul_plain_dev(cps->ctx, X.ptr(), pt.u(), nvec == 1 ? 0 : pw, o.ptr(), (int)X.n, X.level), "CPMult");
+    return detail::rescaleDev(o, cps->scale, qi);
+}
+inline DevCipherVector MaskDev(CryptoParams *cps, const DevCipherVector &ct, int index, bool keepRest, const std::vector<uint64_t> &qi) {       // basics.go:150-172 on one ct
+    std::vector<double> m(cps->GetSlots(), keepRest ? 1.0 : 0.0); m[index] = keepRest ? 0.0 : 1.0;
+    return mulByRealVectorsDev(cps, ct, m, qi);
+}
+inline DevCipherVector CMaskDev(CryptoParams *cps, const DevCipherVector &cv, int index, bool keepRest, const std::vector<uint64_t> &qi) {      // basics.go:673-693
+    std::vector<double> m((size_t)cps->GetSlots() * cv.n, keepRest ? 1.0 : 0.0); m[index] = keepRest ? 0.0 : 1.0;
+    return mulByRealVectorsDev(cps, cv, m, qi);
+}
+inline DevCipherVector viewOne(const DevCipherVector &v, size_t j) { DevCipherVector o = v; o.off = v.off + j * detail::ctWords(v.cps, v.level); o.n = 1; return o; }
 }  // namespace crypto
 
 namespace gwas {
@@ -708,6 +728,44 @@ inline void DCMatMulAAtBLocal2(crypto::CryptoParams *cps, const crypto::DevCiphe
         crypto::DevCipherVector ccTQ = crypto::CMultDev(cps, Ac, one, qi);
         out[j] = out[j].n ? crypto::CAddSubDev(cps, out[j], ccTQ, false) : ccTQ;                             // out starts as CZeroMat (fresh zero encryptions, added by the Go side)
     }
+}
+
+// ---------------------------------------------------------------- A14: ciphertext x ciphertext matrix helpers of the logistic path
+// (matmult.go:1915-2066, called from assoc.go:992-1170).  The reference adds every term onto crypto.InitEncryptedMatrix (fresh
+// encryptions of zero); these return the deterministic sums, the Go shim keeps adding them onto its zero matrix.
+// CMultMatInnerProd (:1915-1944): result[r][0] = sum_c Mask(InnerProd(M[r], N[c]), c, false)
+inline std::vector<crypto::DevCipherVector> CMultMatInnerProdDev(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &M, const crypto::DevCipherMatrix &Nm, const std::vector<uint64_t> &qi) {
+    std::vector<crypto::DevCipherVector> result(M.rows);
+    for (size_t r = 0; r < M.rows; r++) for (size_t c = 0; c < Nm.rows; c++) {
+        crypto::DevCipherVector t = crypto::MaskDev(cps, crypto::InnerProdDev(cps, M.row(r), Nm.row(c), qi), (int)c, false, qi);
+        result[r] = result[r].n ? crypto::CAddSubDev(cps, t, result[r], false) : t;
+    }
+    return result;
+}
+// CMultMatInnerProdVector (:1947-1986): M rows and N are first multiplied by the 0/1 mask of the first MCols slots; result[0] = sum_k Mask(InnerProd(M[k]*mask, N*mask), k, false)
+inline crypto::DevCipherVector CMultMatInnerProdVectorDev(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &M, const crypto::DevCipherVector &Nv, int MCols, const std::vector<uint64_t> &qi) {
+    std::vector<double> maskClear((size_t)cps->GetSlots() * M.cols, 0.0);
+    for (int i = 0; i < MCols; i++) maskClear[i] = 1.0;
+    crypto::DevCipherVector Nmasked = crypto::mulByRealVectorsDev(cps, Nv, maskClear, qi), result;
+    for (size_t k = 0; k < M.rows; k++) {
+        crypto::DevCipherVector Mcur = crypto::mulByRealVectorsDev(cps, M.row(k), maskClear, qi);
+        crypto::DevCipherVector t = crypto::MaskDev(cps, crypto::InnerProdDev(cps, Mcur, Nmasked, qi), (int)k, false, qi);
+        result = result.n ? crypto::CAddSubDev(cps, t, result, false) : t;
+    }
+    return result;
+}
+// CMultMatColTimesColToCol (:1989-2027) and ...RowToCol (:2030-2066): result[c] = sum_k CMult(replicate(InnerSumAll(CMask(sel, idx, false))), M[k])
+// with (sel, idx) = (N[c], k) resp. (N[k], c)
+inline std::vector<crypto::DevCipherVector> CMultMatColTimesToColDev(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &M, const crypto::DevCipherMatrix &Nm, int numColsOut, bool rowForm,
+                                                                     const std::vector<uint64_t> &qi) {
+    std::vector<crypto::DevCipherVector> result(numColsOut);
+    for (size_t k = 0; k < M.rows; k++) for (int c = 0; c < numColsOut; c++) {
+        crypto::DevCipherVector elemRep = rowForm ? crypto::CMaskDev(cps, Nm.row(k), c, false, qi) : crypto::CMaskDev(cps, Nm.row(c), (int)k, false, qi);
+        crypto::DevCipherVector elemRepCiph = crypto::InnerSumAllDev(cps, elemRep);
+        crypto::DevCipherVector multi = crypto::CMultDev(cps, elemRepCiph, M.row(k), qi);        // length-1 broadcast over the cts of M[k]
+        result[c] = result[c].n ? crypto::CAddSubDev(cps, multi, result[c], false) : multi;
+    }
+    return result;
 }
 }  // namespace gwas
 

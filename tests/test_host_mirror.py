@@ -286,3 +286,109 @@ def test_lazy_norm_and_aatb_compositions_stay_on_device_and_match_the_oracle(tmp
     outs = [_orc_cmult(ring, l4, SC * s4, _drop(Q[0, 0], l4), ctq[j], rlk)[0] for j in range(s)]
     got_out = np.fromfile(tmp_path / "aatb_out.bin", dtype=np.uint64).reshape(np.stack(outs).shape)
     assert np.array_equal(got_out, np.stack(outs)), "DCMatMulAAtB: out[j] += CMult(A[c], cTQ[j])"
+
+
+# ------------------------------------------------------------------------------------------------ A14 compositions
+class OCt:
+    """oracle-side ciphertext with lattigo's level / scale bookkeeping (CMult = MulRelin + Rescale(params.Scale()), min-level binary ops)"""
+    SC = 2.0 ** 34
+
+    def __init__(self, ring, keys, rlk, data, level, scale):
+        self.ring, self.keys, self.rlk, self.data, self.level, self.scale = ring, keys, rlk, np.ascontiguousarray(data), level, scale
+
+    def like(self, data, level, scale):
+        return OCt(self.ring, self.keys, self.rlk, data, level, scale)
+
+    def drop(self, level):
+        return self if level == self.level else self.like(self.data[:, :level + 1], level, self.scale)
+
+    def rescaled(self):
+        d, l, s = _orc_rescale_loop(self.ring, self.data, self.level, self.scale)
+        return self.like(d, l, s)
+
+    def cmult(self, o):
+        l = min(self.level, o.level); a, b = self.drop(l), o.drop(l)
+        mr = np.zeros_like(a.data)
+        ol.lib().orc_mulrelin(self.ring.h, l, ol.p64(a.data), ol.p64(b.data), ol.p64(self.rlk), ol.p64(mr))
+        return self.like(mr, l, a.scale * b.scale).rescaled()
+
+    def mul_real(self, vals):
+        pt = self.ring.encode_ntt(np.asarray(vals, dtype=np.float64), OCt.SC, self.level + 1)
+        mp = np.zeros_like(self.data)
+        ol.lib().orc_mul_plain(self.ring.h, self.level, ol.p64(self.data), ol.p64(pt), ol.p64(mp))
+        return self.like(mp, self.level, self.scale * OCt.SC).rescaled()
+
+    def mask(self, index, keep_rest=False):
+        m = np.full(self.ring.slots, 1.0 if keep_rest else 0.0); m[index] = 0.0 if keep_rest else 1.0
+        return self.mul_real(m)
+
+    def innersum(self):
+        return self.like(_orc_innersum(self.ring, self.keys, self.level, [self.data]), self.level, self.scale)
+
+    def add(self, o):
+        l = min(self.level, o.level); a, b = self.drop(l), o.drop(l)
+        out = np.zeros_like(a.data)
+        ol.lib().orc_ct_addsub(self.ring.h, l, ol.p64(a.data), ol.p64(b.data), 0, ol.p64(out))
+        return self.like(out, l, a.scale)
+
+
+@pytest.mark.gpu
+def test_logistic_path_ciphertext_matrix_helpers_match_the_oracle(tmp_path):
+    """CMultMatInnerProd / ...Vector / CMultMatColTimesColToCol / ...RowToCol (matmult.go:1915-2066, used by assoc.go:992-1170)
+    as device-resident compositions vs the same compositions of oracle ops, 2 x 2 matrices of single ciphertexts"""
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_cmat_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rows, qlevel, mcols, slots, SC = 2, 7, 5, 8192, 2.0 ** 34
+    steps, k = [], 1
+    while k < slots:
+        steps.append(k); k *= 2
+    blob = [np.array([len(steps)], dtype=np.uint64)]
+    for k in steps:
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 300 + k)
+        keys.add(g, key)
+        blob += [np.array([g], dtype=np.uint64), key.reshape(-1)]
+    np.concatenate(blob).tofile(tmp_path / "keys.bin")
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    rlk = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 999)
+    rlk.tofile(tmp_path / "rlk.bin")
+    M = np.stack([np.stack([ring.fill_uniform(qlevel, 150 + i)]) for i in range(rows)])
+    Nn = np.stack([np.stack([ring.fill_uniform(qlevel, 160 + i)]) for i in range(rows)])
+    M.tofile(tmp_path / "M.bin"); Nn.tofile(tmp_path / "N.bin")
+    (tmp_path / "case.txt").write_text(f"{rows} {qlevel} {mcols}\n")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr
+    mk = lambda a: OCt(ring, keys, rlk, a, qlevel, SC)
+    Mo, No = [mk(M[i, 0]) for i in range(rows)], [mk(Nn[i, 0]) for i in range(rows)]
+
+    def load(name, like):
+        return np.fromfile(tmp_path / name, dtype=np.uint64).reshape(np.stack([x.data for x in like]).shape)
+
+    # CMultMatInnerProd
+    res = []
+    for r in range(rows):
+        acc = None
+        for c in range(rows):
+            t = Mo[r].cmult(No[c]).innersum().mask(c)
+            acc = t if acc is None else t.add(acc)
+        res.append(acc)
+    assert np.array_equal(load("innerprod.bin", res), np.stack([x.data for x in res])), "CMultMatInnerProd"
+    # CMultMatInnerProdVector
+    mask_clear = np.zeros(slots); mask_clear[:mcols] = 1.0
+    nmask, acc = No[0].mul_real(mask_clear), None
+    for kk in range(rows):
+        t = Mo[kk].mul_real(mask_clear).cmult(nmask).innersum().mask(kk)
+        acc = t if acc is None else t.add(acc)
+    assert np.array_equal(load("innerprod_vec.bin", [acc]), acc.data[None]), "CMultMatInnerProdVector"
+    # CMultMatColTimesColToCol / RowToCol
+    for name, row_form in (("col_col.bin", False), ("col_row.bin", True)):
+        res = [None] * rows
+        for kk in range(rows):
+            for c in range(rows):
+                elem = (No[kk].mask(c) if row_form else No[c].mask(kk)).innersum()
+                multi = elem.cmult(Mo[kk])
+                res[c] = multi if res[c] is None else multi.add(res[c])
+        assert np.array_equal(load(name, res), np.stack([x.data for x in res])), name
