@@ -42,6 +42,7 @@ struct sfg_geno {
 // A/B and diagnostic switches: read ONCE from the environment by sfg_ctx_create (never on the launch path)
 struct SfgConfig {
     bool mac_reg = false;          // SFG_MAC_IMPL=reg      register-staged MAC kernel (mac.hip)
+    bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
     size_t acc_budget = 24ULL << 30;   // SFG_MM_ACC_BUDGET_MB

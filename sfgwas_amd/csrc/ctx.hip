@@ -20,12 +20,13 @@ int sfg_encoder_init(sfg_ctx *ctx);      // encode.hip (tables into ctx->sh)
 void sfg_encoder_destroy(SfgShared *sh);
 int sfg_kernel_attrs_init(sfg_ctx *ctx);  // raises the dynamic-LDS limits of every big-LDS kernel on ctx->device (mac_dma/ntt/encode)
 int mac_dma_set_attrs(sfg_ctx *ctx);
+int mac_bc_set_attrs(sfg_ctx *ctx);
 int ntt_set_attrs(sfg_ctx *ctx);
 int encode_set_attrs(sfg_ctx *ctx);
 
 static void read_config(SfgConfig &c) {
     auto env = [](const char *n) { return getenv(n); };
-    if (const char *e = env("SFG_MAC_IMPL")) c.mac_reg = !strcmp(e, "reg");
+    if (const char *e = env("SFG_MAC_IMPL")) { c.mac_reg = !strcmp(e, "reg"); c.mac_bc = strcmp(e, "dma") != 0 && !c.mac_reg; }
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; }
     if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
@@ -127,7 +128,7 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     ctx_bind_shared(ctx, sh);
     if (sfg_encoder_init(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
     // dynamic-LDS limits are per (function, device): set here for this context's device, not behind process-wide flags
-    if (mac_dma_set_attrs(ctx) || ntt_set_attrs(ctx) || encode_set_attrs(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
+    if (mac_dma_set_attrs(ctx) || mac_bc_set_attrs(ctx) || ntt_set_attrs(ctx) || encode_set_attrs(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
     *out = ctx;
     return 0;
 }

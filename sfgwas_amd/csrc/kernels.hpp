@@ -42,3 +42,6 @@ int launch_rot_sum(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, int K, i
 int launch_pack_pt(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, size_t words_per_row, int L, unsigned packed_mask);
 unsigned mac_dma_packed_mask(sfg_ctx *ctx, int L);
 bool mac_use_dma(const sfg_ctx *ctx);
+// mac_bc.hip (same contract as launch_mac_dma; small-modulus plaintext rows packed)
+int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st,
+                  const double *rotsum);

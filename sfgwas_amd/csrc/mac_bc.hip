@@ -1,0 +1,304 @@
+// mac_bc.hip — DPP-broadcast form of the lazy-MAC batched modular GEMM (the default MAC kernel).
+//
+// Same algebra, operands and results as mac_dma.hip (gwas/matmult.go:247-399: MulCoeffsAndAdd128 / CPMultAccWithoutMRedV2 /
+// ReduceAndAddUint128 net to the canonical sum  out[n][r][l][c] (+)= sum_k rot[k][r][l][c] * pt[k][n][l][c] mod q_l), and the same
+// LDS-DMA ring (global_load_lds_dwordx4, counted vmcnt, one raw s_barrier per chunk of 4 k-steps).  What changed is the thread tile:
+//
+//   lane = (rho < 4 = DPP row = coefficient inside a quad, i < 16 = lane in the row = output column)
+//   wave = (coefficient quad cq < 4, column group cgp < 2);  workgroup = 8 waves = 16 coefficients x 32 columns x ALL 30 rows
+//   thread tile = 30 rows x 1 column x 3 fp64 limb accumulators = 90 accumulators
+//
+// Per coefficient the GEMM is an outer product rot[k][0..29] x pt[k][columns].  Lane i of a DPP row ALSO holds the rot words of rows i
+// and 16 + i of that row's coefficient, and every FMA takes its rot operand from the lane that holds it through the fp64 ALU's own
+// wavefront shuffle: `v_fmac_f64_dpp ... row_newbcast:r` (the one DPP control the DP ALU accepts on gfx90a+).  A k-step therefore
+// costs a thread 2 rot reads + 1 plaintext read from LDS (24 B) and 3 v_perm_b32 for 90 FMAs, against 88 B and 9 for 72 FMAs in the
+// 8 x 3 tile of mac_dma.hip - the LDS pipe (128 B/clk/CU, shared by the four SIMDs) drops from ~60 % to ~13 % of the FMA time, the
+// 30 rows are not padded to 32, and the 46-bit modulus costs the same 90 FMAs (its lo + hi operand is one v_add_f64 per rot word).
+//
+// LDS images are laid out by the DMA's lane -> address map (any 16-byte granule of a 1 KiB job can come from anywhere), which is
+// used to XOR-swizzle granules so that the 16 lanes of a DPP row (rows / columns i = 0..15 at one coefficient: a 128- or 256-byte
+// stride in the natural layout) read 16 different bank groups.
+#include "common.hpp"
+#include "kernels.hpp"
+#include <algorithm>
+#include <utility>
+
+constexpr int BC_CL = 16;          // coefficients per workgroup: 128-byte operand segments
+constexpr int BC_KC = 4;           // k-steps per chunk
+constexpr int BC_WAVES = 8;
+constexpr int BC_COLS = 32;        // columns per workgroup
+constexpr int BC_SROWS = 32;       // rot rows staged per k-step (rows past R are clamped duplicates)
+constexpr int BC_MAXROWS = 30;     // rows per pass (s = 15 ciphertexts x 2 polynomials)
+
+struct BcArgs {
+    const double *rotf; const u64 *pt; u64 *out; const u64 *zeros; const double *rotsum;
+    size_t rotf_k_stride, rotf_r_stride;     // doubles
+    size_t pt_k_stride, pt_n_stride, pt_l_stride;   // words
+    size_t out_n_stride, out_r_stride;       // words
+    int K, R, Ncols, accumulate, r0, l0, nl, flush, ntile, plane0, pt_half;
+};
+
+template <bool BIG> struct BcRing {
+    static constexpr int RW = BIG ? 2 : 1;
+    static constexpr int R_IMG = BC_SROWS * BC_CL * 8 * RW;        // rot image of one k-step: 4 / 8 KiB
+    static constexpr int P_IMG = BC_COLS * BC_CL * 8;              // plaintext image of one k-step: 4 KiB
+    static constexpr int R_BYTES = BC_KC * R_IMG, P_BYTES = BC_KC * P_IMG;
+    static constexpr int SLOT = R_BYTES + P_BYTES;                 // 32 / 48 KiB
+    static constexpr int DEPTH = BIG ? 3 : 4;                      // 128 / 144 KiB of the 160 KiB
+    static constexpr int LDS = DEPTH * SLOT;
+    static constexpr int R_JOBS = R_BYTES / 1024, P_JOBS = P_BYTES / 1024;
+    static constexpr int RT = R_JOBS / BC_WAVES, A = (R_JOBS + P_JOBS) / BC_WAVES;      // issue rounds per wave and chunk: rot rounds, all rounds
+    static_assert(R_JOBS % BC_WAVES == 0 && P_JOBS % BC_WAVES == 0, "jobs must fill whole issue rounds");
+};
+
+// byte offset of the 8-byte word (row, coefficient c < 16) inside an image of 128-byte rows: 1 KiB jobs of 8 rows; inside a job the
+// row order alternates with the job's parity and the 16-byte granules of row a are XORed with a
+__device__ __forceinline__ int bc_swz8(int row, int c) {
+    const int jb = row >> 3, a = row & 7;
+    return jb * 1024 + ((a ^ (jb & 1)) * 128) + ((((c >> 1) ^ a)) * 16) + (c & 1) * 8;
+}
+// 16-byte {lo, hi} pairs of the 46-bit modulus: 256-byte rows, granule c XOR (row & 15)
+__device__ __forceinline__ int bc_swz16(int row, int c) { return row * 256 + ((c ^ (row & 15)) * 16); }
+
+__device__ __forceinline__ void bc_dma16(const void *gsrc, void *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+// acc += rot[lane LANE of this DPP row] * p
+template <int LANE> __device__ __forceinline__ void fmac_bc(double &acc, double rot, double p) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(rot), "v"(p), "n"(LANE));
+}
+template <int LIMB, int... R> __device__ __forceinline__ void bc_rows(double (&acc)[sizeof...(R)][3], double ra, double rb, double p, std::integer_sequence<int, R...>) {
+    (fmac_bc<(R & 15)>(acc[R][LIMB], R < 16 ? ra : rb, p), ...);
+}
+
+template <bool BIG, int ROWS>
+__global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const ModConst *modc) {
+    using Ring = BcRing<BIG>;
+    constexpr int RT = Ring::RT, A = Ring::A, DEPTH = Ring::DEPTH, SLOT = Ring::SLOT, R_IMG = Ring::R_IMG, P_IMG = Ring::P_IMG, R_BYTES = Ring::R_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int N = SFG_N, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rho = lane >> 4, i = lane & 15, cq = wave & 3, cgp = wave >> 2, cc = cq * 4 + rho;
+    // block decode: as k_mac_dma - column tiles that share one (c-block, modulus) slab of `rot` sit on one XCD back to back, and so do
+    // a c-block and its mirror, which read the same half-row plaintext bytes
+    int li, c0, tile; bool mirrored = false;
+    {
+        const int b = blockIdx.x;
+        if (!a.pt_half) {
+            const int grp = b / (8 * a.ntile), rem = b % (8 * a.ntile);
+            const int slab = grp * 8 + (rem & 7); tile = rem >> 3;
+            if (slab >= (N / BC_CL) * a.nl) return;
+            li = slab / (N / BC_CL); c0 = (slab % (N / BC_CL)) * BC_CL;
+        } else {
+            const int per = 16 * a.ntile, grp = b / per, rem = b % per, idx = rem >> 3;
+            const int sup = grp * 8 + (rem & 7); tile = idx % a.ntile; mirrored = idx >= a.ntile;
+            if (sup >= (N / BC_CL / 2) * a.nl) return;
+            li = sup / (N / BC_CL / 2);
+            const int sb = sup % (N / BC_CL / 2);
+            c0 = (mirrored ? (N / BC_CL - 1 - sb) : sb) * BC_CL;
+        }
+    }
+    const int l = a.l0 + li;
+    const double q = modc[l].q, qinv = modc[l].qinv;
+    const int pcc = mirrored ? BC_CL - 1 - cc : cc;                    // P[N-1-c] = P[c]
+    const int nchunk = (a.K + BC_KC - 1) / BC_KC, nchunk_full = a.K / BC_KC;
+
+    // ---- DMA source addressing: wave-uniform operand base (advanced per chunk on the scalar unit) + constant per-lane byte offsets
+    const int cp0 = mirrored ? N - BC_CL - c0 : c0;
+    const unsigned char *rot_u = (const unsigned char *)(a.rotf + (size_t)(a.plane0 + li * Ring::RW) * N + (BIG ? (size_t)c0 * 2 : (size_t)c0));
+    const unsigned char *pt_u = (const unsigned char *)(a.pt + (size_t)tile * BC_COLS * a.pt_n_stride + (size_t)l * a.pt_l_stride + cp0);
+    const unsigned char *z_u = (const unsigned char *)a.zeros + (BIG ? 0 : 256) + (lane & 7) * 16;     // zero plaintext words (packed zeros at +256 B)
+    const size_t rot_step = (size_t)BC_KC * a.rotf_k_stride * 8, pt_step = (size_t)BC_KC * a.pt_k_stride * 8;
+    unsigned roff[RT]; size_t poff[A - RT]; int pkk[A - RT];
+#pragma unroll
+    for (int t = 0; t < A; t++) {
+        const int job = t * BC_WAVES + wave;
+        if (t < RT) {
+            int kk, row, g16;                                          // g16: 16-byte granule inside the row's segment
+            if (BIG) { kk = job >> 3; row = (job & 7) * 4 + (lane >> 4); g16 = (lane & 15) ^ (row & 15); }
+            else { const int jb = job & 3, av = (lane >> 3) ^ (jb & 1); kk = job >> 2; row = jb * 8 + av; g16 = (lane & 7) ^ av; }
+            const int rr = a.r0 + row < a.R ? a.r0 + row : a.R - 1;
+            roff[t] = (unsigned)((size_t)kk * a.rotf_k_stride * 8 + (size_t)rr * a.rotf_r_stride * 8) + (unsigned)g16 * 16u;
+        } else {
+            const int pj = job - Ring::R_JOBS, jb = pj & 3, av = (lane >> 3) ^ (jb & 1), kk = pj >> 2, col = jb * 8 + av;
+            int n = tile * BC_COLS + col; n = n < a.Ncols ? n : a.Ncols - 1;
+            poff[t - RT] = (size_t)kk * a.pt_k_stride * 8 + (size_t)(n - tile * BC_COLS) * a.pt_n_stride * 8 + (size_t)((lane & 7) ^ av) * 16;
+            pkk[t - RT] = kk;
+        }
+    }
+    auto issue_chunk = [&](int ch) {
+        unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
+        const unsigned char *rb = rot_u + (size_t)ch * rot_step, *pb = pt_u + (size_t)ch * pt_step;
+#pragma unroll
+        for (int t = 0; t < RT; t++) bc_dma16(rb + roff[t], slot + (t * BC_WAVES + wave) * 1024);
+        if (ch < nchunk_full) {
+#pragma unroll
+            for (int t = RT; t < A; t++) bc_dma16(pb + poff[t - RT], slot + (t * BC_WAVES + wave) * 1024);
+        } else {        // ragged last chunk: the padded k-steps take a zero plaintext; rot is read as is (finite by the launcher's contract)
+#pragma unroll
+            for (int t = RT; t < A; t++) bc_dma16(ch * BC_KC + pkk[t - RT] < a.K ? pb + poff[t - RT] : z_u, slot + (t * BC_WAVES + wave) * 1024);
+        }
+    };
+
+    double acc[ROWS][3];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < DEPTH - 1; ch++) if (ch < nchunk) issue_chunk(ch);
+
+    // per-thread LDS read offsets inside a k-step image
+    const int ra_off = BIG ? bc_swz16(i, cc) : bc_swz8(i, cc);
+    const int rb_off = BIG ? bc_swz16(16 + i, cc) : bc_swz8(16 + i, cc);
+    const int p_off = R_BYTES + bc_swz8(cgp * 16 + i, pcc);
+    // small moduli: the limb doubles 4096 + x_k live in registers; a k-step rewrites only their HIGH dwords (one v_perm_b32 each)
+    double pl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); pl[k] = __hiloint2double(0, z); }
+    constexpr auto rows = std::make_integer_sequence<int, ROWS>{};
+    int since_flush = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < nchunk; ch++) {
+        const int ahead = (nchunk - 1 - ch) < (DEPTH - 2) ? (nchunk - 1 - ch) : (DEPTH - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's pieces of chunk ch are in LDS; everyone is done with chunk ch-1
+        if (ch + DEPTH - 1 < nchunk) issue_chunk(ch + DEPTH - 1);
+        const unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
+        struct Opd { double ra0, ra1, rb0, rb1; u64 p; };             // small moduli use ra0 / rb0 only
+        auto fetch = [&](int kk, Opd &o) {
+            const unsigned char *ri = slot + kk * R_IMG;
+            if (BIG) {
+                const double2 va = *reinterpret_cast<const double2 *>(ri + ra_off), vb = *reinterpret_cast<const double2 *>(ri + rb_off);
+                o.ra0 = va.x; o.ra1 = va.y; o.rb0 = vb.x; o.rb1 = vb.y;
+            } else { o.ra0 = *reinterpret_cast<const double *>(ri + ra_off); o.rb0 = *reinterpret_cast<const double *>(ri + rb_off); }
+            o.p = *reinterpret_cast<const u64 *>(slot + kk * P_IMG + p_off);
+        };
+        auto fmas = [&](const Opd &o) {
+            if (BIG) {      // Karatsuba: lo*lo, hi*hi, (lo+hi)*(lo+hi); the middle limb is recovered in the epilogue
+                double p0 = (double)(unsigned)(o.p & 0x7FFFFFu), p1 = (double)(unsigned)(o.p >> 23), p2 = p0 + p1;
+                double sa = o.ra0 + o.ra1, sb = o.rb0 + o.rb1;
+                // a VGPR written by the VALU may not be read by a DPP instruction in the next two issue slots, and the hazard recognizer
+                // does not look inside inline asm: everything the VALU just produced passes through this barrier first
+                asm volatile("s_nop 1" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(sa), "+v"(sb));
+                bc_rows<0>(acc, o.ra0, o.rb0, p0, rows); bc_rows<2>(acc, o.ra1, o.rb1, p1, rows); bc_rows<1>(acc, sa, sb, p2, rows);
+            } else {
+                const unsigned plo = (unsigned)o.p, phi = (unsigned)(o.p >> 32);
+                pl[0] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0005040Cu), __double2loint(pl[0]));      // 4096 + x0
+                pl[1] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0007060Cu), __double2loint(pl[1]));      // 4096 + x1
+                pl[2] = __hiloint2double((int)__builtin_amdgcn_perm(phi, 0x40404040u, 0x0005040Cu), __double2loint(pl[2]));      // 4096 + x2
+                asm volatile("s_nop 1" : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]));       // DPP hazard barrier, as above
+                bc_rows<0>(acc, o.ra0, o.rb0, pl[0], rows); bc_rows<1>(acc, o.ra0, o.rb0, pl[1], rows); bc_rows<2>(acc, o.ra0, o.rb0, pl[2], rows);
+            }
+        };
+        Opd oc, on;
+        fetch(0, oc);
+        fetch(1, on); fmas(oc);
+        fetch(2, oc); fmas(on);
+        fetch(3, on); fmas(oc);
+        fmas(on);
+        static_assert(BC_KC == 4, "the pipeline above is written for 4 k-steps per chunk");
+        since_flush += BC_KC;
+        if (since_flush >= a.flush) {
+            since_flush = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { acc[r][0] = pred(acc[r][0], q, qinv); acc[r][1] = pred(acc[r][1], q, qinv); acc[r][2] = pred(acc[r][2], q, qinv); }
+        }
+    }
+    // ---- epilogue: limb recombination, bias removal (packed limbs carry 4096 * sum_k rot[k][row] each), canonical store
+    constexpr double S1 = BIG ? 8388608.0 : 4096.0;
+    const double s1 = S1, s1q = S1 / q;
+    const double s2 = canon(S1 * S1, q, qinv), s2q = s2 / q;
+    const int n = tile * BC_COLS + cgp * 16 + i;
+    const int nclamp = n < a.Ncols ? n : a.Ncols - 1;
+    u64 *ocol = a.out + (size_t)nclamp * a.out_n_stride + (size_t)l * N + c0 + cc;
+    const double *rs = BIG ? nullptr : a.rotsum + (size_t)(a.plane0 + li) * N + c0 + cc;
+    constexpr int HALF = (ROWS + 1) / 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        // all previous-value and bias loads of a half first (one wait), from clamped (always valid) addresses
+        u64 oldv[HALF]; double bias[HALF];
+#pragma unroll
+        for (int x = 0; x < HALF; x++) {
+            const int r = h * HALF + x;
+            const int row = a.r0 + r < a.R ? a.r0 + r : a.R - 1;
+            oldv[x] = a.accumulate ? ocol[(size_t)row * a.out_r_stride] : 0ULL;
+            bias[x] = BIG ? 0.0 : rs[(size_t)row * a.rotf_r_stride];
+        }
+#pragma unroll
+        for (int x = 0; x < HALF; x++) {
+            const int r = h * HALF + x;
+            if (r >= ROWS) continue;
+            const int row = a.r0 + r;
+            const double b = BIG ? 0.0 : pred(bias[x], q, qinv) * 4096.0;
+            const double a0 = pred(acc[r][0], q, qinv), a1 = pred(acc[r][1], q, qinv), a2 = pred(acc[r][2], q, qinv);
+            double v = a0 - b;
+            const double mid = BIG ? a1 - a0 - a2 : a1 - b;
+            v += mulmod_lazy(mid, s1, s1q, q);
+            v += mulmod_lazy(a2 - b, s2, s2q, q);
+            v += u64_to_f64(oldv[x] & 0x000FFFFFFFFFFFFFULL);
+            if (n < a.Ncols && row < a.R) ocol[(size_t)row * a.out_r_stride] = f64_to_u64(canon(v, q, qinv));
+        }
+    }
+}
+
+template <bool BIG, int ROWS> static int bc_set_attr(sfg_ctx *ctx) {
+    auto k = k_mac_bc<BIG, ROWS>;
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, BcRing<BIG>::LDS));
+    return 0;
+}
+int mac_bc_set_attrs(sfg_ctx *ctx) {
+    SFG_TRY((bc_set_attr<false, 30>(ctx))); SFG_TRY((bc_set_attr<false, 16>(ctx))); SFG_TRY((bc_set_attr<false, 4>(ctx)));
+    SFG_TRY((bc_set_attr<true, 30>(ctx))); SFG_TRY((bc_set_attr<true, 16>(ctx))); SFG_TRY((bc_set_attr<true, 4>(ctx)));
+    return 0;
+}
+template <bool BIG, int ROWS> static void bc_launch(sfg_ctx *ctx, dim3 grid, const BcArgs &a) {
+    hipLaunchKernelGGL((k_mac_bc<BIG, ROWS>), grid, dim3(64 * BC_WAVES), BcRing<BIG>::LDS, ctx->stream, a, ctx->modc);
+}
+
+// Same contract as launch_mac_dma (mac_dma.hip).  The small-modulus plaintext rows must be in the packed-limb format.
+int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate,
+                  const MacStrides &st, const double *rotsum) {
+    const int N = SFG_N;
+    if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) return 1;
+    const size_t rowf = (size_t)nplanes * N;
+    for (int r0 = 0; r0 < R; r0 += BC_MAXROWS) {
+        const int rows = std::min(BC_MAXROWS, R - r0);
+        int l = 0;
+        while (l < L) {
+            const bool big = is_big[l]; int e = l; while (e < L && is_big[e] == (int)big) e++;
+            if (!big && !(st.pt_packed && rotsum)) SFG_FAIL(ctx, "sfg_mac: the broadcast MAC needs packed-limb plaintext rows and the rot sums for the small moduli");
+            BcArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev(); a.rotsum = rotsum;
+            a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
+            a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = st.pt_half ? N / 2 : N; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
+            a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l]; a.pt_half = st.pt_half ? 1 : 0;
+            {   // rot lane offsets are 32-bit
+                const double rot_max = (3.0 * (double)a.rotf_k_stride + (double)R * (double)a.rotf_r_stride) * 8.0 + 512.0;
+                if (rot_max >= 4294967296.0) SFG_FAIL(ctx, "sfg_mac: operand strides exceed the 32-bit lane offsets of the DMA addressing (R = %d)", R);
+            }
+            // largest single term of a run (see launch_mac_dma): small moduli q * 2^12 (centred rot x biased 13-bit limb), big ones the Karatsuba middle term
+            double maxterm = 0.0;
+            for (int t = l; t < e; t++) {
+                const double m = big ? (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) * (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) : (double)ctx->q[t] * 4096.0;
+                if (m > maxterm) maxterm = m;
+            }
+            int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / BC_KC) * BC_KC;
+            if (f < BC_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
+            a.flush = f; a.ntile = (Ncols + BC_COLS - 1) / BC_COLS;
+            const int nslab = (st.pt_half ? N / BC_CL / 2 : N / BC_CL) * a.nl, ngrp = (nslab + 7) / 8;
+            dim3 grid((unsigned)(ngrp * 8 * a.ntile * (st.pt_half ? 2 : 1)));
+            PhaseTimer t(ctx, big ? "mac_big" : "mac_small");
+            if (big) { if (rows > 16) bc_launch<true, 30>(ctx, grid, a); else if (rows > 4) bc_launch<true, 16>(ctx, grid, a); else bc_launch<true, 4>(ctx, grid, a); }
+            else { if (rows > 16) bc_launch<false, 30>(ctx, grid, a); else if (rows > 4) bc_launch<false, 16>(ctx, grid, a); else bc_launch<false, 4>(ctx, grid, a); }
+            SFG_HIP(ctx, hipGetLastError());
+            {   // algorithmic bytes of this launch (as launch_mac_dma): fp64 rot operand + plaintext words + accumulators written (and read when accumulating)
+                const double nlm = (double)(e - l), rw = big ? 2.0 : 1.0, pw = st.pt_half ? 0.5 : 1.0;
+                const double bytes = ((double)K * rows * rw + (double)K * Ncols * pw + (double)Ncols * rows * (accumulate ? 2.0 : 1.0)) * nlm * N * 8.0;
+                t.stop(1, bytes);
+            }
+            l = e;
+        }
+    }
+    return 0;
+}

@@ -407,6 +407,8 @@ int launch_pack_pt(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, size_t w
 int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate,
                    const MacStrides &st, const double *rotsum) {
     if (st.pt_packed && !rotsum) SFG_FAIL(ctx, "sfg_mac: packed plaintext panel without the rot sums");
+    if (ctx->cfg.mac_bc && (st.pt_packed || mac_dma_packed_mask(ctx, L) == 0) && !ctx->cfg.mac_plain_pt)      // default: the DPP-broadcast kernel (mac_bc.hip)
+        return launch_mac_bc(ctx, rotf, rows_per_k, pt, out, K, R, Ncols, L, accumulate, st, rotsum);
     const int N = SFG_N;
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
