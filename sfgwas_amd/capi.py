@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsfgwas_hip.so")
+LIB_PATH = os.environ.get("SFG_LIB_PATH") or os.path.join(_HERE, "lib", "libsfgwas_hip.so")      # SFG_LIB_PATH: same-box A/B of two builds
 
 u64p = C.POINTER(C.c_uint64)
 _lib = None

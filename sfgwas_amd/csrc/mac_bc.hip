@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 constexpr int BC_CL = 16;          // coefficients per workgroup: 128-byte operand segments
@@ -36,6 +37,7 @@ struct BcArgs {
     size_t pt_k_stride, pt_n_stride, pt_l_stride;   // words
     size_t out_n_stride, out_r_stride;       // words
     int K, R, Ncols, accumulate, r0, l0, nl, flush, ntile, plane0, pt_half;
+    int diag;        // -DSFG_MAC_DIAG builds only (timing experiments, results invalid): 1 no rot DMA, 2 no pt DMA, 4 no barrier, 8 no FMAs
 };
 
 template <bool BIG> struct BcRing {
@@ -44,7 +46,10 @@ template <bool BIG> struct BcRing {
     static constexpr int P_IMG = BC_COLS * BC_CL * 8;              // plaintext image of one k-step: 4 KiB
     static constexpr int R_BYTES = BC_KC * R_IMG, P_BYTES = BC_KC * P_IMG;
     static constexpr int SLOT = R_BYTES + P_BYTES;                 // 32 / 48 KiB
-    static constexpr int DEPTH = BIG ? 3 : 4;                      // 128 / 144 KiB of the 160 KiB
+#ifndef BC_DEPTH_SMALL
+#define BC_DEPTH_SMALL 5
+#endif
+    static constexpr int DEPTH = BIG ? 3 : BC_DEPTH_SMALL;         // 160 / 144 KiB of the 160 KiB
     static constexpr int LDS = DEPTH * SLOT;
     static constexpr int R_JOBS = R_BYTES / 1024, P_JOBS = P_BYTES / 1024;
     static constexpr int RT = R_JOBS / BC_WAVES, A = (R_JOBS + P_JOBS) / BC_WAVES;      // issue rounds per wave and chunk: rot rounds, all rounds
@@ -65,7 +70,7 @@ __device__ __forceinline__ void bc_dma16(const void *gsrc, void *lds_base) {
 }
 // acc += rot[lane LANE of this DPP row] * p
 template <int LANE> __device__ __forceinline__ void fmac_bc(double &acc, double rot, double p) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(rot), "v"(p), "n"(LANE));
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(rot), "v"(p), "n"(LANE));      // volatile: the hand-made schedule (fetch / wait / FMA order) is kept as written
 }
 template <int LIMB, int... R> __device__ __forceinline__ void bc_rows(double (&acc)[sizeof...(R)][3], double ra, double rb, double p, std::integer_sequence<int, R...>) {
     (fmac_bc<(R & 15)>(acc[R][LIMB], R < 16 ? ra : rb, p), ...);
@@ -128,8 +133,14 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
     auto issue_chunk = [&](int ch) {
         unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
         const unsigned char *rb = rot_u + (size_t)ch * rot_step, *pb = pt_u + (size_t)ch * pt_step;
+#ifdef SFG_MAC_DIAG
+        if (!(a.diag & 1))
+#endif
 #pragma unroll
         for (int t = 0; t < RT; t++) bc_dma16(rb + roff[t], slot + (t * BC_WAVES + wave) * 1024);
+#ifdef SFG_MAC_DIAG
+        if (a.diag & 2) return;
+#endif
         if (ch < nchunk_full) {
 #pragma unroll
             for (int t = RT; t < A; t++) bc_dma16(pb + poff[t - RT], slot + (t * BC_WAVES + wave) * 1024);
@@ -142,60 +153,92 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
     double acc[ROWS][3];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
+    // every ring slot is filled before the loop starts
 #pragma unroll
-    for (int ch = 0; ch < DEPTH - 1; ch++) if (ch < nchunk) issue_chunk(ch);
+    for (int ch = 0; ch < DEPTH; ch++) if (ch < nchunk) issue_chunk(ch);
 
-    // per-thread LDS read offsets inside a k-step image
-    const int ra_off = BIG ? bc_swz16(i, cc) : bc_swz8(i, cc);
-    const int rb_off = BIG ? bc_swz16(16 + i, cc) : bc_swz8(16 + i, cc);
-    const int p_off = R_BYTES + bc_swz8(cgp * 16 + i, pcc);
+    // ---- LDS operand reads, issued and awaited by hand.  (Left to the compiler, every FMA group is preceded by s_waitcnt lgkmcnt(0),
+    // which also waits for the prefetch of the NEXT k-step that was issued just before it.)  A fetch is NLDS ds_read instructions; the
+    // wait that makes a fetch's registers valid names them as in/out operands, so no consumer can be scheduled ahead of it.
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    struct Opd { d2v ra, rb; u64 p; };                                // small moduli: ra = {row i, row 16 + i}; 46-bit modulus: ra = {lo, hi} of row i, rb of row 16 + i
+    constexpr int NLDS = BIG ? 3 : 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned r_thr = lds0 + (unsigned)(BIG ? bc_swz16(i, cc) : bc_swz8(i, cc));       // row 16 + i sits 2048 (BIG: 4096) bytes further
+    const unsigned p_thr = lds0 + (unsigned)bc_swz8(cgp * 16 + i, pcc);
+    unsigned r_cur = r_thr, p_cur = p_thr;                            // + byte offset of the current ring slot
+#define BC_FETCH(KK, O) do { \
+        if (BIG) { \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((O).ra) : "v"(r_cur), "n"((KK) * R_IMG) : "memory"); \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((O).rb) : "v"(r_cur), "n"((KK) * R_IMG + 4096) : "memory"); \
+        } else asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"((O).ra) : "v"(r_cur), "n"((KK) * R_IMG / 512), "n"((KK) * R_IMG / 512 + 4) : "memory"); \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"((O).p) : "v"(p_cur), "n"(R_BYTES + (KK) * P_IMG) : "memory"); \
+    } while (0)
+#define BC_WAIT(NOUT, O) do { \
+        if (BIG) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"((O).ra), "+v"((O).rb), "+v"((O).p) : "n"(NOUT) : "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"((O).ra), "+v"((O).p) : "n"(NOUT) : "memory"); \
+    } while (0)
     // small moduli: the limb doubles 4096 + x_k live in registers; a k-step rewrites only their HIGH dwords (one v_perm_b32 each)
     double pl[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); pl[k] = __hiloint2double(0, z); }
     constexpr auto rows = std::make_integer_sequence<int, ROWS>{};
+    auto fmas = [&](const Opd &o) {
+#ifdef SFG_MAC_DIAG
+        if (a.diag & 8) return;
+#endif
+        if (BIG) {      // Karatsuba: lo*lo, hi*hi, (lo+hi)*(lo+hi); the middle limb is recovered in the epilogue
+            double p0 = (double)(unsigned)(o.p & 0x7FFFFFu), p1 = (double)(unsigned)(o.p >> 23), p2 = p0 + p1;
+            double sa = o.ra.x + o.ra.y, sb = o.rb.x + o.rb.y;
+            // a VGPR written by the VALU may not be read by a DPP instruction in the next two issue slots, and the hazard recognizer
+            // does not look inside inline asm: everything the VALU just produced passes through this barrier first
+            asm volatile("s_nop 1" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(sa), "+v"(sb));
+            bc_rows<0>(acc, o.ra.x, o.rb.x, p0, rows); bc_rows<2>(acc, o.ra.y, o.rb.y, p1, rows); bc_rows<1>(acc, sa, sb, p2, rows);
+        } else {
+            const unsigned plo = (unsigned)o.p, phi = (unsigned)(o.p >> 32);
+            pl[0] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0005040Cu), __double2loint(pl[0]));      // 4096 + x0
+            pl[1] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0007060Cu), __double2loint(pl[1]));      // 4096 + x1
+            pl[2] = __hiloint2double((int)__builtin_amdgcn_perm(phi, 0x40404040u, 0x0005040Cu), __double2loint(pl[2]));      // 4096 + x2
+            asm volatile("s_nop 1" : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]));       // DPP hazard barrier, as above
+            bc_rows<0>(acc, o.ra.x, o.ra.y, pl[0], rows); bc_rows<1>(acc, o.ra.x, o.ra.y, pl[1], rows); bc_rows<2>(acc, o.ra.x, o.ra.y, pl[2], rows);
+        }
+    };
+    // chunk `next` has landed in every wave's view once this wave's own pieces have (counted vmcnt: chunks issued after it may still be in
+    // flight) and the workgroup has passed the barrier; the barrier also tells that everybody has finished READING the current chunk
+    auto sync_for = [&](int next) {
+        int ahead = (nchunk - 1 < next + DEPTH - 2 ? nchunk - 1 : next + DEPTH - 2) - next;      // chunks issued after `next`
+        if (DEPTH == 3 && ahead > 1) ahead = 1;
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * A) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SFG_MAC_DIAG
+        if (!(a.diag & 4))
+#endif
+        __builtin_amdgcn_s_barrier();
+    };
+    static_assert(DEPTH <= 5 && 3 * A < 64, "vmcnt budget");
+    Opd oa, ob;
+    unsigned slot_off = 0;
+    sync_for(0);
+    BC_FETCH(0, oa);
     int since_flush = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ch++) {
-        const int ahead = (nchunk - 1 - ch) < (DEPTH - 2) ? (nchunk - 1 - ch) : (DEPTH - 2);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // everyone's pieces of chunk ch are in LDS; everyone is done with chunk ch-1
-        if (ch + DEPTH - 1 < nchunk) issue_chunk(ch + DEPTH - 1);
-        const unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
-        struct Opd { double ra0, ra1, rb0, rb1; u64 p; };             // small moduli use ra0 / rb0 only
-        auto fetch = [&](int kk, Opd &o) {
-            const unsigned char *ri = slot + kk * R_IMG;
-            if (BIG) {
-                const double2 va = *reinterpret_cast<const double2 *>(ri + ra_off), vb = *reinterpret_cast<const double2 *>(ri + rb_off);
-                o.ra0 = va.x; o.ra1 = va.y; o.rb0 = vb.x; o.rb1 = vb.y;
-            } else { o.ra0 = *reinterpret_cast<const double *>(ri + ra_off); o.rb0 = *reinterpret_cast<const double *>(ri + rb_off); }
-            o.p = *reinterpret_cast<const u64 *>(slot + kk * P_IMG + p_off);
-        };
-        auto fmas = [&](const Opd &o) {
-            if (BIG) {      // Karatsuba: lo*lo, hi*hi, (lo+hi)*(lo+hi); the middle limb is recovered in the epilogue
-                double p0 = (double)(unsigned)(o.p & 0x7FFFFFu), p1 = (double)(unsigned)(o.p >> 23), p2 = p0 + p1;
-                double sa = o.ra0 + o.ra1, sb = o.rb0 + o.rb1;
-                // a VGPR written by the VALU may not be read by a DPP instruction in the next two issue slots, and the hazard recognizer
-                // does not look inside inline asm: everything the VALU just produced passes through this barrier first
-                asm volatile("s_nop 1" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(sa), "+v"(sb));
-                bc_rows<0>(acc, o.ra0, o.rb0, p0, rows); bc_rows<2>(acc, o.ra1, o.rb1, p1, rows); bc_rows<1>(acc, sa, sb, p2, rows);
-            } else {
-                const unsigned plo = (unsigned)o.p, phi = (unsigned)(o.p >> 32);
-                pl[0] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0005040Cu), __double2loint(pl[0]));      // 4096 + x0
-                pl[1] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0007060Cu), __double2loint(pl[1]));      // 4096 + x1
-                pl[2] = __hiloint2double((int)__builtin_amdgcn_perm(phi, 0x40404040u, 0x0005040Cu), __double2loint(pl[2]));      // 4096 + x2
-                asm volatile("s_nop 1" : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]));       // DPP hazard barrier, as above
-                bc_rows<0>(acc, o.ra0, o.rb0, pl[0], rows); bc_rows<1>(acc, o.ra0, o.rb0, pl[1], rows); bc_rows<2>(acc, o.ra0, o.rb0, pl[2], rows);
-            }
-        };
-        Opd oc, on;
-        fetch(0, oc);
-        fetch(1, on); fmas(oc);
-        fetch(2, oc); fmas(on);
-        fetch(3, on); fmas(oc);
-        fmas(on);
+        BC_FETCH(1, ob); BC_WAIT(NLDS, oa); fmas(oa);
+        BC_FETCH(2, oa); BC_WAIT(NLDS, ob); fmas(ob);
+        BC_FETCH(3, ob); BC_WAIT(NLDS, oa); fmas(oa);
+        BC_WAIT(0, ob);                               // this wave has read everything it needs from chunk ch
+        if (ch + 1 < nchunk) {
+            // Before the last k-step's FMAs: hand over to chunk ch + 1 (its first operands travel from LDS while those 90 FMAs run, so the
+            // barrier is not followed by an exposed LDS round trip) and refill the slot of chunk ch, which nobody reads any more.
+            sync_for(ch + 1);
+            if (ch + DEPTH < nchunk) issue_chunk(ch + DEPTH);
+            slot_off = slot_off + SLOT == (unsigned)(DEPTH * SLOT) ? 0u : slot_off + SLOT;
+            r_cur = r_thr + slot_off; p_cur = p_thr + slot_off;
+            BC_FETCH(0, oa);
+        }
+        fmas(ob);
         static_assert(BC_KC == 4, "the pipeline above is written for 4 k-steps per chunk");
         since_flush += BC_KC;
         if (since_flush >= a.flush) {
@@ -204,6 +247,8 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
             for (int r = 0; r < ROWS; r++) { acc[r][0] = pred(acc[r][0], q, qinv); acc[r][1] = pred(acc[r][1], q, qinv); acc[r][2] = pred(acc[r][2], q, qinv); }
         }
     }
+#undef BC_FETCH
+#undef BC_WAIT
     // ---- epilogue: limb recombination, bias removal (packed limbs carry 4096 * sum_k rot[k][row] each), canonical store
     constexpr double S1 = BIG ? 8388608.0 : 4096.0;
     const double s1 = S1, s1q = S1 / q;
@@ -285,6 +330,10 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
             }
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / BC_KC) * BC_KC;
             if (f < BC_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
+            a.diag = 0;
+#ifdef SFG_MAC_DIAG
+            if (const char *e = getenv("SFG_MAC_DIAG")) a.diag = atoi(e);
+#endif
             a.flush = f; a.ntile = (Ncols + BC_COLS - 1) / BC_COLS;
             const int nslab = (st.pt_half ? N / BC_CL / 2 : N / BC_CL) * a.nl, ngrp = (nslab + 7) / 8;
             dim3 grid((unsigned)(ngrp * 8 * a.ntile * (st.pt_half ? 2 : 1)));
