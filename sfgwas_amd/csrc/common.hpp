@@ -179,13 +179,13 @@ __device__ __forceinline__ double mulmod_lazy(double x, double w, double wq, dou
     double r = __builtin_fma(-qh, q, h);
     return r + l;
 }
-// canonical representative in [0, q) of an integer-valued double |x| < 2^52
+// canonical representative in [0, q) of an integer-valued double |x| < 2^51.
+// y = fl(x * fl(1/q)) is within |x/q| * 2^-52 (1 + 2^-53) of x/q.  Write x = k q + e, 0 <= e < q: for e >= 1 both e/q and (q - e)/q exceed
+// that error (e >= 1 > |x| 2^-51), so floor(y) = k; for e = 0, y = k (1 + d) may fall just below k, floor(y) = k - 1 and the exact
+// remainder fma(-floor(y), q, x) is q.  One equality test is therefore the whole fix-up.
 __device__ __forceinline__ double canon(double x, double q, double qinv) {
-    double qh = __builtin_floor(x * qinv);
-    double r = __builtin_fma(-qh, q, x);
-    r = r < 0.0 ? r + q : r;
-    r = r >= q ? r - q : r;
-    return r;
+    const double r = __builtin_fma(-__builtin_floor(x * qinv), q, x);
+    return r == q ? 0.0 : r;
 }
 // partial reduction to (-q, q): cheap, for lazy sums that would otherwise grow
 __device__ __forceinline__ double pred(double x, double q, double qinv) {
@@ -197,6 +197,14 @@ __device__ __forceinline__ double u64_to_f64(u64 x) {            // exact for x 
 }
 __device__ __forceinline__ u64 f64_to_u64(double x) {            // exact for integer 0 <= x < 2^52
     return (u64)__double_as_longlong(x + 4503599627370496.0) & 0x000FFFFFFFFFFFFFULL;
+}
+// packed-limb word (pack_limbs) of an integer-valued double 0 <= x < 2^36 straight from the bits of x + 2^52: 1 fp add + 5 integer ops
+__device__ __forceinline__ u64 pack_limbs_f64(double x) {
+    const u64 b = (u64)__double_as_longlong(x + 4503599627370496.0);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const unsigned x01 = (((lo << 4) & 0x0FFF0000u) | ((lo & 0xFFFu) | 0xB000B000u));
+    const unsigned x2 = (__builtin_amdgcn_alignbit(hi, lo, 24) & 0xFFFu) | 0xB000u;
+    return ((u64)x2 << 32) | x01;
 }
 __device__ __forceinline__ u64 d_mulmod_u64(u64 a, u64 b, u64 q) { // generic (slow) path for setup kernels
     u64 hi = __umul64hi(a, b), lo = a * b;

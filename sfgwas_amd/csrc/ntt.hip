@@ -312,11 +312,19 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
 #pragma unroll
         for (int c = 0; c < 16; c++) lds[(a & 7) * LDS_ROW + c * 33 + b] = wc[r][c];
         __syncthreads();
+        // (the format test is hoisted: inside the loop it costs a branch per word)
+        if (packed) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
-            const u64 w = f64_to_u64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
-            out[r * 4096 + jj] = packed ? pack_limbs(w) : w;
+            for (int k = 0; k < 16; k++) {
+                const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
+                out[r * 4096 + jj] = pack_limbs_f64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;
+                out[r * 4096 + jj] = f64_to_u64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
+            }
         }
     }
 }
