@@ -208,6 +208,24 @@ int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, 
 /* after an integer all-reduce(sum) of partial outputs across ranks: canonical reduction mod q_l of [rows][L][N] */
 int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows_dev, size_t nrows_of_L, int L);
 
+/* ---- f-1: collective bootstrap, LOCAL work (mpc/mhe.go:222-348: CollectiveBootstrap / CollectiveBootstrapMat) ----
+ * Per ciphertext the reference calls lattigo's dckks.RefreshProtocol: GenShares (mhe.go:251,315), aggregates the shares over the network
+ * (AggregateRefreshShare*, stays in Go), then Decrypt / Recode / Recrypt (mhe.go:256-258,329-331).  PARITY UNPINNED: restated from the published
+ * lattigo v2.1.0 dckks/refresh.go for ciphertext scale == target scale (the fork's target-scale argument is not in the reference tree).
+ * Randomness stays with the caller: mask_dev [nct][N][mask_limbs] two's-complement 64-bit limbs (ring.RandInt(bound) recentred, one big
+ * integer per coefficient), e0/e1 [nct][N] Gaussian error coefficients, crs [nct][nq][N] the common reference polynomials (NTT domain). */
+/* cryptoParams.Sk.Value (crypto.go:44): secret-key shard, rows [nq][N] in the NTT domain; montgomery_form != 0 for lattigo's stored form */
+int sfg_ctx_load_secret_key(sfg_ctx *ctx, const uint64_t *sk_host, int montgomery_form);
+/* RefreshProtocol.GenShares on nct ciphertexts [nct][2][level+1][N]:
+ *   h0 [nct][level+1][N] = NTT(mask + e0) + sk (.) c1        (refSharesDecrypt)
+ *   h1 [nct][nq][N]      = -(NTT(mask + e1) + sk (.) crs)     (refSharesRecrypt, at MaxLevel) */
+int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, const uint64_t *crs_dev, const uint64_t *mask_dev, int mask_limbs,
+                               const int32_t *e0_dev, const int32_t *e1_dev, uint64_t *h0_dev, uint64_t *h1_dev);
+/* RefreshProtocol.Decrypt + Recode + Recrypt with the AGGREGATED shares: out [nct][2][nq][N] at MaxLevel = nq-1:
+ *   c0' = NTT( centred( CRT( INTT(c0 + h0agg) ) ) mod every q_j ) + h1agg,   c1' = crs */
+int sfg_refresh_finish_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, const uint64_t *h0agg_dev, const uint64_t *h1agg_dev,
+                           const uint64_t *crs_dev, uint64_t *out_dev);
+
 /* ---- B1-B3: Beaver local products (mpc/beavermult.go:94-147) over a prime field of `limbs` 64-bit LE limbs ---- */
 int sfg_beaver_elem_dev(sfg_ctx *ctx, int pid, int limbs, const uint64_t *modulus_host,
                         const uint64_t *ar_dev, const uint64_t *am_dev, const uint64_t *br_dev, const uint64_t *bm_dev,

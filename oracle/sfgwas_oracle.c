@@ -1056,3 +1056,95 @@ double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double
     if (macs_done) *macs_done = total;
     return (double)total / (t_end - t_begin);
 }
+
+
+/* ------------------------------------------------------------------ collective bootstrap, LOCAL work
+ * mpc/mhe.go:222-348 (CollectiveBootstrap / CollectiveBootstrapMat) calls, per ciphertext, lattigo's dckks.RefreshProtocol:
+ *   GenShares (mhe.go:251,315), network aggregation, Decrypt / Recode / Recrypt (mhe.go:256-258,329-331).
+ * PARITY UNPINNED: the protocol lives in the absent fork (github.com/hcholab/lattigo/v2 v2.1.2-0.20230123224332-e8d68c24b94a); what follows restates the
+ * PUBLISHED lattigo v2.1.0 dckks/refresh.go:
+ *   GenShares: mask_i uniform in [0, bound), bound = Q_level / (2 nParties), recentred to [-bound/2, bound/2);
+ *              h0 = NTT_level(mask) + sk (.) c1 + NTT_level(e0);   h1 = -( NTT(mask) + sk (.) crs + NTT(e1) )   (all nq moduli)
+ *   Decrypt:   c0 += sum_parties h0          Recode: c0 <- NTT( centred( PolyToBigint( INTT_level(c0) ) ) mod q_j, all nq moduli )
+ *   Recrypt:   c0 += sum_parties h1;  c1 = crs.
+ * The fork's GenShares / Recode carry an extra target-scale argument (mhe.go:315,330 pass parameters.Scale()); its arithmetic is not in the
+ * reference tree, so only the case "ciphertext scale == target scale" (no rescaling of the mask) is restated.  Randomness (mask, e0, e1, crs)
+ * is an INPUT here: the Go side keeps drawing it (crypto/rand, the shared CRP generator). */
+#define ORC_BIG 16
+typedef struct { u64 w[ORC_BIG]; } obig;                       /* non-negative, little-endian limbs */
+static void obig_set(obig *a, u64 v) { memset(a, 0, sizeof *a); a->w[0] = v; }
+static void obig_mul_small(obig *a, u64 m) { u128 c = 0; for (int i = 0; i < ORC_BIG; i++) { c += (u128)a->w[i] * m; a->w[i] = (u64)c; c >>= 64; } }
+static void obig_add(obig *a, const obig *b) { u128 c = 0; for (int i = 0; i < ORC_BIG; i++) { c += (u128)a->w[i] + b->w[i]; a->w[i] = (u64)c; c >>= 64; } }
+static void obig_sub(obig *a, const obig *b) { u64 br = 0; for (int i = 0; i < ORC_BIG; i++) { u128 d = (u128)a->w[i] - b->w[i] - br; a->w[i] = (u64)d; br = (u64)(d >> 64) & 1; } }
+static int obig_cmp(const obig *a, const obig *b) { for (int i = ORC_BIG - 1; i >= 0; i--) if (a->w[i] != b->w[i]) return a->w[i] > b->w[i] ? 1 : -1; return 0; }
+static void obig_shr1(obig *a) { for (int i = 0; i < ORC_BIG; i++) a->w[i] = (a->w[i] >> 1) | (i + 1 < ORC_BIG ? a->w[i + 1] << 63 : 0); }
+static u64 obig_mod_small(const obig *a, u64 q) { u128 r = 0; for (int i = ORC_BIG - 1; i >= 0; i--) r = ((r << 64) | a->w[i]) % q; return (u64)r; }
+
+/* ring.SetCoefficientsBigint on signed values given as two's-complement limbs [N][W]: out[j][c] = mask_c mod q_j for the first nmod moduli */
+void orc_bigint_to_rns(const orc_ring *r, int nmod, const uint64_t *limbs, int W, uint64_t *out) {
+    for (int c = 0; c < r->N; c++) {
+        obig a; memset(&a, 0, sizeof a);
+        const u64 *src = limbs + (size_t)c * W;
+        int neg = (int)(src[W - 1] >> 63);
+        for (int i = 0; i < W; i++) a.w[i] = neg ? ~src[i] : src[i];
+        if (neg) { obig one; obig_set(&one, 1); for (int i = W; i < ORC_BIG; i++) a.w[i] = 0; obig_add(&a, &one); for (int i = W; i < ORC_BIG; i++) a.w[i] = 0; }
+        for (int j = 0; j < nmod; j++) { u64 m = obig_mod_small(&a, r->q[j]); out[(size_t)j * r->N + c] = neg && m ? r->q[j] - m : m; }
+    }
+}
+/* dckks RefreshProtocol.GenShares.  ct [2][level+1][N]; sk [nq][N] NTT domain, canonical (lattigo keeps it in Montgomery form: same residues after
+ * MulCoeffsMontgomery); crs [nq][N] NTT domain; mask [N][W] two's complement; e0, e1 [N] small signed coefficients. h0 [level+1][N], h1 [nq][N]. */
+void orc_refresh_gen_shares(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *sk, const uint64_t *crs, const uint64_t *mask, int W,
+                            const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1) {
+    int N = r->N, nl = level + 1;
+    u64 *m = malloc((size_t)r->nq * N * 8), *t = malloc((size_t)N * 8);
+    orc_bigint_to_rns(r, r->nq, mask, W, m);
+    for (int j = 0; j < r->nq; j++) {
+        u64 q = r->q[j];
+        if (j < nl) {
+            for (int c = 0; c < N; c++) { h0[(size_t)j * N + c] = m[(size_t)j * N + c]; t[c] = e0[c] < 0 ? q - (u64)(-(int64_t)e0[c]) : (u64)e0[c]; }
+            orc_ntt(r, j, h0 + (size_t)j * N); orc_ntt(r, j, t);
+            const u64 *c1 = ct + ((size_t)nl + j) * N;
+            for (int c = 0; c < N; c++) h0[(size_t)j * N + c] = (h0[(size_t)j * N + c] + orc_mulmod(sk[(size_t)j * N + c], c1[c], q) + t[c]) % q;
+        }
+        for (int c = 0; c < N; c++) { h1[(size_t)j * N + c] = m[(size_t)j * N + c]; t[c] = e1[c] < 0 ? q - (u64)(-(int64_t)e1[c]) : (u64)e1[c]; }
+        orc_ntt(r, j, h1 + (size_t)j * N); orc_ntt(r, j, t);
+        for (int c = 0; c < N; c++) {
+            u64 v = (h1[(size_t)j * N + c] + orc_mulmod(sk[(size_t)j * N + c], crs[(size_t)j * N + c], q) + t[c]) % q;
+            h1[(size_t)j * N + c] = v ? q - v : 0;
+        }
+    }
+    free(m); free(t);
+}
+/* Decrypt + Recode + Recrypt on one ciphertext: ct [2][level+1][N], h0agg [level+1][N], h1agg [nq][N], crs [nq][N]; out [2][nq][N] (level nq-1) */
+void orc_refresh_finish(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs, uint64_t *out) {
+    int N = r->N, nl = level + 1, nq = r->nq;
+    u64 *x = malloc((size_t)nl * N * 8);
+    for (int j = 0; j < nl; j++) {                                  /* Decrypt: c0 + h0, then InvNTTLvl */
+        for (int c = 0; c < N; c++) x[(size_t)j * N + c] = (ct[(size_t)j * N + c] + h0agg[(size_t)j * N + c]) % r->q[j];
+        orc_intt(r, j, x + (size_t)j * N);
+    }
+    /* ring.PolyToBigint: x = sum_i r_i * ((Q/q_i)^-1 mod q_i) * (Q/q_i) mod Q */
+    obig Q, Qh, Qi[ORC_MAXMOD]; u64 inv[ORC_MAXMOD];
+    obig_set(&Q, 1); for (int i = 0; i < nl; i++) obig_mul_small(&Q, r->q[i]);
+    Qh = Q; obig_shr1(&Qh);
+    for (int i = 0; i < nl; i++) {
+        obig_set(&Qi[i], 1); for (int t = 0; t < nl; t++) if (t != i) obig_mul_small(&Qi[i], r->q[t]);
+        inv[i] = orc_invmod(obig_mod_small(&Qi[i], r->q[i]), r->q[i]);
+    }
+    for (int c = 0; c < N; c++) {
+        obig acc; obig_set(&acc, 0);
+        for (int i = 0; i < nl; i++) { obig t = Qi[i]; obig_mul_small(&t, orc_mulmod(x[(size_t)i * N + c], inv[i], r->q[i])); obig_add(&acc, &t); }
+        while (obig_cmp(&acc, &Q) >= 0) obig_sub(&acc, &Q);
+        int neg = obig_cmp(&acc, &Qh) >= 0;                         /* sign == 1 || sign == 0  ->  x -= Q */
+        if (neg) { obig t = Q; obig_sub(&t, &acc); acc = t; }       /* |x - Q| */
+        for (int j = 0; j < nq; j++) { u64 m = obig_mod_small(&acc, r->q[j]); out[(size_t)j * N + c] = neg && m ? r->q[j] - m : m; }
+    }
+    for (int j = 0; j < nq; j++) {                                  /* NTT at the top level, Recrypt: + h1, c1 = crs */
+        orc_ntt(r, j, out + (size_t)j * N);
+        for (int c = 0; c < N; c++) {
+            out[(size_t)j * N + c] = (out[(size_t)j * N + c] + h1agg[(size_t)j * N + c]) % r->q[j];
+            out[((size_t)nq + j) * N + c] = crs[(size_t)j * N + c];
+        }
+    }
+    free(x);
+}

@@ -166,6 +166,13 @@ void orc_beaver_matmul(int pid, int limbs, const uint64_t *mod, const uint64_t *
 void orc_sketch(const int8_t *X, size_t nrow, size_t ncol, const int32_t *bucket, const int8_t *sgn, int kp,
                 double *sketch /*kp x ncol*/, uint64_t *xsum, uint64_t *x2sum);
 
+/* ---- collective bootstrap, local work (mpc/mhe.go:222-348 -> lattigo v2.1.0 dckks/refresh.go; PARITY UNPINNED, see the .c file) ---- */
+void orc_bigint_to_rns(const orc_ring *r, int nmod, const uint64_t *limbs /*[N][W] two's complement*/, int W, uint64_t *out /*[nmod][N]*/);
+void orc_refresh_gen_shares(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *sk, const uint64_t *crs, const uint64_t *mask, int W,
+                            const int32_t *e0, const int32_t *e1, uint64_t *h0 /*[level+1][N]*/, uint64_t *h1 /*[nq][N]*/);
+void orc_refresh_finish(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs,
+                        uint64_t *out /*[2][nq][N]*/);
+
 /* splitmix64 — the synthetic-data PRNG shared by oracle, tests, bench and device generators */
 uint64_t orc_splitmix64(uint64_t *state);
 

@@ -31,6 +31,9 @@ def _sig(L):
         "sfg_ctx_synchronize": (i, [vp]),
         "sfg_ctx_set_stream": (i, [vp, vp]),
         "sfg_ctx_load_rotkey": (i, [vp, u64, u64p, i]),
+        "sfg_ctx_load_secret_key": (i, [vp, u64p, i]),
+        "sfg_refresh_gen_shares_dev": (i, [vp, vp, i, i, vp, vp, i, vp, vp, vp, vp]),
+        "sfg_refresh_finish_dev": (i, [vp, vp, i, i, vp, vp, vp, vp]),
         "sfg_ctx_has_rotkey": (i, [vp, u64]),
         "sfg_ctx_export_rotkey": (i, [vp, u64, u64p]),
         "sfg_galois_for_rotation": (u64, [vp, i]),
@@ -190,6 +193,33 @@ class Context:
         key = np.zeros((self.beta, 2, self.nq + self.np_, self.N), dtype=np.uint64)
         self.check(lib().sfg_ctx_export_rotkey(self.h, int(galois), p64(key)), "export_rotkey")
         return key
+
+    # ---- collective bootstrap, local work
+    def load_secret_key(self, sk_rows, montgomery=False):
+        sk_rows = np.ascontiguousarray(sk_rows, dtype=np.uint64)
+        assert sk_rows.shape == (self.nq, self.N)
+        self.check(lib().sfg_ctx_load_secret_key(self.h, p64(sk_rows), int(montgomery)), "load_secret_key")
+
+    def refresh_gen_shares(self, cts, level, crs, mask_limbs, e0, e1):
+        """cts [nct][2][level+1][N], crs [nct][nq][N], mask_limbs [nct][N][W] uint64, e0/e1 [nct][N] int32 -> (h0 [nct][level+1][N], h1 [nct][nq][N])"""
+        nct, W = cts.shape[0], mask_limbs.shape[-1]
+        d = [self.to_device(np.ascontiguousarray(a)) for a in (cts, crs, mask_limbs, e0.astype(np.int32), e1.astype(np.int32))]
+        h0, h1 = self.malloc(nct * (level + 1) * self.N * 8), self.malloc(nct * self.nq * self.N * 8)
+        self.check(lib().sfg_refresh_gen_shares_dev(self.h, d[0], nct, level, d[1], d[2], W, d[3], d[4], h0, h1), "refresh_gen_shares")
+        out = self.to_host(h0, (nct, level + 1, self.N), np.uint64), self.to_host(h1, (nct, self.nq, self.N), np.uint64)
+        for p_ in d + [h0, h1]:
+            self.free(p_)
+        return out
+
+    def refresh_finish(self, cts, level, h0agg, h1agg, crs):
+        nct = cts.shape[0]
+        d = [self.to_device(np.ascontiguousarray(a)) for a in (cts, h0agg, h1agg, crs)]
+        o = self.malloc(nct * 2 * self.nq * self.N * 8)
+        self.check(lib().sfg_refresh_finish_dev(self.h, d[0], nct, level, d[1], d[2], d[3], o), "refresh_finish")
+        out = self.to_host(o, (nct, 2, self.nq, self.N), np.uint64)
+        for p_ in d + [o]:
+            self.free(p_)
+        return out
 
     def fork(self):
         """a second caller on the same tables and keys (sfg_ctx_fork): own queues, scratch and timers"""

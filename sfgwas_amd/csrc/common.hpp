@@ -66,6 +66,7 @@ struct SfgShared {
     ModConst modc_host[SFG_MAXMOD];
     void *enc_tables = nullptr;  // encoder tables (double-double twiddles), see encode.hip
     void *zeros_dev = nullptr;   // 256 B of zeros (DMA source for padded k-steps)
+    u64 *sk_dev = nullptr;       // secret-key shard [nq][N], NTT domain, canonical (sfg_ctx_load_secret_key; collective bootstrap shares)
     std::map<u64, RotKey> rotkeys;      // written only by sfg_ctx_load_rotkey / _relinkey (setup time), read by every fork
     SfgConfig cfg;
     int refs = 1;                // the creating context + live forks

@@ -167,7 +167,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     if (sh && __atomic_sub_fetch(&sh->refs, 1, __ATOMIC_ACQ_REL) == 0) {
         for (auto &kv : sh->rotkeys) { (void)hipFree(kv.second.key_dev); (void)hipFree(kv.second.index_dev); }
         sfg_encoder_destroy(sh);
-        (void)hipFree(sh->tw_fwd); (void)hipFree(sh->tw_inv); (void)hipFree(sh->pack_fwd); (void)hipFree(sh->pack_inv); (void)hipFree(sh->modc); (void)hipFree(sh->zeros_dev);
+        (void)hipFree(sh->tw_fwd); (void)hipFree(sh->tw_inv); (void)hipFree(sh->pack_fwd); (void)hipFree(sh->pack_inv); (void)hipFree(sh->modc); (void)hipFree(sh->zeros_dev); (void)hipFree(sh->sk_dev);
         delete sh;
     }
     delete ctx;
@@ -302,6 +302,20 @@ __global__ void k_from_montgomery(u64 *rows, int nmod, const ModConst *modc, siz
     __syncthreads();
     u64 *p = rows + row * SFG_N;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < SFG_N; x += gridDim.x * blockDim.x) p[x] = d_mulmod_u64(p[x], r64inv, q);
+}
+
+// cryptoParams.Sk.Value (crypto.go:44): this party's secret-key shard, the Q rows [nq][N] in the NTT domain
+extern "C" int sfg_ctx_load_secret_key(sfg_ctx *ctx, const uint64_t *sk_host, int mont) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t words = (size_t)ctx->nq * SFG_N;
+    if (!ctx->sh->sk_dev) SFG_HIP(ctx, hipMalloc(&ctx->sh->sk_dev, words * 8));
+    SFG_HIP(ctx, hipMemcpyAsync(ctx->sh->sk_dev, sk_host, words * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (mont) {
+        dim3 grid(8, (unsigned)ctx->nq);
+        hipLaunchKernelGGL(k_from_montgomery, grid, dim3(256), 0, ctx->stream, ctx->sh->sk_dev, ctx->nq, ctx->modc, (size_t)grid.y);
+    }
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 extern "C" int sfg_ctx_load_rotkey(sfg_ctx *ctx, uint64_t g, const uint64_t *key_host, int mont) {

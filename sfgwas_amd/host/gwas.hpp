@@ -338,6 +338,32 @@ inline DevCipherVector DropLevelDev(const DevCipherVector &X, int outLevel) {
     X.cps->check(sfg_ct_drop_level_dev(X.cps->ctx, X.ptr(), o.ptr(), (int)X.n, X.level, outLevel), "DropLevel");
     return o;
 }
+// crypto.FlattenLevels (basics.go:514-531): every ciphertext dropped to the minimum level of the matrix; returns that level
+inline std::pair<CipherMatrix, int> FlattenLevels(CryptoParams *cps, const CipherMatrix &cm) {
+    int minLevel = cm[0][0].level; bool mixed = false;
+    for (const auto &row : cm) for (const auto &ct : row) { if (ct.level != minLevel) mixed = true; if (ct.level < minLevel) minLevel = ct.level; }
+    if (!mixed) return {cm, minLevel};
+    CipherMatrix out(cm.size());
+    for (size_t i = 0; i < cm.size(); i++) {
+        out[i].resize(cm[i].size());
+        for (size_t j = 0; j < cm[i].size(); j++) {
+            if (cm[i][j].level == minLevel) { out[i][j] = cm[i][j]; continue; }
+            DevCipherVector one = DropLevelDev(ToDevice(cps, CipherVector{cm[i][j]}), minLevel);
+            out[i][j] = ToHost(one)[0];
+        }
+    }
+    return {out, minLevel};
+}
+// crypto.ConcatCipherMatrix (basics.go:773-790): column-wise concatenation of the rows of several matrices (device to device)
+inline DevCipherMatrix ConcatCipherMatrixDev(CryptoParams *cps, const std::vector<DevCipherMatrix> &parts) {
+    if (parts.empty()) throw std::runtime_error("ConcatCipherMatrix: no matrices");
+    size_t cols = 0; for (const auto &p : parts) { if (p.rows != parts[0].rows || p.level != parts[0].level) throw std::runtime_error("ConcatCipherMatrix: shapes differ"); cols += p.cols; }
+    DevCipherMatrix out = NewDevCipherMatrix(cps, parts[0].rows, cols, parts[0].level, parts[0].scale);
+    const size_t w = (size_t)2 * (out.level + 1) * cps->N();
+    for (size_t i = 0; i < out.rows; i++) { size_t c0 = 0;
+        for (const auto &p : parts) { cps->check(sfg_memcpy_d2d(cps->ctx, out.row(i).ptr(c0), p.row(i).ptr(), p.cols * w * 8), "d2d"); c0 += p.cols; } }
+    return out;
+}
 namespace detail {
 // n copies of one ciphertext (the length-1 broadcast of CMult / CSub), device to device
 inline DevCipherVector broadcast(const DevCipherVector &x, size_t n) {
@@ -783,6 +809,31 @@ inline RVec BeaverMultElemVec(MPC *m, const RVec &ar, const RVec &am, const RVec
 inline RVec BeaverMultMat(MPC *m, const RVec &ar, const RVec &am, const RVec &br, const RVec &bm, int rows, int inner, int cols) {
     RVec out; out.limbs = am.limbs; out.w.resize((size_t)rows * cols * am.limbs);
     m->cps->check(sfg_beaver_matmul(m->cps->ctx, m->pid, am.limbs, m->modulus.data(), ar.w.data(), am.w.data(), br.w.data(), bm.w.data(), out.w.data(), rows, inner, cols), "BeaverMultMat");
+    return out;
+}
+
+// ---- collective bootstrap, local halves (mpc/mhe.go:289-348 CollectiveBootstrapMat).  The network steps between them stay in Go:
+//      broadcast of cm (:296-311), AggregateRefreshShareMat (:326-327).  PARITY UNPINNED (see include/sfgwas_hip.h).
+// Per-ciphertext randomness is drawn by the caller, as the reference draws it (ring.RandInt masks, the Gaussian sampler, crpGen.ReadNew()):
+//   masks [nct][N][maskLimbs] two's-complement limbs, e0 / e1 [nct][N], crs [nct][nq][N]  - all device resident
+struct RefreshRandomness { const uint64_t *mask = nullptr; int maskLimbs = 0; const int32_t *e0 = nullptr, *e1 = nullptr; const uint64_t *crs = nullptr; };
+struct RefreshShares {            // refSharesDecrypt [nct][level+1][N], refSharesRecrypt [nct][nq][N]
+    std::shared_ptr<crypto::detail::DevBuf> h0, h1; size_t nct = 0; int level = 0;
+};
+// mhe.go:313-324: FlattenLevels has already been applied (cm is one level); one GenShares per ciphertext, batched
+inline RefreshShares CollectiveBootstrapGenShares(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &cm, const RefreshRandomness &rnd) {
+    RefreshShares sh; sh.nct = cm.rows * cm.cols; sh.level = cm.level;
+    const size_t N = (size_t)cps->N();
+    sh.h0 = std::make_shared<crypto::detail::DevBuf>(cps, sh.nct * (cm.level + 1) * N * 8);
+    sh.h1 = std::make_shared<crypto::detail::DevBuf>(cps, sh.nct * cps->nq * N * 8);
+    cps->check(sfg_refresh_gen_shares_dev(cps->ctx, cm.buf->u(), (int)sh.nct, cm.level, rnd.crs, rnd.mask, rnd.maskLimbs, rnd.e0, rnd.e1, sh.h0->u(), sh.h1->u()), "RefreshProtocol.GenShares");
+    return sh;
+}
+// mhe.go:329-346: Decrypt, Recode, Recrypt with the aggregated shares; the result is at MaxLevel with scale unchanged (scale == target scale)
+inline crypto::DevCipherMatrix CollectiveBootstrapFinish(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &cm, const uint64_t *h0agg, const uint64_t *h1agg,
+                                                         const uint64_t *crs) {
+    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, cm.rows, cm.cols, cps->nq - 1, cm.scale);
+    cps->check(sfg_refresh_finish_dev(cps->ctx, cm.buf->u(), (int)(cm.rows * cm.cols), cm.level, h0agg, h1agg, crs, out.buf->u()), "RefreshProtocol.Decrypt/Recode/Recrypt");
     return out;
 }
 }  // namespace mpc

@@ -115,6 +115,9 @@ def lib():
         L.orc_diagcache_close.argtypes = [C.c_void_p]
         L.orc_beaver_elem.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_size_t]
         L.orc_beaver_matmul.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int, C.c_int, C.c_int]
+        L.orc_bigint_to_rns.argtypes = [C.c_void_p, C.c_int, u64p, C.c_int, u64p]
+        L.orc_refresh_gen_shares.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, u64p]
+        L.orc_refresh_finish.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p, u64p]
         L.orc_sketch.argtypes = [C.POINTER(C.c_int8), C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.c_int,
                                  C.POINTER(C.c_double), u64p, u64p]
     return _lib
@@ -302,3 +305,45 @@ def splitmix64_array(seed, n):
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
+
+
+# ---- collective bootstrap, local work (oracle restatement of lattigo v2.1.0 dckks/refresh.go; parity unpinned)
+def bigints_to_limbs(vals, W):
+    """signed Python ints -> [len][W] two's-complement little-endian uint64 limbs"""
+    out = np.zeros((len(vals), W), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        u = int(v) & ((1 << (64 * W)) - 1)
+        for w in range(W):
+            out[i, w] = (u >> (64 * w)) & mask
+    return out
+
+
+def pi32(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def refresh_gen_shares(ring, level, ct, sk, crs, mask_limbs, e0, e1):
+    h0 = np.zeros((level + 1, ring.N), dtype=np.uint64)
+    h1 = np.zeros((ring.nq, ring.N), dtype=np.uint64)
+    lib().orc_refresh_gen_shares(ring.h, level, p64(np.ascontiguousarray(ct)), p64(np.ascontiguousarray(sk)), p64(np.ascontiguousarray(crs)),
+                                 p64(np.ascontiguousarray(mask_limbs)), mask_limbs.shape[1], pi32(np.ascontiguousarray(e0)), pi32(np.ascontiguousarray(e1)),
+                                 p64(h0), p64(h1))
+    return h0, h1
+
+
+def refresh_finish(ring, level, ct, h0agg, h1agg, crs):
+    out = np.zeros((2, ring.nq, ring.N), dtype=np.uint64)
+    lib().orc_refresh_finish(ring.h, level, p64(np.ascontiguousarray(ct)), p64(np.ascontiguousarray(h0agg)), p64(np.ascontiguousarray(h1agg)),
+                             p64(np.ascontiguousarray(crs)), p64(out))
+    return out
+
+
+def secret_ntt(ring, s_coeff):
+    """ternary secret coefficients -> NTT-domain canonical rows [nq][N]"""
+    rows = np.zeros((ring.nq, ring.N), dtype=np.uint64)
+    for j in range(ring.nq):
+        q = ring.moduli[j]
+        rows[j] = ring.ntt(j, np.where(s_coeff < 0, q - 1, s_coeff.astype(np.int64)).astype(np.uint64))
+    return rows

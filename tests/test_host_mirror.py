@@ -392,3 +392,53 @@ def test_logistic_path_ciphertext_matrix_helpers_match_the_oracle(tmp_path):
                 multi = elem.cmult(Mo[kk])
                 res[c] = multi if res[c] is None else multi.add(res[c])
         assert np.array_equal(load(name, res), np.stack([x.data for x in res])), name
+
+
+@pytest.mark.gpu
+def test_collective_bootstrap_local_halves_flatten_and_concat_match_the_oracle(tmp_path):
+    """mpc/mhe.go:289-348 (CollectiveBootstrapMat) local halves + crypto.FlattenLevels / ConcatCipherMatrix (basics.go:514-531, 773-790) through the
+    host mirror, device resident, vs the oracle's restatement of dckks.RefreshProtocol (parity unpinned: fork source absent)"""
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_bootstrap_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    rows, level, W = 3, 2, 3
+    rnd = np.random.default_rng(21)
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    sk = ol.secret_ntt(ring, ring.gen_secret(6)); sk.tofile(tmp_path / "sk.bin")
+    first_hi = ring.fill_uniform(level + 1, 301)
+    rest = np.stack([ring.fill_uniform(level, 310 + i) for i in range(rows - 1)])
+    first_hi.tofile(tmp_path / "cm_first_hi.bin"); rest.tofile(tmp_path / "cm_rest.bin")
+    cm = np.concatenate([first_hi[None, :, :level + 1, :], rest])                 # DropLevel keeps the first level+1 rows of both polynomials
+    Ql = 1
+    for q in ring.moduli[:level + 1]:
+        Ql *= q
+    bound = Ql // 4
+    limbs = np.zeros((rows, ring.N, W), dtype=np.uint64)
+    for i in range(rows):
+        vals = []
+        for _ in range(ring.N):
+            m = int.from_bytes(rnd.bytes(40), "little") % bound
+            vals.append(m - bound if m >= bound >> 1 else m)
+        limbs[i] = ol.bigints_to_limbs(vals, W)
+    limbs.tofile(tmp_path / "mask.bin")
+    crs = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(ring.nq)]) for _ in range(rows)])
+    crs.tofile(tmp_path / "crs.bin")
+    e0 = rnd.integers(-19, 20, (rows, ring.N)).astype(np.int32); e1 = rnd.integers(-19, 20, (rows, ring.N)).astype(np.int32)
+    np.concatenate([e0.reshape(-1), e1.reshape(-1)]).tofile(tmp_path / "e.bin")
+    h0agg = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(level + 1)]) for _ in range(rows)])
+    h1agg = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(ring.nq)]) for _ in range(rows)])
+    h0agg.tofile(tmp_path / "h0agg.bin"); h1agg.tofile(tmp_path / "h1agg.bin")
+    (tmp_path / "case.txt").write_text(f"{rows} {level} {W}\n")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr
+    ld = lambda name, shape: np.fromfile(tmp_path / name, dtype=np.uint64).reshape(shape)
+    assert np.array_equal(ld("flat.bin", cm.shape), cm), "FlattenLevels"
+    cc = ld("concat.bin", (rows, 2) + cm.shape[1:])
+    assert np.array_equal(cc[:, 0], cm) and np.array_equal(cc[:, 1], cm), "ConcatCipherMatrix"
+    h0, h1 = ld("h0.bin", (rows, level + 1, ring.N)), ld("h1.bin", (rows, ring.nq, ring.N))
+    got = ld("out.bin", (rows, 2, ring.nq, ring.N))
+    for i in range(rows):
+        w0, w1 = ol.refresh_gen_shares(ring, level, cm[i], sk, crs[i], limbs[i], e0[i], e1[i])
+        assert np.array_equal(h0[i], w0) and np.array_equal(h1[i], w1), f"GenShares of ciphertext {i}"
+        assert np.array_equal(got[i], ol.refresh_finish(ring, level, cm[i], h0agg[i], h1agg[i], crs[i])), f"Decrypt/Recode/Recrypt of ciphertext {i}"
