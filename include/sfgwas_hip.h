@@ -105,6 +105,9 @@ int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, int nvec, in
  * (RotateRightWithEvaluator semantics: nrot mod slots, 0 = copy). in/out may not alias. */
 int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *ct_in_dev, uint64_t *ct_out_dev, int nct, int level,
                          const int *nrot_host);
+/* eval.ConjugateNew behind crypto.ComplexConjugate / CReal (basics.go:826-846): the automorphism X -> X^galois_el with the switching key loaded
+ * under that element by sfg_ctx_load_rotkey (lattigo's conjugation key: galois element 2N-1).  Batch of nct ciphertexts; in/out may not alias. */
+int sfg_ct_galois_dev(sfg_ctx *ctx, const uint64_t *ct_in_dev, uint64_t *ct_out_dev, int nct, int level, uint64_t galois_el);
 /* C4: element-wise ciphertext add (eval.Add, basics.go:174, matmult.go:1225,1494): out = a + b */
 int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev, int nct, int level);
 /* C4: eval.Sub (crypto.CSub, basics.go:575-590): out = a - b */
@@ -225,6 +228,12 @@ int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, in
  *   c0' = NTT( centred( CRT( INTT(c0 + h0agg) ) ) mod every q_j ) + h1agg,   c1' = crs */
 int sfg_refresh_finish_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, const uint64_t *h0agg_dev, const uint64_t *h1agg_dev,
                            const uint64_t *crs_dev, uint64_t *out_dev);
+
+/* f-4 (partial): ring work of MPC.CMatToSS (mpc/ss.go:146-281): the masked decryption share of each ciphertext and NTT(mask), which the Go side
+ * turns into the additive share with the fork's DecodeRVec (ss.go:253-262; fork-only encoder API, stays in Go).
+ *   h0 [nct][level+1][N] = NTT(mask) + sk (.) c1 + NTT(e0)   (ss.go:222-236)      mask_ntt [nct][level+1][N] = NTT(mask)   (ctMask, ss.go:226) */
+int sfg_ckks_to_ss_share_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, const uint64_t *mask_dev, int mask_limbs, const int32_t *e0_dev,
+                             uint64_t *h0_dev, uint64_t *mask_ntt_dev);
 
 /* ---- B1-B3: Beaver local products (mpc/beavermult.go:94-147) over a prime field of `limbs` 64-bit LE limbs ---- */
 int sfg_beaver_elem_dev(sfg_ctx *ctx, int pid, int limbs, const uint64_t *modulus_host,

@@ -468,6 +468,23 @@ int orc_rotate_left(const orc_ring *r, const orc_rotkeys *keys, int level, const
     }
     free(d0); free(d1); free(idx); return 0;
 }
+/* eval.ConjugateNew (crypto.ComplexConjugate, basics.go:826-837) and any other automorphism: key switch under the key of `galois_el`, then
+ * X -> X^galois_el (lattigo: galois element 2N-1 = GaloisElementForRowRotation conjugates the slots) */
+int orc_apply_galois(const orc_ring *r, const orc_rotkeys *keys, int level, const u64 *ct, u64 g, u64 *out) {
+    int N = r->N, nl = level + 1;
+    const u64 *key = orc_rotkeys_get(keys, g); if (!key) return -1;
+    u64 *d0 = malloc(sizeof(u64) * nl * N), *d1 = malloc(sizeof(u64) * nl * N);
+    uint32_t *idx = malloc(sizeof(uint32_t) * N);
+    orc_keyswitch(r, level, ct + (size_t)nl * N, key, d0, d1);
+    orc_automorphism_index(r, g, idx);
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m]; const u64 *c0 = ct + (size_t)m * N; u64 *t0 = d0 + (size_t)m * N, *t1 = d1 + (size_t)m * N;
+        u64 *o0 = out + (size_t)m * N, *o1 = out + (size_t)(nl + m) * N;
+        for (int x = 0; x < N; x++) { u64 s = t0[x] + c0[x]; if (s >= q) s -= q; t0[x] = s; }
+        for (int x = 0; x < N; x++) { o0[x] = t0[idx[x]]; o1[x] = t1[idx[x]]; }
+    }
+    free(d0); free(d1); free(idx); return 0;
+}
 int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, const u64 *ct, int nrot, u64 *out) {
     int n = r->N / 2; nrot = mod_i(nrot, n);
     return orc_rotate_left(r, keys, level, ct, nrot ? n - nrot : 0, out);

@@ -88,6 +88,7 @@ void orc_keyswitch(const orc_ring *r, int level, const uint64_t *cx, const uint6
 /* ct layout: [2][level+1][N]. rotate LEFT by k slots (lattigo RotateNew(ct,k)). returns 0 ok, -1 missing key */
 int orc_rotate_left(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *ct_in, int k, uint64_t *ct_out);
 /* crypto.RotateRightWithEvaluator semantics (basics.go:201-210) */
+int orc_apply_galois(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *ct_in, uint64_t galois_el, uint64_t *ct_out);   /* ConjugateNew: 2N-1 */
 int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *ct_in, int nrot, uint64_t *ct_out);
 
 /* ---- input formats (scripts/plinkBedToBinary.py, filterMatrix.py) ---- */

@@ -32,8 +32,10 @@ def _sig(L):
         "sfg_ctx_set_stream": (i, [vp, vp]),
         "sfg_ctx_load_rotkey": (i, [vp, u64, u64p, i]),
         "sfg_ctx_load_secret_key": (i, [vp, u64p, i]),
+        "sfg_ct_galois_dev": (i, [vp, vp, vp, i, i, u64]),
         "sfg_refresh_gen_shares_dev": (i, [vp, vp, i, i, vp, vp, i, vp, vp, vp, vp]),
         "sfg_refresh_finish_dev": (i, [vp, vp, i, i, vp, vp, vp, vp]),
+        "sfg_ckks_to_ss_share_dev": (i, [vp, vp, i, i, vp, i, vp, vp, vp]),
         "sfg_ctx_has_rotkey": (i, [vp, u64]),
         "sfg_ctx_export_rotkey": (i, [vp, u64, u64p]),
         "sfg_galois_for_rotation": (u64, [vp, i]),
@@ -208,6 +210,16 @@ class Context:
         self.check(lib().sfg_refresh_gen_shares_dev(self.h, d[0], nct, level, d[1], d[2], W, d[3], d[4], h0, h1), "refresh_gen_shares")
         out = self.to_host(h0, (nct, level + 1, self.N), np.uint64), self.to_host(h1, (nct, self.nq, self.N), np.uint64)
         for p_ in d + [h0, h1]:
+            self.free(p_)
+        return out
+
+    def ckks_to_ss_share(self, cts, level, mask_limbs, e0):
+        nct, W = cts.shape[0], mask_limbs.shape[-1]
+        d = [self.to_device(np.ascontiguousarray(a)) for a in (cts, mask_limbs, e0.astype(np.int32))]
+        h0, mk = self.malloc(nct * (level + 1) * self.N * 8), self.malloc(nct * (level + 1) * self.N * 8)
+        self.check(lib().sfg_ckks_to_ss_share_dev(self.h, d[0], nct, level, d[1], W, d[2], h0, mk), "ckks_to_ss_share")
+        out = self.to_host(h0, (nct, level + 1, self.N), np.uint64), self.to_host(mk, (nct, level + 1, self.N), np.uint64)
+        for p_ in d + [h0, mk]:
             self.free(p_)
         return out
 

@@ -42,6 +42,12 @@ __global__ void __launch_bounds__(256) k_bigint_rows(const u64 *mask, int W, con
     v = v < 0.0 ? v + q : v; v = v >= q ? v - q : v;
     rows[(c * nmod + j) * (size_t)N + x] = f64_to_u64(v);
 }
+// rows[(ct, j)][x] = e[ct][x] mod q_j (small signed coefficients).  grid (N/256, nmod, nct)
+__global__ void __launch_bounds__(256) k_small_rows(const int *e, u64 *rows, int nmod, const ModConst *modc) {
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y; const size_t c = blockIdx.z;
+    const long long v = e[c * N + x];
+    rows[(c * nmod + j) * (size_t)N + x] = v < 0 ? modc[j].qi - (u64)(-v) : (u64)v;
+}
 // h = rows + sk (.) xrow (mod q), negated if neg.  rows/h: [nct][nmod][N]; xrow: row (ct, j) at x + ct * x_ct_stride + j * N.  grid (N/256, nmod, nct)
 __global__ void __launch_bounds__(256) k_share(const u64 *rows, const u64 *sk, const u64 *xr, size_t x_ct_stride, u64 *h, int nmod, int neg, const ModConst *modc) {
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y; const size_t c = blockIdx.z;
@@ -129,6 +135,34 @@ extern "C" int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct, int 
     ModPattern p1; p1.period = nq; for (int j = 0; j < nq; j++) p1.m[j] = (int8_t)j;
     SFG_TRY(launch_ntt_fwd(ctx, (const u64 *)h1, (u64 *)h1, (size_t)nct * nq, p1));
     hipLaunchKernelGGL(k_share, dim3(N / 256, nq, nct), dim3(256), 0, ctx->stream, (const u64 *)h1, sk, (const u64 *)crs, (size_t)nq * N, (u64 *)h1, nq, 1, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- f-4 (partial): the ring work of MPC.CMatToSS (mpc/ss.go:146-281).  Its mask share is GenShares' h0 (ss.go:222-236: SetCoefficientsBigintLvl,
+// NTTLvl, MulCoeffsMontgomeryAndAddLvl(sk, c1), + NTT(gaussian)), and it also keeps NTT(mask) itself as the plaintext ctMask (ss.go:226) that
+// DecodeRVec turns into the party's additive share.  DecodeRVec / EncodeRVecNew are fork-only encoder entry points and stay in Go.
+//   h0 [nct][level+1][N] = NTT(mask) + sk (.) c1 + NTT(e0);   mask_ntt [nct][level+1][N] = NTT(mask)
+extern "C" int sfg_ckks_to_ss_share_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *mask, int W, const int32_t *e0,
+                                        uint64_t *h0, uint64_t *mask_ntt) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(refresh_check(ctx, nct, level));
+    if (!ctx->sh->sk_dev) SFG_FAIL(ctx, "CMatToSS: no secret-key shard loaded (sfg_ctx_load_secret_key)");
+    if (W < 1 || W > 16) SFG_FAIL(ctx, "CMatToSS: mask limb count %d out of range", W);
+    if (!nct) return 0;
+    const int N = SFG_N, nl = level + 1;
+    int *zero = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "refresh.zero_e", (size_t)nct * N * sizeof(int), (void **)&zero));
+    SFG_HIP(ctx, hipMemsetAsync(zero, 0, (size_t)nct * N * sizeof(int), ctx->stream));
+    ModPattern p0; p0.period = nl; for (int j = 0; j < nl; j++) p0.m[j] = (int8_t)j;
+    hipLaunchKernelGGL(k_bigint_rows, dim3(N / 256, nl, nct), dim3(256), 0, ctx->stream, (const u64 *)mask, W, (const int *)zero, (u64 *)mask_ntt, nl, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_TRY(launch_ntt_fwd(ctx, (const u64 *)mask_ntt, (u64 *)mask_ntt, (size_t)nct * nl, p0));
+    hipLaunchKernelGGL(k_small_rows, dim3(N / 256, nl, nct), dim3(256), 0, ctx->stream, (const int *)e0, (u64 *)h0, nl, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_TRY(launch_ntt_fwd(ctx, (const u64 *)h0, (u64 *)h0, (size_t)nct * nl, p0));
+    hipLaunchKernelGGL(k_add_rows, dim3(N / 256, nl, nct), dim3(256), 0, ctx->stream, (const u64 *)h0, (size_t)nl * N, (const u64 *)mask_ntt, (size_t)nl * N, (u64 *)h0, (size_t)nl * N, ctx->modc);
+    hipLaunchKernelGGL(k_share, dim3(N / 256, nl, nct), dim3(256), 0, ctx->stream, (const u64 *)h0, ctx->sh->sk_dev, (const u64 *)ct + (size_t)nl * N, (size_t)2 * nl * N, (u64 *)h0, nl, 0, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -314,6 +314,23 @@ extern "C" int sfg_rotate_right_dev(sfg_ctx *ctx, const uint64_t *in, uint64_t *
     return rc;
 }
 
+// eval.ConjugateNew (crypto.ComplexConjugate / CReal, basics.go:826-846) and any other automorphism X -> X^g whose switching key was loaded under g
+// (lattigo: g = 2N-1 conjugates the slots)
+extern "C" int sfg_ct_galois_dev(sfg_ctx *ctx, const uint64_t *in, uint64_t *out, int nct, int level, uint64_t galois_el) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (in == out) SFG_FAIL(ctx, "galois: in and out must not alias");
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "galois: level out of range");
+    auto it = ctx->rotkeys().find(galois_el);
+    if (it == ctx->rotkeys().end() || galois_el == 1) SFG_FAIL(ctx, "galois: no switching key loaded for galois element %llu", (unsigned long long)galois_el);
+    const size_t ctw = (size_t)2 * (level + 1) * SFG_N;
+    std::vector<int> job_in(nct); std::vector<const u64 *> keyp(nct, it->second.key_dev); std::vector<const uint16_t *> idxp(nct, it->second.index_dev); std::vector<u64 *> outp(nct);
+    for (int j = 0; j < nct; j++) { job_in[j] = j; outp[j] = (u64 *)out + (size_t)j * ctw; }
+    PhaseTimer t(ctx, "rotate");
+    int rc = launch_keyswitch_jobs(ctx, (const u64 *)in, nct, level, job_in, keyp, idxp, outp, nullptr);
+    t.stop(1);
+    return rc;
+}
+
 int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct, int level) {
     const int nl = level + 1; const size_t rows = nct * 2 * nl;
     if (!rows) return 0;

@@ -66,6 +66,8 @@ def lib():
         L.orc_rotate_left.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_int, u64p]
         L.orc_rotate_right.restype = C.c_int
         L.orc_rotate_right.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_int, u64p]
+        L.orc_apply_galois.restype = C.c_int
+        L.orc_apply_galois.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u64p, C.c_uint64, u64p]
         L.orc_gen_secret.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int8)]
         L.orc_gen_rotkey.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_uint64, C.c_uint64, u64p]
         L.orc_encrypt_coeffs.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_int, C.POINTER(C.c_int64), C.c_uint64, u64p]

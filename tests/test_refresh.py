@@ -179,3 +179,27 @@ def test_gpu_recode_tie_at_half_modulus():
         coeffs = ring.intt(j, got[0, 0, j])
         assert [int(x) for x in coeffs[:6]] == [v % ring.moduli[j] for v in signed]
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ckks_to_ss_share_is_the_decrypt_share_and_the_mask_plaintext():
+    """MPC.CMatToSS ring work (mpc/ss.go:222-236): h0 equals GenShares' decrypt share; mask_ntt equals NTT(mask) = the same share with sk = 0, e0 = 0"""
+    from sfgwas_amd import capi
+    level, W, nct = 3, 4, 2
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    sk = ol.secret_ntt(ring, ring.gen_secret(4))
+    ctx.load_secret_key(sk)
+    rnd = np.random.default_rng(55)
+    Ql = 1
+    for q in ring.moduli[:level + 1]:
+        Ql *= q
+    cts = np.stack([ring.fill_uniform(level, 70 + i) for i in range(nct)])
+    limbs = np.stack([make_masks(rnd, ring.N, Ql // 4, W)[1] for _ in range(nct)])
+    e0 = rnd.integers(-19, 20, (nct, ring.N)).astype(np.int32)
+    zero_e, zero_crs, zero_sk = np.zeros(ring.N, dtype=np.int32), np.zeros((ring.nq, ring.N), dtype=np.uint64), np.zeros_like(sk)
+    h0, mk = ctx.ckks_to_ss_share(cts, level, limbs, e0)
+    for i in range(nct):
+        assert np.array_equal(h0[i], ol.refresh_gen_shares(ring, level, cts[i], sk, zero_crs, limbs[i], e0[i], zero_e)[0])
+        assert np.array_equal(mk[i], ol.refresh_gen_shares(ring, level, cts[i], zero_sk, zero_crs, limbs[i], zero_e, zero_e)[0])
+    ctx.close()
