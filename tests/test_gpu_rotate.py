@@ -84,7 +84,7 @@ def test_conjugate_and_generic_galois_element_bit_exact(env):
         assert np.array_equal(got[j], want), f"ciphertext {j}"
     # semantics: p(X) -> p(X^(2N-1)) = p(X^-1): coefficient c moves to N - c with a sign flip (c > 0)
     q0 = ring.moduli[0]
-    dec = ring.intt(0, ring.decrypt_residues(s, level, got[0])[0])
+    dec = ring.decrypt_residues(s, level, got[0])[0]                      # coefficient domain, modulus 0
     dec = np.array([int(v) - q0 if int(v) > q0 // 2 else int(v) for v in dec])
     want_m = np.zeros(ring.N, dtype=np.int64); want_m[0] = m[0]; want_m[1:] = -m[:0:-1]
     assert np.max(np.abs(dec - want_m)) < 1 << 16          # key-switch noise only
