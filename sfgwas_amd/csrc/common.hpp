@@ -180,6 +180,15 @@ __device__ __forceinline__ double mulmod_lazy(double x, double w, double wq, dou
     double r = __builtin_fma(-qh, q, h);
     return r + l;
 }
+// The same product with the quotient estimated from the rounded high part: needs only 1/q, not w/q, so butterflies that take a fresh twiddle
+// spend no multiply on w * (1/q).  |x * w / q| < 2^41 keeps the estimate within 1/2 + 2^-11 of the true quotient: result in (-q, q).
+__device__ __forceinline__ double mulmod_lazy_q(double x, double w, double q, double qinv) {
+    double h = x * w;
+    double qh = __builtin_rint(h * qinv);
+    double l = __builtin_fma(x, w, -h);
+    double r = __builtin_fma(-qh, q, h);
+    return r + l;
+}
 // canonical representative in [0, q) of an integer-valued double |x| < 2^51.
 // y = fl(x * fl(1/q)) is within |x/q| * 2^-52 (1 + 2^-53) of x/q.  Write x = k q + e, 0 <= e < q: for e >= 1 both e/q and (q - e)/q exceed
 // that error (e >= 1 > |x| 2^-51), so floor(y) = k; for e = 0, y = k (1 + d) may fall just below k, floor(y) = k - 1 and the exact

@@ -130,25 +130,32 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
             pkk[t - RT] = kk;
         }
     }
-    auto issue_chunk = [&](int ch) {
+    // DMA issue rounds [t0, t1) of chunk ch (A rounds per wave and chunk; round t moves job t * 8 + wave).  The rounds of one chunk are issued
+    // a few at a time between the k-steps of the chunk that runs meanwhile: 32 KiB landing in one burst would hold the LDS ports long
+    // enough to delay the operand reads of the running k-step.
+    auto issue_rounds = [&](int ch, int t0, int t1) {
         unsigned char *slot = lds + (size_t)(ch % DEPTH) * SLOT;
         const unsigned char *rb = rot_u + (size_t)ch * rot_step, *pb = pt_u + (size_t)ch * pt_step;
+        const bool ragged = ch >= nchunk_full;     // ragged last chunk: the padded k-steps take a zero plaintext; rot is read as is (finite by the launcher's contract)
+#pragma unroll
+        for (int t = 0; t < A; t++) {
+            if (t < t0 || t >= t1) continue;
+            if (t < RT) {
 #ifdef SFG_MAC_DIAG
-        if (!(a.diag & 1))
+                if (a.diag & 1) continue;
 #endif
-#pragma unroll
-        for (int t = 0; t < RT; t++) bc_dma16(rb + roff[t], slot + (t * BC_WAVES + wave) * 1024);
+                bc_dma16(rb + roff[t], slot + (t * BC_WAVES + wave) * 1024);
+            } else {
 #ifdef SFG_MAC_DIAG
-        if (a.diag & 2) return;
+                if (a.diag & 2) continue;
 #endif
-        if (ch < nchunk_full) {
-#pragma unroll
-            for (int t = RT; t < A; t++) bc_dma16(pb + poff[t - RT], slot + (t * BC_WAVES + wave) * 1024);
-        } else {        // ragged last chunk: the padded k-steps take a zero plaintext; rot is read as is (finite by the launcher's contract)
-#pragma unroll
-            for (int t = RT; t < A; t++) bc_dma16(ch * BC_KC + pkk[t - RT] < a.K ? pb + poff[t - RT] : z_u, slot + (t * BC_WAVES + wave) * 1024);
+                bc_dma16(ragged && ch * BC_KC + pkk[t - RT] >= a.K ? z_u : pb + poff[t - RT], slot + (t * BC_WAVES + wave) * 1024);
+            }
         }
     };
+    auto issue_chunk = [&](int ch) { issue_rounds(ch, 0, A); };
+    // round groups of the four issue points of the loop
+    constexpr int G1 = (A + 3) / 4, G2 = G1 + (A + 2) / 4, G3 = G2 + (A + 1) / 4;
 
     double acc[ROWS][3];
 #pragma unroll
@@ -225,15 +232,20 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
     int since_flush = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ch++) {
+        // the slot of chunk ch - 1 was handed back at the end of the previous iteration; its refill (chunk ch - 1 + DEPTH) goes out in four parts
+        const int refill = ch - 1 + DEPTH; const bool do_refill = ch >= 1 && refill < nchunk;
+        if (do_refill) issue_rounds(refill, G1, G2);
         BC_FETCH(1, ob); BC_WAIT(NLDS, oa); fmas(oa);
+        if (do_refill) issue_rounds(refill, G2, G3);
         BC_FETCH(2, oa); BC_WAIT(NLDS, ob); fmas(ob);
+        if (do_refill) issue_rounds(refill, G3, A);
         BC_FETCH(3, ob); BC_WAIT(NLDS, oa); fmas(oa);
         BC_WAIT(0, ob);                               // this wave has read everything it needs from chunk ch
         if (ch + 1 < nchunk) {
             // Before the last k-step's FMAs: hand over to chunk ch + 1 (its first operands travel from LDS while those 90 FMAs run, so the
-            // barrier is not followed by an exposed LDS round trip) and refill the slot of chunk ch, which nobody reads any more.
+            // barrier is not followed by an exposed LDS round trip) and start refilling the slot of chunk ch, which nobody reads any more.
             sync_for(ch + 1);
-            if (ch + DEPTH < nchunk) issue_chunk(ch + DEPTH);
+            if (ch + DEPTH < nchunk) issue_rounds(ch + DEPTH, 0, G1);
             slot_off = slot_off + SLOT == (unsigned)(DEPTH * SLOT) ? 0u : slot_off + SLOT;
             r_cur = r_thr + slot_off; p_cur = p_thr + slot_off;
             BC_FETCH(0, oa);

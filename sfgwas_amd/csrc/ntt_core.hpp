@@ -6,17 +6,16 @@
 constexpr int LDS_ROW = 528;                 // 512 + 16 doubles: keeps (a, a+1) rows 32 banks apart
 constexpr int LDS_DOUBLES = 32 * LDS_ROW;    // 135,168 B
 
-// twiddles are stored as w only; w/q is recovered with one multiply (its rounding only moves the quotient
-// estimate of mulmod_lazy by << 1, the remainder stays exact)
+// twiddles are stored as w only; the quotient of a butterfly product is estimated from the rounded product and 1/q (mulmod_lazy_q)
 template <int LEN, int H, class TW>
 __device__ __forceinline__ void ct_stage(double (&v)[LEN], double q, double qinv, TW tw) {
 #pragma unroll
     for (int g = 0; g < LEN / (2 * H); g++) {
-        const double w = tw(g), wq = w * qinv;
+        const double w = tw(g);
 #pragma unroll
         for (int x = 0; x < H; x++) {
             const int i0 = g * 2 * H + x, i1 = i0 + H;
-            double r = mulmod_lazy(v[i1], w, wq, q);
+            double r = mulmod_lazy_q(v[i1], w, q, qinv);
             double U = v[i0];
             v[i0] = U + r; v[i1] = U - r;
         }
@@ -26,13 +25,13 @@ template <int LEN, int H, class TW>
 __device__ __forceinline__ void gs_stage(double (&v)[LEN], double q, double qinv, TW tw) {
 #pragma unroll
     for (int g = 0; g < LEN / (2 * H); g++) {
-        const double w = tw(g), wq = w * qinv;
+        const double w = tw(g);
 #pragma unroll
         for (int x = 0; x < H; x++) {
             const int i0 = g * 2 * H + x, i1 = i0 + H;
             double U = v[i0], V = v[i1];
             v[i0] = U + V;
-            v[i1] = mulmod_lazy(U - V, w, wq, q);
+            v[i1] = mulmod_lazy_q(U - V, w, q, qinv);
         }
     }
 }

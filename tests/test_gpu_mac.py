@@ -77,3 +77,28 @@ def test_mac_worst_case_magnitudes_and_accumulate(env):
         val = (K * (q - 1) * (q - 1)) % q
         want = (init[:, :, l, :].astype(object) + val) % q
         assert np.array_equal(got[:, :, l, :].astype(object), want)
+
+
+def test_mac_centred_operand_and_packed_limb_worst_case(env):
+    """The device works with rot centred to (-q/2, q/2] and plaintext limbs biased by 4096: the largest single term is rot = (q-1)/2 (or its negative,
+    (q+1)/2) against all-ones 12-bit limbs, every term of one sign.  K = 200 spans several flush periods (60 k-steps for 35-bit moduli)."""
+    ctx = env
+    K, R, Ncols, L, N = 200, 5, 3, 5, ctx.N
+    rot = np.zeros((K, R, L, N), dtype=np.uint64)
+    pt = np.zeros((K, Ncols, L, N), dtype=np.uint64)
+    for l in range(L):
+        q = ol.Q_PN14[l]
+        hi = ((q >> 24) - 1) << 24 | 0xFFFFFF            # largest residue with all-ones low limbs
+        assert hi < q
+        rot[:, 0::2, l, :] = (q - 1) // 2                # +max after centring
+        rot[:, 1::2, l, :] = (q + 1) // 2                # -max after centring
+        pt[:, :, l, :] = hi
+        pt[:, 1, l, : N // 2] = q - 1
+    got = ctx.mac(rot, pt, L)
+    for l in range(L):
+        q = ol.Q_PN14[l]
+        for r in range(R):
+            for n in range(Ncols):
+                for half, sl in ((0, slice(0, N // 2)), (1, slice(N // 2, N))):
+                    want = K * int(rot[0, r, l, 0]) * int(pt[0, n, l, 0 if half == 0 else N - 1]) % q
+                    assert (got[n, r, l, sl] == want).all(), (l, r, n, half)
