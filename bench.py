@@ -41,8 +41,8 @@ CONFIGS = {          # n_ind, m_snp  
 KP = 15                    # num_pcs_to_remove + num_oversampling (pca.go:87)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_SPEC_FMA_S = 256 * 4 * 16 * 2.4e9          # 3.93e13: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz (78.6 TFLOP/s spec)
-UBENCH_FILE = "profiles/r01_ubench_instruction_rates.txt"      # committed microbenchmark: v_fma_f64 at 16 waves/CU
-UBENCH_FMA_S = 3.217e13
+UBENCH_FILE = "profiles/r02_ubench_dpp_fma_rate.txt"           # committed microbenchmark (tools/ubench_dpp.hip): the MAC's own LDS-fed DPP tile, no DMA, no barrier
+UBENCH_FMA_S = 3.398e13
 
 
 def ceil_div(a, b):
@@ -301,7 +301,7 @@ def main():
                         continue
                     pm = json.load(open(path))
                     if pm.get("_config") == args.config:
-                        ks = [k for k in pm if k.startswith("void k_mac_dma<false")]
+                        ks = [k for k in pm if k.startswith("void k_mac_bc<false") or k.startswith("void k_mac_dma<false")]
                         best = max(ks, key=lambda k: pm[k]["launches"])
                         traffic, traffic_src = pm[best]["hbm_bytes_per_launch"], f"profiles/{name} (static: separate --pmc passes, not measured in this run)"
                         break
@@ -310,14 +310,14 @@ def main():
             res["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_mac_dma<false, 1>", "avg_launch_ms": avg_ms, "launches": n_small,
+                "kernel": "k_mac_bc<false, 30>", "avg_launch_ms": avg_ms, "launches": n_small,
                 "bytes_kind": "kernel operands: fp64 rotation-cache slab + half-row plaintext panel + accumulator tile, each counted once "
                               "(DESIGN.md §4); these are intermediates the encode / key-switch kernels wrote, not SURVEY §8(d)'s input/output bytes",
                 "alg_bytes_per_launch": by_small / n_small,
                 "hbm_algorithmic": {"bytes_per_step": alg_step, "achieved_GBps": hbm_alg, "frac": hbm_alg / HBM_PEAK_GBS,
                                     "what": "SURVEY §8(d): int8 genotypes once per product + ciphertexts in/out, divided by the WHOLE step time"},
-                "alu": {"what": "the roofline that binds (SURVEY §8d): fp64 FMA issue of the dominant kernel; 3 v_fma_f64 per ring-MAC "
-                                "(36-bit modulus: plaintext word split into 3 x 12-bit limbs, products < 2^48 summed exactly)",
+                "alu": {"what": "the roofline that binds (SURVEY §8d): fp64 FMA issue of the dominant kernel; 3 v_fmac_f64_dpp per ring-MAC "
+                                "(35-bit modulus: plaintext word split into 3 x 12-bit limbs, products < 2^48 summed exactly; rot operand by row_newbcast)",
                         "fma_per_mac": 3, "padded_ring_macs_per_s_in_kernel": padded_macs_s, "fma_per_s_in_kernel": fma_s,
                         "frac_of_spec": fma_s / FP64_VALU_SPEC_FMA_S, "spec_fma_per_s": FP64_VALU_SPEC_FMA_S,
                         "frac_of_measured_peak": fma_s / UBENCH_FMA_S, "measured_peak_fma_per_s": UBENCH_FMA_S, "measured_peak_source": UBENCH_FILE,

@@ -52,7 +52,6 @@ __host__ __device__ static inline cdd cdd_mul(cdd a, cdd b) {
 
 constexpr int ENC_H = SFG_SLOTS / 2;         // 4096-point complex FFT
 constexpr int ENC_TW = 16384;                // table of zeta^-k, k = 0..16384, zeta = exp(2 pi i / 32768)
-constexpr int ENC_PADN = ENC_H + ENC_H / 8;  // padded index j' = j + (j >> 3)
 
 struct EncTables {                // immutable, shared by a context and its forks
     double4 *zt = nullptr;        // [ENC_TW + 1] {re.hi, re.lo, im.hi, im.lo} of exp(-2 pi i k / 32768)
@@ -173,7 +172,10 @@ __global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int 
 }
 
 // ---------------------------------------------------------------- FFT encode
-__device__ __forceinline__ int padj(int j) { return j + (j >> 3); }
+// Exchange images are indexed through an XOR swizzle instead of padding: address bits 0..4 (the 32 eight-byte bank pairs of a 256-byte bank
+// sweep) are XORed with index bits 3..7.  Every access pattern of the kernel - 64 lanes that vary any six of the index bits 0..7 with the others
+// fixed (contiguous, stride 4, stride 32, bit-reversed) - then maps onto all 32 bank pairs exactly twice, the minimum for 512 bytes.
+__device__ __forceinline__ int padj(int j) { return j ^ ((j >> 3) & 31); }
 
 // (ar + i ai) * (wr + i wi) with each component as ONE double-double dot product (two products share the final
 // renormalisation): 19 flops per component instead of 2 dd_mul + 1 dd_add = 25.
@@ -260,8 +262,8 @@ __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {     
 // rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
 // F64IN: rows are n doubles (arbitrary real slot vectors, no rotation) — the Mask / EncodeFloatVector use.
 constexpr int ENC_HALF = ENC_H / 2;                 // the exchange image holds half of the points (2048) at a time
-constexpr int ENC_HPAD = ENC_HALF + ENC_HALF / 8;  // padded
-constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 73,728 B: two workgroups per CU
+constexpr int ENC_HPAD = ENC_HALF;                  // no padding: see padj
+constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 65,536 B: two workgroups per CU
 // After the first radix-8 pass the transform splits into 8 independent 512-point sub-transforms (one per `a`), and the
 // final recombination pairs Z_c with Z_{h-c}, whose bit-reversed positions share the top bit (= parity of c).  So every
 // exchange can go through an image of HALF the points: the sub-transforms a < 4 (threads 0..255) and a >= 4 (threads
@@ -349,12 +351,14 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     __syncthreads();
     if (my_half == r) {
 #pragma unroll
-        for (int dd_ = 0; dd_ < 8; dd_++) put(padj(tl * 8 + dd_), yr[dd_], yi[dd_]);
+        // position p = tl*8 + dd holds Z_c with c >> 1 = brev11(p) = brev3(dd) << 8 | brev8(tl): stored under that index, so that the
+        // readers below (consecutive c) touch consecutive words instead of a bit-reversed scatter
+        for (int dd_ = 0; dd_ < 8; dd_++) put(padj((int)((__brev((unsigned)dd_) >> 29) << 8) | (int)(__brev((unsigned)tl) >> 24)), yr[dd_], yi[dd_]);
     }
     __syncthreads();
     for (int c = 2 * tid + r; c <= h / 2; c += 1024) {
         const int c2 = (h - c) & (h - 1);
-        const int pa = padj((int)(__brev((unsigned)c) >> 20) & (ENC_HALF - 1)), pb = padj((int)(__brev((unsigned)c2) >> 20) & (ENC_HALF - 1));
+        const int pa = padj(c >> 1), pb = padj(c2 >> 1);               // both have the parity of this round (c2 = h - c)
         dd Ar = dd_make(RH[pa], RL[pa]), Ai = dd_make(IH[pa], IL[pa]);
         dd Br = dd_make(RH[pb], RL[pb]), Bi = dd_neg(dd_make(IH[pb], IL[pb]));
         dd Xr = dd_mul_d(dd_add(Ar, Br), 0.5), Xi = dd_mul_d(dd_add(Ai, Bi), 0.5);
