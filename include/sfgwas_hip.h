@@ -188,6 +188,17 @@ int sfg_diagcache_header(sfg_ctx *ctx, const char *cache_prefix, int block_row, 
 int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level, int max_level,
                       const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, unsigned flags,
                       uint64_t *out_host, double *sum_host, double *sqsum_host);
+/* ---- f-3: the association scan's batches streamed from storage (gwas/assoc.go:340-420, GenoBlockMult; BASELINE config 5) ----
+ * Replaces, per batch of `batch_snps` KEPT SNPs: FilterMatrixFilePgen (plink2 and the Python converters under scripts/ writing an int8 temp file), NewGenoFileStream,
+ * MatMult4Stream(cps, mat, X, 5, false, square, nproc) and the final crypto.ConcatCipherMatrix.  `bed_path` is a SNP-major PLINK .bed of
+ * num_sample x num_snp (a .pgen is converted once with plink2 --make-bed); row_filter / col_filter: one byte per sample / SNP, zero = drop, NULL = keep
+ * all.  A batch is one contiguous byte range of the file: read by a reader thread into pinned memory while the GPU multiplies the previous batch,
+ * moved to HBM as packed 2-bit codes, decoded / filtered / transposed on the device.  A_dev: [s][ceil(kept_samples / slots)] ciphertexts;
+ * out_dev: [s][out_ct_capacity][2][max_level][N]; *out_ct = sum over batches of ceil(kept / slots).  sum_host / sqsum_host (optional):
+ * [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).  flags: SFG_SQUARE. */
+int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                         size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                         uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
 /* sharding hooks for one-process-per-GPU runs: restrict a resident product to block columns
  * [j0, j1) of the output (X: SNP-column blocks) or block rows [b0, b1) of the contraction (X^T) */
 int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,

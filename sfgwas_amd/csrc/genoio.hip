@@ -41,6 +41,13 @@ __global__ void __launch_bounds__(256) k_geno_transpose(const int8_t *in, size_t
     for (int it = 0; it < 16; it++) { const int idx = it * 256 + t, c = idx >> 6, r = idx & 63; if (r0 + r < nrow && c0 + c < ncol) out[(c0 + c) * nrow + r0 + r] = tile[r][c]; }
 }
 
+// decode + filter + transpose of a packed SNP range already in HBM, on the given queue (stream.hip streams batches through this)
+int launch_bed_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
+                      int8_t *out, size_t ld) {
+    hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((bps + 63) / 64), (unsigned)((num_snp + 63) / 64)), dim3(256), 0, st, dbed, bps, num_sample, num_snp, rmap, cmap, out, ld);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
 static int make_map(sfg_ctx *ctx, const uint8_t *filt, size_t n, int32_t **dev, size_t *kept) {
     *dev = nullptr; *kept = n;
     if (!filt) return 0;

@@ -1,0 +1,145 @@
+// stream.hip — the association scan's genotype batches streamed from storage (BASELINE config 5).
+//
+// Reference (gwas/assoc.go:340-420): GenoBlockMult walks the SNPs of a chromosome file; every `pgenBatchSize` KEPT SNPs it shells out to
+// plink2 + Python (scripts/filterMatrixPgen.sh, plinkBedToBinary.py, transposeMatrix.py) to materialise an int8 [numInd x batch] temp file,
+// opens it as a GenoFileStream, calls MatMult4Stream(cps, mat, X, 5, false, square, nproc) and concatenates the batch outputs
+// (crypto.ConcatCipherMatrix).  Here the SNP-major 2-bit PLINK .bed IS the input: a batch is one contiguous byte range of the file
+// (bps = ceil(num_sample / 4) bytes per SNP), read with pread() into pinned memory by a reader thread while the GPU works on the previous
+// batch, copied to HBM as packed 2-bit codes (4x less than int8 over PCIe), decoded / filtered / transposed on the device
+// (k_bed_decode, pinned by the reference scripts' outputs in tests/test_input_formats.py), multiplied, concatenated.  A .pgen file is
+// converted once with `plink2 --make-bed` (the reference already depends on plink2 for this path).
+#include "common.hpp"
+#include "kernels.hpp"
+#include <condition_variable>
+#include <fcntl.h>
+#include <mutex>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+// genoio.hip
+int launch_bed_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
+                      int8_t *out, size_t ld);
+
+namespace {
+struct Batch { size_t snp0, nsnp, kept; };            // file SNPs [snp0, snp0 + nsnp), `kept` of them pass the filter
+// assoc.go:371-416: a batch closes when `batch_snps` kept SNPs have been seen or the file ends with a non-empty batch
+std::vector<Batch> make_batches(const uint8_t *col_filter, size_t num_snp, size_t batch_snps) {
+    std::vector<Batch> b; size_t start = 0, counter = 0;
+    for (size_t idx = 0; idx < num_snp; idx++) {
+        if (!col_filter || col_filter[idx]) counter++;
+        if (counter == batch_snps || (idx == num_snp - 1 && counter > 0)) { b.push_back({start, idx + 1 - start, counter}); start = idx + 1; counter = 0; }
+    }
+    return b;
+}
+struct Reader {                                        // fills pinned slot k & 1 with the bytes of batch k, one batch ahead of the consumer
+    int fd; size_t bps; const std::vector<Batch> *bt; uint8_t *slot[2];
+    std::mutex mu; std::condition_variable cv; long filled = -1, released = -1; bool failed = false; std::string err;
+    void run() {
+        for (size_t k = 0; k < bt->size(); k++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return (long)k - 2 <= released; }); }      // slot k & 1 was last used by batch k - 2
+            const Batch &b = (*bt)[k]; size_t want = b.nsnp * bps, got = 0; const off_t off = 3 + (off_t)(b.snp0 * bps);
+            while (got < want) {
+                ssize_t r = pread(fd, slot[k & 1] + got, want - got, off + (off_t)got);
+                if (r <= 0) { std::lock_guard<std::mutex> lk(mu); failed = true; err = "short read from the .bed file"; cv.notify_all(); return; }
+                got += (size_t)r;
+            }
+            { std::lock_guard<std::mutex> lk(mu); filled = (long)k; }
+            cv.notify_all();
+        }
+    }
+    bool wait_filled(size_t k) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || filled >= (long)k; }); return !failed; }
+    void release(size_t k) { { std::lock_guard<std::mutex> lk(mu); released = (long)k; } cv.notify_all(); }
+};
+}  // namespace
+
+// out_dev: [s][out_ct_capacity][2][max_level][N]; *out_ct = sum over batches of ceil(kept / slots) (the width ConcatCipherMatrix would give).
+// sum_host / sqsum_host: optional [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).
+extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                                    size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                                    uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!num_sample || !num_snp || !batch_snps) SFG_FAIL(ctx, "assoc_stream_bed: bad dimensions");
+    if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_stream_bed: batches are multiplied as X (samples x SNPs)");
+    const size_t bps = (num_sample + 3) / 4, N = SFG_N, slots = SFG_SLOTS, L = (size_t)max_level;
+    const int fd = open(bed_path, O_RDONLY);
+    if (fd < 0) SFG_FAIL(ctx, "assoc_stream_bed: cannot open %s", bed_path);                     // os.Open panics in the reference (filestream.go:59-61)
+    struct stat stt; uint8_t magic[3] = {0, 0, 0};
+    if (fstat(fd, &stt) || pread(fd, magic, 3, 0) != 3) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: cannot read %s", bed_path); }
+    if ((size_t)stt.st_size != 3 + num_snp * bps) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: file holds %zu bytes, expected 3 + %zu x %zu", (size_t)stt.st_size, num_snp, bps); }
+    if (magic[0] != 0x6C || magic[1] != 0x1B || magic[2] != 0x01) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: not a SNP-major PLINK .bed"); }
+    const std::vector<Batch> bt = make_batches(col_filter, num_snp, batch_snps);
+    size_t total_ct = 0, max_nsnp = 0, max_kept = 0;
+    for (const Batch &b : bt) { total_ct += (b.kept + slots - 1) / slots; max_nsnp = std::max(max_nsnp, b.nsnp); max_kept = std::max(max_kept, b.kept); }
+    if (out_ct) *out_ct = total_ct;
+    if (bt.empty()) { close(fd); return 0; }
+    if (total_ct > out_ct_capacity) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: output needs %zu ciphertexts per row, capacity %zu", total_ct, out_ct_capacity); }
+    // row map once; column maps per batch
+    std::vector<int32_t> rmap_h(num_sample); size_t nr = 0;
+    for (size_t i = 0; i < num_sample; i++) rmap_h[i] = (!row_filter || row_filter[i]) ? (int32_t)nr++ : -1;
+    if (!nr) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: the row filter keeps nothing"); }
+    int rc = 0;
+    int32_t *rmap = nullptr, *cmap[2] = {nullptr, nullptr}; uint8_t *hb[2] = {nullptr, nullptr}, *db[2] = {nullptr, nullptr}; int8_t *gb[2] = {nullptr, nullptr};
+    u64 *tmp = nullptr; hipStream_t copy = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    const size_t ctw = 2 * L * N, max_ct = (max_kept + slots - 1) / slots;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream); if (copy) (void)hipStreamSynchronize(copy);
+        for (int i = 0; i < 2; i++) { (void)hipHostFree(hb[i]); (void)hipFree(db[i]); (void)hipFree(gb[i]); (void)hipFree(cmap[i]);
+            if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_free[i]) (void)hipEventDestroy(ev_free[i]); }
+        (void)hipFree(rmap); (void)hipFree(tmp); if (copy) (void)hipStreamDestroy(copy); close(fd);
+    };
+#define ST_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; snprintf(_b, sizeof _b, "assoc_stream_bed: %s failed: %s", #call, hipGetErrorString(_e)); ctx->err = _b; rc = 1; } } while (0)
+    ST_HIP(hipMalloc(&rmap, num_sample * sizeof(int32_t)));
+    if (!rc) ST_HIP(hipMemcpy(rmap, rmap_h.data(), num_sample * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!rc) ST_HIP(hipMalloc(&tmp, (size_t)s * max_ct * ctw * 8));
+    if (!rc) ST_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2 && !rc; i++) {
+        ST_HIP(hipHostMalloc((void **)&hb[i], max_nsnp * bps, hipHostMallocDefault));
+        if (!rc) ST_HIP(hipMalloc(&db[i], max_nsnp * bps));
+        if (!rc) ST_HIP(hipMalloc(&gb[i], nr * max_kept));
+        if (!rc) ST_HIP(hipMalloc(&cmap[i], max_nsnp * sizeof(int32_t)));
+        if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
+        if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
+        if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
+    }
+    if (rc) { cleanup(); return rc; }
+    Reader rd; rd.fd = fd; rd.bps = bps; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1];
+    std::thread reader([&rd] { rd.run(); });
+    std::vector<int32_t> cmap_h(max_nsnp);
+    size_t out_shift = 0;
+    for (size_t k = 0; k < bt.size() && !rc; k++) {
+        const Batch &b = bt[k]; const int sl = (int)(k & 1);
+        if (!rd.wait_filled(k)) { ctx->err = "assoc_stream_bed: " + rd.err; rc = 1; break; }
+        size_t kc = 0;
+        for (size_t j = 0; j < b.nsnp; j++) cmap_h[j] = (!col_filter || col_filter[b.snp0 + j]) ? (int32_t)kc++ : -1;
+        // copy queue: packed bytes and column map of batch k into slot sl (free once the product of batch k - 2 has run), decode into gb[sl]
+        if (k >= 2) ST_HIP(hipStreamWaitEvent(copy, ev_free[sl], 0));
+        if (!rc) ST_HIP(hipMemcpyAsync(db[sl], hb[sl], b.nsnp * bps, hipMemcpyHostToDevice, copy));
+        if (!rc) ST_HIP(hipMemcpyAsync(cmap[sl], cmap_h.data(), b.nsnp * sizeof(int32_t), hipMemcpyHostToDevice, copy));
+        if (!rc) ST_HIP(hipEventRecord(ev_h2d[sl], copy));
+        if (!rc) rc = launch_bed_decode(ctx, copy, db[sl], bps, num_sample, b.nsnp, rmap, cmap[sl], gb[sl], b.kept);
+        if (!rc) ST_HIP(hipEventRecord(ev_ready[sl], copy));
+        if (!rc) ST_HIP(hipEventSynchronize(ev_h2d[sl]));          // the pinned slot (and cmap_h) may be refilled: ~tens of ms, the previous product is still running
+        rd.release(k);
+        if (rc) break;
+        // compute queue: the product of batch k (MatMult4Stream(cps, mat, X, maxLevel, false, square, nproc), assoc.go:395), rows copied into place
+        ST_HIP(hipStreamWaitEvent(ctx->stream, ev_ready[sl], 0));
+        sfg_geno g; g.dev = gb[sl]; g.nrow = nr; g.ncol = b.kept; g.ld = b.kept; g.owned = false;
+        const size_t nct = (b.kept + slots - 1) / slots;
+        if (!rc) rc = sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, &g, flags, (uint64_t *)tmp);
+        for (int i = 0; i < s && !rc; i++)
+            ST_HIP(hipMemcpyAsync(out_dev + ((size_t)i * out_ct_capacity + out_shift) * ctw, tmp + (size_t)i * nct * ctw, nct * ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!rc && (sum_host || sqsum_host)) {
+            if (sum_host) std::fill(sum_host + out_shift * slots, sum_host + (out_shift + nct) * slots, 0.0);
+            if (sqsum_host) std::fill(sqsum_host + out_shift * slots, sqsum_host + (out_shift + nct) * slots, 0.0);
+            rc = sfg_geno_colsums(ctx, &g, sum_host ? sum_host + out_shift * slots : nullptr, sqsum_host ? sqsum_host + out_shift * slots : nullptr);
+        }
+        if (!rc) ST_HIP(hipEventRecord(ev_free[sl], ctx->stream));
+        out_shift += nct;
+    }
+#undef ST_HIP
+    if (rc) rd.release(bt.size() + 2);                             // let the reader run out
+    reader.join();
+    cleanup();
+    return rc;
+}

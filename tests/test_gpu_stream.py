@@ -1,0 +1,86 @@
+"""Association batches streamed from a PLINK .bed on disk (gwas/assoc.go:340-420 GenoBlockMult): batching by kept SNPs, row / column
+filters, per-batch MatMult4Stream, ConcatCipherMatrix layout, padded column sums - every output word vs the oracle run on the batch matrices
+that numpy decodes from the same file."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def write_bed(path, geno):
+    """geno: [num_sample][num_snp] int8 in {2, -1, 1, 0} -> SNP-major 2-bit codes {2: 00, -1: 01, 1: 10, 0: 11} (scripts/plinkBedToBinary.py:18-27)"""
+    code = {2: 0, -1: 1, 1: 2, 0: 3}
+    ns, nv = geno.shape
+    bps = (ns + 3) // 4
+    out = bytearray([0x6C, 0x1B, 0x01])
+    for j in range(nv):
+        col = bytearray(bps)
+        for i in range(ns):
+            col[i // 4] |= code[int(geno[i, j])] << (2 * (i % 4))
+        out += col
+    open(path, "wb").write(bytes(out))
+
+
+def batches(colf, batch):
+    """assoc.go:371-416"""
+    out, start, counter = [], 0, 0
+    for idx in range(len(colf)):
+        counter += int(colf[idx])
+        if counter == batch or (idx == len(colf) - 1 and counter > 0):
+            out.append((start, idx + 1)); start, counter = idx + 1, 0
+    return out
+
+
+@pytest.mark.parametrize("square", [False, True])
+def test_stream_bed_batches_match_oracle(tmp_path, square):
+    from sfgwas_amd import capi
+    ns, nv, batch, s, level, maxl = 130, 260, 100, 2, 5, 5
+    rnd = np.random.default_rng(17)
+    geno = rnd.choice(np.array([2, -1, 1, 0], dtype=np.int8), size=(ns, nv), p=[0.2, 0.05, 0.35, 0.4])
+    rowf = (rnd.random(ns) < 0.9).astype(np.uint8); colf = (rnd.random(nv) < 0.85).astype(np.uint8)
+    path = str(tmp_path / "chr1.bed")
+    write_bed(path, geno)
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    nr = int(rowf.sum())
+    slots, d = ring.slots, 91
+    shifts = set(range(nr)) | set(range(slots - batch + 1, slots))
+    rots = sorted({sh % d for sh in shifts if sh % d} | {(sh // d) * d for sh in shifts if sh // d})
+    for k in rots:
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 900 + k)
+        keys.add(g, key); ctx.load_rotkey(g, key)
+    A = np.stack([np.stack([ring.fill_uniform(level, 40 + i)]) for i in range(s)])          # [s][1 block row]
+    bt = batches(colf, batch)
+    nct_total = sum((int(colf[a:b].sum()) - 1) // slots + 1 for a, b in bt)
+    cap = nct_total + 1
+    dA = capi.DevArray.from_host(ctx, A)
+    dout = capi.DevArray(ctx, (s, cap, 2, maxl, ring.N))
+    sums = np.full(cap * slots, -7.0); sq = np.full(cap * slots, -7.0)
+    got_ct = C.c_size_t()
+    flags = capi.SFG_SQUARE if square else 0
+    ctx.check(capi.lib().sfg_assoc_stream_bed(ctx.h, path.encode(), ns, nv, rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch,
+                                              dA.p, s, level, maxl, flags, dout.p, cap, C.byref(got_ct), sums.ctypes.data_as(C.c_void_p),
+                                              sq.ctypes.data_as(C.c_void_p)), "assoc_stream_bed")
+    assert got_ct.value == nct_total and len(bt) == 3
+    out = dout.host()
+    shift = 0
+    for a, b in bt:
+        sub = np.ascontiguousarray(geno[rowf.astype(bool)][:, a:b][:, colf[a:b].astype(bool)])
+        want, wsum, wsq = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, maxl, sub, compute_sqsum=True, square=square, enc_prec=1)
+        nct = want.shape[1]
+        assert np.array_equal(out[:, shift:shift + nct], want), f"batch {a}:{b}"
+        assert np.array_equal(sums[shift * slots: shift * slots + sub.shape[1]], wsum) and np.array_equal(sq[shift * slots: shift * slots + sub.shape[1]], wsq)
+        assert not sums[shift * slots + sub.shape[1]: (shift + nct) * slots].any()               # padded tail of the reference's dosage vectors
+        shift += nct
+    assert (sums[shift * slots:] == -7.0).all()
+    # errors the reference would panic on
+    with pytest.raises(capi.SfgError, match="cannot open"):
+        ctx.check(capi.lib().sfg_assoc_stream_bed(ctx.h, b"/nonexistent.bed", ns, nv, None, None, batch, dA.p, s, level, maxl, 0, dout.p, cap, C.byref(got_ct), None, None), "x")
+    with pytest.raises(capi.SfgError, match="expected 3 \\+"):
+        ctx.check(capi.lib().sfg_assoc_stream_bed(ctx.h, path.encode(), ns + 4, nv, None, None, batch, dA.p, s, level, maxl, 0, dout.p, cap, C.byref(got_ct), None, None), "x")
+    dA.free(); dout.free(); ctx.close()
