@@ -47,6 +47,7 @@ struct SfgConfig {
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
     size_t acc_budget = 24ULL << 30;   // SFG_MM_ACC_BUDGET_MB
     bool no_overlap = false;       // SFG_MM_NO_OVERLAP     single queue
+    bool ntt_fwd_full = false;     // SFG_NTT_FWD_IMPL=full   one 512-thread workgroup per row for the general forward NTT (instead of two half-row workgroups)
     bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
     bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)

@@ -22,8 +22,12 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
     const int N = SFG_N, tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const int m = pat.m[row % pat.period];
-    if (m < 0) return;                                   // row marked "leave untouched"
     const size_t grp = row / rm.rpg, gi = row % rm.rpg;
+    if (m < 0) {                                         // row marked "leave untouched": copied through when the transform runs out of place
+        const u64 *src = (const u64 *)in_ + grp * rm.gstride_in + gi * N; u64 *dst = out_ + grp * rm.gstride_out + gi * N;
+        if (IN_MODE == 0 && src != dst) for (int a = 0; a < 32; a++) dst[a * 512 + tid] = src[a * 512 + tid];
+        return;
+    }
     const double *tw = tw_all + (size_t)m * N;
     const double2 *pack = pack_all + (size_t)m * (N / 2);      // late-stage twiddles, see build_pack() in ctx.hip
     const double q = modc[m].q, qinv = modc[m].qinv;
@@ -239,16 +243,11 @@ __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out
 constexpr int H3_ROWA = 264;                  // 256 + 8 doubles per `a` row of the A->B half image
 constexpr int H3_DOUBLES = 16 * H3_ROWA;
 constexpr int H3_LDS_BYTES = (H3_DOUBLES > 8 * LDS_ROW ? H3_DOUBLES : 8 * LDS_ROW) * 8;      // 33,792 B (the B->C / C->out half image needs 8 * LDS_ROW = 4224 doubles as well)
-__global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
-    extern __shared__ double lds[];
-    const int N = SFG_N, n = N / 2, tid = threadIdx.x;
-    size_t row; int m;
-    if (!plain_block(nplain, L, row, m)) return;
-    const double *tw = tw_all + (size_t)m * N;
-    const double2 *pack = pack_all + (size_t)m * (N / 2);
-    const double q = modc[m].q, qinv = modc[m].qinv;
-    const double *pc = pc_all + (row / L) * (size_t)n;
-    const double W = tw[1], Wq = W * qinv;
+// The 13 stages that follow the first Cooley-Tukey stage, on ONE half (hs = 0: indices [0, n), hs = 1: [n, N)) of a row: after stage 1 the
+// halves are independent size-n transforms whose twiddles sit hs * (m / 2) further in each stage's table (tw[m + i], i in [hs m/2, (hs+1) m/2)).
+// first(j) returns the stage-1 output r_j of this half, j < n; store(j, x) receives the lazy result of output index hs * n + j.
+template <class First, class Store>
+__device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store, double *lds, const double *tw, const double2 *pack, double q, double qinv, int tid) {
     double v[32];
     const int a_b = tid >> 4, c_b = tid & 15;                  // phase B identity
     // ---- phase A (two columns) interleaved with the two A->B rounds
@@ -257,16 +256,11 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
         const int pp = tid + 256 * h;
         double w[16];
 #pragma unroll
-        for (int a = 0; a < 16; a++) {
-            const int j = a * 512 + pp;
-            const double lo = pc[j];
-            const double hi = j == 0 ? 0.0 : pc[n - j];          // p_{n+j} = -p_{n-j}
-            w[a] = lo - mulmod_lazy(hi, W, Wq, q);
-        }
-        ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + g]; });
-        ct_stage<16, 4>(w, q, qinv, [&](int g) { return tw[4 + g]; });
-        ct_stage<16, 2>(w, q, qinv, [&](int g) { return tw[8 + g]; });
-        ct_stage<16, 1>(w, q, qinv, [&](int g) { return tw[16 + g]; });
+        for (int a = 0; a < 16; a++) w[a] = first(a * 512 + pp);
+        ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + hs + g]; });
+        ct_stage<16, 4>(w, q, qinv, [&](int g) { return tw[4 + 2 * hs + g]; });
+        ct_stage<16, 2>(w, q, qinv, [&](int g) { return tw[8 + 4 * hs + g]; });
+        ct_stage<16, 1>(w, q, qinv, [&](int g) { return tw[16 + 8 * hs + g]; });
         if (h) __syncthreads();                                           // round-0 readers are done with the image
 #pragma unroll
         for (int a = 0; a < 16; a++) lds[a * H3_ROWA + tid] = w[a];
@@ -275,11 +269,12 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
         for (int b = 0; b < 16; b++) v[h * 16 + b] = lds[a_b * H3_ROWA + b * 16 + c_b];
     }
     // ---- phase B: thread (a, c), 32 values of b; stages t = 256 .. 16
-    ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + a_b + g]; });
-    ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + a_b * 2 + g]; });
-    ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + a_b * 4 + g]; });
-    ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + a_b * 8 + g]; });
-    ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + a_b * 16 + g]; });
+    const int ab = 16 * hs + a_b;
+    ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + ab + g]; });
+    ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + ab * 2 + g]; });
+    ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + ab * 4 + g]; });
+    ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + ab * 8 + g]; });
+    ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + ab * 16 + g]; });
     // ---- B->C rounds by row half, phase C per group
     double wc[2][16];
 #pragma unroll
@@ -299,7 +294,7 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
         const int p = tid + 256 * r;
         double tl[16];
         {
-            const double2 *pk = pack + (size_t)(p >> 6) * 512 + (p & 63);
+            const double2 *pk = pack + (size_t)((p >> 6) + 8 * hs) * 512 + (p & 63);
 #pragma unroll
             for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
         }
@@ -309,10 +304,6 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
         ct_stage<16, 1>(wc[r], q, qinv, [&](int g) { return tl[7 + g]; });
     }
     // ---- C->out rounds by row half
-    const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
-    const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
-    u64 *out = out_ + (dst * L + m) * (size_t)n;
-    const bool packed = (pm.packed_mask >> m) & 1u;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int p = tid + 256 * r, a = p >> 5, b = p & 31;
@@ -320,21 +311,55 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
 #pragma unroll
         for (int c = 0; c < 16; c++) lds[(a & 7) * LDS_ROW + c * 33 + b] = wc[r][c];
         __syncthreads();
-        // (the format test is hoisted: inside the loop it costs a branch per word)
-        if (packed) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
-                out[r * 4096 + jj] = pack_limbs_f64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;
-                out[r * 4096 + jj] = f64_to_u64(canon(lds[a8 * LDS_ROW + c * 33 + bb], q, qinv));
-            }
+        for (int k = 0; k < 16; k++) {
+            const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
+            store(r * 4096 + jj, lds[a8 * LDS_ROW + c * 33 + bb]);
         }
     }
+}
+__global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, n = N / 2, tid = threadIdx.x;
+    size_t row; int m;
+    if (!plain_block(nplain, L, row, m)) return;
+    const double *tw = tw_all + (size_t)m * N;
+    const double2 *pack = pack_all + (size_t)m * (N / 2);
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const double *pc = pc_all + (row / L) * (size_t)n;
+    const double W = tw[1], Wq = W * qinv;
+    // stage 1 on the antisymmetric input: r_j = p_j + W p_{n+j} = p_j - W p_{n-j}, r_0 = p_0
+    auto first = [&](int j) { const double lo = pc[j], hi = j == 0 ? 0.0 : pc[n - j]; return lo - mulmod_lazy(hi, W, Wq, q); };
+    // destination plaintext slot inside a (possibly multi-block-row) panel: see PanelMap
+    const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
+    const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
+    u64 *out = out_ + (dst * L + m) * (size_t)n;
+    // (the format test is hoisted: inside the store loop it costs a branch per word)
+    if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+    else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+}
+// Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
+// CU, instead of one 512-thread workgroup holding a 132 KiB image.  Each half reads both halves of the input (the second read is an L2 hit: the two
+// workgroups of a row are numbered b and b + 8, same XCD) and pays the stage-1 product itself.
+__global__ void __launch_bounds__(256) k_ntt_fwd_split(const u64 *in_, u64 *out_, size_t nrows, ModPattern pat, RowMap rm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, n = N / 2, tid = threadIdx.x;
+    const size_t b = blockIdx.x, row = (b / 16) * 8 + b % 8; const int hs = (int)((b / 8) & 1);
+    if (row >= nrows) return;
+    const int m = pat.m[row % pat.period];
+    const size_t grp = row / rm.rpg, gi = row % rm.rpg;
+    const u64 *in = in_ + grp * rm.gstride_in + gi * N;
+    u64 *out = out_ + grp * rm.gstride_out + gi * N + (size_t)hs * n;
+    if (m < 0) {                                         // row marked "leave untouched": out of place that means "copy through"
+        for (int k = 0; k < 32; k++) out[k * 256 + tid] = in[(size_t)hs * n + k * 256 + tid];
+        return;
+    }
+    const double *tw = tw_all + (size_t)m * N;
+    const double2 *pack = pack_all + (size_t)m * (N / 2);
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const double W = hs ? -tw[1] : tw[1], Wq = W * qinv;
+    auto first = [&](int j) { return u64_to_f64(in[j]) + mulmod_lazy(u64_to_f64(in[n + j]), W, Wq, q); };
+    ntt_half3_body(hs, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
 }
 // full rows from half rows: out[i] = out[N-1-i] = half[i]
 __global__ void __launch_bounds__(256) k_expand_half(const u64 *half, u64 *full) {
@@ -350,6 +375,7 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
 }
@@ -359,7 +385,11 @@ int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const Mo
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat) { return launch_ntt_inv_map(ctx, in, out, nrows, pat, dense_map()); }
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm) {
     if (!nrows) return 0;
-    hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, rm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    // in place the two half-workgroups of a row would overwrite each other's input: the split form needs distinct buffers
+    if (in != out && !ctx->cfg.ntt_fwd_full)
+        hipLaunchKernelGGL(k_ntt_fwd_split, dim3((unsigned)((nrows + 7) / 8 * 16)), dim3(256), H3_LDS_BYTES, ctx->stream, in, out, nrows, pat, rm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    else
+        hipLaunchKernelGGL(k_ntt_fwd<0>, dim3((unsigned)nrows), dim3(512), LDS_DOUBLES * 8, ctx->stream, (const void *)in, out, pat, rm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }

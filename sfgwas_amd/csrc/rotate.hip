@@ -219,10 +219,13 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
     int in_grp = (int)((3ULL << 29) / (in_rows * N * 8)); if (in_grp < 1) in_grp = 1; if (in_grp > nin) in_grp = nin;
     int chunk = (int)((3ULL << 29) / (job_rows * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
     const size_t ptr_bytes = (size_t)nr * (3 * sizeof(void *) + sizeof(int)) + 256;     // pointer tables for every job of a group
-    SFG_TRY(sfg_ws_reserve(ctx, (in_rows * in_grp + job_rows * chunk) * N * 8 + ptr_bytes));
+    // the forward NTTs run out of place (two half-row workgroups per row cannot share a buffer with their input): extT / ext2T receive the transforms
+    const size_t ext_rows = (size_t)in_grp * kc.beta * kc.nt, ext2_rows = (size_t)chunk * 2 * nl;
+    SFG_TRY(sfg_ws_reserve(ctx, (in_rows * in_grp + job_rows * chunk + ext_rows + ext2_rows) * N * 8 + ptr_bytes));
     u64 *c2 = (u64 *)ctx->ws, *ext = c2 + (size_t)in_grp * nl * N;
-    u64 *acc = ext + (size_t)in_grp * kc.beta * kc.nt * N, *ext2 = acc + (size_t)chunk * 2 * kc.nt * N;
-    const u64 **keys_all = (const u64 **)(ext2 + (size_t)chunk * 2 * nl * N);
+    u64 *acc = ext + ext_rows * N, *ext2 = acc + (size_t)chunk * 2 * kc.nt * N;
+    u64 *extT = ext2 + ext2_rows * N, *ext2T = extT + ext_rows * N;
+    const u64 **keys_all = (const u64 **)(ext2T + ext2_rows * N);
     const uint16_t **idx_all = (const uint16_t **)(keys_all + nr);
     u64 **out_all = (u64 **)(idx_all + nr);
     int *inidx_all = (int *)(out_all + nr);
@@ -242,7 +245,7 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
         // 2. digit extension + NTT (in-digit rows are skipped by the pattern)
         hipLaunchKernelGGL(k_ksw_extend, dim3(N / 256, kc.beta, ni), dim3(256), 0, ctx->stream, c2, bin, ext, kcd, ctx->modc);
         SFG_HIP(ctx, hipGetLastError());
-        SFG_TRY(launch_ntt_fwd(ctx, ext, ext, (size_t)ni * kc.beta * kc.nt, pext));
+        SFG_TRY(launch_ntt_fwd(ctx, ext, extT, (size_t)ni * kc.beta * kc.nt, pext));          // in-digit rows (pattern -1) are copied through
         // pointer tables of the whole group: staged in the pinned ring, stream-ordered (no host wait on the launch path)
         {
             const size_t nj = jobs.size();
@@ -257,16 +260,16 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
             const int nb = (int)(jobs.size() - c0 < (size_t)chunk ? jobs.size() - c0 : (size_t)chunk);
             const u64 **keys_d = keys_all + c0; const uint16_t **idx_d = idx_all + c0; u64 **out_d = out_all + c0; int *inidx_d = inidx_all + c0;
             // 3. inner product with the key
-            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, ext, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
+            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, extT, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
             SFG_HIP(ctx, hipGetLastError());
             // 4. ModDown: INTT special rows in place, extend to Q, NTT
             RowMap rm4; rm4.rpg = kc.np; rm4.gstride_in = (size_t)kc.nt * N; rm4.gstride_out = (size_t)kc.nt * N;
             SFG_TRY(launch_ntt_inv_map(ctx, acc + (size_t)nl * N, acc + (size_t)nl * N, (size_t)nb * 2 * kc.np, pp, rm4));
             hipLaunchKernelGGL(k_moddown_extend, dim3(N / 256, 2, nb), dim3(256), 0, ctx->stream, acc, ext2, kcd, ctx->modc);
             SFG_HIP(ctx, hipGetLastError());
-            SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2, (size_t)nb * 2 * nl, pq));
+            SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2T, (size_t)nb * 2 * nl, pq));
             // 5. finish + automorphism
-            hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2, idx_d, out_d, kcd, ctx->modc,
+            hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2T, idx_d, out_d, kcd, ctx->modc,
                                add1 ? add1 + (size_t)i0 * nl * N : nullptr);
             SFG_HIP(ctx, hipGetLastError());
         }
