@@ -90,7 +90,7 @@ int sfg_encode_diags_dev(sfg_ctx *ctx, const int8_t *block_dev, size_t ld, int r
  * Mask/MaskTrunc-style callers, basics.go:110-172): values_host[nvec][slots] -> coeffs_host[nvec][N] int64 */
 int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, int64_t *coeffs_host);
 /* Rounding audit of the encoder.  The reference rounds Delta * sigma^-1(v) computed with 256-bit big floats (NewEncoderBig(params, 256),
- * matmult.go:1019,1421); the device computes the same reals in double-double (~2^-65 absolute here).  The two can only round a
+ * matmult.go:1019,1421); the device computes the same reals in double-double (better than 2^-58 absolute here).  The two can only round a
  * coefficient differently when its exact value lies within that distance of a tie; every coefficient within 2^-40 of a tie is counted
  * per context.  count == 0 after a call proves that call's plaintexts are the reference's, bit for bit; a non-zero count (expected
  * about once per 2 * 10^11 coefficients) names a call whose result should be re-derived with the CPU big-float encoder. */

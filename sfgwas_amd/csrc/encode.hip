@@ -193,6 +193,32 @@ __device__ __forceinline__ void cdd_mul_ip(dd &re, dd &im, dd wr, dd wi) {
     const dd r = dd_dot2(re, wr, im, wi, -1.0), i = dd_dot2(re, wi, im, wr, 1.0);
     re = r; im = i;
 }
+// ---- fixed-grid double-double for the FFT of GENOTYPE rows.  Every intermediate of that transform is bounded by sum |z_m| <= 4096 * |128 + 128i| < 2^20
+// for ANY int8 row (genotypes after missing -> 0 and squaring are <= 4: < 2^15), so the high parts can live on the fixed grid 2^-31 Z (|hi| < 2^20:
+// 51 bits): two grid numbers add EXACTLY in one plain addition, the low parts (|lo| <= 2^-32 after a product, <= 2^-29 after the three add levels of
+// a radix-8 pass) in another - 2 flops per sum instead of 8.  Only products leave the grid; they are put back by the magic-number split
+// hi' = (p + M) - M, lo' = (p - hi') + e with M = 1.5 * 2^21 (4 flops, which replace the 3 of the renormalisation they had).  Absolute error: low-part
+// sums 2^-83 each, products 2^-85: ~2^-80 after four passes, ~2^-59 on a scaled coefficient - far inside the 2^-40 band of the near-tie audit.
+// Arbitrary real slot vectors (F64IN) are unbounded and keep the general path.
+constexpr double GRID_M = 3145728.0;                      // 1.5 * 2^21: ulp(M) = 2^-31
+__device__ __forceinline__ dd grid_split(double p, double e) { const double h = (p + GRID_M) - GRID_M; return dd_make(h, (p - h) + e); }
+template <bool GRID> __device__ __forceinline__ dd fx_add(dd a, dd b) { return GRID ? dd_make(a.hi + b.hi, a.lo + b.lo) : dd_add_lazy(a, b); }
+template <bool GRID> __device__ __forceinline__ dd fx_sub(dd a, dd b) { return GRID ? dd_make(a.hi - b.hi, a.lo - b.lo) : dd_sub_lazy(a, b); }
+template <bool GRID> __device__ __forceinline__ dd fx_mul(dd a, dd b) {          // dd_mul, result on the grid
+    double p = a.hi * b.hi, e = fma(a.hi, b.hi, -p);
+    e = fma(a.hi, b.lo, e); e = fma(a.lo, b.hi, e);
+    return GRID ? grid_split(p, e) : dd_quick(p, e);
+}
+template <bool GRID> __device__ __forceinline__ dd fx_dot2(dd a, dd w, dd b, dd x, double sgn) {   // dd_dot2, result on the grid
+    const double p1 = a.hi * w.hi, e1 = fma(a.hi, w.hi, -p1);
+    const double bh = sgn * b.hi, bl = sgn * b.lo;
+    const double p2 = bh * x.hi, e2 = fma(bh, x.hi, -p2);
+    dd s = dd_two_sum(p1, p2);
+    double lo = e1 + e2;
+    lo = fma(a.hi, w.lo, lo); lo = fma(a.lo, w.hi, lo);
+    lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
+    return GRID ? grid_split(s.hi, s.lo + lo) : dd_quick(s.hi, s.lo + lo);
+}
 // zeta^-idx for idx in [0, 32768): the table covers [0, 16384], the rest is the negated first half
 __device__ __forceinline__ void tw_at(const double4 *zt, int idx, dd &wr, dd &wi) {
     const bool neg = idx > ENC_TW;
@@ -203,36 +229,36 @@ __device__ __forceinline__ void tw_at(const double4 *zt, int idx, dd &wr, dd &wi
 // One radix-8 DIF pass on 8 register-resident points at stride S of a sub-transform of length 8S: identical to three
 // radix-2 DIF stages (pairs (i,i+4), (i,i+2), (i,i+1)) with the twiddles regrouped - the 12 twiddle products of the
 // radix-2 form become 7 output products W^(e t), e = bitrev(r), plus two rotations by 1/8 turn; t = j mod S.
-template <int S>
+template <int S, bool GRID>
 __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const double4 *zt, int t) {
     const dd rs = dd_make(7.071067811865475727e-01, -4.833646656726456726e-17);      // 1/sqrt(2) in double-double
     dd ur[4], ui[4], dr[4], di[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        ur[i] = dd_add_lazy(xr[i], xr[i + 4]); ui[i] = dd_add_lazy(xi[i], xi[i + 4]);
-        dr[i] = dd_sub_lazy(xr[i], xr[i + 4]); di[i] = dd_sub_lazy(xi[i], xi[i + 4]);
+        ur[i] = fx_add<GRID>(xr[i], xr[i + 4]); ui[i] = fx_add<GRID>(xi[i], xi[i + 4]);
+        dr[i] = fx_sub<GRID>(xr[i], xr[i + 4]); di[i] = fx_sub<GRID>(xi[i], xi[i + 4]);
     }
     {   // d1 *= W8 = (1 - i)/sqrt2: (a + bi) -> ((a + b) + (b - a) i)/sqrt2
         dd a = dr[1], b = di[1];
-        dr[1] = dd_mul(dd_add_lazy(a, b), rs); di[1] = dd_mul(dd_sub_lazy(b, a), rs);
+        dr[1] = fx_mul<GRID>(fx_add<GRID>(a, b), rs); di[1] = fx_mul<GRID>(fx_sub<GRID>(b, a), rs);
     }
     {   // d2 *= -i: (a + bi) -> (b - ai)
         dd a = dr[2]; dr[2] = di[2]; di[2] = dd_neg(a);
     }
     {   // d3 *= W8^3 = (-1 - i)/sqrt2: (a + bi) -> ((b - a) - (a + b) i)/sqrt2
         dd a = dr[3], b = di[3];
-        dr[3] = dd_mul(dd_sub_lazy(b, a), rs); di[3] = dd_neg(dd_mul(dd_add_lazy(a, b), rs));
+        dr[3] = fx_mul<GRID>(fx_sub<GRID>(b, a), rs); di[3] = dd_neg(fx_mul<GRID>(fx_add<GRID>(a, b), rs));
     }
     auto quad = [&](dd (&hr)[4], dd (&hi)[4], int o) {
-        dd p0r = dd_add_lazy(hr[0], hr[2]), p0i = dd_add_lazy(hi[0], hi[2]);
-        dd p1r = dd_add_lazy(hr[1], hr[3]), p1i = dd_add_lazy(hi[1], hi[3]);
-        dd q0r = dd_sub_lazy(hr[0], hr[2]), q0i = dd_sub_lazy(hi[0], hi[2]);
-        dd t1r = dd_sub_lazy(hr[1], hr[3]), t1i = dd_sub_lazy(hi[1], hi[3]);
+        dd p0r = fx_add<GRID>(hr[0], hr[2]), p0i = fx_add<GRID>(hi[0], hi[2]);
+        dd p1r = fx_add<GRID>(hr[1], hr[3]), p1i = fx_add<GRID>(hi[1], hi[3]);
+        dd q0r = fx_sub<GRID>(hr[0], hr[2]), q0i = fx_sub<GRID>(hi[0], hi[2]);
+        dd t1r = fx_sub<GRID>(hr[1], hr[3]), t1i = fx_sub<GRID>(hi[1], hi[3]);
         dd q1r = t1i, q1i = dd_neg(t1r);                                               // * -i
-        xr[o + 0] = dd_add_lazy(p0r, p1r); xi[o + 0] = dd_add_lazy(p0i, p1i);
-        xr[o + 1] = dd_sub_lazy(p0r, p1r); xi[o + 1] = dd_sub_lazy(p0i, p1i);
-        xr[o + 2] = dd_add_lazy(q0r, q1r); xi[o + 2] = dd_add_lazy(q0i, q1i);
-        xr[o + 3] = dd_sub_lazy(q0r, q1r); xi[o + 3] = dd_sub_lazy(q0i, q1i);
+        xr[o + 0] = fx_add<GRID>(p0r, p1r); xi[o + 0] = fx_add<GRID>(p0i, p1i);
+        xr[o + 1] = fx_sub<GRID>(p0r, p1r); xi[o + 1] = fx_sub<GRID>(p0i, p1i);
+        xr[o + 2] = fx_add<GRID>(q0r, q1r); xi[o + 2] = fx_add<GRID>(q0i, q1i);
+        xr[o + 3] = fx_sub<GRID>(q0r, q1r); xi[o + 3] = fx_sub<GRID>(q0i, q1i);
     };
     quad(ur, ui, 0);
     quad(dr, di, 4);
@@ -242,12 +268,13 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
 #pragma unroll
         for (int r = 1; r < 8; r++) {
             dd wr, wi; tw_at(zt, E[r] * t * STEP, wr, wi);
-            cdd_mul_ip(xr[r], xi[r], wr, wi);
+            const dd pr = fx_dot2<GRID>(xr[r], wr, xi[r], wi, -1.0), pi = fx_dot2<GRID>(xr[r], wi, xi[r], wr, 1.0);
+            xr[r] = pr; xi[r] = pi;
         }
     }
 }
 
-// The double-double pipeline carries ~2^-100 relative error (absolute ~2^-65 on these magnitudes), the reference's EncoderBig 256
+// The double-double pipeline carries ~2^-100 relative error (absolute ~2^-65 on these magnitudes; ~2^-59 on the fixed grid), the reference's EncoderBig 256
 // bits.  A coefficient whose exact value lies within 2^-40 of a rounding tie is counted (sfg_ctx_encoder_near_ties): the two
 // encoders can only disagree on such a coefficient, so a zero count PROVES the block was rounded as the reference rounds it.
 __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {                // integer-valued double
@@ -295,7 +322,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         if (F64IN) { xr[a] = dd_make(rowd[t0], 0.0); xi[a] = dd_make(rowd[t1], 0.0); }
         else { xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0); }
     }
-    dif_radix8<512>(xr, xi, zt, tid);
+    dif_radix8<512, !F64IN>(xr, xi, zt, tid);
     // Every exchange runs in two rounds through the half image.  Round r moves the points whose split bit equals r: the
     // threads that own them write all 8 of their values, then EVERY thread reads the 4 values of that round it needs
     // (unconditional reads keep the register live ranges short).
@@ -314,7 +341,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
             for (int b = 0; b < 4; b++) get(padj(ar * 256 + b * 64 + cd), yr[4 * r + b], yi[4 * r + b]);
         }
-        dif_radix8<64>(yr, yi, zt, cd);
+        dif_radix8<64, !F64IN>(yr, yi, zt, cd);
         // ---- exchange 2 -> 3, split on c >> 2.  Writer (a, c, d) holds b = 0..7; reader (ab, d) needs c = 0..7 of j = ab*64 + c*8 + d
         const int cw = (tid >> 3) & 7, d = tid & 7, ab = tid >> 3;
 #pragma unroll
@@ -328,7 +355,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
             for (int c = 0; c < 4; c++) get(padj(ab * 32 + c * 8 + d), xr[4 * r + c], xi[4 * r + c]);
         }
-        dif_radix8<8>(xr, xi, zt, d);
+        dif_radix8<8, !F64IN>(xr, xi, zt, d);
         // ---- exchange 3 -> 4, split on d >> 2.  Writer (ab, d) holds c = 0..7; reader tid = abc needs d = 0..7 of j = tid*8 + d
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -341,7 +368,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
             for (int d4 = 0; d4 < 4; d4++) get(padj(tid * 4 + d4), yr[4 * r + d4], yi[4 * r + d4]);
         }
-        dif_radix8<1>(yr, yi, zt, 0);
+        dif_radix8<1, !F64IN>(yr, yi, zt, 0);
     }
     const int my_half = tid >> 8, tl = tid & 255;                   // result position j = tid*8 + d: top bit = tid >> 8
     // Round r handles the c of parity r: Z_c and Z_{h-c} then sit in half r of the (bit-reversed) result.
@@ -359,17 +386,22 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     for (int c = 2 * tid + r; c <= h / 2; c += 1024) {
         const int c2 = (h - c) & (h - 1);
         const int pa = padj(c >> 1), pb = padj(c2 >> 1);               // both have the parity of this round (c2 = h - c)
+        // (genotype rows: A and B are sums on the fixed grid, so the recombination adds are exact two-flop grid adds as well)
+        constexpr bool GRID = !F64IN;
+        auto radd = [](dd a, dd b) { return GRID ? dd_make(a.hi + b.hi, a.lo + b.lo) : dd_add(a, b); };
+        auto rsub = [](dd a, dd b) { return GRID ? dd_make(a.hi - b.hi, a.lo - b.lo) : dd_sub(a, b); };
+        auto half = [](dd a) { return dd_make(a.hi * 0.5, a.lo * 0.5); };                         // exact
         dd Ar = dd_make(RH[pa], RL[pa]), Ai = dd_make(IH[pa], IL[pa]);
         dd Br = dd_make(RH[pb], RL[pb]), Bi = dd_neg(dd_make(IH[pb], IL[pb]));
-        dd Xr = dd_mul_d(dd_add(Ar, Br), 0.5), Xi = dd_mul_d(dd_add(Ai, Bi), 0.5);
-        dd Dr = dd_mul_d(dd_sub(Ar, Br), 0.5), Di = dd_mul_d(dd_sub(Ai, Bi), 0.5);
+        dd Xr = half(radd(Ar, Br)), Xi = half(radd(Ai, Bi));
+        dd Dr = half(rsub(Ar, Br)), Di = half(rsub(Ai, Bi));
         dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/(2i) = -i (A-B)/2
         const double4 wo = zt[4 * c];                               // omega^-c = zeta^-4c
         dd wor = dd_make(wo.x, wo.y), woi = dd_make(wo.z, wo.w);
-        dd Yr = dd_dot2(Or, wor, Oi, woi, -1.0), Yi = dd_dot2(Or, woi, Oi, wor, 1.0);
+        dd Yr = fx_dot2<GRID>(Or, wor, Oi, woi, -1.0), Yi = fx_dot2<GRID>(Or, woi, Oi, wor, 1.0);
         // W_c
         {
-            dd Wr = dd_add(Xr, Yr), Wi = dd_add(Xi, Yi);
+            dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
             const double4 z = zt[c];
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
@@ -380,7 +412,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         // W_{h-c}  (c = 0 gives W_h)
         if (c < h / 2) {
             const int cc = h - c;
-            dd Wr = dd_sub(Xr, Yr), Wi = dd_neg(dd_sub(Xi, Yi));
+            dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
             const double4 z = zt[cc];
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
