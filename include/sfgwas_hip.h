@@ -121,6 +121,9 @@ int sfg_ct_drop_level_dev(sfg_ctx *ctx, const uint64_t *in_dev, uint64_t *out_de
  * AddPlain, CPAdd (basics.go:183-199, 472-497, 533-551, 592-611). scalars_host[level+1]: one canonical residue per modulus
  * (lattigo scaleUpExact(constant, scale, q_m); the host side owns that rule and the scale bookkeeping). out may alias ct. */
 int sfg_ct_mul_scalar_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *scalars_host, uint64_t *out_dev, int nct, int level);
+/* eval.MultByConstAndAdd (pca.go:264; qrfact.go:195,280): acc += ct * scalars[m], both polynomials, acc and ct at the same level.  The scale
+ * matching lattigo performs first (MultByConst of the receiver by floor(scale ratio), SetScale) is host-side: crypto::MultByConstAndAddDev. */
+int sfg_ct_mul_scalar_add_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *scalars_host, uint64_t *acc_dev, int nct, int level);
 int sfg_ct_add_scalar_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *scalars_host, uint64_t *out_dev, int nct, int level);
 int sfg_ct_add_plain_dev(sfg_ctx *ctx, const uint64_t *ct_dev, const uint64_t *pt_dev, size_t pt_stride, uint64_t *out_dev,
                          int nct, int level);

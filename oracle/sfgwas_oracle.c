@@ -594,6 +594,29 @@ void orc_mul_const(const orc_ring *r, int level, const u64 *ct, double constant,
     }
     *scale_mult = scale;
 }
+/* eval.MultByConstAndAdd(ct0, constant, ctOut) (pca.go:264; qrfact.go:195,280), restated from the published lattigo v2.1 / v2.2 evaluator - PARITY UNPINNED
+ * (the scale-matching rule is lattigo-internal): both ciphertexts at `level`; a constant with a fractional part is scaled by q_level, an integer is not;
+ * a receiver with the smaller scale is multiplied by floor(scale ratio) and relabelled, with the larger scale the constant absorbs the ratio;
+ * then out += ct0 * scaleUpExact(constant, scale, q_m).  *scale_out is read and updated. */
+void orc_mul_const_and_add(const orc_ring *r, int level, const u64 *ct0, double scale0, double constant, u64 *out, double *scale_out) {
+    int N = r->N, nl = level + 1; double scale = 1.0, k = 0;
+    if (constant != 0 && constant - (double)(long long)constant != 0) scale = (double)r->q[level];
+    if (scale != 1.0) {
+        if (*scale_out < scale0 * scale) { k = floor(scale * scale0 / *scale_out); *scale_out = scale * scale0; }
+        else if (*scale_out > scale0 * scale) scale = *scale_out / scale0;
+    } else {
+        if (*scale_out > scale0) scale = *scale_out / scale0;
+        else if (scale0 > *scale_out) { k = floor(scale0 / *scale_out); *scale_out = scale0; }
+    }
+    for (int m = 0; m < nl; m++) {
+        u64 q = r->q[m], c = constant != 0 ? orc_scale_up_exact(constant, scale, q) % q : 0, kk = k > 1 ? orc_scale_up_exact(k, 1.0, q) % q : 1;
+        for (int p = 0; p < 2; p++) for (int x = 0; x < N; x++) {
+            size_t i = ((size_t)p * nl + m) * N + x;
+            u64 o = k > 1 ? orc_mulmod(out[i], kk, q) : out[i];
+            out[i] = (o + orc_mulmod(ct0[i], c, q)) % q;
+        }
+    }
+}
 /* eval.AddConst(ct, constant float64) (basics.go:192-199, 604-611): adds round(constant * ct_scale) to every NTT coefficient of c0 */
 void orc_add_const(const orc_ring *r, int level, const u64 *ct, double constant, double ct_scale, u64 *out) {
     int N = r->N, nl = level + 1;

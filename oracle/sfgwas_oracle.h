@@ -103,6 +103,7 @@ void orc_rescale(const orc_ring *r, int level, const uint64_t *ct, uint64_t *out
 int orc_innersum_all(const orc_ring *r, const orc_rotkeys *keys, int level, const uint64_t *cts, int nct, uint64_t *out);
 uint64_t orc_scale_up_exact(double value, double n, uint64_t q);
 void orc_mul_const(const orc_ring *r, int level, const uint64_t *ct, double constant, uint64_t *out, double *scale_mult);
+void orc_mul_const_and_add(const orc_ring *r, int level, const uint64_t *ct0, double scale0, double constant, uint64_t *out, double *scale_out);   /* parity unpinned */
 void orc_add_const(const orc_ring *r, int level, const uint64_t *ct, double constant, double ct_scale, uint64_t *out);
 void orc_add_plain(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *pt, uint64_t *out);
 void orc_gen_rlk(const orc_ring *r, const int8_t *s_coeff, uint64_t seed, uint64_t *key_out);

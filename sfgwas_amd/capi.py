@@ -33,6 +33,7 @@ def _sig(L):
         "sfg_ctx_load_rotkey": (i, [vp, u64, u64p, i]),
         "sfg_ctx_load_secret_key": (i, [vp, u64p, i]),
         "sfg_ct_galois_dev": (i, [vp, vp, vp, i, i, u64]),
+        "sfg_ct_mul_scalar_add_dev": (i, [vp, vp, u64p, vp, i, i]),
         "sfg_refresh_gen_shares_dev": (i, [vp, vp, i, i, vp, vp, i, vp, vp, vp, vp]),
         "sfg_refresh_finish_dev": (i, [vp, vp, i, i, vp, vp, vp, vp]),
         "sfg_ckks_to_ss_share_dev": (i, [vp, vp, i, i, vp, i, vp, vp, vp]),

@@ -65,6 +65,14 @@ __global__ void __launch_bounds__(256) k_mul_scalar(const u64 *ct, ScalarRow sc,
     const size_t i = (c * 2 * nl + row) * N + x;
     out[i] = f64_to_u64(mm2(u64_to_f64(ct[i]), u64_to_f64(sc.c[m]), q, qinv));
 }
+// grid (N/256, 2*nl, nct): acc += ct * c[m]  (MultByConstAndAdd's arithmetic: ring.MRed(p0, MForm(c)) + CRed)
+__global__ void __launch_bounds__(256) k_mul_scalar_add(const u64 *ct, ScalarRow sc, u64 *acc, int nl, const ModConst *modc) {
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, m = row % nl; const size_t c = blockIdx.z;
+    const double q = modc[m].q, qinv = modc[m].qinv;
+    const size_t i = (c * 2 * nl + row) * N + x;
+    double v = mm2(u64_to_f64(ct[i]), u64_to_f64(sc.c[m]), q, qinv) + u64_to_f64(acc[i]);
+    acc[i] = f64_to_u64(v >= q ? v - q : v);
+}
 // grid (N/256, 2*nl, nct): out = ct, with c[m] (AddConst) or pt[m][x] (AddNew(ct, plaintext)) added to polynomial 0
 __global__ void __launch_bounds__(256) k_add_c0(const u64 *ct, ScalarRow sc, const u64 *pt, size_t pt_stride, u64 *out, int nl, const ModConst *modc) {
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, m = row % nl; const size_t c = blockIdx.z;
@@ -183,6 +191,19 @@ extern "C" int sfg_ct_mul_scalar_dev(sfg_ctx *ctx, const uint64_t *ct, const uin
     ScalarRow sc; memset(&sc, 0, sizeof sc);
     for (int m = 0; m < nl; m++) { if (scalars_host[m] >= ctx->q[m]) SFG_FAIL(ctx, "mul_scalar: residue %d not canonical", m); sc.c[m] = scalars_host[m]; }
     hipLaunchKernelGGL(k_mul_scalar, dim3(N / 256, 2 * nl, nct), dim3(256), 0, ctx->stream, (const u64 *)ct, sc, (u64 *)out, nl, ctx->modc);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// eval.MultByConstAndAdd's arithmetic (pca.go:264, qrfact.go:195,280): acc += ct * scalars[m] on both polynomials; the scale matching that
+// precedes it in lattigo is host-side bookkeeping (crypto::MultByConstAndAddDev in the host mirror)
+extern "C" int sfg_ct_mul_scalar_add_dev(sfg_ctx *ctx, const uint64_t *ct, const uint64_t *scalars_host, uint64_t *acc, int nct, int level) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(check_level(ctx, level, nct));
+    if (!nct) return 0;
+    const int N = SFG_N, nl = level + 1;
+    ScalarRow sc; memset(&sc, 0, sizeof sc);
+    for (int m = 0; m < nl; m++) { if (scalars_host[m] >= ctx->q[m]) SFG_FAIL(ctx, "mul_scalar_add: residue %d not canonical", m); sc.c[m] = scalars_host[m]; }
+    hipLaunchKernelGGL(k_mul_scalar_add, dim3(N / 256, 2 * nl, nct), dim3(256), 0, ctx->stream, (const u64 *)ct, sc, (u64 *)acc, nl, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -443,6 +443,32 @@ inline DevCipherVector CMaskDev(CryptoParams *cps, const DevCipherVector &cv, in
     std::vector<double> m((size_t)cps->GetSlots() * cv.n, keepRest ? 1.0 : 0.0); m[index] = keepRest ? 0.0 : 1.0;
     return mulByRealVectorsDev(cps, cv, m, qi);
 }
+// eval.MultByConstAndAdd(ct0, constant, ctOut) on device vectors (pca.go:264: XMean * -meanWeight onto Q[b]; qrfact.go:195,280: vvTA * -2/N onto A / Q):
+//   ctOut += ct0 * constant, after lattigo has matched the two scales.  PARITY UNPINNED - the rule is restated from the published lattigo v2.1/v2.2
+//   evaluator: a constant with a fractional part is scaled by q_level (as in MultByConst), integers are not; if the receiver's scale is the smaller one it is
+//   first multiplied by floor(scale ratio) (an integer MultByConst) and relabelled, if it is the larger one the constant absorbs the ratio.
+inline void MultByConstAndAddDev(CryptoParams *cps, const DevCipherVector &ct0, double constant, DevCipherVector &ctOut, const std::vector<uint64_t> &qi) {
+    if (ct0.n != ctOut.n) throw std::runtime_error("MultByConstAndAdd: vector lengths differ");
+    const int level = std::min(ct0.level, ctOut.level);
+    DevCipherVector in = ct0.level > level ? DropLevelDev(ct0, level) : ct0;
+    if (ctOut.level > level) ctOut = DropLevelDev(ctOut, level);                     // "forces a drop of ctOut level to ct0 level"
+    double scale = 1.0;
+    if (constant != 0 && constant - (double)(long long)constant != 0) scale = (double)qi[level];
+    auto mulOutByInt = [&](double k) {
+        std::vector<uint64_t> sc(level + 1); for (int m = 0; m <= level; m++) sc[m] = scaleUpExact(k, 1.0, qi[m]) % qi[m];
+        cps->check(sfg_ct_mul_scalar_dev(cps->ctx, ctOut.ptr(), sc.data(), ctOut.ptr(), (int)ctOut.n, level), "MultByConst(ctOut)");
+    };
+    if (scale != 1.0) {
+        if (ctOut.scale < in.scale * scale) { const double k = std::floor(scale * in.scale / ctOut.scale); if (k > 1) mulOutByInt(k); ctOut.scale = scale * in.scale; }
+        else if (ctOut.scale > in.scale * scale) scale = ctOut.scale / in.scale;
+    } else {
+        if (ctOut.scale > in.scale) scale = ctOut.scale / in.scale;
+        else if (in.scale > ctOut.scale) { const double k = std::floor(in.scale / ctOut.scale); if (k > 1) mulOutByInt(k); ctOut.scale = in.scale; }
+    }
+    std::vector<uint64_t> sc(level + 1, 0);
+    for (int m = 0; m <= level; m++) sc[m] = constant != 0 ? scaleUpExact(constant, scale, qi[m]) % qi[m] : 0;
+    cps->check(sfg_ct_mul_scalar_add_dev(cps->ctx, in.ptr(), sc.data(), ctOut.ptr(), (int)ctOut.n, level), "MultByConstAndAdd");
+}
 inline DevCipherVector viewOne(const DevCipherVector &v, size_t j) { DevCipherVector o = v; o.off = v.off + j * detail::ctWords(v.cps, v.level); o.n = 1; return o; }
 }  // namespace crypto
 

@@ -54,6 +54,20 @@ int main(int argc, char **argv) {
         crypto::DevCipherMatrix out = mpc::CollectiveBootstrapFinish(cps.get(), dcm, h0agg.u(), h1agg.u(), crs.u());
         if (out.level != nq - 1) throw std::runtime_error("bootstrap output is not at MaxLevel");
         dumpDev(cps.get(), dir + "/out.bin", out.buf->u(), (size_t)rows * 2 * nq * N);
+        // eval.MultByConstAndAdd through the mirror: cases "<constant> <level0> <scale0> <levelOut> <scaleOut>" on 2-ciphertext vectors
+        {
+            std::ifstream mc(dir + "/mbca_cases.txt"); int ncase; mc >> ncase;
+            std::ofstream res(dir + "/mbca_scales.txt"); res.precision(17);
+            for (int k = 0; k < ncase; k++) {
+                double c, s0, sO; int l0, lO; mc >> c >> l0 >> s0 >> lO >> sO;
+                auto a = gwas::unflatten(readU64(dir + "/mbca_in_" + std::to_string(k) + ".bin"), 1, 2, l0, s0, (int)N)[0];
+                auto o = gwas::unflatten(readU64(dir + "/mbca_out_" + std::to_string(k) + ".bin"), 1, 2, lO, sO, (int)N)[0];
+                crypto::DevCipherVector da = crypto::ToDevice(cps.get(), a), dout = crypto::ToDevice(cps.get(), o);
+                crypto::MultByConstAndAddDev(cps.get(), da, c, dout, qi);
+                dumpDev(cps.get(), dir + "/mbca_res_" + std::to_string(k) + ".bin", dout.ptr(), (size_t)2 * 2 * (dout.level + 1) * N);
+                res << dout.level << " " << dout.scale << "\n";
+            }
+        }
         std::cout << "OK" << std::endl;
         return 0;
     } catch (const std::exception &e) { std::cerr << "ERROR: " << e.what() << std::endl; return 1; }

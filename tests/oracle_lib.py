@@ -89,6 +89,7 @@ def lib():
         L.orc_scale_up_exact.restype = C.c_uint64
         L.orc_scale_up_exact.argtypes = [C.c_double, C.c_double, C.c_uint64]
         L.orc_mul_const.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, u64p, C.POINTER(C.c_double)]
+        L.orc_mul_const_and_add.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, C.c_double, u64p, C.POINTER(C.c_double)]
         L.orc_add_const.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, C.c_double, u64p]
         L.orc_add_plain.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
         L.orc_ct_addsub.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_int, u64p]

@@ -430,9 +430,27 @@ def test_collective_bootstrap_local_halves_flatten_and_concat_match_the_oracle(t
     h1agg = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(ring.nq)]) for _ in range(rows)])
     h0agg.tofile(tmp_path / "h0agg.bin"); h1agg.tofile(tmp_path / "h1agg.bin")
     (tmp_path / "case.txt").write_text(f"{rows} {level} {W}\n")
+    # eval.MultByConstAndAdd cases (pca.go:264: integer constant; qrfact.go:195,280: -2/N): (constant, level0, scale0, levelOut, scaleOut)
+    SC = 2.0 ** 34
+    mb = [(-3.0, 4, SC, 4, SC), (-2.0 / 3000.0, 4, SC * 1.0001, 4, SC), (5.0, 3, SC, 5, SC * 64.0), (-7.0, 4, SC * 1000.0, 4, SC), (0.375, 2, SC, 2, SC * 2.0 ** 40)]
+    (tmp_path / "mbca_cases.txt").write_text(f"{len(mb)}\n" + "".join(f"{c!r} {l0} {s0!r} {lo} {so!r}\n" for c, l0, s0, lo, so in mb))
+    mb_in, mb_out = [], []
+    for k, (c, l0, s0, lo, so) in enumerate(mb):
+        a = np.stack([ring.fill_uniform(l0, 700 + 2 * k + j) for j in range(2)]); o = np.stack([ring.fill_uniform(lo, 800 + 2 * k + j) for j in range(2)])
+        a.tofile(tmp_path / f"mbca_in_{k}.bin"); o.tofile(tmp_path / f"mbca_out_{k}.bin"); mb_in.append(a); mb_out.append(o)
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr
     ld = lambda name, shape: np.fromfile(tmp_path / name, dtype=np.uint64).reshape(shape)
+    got_scales = [ln.split() for ln in (tmp_path / "mbca_scales.txt").read_text().splitlines()]
+    for k, (c, l0, s0, lo, so) in enumerate(mb):
+        lev = min(l0, lo)
+        res = ld(f"mbca_res_{k}.bin", (2, 2, lev + 1, ring.N))
+        for j in range(2):
+            a = np.ascontiguousarray(mb_in[k][j][:, :lev + 1]); o = np.ascontiguousarray(mb_out[k][j][:, :lev + 1])     # DropLevel keeps the first lev+1 rows
+            sc = C.c_double(so)
+            ol.lib().orc_mul_const_and_add(ring.h, lev, ol.p64(a), s0, c, ol.p64(o), C.byref(sc))
+            assert np.array_equal(res[j], o), f"MultByConstAndAdd case {k} ciphertext {j}"
+        assert int(got_scales[k][0]) == lev and float(got_scales[k][1]) == sc.value, f"MultByConstAndAdd case {k}: level / scale bookkeeping"
     assert np.array_equal(ld("flat.bin", cm.shape), cm), "FlattenLevels"
     cc = ld("concat.bin", (rows, 2) + cm.shape[1:])
     assert np.array_equal(cc[:, 0], cm) and np.array_equal(cc[:, 1], cm), "ConcatCipherMatrix"

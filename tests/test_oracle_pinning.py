@@ -427,3 +427,25 @@ def test_mul_const_add_const_add_plain_decrypt_correctly():
     L().orc_add_plain(ring.h, level, ol.p64(cu), ol.p64(pt), ol.p64(out))
     got = _decrypt_decode(ring, s, level, out, scale)
     assert np.max(np.abs(got.real - (u + v))) < 1e-4
+
+
+def test_mul_const_and_add_semantics_on_decrypted_values():
+    """eval.MultByConstAndAdd restatement (parity unpinned): whatever branch of the scale matching runs, the receiver afterwards decrypts to
+    out/scale_out + constant * in/scale_in (up to the rounding of the scaled constant and the truncated integer ratio)"""
+    import ctypes as C
+    ring = small_ring(4)
+    s = ring.gen_secret(3)
+    rnd = np.random.default_rng(9)
+    SC = 2.0 ** 30
+    for const, s0, so in [(-3.0, SC, SC), (-2.0 / 3000.0, SC, SC), (5.0, SC, SC * 64.0), (-7.0, SC * 1000.0, SC), (0.375, SC, SC * 2.0 ** 20)]:
+        level = 2
+        va, vo = rnd.uniform(-1, 1, ring.N), rnd.uniform(-1, 1, ring.N)
+        a = ring.encrypt(s, level, np.round(va * s0).astype(np.int64), 5)
+        o = ring.encrypt(s, level, np.round(vo * so).astype(np.int64), 6)
+        sc = C.c_double(so)
+        ol.lib().orc_mul_const_and_add(ring.h, level, ol.p64(a), s0, const, ol.p64(o), C.byref(sc))
+        res = ring.decrypt_residues(s, level, o)
+        big = pyref.crt_centered([res[m] for m in range(level + 1)], ring.moduli[:level + 1])
+        got = np.array([float(x) for x in big]) / sc.value
+        want = vo + const * va
+        assert np.max(np.abs(got - want)) < 1e-3 * max(1.0, abs(const)), (const, s0, so, float(np.max(np.abs(got - want))))
