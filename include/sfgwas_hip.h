@@ -160,6 +160,11 @@ void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g);
  * (the script's assert) or wrong magic. */
 int sfg_geno_from_bed(sfg_ctx *ctx, const uint8_t *bed_host, size_t bed_bytes, size_t num_sample, size_t num_snp,
                       const uint8_t *row_filter, const uint8_t *col_filter, sfg_geno **out);
+/* 2-bit packed residency (c4 is 25 GB instead of 100 GB; c5 fits 8 GPUs): codes 0, 1, 2 = the genotype, 3 = missing, 4 columns per byte.
+ * Every product entry point takes a packed handle (blocks are expanded on the fly, ~1 % of a block's time); results are bit-identical.  Fails if a
+ * value above 2 is present (the int8 layout stays available for such matrices).  Free the int8 handle afterwards to release its memory. */
+int sfg_geno_pack(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out);
+int sfg_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out);
 int sfg_geno_dims(const sfg_geno *g, size_t *nrow, size_t *ncol);
 /* host [nrow][ncol] copy of a resident matrix (interoperability with CPU-only parties, tests) */
 int sfg_geno_download(sfg_ctx *ctx, const sfg_geno *g, int8_t *host);

@@ -37,6 +37,8 @@ def _sig(L):
         "sfg_refresh_gen_shares_dev": (i, [vp, vp, i, i, vp, vp, i, vp, vp, vp, vp]),
         "sfg_refresh_finish_dev": (i, [vp, vp, i, i, vp, vp, vp, vp]),
         "sfg_ckks_to_ss_share_dev": (i, [vp, vp, i, i, vp, i, vp, vp, vp]),
+        "sfg_geno_pack": (i, [vp, vp, C.POINTER(vp)]),
+        "sfg_geno_unpack": (i, [vp, vp, C.POINTER(vp)]),
         "sfg_assoc_stream_bed": (i, [vp, C.c_char_p, sz, sz, vp, vp, sz, vp, i, i, i, C.c_uint, vp, sz, C.POINTER(sz), vp, vp]),
         "sfg_ctx_has_rotkey": (i, [vp, u64]),
         "sfg_ctx_export_rotkey": (i, [vp, u64, u64p]),

@@ -34,9 +34,10 @@ struct PhaseStat { double ms = 0; int launches = 0; double bytes = 0; };   // by
 struct PendingEvent { hipEvent_t e0, e1; std::string name; int launches; double bytes; };
 
 struct sfg_geno {
-    const int8_t *dev = nullptr;
+    const int8_t *dev = nullptr;           // int8 [nrow][ld], or (packed) 2-bit codes: 4 columns per byte, row stride ld BYTES (multiple of 4)
     size_t nrow = 0, ncol = 0, ld = 0;
     bool owned = false;
+    bool packed = false;                   // codes 0, 1, 2 = the genotype, 3 = missing (sfg_geno_pack)
 };
 
 // A/B and diagnostic switches: read ONCE from the environment by sfg_ctx_create (never on the launch path)

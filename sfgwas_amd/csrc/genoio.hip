@@ -6,6 +6,7 @@
 // The packed image crosses PCIe (4x less than int8) and is expanded in HBM; results are resident sfg_geno handles.
 #include "common.hpp"
 #include "kernels.hpp"
+#include <algorithm>
 
 // tile = 64 SNPs x 64 bytes (256 samples). grid (ceil(bps/64), ceil(num_snp/64)), 256 threads
 __global__ void __launch_bounds__(256) k_bed_decode(const uint8_t *bed, size_t bps, size_t num_sample, size_t num_snp,
@@ -47,6 +48,71 @@ int launch_bed_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t 
     hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((bps + 63) / 64), (unsigned)((num_snp + 63) / 64)), dim3(256), 0, st, dbed, bps, num_sample, num_snp, rmap, cmap, out, ld);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
+}
+// ---- 2-bit packed residency (100k x 1M is 25 GB instead of 100 GB; 500k x 10M fits 8 GPUs).  Codes 0, 1, 2 = the genotype,
+// 3 = missing; 4 consecutive columns per byte, low bits first; a row is ceil(ncol / 16) dwords.  The products expand one 8192 x 8192 block at a time
+// into the int8 staging block the skew kernel reads (16 MB in, 64 MB out per block: ~1 % of a block's encode + MAC time).
+// grid (ceil(ldb/4 / 256), nrow): one dword = 16 columns per thread
+__global__ void __launch_bounds__(256) k_geno_pack(const int8_t *in, size_t ncol, size_t ld, unsigned *out, size_t ldw, unsigned *bad) {
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (w >= ldw) return;
+    unsigned v = 0, nb = 0;
+    for (int k = 0; k < 16; k++) {
+        const size_t c = w * 16 + k;
+        int g = c < ncol ? in[r * ld + c] : 0;
+        if (g > 2) nb++;
+        v |= (unsigned)(g < 0 ? 3 : (g & 3)) << (2 * k);
+    }
+    out[r * ldw + w] = v;
+    if (nb) atomicAdd(bad, nb);
+}
+// grid (ceil(nc / 1024), nr): thread = 4 columns (one packed byte)
+__global__ void __launch_bounds__(256) k_geno_unpack(const uint8_t *in, size_t ldb, size_t r0, size_t b0, size_t nc, int8_t *out, size_t ld_out) {
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (b * 4 >= nc) return;
+    const unsigned v = in[(r0 + r) * ldb + b0 + b];
+    int8_t *o = out + r * ld_out + b * 4;
+    const unsigned lut = 0xFF020100u;                                  // code -> int8 {0, 1, 2, -1}
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (b * 4 + k < nc) o[k] = (int8_t)(lut >> (8 * ((v >> (2 * k)) & 3)));
+}
+int launch_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, size_t r0, size_t c0, size_t nr, size_t nc, int8_t *out, size_t ld_out) {
+    if (!g->packed || (c0 & 3)) SFG_FAIL(ctx, "geno_unpack: not a packed matrix or unaligned column");
+    if (!nr || !nc) return 0;
+    hipLaunchKernelGGL(k_geno_unpack, dim3((unsigned)((nc + 1023) / 1024), (unsigned)nr), dim3(256), 0, ctx->stream, (const uint8_t *)g->dev, g->ld, r0, c0 / 4, nc, out, ld_out);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+extern "C" int sfg_geno_pack(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (g->packed) SFG_FAIL(ctx, "sfg_geno_pack: already packed");
+    if (g->nrow > 65535u * 1024u) SFG_FAIL(ctx, "sfg_geno_pack: too many rows");
+    const size_t ldw = (g->ncol + 15) / 16;
+    unsigned *d = nullptr, *bad = nullptr, hbad = 0;
+    SFG_HIP(ctx, hipMalloc(&d, g->nrow * ldw * 4));
+    SFG_HIP(ctx, hipMalloc(&bad, 4));
+    SFG_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+    for (size_t r0 = 0; r0 < g->nrow; r0 += 65535) {
+        const size_t nr = std::min<size_t>(65535, g->nrow - r0);
+        hipLaunchKernelGGL(k_geno_pack, dim3((unsigned)((ldw + 255) / 256), (unsigned)nr), dim3(256), 0, ctx->stream, g->dev + r0 * g->ld, g->ncol, g->ld, d + r0 * ldw, ldw, bad);
+    }
+    SFG_HIP(ctx, hipGetLastError());
+    SFG_HIP(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(bad);
+    if (hbad) { (void)hipFree(d); SFG_FAIL(ctx, "sfg_geno_pack: %u values above 2 do not fit the 2-bit layout", hbad); }
+    sfg_geno *p = new sfg_geno(); p->dev = (const int8_t *)d; p->nrow = g->nrow; p->ncol = g->ncol; p->ld = ldw * 4; p->owned = true; p->packed = true;
+    *out = p; return 0;
+}
+extern "C" int sfg_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!g->packed) SFG_FAIL(ctx, "sfg_geno_unpack: not packed");
+    int8_t *d = nullptr;
+    SFG_HIP(ctx, hipMalloc(&d, g->nrow * g->ncol));
+    for (size_t r0 = 0; r0 < g->nrow; r0 += 65535) SFG_TRY(launch_geno_unpack(ctx, g, r0, 0, std::min<size_t>(65535, g->nrow - r0), g->ncol, d + r0 * g->ncol, g->ncol));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sfg_geno *u = new sfg_geno(); u->dev = d; u->nrow = g->nrow; u->ncol = g->ncol; u->ld = g->ncol; u->owned = true;
+    *out = u; return 0;
 }
 static int make_map(sfg_ctx *ctx, const uint8_t *filt, size_t n, int32_t **dev, size_t *kept) {
     *dev = nullptr; *kept = n;
@@ -92,12 +158,14 @@ extern "C" int sfg_geno_dims(const sfg_geno *g, size_t *nrow, size_t *ncol) {
 }
 extern "C" int sfg_geno_download(sfg_ctx *ctx, const sfg_geno *g, int8_t *host) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (g->packed) { sfg_geno *u = nullptr; SFG_TRY(sfg_geno_unpack(ctx, g, &u)); int rc = sfg_geno_download(ctx, u, host); sfg_geno_free(ctx, u); return rc; }
     SFG_HIP(ctx, hipMemcpy2DAsync(host, g->ncol, g->dev, g->ld, g->ncol, g->nrow, hipMemcpyDeviceToHost, ctx->stream));
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 extern "C" int sfg_geno_transpose(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (g->packed) SFG_FAIL(ctx, "sfg_geno_transpose: packed matrix (the products take SFG_TRANSPOSE on the one copy; sfg_geno_unpack first for a materialised transpose)");
     int8_t *d = nullptr;
     SFG_HIP(ctx, hipMalloc(&d, g->nrow * g->ncol));
     hipLaunchKernelGGL(k_geno_transpose, dim3((unsigned)((g->ncol + 63) / 64), (unsigned)((g->nrow + 63) / 64)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, d);
@@ -110,6 +178,7 @@ extern "C" int sfg_geno_concat_cols(sfg_ctx *ctx, const sfg_geno *const *parts, 
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (k < 1) SFG_FAIL(ctx, "sfg_geno_concat_cols: nothing to merge");
     size_t nrow = parts[0]->nrow, ncol = 0;
+    for (int i = 0; i < k; i++) if (parts[i]->packed) SFG_FAIL(ctx, "sfg_geno_concat_cols: part %d is packed (merge before sfg_geno_pack)", i);
     for (int i = 0; i < k; i++) { if (parts[i]->nrow != nrow) SFG_FAIL(ctx, "sfg_geno_concat_cols: part %d has %zu rows, expected %zu", i, parts[i]->nrow, nrow); ncol += parts[i]->ncol; }
     int8_t *d = nullptr;
     SFG_HIP(ctx, hipMalloc(&d, nrow * ncol));

@@ -28,6 +28,8 @@ int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, in
 // encode.hip
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D);
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0, unsigned packed_mask = 0);
+// genoio.hip: dense int8 copy [nr][ld_out] of the stored sub-block (r0.., c0..) of a 2-bit packed matrix (c0 a multiple of 4)
+int launch_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, size_t r0, size_t c0, size_t nr, size_t nc, int8_t *out, size_t ld_out);
 // rotate.hip
 int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host);
 int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index);

@@ -26,6 +26,7 @@ struct Shape {
     int nbr, m_ct;
     bool transposed;
     const int8_t *dev; size_t ld;
+    const sfg_geno *g;      // the resident matrix (2-bit packed matrices are expanded block by block, see matmul_accumulate)
     int rows_of(int bi) const { return (int)(std::min((size_t)(bi + 1) * SFG_SLOTS, nrow) - (size_t)bi * SFG_SLOTS); }
     int cols_of(int bj) const { return (int)(std::min((size_t)(bj + 1) * SFG_SLOTS, ncol) - (size_t)bj * SFG_SLOTS); }
     // pointer to the stored top-left element of logical block (bi, bj)
@@ -38,7 +39,7 @@ static Shape make_shape(const sfg_geno *g, unsigned flags) {
     Shape sh; sh.transposed = (flags & SFG_TRANSPOSE) != 0;
     sh.nrow = sh.transposed ? g->ncol : g->nrow; sh.ncol = sh.transposed ? g->nrow : g->ncol;
     sh.nbr = ceil_div(sh.nrow, SFG_SLOTS); sh.m_ct = ceil_div(sh.ncol, SFG_SLOTS);
-    sh.dev = g->dev; sh.ld = g->ld; return sh;
+    sh.dev = g->dev; sh.ld = g->ld; sh.g = g; return sh;
 }
 
 // ---------------------------------------------------------------- small kernels
@@ -138,6 +139,10 @@ extern "C" void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g) {
 }
 extern "C" int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *sqsum_host) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (g->packed) {        // setup-time statistic: through a dense copy
+        sfg_geno *u = nullptr; SFG_TRY(sfg_geno_unpack(ctx, g, &u));
+        const int rc = sfg_geno_colsums(ctx, u, sum_host, sqsum_host); sfg_geno_free(ctx, u); return rc;
+    }
     SFG_TRY(sfg_ws_reserve(ctx, g->ncol * 16));
     double *ds = (double *)ctx->ws, *dq = ds + g->ncol;
     hipLaunchKernelGGL(k_colsums, dim3((unsigned)((g->ncol + 255) / 256)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, ds, dq);
@@ -223,6 +228,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
     SFG_TRY(sfg_scratch(ctx, "mm.pt", (size_t)G * nplain * L * prow * 8, (void **)&pt));
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
+    int8_t *unpacked = nullptr;
+    if (sh.g->packed) SFG_TRY(sfg_scratch(ctx, "mm.unpack", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&unpacked));
     if (dma) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
@@ -276,7 +283,11 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 const int bi = bg + g, nr = sh.rows_of(bi);
                 {
                     PhaseTimer t(ctx, "skew");
-                    rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
+                    if (sh.g->packed) {        // expand the stored block (rows x cols as stored) into the int8 staging block, then skew as usual
+                        const size_t sr0 = (size_t)(sh.transposed ? bj : bi) * SFG_SLOTS, sc0 = (size_t)(sh.transposed ? bi : bj) * SFG_SLOTS;
+                        rc = launch_geno_unpack(ctx, sh.g, sr0, sc0, sh.transposed ? nc : nr, sh.transposed ? nr : nc, unpacked, SFG_SLOTS);
+                        if (!rc) rc = launch_skew(ctx, unpacked, SFG_SLOTS, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
+                    } else rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
                     t.stop(1);
                 }
                 if (rc) break;

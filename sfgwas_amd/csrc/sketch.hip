@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(256) k_sketch(const int8_t *X, size_t nrow, si
 
 extern "C" int sfg_sketch(sfg_ctx *ctx, const sfg_geno *g, const int32_t *bucket_host, const int8_t *sgn_host, int kp,
                           double *sketch_host, uint64_t *xsum_host, uint64_t *x2sum_host) {
+    if (g->packed) { ctx->err = "sfg_sketch: 2-bit packed matrix (sketch before sfg_geno_pack, or sfg_geno_unpack first)"; return 1; }
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (kp < 1 || kp > 16) SFG_FAIL(ctx, "sfg_sketch: kp must be in 1..16 (one MFMA tile of buckets)");
     for (size_t i = 0; i < g->nrow; i++) if (bucket_host[i] < 0 || bucket_host[i] >= kp) SFG_FAIL(ctx, "sfg_sketch: bucket index out of range");
