@@ -35,6 +35,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
     c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
     if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
+    if (const char *e = env("SFG_ENC_BATCH")) { c.enc_batch = atoi(e); if (c.enc_batch < 64) c.enc_batch = 64; if (c.enc_batch > 8192) c.enc_batch = 8192; }
 }
 
 // copy the shared scalars / table pointers into the context (read-only mirrors: the launch code reads ctx->q, ctx->modc, ...)

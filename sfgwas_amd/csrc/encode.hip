@@ -445,7 +445,7 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask) {
     EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
-    const int BATCH = 2048;
+    const int BATCH = ctx->cfg.enc_batch;                 // plaintexts per FFT / NTT launch pair (SFG_ENC_BATCH)
     double *pc = nullptr;
     SFG_TRY(enc_pc_scratch(ctx, (size_t)(nshift < BATCH ? nshift : BATCH), &pc));
     for (int s0 = 0; s0 < nshift; s0 += BATCH) {
