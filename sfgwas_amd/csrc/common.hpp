@@ -51,6 +51,7 @@ struct SfgConfig {
     bool ntt_fwd_full = false;     // SFG_NTT_FWD_IMPL=full   one 512-thread workgroup per row for the general forward NTT (instead of two half-row workgroups)
     bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
+    size_t ksw_budget = 4ULL << 30; // SFG_KSW_BUDGET_MB      key-switch scratch per input group / job chunk: more jobs per chunk = more reuse of a key (64 MB: +45 %, 1.5 GB: +2 %, 12 GB: -2 %)
     int enc_batch = 1024;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 64 MB of coefficient rows stay cache resident between the two (measured 256..8192: 1024 is best, 2048 +2.5 %, 512 +4 %)
     bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)
 };

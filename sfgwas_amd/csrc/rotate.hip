@@ -214,10 +214,11 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
     const size_t ctw = (size_t)2 * nl * N;
     const int nr = (int)job_in.size();
     if (!nr) return 0;
-    // inputs are processed in groups whose decomposition fits ~1.5 GiB; jobs of a group in chunks whose acc/ext2 fit ~1.5 GiB
+    // inputs are processed in groups whose decomposition fits the budget (4 GiB by default); jobs of a group in chunks whose acc/ext2 fit it
     const size_t in_rows = (size_t)nl + (size_t)kc.beta * kc.nt, job_rows = 2 * (size_t)kc.nt + 2 * (size_t)nl;
-    int in_grp = (int)((3ULL << 29) / (in_rows * N * 8)); if (in_grp < 1) in_grp = 1; if (in_grp > nin) in_grp = nin;
-    int chunk = (int)((3ULL << 29) / (job_rows * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
+    const size_t budget = ctx->cfg.ksw_budget;                  // bytes of decomposition / accumulator scratch per group resp. chunk (SFG_KSW_BUDGET_MB)
+    int in_grp = (int)(budget / (in_rows * N * 8)); if (in_grp < 1) in_grp = 1; if (in_grp > nin) in_grp = nin;
+    int chunk = (int)(budget / (job_rows * N * 8)); if (chunk < 1) chunk = 1; if (chunk > nr) chunk = nr;
     const size_t ptr_bytes = (size_t)nr * (3 * sizeof(void *) + sizeof(int)) + 256;     // pointer tables for every job of a group
     // the forward NTTs run out of place (two half-row workgroups per row cannot share a buffer with their input): extT / ext2T receive the transforms
     const size_t ext_rows = (size_t)in_grp * kc.beta * kc.nt, ext2_rows = (size_t)chunk * 2 * nl;
