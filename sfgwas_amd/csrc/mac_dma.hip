@@ -17,9 +17,7 @@
 
 constexpr int DM_CL = 16, DM_CT = 3, DM_CG = 4, DM_WC = 2, DM_RG = 4, DM_RH = 8;
 constexpr int DM_ROWS = DM_RG * DM_RH;                 // 32 rows per pass
-constexpr int DM_COLS = DM_CG * DM_CT * DM_WC;         // 24 columns per workgroup
 constexpr int DM_KC = 4;
-constexpr int DM_THREADS = 512;
 
 struct DmaArgs {
     const double *rotf;          // fp64 rotation cache, see k_rot_to_f64
