@@ -15,7 +15,7 @@
 #include "kernels.hpp"
 #include <algorithm>
 
-constexpr int DM_CL = 16, DM_CT = 3, DM_CG = 4, DM_WC = 2, DM_RG = 4, DM_RH = 8;
+constexpr int DM_CL = 16, DM_CT = 3, DM_CG = 4, DM_RG = 4, DM_RH = 8;
 constexpr int DM_ROWS = DM_RG * DM_RH;                 // 32 rows per pass
 constexpr int DM_KC = 4;
 
