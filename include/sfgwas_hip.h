@@ -11,7 +11,8 @@
  *    sfg_last_error(ctx) describes the failure (the reference panics on this path — matmult.go:361,
  *    filestream.go:60 — so the Go shim turns non-zero into panic()).
  *  - Ring: N = 2^logN (logN = 14 for the PN14QP438 preset used by the reference, gwas.go:169),
- *    nq ciphertext primes q_0..q_{nq-1} followed by np special primes; all < 2^50 and == 1 mod 2N.
+ *    nq ciphertext primes q_0..q_{nq-1} followed by np special primes; all < 2^47 and == 1 mod 2N
+ *    (PN12..PN14 presets of gwas.go:164-177 in prime size; the 55-bit primes of PN15 / PN16 and logN != 14 are not supported).
  *  - Polynomial rows are N uint64 canonical residues in lattigo's NTT order
  *    (row[i] = p(psi^(2*bitrev(i)+1))); a ciphertext at level l is [2][l+1][N]
  *    (= ct.Value()[k].Coeffs[m][:] flattened, crypto.go:32-60).

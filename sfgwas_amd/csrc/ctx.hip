@@ -81,7 +81,7 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     std::vector<double> twf((size_t)sh->nmod * N), twi((size_t)sh->nmod * N);
     for (int m = 0; m < sh->nmod; m++) {
         u64 q = moduli[m];
-        if (q >= (1ULL << 50) || (q - 1) % (2ULL * N)) return fail("modulus must be < 2^50 and == 1 mod 2N");
+        if (q >= (1ULL << 47) || (q - 1) % (2ULL * N)) return fail("modulus must be < 2^47 (exact fp64 arithmetic: 14 lazy NTT stages stay below 2^51) and == 1 mod 2N");
         sh->q[m] = q;
         sh->psi[m] = psi ? psi[m] : derive_psi(q, logN);
         if (h_powmod(sh->psi[m], N, q) != q - 1) return fail("psi is not a primitive 2N-th root of unity");
