@@ -102,3 +102,30 @@ def test_mac_centred_operand_and_packed_limb_worst_case(env):
                 for half, sl in ((0, slice(0, N // 2)), (1, slice(N // 2, N))):
                     want = K * int(rot[0, r, l, 0]) * int(pt[0, n, l, 0 if half == 0 else N - 1]) % q
                     assert (got[n, r, l, sl] == want).all(), (l, r, n, half)
+
+
+def test_mac_with_a_47_bit_modulus():
+    """The Karatsuba middle term (r_lo + r_hi)(p_lo + p_hi) reaches 2.25 * 2^48 for q in [2^46, 2^47): the fold period must follow the actual modulus.
+    q0 just below 2^47, all operands q - 1 (and random ones), K spanning many fold periods, both MAC kernels' paths through sfg_mac_dev."""
+    from sfgwas_amd import capi
+    q47 = ol.small_primes(14, 47, 1)[0]
+    assert (1 << 46) <= q47 < (1 << 47)
+    moduli = [q47] + list(ol.Q_PN14[1:3])
+    ctx = capi.Context(moduli, ol.P_PN14)
+    K, R, Ncols, L, N = 240, 3, 2, 2, ctx.N
+    rnd = np.random.default_rng(47)
+    rot = rand_rows(rnd, (K, R), L, moduli, N)
+    pt = rand_rows(rnd, (K, Ncols), L, moduli, N)
+    rot[:, 0, 0, :] = q47 - 1; pt[:, 0, 0, :] = q47 - 1                   # worst case on (row 0, column 0) of the big modulus
+    rot[:, 1, 0, : N // 2] = (1 << 46) + (1 << 23) - 1                       # hi and lo halves both maximal
+    got = ctx.mac(rot, pt, L)
+    for l in range(L):
+        q = moduli[l]
+        for r in range(R):
+            for n in range(Ncols):
+                want = np.array([sum(int(a) * int(b) for a, b in zip(rot[:, r, l, x], pt[:, n, l, x])) % q for x in (0, 1, N // 2, N - 1)], dtype=object)
+                assert [int(v) for v in got[n, r, l, [0, 1, N // 2, N - 1]]] == list(want), (l, r, n)
+    # whole rows of the worst-case pair
+    want00 = (K * (q47 - 1) * (q47 - 1)) % q47
+    assert (got[0, 0, 0, :] == np.uint64(want00)).all()
+    ctx.close()
