@@ -159,7 +159,12 @@ def main():
 
     ctx = capi.Context(P.Q_PN14, P.P_PN14, device=local_rank)
     lib = capi.lib()
-    stream = torch.cuda.current_stream()
+    # One explicit (non-default) stream carries torch's tensor ops, the library's launches and - through torch.distributed's stream
+    # synchronisation - the RCCL collectives.  torch's DEFAULT stream has the handle 0, which sfg_ctx_set_stream reads as "use the context's own
+    # stream": the collectives would then not be ordered after the library's kernels.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream))
 
     def chk(rc, what):
