@@ -46,7 +46,8 @@ int sfg_ctx_fork(sfg_ctx *parent, sfg_ctx **out);
 void sfg_ctx_destroy(sfg_ctx *ctx);
 const char *sfg_last_error(const sfg_ctx *ctx);     /* ctx may be NULL: error of a failed sfg_ctx_create */
 int sfg_ctx_synchronize(sfg_ctx *ctx);
-/* run all subsequent work of this context on the given hipStream_t (NULL = the context's own stream) */
+/* run all subsequent work of this context on the given hipStream_t.  NULL selects the context's OWN (non-blocking) stream, not HIP's default stream:
+ * a caller that orders other work (RCCL collectives, torch ops) against the library must hand over an explicit stream, or call sfg_ctx_synchronize. */
 int sfg_ctx_set_stream(sfg_ctx *ctx, void *hip_stream);
 
 /* rotation key of one Galois element (cryptoParams.RotKs, crypto.go:50; generated at mhe.go:73, crypto.go:232-275).
