@@ -10,7 +10,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-struct FieldConst { uint32_t p[8]; uint32_t r2[8]; uint32_t n0inv; int nw; };
+struct FieldConst { uint32_t p[8]; uint32_t r2[8]; uint32_t n0inv; int nw; int pm_w, pm_s; uint32_t pm_c; };     // pm_*: p = 2^(32 pm_w + pm_s) - pm_c (pm_w < 0: not of that form)
 
 template <int NW>
 __device__ __forceinline__ void f_montmul(const uint32_t (&a)[NW], const uint32_t (&b)[NW], const FieldConst &f, uint32_t (&out)[NW]) {
@@ -76,7 +76,76 @@ __device__ __forceinline__ void f_store(uint64_t *p, size_t e, const uint32_t (&
     for (int k = 0; k < NW / 4; k++) q[k] = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
 }
 
-// BeaverMultElemMat (beavermult.go:112-133)
+// ---- pseudo-Mersenne moduli p = 2^B - c, c < 2^32 (both candidates for mpc-core's fields are: 2^127 - 1, 2^255 - 19): the whole share
+// expression a1*b1 + a2*b2 is formed as ONE double-width integer (2 NW^2 multiply-adds) and reduced by folding the part above 2^B back as c * H - three
+// folds of at most NW + 3 single-word products and one conditional subtraction - instead of two Montgomery products (4 NW^2) per field product.
+// Same canonical residues; the generic Montgomery path remains for any other odd modulus.  W = B / 32, s = B % 32.
+template <int NIN, int W, int NOUT>
+__device__ __forceinline__ void pm_fold(const uint32_t (&in)[NIN], int s, uint32_t c, uint32_t (&out)[NOUT]) {
+    constexpr int NH = NIN - W;                                        // words of H = in >> B
+    static_assert(NOUT >= W + 1, "fold output too narrow");
+    const uint32_t lowmask = s ? ((1u << s) - 1u) : 0u;
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < NOUT; k++) {
+        const uint32_t lo = k < W ? in[k] : (k == W ? in[W] & lowmask : 0u);
+        uint32_t h = 0;
+        if (k < NH) h = __funnelshift_r(in[W + k], W + k + 1 < NIN ? in[W + k + 1] : 0u, s);
+        const u64 v = (u64)h * c + lo + carry;
+        out[k] = (uint32_t)v; carry = v >> 32;
+    }
+}
+template <int NW, int W, bool TWO>
+__device__ __forceinline__ void f_mulsum_pm(const uint32_t (&a1)[NW], const uint32_t (&b1)[NW], const uint32_t (&a2)[NW], const uint32_t (&b2)[NW],
+                                            const FieldConst &f, uint32_t (&out)[NW]) {
+    uint32_t T[2 * NW + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * NW + 1; i++) T[i] = 0;
+#pragma unroll
+    for (int pass = 0; pass < (TWO ? 2 : 1); pass++) {
+        const uint32_t (&a)[NW] = pass ? a2 : a1; const uint32_t (&b)[NW] = pass ? b2 : b1;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            u64 c = 0;
+#pragma unroll
+            for (int j = 0; j < NW; j++) { const u64 v = (u64)a[j] * b[i] + T[i + j] + c; T[i + j] = (uint32_t)v; c = v >> 32; }
+#pragma unroll
+            for (int j = i + NW; j < 2 * NW + 1; j++) { const u64 v = (u64)T[j] + c; T[j] = (uint32_t)v; c = v >> 32; }
+        }
+    }
+    const int sh = f.pm_s; const uint32_t c = f.pm_c;
+    uint32_t S1[NW + 4], S2[W + 2], S3[W + 1];
+    pm_fold<2 * NW + 1, W, NW + 4>(T, sh, c, S1);                       // < 2^B + c 2^(32 (2 NW + 1) - B)
+    pm_fold<NW + 4, W, W + 2>(S1, sh, c, S2);                            // < 2^B + 2^(32 (NW + 4 - W) + 32)
+    pm_fold<W + 2, W, W + 1>(S2, sh, c, S3);                             // < 2^B <= p + c
+    uint32_t t[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) t[j] = j < W + 1 ? S3[j] : 0u;
+    bool ge = true;
+#pragma unroll
+    for (int j = NW - 1; j >= 0; j--) { if (t[j] != f.p[j]) { ge = t[j] > f.p[j]; break; } }
+    u64 br = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) { const u64 d = (u64)t[j] - (ge ? f.p[j] : 0) - br; out[j] = (uint32_t)d; br = (d >> 32) & 1; }
+}
+
+// BeaverMultElemMat (beavermult.go:112-133).  W >= 0 selects the pseudo-Mersenne reduction with B / 32 = W.
+template <int NW, int W>
+__global__ void __launch_bounds__(256) k_beaver_elem_pm(int pid, FieldConst f, const uint64_t *ar, const uint64_t *am, const uint64_t *br, const uint64_t *bm,
+                                                       uint64_t *out, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        uint32_t xam[NW], xbm[NW], o[NW];
+        f_load<NW>(am, e, xam); f_load<NW>(bm, e, xbm);
+        if (pid == 0) f_mulsum_pm<NW, W, false>(xam, xbm, xam, xbm, f, o);
+        else {
+            uint32_t xar[NW], xbr[NW], t[NW];
+            f_load<NW>(ar, e, xar); f_load<NW>(br, e, xbr);
+            if (pid == 1) { f_add<NW>(xbm, xbr, f, t); f_mulsum_pm<NW, W, true>(xar, t, xbr, xam, f, o); }      // ar*(bm + br) + br*am
+            else f_mulsum_pm<NW, W, true>(xar, xbm, xbr, xam, f, o);                                          // ar*bm + br*am
+        }
+        f_store<NW>(out, e, o);
+    }
+}
 template <int NW>
 __global__ void __launch_bounds__(256) k_beaver_elem(int pid, FieldConst f, const uint64_t *ar, const uint64_t *am, const uint64_t *br, const uint64_t *bm,
                                                     uint64_t *out, size_t n) {
@@ -138,6 +207,14 @@ static int field_setup(sfg_ctx *ctx, int limbs, const uint64_t *mod, FieldConst 
         if (ge(x)) { u64 br = 0; for (int j = 0; j <= nw; j++) { u64 d = (u64)x[j] - (j < nw ? f.p[j] : 0) - br; x[j] = (uint32_t)d; br = (d >> 32) & 1; } }
     }
     for (int j = 0; j < nw; j++) f.r2[j] = x[j];
+    // p = 2^B - c with c < 2^32 and the top word in use?  (c = 2^B - p: every word above the lowest must be all ones up to bit B)
+    f.pm_w = -1; f.pm_s = 0; f.pm_c = 0;
+    if (f.p[nw - 1]) {
+        int B = 32 * nw; while (!((f.p[(B - 1) / 32] >> ((B - 1) % 32)) & 1)) B--;
+        bool ones = true;
+        for (int b = 32; b < B && ones; b++) ones = (f.p[b / 32] >> (b % 32)) & 1;
+        if (ones && B > 32 * (nw - 1)) { f.pm_w = B / 32; f.pm_s = B % 32; f.pm_c = (uint32_t)(0u - f.p[0]); }
+    }
     return 0;
 }
 
@@ -147,8 +224,13 @@ extern "C" int sfg_beaver_elem_dev(sfg_ctx *ctx, int pid, int limbs, const uint6
     if (!n) return 0;
     FieldConst f; SFG_TRY(field_setup(ctx, limbs, mod, f));
     size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
-    if (limbs == 2) hipLaunchKernelGGL(k_beaver_elem<4>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
-    else hipLaunchKernelGGL(k_beaver_elem<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
+    const dim3 g((unsigned)blocks), b(256);
+    if (limbs == 2 && f.pm_w == 3) hipLaunchKernelGGL((k_beaver_elem_pm<4, 3>), g, b, 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
+    else if (limbs == 2 && f.pm_w == 4) hipLaunchKernelGGL((k_beaver_elem_pm<4, 4>), g, b, 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
+    else if (limbs == 4 && f.pm_w == 7) hipLaunchKernelGGL((k_beaver_elem_pm<8, 7>), g, b, 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
+    else if (limbs == 4 && f.pm_w == 8) hipLaunchKernelGGL((k_beaver_elem_pm<8, 8>), g, b, 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
+    else if (limbs == 2) hipLaunchKernelGGL(k_beaver_elem<4>, g, b, 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
+    else hipLaunchKernelGGL(k_beaver_elem<8>, g, b, 0, ctx->stream, pid, f, ar, am, br, bm, out, n);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -22,7 +22,9 @@ def _limbs(x, n):
     return [(x >> (64 * i)) & ((1 << 64) - 1) for i in range(n)]
 
 
-@pytest.mark.parametrize("limbs,p", [(2, (1 << 127) - 1), (4, (1 << 255) - 19), (2, (1 << 128) - 159)])
+@pytest.mark.parametrize("limbs,p", [(2, (1 << 127) - 1), (4, (1 << 255) - 19), (2, (1 << 128) - 159), (4, (1 << 256) - 189),           # pseudo-Mersenne: folded reduction
+                                     (2, 0xC3A5C85C97CB3127B492B66FBE98F273), (4, 0x9E3779B97F4A7C15F39CC0605CEDC8341082276BF3A27251F86C6A11D0C18E95),  # generic odd moduli: Montgomery path
+                                     (2, (1 << 127) - (1 << 40) - 1)])                                                                     # 2^127 - c with c >= 2^32: not the folded form
 @pytest.mark.parametrize("pid", [0, 1, 2])
 def test_beaver_elem_matches_oracle_and_bigint(ctx, limbs, p, pid):
     from sfgwas_amd import capi
