@@ -165,11 +165,15 @@ struct PhaseTimer {
     ~PhaseTimer() { stop(0); }
 };
 
-// packed-limb plaintext word of a canonical residue w < 2^36 (see mac_dma.hip): three 16-bit fields 0xB000 | 12-bit limb
-constexpr u64 PACKED_ZERO = 0x0000B000B000B000ULL;
+// Packed-limb plaintext word of a canonical residue w = x0 + x1 2^12 + x2 2^24 < 2^36 (the broadcast MAC's panel format): the three 12-bit limbs in
+// 16-bit fields.  Framed by a zero byte above and below, a field IS the high dword of the SUBNORMAL double x * 2^-1034 (exponent field 0, x in mantissa
+// bits 51..40), so the MAC turns a limb into an FMA operand with one v_perm_b32 and nothing to undo: products with the integer rot operand are exact
+// multiples of 2^-1034, sums stay exact below 2^53 * 2^-1034, and two multiplications by 2^517 bring a sum back (fp64 subnormals run at full rate:
+// tools/ubench_dpp.hip).  Zero is the all-zero word.
+constexpr u64 PACKED_ZERO = 0ULL;
 #ifdef __HIPCC__
 __device__ __host__ __forceinline__ u64 pack_limbs(u64 w) {
-    return (0xB000ULL | (w & 0xFFF)) | ((0xB000ULL | ((w >> 12) & 0xFFF)) << 16) | ((0xB000ULL | (w >> 24)) << 32);
+    return (w & 0xFFF) | (((w >> 12) & 0xFFF) << 16) | ((w >> 24) << 32);
 }
 // ---------------------------------------------------------------- device arithmetic
 // All ring arithmetic on the device is done on exact integers held in fp64 registers (|x| < 2^53):
@@ -212,12 +216,12 @@ __device__ __forceinline__ double u64_to_f64(u64 x) {            // exact for x 
 __device__ __forceinline__ u64 f64_to_u64(double x) {            // exact for integer 0 <= x < 2^52
     return (u64)__double_as_longlong(x + 4503599627370496.0) & 0x000FFFFFFFFFFFFFULL;
 }
-// packed-limb word (pack_limbs) of an integer-valued double 0 <= x < 2^36 straight from the bits of x + 2^52: 1 fp add + 5 integer ops
+// packed-limb word (pack_limbs) of an integer-valued double 0 <= x < 2^36 straight from the bits of x + 2^52: 1 fp add + 4 integer ops
 __device__ __forceinline__ u64 pack_limbs_f64(double x) {
     const u64 b = (u64)__double_as_longlong(x + 4503599627370496.0);
     const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-    const unsigned x01 = (((lo << 4) & 0x0FFF0000u) | ((lo & 0xFFFu) | 0xB000B000u));
-    const unsigned x2 = (__builtin_amdgcn_alignbit(hi, lo, 24) & 0xFFFu) | 0xB000u;
+    const unsigned x01 = ((lo << 4) & 0x0FFF0000u) | (lo & 0xFFFu);
+    const unsigned x2 = __builtin_amdgcn_alignbit(hi, lo, 24) & 0xFFFu;
     return ((u64)x2 << 32) | x01;
 }
 __device__ __forceinline__ u64 d_mulmod_u64(u64 a, u64 b, u64 q) { // generic (slow) path for setup kernels

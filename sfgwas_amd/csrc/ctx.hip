@@ -125,7 +125,7 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
         hipMemcpy(sh->modc, sh->modc_host, sizeof(ModConst) * SFG_MAXMOD, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(sh->zeros_dev, 0, 512) != hipSuccess) return fail("table upload failed");
     {   // second 256 B: zero plaintext words in the packed-limb format (mac_dma.hip PACKED_ZERO)
-        u64 pz[32]; for (int i = 0; i < 32; i++) pz[i] = 0x0000B000B000B000ULL;
+        u64 pz[32]; for (int i = 0; i < 32; i++) pz[i] = PACKED_ZERO;
         if (hipMemcpy((char *)sh->zeros_dev + 256, pz, 256, hipMemcpyHostToDevice) != hipSuccess) return fail("table upload failed");
     }
     ctx_bind_shared(ctx, sh);

@@ -32,7 +32,7 @@ constexpr int BC_SROWS = 32;       // rot rows staged per k-step (rows past R ar
 constexpr int BC_MAXROWS = 30;     // rows per pass (s = 15 ciphertexts x 2 polynomials)
 
 struct BcArgs {
-    const double *rotf; const u64 *pt; u64 *out; const u64 *zeros; const double *rotsum;
+    const double *rotf; const u64 *pt; u64 *out; const u64 *zeros;
     size_t rotf_k_stride, rotf_r_stride;     // doubles
     size_t pt_k_stride, pt_n_stride, pt_l_stride;   // words
     size_t out_n_stride, out_r_stride;       // words
@@ -185,10 +185,12 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
         if (BIG) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"((O).ra), "+v"((O).rb), "+v"((O).p) : "n"(NOUT) : "memory"); \
         else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"((O).ra), "+v"((O).p) : "n"(NOUT) : "memory"); \
     } while (0)
-    // small moduli: the limb doubles 4096 + x_k live in registers; a k-step rewrites only their HIGH dwords (one v_perm_b32 each)
+    // small moduli: the (subnormal) limb doubles x_k * 2^-1034 live in registers; a k-step rewrites only their HIGH dwords (one v_perm_b32 each), and the
+    // accumulators are exact multiples of 2^-1034: the periodic fold uses q and 1/q scaled accordingly (both normal numbers)
     double pl[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); pl[k] = __hiloint2double(0, z); }
+    const double qf = BIG ? q : (q * 0x1p-517) * 0x1p-517, qfinv = BIG ? qinv : (qinv * 0x1p517) * 0x1p517;
     constexpr auto rows = std::make_integer_sequence<int, ROWS>{};
     auto fmas = [&](const Opd &o) {
 #ifdef SFG_MAC_DIAG
@@ -203,9 +205,9 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
             bc_rows<0>(acc, o.ra.x, o.rb.x, p0, rows); bc_rows<2>(acc, o.ra.y, o.rb.y, p1, rows); bc_rows<1>(acc, sa, sb, p2, rows);
         } else {
             const unsigned plo = (unsigned)o.p, phi = (unsigned)(o.p >> 32);
-            pl[0] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0005040Cu), __double2loint(pl[0]));      // 4096 + x0
-            pl[1] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0007060Cu), __double2loint(pl[1]));      // 4096 + x1
-            pl[2] = __hiloint2double((int)__builtin_amdgcn_perm(phi, 0x40404040u, 0x0005040Cu), __double2loint(pl[2]));      // 4096 + x2
+            pl[0] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0u, 0x0C05040Cu), __double2loint(pl[0]));      // x0 * 2^-1034: high dword 00 | x0 | 00
+            pl[1] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0u, 0x0C07060Cu), __double2loint(pl[1]));      // x1 * 2^-1034
+            pl[2] = __hiloint2double((int)__builtin_amdgcn_perm(phi, 0u, 0x0C05040Cu), __double2loint(pl[2]));      // x2 * 2^-1034
             asm volatile("s_nop 1" : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]));       // DPP hazard barrier, as above
             bc_rows<0>(acc, o.ra.x, o.ra.y, pl[0], rows); bc_rows<1>(acc, o.ra.x, o.ra.y, pl[1], rows); bc_rows<2>(acc, o.ra.x, o.ra.y, pl[2], rows);
         }
@@ -256,42 +258,42 @@ __global__ void __launch_bounds__(64 * BC_WAVES, 2) k_mac_bc(BcArgs a, const Mod
         if (since_flush >= a.flush) {
             since_flush = 0;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) { acc[r][0] = pred(acc[r][0], q, qinv); acc[r][1] = pred(acc[r][1], q, qinv); acc[r][2] = pred(acc[r][2], q, qinv); }
+            for (int r = 0; r < ROWS; r++) { acc[r][0] = pred(acc[r][0], qf, qfinv); acc[r][1] = pred(acc[r][1], qf, qfinv); acc[r][2] = pred(acc[r][2], qf, qfinv); }
         }
     }
 #undef BC_FETCH
 #undef BC_WAIT
-    // ---- epilogue: limb recombination, bias removal (packed limbs carry 4096 * sum_k rot[k][row] each), canonical store
+    // ---- epilogue: limb recombination, canonical store
     constexpr double S1 = BIG ? 8388608.0 : 4096.0;
     const double s1 = S1, s1q = S1 / q;
     const double s2 = canon(S1 * S1, q, qinv), s2q = s2 / q;
     const int n = tile * BC_COLS + cgp * 16 + i;
     const int nclamp = n < a.Ncols ? n : a.Ncols - 1;
     u64 *ocol = a.out + (size_t)nclamp * a.out_n_stride + (size_t)l * N + c0 + cc;
-    const double *rs = BIG ? nullptr : a.rotsum + (size_t)(a.plane0 + li) * N + c0 + cc;
     constexpr int HALF = (ROWS + 1) / 2;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        // all previous-value and bias loads of a half first (one wait), from clamped (always valid) addresses
-        u64 oldv[HALF]; double bias[HALF];
+        // all previous-value loads of a half first (one wait), from clamped (always valid) addresses
+        u64 oldv[HALF];
 #pragma unroll
         for (int x = 0; x < HALF; x++) {
             const int r = h * HALF + x;
             const int row = a.r0 + r < a.R ? a.r0 + r : a.R - 1;
             oldv[x] = a.accumulate ? ocol[(size_t)row * a.out_r_stride] : 0ULL;
-            bias[x] = BIG ? 0.0 : rs[(size_t)row * a.rotf_r_stride];
         }
 #pragma unroll
         for (int x = 0; x < HALF; x++) {
             const int r = h * HALF + x;
             if (r >= ROWS) continue;
             const int row = a.r0 + r;
-            const double b = BIG ? 0.0 : pred(bias[x], q, qinv) * 4096.0;
-            const double a0 = pred(acc[r][0], q, qinv), a1 = pred(acc[r][1], q, qinv), a2 = pred(acc[r][2], q, qinv);
-            double v = a0 - b;
-            const double mid = BIG ? a1 - a0 - a2 : a1 - b;
+            // small moduli: the sums are multiples of 2^-1034 (< 2^53 of them): two exact scalings give the integers back
+            const double i0 = BIG ? acc[r][0] : (acc[r][0] * 0x1p517) * 0x1p517, i1 = BIG ? acc[r][1] : (acc[r][1] * 0x1p517) * 0x1p517,
+                         i2 = BIG ? acc[r][2] : (acc[r][2] * 0x1p517) * 0x1p517;
+            const double a0 = pred(i0, q, qinv), a1 = pred(i1, q, qinv), a2 = pred(i2, q, qinv);
+            double v = a0;
+            const double mid = BIG ? a1 - a0 - a2 : a1;
             v += mulmod_lazy(mid, s1, s1q, q);
-            v += mulmod_lazy(a2 - b, s2, s2q, q);
+            v += mulmod_lazy(a2, s2, s2q, q);
             v += u64_to_f64(oldv[x] & 0x000FFFFFFFFFFFFFULL);
             if (n < a.Ncols && row < a.R) ocol[(size_t)row * a.out_r_stride] = f64_to_u64(canon(v, q, qinv));
         }
@@ -325,8 +327,8 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
         int l = 0;
         while (l < L) {
             const bool big = is_big[l]; int e = l; while (e < L && is_big[e] == (int)big) e++;
-            if (!big && !(st.pt_packed && rotsum)) SFG_FAIL(ctx, "sfg_mac: the broadcast MAC needs packed-limb plaintext rows and the rot sums for the small moduli");
-            BcArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev(); a.rotsum = rotsum;
+            if (!big && !st.pt_packed) SFG_FAIL(ctx, "sfg_mac: the broadcast MAC needs packed-limb plaintext rows for the small moduli");
+            BcArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev();
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = st.pt_half ? N / 2 : N; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
             a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l]; a.pt_half = st.pt_half ? 1 : 0;
@@ -334,10 +336,10 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
                 const double rot_max = (3.0 * (double)a.rotf_k_stride + (double)R * (double)a.rotf_r_stride) * 8.0 + 512.0;
                 if (rot_max >= 4294967296.0) SFG_FAIL(ctx, "sfg_mac: operand strides exceed the 32-bit lane offsets of the DMA addressing (R = %d)", R);
             }
-            // largest single term of a run (see launch_mac_dma): small moduli q * 2^12 (centred rot x biased 13-bit limb), big ones the Karatsuba middle term
+            // largest single term of a run (in units of 2^-1034 for the small moduli): q / 2 * 2^12 (centred rot x 12-bit limb), big ones the Karatsuba middle term
             double maxterm = 0.0;
             for (int t = l; t < e; t++) {
-                const double m = big ? (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) * (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) : (double)ctx->q[t] * 4096.0;
+                const double m = big ? (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) * (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) : (double)ctx->q[t] * 2048.0;
                 if (m > maxterm) maxterm = m;
             }
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / BC_KC) * BC_KC;

@@ -30,16 +30,10 @@ struct DmaArgs {
     int plane0;                  // fp64 plane index of modulus l0 inside a rotf row
     int pt_half;                 // pt rows hold N/2 words: P[N-1-c] = P[c] (plaintexts of real slot vectors)
     size_t pt_l_stride;          // words between consecutive modulus rows of one plaintext (N or N/2)
-    const double *rotsum;        // PACKED only: [R][row stride rotf_r_stride] sum over k < K of the (centred) rot operand
 };
 
-// Packed-limb plaintext words (small moduli, q < 2^36).  A canonical residue w = x0 + x1 2^12 + x2 2^24 is stored as three 16-bit
-// fields h_k = 0xB000 | x_k.  Prefixed with the byte 0x40 and suffixed with a zero byte, a field IS the high dword of the double
-// 4096 + x_k (exponent 0x40B, x_k in the top 12 mantissa bits), so one v_perm_b32 per limb replaces the shift/mask/v_cvt_f64_u32
-// chain.  The sums then carry 4096 * sum_k rot[k] per limb, which the epilogue removes with the precomputed rotsum.  The rot
-// operand is centred to (-q/2, q/2] so a term stays below q * 2^12 and the flush period is unchanged.
-// (PACKED_ZERO / pack_limbs live in common.hpp: the plaintext NTT writes the format)
-
+// Packed-limb plaintext words (small moduli, q < 2^36) are the panel format of the DPP-broadcast kernel (mac_bc.hip; pack_limbs in common.hpp): this
+// kernel, kept as the SFG_MAC_IMPL=dma baseline, reads plain canonical words and converts limbs with shift / mask / v_cvt_f64_u32.
 
 // one 16-byte-per-lane LDS-DMA; lds_base must be wave-uniform (it goes to M0)
 __device__ __forceinline__ void dma16(const void *gsrc, void *lds_base) {
@@ -58,9 +52,8 @@ template <bool BIG, int WC_> struct MacRing {
 template <int WC_> struct MacGeom {
     static constexpr int WAVES = 4 * WC_, THREADS = 64 * WAVES, COLS = DM_CG * DM_CT * WC_;
 };
-template <bool BIG, int WC_, bool PACKED = false>
+template <bool BIG, int WC_>
 __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const ModConst *modc) {
-    static_assert(!(BIG && PACKED), "the packed-limb panel format exists for the small moduli only");
     constexpr int DM_COLS = MacGeom<WC_>::COLS, NWAVE = MacGeom<WC_>::WAVES;      // shadow the file-scope 2-wave-column geometry
     constexpr int RW = BIG ? 2 : 1;                                  // doubles per rot word
     constexpr int R_BYTES = DM_KC * DM_ROWS * DM_CL * 8 * RW;        // 16 KiB / 32 KiB
@@ -135,7 +128,7 @@ __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const Mo
             kk_of[t] = kk;
         }
     }
-    const unsigned zoff = (PACKED ? 256u : 0u) + (unsigned)piece * 16u;       // zero plaintext words (packed zeros at +256 B)
+    const unsigned zoff = (unsigned)piece * 16u;                      // zero plaintext words
     const int nchunk_full = a.K / DM_KC;                              // chunks whose 4 k-steps all exist
     // In the ragged last chunk (K % 4 != 0) the padded k-steps take a zero plaintext; the rot operand is read as is - the caller
     // guarantees that the (up to 3) k-slices after the last hold finite doubles (launch_mac_dma contract).
@@ -165,16 +158,6 @@ __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const Mo
 #pragma unroll
     for (int ch = 0; ch < DEPTH - 1; ch++) if (ch < nchunk) issue_chunk(ch);
 
-    // PACKED: the limb doubles live in registers for the whole kernel; a k-step rewrites only their HIGH dwords (one v_perm_b32 each).
-    // The low dwords are zeros the compiler cannot see through (else it re-materialises them with a v_mov per limb and k-step).
-    double pl[3][DM_CT];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int t = 0; t < DM_CT; t++) {
-            if (PACKED) { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); pl[k][t] = __hiloint2double(0, z); }
-            else pl[k][t] = 0.0;
-        }
     int since_flush = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ch++) {
@@ -206,13 +189,7 @@ __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const Mo
             for (int t = 0; t < DM_CT; t++) {
                 const u64 p = pp[t];
                 if (BIG) { p0[t] = (double)(unsigned)(p & 0x7FFFFFu); p1[t] = (double)(unsigned)(p >> 23); p2[t] = p0[t] + p1[t]; }   // Karatsuba: p2 = p_lo + p_hi
-                else if (PACKED) {
-                    const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
-                    pl[0][t] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0005040Cu), __double2loint(pl[0][t]));      // 4096 + x0
-                    pl[1][t] = __hiloint2double((int)__builtin_amdgcn_perm(plo, 0x40404040u, 0x0007060Cu), __double2loint(pl[1][t]));      // 4096 + x1
-                    pl[2][t] = __hiloint2double((int)__builtin_amdgcn_perm(phi, 0x40404040u, 0x0005040Cu), __double2loint(pl[2][t]));      // 4096 + x2
-                    p0[t] = pl[0][t]; p1[t] = pl[1][t]; p2[t] = pl[2][t];
-                } else {
+                else {
                     const unsigned plo = (unsigned)p, phi = (unsigned)(p >> 32);
                     p0[t] = (double)(plo & 0xFFFu); p1[t] = (double)((plo >> 12) & 0xFFFu); p2[t] = (double)((plo >> 24) | (phi << 8));
                 }
@@ -257,14 +234,6 @@ __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const Mo
     // epilogue: all previous-value loads are issued first (one wait), then the tile is reduced and stored;
     // a load->add->store chain per element would serialize 24 HBM round trips per thread
     u64 oldv[DM_RH][DM_CT];
-    double bias[DM_RH];                    // PACKED: every limb sum carries 4096 * sum_k rot[k][row]  (mod q: (-q, q) * 2^12 < 2^48)
-#pragma unroll
-    for (int r = 0; r < DM_RH; r++) {
-        if (PACKED) {
-            const int row = a.r0 + rh * DM_RH + r < a.R ? a.r0 + rh * DM_RH + r : a.R - 1;
-            bias[r] = pred(a.rotsum[(size_t)row * a.rotf_r_stride + (size_t)(a.plane0 + li) * N + c0 + cc], q, qinv) * 4096.0;
-        } else bias[r] = 0.0;
-    }
 #pragma unroll
     for (int t = 0; t < DM_CT; t++)
 #pragma unroll
@@ -281,10 +250,10 @@ __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const Mo
 #pragma unroll
         for (int r = 0; r < DM_RH; r++) {
             const int row = a.r0 + rh * DM_RH + r;
-            double x = pred(acc[r][t][0], q, qinv) - bias[r];
-            const double mid = BIG ? pred(acc[r][t][1], q, qinv) - pred(acc[r][t][0], q, qinv) - pred(acc[r][t][2], q, qinv) : pred(acc[r][t][1], q, qinv) - bias[r];
+            double x = pred(acc[r][t][0], q, qinv);
+            const double mid = BIG ? pred(acc[r][t][1], q, qinv) - pred(acc[r][t][0], q, qinv) - pred(acc[r][t][2], q, qinv) : pred(acc[r][t][1], q, qinv);
             x += mulmod_lazy(mid, s1, s1q, q);
-            x += mulmod_lazy(pred(acc[r][t][2], q, qinv) - bias[r], s2, s2q, q);
+            x += mulmod_lazy(pred(acc[r][t][2], q, qinv), s2, s2q, q);
             x += a.accumulate ? u64_to_f64(oldv[r][t] & 0x000FFFFFFFFFFFFFULL) : 0.0;
             if (n < a.Ncols && row < a.R)
                 a.out[(size_t)n * a.out_n_stride + (size_t)row * a.out_r_stride + (size_t)l * N + c0 + cc] = f64_to_u64(canon(x, q, qinv));
@@ -309,17 +278,6 @@ __global__ void __launch_bounds__(256) k_rot_to_f64(const u64 *in, double *out, 
         o[x] = (centre && w > (q >> 1)) ? -u64_to_f64(q - w) : u64_to_f64(w);
     }
 }
-// rotsum[row][x] = sum_{k < K} rotf[k][row][x] over a whole rotf row (all planes; only the small-modulus planes are used).
-// |sum| < K * 2^35: exact in fp64.
-__global__ void __launch_bounds__(256) k_rot_sum(const double *rotf, size_t k_stride, size_t row_stride, int K, double *out) {
-    const size_t row = blockIdx.y, x = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (x >= row_stride) return;
-    const double *p = rotf + row * row_stride + x;
-    double s0 = 0.0, s1 = 0.0; int k = 0;
-    for (; k + 1 < K; k += 2) { s0 += p[(size_t)k * k_stride]; s1 += p[(size_t)(k + 1) * k_stride]; }
-    if (k < K) s0 += p[(size_t)k * k_stride];
-    out[row * row_stride + x] = s0 + s1;
-}
 // plain canonical words -> packed-limb words for the small-modulus rows of a plaintext array [nrows = (k, n, l)][words]
 __global__ void __launch_bounds__(256) k_pack_pt(const u64 *in, u64 *out, size_t words_per_row, int L, unsigned packed_mask) {
     const size_t row = blockIdx.y, x = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -331,17 +289,14 @@ __global__ void __launch_bounds__(256) k_pack_pt(const u64 *in, u64 *out, size_t
 int mac_dma_set_attrs(sfg_ctx *ctx) {
     constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
     auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
-    auto ks2p = k_mac_dma<false, 2, true>; auto ks1p = k_mac_dma<false, 1, true>;
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s2));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b2));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s1));
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks2p, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s2));
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks1p, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s1));
     return 0;
 }
-// bit l set: the plaintext rows of modulus l use the packed-limb format (small moduli, unless SFG_MAC_PT=plain)
+// bit l set: the plaintext rows of modulus l use the packed-limb format (small moduli with the default broadcast kernel; not with SFG_MAC_PT=plain / SFG_MAC_IMPL=dma|reg)
 unsigned mac_dma_packed_mask(sfg_ctx *ctx, int L) {
-    if (ctx->cfg.mac_plain_pt || ctx->cfg.mac_reg) return 0u;
+    if (ctx->cfg.mac_plain_pt || ctx->cfg.mac_reg || !ctx->cfg.mac_bc) return 0u;       // the packed format is the broadcast kernel's
     unsigned m = 0; for (int l = 0; l < L; l++) if (ctx->q[l] < (1ULL << 36)) m |= 1u << l;
     return m;
 }
@@ -374,18 +329,8 @@ int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, in
     return 0;
 }
 
-// rotsum[row][nplanes*N] = sum over the k-slices of rotf the MAC kernel touches (rows_per_k rows per slice): the kernel runs
-// 4 k-steps per chunk, and in the ragged last chunk the padded k-steps multiply whatever the slices K..4*ceil(K/4)-1 hold by the
-// packed zero word (= 4096 per limb), so those slices belong to the bias as well
-int launch_rot_sum(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, int K, int L, double *rotsum) {
-    K = (K + DM_KC - 1) / DM_KC * DM_KC;
-    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
-    if (nplanes < 0) return 1;
-    const size_t rowf = (size_t)nplanes * SFG_N;
-    hipLaunchKernelGGL(k_rot_sum, dim3((unsigned)((rowf + 255) / 256), (unsigned)rows_per_k), dim3(256), 0, ctx->stream, rotf, rows_per_k * rowf, rowf, K, rotsum);
-    SFG_HIP(ctx, hipGetLastError());
-    return 0;
-}
+// (kept for the call sites: the bias-free packed limbs of round 2 need no rot sums any more)
+int launch_rot_sum(sfg_ctx *, const double *, size_t, int, int, double *) { return 0; }
 int launch_pack_pt(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, size_t words_per_row, int L, unsigned packed_mask) {
     if (!nrows) return 0;
     if (nrows > 65535u * 1024u) SFG_FAIL(ctx, "pack_pt: too many rows");
@@ -399,12 +344,11 @@ int launch_pack_pt(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, size_t w
 }
 
 // rotf: fp64 rotation cache with row stride nplanes*N doubles; rows_per_k = rows (ct, poly) between consecutive k.
-// st.pt_packed: the small-modulus plaintext rows hold packed-limb words, rotf is centred and rotsum (launch_rot_sum) is given.
+// st.pt_packed: the small-modulus plaintext rows hold packed-limb words and rotf is centred (broadcast kernel only).
 // Contract: when K % 4 != 0 the buffer must extend over the k-slices K .. 4*ceil(K/4)-1 and hold finite doubles there
 // (they are multiplied by zero plaintexts).
 int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate,
                    const MacStrides &st, const double *rotsum) {
-    if (st.pt_packed && !rotsum) SFG_FAIL(ctx, "sfg_mac: packed plaintext panel without the rot sums");
     if (ctx->cfg.mac_bc && (st.pt_packed || mac_dma_packed_mask(ctx, L) == 0) && !ctx->cfg.mac_plain_pt)      // default: the DPP-broadcast kernel (mac_bc.hip)
         return launch_mac_bc(ctx, rotf, rows_per_k, pt, out, K, R, Ncols, L, accumulate, st, rotsum);
     const int N = SFG_N;
@@ -420,8 +364,8 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
             a.K = K; a.R = R; a.Ncols = Ncols; a.L = L; a.accumulate = accumulate; a.r0 = r0; a.l0 = l; a.nl = e - l; a.plane0 = plane_of[l];
-            a.pt_half = st.pt_half ? 1 : 0; a.pt_l_stride = st.pt_half ? N / 2 : N; a.rotsum = rotsum;
-            const bool packed = st.pt_packed && !big;
+            a.pt_half = st.pt_half ? 1 : 0; a.pt_l_stride = st.pt_half ? N / 2 : N;
+            if (st.pt_packed) SFG_FAIL(ctx, "sfg_mac: the LDS-DMA baseline kernel reads plain plaintext words");
             {   // the kernel addresses its operands as uniform base + 32-bit per-lane byte offset
                 const double rot_max = (3.0 * (double)a.rotf_k_stride + (double)R * (double)a.rotf_r_stride) * 8.0 + 512.0;
                 if (rot_max >= 4294967296.0) SFG_FAIL(ctx, "sfg_mac: operand strides exceed the 32-bit lane offsets of the DMA addressing (R = %d)", R);
@@ -441,10 +385,9 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
             PhaseTimer t(ctx, big ? "mac_big" : "mac_small");
             constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
             auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
-            auto ks2p = k_mac_dma<false, 2, true>; auto ks1p = k_mac_dma<false, 1, true>;
-            if (big) hipLaunchKernelGGL(kb2, grid, dim3(512), lds_b2, ctx->stream, a, ctx->modc);
-            else if (wcs == 2) hipLaunchKernelGGL(packed ? ks2p : ks2, grid, dim3(512), lds_s2, ctx->stream, a, ctx->modc);
-            else hipLaunchKernelGGL(packed ? ks1p : ks1, grid, dim3(256), lds_s1, ctx->stream, a, ctx->modc);
+                    if (big) hipLaunchKernelGGL(kb2, grid, dim3(512), lds_b2, ctx->stream, a, ctx->modc);
+            else if (wcs == 2) hipLaunchKernelGGL(ks2, grid, dim3(512), lds_s2, ctx->stream, a, ctx->modc);
+            else hipLaunchKernelGGL(ks1, grid, dim3(256), lds_s1, ctx->stream, a, ctx->modc);
             SFG_HIP(ctx, hipGetLastError());
             {   // algorithmic bytes of this launch: fp64 rot operand + plaintext words + accumulators written (and read when accumulating)
                 const double nlm = (double)(e - l), rw = big ? 2.0 : 1.0, pw = st.pt_half ? 0.5 : 1.0;

@@ -23,9 +23,17 @@ __global__ void k_sem(double *out, const double *in) {
     out[threadIdx.x] = acc;          // expect in[(lane & ~15) + 5]
 }
 
+// subnormal multiplier semantics: the double with exponent field 0 and mantissa bits 51..40 = x is x * 2^-1034; products with integers stay exact and
+// two multiplications by 2^517 bring the sum back
+__global__ void k_subnormal(double *out) {
+    const unsigned x = 0xABC + threadIdx.x;
+    double lim = __hiloint2double((int)(x << 8), 0), acc = 0.0, r = 12345678901.0 + threadIdx.x;
+    for (int k = 0; k < 100; k++) acc = __builtin_fma(r, lim, acc);
+    out[threadIdx.x] = (acc * 0x1p517) * 0x1p517 - 100.0 * r * (double)x;          // expect 0
+}
 template <int DPP>
 __global__ void __launch_bounds__(512, 2) k_reg(double *out, int iters, double seed) {
-    double a0[15][3], a1[15][3], ra = seed + threadIdx.x, rb = seed * 3 + threadIdx.x, p[3] = {seed, seed + 1, seed + 2};
+    double a0[15][3], a1[15][3], ra = seed + threadIdx.x, rb = seed * 3 + threadIdx.x, p[3] = {seed, seed < 1e-300 ? seed * 2 : seed + 1, seed < 1e-300 ? seed * 3 : seed + 2};
     for (int r = 0; r < 15; r++) for (int l = 0; l < 3; l++) a0[r][l] = a1[r][l] = 0.0;
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
@@ -96,6 +104,17 @@ template <class K> void run(const char *name, K kern, int nblk, int threads, siz
     printf("%-60s blocks=%d x %d  %.3f ms  %.3e FMA/s  %.2f lanes/clk/SIMD@2.4GHz\n", name, nblk, threads, ms, fma / (ms * 1e-3), fma / (ms * 1e-3) / (1024 * 2.4e9));
     (void)hipFree(out);
 }
+template <class K> void run_seed(const char *name, K kern, int nblk, int threads, size_t ldsb, double seed) {
+    double *out; (void)hipMalloc(&out, (size_t)nblk * threads * 8);
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(threads), ldsb, 0, out, 100, seed);
+    (void)hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(nblk), dim3(threads), ldsb, 0, out, iters, seed); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double fma = (double)nblk * threads * 90.0 * iters, h; (void)hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
+    printf("%-60s blocks=%d x %d  %.3f ms  %.3e FMA/s  %.2f lanes/clk/SIMD@2.4GHz   (sample result %.6g)\n", name, nblk, threads, ms, fma / (ms * 1e-3), fma / (ms * 1e-3) / (1024 * 2.4e9), h);
+    (void)hipFree(out);
+}
 int main() {
     {   // semantics
         double h[64], *din, *dout, o[64]; for (int i = 0; i < 64; i++) h[i] = 100.0 + i;
@@ -104,11 +123,17 @@ int main() {
         int bad = 0; for (int i = 0; i < 64; i++) if (o[i] != h[(i & ~15) + 5]) bad++;
         printf("row_newbcast:5 semantics: %s (lane 0 -> %.0f, lane 17 -> %.0f, lane 63 -> %.0f)\n", bad ? "UNEXPECTED" : "lane 5 of each 16-lane row, as assumed", o[0], o[17], o[63]);
     }
+    {
+        double *d, o[64]; (void)hipMalloc(&d, 512); hipLaunchKernelGGL(k_subnormal, dim3(1), dim3(64), 0, 0, d); (void)hipMemcpy(o, d, 512, hipMemcpyDeviceToHost);
+        int bad = 0; for (int i = 0; i < 64; i++) if (o[i] != 0.0) bad++;
+        printf("subnormal limb x * 2^-1034: 100-term sums %s\n", bad ? "NOT exact (flushed?)" : "exact after scaling back by 2^517 twice");
+    }
     const size_t L64 = 64 * 1024, L128 = 128 * 1024;
     (void)hipFuncSetAttribute((const void *)k_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128);
     (void)hipFuncSetAttribute((const void *)k_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L64);
     run("registers: plain v_fma_f64, 90 acc", k_reg<0>, 256, 512, 0);
     run("registers: v_fmac_f64_dpp row_newbcast, 90 acc", k_reg<1>, 256, 512, 0);
+    run_seed("registers: v_fmac_f64_dpp, SUBNORMAL multiplier (3e-311)", k_reg<1>, 256, 512, 0, 3e-311);
     run("LDS-fed DPP tile, 8-wave WG, 1 per CU (2 waves/SIMD)", k_lds<8>, 256, 512, L128);
     run("LDS-fed DPP tile, 4-wave WG, 2 per CU (2 waves/SIMD)", k_lds<4>, 512, 256, L64);
     return 0;
