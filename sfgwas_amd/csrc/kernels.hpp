@@ -37,6 +37,7 @@ int launch_relinearize(sfg_ctx *ctx, const u64 *tmp, int nct, int level, const u
 int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct, int level);
 // mac_dma.hip
 int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<int> &is_big);
+double mac_big_maxterm(u64 q);
 int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, int L, double *rotf);
 int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st,
                    const double *rotsum = nullptr);

@@ -339,7 +339,7 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
             // largest single term of a run (in units of 2^-1034 for the small moduli): q / 2 * 2^12 (centred rot x 12-bit limb), big ones the Karatsuba middle term
             double maxterm = 0.0;
             for (int t = l; t < e; t++) {
-                const double m = big ? (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) * (8388608.0 + (double)((ctx->q[t] >> 23) + 1)) : (double)ctx->q[t] * 2048.0;
+                const double m = big ? mac_big_maxterm(ctx->q[t]) : (double)ctx->q[t] * 2048.0;
                 if (m > maxterm) maxterm = m;
             }
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / BC_KC) * BC_KC;

@@ -272,7 +272,12 @@ __global__ void __launch_bounds__(256) k_rot_to_f64(const u64 *in, double *out, 
     const size_t x = (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
     const u64 w = in[(ctp * nl + l) * N + x];
     double *o = out + ctp * out_row_stride + (size_t)plane_of[l] * N;
-    if (is_big[l]) { o[2 * x] = (double)(unsigned)(w & 0x7FFFFFu); o[2 * x + 1] = u64_to_f64(w >> 23); }
+    if (is_big[l]) {            // centred, then a SIGNED 23-bit split: |lo| <= 2^22, |hi| <= (q / 2 >> 23) + 1 - the Karatsuba middle term (lo + hi)(p_lo + p_hi) halves
+        const u64 q = modc[l].qi;
+        const long long wc = w > (q >> 1) ? (long long)w - (long long)q : (long long)w;
+        const long long lo = ((wc + 4194304) & 0x7FFFFF) - 4194304, hi = (wc - lo) >> 23;
+        o[2 * x] = (double)lo; o[2 * x + 1] = (double)hi;
+    }
     else {
         const u64 q = modc[l].qi;
         o[x] = (centre && w > (q >> 1)) ? -u64_to_f64(q - w) : u64_to_f64(w);
@@ -301,6 +306,9 @@ unsigned mac_dma_packed_mask(sfg_ctx *ctx, int L) {
     return m;
 }
 
+// 46/47-bit moduli: rot words are centred and split into signed halves (k_rot_to_f64: |lo| <= 2^22, |hi| <= (q >> 24) + 1), plaintext words into
+// unsigned halves (p_lo < 2^23, p_hi <= q >> 23).  The largest product of a k-step is the Karatsuba middle term.
+double mac_big_maxterm(u64 q) { return (4194304.0 + (double)((q >> 24) + 1)) * (8388608.0 + (double)((q >> 23) + 1)); }
 int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<int> &is_big) {
     plane_of.assign(L, 0); is_big.assign(L, 0); int nplanes = 0;
     for (int l = 0; l < L; l++) {
@@ -370,10 +378,10 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
                 const double rot_max = (3.0 * (double)a.rotf_k_stride + (double)R * (double)a.rotf_r_stride) * 8.0 + 512.0;
                 if (rot_max >= 4294967296.0) SFG_FAIL(ctx, "sfg_mac: operand strides exceed the 32-bit lane offsets of the DMA addressing (R = %d)", R);
             }
-            // largest single term of a run: small moduli q * 2^12; big ones the Karatsuba middle term (r_lo + r_hi) * (p_lo + p_hi) with
-            // lo < 2^23 and hi = w >> 23 <= q >> 23, i.e. < 2^48 only for q < 2^46 and up to 2.25 * 2^48 for a 47-bit modulus
+            // largest single term of a run: small moduli q * 2^12 (plain words, uncentred rot: this baseline kernel); big ones the Karatsuba middle
+            // term (r_lo + r_hi) * (p_lo + p_hi), see mac_big_maxterm
             double maxterm = 0.0;
-            for (int t = l; t < e; t++) if (big) { const double hs = 8388608.0 + (double)((ctx->q[t] >> 23) + 1); if (hs * hs > maxterm) maxterm = hs * hs; }
+            for (int t = l; t < e; t++) if (big) { const double m = mac_big_maxterm(ctx->q[t]); if (m > maxterm) maxterm = m; }
             for (int t = l; t < e; t++) if (!big && (double)ctx->q[t] * 4096.0 > maxterm) maxterm = (double)ctx->q[t] * 4096.0;
             int f = (int)((9007199254740992.0 - 140737488355328.0) / maxterm); f = (f / DM_KC) * DM_KC;
             if (f < DM_KC) SFG_FAIL(ctx, "sfg_mac: flush period underflow");
