@@ -193,10 +193,11 @@ static int build_rot_row_tab(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int n
         PhaseTimer t(ctx, "rotate");
         std::vector<int> nrv((size_t)d * s, 0), inv((size_t)d * s, 0);
         for (int baby = 0; baby < d; baby++) for (int i = 0; i < s; i++) { nrv[(size_t)baby * s + i] = baby_t[baby] ? -baby : 0; inv[(size_t)baby * s + i] = i; }
-        SFG_TRY(launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data()));
+        // LDS-DMA / broadcast MAC: the rotated ciphertexts are produced directly as its fp64 operand rows (no u64 rotation cache, no conversion pass)
+        if (dma) SFG_TRY(launch_rotate_right_indexed_f64(ctx, a_row, s, rotf_dst, d * s, lev, nrv.data(), inv.data(), L));
+        else SFG_TRY(launch_rotate_right_indexed(ctx, a_row, s, rotc, d * s, lev, nrv.data(), inv.data()));
         t.stop(1);
     }
-    if (dma) SFG_TRY(launch_rot_to_f64(ctx, rotc, (size_t)d * s * 2, nl, L, rotf_dst));
     return 0;
 }
 
@@ -225,7 +226,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
     const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
-    SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
+    SFG_TRY(sfg_scratch(ctx, "mm.rotc", dma ? 8 : (size_t)d * s * ctw * 8, (void **)&rotc));     // u64 rotation cache: only the register-staged MAC reads one
     SFG_TRY(sfg_scratch(ctx, "mm.pt", (size_t)G * nplain * L * prow * 8, (void **)&pt));
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
     int8_t *unpacked = nullptr;
@@ -427,7 +428,7 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
             const size_t ctw = (size_t)2 * nl * N;
             SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)(b1 - b0) * per_row + 3 * (size_t)s * 2 * rowf) * 8, (void **)&buf));
             SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
-            SFG_TRY(sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc));
+            SFG_TRY(sfg_scratch(ctx, "mm.rotc", 8, (void **)&rotc));                         // unused: the key switch writes the fp64 operand rows itself
             for (int bi = b0; bi < b1; bi++) SFG_TRY(build_rot_row(ctx, (const u64 *)A, s, in_level + 1, nl, lev, L, sh, bi, a_row, rotc, true, buf + (size_t)(bi - b0) * per_row));
             SFG_HIP(ctx, hipMemsetAsync(buf + (size_t)(b1 - b0) * per_row, 0, 3 * (size_t)s * 2 * rowf * 8, ctx->stream));   // k-slices read by a ragged last chunk
             rotf_all = buf;
@@ -579,7 +580,7 @@ extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int
     uint8_t *present_d = nullptr; unsigned long long *asym_d = nullptr; u64 *raw_h = nullptr;
     int rc = 0;
     auto bail = [&](int r) { close_all(); if (raw_h) (void)hipHostFree(raw_h); return r; };
-    if (sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row) || sfg_scratch(ctx, "mm.rotc", (size_t)d * s * ctw * 8, (void **)&rotc) ||
+    if (sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row) || sfg_scratch(ctx, "mm.rotc", 8, (void **)&rotc) ||
         sfg_scratch(ctx, "mm.rotf", ((size_t)d + 3) * s * 2 * rowf * 8, (void **)&rotf) || sfg_scratch(ctx, "mm.rotsum", (size_t)2 * s * 2 * rowf * 8, (void **)&rotsum) ||
         sfg_scratch(ctx, "mm.acc", (size_t)jp * d * accw * 8, (void **)&acc) || sfg_scratch(ctx, "dc.panel", (size_t)jp * d * plw * 8, (void **)&panel) ||
         sfg_scratch(ctx, "dc.raw", (size_t)d * jp * L * N * 8 + (size_t)d * jp + 64 + 8 * SFG_MAXMOD, (void **)&raw_d)) return bail(1);

@@ -175,12 +175,26 @@ __global__ void __launch_bounds__(256) k_moddown_extend(const u64 *acc, u64 *ext
     }
 }
 
+// Optional output form of a key-switch job: instead of a u64 ciphertext, the fp64 operand rows the MAC reads (mac_dma.hip k_rot_to_f64: one centred double per
+// word for a small modulus, a signed {lo, hi} pair for the 46-bit one; only the first L moduli, which are all the MAC accumulates over).  The baby-step
+// rotation cache is written in this form directly: no u64 copy of it exists, and the rows of modulus L are never produced.
+struct F64Form { int on, L, centre; size_t rowf; int plane_of[SFG_MAXMOD], big[SFG_MAXMOD]; };
+__device__ __forceinline__ void store_rot_f64(double *row, const F64Form &ff, int t, int x, double v, double q) {     // v canonical in [0, q)
+    const int N = SFG_N;
+    double *o = row + (size_t)ff.plane_of[t] * N;
+    if (ff.big[t]) {
+        const double wc = v > __builtin_floor(q * 0.5) ? v - q : v;                         // centred; q odd: floor(q/2) = (q-1)/2 = q >> 1
+        const double hi = __builtin_floor((wc + 4194304.0) * 0x1p-23), lo = wc - hi * 8388608.0;
+        o[2 * x] = lo; o[2 * x + 1] = hi;
+    } else o[x] = (ff.centre && v > __builtin_floor(q * 0.5)) ? v - q : v;
+}
 // grid (N/256, nl, B): out = perm(c0 + (acc0 - ext0)/P), perm((acc1 - ext1)/P); out[x] = in[index[x]]
 // add1 (nullable): [nin][nl][N] rows added to polynomial 1 (relinearisation: the degree-1 term of the tensor product)
 __global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const int *inidx, const u64 *acc, const u64 *ext2, const uint16_t *const *index,
-                                                   u64 *const *ct_out, const KswConst *kcp, const ModConst *modc, const u64 *add1) {
+                                                   u64 *const *ct_out, const KswConst *kcp, const ModConst *modc, const u64 *add1, F64Form ff) {
     const KswConst &kc = *kcp;
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
+    if (ff.on && t >= ff.L) return;
     const double q = modc[t].q, qinv = modc[t].qinv, pinv = kc.pinv[t], pinv_q = kc.pinv_q[t];
     const int src = index[b][x];
 #pragma unroll
@@ -190,7 +204,9 @@ __global__ void __launch_bounds__(256) k_ksw_finish(const u64 *ct_in, const int 
         double r = mulmod_lazy(a - e, pinv, pinv_q, q);
         if (p == 0) r += u64_to_f64(ct_in[((size_t)inidx[b] * 2 * (size_t)kc.nl + t) * N + src]);
         else if (add1) r += u64_to_f64(add1[((size_t)inidx[b] * (size_t)kc.nl + t) * N + src]);
-        ct_out[b][((size_t)p * kc.nl + t) * N + x] = f64_to_u64(canon(r, q, qinv));
+        const double v = canon(r, q, qinv);
+        if (ff.on) store_rot_f64(reinterpret_cast<double *>(ct_out[b]) + (size_t)p * ff.rowf, ff, t, x, v, q);
+        else ct_out[b][((size_t)p * kc.nl + t) * N + x] = f64_to_u64(v);
     }
 }
 
@@ -207,8 +223,9 @@ __global__ void __launch_bounds__(256) k_ct_add(const u64 *a, const u64 *b, u64 
 // Decomposition (steps 1-2) is done once per INPUT and shared by all its jobs ("hoisting"): the per-key work is
 // only the inner product, ModDown and the automorphism.  Same arithmetic, same bits.
 static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level, const std::vector<int> &job_in, const std::vector<const u64 *> &keyp,
-                                 const std::vector<const uint16_t *> &idxp, const std::vector<u64 *> &outp, const u64 *add1) {
+                                 const std::vector<const uint16_t *> &idxp, const std::vector<u64 *> &outp, const u64 *add1, const F64Form *ffp = nullptr) {
     const int N = SFG_N, nl = level + 1;
+    F64Form ff; memset(&ff, 0, sizeof ff); if (ffp) ff = *ffp;
     KswConst *kcd; KswConst kc;
     SFG_TRY(get_ksw(ctx, level, &kcd, &kc));
     const size_t ctw = (size_t)2 * nl * N;
@@ -271,7 +288,7 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
             SFG_TRY(launch_ntt_fwd(ctx, ext2, ext2T, (size_t)nb * 2 * nl, pq));
             // 5. finish + automorphism
             hipLaunchKernelGGL(k_ksw_finish, dim3(N / 256, nl, nb), dim3(256), 0, ctx->stream, bin, inidx_d, acc, ext2T, idx_d, out_d, kcd, ctx->modc,
-                               add1 ? add1 + (size_t)i0 * nl * N : nullptr);
+                               add1 ? add1 + (size_t)i0 * nl * N : nullptr, ff);
             SFG_HIP(ctx, hipGetLastError());
         }
     }
@@ -295,6 +312,31 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
         job_in.push_back(src); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev); outp.push_back(out + j * ctw);
     }
     return launch_keyswitch_jobs(ctx, in, nin, level, job_in, keyp, idxp, outp, nullptr);
+}
+// The same batch written as the MAC's fp64 operand rows: job j lands at outf + j * 2 * rowf (row pair of polynomials 0, 1), rowf = nplanes * N doubles.
+// Jobs that do not rotate (nrot == 0) are converted from their input.
+int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double *outf, int nct, int level, const int *nrot_host, const int *in_index, int L) {
+    const int N = SFG_N, nl = level + 1;
+    if (level < 0 || level >= ctx->nq || L > nl) SFG_FAIL(ctx, "rotate: level out of range");
+    const size_t ctw = (size_t)2 * nl * N;
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) return 1;
+    F64Form ff; memset(&ff, 0, sizeof ff);
+    ff.on = 1; ff.L = L; ff.centre = mac_dma_packed_mask(ctx, L) != 0; ff.rowf = (size_t)nplanes * N;
+    for (int l = 0; l < L; l++) { ff.plane_of[l] = plane_of[l]; ff.big[l] = is_big[l]; }
+    std::vector<int> job_in; std::vector<const u64 *> keyp; std::vector<const uint16_t *> idxp; std::vector<u64 *> outp;
+    for (int j = 0; j < nct; j++) {
+        int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
+        const int src = in_index ? in_index[j] : j;
+        if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
+        double *dst = outf + (size_t)j * 2 * ff.rowf;
+        if (nrot == 0) { SFG_TRY(launch_rot_to_f64(ctx, in + (size_t)src * ctw, 2, nl, L, dst)); continue; }
+        u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);
+        auto it = ctx->rotkeys().find(g);
+        if (it == ctx->rotkeys().end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
+        job_in.push_back(src); keyp.push_back(it->second.key_dev); idxp.push_back(it->second.index_dev); outp.push_back(reinterpret_cast<u64 *>(dst));
+    }
+    return launch_keyswitch_jobs(ctx, in, nin, level, job_in, keyp, idxp, outp, nullptr, &ff);
 }
 // relinearisation: out[i] = (tmp[i].p0 + d0, mid[i] + d1) with (d0, d1) = key switch of tmp[i].p1 under the key stored at Galois element 1
 int launch_relinearize(sfg_ctx *ctx, const u64 *tmp, int nct, int level, const u64 *mid, u64 *out) {
