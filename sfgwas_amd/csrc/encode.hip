@@ -51,10 +51,15 @@ __host__ __device__ static inline cdd cdd_mul(cdd a, cdd b) {
 }
 
 constexpr int ENC_H = SFG_SLOTS / 2;         // 4096-point complex FFT
-constexpr int ENC_TW = 16384;                // table of zeta^-k, k = 0..16384, zeta = exp(2 pi i / 32768)
+constexpr int ENC_TW = 16384;                // zeta^-k is built for k = 0..16384, zeta = exp(2 pi i / 32768)
+// device twiddle table (double4 entries): the three twiddled radix-8 passes, then the recombination lists
+constexpr int ENC_TB_P512 = 0, ENC_TB_P64 = ENC_TB_P512 + 7 * 512, ENC_TB_P8 = ENC_TB_P64 + 7 * 64;
+constexpr int ENC_TB_RLEN = ENC_H / 4 + 1;   // c = 2k + parity <= h/2: k = 0..1024
+constexpr int ENC_TB_RW = ENC_TB_P8 + 7 * 8, ENC_TB_RZ = ENC_TB_RW + 2 * ENC_TB_RLEN, ENC_TB_RZ2 = ENC_TB_RZ + 2 * ENC_TB_RLEN;
+constexpr int ENC_TB_SIZE = ENC_TB_RZ2 + 2 * ENC_TB_RLEN;
 
 struct EncTables {                // immutable, shared by a context and its forks
-    double4 *zt = nullptr;        // [ENC_TW + 1] {re.hi, re.lo, im.hi, im.lo} of exp(-2 pi i k / 32768)
+    double4 *tb = nullptr;        // twiddles {re.hi, re.lo, im.hi, im.lo} of zeta^-k = exp(-2 pi i k / 32768), laid out in the order the kernel's lanes read them (ENC_TB_*)
     uint16_t *tinv = nullptr;     // [n] slot index t with (5^t - 1)/4 mod n == m
 };
 // per-context scratch (sfg_scratch pool): "enc.skew" diag-major copy of one block [n][n] int8;
@@ -95,21 +100,37 @@ int sfg_encoder_init(sfg_ctx *ctx) {
     // exact values at the octants
     z[ENC_TW].re = dd_make(-1, 0); z[ENC_TW].im = dd_make(0, 0);                    // k = 16384: exp(-i pi)
     z[ENC_TW / 2].re = dd_make(0, 0); z[ENC_TW / 2].im = dd_make(-1, 0);            // k = 8192: exp(-i pi/2)
-    std::vector<double4> zt(ENC_TW + 1);
-    for (int k = 0; k <= ENC_TW; k++) zt[k] = make_double4(z[k].re.hi, z[k].re.lo, z[k].im.hi, z[k].im.lo);
+    // per-pass tables: entry [r - 1][t] = W_{8S}^(bitrev3(r) t) = zeta^-(bitrev3(r) t 4096 / S), so lane t of a wave reads consecutive 32-byte entries;
+    // recombination tables by parity of c (c = 2k + par): omega^-c = zeta^-4c, zeta^-c, zeta^-(h - c)
+    auto zat = [&](int idx) {                                   // idx in [0, 32768): the second half is the negated first half
+        const bool neg = idx > ENC_TW; const cdd w = z[neg ? idx - ENC_TW : idx]; const double sg = neg ? -1.0 : 1.0;
+        return make_double4(sg * w.re.hi, sg * w.re.lo, sg * w.im.hi, sg * w.im.lo);
+    };
+    std::vector<double4> tb(ENC_TB_SIZE);
+    {
+        const int E[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+        const int S3[3] = {512, 64, 8}, off[3] = {ENC_TB_P512, ENC_TB_P64, ENC_TB_P8};
+        for (int k = 0; k < 3; k++) for (int r = 1; r < 8; r++) for (int t = 0; t < S3[k]; t++) tb[off[k] + (r - 1) * S3[k] + t] = zat(E[r] * t * (4096 / S3[k]));
+        for (int par = 0; par < 2; par++) for (int k = 0; k < ENC_TB_RLEN; k++) {
+            int c = 2 * k + par; if (c > ENC_H / 2) c = ENC_H / 2;                       // (padding entry of the odd list)
+            tb[ENC_TB_RW + par * ENC_TB_RLEN + k] = zat(4 * c);
+            tb[ENC_TB_RZ + par * ENC_TB_RLEN + k] = zat(c);
+            tb[ENC_TB_RZ2 + par * ENC_TB_RLEN + k] = zat(ENC_H - c);
+        }
+    }
     std::vector<uint16_t> tinv(n);
     u64 g = 1;
     for (int t = 0; t < n; t++) { tinv[((g - 1) / 4) % n] = (uint16_t)t; g = (g * 5) % M; }
-    SFG_HIP(ctx, hipMalloc(&et->zt, zt.size() * sizeof(double4)));
+    SFG_HIP(ctx, hipMalloc(&et->tb, tb.size() * sizeof(double4)));
     SFG_HIP(ctx, hipMalloc(&et->tinv, n * sizeof(uint16_t)));
-    SFG_HIP(ctx, hipMemcpy(et->zt, zt.data(), zt.size() * sizeof(double4), hipMemcpyHostToDevice));
+    SFG_HIP(ctx, hipMemcpy(et->tb, tb.data(), tb.size() * sizeof(double4), hipMemcpyHostToDevice));
     SFG_HIP(ctx, hipMemcpy(et->tinv, tinv.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
     return 0;
 }
 void sfg_encoder_destroy(SfgShared *sh) {
     EncTables *et = (EncTables *)sh->enc_tables;
     if (!et) return;
-    (void)hipFree(et->zt); (void)hipFree(et->tinv);
+    (void)hipFree(et->tb); (void)hipFree(et->tinv);
     delete et; sh->enc_tables = nullptr;
 }
 
@@ -219,18 +240,19 @@ template <bool GRID> __device__ __forceinline__ dd fx_dot2(dd a, dd w, dd b, dd 
     lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
     return GRID ? grid_split(s.hi, s.lo + lo) : dd_quick(s.hi, s.lo + lo);
 }
-// zeta^-idx for idx in [0, 32768): the table covers [0, 16384], the rest is the negated first half
-__device__ __forceinline__ void tw_at(const double4 *zt, int idx, dd &wr, dd &wi) {
-    const bool neg = idx > ENC_TW;
-    const double4 w = zt[neg ? idx - ENC_TW : idx];
-    const double sg = neg ? -1.0 : 1.0;
-    wr = dd_make(sg * w.x, sg * w.y); wi = dd_make(sg * w.z, sg * w.w);
+#ifndef SFG_ENC_DIAG
+#define SFG_ENC_DIAG 0          // timing diagnostics only (wrong results): 1 no twiddle loads, 2 no recombination arithmetic, 4 no exchanges, 8 no twiddle products
+#endif
+__device__ __forceinline__ void tw_at(const double4 *tab, int idx, dd &wr, dd &wi) {
+    if (SFG_ENC_DIAG & 1) { wr = dd_make(0.7 + idx * 1e-9, 1e-18); wi = dd_make(0.3 - idx * 1e-9, 2e-18); return; }
+    const double4 w = tab[idx];
+    wr = dd_make(w.x, w.y); wi = dd_make(w.z, w.w);
 }
 // One radix-8 DIF pass on 8 register-resident points at stride S of a sub-transform of length 8S: identical to three
 // radix-2 DIF stages (pairs (i,i+4), (i,i+2), (i,i+1)) with the twiddles regrouped - the 12 twiddle products of the
 // radix-2 form become 7 output products W^(e t), e = bitrev(r), plus two rotations by 1/8 turn; t = j mod S.
 template <int S, bool GRID>
-__device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const double4 *zt, int t) {
+__device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const double4 *tab, int t) {          // tab: this pass's [7][S] twiddle list
     const dd rs = dd_make(7.071067811865475727e-01, -4.833646656726456726e-17);      // 1/sqrt(2) in double-double
     dd ur[4], ui[4], dr[4], di[4];
 #pragma unroll
@@ -263,11 +285,10 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
     quad(ur, ui, 0);
     quad(dr, di, 4);
     if (S > 1) {                                                                       // S == 1: t = 0, every output twiddle is 1
-        constexpr int STEP = 4096 / S;                                                 // W_{8S} = zeta^-(32768 / 8S)
-        constexpr int E[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 #pragma unroll
-        for (int r = 1; r < 8; r++) {
-            dd wr, wi; tw_at(zt, E[r] * t * STEP, wr, wi);
+        for (int r = 1; r < 8; r++) {                                                  // output r carries W_{8S}^(bitrev3(r) t)
+            if (SFG_ENC_DIAG & 8) continue;
+            dd wr, wi; tw_at(tab, (r - 1) * S + t, wr, wi);
             const dd pr = fx_dot2<GRID>(xr[r], wr, xi[r], wi, -1.0), pi = fx_dot2<GRID>(xr[r], wi, xi[r], wr, 1.0);
             xr[r] = pr; xi[r] = pi;
         }
@@ -281,9 +302,8 @@ __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {     
     double nn = __builtin_rint(x.hi);
     double diff = (x.hi - nn) + x.lo;
     near_tie += __builtin_fabs(__builtin_fabs(diff) - 0.5) < 0x1p-40 ? 1u : 0u;
-    if (diff > 0.5 || (diff == 0.5 && nn >= 0)) nn += 1.0;
-    else if (diff < -0.5 || (diff == -0.5 && nn <= 0)) nn -= 1.0;
-    return nn;
+    const bool up = (diff > 0.5) | ((diff == 0.5) & (nn >= 0)), dn = (diff < -0.5) | ((diff == -0.5) & (nn <= 0));      // (no short-circuit: selects, not branches)
+    return nn + (up ? 1.0 : 0.0) - (dn ? 1.0 : 0.0);
 }
 
 // rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
@@ -296,7 +316,7 @@ constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 65,536 B: two
 // exchange can go through an image of HALF the points: the sub-transforms a < 4 (threads 0..255) and a >= 4 (threads
 // 256..511) take turns, data stays in registers meanwhile.  16 waves per CU instead of 8.
 template <bool F64IN>
-__global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *zt, const uint16_t *tinv,
+__global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *tb, const uint16_t *tinv,
                                                       double scale_over_n, double *pc_out, unsigned long long *tie_count) {
     unsigned near_tie = 0;
     extern __shared__ double lds[];
@@ -311,8 +331,8 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     if (!F64IN) reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
     __syncthreads();
     dd xr[8], xi[8];
-    auto put = [&](int p, dd re, dd im) { RH[p] = re.hi; RL[p] = re.lo; IH[p] = im.hi; IL[p] = im.lo; };
-    auto get = [&](int p, dd &re, dd &im) { re = dd_make(RH[p], RL[p]); im = dd_make(IH[p], IL[p]); };
+    auto put = [&](int p, dd re, dd im) { if (SFG_ENC_DIAG & 4) return; RH[p] = re.hi; RL[p] = re.lo; IH[p] = im.hi; IL[p] = im.lo; };
+    auto get = [&](int p, dd &re, dd &im) { if (SFG_ENC_DIAG & 4) { re = dd_make(re.hi + p, re.lo); im = dd_make(im.hi - p, im.lo); return; } re = dd_make(RH[p], RL[p]); im = dd_make(IH[p], IL[p]); };
     // ---- pass 1: bits a; thread = (b,c,d) = tid, element j = a*512 + tid
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -322,11 +342,12 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         if (F64IN) { xr[a] = dd_make(rowd[t0], 0.0); xi[a] = dd_make(rowd[t1], 0.0); }
         else { xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0); }
     }
-    dif_radix8<512, !F64IN>(xr, xi, zt, tid);
+    dif_radix8<512, !F64IN>(xr, xi, tb + ENC_TB_P512, tid);
     // Every exchange runs in two rounds through the half image.  Round r moves the points whose split bit equals r: the
     // threads that own them write all 8 of their values, then EVERY thread reads the 4 values of that round it needs
     // (unconditional reads keep the register live ranges short).
     dd yr[8], yi[8];
+    if (SFG_ENC_DIAG & 4) { for (int i = 0; i < 8; i++) { yr[i] = xr[i]; yi[i] = xi[i]; } }
     {
         // ---- exchange 1 -> 2, split on b >> 2.  Writer tid = (b, cd) holds a = 0..7; reader (a, cd) needs b = 0..7 of j = a*512 + b*64 + cd
         const int bw = tid >> 6, cd = tid & 63, ar = tid >> 6;
@@ -341,7 +362,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
             for (int b = 0; b < 4; b++) get(padj(ar * 256 + b * 64 + cd), yr[4 * r + b], yi[4 * r + b]);
         }
-        dif_radix8<64, !F64IN>(yr, yi, zt, cd);
+        dif_radix8<64, !F64IN>(yr, yi, tb + ENC_TB_P64, cd);
         // ---- exchange 2 -> 3, split on c >> 2.  Writer (a, c, d) holds b = 0..7; reader (ab, d) needs c = 0..7 of j = ab*64 + c*8 + d
         const int cw = (tid >> 3) & 7, d = tid & 7, ab = tid >> 3;
 #pragma unroll
@@ -355,7 +376,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
             for (int c = 0; c < 4; c++) get(padj(ab * 32 + c * 8 + d), xr[4 * r + c], xi[4 * r + c]);
         }
-        dif_radix8<8, !F64IN>(xr, xi, zt, d);
+        dif_radix8<8, !F64IN>(xr, xi, tb + ENC_TB_P8, d);
         // ---- exchange 3 -> 4, split on d >> 2.  Writer (ab, d) holds c = 0..7; reader tid = abc needs d = 0..7 of j = tid*8 + d
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -368,7 +389,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
             for (int d4 = 0; d4 < 4; d4++) get(padj(tid * 4 + d4), yr[4 * r + d4], yi[4 * r + d4]);
         }
-        dif_radix8<1, !F64IN>(yr, yi, zt, 0);
+        dif_radix8<1, !F64IN>(yr, yi, tb, 0);
     }
     const int my_half = tid >> 8, tl = tid & 255;                   // result position j = tid*8 + d: top bit = tid >> 8
     // Round r handles the c of parity r: Z_c and Z_{h-c} then sit in half r of the (bit-reversed) result.
@@ -391,18 +412,20 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         auto radd = [](dd a, dd b) { return GRID ? dd_make(a.hi + b.hi, a.lo + b.lo) : dd_add(a, b); };
         auto rsub = [](dd a, dd b) { return GRID ? dd_make(a.hi - b.hi, a.lo - b.lo) : dd_sub(a, b); };
         auto half = [](dd a) { return dd_make(a.hi * 0.5, a.lo * 0.5); };                         // exact
+        if (SFG_ENC_DIAG & 2) { pc[c] = RH[pa]; if (c > 0) pc[n - c] = IH[pa]; if (c < h / 2) { pc[h - c] = RH[pb]; pc[n - (h - c)] = IH[pb]; } continue; }
         dd Ar = dd_make(RH[pa], RL[pa]), Ai = dd_make(IH[pa], IL[pa]);
         dd Br = dd_make(RH[pb], RL[pb]), Bi = dd_neg(dd_make(IH[pb], IL[pb]));
         dd Xr = half(radd(Ar, Br)), Xi = half(radd(Ai, Bi));
         dd Dr = half(rsub(Ar, Br)), Di = half(rsub(Ai, Bi));
         dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/(2i) = -i (A-B)/2
-        const double4 wo = zt[4 * c];                               // omega^-c = zeta^-4c
+        const int kc = (c >> 1) + r * ENC_TB_RLEN;                  // this round's parity list
+        const double4 wo = tb[ENC_TB_RW + kc];                      // omega^-c = zeta^-4c
         dd wor = dd_make(wo.x, wo.y), woi = dd_make(wo.z, wo.w);
         dd Yr = fx_dot2<GRID>(Or, wor, Oi, woi, -1.0), Yi = fx_dot2<GRID>(Or, woi, Oi, wor, 1.0);
         // W_c
         {
             dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
-            const double4 z = zt[c];
+            const double4 z = tb[ENC_TB_RZ + kc];                   // zeta^-c
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
             dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
@@ -413,7 +436,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         if (c < h / 2) {
             const int cc = h - c;
             dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
-            const double4 z = zt[cc];
+            const double4 z = tb[ENC_TB_RZ2 + kc];                  // zeta^-(h - c)
             dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
             dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
@@ -452,7 +475,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         const int nb = nshift - s0 < BATCH ? nshift - s0 : BATCH;
         {
             PhaseTimer t(ctx, "encode", false);
-            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->zt, et->tinv,
+            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->tb, et->tinv,
                                ctx->scale / (double)SFG_SLOTS, pc, (unsigned long long *)ctx->tie_count_dev);
             SFG_HIP(ctx, hipGetLastError());
         }
@@ -492,7 +515,7 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     int rc = 0;
     if (hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
     if (!rc) {
-        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
+        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
         if (hipGetLastError() != hipSuccess) rc = 1;
     }
     if (!rc && hipMemcpyAsync(pc.data(), dpc, (size_t)nvec * n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
@@ -519,7 +542,7 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
     double *dv = (double *)p; double *dpc = dv + (size_t)nvec * n;
     SFG_HIP(ctx, hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->zt, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
+    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
     SFG_HIP(ctx, hipGetLastError());
     SFG_TRY(launch_ntt_plain(ctx, dpc, (u64 *)pt_dev, (size_t)nvec, level + 1));
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // values_host may be reused by the caller
