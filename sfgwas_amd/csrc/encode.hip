@@ -54,9 +54,9 @@ constexpr int ENC_H = SFG_SLOTS / 2;         // 4096-point complex FFT
 constexpr int ENC_TW = 16384;                // zeta^-k is built for k = 0..16384, zeta = exp(2 pi i / 32768)
 // device twiddle table (double4 entries): the three twiddled radix-8 passes, then the recombination lists
 constexpr int ENC_TB_P512 = 0, ENC_TB_P64 = ENC_TB_P512 + 7 * 512, ENC_TB_P8 = ENC_TB_P64 + 7 * 64;
-constexpr int ENC_TB_RLEN = ENC_H / 4 + 1;   // c = 2k + parity <= h/2: k = 0..1024
-constexpr int ENC_TB_RW = ENC_TB_P8 + 7 * 8, ENC_TB_RZ = ENC_TB_RW + 2 * ENC_TB_RLEN, ENC_TB_RZ2 = ENC_TB_RZ + 2 * ENC_TB_RLEN;
-constexpr int ENC_TB_SIZE = ENC_TB_RZ2 + 2 * ENC_TB_RLEN;
+constexpr int ENC_TB_RLEN = ENC_H / 2 + 1;   // c = 0..h/2
+constexpr int ENC_TB_RW = ENC_TB_P8 + 7 * 8, ENC_TB_RZ = ENC_TB_RW + ENC_TB_RLEN, ENC_TB_RZ2 = ENC_TB_RZ + ENC_TB_RLEN;
+constexpr int ENC_TB_SIZE = ENC_TB_RZ2 + ENC_TB_RLEN;
 
 struct EncTables {                // immutable, shared by a context and its forks
     double4 *tb = nullptr;        // twiddles {re.hi, re.lo, im.hi, im.lo} of zeta^-k = exp(-2 pi i k / 32768), laid out in the order the kernel's lanes read them (ENC_TB_*)
@@ -101,7 +101,7 @@ int sfg_encoder_init(sfg_ctx *ctx) {
     z[ENC_TW].re = dd_make(-1, 0); z[ENC_TW].im = dd_make(0, 0);                    // k = 16384: exp(-i pi)
     z[ENC_TW / 2].re = dd_make(0, 0); z[ENC_TW / 2].im = dd_make(-1, 0);            // k = 8192: exp(-i pi/2)
     // per-pass tables: entry [r - 1][t] = W_{8S}^(bitrev3(r) t) = zeta^-(bitrev3(r) t 4096 / S), so lane t of a wave reads consecutive 32-byte entries;
-    // recombination tables by parity of c (c = 2k + par): omega^-c = zeta^-4c, zeta^-c, zeta^-(h - c)
+    // recombination tables for c = 0..h/2: omega^-c = zeta^-4c, zeta^-c, zeta^-(h - c)
     auto zat = [&](int idx) {                                   // idx in [0, 32768): the second half is the negated first half
         const bool neg = idx > ENC_TW; const cdd w = z[neg ? idx - ENC_TW : idx]; const double sg = neg ? -1.0 : 1.0;
         return make_double4(sg * w.re.hi, sg * w.re.lo, sg * w.im.hi, sg * w.im.lo);
@@ -111,12 +111,7 @@ int sfg_encoder_init(sfg_ctx *ctx) {
         const int E[8] = {0, 4, 2, 6, 1, 5, 3, 7};
         const int S3[3] = {512, 64, 8}, off[3] = {ENC_TB_P512, ENC_TB_P64, ENC_TB_P8};
         for (int k = 0; k < 3; k++) for (int r = 1; r < 8; r++) for (int t = 0; t < S3[k]; t++) tb[off[k] + (r - 1) * S3[k] + t] = zat(E[r] * t * (4096 / S3[k]));
-        for (int par = 0; par < 2; par++) for (int k = 0; k < ENC_TB_RLEN; k++) {
-            int c = 2 * k + par; if (c > ENC_H / 2) c = ENC_H / 2;                       // (padding entry of the odd list)
-            tb[ENC_TB_RW + par * ENC_TB_RLEN + k] = zat(4 * c);
-            tb[ENC_TB_RZ + par * ENC_TB_RLEN + k] = zat(c);
-            tb[ENC_TB_RZ2 + par * ENC_TB_RLEN + k] = zat(ENC_H - c);
-        }
+        for (int c = 0; c < ENC_TB_RLEN; c++) { tb[ENC_TB_RW + c] = zat(4 * c); tb[ENC_TB_RZ + c] = zat(c); tb[ENC_TB_RZ2 + c] = zat(ENC_H - c); }
     }
     std::vector<uint16_t> tinv(n);
     u64 g = 1;
@@ -308,19 +303,16 @@ __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {     
 
 // rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
 // F64IN: rows are n doubles (arbitrary real slot vectors, no rotation) — the Mask / EncodeFloatVector use.
-constexpr int ENC_HALF = ENC_H / 2;                 // the exchange image holds half of the points (2048) at a time
-constexpr int ENC_HPAD = ENC_HALF;                  // no padding: see padj
-constexpr size_t ENC_LDS_BYTES = (size_t)4 * ENC_HPAD * 8;      // 65,536 B: two workgroups per CU
-// After the first radix-8 pass the transform splits into 8 independent 512-point sub-transforms (one per `a`), and the
-// final recombination pairs Z_c with Z_{h-c}, whose bit-reversed positions share the top bit (= parity of c).  So every
-// exchange can go through an image of HALF the points: the sub-transforms a < 4 (threads 0..255) and a >= 4 (threads
-// 256..511) take turns, data stays in registers meanwhile.  16 waves per CU instead of 8.
+constexpr size_t ENC_LDS_BYTES = (size_t)2 * ENC_H * 8;        // 65,536 B: two workgroups per CU
+// Every exchange moves the HIGH parts of all 4096 points through the 64 KiB image (re, im: 2 x 4096 doubles), then the LOW parts: the image
+// holds half of the double-double data at a time, every thread does the same work in both rounds (no divergent writers), and a thread carries
+// at most 8 high + 8 low complex parts across a round.  16 waves per CU.
 template <bool F64IN>
 __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *tb, const uint16_t *tinv,
                                                       double scale_over_n, double *pc_out, unsigned long long *tie_count) {
     unsigned near_tie = 0;
     extern __shared__ double lds[];
-    double *RH = lds, *RL = lds + ENC_HPAD, *IH = lds + 2 * ENC_HPAD, *IL = lds + 3 * ENC_HPAD;
+    double *RE = lds, *IM = lds + ENC_H;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
     const int shift = shift0 + blockIdx.x;
     const int nrot = F64IN ? 0 : SFG_D * (shift / SFG_D);          // matmult.go:1426: nrot = d * giant
@@ -330,9 +322,23 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     int8_t *rowl = reinterpret_cast<int8_t *>(lds);
     if (!F64IN) reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
     __syncthreads();
-    dd xr[8], xi[8];
-    auto put = [&](int p, dd re, dd im) { if (SFG_ENC_DIAG & 4) return; RH[p] = re.hi; RL[p] = re.lo; IH[p] = im.hi; IL[p] = im.lo; };
-    auto get = [&](int p, dd &re, dd &im) { if (SFG_ENC_DIAG & 4) { re = dd_make(re.hi + p, re.lo); im = dd_make(im.hi - p, im.lo); return; } re = dd_make(RH[p], RL[p]); im = dd_make(IH[p], IL[p]); };
+    dd xr[8], xi[8], yr[8], yi[8];
+    // src[k] goes to image index widx(k); dst[k] comes from index ridx(k)
+    auto exchange = [&](dd (&sr)[8], dd (&si)[8], dd (&dr)[8], dd (&di)[8], auto widx, auto ridx) {
+        if (SFG_ENC_DIAG & 4) { for (int k = 0; k < 8; k++) { dr[k] = sr[k]; di[k] = si[k]; } return; }
+        __syncthreads();                                           // the row staging area / the previous readers are done
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int p = padj(widx(k)); RE[p] = sr[k].hi; IM[p] = si[k].hi; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int p = padj(ridx(k)); dr[k].hi = RE[p]; di[k].hi = IM[p]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int p = padj(widx(k)); RE[p] = sr[k].lo; IM[p] = si[k].lo; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int p = padj(ridx(k)); dr[k].lo = RE[p]; di[k].lo = IM[p]; }
+    };
     // ---- pass 1: bits a; thread = (b,c,d) = tid, element j = a*512 + tid
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -343,90 +349,64 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         else { xr[a] = dd_make((double)rowl[t0], 0.0); xi[a] = dd_make((double)rowl[t1], 0.0); }
     }
     dif_radix8<512, !F64IN>(xr, xi, tb + ENC_TB_P512, tid);
-    // Every exchange runs in two rounds through the half image.  Round r moves the points whose split bit equals r: the
-    // threads that own them write all 8 of their values, then EVERY thread reads the 4 values of that round it needs
-    // (unconditional reads keep the register live ranges short).
-    dd yr[8], yi[8];
-    if (SFG_ENC_DIAG & 4) { for (int i = 0; i < 8; i++) { yr[i] = xr[i]; yi[i] = xi[i]; } }
     {
-        // ---- exchange 1 -> 2, split on b >> 2.  Writer tid = (b, cd) holds a = 0..7; reader (a, cd) needs b = 0..7 of j = a*512 + b*64 + cd
-        const int bw = tid >> 6, cd = tid & 63, ar = tid >> 6;
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            __syncthreads();                                       // r = 0: row staging area is dead; r = 1: round-0 readers are done
-            if ((bw >> 2) == r) {
-#pragma unroll
-                for (int a = 0; a < 8; a++) put(padj(a * 256 + (bw & 3) * 64 + cd), xr[a], xi[a]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < 4; b++) get(padj(ar * 256 + b * 64 + cd), yr[4 * r + b], yi[4 * r + b]);
-        }
+        // ---- exchange 1 -> 2.  Writer tid = (b, cd) holds a = 0..7; reader (a, cd) needs b = 0..7 of j = a*512 + b*64 + cd
+        const int cd = tid & 63, ar = tid >> 6;
+        exchange(xr, xi, yr, yi, [&](int a) { return a * 512 + tid; }, [&](int b) { return ar * 512 + b * 64 + cd; });
         dif_radix8<64, !F64IN>(yr, yi, tb + ENC_TB_P64, cd);
-        // ---- exchange 2 -> 3, split on c >> 2.  Writer (a, c, d) holds b = 0..7; reader (ab, d) needs c = 0..7 of j = ab*64 + c*8 + d
-        const int cw = (tid >> 3) & 7, d = tid & 7, ab = tid >> 3;
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            __syncthreads();
-            if ((cw >> 2) == r) {
-#pragma unroll
-                for (int b = 0; b < 8; b++) put(padj((ar * 8 + b) * 32 + (cw & 3) * 8 + d), yr[b], yi[b]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 4; c++) get(padj(ab * 32 + c * 8 + d), xr[4 * r + c], xi[4 * r + c]);
-        }
+        // ---- exchange 2 -> 3.  Writer (a, c, d) holds b = 0..7; reader (ab, d) needs c = 0..7 of j = ab*64 + c*8 + d
+        const int d = tid & 7, ab = tid >> 3;
+        exchange(yr, yi, xr, xi, [&](int b) { return ar * 512 + b * 64 + cd; }, [&](int c) { return ab * 64 + c * 8 + d; });
         dif_radix8<8, !F64IN>(xr, xi, tb + ENC_TB_P8, d);
-        // ---- exchange 3 -> 4, split on d >> 2.  Writer (ab, d) holds c = 0..7; reader tid = abc needs d = 0..7 of j = tid*8 + d
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            __syncthreads();
-            if ((d >> 2) == r) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) put(padj((ab * 8 + c) * 4 + (d & 3)), xr[c], xi[c]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int d4 = 0; d4 < 4; d4++) get(padj(tid * 4 + d4), yr[4 * r + d4], yi[4 * r + d4]);
-        }
+        // ---- exchange 3 -> 4.  Writer (ab, d) holds c = 0..7; reader tid = abc needs d = 0..7 of j = tid*8 + d
+        exchange(xr, xi, yr, yi, [&](int c) { return ab * 64 + c * 8 + d; }, [&](int d4) { return tid * 8 + d4; });
         dif_radix8<1, !F64IN>(yr, yi, tb, 0);
     }
-    const int my_half = tid >> 8, tl = tid & 255;                   // result position j = tid*8 + d: top bit = tid >> 8
-    // Round r handles the c of parity r: Z_c and Z_{h-c} then sit in half r of the (bit-reversed) result.
+    // ---- recombination.  Position p = tid*8 + d holds Z_c with c = brev12(p) = brev3(d) << 9 | brev9(tid): the results are stored under c, and
+    // thread tid takes the pairs (c, h - c), c = tid + 512 i, i = 0..3 (and thread 0 the self-paired c = h/2): consecutive lanes read consecutive
+    // image words and twiddle entries and write consecutive coefficients.
     double *pc = pc_out + (size_t)blockIdx.x * n;
-#pragma unroll 1
-    for (int r = 0; r < 2; r++) {
+    const int cbase = (int)(__brev((unsigned)tid) >> 23);
+    dd Ar[5], Ai[5], Br[5], Bi[5];
+    const int npair = tid == 0 ? 5 : 4;
     __syncthreads();
-    if (my_half == r) {
 #pragma unroll
-        // position p = tl*8 + dd holds Z_c with c >> 1 = brev11(p) = brev3(dd) << 8 | brev8(tl): stored under that index, so that the
-        // readers below (consecutive c) touch consecutive words instead of a bit-reversed scatter
-        for (int dd_ = 0; dd_ < 8; dd_++) put(padj((int)((__brev((unsigned)dd_) >> 29) << 8) | (int)(__brev((unsigned)tl) >> 24)), yr[dd_], yi[dd_]);
+    for (int d4 = 0; d4 < 8; d4++) { const int p = padj((int)((__brev((unsigned)d4) >> 29) << 9) | cbase); RE[p] = yr[d4].hi; IM[p] = yi[d4].hi; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++) if (i < npair) {
+        const int c = tid + 512 * i, pa = padj(c), pb = padj((h - c) & (h - 1));
+        Ar[i].hi = RE[pa]; Ai[i].hi = IM[pa]; Br[i].hi = RE[pb]; Bi[i].hi = -IM[pb];
     }
     __syncthreads();
-    for (int c = 2 * tid + r; c <= h / 2; c += 1024) {
-        const int c2 = (h - c) & (h - 1);
-        const int pa = padj(c >> 1), pb = padj(c2 >> 1);               // both have the parity of this round (c2 = h - c)
+#pragma unroll
+    for (int d4 = 0; d4 < 8; d4++) { const int p = padj((int)((__brev((unsigned)d4) >> 29) << 9) | cbase); RE[p] = yr[d4].lo; IM[p] = yi[d4].lo; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++) if (i < npair) {
+        const int c = tid + 512 * i, pa = padj(c), pb = padj((h - c) & (h - 1));
+        Ar[i].lo = RE[pa]; Ai[i].lo = IM[pa]; Br[i].lo = RE[pb]; Bi[i].lo = -IM[pb];
+    }
+    // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c = zeta^-4c, zc = zeta^-c, zh = zeta^-(h-c)
+    auto recomb = [&](int c, dd Ar, dd Ai, dd Br, dd Bi) {
         // (genotype rows: A and B are sums on the fixed grid, so the recombination adds are exact two-flop grid adds as well)
         constexpr bool GRID = !F64IN;
         auto radd = [](dd a, dd b) { return GRID ? dd_make(a.hi + b.hi, a.lo + b.lo) : dd_add(a, b); };
         auto rsub = [](dd a, dd b) { return GRID ? dd_make(a.hi - b.hi, a.lo - b.lo) : dd_sub(a, b); };
         auto half = [](dd a) { return dd_make(a.hi * 0.5, a.lo * 0.5); };                         // exact
-        if (SFG_ENC_DIAG & 2) { pc[c] = RH[pa]; if (c > 0) pc[n - c] = IH[pa]; if (c < h / 2) { pc[h - c] = RH[pb]; pc[n - (h - c)] = IH[pb]; } continue; }
-        dd Ar = dd_make(RH[pa], RL[pa]), Ai = dd_make(IH[pa], IL[pa]);
-        dd Br = dd_make(RH[pb], RL[pb]), Bi = dd_neg(dd_make(IH[pb], IL[pb]));
+        if (SFG_ENC_DIAG & 2) { pc[c] = Ar.hi; if (c > 0) pc[n - c] = Ai.hi; if (c < h / 2) { pc[h - c] = Br.hi; pc[n - (h - c)] = Bi.hi; } return; }
+        const bool nt = SFG_ENC_DIAG & 16;
+        const double4 wo = nt ? make_double4(0.7 + c * 1e-9, 1e-18, 0.3, 1e-18) : tb[ENC_TB_RW + c];
+        const double4 zc = nt ? make_double4(0.6 + c * 1e-9, 1e-18, 0.4, 1e-18) : tb[ENC_TB_RZ + c];
         dd Xr = half(radd(Ar, Br)), Xi = half(radd(Ai, Bi));
         dd Dr = half(rsub(Ar, Br)), Di = half(rsub(Ai, Bi));
         dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/(2i) = -i (A-B)/2
-        const int kc = (c >> 1) + r * ENC_TB_RLEN;                  // this round's parity list
-        const double4 wo = tb[ENC_TB_RW + kc];                      // omega^-c = zeta^-4c
         dd wor = dd_make(wo.x, wo.y), woi = dd_make(wo.z, wo.w);
         dd Yr = fx_dot2<GRID>(Or, wor, Oi, woi, -1.0), Yi = fx_dot2<GRID>(Or, woi, Oi, wor, 1.0);
         // W_c
         {
             dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
-            const double4 z = tb[ENC_TB_RZ + kc];                   // zeta^-c
-            dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
+            dd zr = dd_make(zc.x, zc.y), zi = dd_make(zc.z, zc.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
             dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
             pc[c] = dd_round_away(wr, near_tie);
@@ -435,16 +415,18 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         // W_{h-c}  (c = 0 gives W_h)
         if (c < h / 2) {
             const int cc = h - c;
+            const double4 zh = nt ? make_double4(0.5 + c * 1e-9, 1e-18, 0.45, 1e-18) : tb[ENC_TB_RZ2 + c];
             dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
-            const double4 z = tb[ENC_TB_RZ2 + kc];                  // zeta^-(h - c)
-            dd zr = dd_make(z.x, z.y), zi = dd_make(z.z, z.w);
+            dd zr = dd_make(zh.x, zh.y), zi = dd_make(zh.z, zh.w);
             dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
             dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
             pc[cc] = dd_round_away(wr, near_tie);
             if (cc < h) pc[n - cc] = -dd_round_away(wi, near_tie);
         }
-    }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; i++) recomb(tid + 512 * i, Ar[i], Ai[i], Br[i], Bi[i]);
+    if (tid == 0) recomb(h / 2, Ar[4], Ai[4], Br[4], Bi[4]);
     if (near_tie) atomicAdd(tie_count, (unsigned long long)near_tie);
 }
 
