@@ -206,6 +206,11 @@ __device__ __forceinline__ double canon(double x, double q, double qinv) {
     return r == q ? 0.0 : r;
 }
 // partial reduction to (-q, q): cheap, for lazy sums that would otherwise grow
+// the same without the fix-up: a representative in [0, q] (q itself only for multiples of q).  Enough wherever the value is an operand of further
+// lazy arithmetic and merely has to be congruent, non-negative and <= q - e.g. the packed-limb plaintext words the MAC reads (q < 2^36 fits the limbs).
+__device__ __forceinline__ double canon_le(double x, double q, double qinv) {
+    return __builtin_fma(-__builtin_floor(x * qinv), q, x);
+}
 __device__ __forceinline__ double pred(double x, double q, double qinv) {
     double qh = __builtin_rint(x * qinv);
     return __builtin_fma(-qh, q, x);

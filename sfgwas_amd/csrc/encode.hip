@@ -111,7 +111,13 @@ int sfg_encoder_init(sfg_ctx *ctx) {
         const int E[8] = {0, 4, 2, 6, 1, 5, 3, 7};
         const int S3[3] = {512, 64, 8}, off[3] = {ENC_TB_P512, ENC_TB_P64, ENC_TB_P8};
         for (int k = 0; k < 3; k++) for (int r = 1; r < 8; r++) for (int t = 0; t < S3[k]; t++) tb[off[k] + (r - 1) * S3[k] + t] = zat(E[r] * t * (4096 / S3[k]));
-        for (int c = 0; c < ENC_TB_RLEN; c++) { tb[ENC_TB_RW + c] = zat(4 * c); tb[ENC_TB_RZ + c] = zat(c); tb[ENC_TB_RZ2 + c] = zat(ENC_H - c); }
+        // the final twist carries the scaling Delta / n as well (exact when that is a power of two, as with every preset; one double-double product otherwise)
+        const double son = ctx->sh->scale / (double)n;
+        auto scaled = [&](int idx) {
+            const double4 w = zat(idx); const dd re = dd_mul_d(dd_make(w.x, w.y), son), im = dd_mul_d(dd_make(w.z, w.w), son);
+            return make_double4(re.hi, re.lo, im.hi, im.lo);
+        };
+        for (int c = 0; c < ENC_TB_RLEN; c++) { tb[ENC_TB_RW + c] = zat(4 * c); tb[ENC_TB_RZ + c] = scaled(c); tb[ENC_TB_RZ2 + c] = scaled(ENC_H - c); }
     }
     std::vector<uint16_t> tinv(n);
     u64 g = 1;
@@ -309,7 +315,7 @@ constexpr size_t ENC_LDS_BYTES = (size_t)2 * ENC_H * 8;        // 65,536 B: two 
 // at most 8 high + 8 low complex parts across a round.  16 waves per CU.
 template <bool F64IN>
 __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *tb, const uint16_t *tinv,
-                                                      double scale_over_n, double *pc_out, unsigned long long *tie_count) {
+                                                      double *pc_out, unsigned long long *tie_count) {
     unsigned near_tie = 0;
     extern __shared__ double lds[];
     double *RE = lds, *IM = lds + ENC_H;
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         const int c = tid + 512 * i, pa = padj(c), pb = padj((h - c) & (h - 1));
         Ar[i].lo = RE[pa]; Ai[i].lo = IM[pa]; Br[i].lo = RE[pb]; Bi[i].lo = -IM[pb];
     }
-    // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c = zeta^-4c, zc = zeta^-c, zh = zeta^-(h-c)
+    // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c = zeta^-4c, zc = (Delta/n) zeta^-c, zh = (Delta/n) zeta^-(h-c)
     auto recomb = [&](int c, dd Ar, dd Ai, dd Br, dd Bi) {
         // (genotype rows: A and B are sums on the fixed grid, so the recombination adds are exact two-flop grid adds as well)
         constexpr bool GRID = !F64IN;
@@ -407,8 +413,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         {
             dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
             dd zr = dd_make(zc.x, zc.y), zi = dd_make(zc.z, zc.w);
-            dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
-            dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
+            dd wr = dd_dot2(Wr, zr, Wi, zi, -1.0), wi = dd_dot2(Wr, zi, Wi, zr, 1.0);
             pc[c] = dd_round_away(wr, near_tie);
             if (c > 0) pc[n - c] = -dd_round_away(wi, near_tie);
         }
@@ -418,8 +423,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             const double4 zh = nt ? make_double4(0.5 + c * 1e-9, 1e-18, 0.45, 1e-18) : tb[ENC_TB_RZ2 + c];
             dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
             dd zr = dd_make(zh.x, zh.y), zi = dd_make(zh.z, zh.w);
-            dd wr = dd_mul_d(dd_dot2(Wr, zr, Wi, zi, -1.0), scale_over_n);
-            dd wi = dd_mul_d(dd_dot2(Wr, zi, Wi, zr, 1.0), scale_over_n);
+            dd wr = dd_dot2(Wr, zr, Wi, zi, -1.0), wi = dd_dot2(Wr, zi, Wi, zr, 1.0);
             pc[cc] = dd_round_away(wr, near_tie);
             if (cc < h) pc[n - cc] = -dd_round_away(wi, near_tie);
         }
@@ -457,8 +461,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         const int nb = nshift - s0 < BATCH ? nshift - s0 : BATCH;
         {
             PhaseTimer t(ctx, "encode", false);
-            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->tb, et->tinv,
-                               ctx->scale / (double)SFG_SLOTS, pc, (unsigned long long *)ctx->tie_count_dev);
+            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->tb, et->tinv, pc, (unsigned long long *)ctx->tie_count_dev);
             SFG_HIP(ctx, hipGetLastError());
         }
         if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
@@ -497,7 +500,7 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     int rc = 0;
     if (hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
     if (!rc) {
-        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
+        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, dpc, (unsigned long long *)ctx->tie_count_dev);
         if (hipGetLastError() != hipSuccess) rc = 1;
     }
     if (!rc && hipMemcpyAsync(pc.data(), dpc, (size_t)nvec * n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
@@ -524,7 +527,7 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
     double *dv = (double *)p; double *dpc = dv + (size_t)nvec * n;
     SFG_HIP(ctx, hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, ctx->scale / (double)n, dpc, (unsigned long long *)ctx->tie_count_dev);
+    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, dpc, (unsigned long long *)ctx->tie_count_dev);
     SFG_HIP(ctx, hipGetLastError());
     SFG_TRY(launch_ntt_plain(ctx, dpc, (u64 *)pt_dev, (size_t)nvec, level + 1));
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // values_host may be reused by the caller

@@ -335,7 +335,11 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
     const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
     u64 *out = out_ + (dst * L + m) * (size_t)n;
     // (the format test is hoisted: inside the store loop it costs a branch per word)
-    if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+#ifdef SFG_NTT_DIAG          // timing diagnostics only: 1 = no panel stores (kept alive by an impossible value), 2 = stores without canon / packing
+    if (SFG_NTT_DIAG == 1) { ntt_half3_body(0, first, [&](int j, double x) { if (x == 0.123) out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid); return; }
+    if (SFG_NTT_DIAG == 2) { ntt_half3_body(0, first, [&](int j, double x) { out[j] = (u64)__double_as_longlong(x); }, lds, tw, pack, q, qinv, tid); return; }
+#endif
+    if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
     else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
 }
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
