@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cmath>
+#include <type_traits>
 
 // ---------------------------------------------------------------- double-double (host + device)
 struct dd { double hi, lo; };
@@ -198,6 +199,8 @@ __global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int 
 // sweep) are XORed with index bits 3..7.  Every access pattern of the kernel - 64 lanes that vary any six of the index bits 0..7 with the others
 // fixed (contiguous, stride 4, stride 32, bit-reversed) - then maps onto all 32 bank pairs exactly twice, the minimum for 512 bytes.
 __device__ __forceinline__ int padj(int j) { return j ^ ((j >> 3) & 31); }
+// the last exchange (bit-reversed writers: 32 lanes vary index bits 4..8; readers take consecutive words) uses index bits 5..8 instead
+__device__ __forceinline__ int padj_fin(int j) { return j ^ ((j >> 5) & 15); }
 
 // (ar + i ai) * (wr + i wi) with each component as ONE double-double dot product (two products share the final
 // renormalisation): 19 flops per component instead of 2 dd_mul + 1 dd_add = 25.
@@ -329,22 +332,27 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     if (!F64IN) reinterpret_cast<uint4 *>(rowl)[tid] = reinterpret_cast<const uint4 *>(row)[tid];
     __syncthreads();
     dd xr[8], xi[8], yr[8], yi[8];
-    // src[k] goes to image index widx(k); dst[k] comes from index ridx(k)
-    auto exchange = [&](dd (&sr)[8], dd (&si)[8], dd (&dr)[8], dd (&di)[8], auto widx, auto ridx) {
+    // src[k] goes to image index widx(k); dst[k] comes from index ridx(k).  WAVE: every index a wave writes or reads lies in its own 512-point
+    // region (exchanges 2 -> 3 and 3 -> 4 are transposes inside a wave), so after one workgroup barrier (the previous exchange's readers) only
+    // wave-level ordering is needed and the waves drift freely.
+    auto exchange = [&](dd (&sr)[8], dd (&si)[8], dd (&dr)[8], dd (&di)[8], auto widx, auto ridx, auto wave, bool entry_barrier) {
+        constexpr bool WAVE = decltype(wave)::value;
+        auto sync = [&]() { if (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads(); };
         if (SFG_ENC_DIAG & 4) { for (int k = 0; k < 8; k++) { dr[k] = sr[k]; di[k] = si[k]; } return; }
-        __syncthreads();                                           // the row staging area / the previous readers are done
+        if (entry_barrier) __syncthreads(); else sync();             // the row staging area / the previous readers are done
 #pragma unroll
         for (int k = 0; k < 8; k++) { const int p = padj(widx(k)); RE[p] = sr[k].hi; IM[p] = si[k].hi; }
-        __syncthreads();
+        sync();
 #pragma unroll
         for (int k = 0; k < 8; k++) { const int p = padj(ridx(k)); dr[k].hi = RE[p]; di[k].hi = IM[p]; }
-        __syncthreads();
+        sync();
 #pragma unroll
         for (int k = 0; k < 8; k++) { const int p = padj(widx(k)); RE[p] = sr[k].lo; IM[p] = si[k].lo; }
-        __syncthreads();
+        sync();
 #pragma unroll
         for (int k = 0; k < 8; k++) { const int p = padj(ridx(k)); dr[k].lo = RE[p]; di[k].lo = IM[p]; }
     };
+    const std::false_type wg_wide; const std::true_type wave_local;
     // ---- pass 1: bits a; thread = (b,c,d) = tid, element j = a*512 + tid
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -358,14 +366,14 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     {
         // ---- exchange 1 -> 2.  Writer tid = (b, cd) holds a = 0..7; reader (a, cd) needs b = 0..7 of j = a*512 + b*64 + cd
         const int cd = tid & 63, ar = tid >> 6;
-        exchange(xr, xi, yr, yi, [&](int a) { return a * 512 + tid; }, [&](int b) { return ar * 512 + b * 64 + cd; });
+        exchange(xr, xi, yr, yi, [&](int a) { return a * 512 + tid; }, [&](int b) { return ar * 512 + b * 64 + cd; }, wg_wide, true);
         dif_radix8<64, !F64IN>(yr, yi, tb + ENC_TB_P64, cd);
         // ---- exchange 2 -> 3.  Writer (a, c, d) holds b = 0..7; reader (ab, d) needs c = 0..7 of j = ab*64 + c*8 + d
         const int d = tid & 7, ab = tid >> 3;
-        exchange(yr, yi, xr, xi, [&](int b) { return ar * 512 + b * 64 + cd; }, [&](int c) { return ab * 64 + c * 8 + d; });
+        exchange(yr, yi, xr, xi, [&](int b) { return ar * 512 + b * 64 + cd; }, [&](int c) { return ab * 64 + c * 8 + d; }, wave_local, true);
         dif_radix8<8, !F64IN>(xr, xi, tb + ENC_TB_P8, d);
         // ---- exchange 3 -> 4.  Writer (ab, d) holds c = 0..7; reader tid = abc needs d = 0..7 of j = tid*8 + d
-        exchange(xr, xi, yr, yi, [&](int c) { return ab * 64 + c * 8 + d; }, [&](int d4) { return tid * 8 + d4; });
+        exchange(xr, xi, yr, yi, [&](int c) { return ab * 64 + c * 8 + d; }, [&](int d4) { return tid * 8 + d4; }, wave_local, false);
         dif_radix8<1, !F64IN>(yr, yi, tb, 0);
     }
     // ---- recombination.  Position p = tid*8 + d holds Z_c with c = brev12(p) = brev3(d) << 9 | brev9(tid): the results are stored under c, and
@@ -377,20 +385,20 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
     const int npair = tid == 0 ? 5 : 4;
     __syncthreads();
 #pragma unroll
-    for (int d4 = 0; d4 < 8; d4++) { const int p = padj((int)((__brev((unsigned)d4) >> 29) << 9) | cbase); RE[p] = yr[d4].hi; IM[p] = yi[d4].hi; }
+    for (int d4 = 0; d4 < 8; d4++) { const int p = padj_fin((int)((__brev((unsigned)d4) >> 29) << 9) | cbase); RE[p] = yr[d4].hi; IM[p] = yi[d4].hi; }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 5; i++) if (i < npair) {
-        const int c = tid + 512 * i, pa = padj(c), pb = padj((h - c) & (h - 1));
+        const int c = tid + 512 * i, pa = padj_fin(c), pb = padj_fin((h - c) & (h - 1));
         Ar[i].hi = RE[pa]; Ai[i].hi = IM[pa]; Br[i].hi = RE[pb]; Bi[i].hi = -IM[pb];
     }
     __syncthreads();
 #pragma unroll
-    for (int d4 = 0; d4 < 8; d4++) { const int p = padj((int)((__brev((unsigned)d4) >> 29) << 9) | cbase); RE[p] = yr[d4].lo; IM[p] = yi[d4].lo; }
+    for (int d4 = 0; d4 < 8; d4++) { const int p = padj_fin((int)((__brev((unsigned)d4) >> 29) << 9) | cbase); RE[p] = yr[d4].lo; IM[p] = yi[d4].lo; }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 5; i++) if (i < npair) {
-        const int c = tid + 512 * i, pa = padj(c), pb = padj((h - c) & (h - 1));
+        const int c = tid + 512 * i, pa = padj_fin(c), pb = padj_fin((h - c) & (h - 1));
         Ar[i].lo = RE[pa]; Ai[i].lo = IM[pa]; Br[i].lo = RE[pb]; Bi[i].lo = -IM[pb];
     }
     // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c = zeta^-4c, zc = (Delta/n) zeta^-c, zh = (Delta/n) zeta^-(h-c)

@@ -238,11 +238,10 @@ __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out
 // Same transform with every exchange split in two rounds through a HALF image (33 KiB instead of 66 KiB): three
 // workgroups (12 waves) fit a CU instead of two.  Round structure:
 //   A->B  by column half h (pp = tid + 256 h  <=>  b < 16 or b >= 16): everyone writes its column h, (a, c) readers take 16 b's
-//   B->C  by row half (a < 8 or a >= 8): the 128 producers of the half write 32 b's each, everyone reads the group p = tid + 256 r
-//   C->out by row half: everyone writes its group r, then 4096 words are stored coalesced
+//   B->C / C->out: wave-private 16 x 16 transposes, one group b = (tid & 15) + 16 r at a time (see below)
 constexpr int H3_ROWA = 264;                  // 256 + 8 doubles per `a` row of the A->B half image
 constexpr int H3_DOUBLES = 16 * H3_ROWA;
-constexpr int H3_LDS_BYTES = (H3_DOUBLES > 8 * LDS_ROW ? H3_DOUBLES : 8 * LDS_ROW) * 8;      // 33,792 B (the B->C / C->out half image needs 8 * LDS_ROW = 4224 doubles as well)
+constexpr int H3_LDS_BYTES = H3_DOUBLES * 8;      // 33,792 B (the wave-private B->C / staging regions reuse 4 x 8 KiB of it)
 // The 13 stages that follow the first Cooley-Tukey stage, on ONE half (hs = 0: indices [0, n), hs = 1: [n, N)) of a row: after stage 1 the
 // halves are independent size-n transforms whose twiddles sit hs * (m / 2) further in each stage's table (tw[m + i], i in [hs m/2, (hs+1) m/2)).
 // first(j) returns the stage-1 output r_j of this half, j < n; store(j, x) receives the lazy result of output index hs * n + j.
@@ -275,50 +274,53 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
     ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + ab * 4 + g]; });
     ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + ab * 8 + g]; });
     ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + ab * 16 + g]; });
-    // ---- B->C rounds by row half, phase C per group
-    double wc[2][16];
+    // ---- B->C, phase C and the output staging are WAVE-PRIVATE.  Thread (a_b, c_b) of phase B and the phase-C owner of group (a, b) with
+    // a = tid >> 4 live in the same 16-lane quarter of a wave: the B->C exchange is a 16 x 16 transpose inside each quarter, and staging a wave's
+    // results for coalesced stores needs only that wave's four `a` rows.  So each wave works in its own 8 KiB of the (dead) A->B image with
+    // wave-level ordering only - no workgroup barrier after phase B - and takes its two groups b = (tid & 15) + 16 r one after the other, which
+    // keeps 16 + 16 values live instead of 32 + 32 (128 registers: four workgroups per CU).
+    __syncthreads();                                                      // the A->B image is dead
+    {
+        const int wv = tid >> 6, lane = tid & 63, al = lane >> 4, bk = lane & 15;
+        double *img = lds + wv * 1024;                                    // [a_local 4][c 16][bk 16], XOR-swizzled: conflict-free for all four access patterns
+        auto sw = [](int idx) { return idx ^ ((idx >> 4) & 15) ^ (((idx >> 8) & 1) << 4); };
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        __syncthreads();                                                  // previous readers are done
-        if ((a_b >> 3) == r) {
+        for (int r = 0; r < 2; r++) {
+            double wc[16];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // (the previous round's staging reads are issued)
 #pragma unroll
-            for (int b = 0; b < 32; b++) lds[(a_b & 7) * LDS_ROW + c_b * 33 + b] = v[b];
-        }
-        __syncthreads();
-        const int p = tid + 256 * r, a = p >> 5, b = p & 31;
+            for (int k = 0; k < 16; k++) img[sw(al * 256 + c_b * 16 + k)] = v[16 * r + k];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int c = 0; c < 16; c++) wc[r][c] = lds[(a & 7) * LDS_ROW + c * 33 + b];
-    }
+            for (int c = 0; c < 16; c++) wc[c] = img[sw(al * 256 + c * 16 + bk)];
+            const int p = a_b * 32 + 16 * r + bk;                         // group (a, b)
+            double tl[16];
+            {
+                const double2 *pk = pack + (size_t)((p >> 6) + 8 * hs) * 512 + (p & 63);
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int p = tid + 256 * r;
-        double tl[16];
-        {
-            const double2 *pk = pack + (size_t)((p >> 6) + 8 * hs) * 512 + (p & 63);
+                for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
+            }
+            ct_stage<16, 8>(wc, q, qinv, [&](int g) { return tl[0 + g]; });
+            ct_stage<16, 4>(wc, q, qinv, [&](int g) { return tl[1 + g]; });
+            ct_stage<16, 2>(wc, q, qinv, [&](int g) { return tl[3 + g]; });
+            ct_stage<16, 1>(wc, q, qinv, [&](int g) { return tl[7 + g]; });
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
-        }
-        ct_stage<16, 8>(wc[r], q, qinv, [&](int g) { return tl[0 + g]; });
-        ct_stage<16, 4>(wc[r], q, qinv, [&](int g) { return tl[1 + g]; });
-        ct_stage<16, 2>(wc[r], q, qinv, [&](int g) { return tl[3 + g]; });
-        ct_stage<16, 1>(wc[r], q, qinv, [&](int g) { return tl[7 + g]; });
-    }
-    // ---- C->out rounds by row half
+            for (int c = 0; c < 16; c++) img[sw(al * 256 + c * 16 + bk)] = wc[c];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // output j = a*512 + (16 r + b')*16 + c: per `a` row 256 consecutive words, 64 lanes at a time
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int p = tid + 256 * r, a = p >> 5, b = p & 31;
-        __syncthreads();
+            for (int ai = 0; ai < 4; ai++) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) lds[(a & 7) * LDS_ROW + c * 33 + b] = wc[r][c];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int jj = k * 256 + tid, a8 = jj >> 9, x = jj & 511, bb = x >> 4, c = x & 15;      // j = r*4096 + jj
-            store(r * 4096 + jj, lds[a8 * LDS_ROW + c * 33 + bb]);
+                for (int qd = 0; qd < 4; qd++) {
+                    const int x = qd * 64 + lane;                        // b' = x >> 4, c = x & 15
+                    store((4 * wv + ai) * 512 + 256 * r + x, img[sw(ai * 256 + (x & 15) * 16 + (x >> 4))]);
+                }
+            }
         }
     }
 }
-__global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     size_t row; int m;
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(256) k_ntt_half3(const double *pc_all, u64 *ou
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
 // CU, instead of one 512-thread workgroup holding a 132 KiB image.  Each half reads both halves of the input (the second read is an L2 hit: the two
 // workgroups of a row are numbered b and b + 8, same XCD) and pays the stage-1 product itself.
-__global__ void __launch_bounds__(256) k_ntt_fwd_split(const u64 *in_, u64 *out_, size_t nrows, ModPattern pat, RowMap rm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+__global__ void __launch_bounds__(256, 4) k_ntt_fwd_split(const u64 *in_, u64 *out_, size_t nrows, ModPattern pat, RowMap rm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     const size_t b = blockIdx.x, row = (b / 16) * 8 + b % 8; const int hs = (int)((b / 8) & 1);
