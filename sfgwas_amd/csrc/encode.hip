@@ -10,8 +10,8 @@
 //   * v is real, so the DFT is done as a length-n/2 complex FFT of z_m = u_2m + i u_2m+1 plus one
 //     recombination pass, and only p_0..p_{n-1} are produced: p_n = 0 and p_{N-c} = -p_c follow from
 //     invariance under X -> X^-1 (the NTT kernel expands them, ntt.hip IN_MODE 1).
-// One 512-thread workgroup encodes one diagonal; the 4096-point FFT lives in a 144 KiB structure-of-arrays
-// LDS image (re.hi, re.lo, im.hi, im.lo) and runs as 4 register passes of 3 radix-2 DIF stages.
+// One 512-thread workgroup encodes one diagonal; the 4096-point FFT runs as 4 radix-8 register passes whose exchanges
+// move the high parts of all points through a 64 KiB LDS image (re, im), then the low parts.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cmath>
