@@ -469,6 +469,33 @@ inline void MultByConstAndAddDev(CryptoParams *cps, const DevCipherVector &ct0, 
     for (int m = 0; m <= level; m++) sc[m] = constant != 0 ? scaleUpExact(constant, scale, qi[m]) % qi[m] : 0;
     cps->check(sfg_ct_mul_scalar_add_dev(cps->ctx, in.ptr(), sc.data(), ctOut.ptr(), (int)ctOut.n, level), "MultByConstAndAdd");
 }
+// eval.AddConstNew / eval.NegNew on device vectors (the receiver keeps its level and scale)
+inline DevCipherVector AddConstDev(CryptoParams *cps, const DevCipherVector &X, double constant, const std::vector<uint64_t> &qi) {
+    std::vector<uint64_t> sc(X.level + 1, 0);
+    for (int m = 0; m <= X.level; m++) sc[m] = constant != 0 ? scaleUpExact(constant, X.scale, qi[m]) : 0;
+    DevCipherVector o = NewDevCipherVector(cps, X.n, X.level, X.scale);
+    cps->check(sfg_ct_add_scalar_dev(cps->ctx, X.ptr(), sc.data(), o.ptr(), (int)X.n, X.level), "AddConst");
+    return o;
+}
+inline DevCipherVector NegDev(CryptoParams *cps, const DevCipherVector &X, const std::vector<uint64_t> &qi) {
+    std::vector<uint64_t> sc(X.level + 1);
+    for (int m = 0; m <= X.level; m++) sc[m] = qi[m] - 1;
+    DevCipherVector o = NewDevCipherVector(cps, X.n, X.level, X.scale);
+    cps->check(sfg_ct_mul_scalar_dev(cps->ctx, X.ptr(), sc.data(), o.ptr(), (int)X.n, X.level), "Neg");
+    return o;
+}
+// crypto.CInverse (basics.go:627-640) = eval.InverseNew(ct, intv.Iter) per ciphertext.  PARITY UNPINNED - lattigo v2.1.0 ckks/algorithms.go restated
+// (the fork's source is absent): Goldschmidt iteration for values in (0, 2): cbar = 1 - x, res = 1 + cbar, then steps - 1 times
+// cbar = Rescale(cbar^2), res = Rescale((1 + cbar) * res); every product is MulRelin + Rescale(params.Scale()) (= CMultDev), binary ops at the lower level.
+inline DevCipherVector CInverseDev(CryptoParams *cps, const DevCipherVector &X, int steps, const std::vector<uint64_t> &qi) {
+    DevCipherVector cbar = AddConstDev(cps, NegDev(cps, X, qi), 1.0, qi);
+    DevCipherVector res = AddConstDev(cps, cbar, 1.0, qi);
+    for (int i = 1; i < steps; i++) {
+        cbar = CMultDev(cps, cbar, cbar, qi);
+        res = CMultDev(cps, AddConstDev(cps, cbar, 1.0, qi), res, qi);
+    }
+    return res;
+}
 inline DevCipherVector viewOne(const DevCipherVector &v, size_t j) { DevCipherVector o = v; o.off = v.off + j * detail::ctWords(v.cps, v.level); o.n = 1; return o; }
 }  // namespace crypto
 

@@ -31,6 +31,10 @@ int main(int argc, char **argv) {
         dump(dir + "/innerprod_vec.bin", {gwas::CMultMatInnerProdVectorDev(cps.get(), M, Nm.row(0), mcols, qi)});
         dump(dir + "/col_col.bin", gwas::CMultMatColTimesToColDev(cps.get(), M, Nm, rows, false, qi));
         dump(dir + "/col_row.bin", gwas::CMultMatColTimesToColDev(cps.get(), M, Nm, rows, true, qi));
+        // crypto.CInverse (basics.go:627-640) on the column of M, 3 iterations
+        crypto::DevCipherVector col = crypto::NewDevCipherVector(cps.get(), (size_t)rows, qlevel, SC);
+        for (int i = 0; i < rows; i++) cps->check(sfg_memcpy_d2d(cps->ctx, col.ptr(i), M.row(i).ptr(), crypto::detail::ctWords(cps.get(), qlevel) * 8), "d2d");
+        dump(dir + "/inverse.bin", {crypto::CInverseDev(cps.get(), col, 3, qi)});
         std::cout << "OK" << std::endl;
         return 0;
     } catch (const std::exception &e) { std::cerr << "ERROR: " << e.what() << std::endl; return 1; }

@@ -325,6 +325,17 @@ class OCt:
     def innersum(self):
         return self.like(_orc_innersum(self.ring, self.keys, self.level, [self.data]), self.level, self.scale)
 
+    def add_const(self, c):
+        out = np.zeros_like(self.data)
+        ol.lib().orc_add_const(self.ring.h, self.level, ol.p64(self.data), C.c_double(c), C.c_double(self.scale), ol.p64(out))
+        return self.like(out, self.level, self.scale)
+
+    def neg(self):
+        out = np.zeros_like(self.data); sm = C.c_double(0)
+        ol.lib().orc_mul_const(self.ring.h, self.level, ol.p64(self.data), C.c_double(-1.0), ol.p64(out), C.byref(sm))
+        assert sm.value == 1.0
+        return self.like(out, self.level, self.scale)
+
     def add(self, o):
         l = min(self.level, o.level); a, b = self.drop(l), o.drop(l)
         out = np.zeros_like(a.data)
@@ -392,6 +403,15 @@ def test_logistic_path_ciphertext_matrix_helpers_match_the_oracle(tmp_path):
                 multi = elem.cmult(Mo[kk])
                 res[c] = multi if res[c] is None else multi.add(res[c])
         assert np.array_equal(load(name, res), np.stack([x.data for x in res])), name
+    # crypto.CInverse = eval.InverseNew(ct, 3) (lattigo v2.1.0 algorithms.go restated, parity unpinned): same composition of oracle ops
+    inv = []
+    for x in Mo:
+        cbar = x.neg().add_const(1.0); res = cbar.add_const(1.0)
+        for _ in range(2):
+            cbar = cbar.cmult(cbar); res = cbar.add_const(1.0).cmult(res)
+        inv.append(res)
+    assert inv[0].level == qlevel - 3                       # cbar^2 and the product with res each consume one level per iteration, in parallel
+    assert np.array_equal(load("inverse.bin", inv), np.stack([x.data for x in inv])), "CInverse"
 
 
 @pytest.mark.gpu
