@@ -240,8 +240,9 @@ __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out
 //   A->B  by column half h (pp = tid + 256 h  <=>  b < 16 or b >= 16): everyone writes its column h, (a, c) readers take 16 b's
 //   B->C / C->out: wave-private 16 x 16 transposes, one group b = (tid & 15) + 16 r at a time (see below)
 constexpr int H3_ROWA = 264;                  // 256 + 8 doubles per `a` row of the A->B half image
-constexpr int H3_DOUBLES = 16 * H3_ROWA;
-constexpr int H3_LDS_BYTES = H3_DOUBLES * 8;      // 33,792 B (the wave-private B->C / staging regions reuse 4 x 8 KiB of it)
+constexpr int H3_WREG = 4 * 272;              // doubles per wave-private region (B->C transposes, output staging)
+constexpr int H3_DOUBLES = 16 * H3_ROWA > 4 * H3_WREG ? 16 * H3_ROWA : 4 * H3_WREG;
+constexpr int H3_LDS_BYTES = H3_DOUBLES * 8;      // 34,816 B: four workgroups per CU
 // The 13 stages that follow the first Cooley-Tukey stage, on ONE half (hs = 0: indices [0, n), hs = 1: [n, N)) of a row: after stage 1 the
 // halves are independent size-n transforms whose twiddles sit hs * (m / 2) further in each stage's table (tw[m + i], i in [hs m/2, (hs+1) m/2)).
 // first(j) returns the stage-1 output r_j of this half, j < n; store(j, x) receives the lazy result of output index hs * n + j.
@@ -282,8 +283,8 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
     __syncthreads();                                                      // the A->B image is dead
     {
         const int wv = tid >> 6, lane = tid & 63, al = lane >> 4, bk = lane & 15;
-        double *img = lds + wv * 1024;                                    // [a_local 4][c 16][bk 16], XOR-swizzled: conflict-free for all four access patterns
-        auto sw = [](int idx) { return idx ^ ((idx >> 4) & 15) ^ (((idx >> 8) & 1) << 4); };
+        double *img = lds + wv * H3_WREG;                                 // [a_local 4][c 16][bk 16 (+1 pad)]: rows of 17 doubles, `a` blocks of 272 (= 16 mod 32):
+        auto sw = [](int idx) { return (idx >> 8) * 272 + ((idx >> 4) & 15) * 17 + (idx & 15); };   // conflict-free, and every access is base + immediate
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             double wc[16];
