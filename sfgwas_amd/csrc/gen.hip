@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) k_fill_uniform(u64 *rows, int nl, u64 see
 }
 extern "C" int sfg_fill_uniform_ct_dev(sfg_ctx *ctx, uint64_t *ct, int nct, int level, uint64_t seed) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (level < 0 || level >= ctx->nq || nct < 0) SFG_FAIL(ctx, "fill_uniform_ct: level %d / count %d out of range", level, nct);
     const int nl = level + 1; const size_t rows = (size_t)nct * 2 * nl;
     if (!rows) return 0;
     hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)(rows * (SFG_N / 256))), dim3(256), 0, ctx->stream, (u64 *)ct, nl, (u64)seed, ctx->modc, 1);

@@ -386,5 +386,7 @@ int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct
 }
 extern "C" int sfg_ct_add_dev(sfg_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, int nct, int level) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "evaluator op: level %d out of range", level);
+    if (nct < 0) SFG_FAIL(ctx, "evaluator op: negative ciphertext count");
     return launch_ct_add(ctx, (const u64 *)a, (const u64 *)b, (u64 *)out, (size_t)nct, level);
 }
