@@ -239,6 +239,7 @@ bool mac_use_dma(const sfg_ctx *ctx) { return !ctx->cfg.mac_reg; }
 extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt, uint64_t *out, int K, int R, int Ncols, int L, int accumulate) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac: L out of range");
+    if (K < 1 || R < 1 || Ncols < 1) SFG_FAIL(ctx, "sfg_mac: K, R and Ncols must be positive (got %d, %d, %d)", K, R, Ncols);
     PhaseTimer t(ctx, "mac");
     int rc;
     if (!mac_use_dma(ctx)) rc = launch_mac(ctx, (const u64 *)rot, (const u64 *)pt, (u64 *)out, K, R, Ncols, L, accumulate);
