@@ -143,9 +143,25 @@ void sfg_encoder_destroy(SfgShared *sh) {
 // Tiled: a workgroup produces 128 shifts x 128 columns.  The X elements it needs, X[(S0+J0+u) mod n][J0+jj] with
 // u = s + jj < 255, are 255 row segments of 128 contiguous bytes (for the transposed operand: 128 rows of 255
 // contiguous bytes), staged through LDS so that both the HBM reads and the D writes are contiguous runs.
-constexpr int SK_T = 128, SK_U = 2 * SK_T - 1, SK_PITCH = 132;
-__global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D) {
-    __shared__ int8_t tile[SK_U * SK_PITCH];                 // tile[u][jj]
+// The tile is read back as DWORDS and the diagonal bytes are gathered with v_perm_b32: a thread produces 4 shifts x 4 columns from 7 dword reads
+// (10 byte-permutes; transposed operand: 7 reads, 3 funnel shifts, 8 permutes) instead of 16 byte reads, and missing -> 0 is applied to 4 packed bytes at once.
+constexpr int SK_T = 128, SK_U = 2 * SK_T - 1, SK_PITCH = 144, SK_PITCH_T = 272;      // pitches: multiples of 16 bytes, odd multiples of 4 dwords + ... (dword stride 4 * pitch / 4 + 1 = 17 mod 64: conflict-free gathers)
+constexpr int SK_LDS = SK_U * SK_PITCH > SK_T * SK_PITCH_T ? SK_U * SK_PITCH : SK_T * SK_PITCH_T;
+// genotype bytes -> contribution bytes: missing (negative) -> 0 (matmult.go:1292-1295), optional squaring in int8 arithmetic (:1301-1303), 4 at a time
+__device__ __forceinline__ unsigned sk_clean(unsigned w, int square) {
+    const unsigned t = w & 0x80808080u;
+    w &= ~((t << 1) - (t >> 7));                          // 0xFF in every byte whose sign bit is set (no borrow crosses a byte: each term is 0x100 - 0x01)
+    if (square) {
+        unsigned o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const unsigned v = (w >> (8 * k)) & 0xFFu; o |= ((v * v) & 0xFFu) << (8 * k); }
+        w = o;
+    }
+    return w;
+}
+template <bool TR>
+__global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int r, int c, int square, int8_t *D) {
+    __shared__ __attribute__((aligned(16))) int8_t tile[SK_LDS];          // tile[u][jj] (pitch 132); transposed operand: tile[jj][u] (pitch 260)
     const int n = SFG_SLOTS, tid = threadIdx.x;
     const int J0 = blockIdx.x * SK_T, S0 = blockIdx.y * SK_T;
     // 4 consecutive bytes along the contiguous axis: one dword load when the run is inside the block and 4-byte aligned
@@ -156,41 +172,61 @@ __global__ void __launch_bounds__(256) k_skew(const int8_t *blk, size_t ld, int 
         for (int k = 0; k < 4; k++) if (k < nvalid) w |= (unsigned)(uint8_t)src[k] << (8 * k);
         return w;
     };
-    if (!transposed) {
-        // rows u (255) x 128 bytes: thread = (row-in-pass tid >> 5, dword tid & 31)
-        const int q = tid & 31;
-        for (int u = tid >> 5; u < SK_U; u += 8) {
+    // 16 bytes per lane when the run is inside the block and 16-byte aligned (ld a multiple of 16: every bench shape), else four guarded dwords
+    auto load16 = [&](const int8_t *src, int nvalid) -> uint4 {
+        if (nvalid >= 16 && ((uintptr_t)src & 15) == 0) return *reinterpret_cast<const uint4 *>(src);
+        return make_uint4(load4(src, nvalid), load4(src + 4, nvalid - 4), load4(src + 8, nvalid - 8), load4(src + 12, nvalid - 12));
+    };
+    if (!TR) {
+        // rows u (255) x 128 bytes: thread = (row-in-pass tid >> 3, 16-byte piece tid & 7)
+        const int x = tid & 7;
+        for (int u = tid >> 3; u < SK_U; u += 32) {
             int i = S0 + J0 + u; if (i >= n) i -= n;
-            const int j = J0 + 4 * q;
-            const unsigned w = i < r ? load4(blk + (size_t)i * ld + j, c - j) : 0u;
-            *reinterpret_cast<unsigned *>(tile + u * SK_PITCH + 4 * q) = w;
+            const int j = J0 + 16 * x;
+            const uint4 w = i < r ? load16(blk + (size_t)i * ld + j, c - j) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(tile + u * SK_PITCH + 16 * x) = w;
         }
     } else {
         // element (i, j) lives at blk[j*ld + i]: rows jj (128) x 256 contiguous bytes along u (S0 + J0 and the wrap
-        // point are multiples of 128, so a dword never straddles the wrap)
-        for (int idx = tid; idx < SK_T * 64; idx += 256) {
-            const int jj = idx >> 6, u = (idx & 63) * 4;
+        // point are multiples of 128, so a 16-byte piece never straddles the wrap); kept in that orientation
+        const int x = tid & 15;
+        for (int jj = tid >> 4; jj < SK_T; jj += 16) {
+            const int u = 16 * x;
             int i = S0 + J0 + u; if (i >= n) i -= n;
             const int j = J0 + jj;
-            const unsigned w = j < c ? load4(blk + (size_t)j * ld + i, r - i) : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (u + k < SK_U) tile[(u + k) * SK_PITCH + jj] = (int8_t)(w >> (8 * k));
+            const uint4 w = j < c ? load16(blk + (size_t)j * ld + i, r - i) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(tile + jj * SK_PITCH_T + u) = w;
         }
     }
     __syncthreads();
-    // D[S0+s][J0 + 4q .. 4q+3] = tile[s + jj][jj]
+    // thread: columns 4q .. 4q+3, shifts s0 .. s0+3 for four s0.  D[S0+s][J0+jj] = X-tile element (u = s + jj, jj)
     const int q = tid & 31;
-    for (int s = tid >> 5; s < SK_T; s += 8) {
-        unsigned packed = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int jj = 4 * q + k;
-            int v = tile[(s + jj) * SK_PITCH + jj];
-            if (v < 0) v = 0;                    // missing -> 0 (matmult.go:1292-1295)
-            if (square) v = v * v;               // :1301-1303
-            packed |= (unsigned)(v & 0xFF) << (8 * k);
+    for (int it = 0; it < 4; it++) {
+        const int s0 = 4 * ((tid >> 5) + 8 * it);
+        unsigned out[4];
+        if (!TR) {
+            unsigned W[7], E[6];
+#pragma unroll
+            for (int k = 0; k < 7; k++) W[k] = *reinterpret_cast<const unsigned *>(tile + (s0 + 4 * q + k) * SK_PITCH + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 6; k++) E[k] = __builtin_amdgcn_perm(W[k + 1], W[k], 0x07020500u);          // [W_k.b0, W_k+1.b1, W_k.b2, W_k+1.b3]
+#pragma unroll
+            for (int m = 0; m < 4; m++) out[m] = __builtin_amdgcn_perm(E[m + 2], E[m], 0x07060100u);        // [W_m.b0, W_m+1.b1, W_m+2.b2, W_m+3.b3]
+        } else {
+            unsigned V[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {                                    // row jj = 4q + t, bytes s0 + 4q + t .. + 3: shift t inside an aligned pair
+                const unsigned *rowp = reinterpret_cast<const unsigned *>(tile + (4 * q + t) * SK_PITCH_T + s0 + 4 * q);
+                V[t] = t ? __builtin_amdgcn_alignbyte(rowp[1], rowp[0], (unsigned)t) : rowp[0];
+            }
+            const unsigned P0 = __builtin_amdgcn_perm(V[1], V[0], 0x05010400u), P1 = __builtin_amdgcn_perm(V[1], V[0], 0x07030602u);
+            const unsigned Q0 = __builtin_amdgcn_perm(V[3], V[2], 0x05010400u), Q1 = __builtin_amdgcn_perm(V[3], V[2], 0x07030602u);
+            out[0] = __builtin_amdgcn_perm(Q0, P0, 0x05040100u); out[1] = __builtin_amdgcn_perm(Q0, P0, 0x07060302u);
+            out[2] = __builtin_amdgcn_perm(Q1, P1, 0x05040100u); out[3] = __builtin_amdgcn_perm(Q1, P1, 0x07060302u);
         }
-        *reinterpret_cast<unsigned *>(D + (size_t)(S0 + s) * n + J0 + 4 * q) = packed;
+#pragma unroll
+        for (int m = 0; m < 4; m++) *reinterpret_cast<unsigned *>(D + (size_t)(S0 + s0 + m) * n + J0 + 4 * q) = sk_clean(out[m], square);
     }
 }
 
@@ -452,7 +488,8 @@ int encode_set_attrs(sfg_ctx *ctx) {
 }
 
 int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int transposed, int square, int8_t *D) {
-    hipLaunchKernelGGL(k_skew, dim3(SFG_SLOTS / SK_T, SFG_SLOTS / SK_T), dim3(256), 0, ctx->stream, blk, ld, r, c, transposed, square, D);
+    if (transposed) hipLaunchKernelGGL(k_skew<true>, dim3(SFG_SLOTS / SK_T, SFG_SLOTS / SK_T), dim3(256), 0, ctx->stream, blk, ld, r, c, square, D);
+    else hipLaunchKernelGGL(k_skew<false>, dim3(SFG_SLOTS / SK_T, SFG_SLOTS / SK_T), dim3(256), 0, ctx->stream, blk, ld, r, c, square, D);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
