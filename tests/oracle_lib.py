@@ -13,6 +13,8 @@ _SO = os.path.join(_ROOT, "oracle", "_build", "liboracle.so")
 
 
 def build_oracle():
+    if os.environ.get("SFG_ORACLE_SO"):            # e.g. a sanitizer build of the oracle (tools/oracle_asan.sh)
+        return os.environ["SFG_ORACLE_SO"]
     src = os.path.join(_ROOT, "oracle", "sfgwas_oracle.c")
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
