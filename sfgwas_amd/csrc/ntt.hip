@@ -251,12 +251,15 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
     double v[32];
     const int a_b = tid >> 4, c_b = tid & 15;                  // phase B identity
     // ---- phase A (two columns) interleaved with the two A->B rounds
+    // (both columns' stage-1 values are formed up front: all 64 input loads are in flight together and their latency is paid once)
+    double w2[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int a = 0; a < 16; a++) w2[h][a] = first(a * 512 + tid + 256 * h);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const int pp = tid + 256 * h;
-        double w[16];
-#pragma unroll
-        for (int a = 0; a < 16; a++) w[a] = first(a * 512 + pp);
+        double (&w)[16] = w2[h];
         ct_stage<16, 8>(w, q, qinv, [&](int g) { return tw[2 + hs + g]; });
         ct_stage<16, 4>(w, q, qinv, [&](int g) { return tw[4 + 2 * hs + g]; });
         ct_stage<16, 2>(w, q, qinv, [&](int g) { return tw[8 + 4 * hs + g]; });
