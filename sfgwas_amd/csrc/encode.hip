@@ -274,14 +274,23 @@ template <bool GRID> __device__ __forceinline__ dd fx_dot2(dd a, dd w, dd b, dd 
     const double p1 = a.hi * w.hi, e1 = fma(a.hi, w.hi, -p1);
     const double bh = sgn * b.hi, bl = sgn * b.lo;
     const double p2 = bh * x.hi, e2 = fma(bh, x.hi, -p2);
+    if (GRID) {
+        // each product is split on the grid by itself (the remainders p - h are exact, |.| <= 2^-32), the grid parts add exactly: no two_sum
+        const double h1 = (p1 + GRID_M) - GRID_M, h2 = (p2 + GRID_M) - GRID_M;
+        double lo = (p1 - h1) + (p2 - h2);
+        lo += e1 + e2;
+        lo = fma(a.hi, w.lo, lo); lo = fma(a.lo, w.hi, lo);
+        lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
+        return dd_make(h1 + h2, lo);
+    }
     dd s = dd_two_sum(p1, p2);
     double lo = e1 + e2;
     lo = fma(a.hi, w.lo, lo); lo = fma(a.lo, w.hi, lo);
     lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
-    return GRID ? grid_split(s.hi, s.lo + lo) : dd_quick(s.hi, s.lo + lo);
+    return dd_quick(s.hi, s.lo + lo);
 }
 #ifndef SFG_ENC_DIAG
-#define SFG_ENC_DIAG 0          // timing diagnostics only (wrong results): 1 no twiddle loads, 2 no recombination arithmetic, 4 no exchanges, 8 no twiddle products
+#define SFG_ENC_DIAG 0          // timing diagnostics only (wrong results): 1 no pass-twiddle loads, 2 no recombination arithmetic, 4 no exchanges, 8 no twiddle products, 16 no recombination-twiddle loads
 #endif
 __device__ __forceinline__ void tw_at(const double4 *tab, int idx, dd &wr, dd &wi) {
     if (SFG_ENC_DIAG & 1) { wr = dd_make(0.7 + idx * 1e-9, 1e-18); wi = dd_make(0.3 - idx * 1e-9, 2e-18); return; }
