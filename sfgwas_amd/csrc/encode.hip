@@ -250,6 +250,17 @@ __device__ __forceinline__ dd dd_dot2(dd a, dd w, dd b, dd x, double sgn) {     
     lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
     return dd_quick(s.hi, s.lo + lo);
 }
+// the same without the final renormalisation: (hi, lo) with |lo| a few ulps of hi - all that dd_round_away needs
+__device__ __forceinline__ dd dd_dot2_raw(dd a, dd w, dd b, dd x, double sgn) {
+    const double p1 = a.hi * w.hi, e1 = fma(a.hi, w.hi, -p1);
+    const double bh = sgn * b.hi, bl = sgn * b.lo;
+    const double p2 = bh * x.hi, e2 = fma(bh, x.hi, -p2);
+    dd s = dd_two_sum(p1, p2);
+    double lo = e1 + e2;
+    lo = fma(a.hi, w.lo, lo); lo = fma(a.lo, w.hi, lo);
+    lo = fma(bh, x.lo, lo); lo = fma(bl, x.hi, lo);
+    return dd_make(s.hi, s.lo + lo);
+}
 __device__ __forceinline__ void cdd_mul_ip(dd &re, dd &im, dd wr, dd wi) {
     const dd r = dd_dot2(re, wr, im, wi, -1.0), i = dd_dot2(re, wi, im, wr, 1.0);
     re = r; im = i;
@@ -466,7 +477,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         {
             dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
             dd zr = dd_make(zc.x, zc.y), zi = dd_make(zc.z, zc.w);
-            dd wr = dd_dot2(Wr, zr, Wi, zi, -1.0), wi = dd_dot2(Wr, zi, Wi, zr, 1.0);
+            dd wr = dd_dot2_raw(Wr, zr, Wi, zi, -1.0), wi = dd_dot2_raw(Wr, zi, Wi, zr, 1.0);       // (rounded next: no renormalisation needed)
             pc[c] = dd_round_away(wr, near_tie);
             if (c > 0) pc[n - c] = -dd_round_away(wi, near_tie);
         }
@@ -476,7 +487,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             const double4 zh = nt ? make_double4(0.5 + c * 1e-9, 1e-18, 0.45, 1e-18) : tb[ENC_TB_RZ2 + c];
             dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
             dd zr = dd_make(zh.x, zh.y), zi = dd_make(zh.z, zh.w);
-            dd wr = dd_dot2(Wr, zr, Wi, zi, -1.0), wi = dd_dot2(Wr, zi, Wi, zr, 1.0);
+            dd wr = dd_dot2_raw(Wr, zr, Wi, zi, -1.0), wi = dd_dot2_raw(Wr, zi, Wi, zr, 1.0);       // (rounded next: no renormalisation needed)
             pc[cc] = dd_round_away(wr, near_tie);
             if (cc < h) pc[n - cc] = -dd_round_away(wi, near_tie);
         }
