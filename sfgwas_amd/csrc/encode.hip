@@ -118,7 +118,7 @@ int sfg_encoder_init(sfg_ctx *ctx) {
             const double4 w = zat(idx); const dd re = dd_mul_d(dd_make(w.x, w.y), son), im = dd_mul_d(dd_make(w.z, w.w), son);
             return make_double4(re.hi, re.lo, im.hi, im.lo);
         };
-        for (int c = 0; c < ENC_TB_RLEN; c++) { tb[ENC_TB_RW + c] = zat(4 * c); tb[ENC_TB_RZ + c] = scaled(c); tb[ENC_TB_RZ2 + c] = scaled(ENC_H - c); }
+        for (int c = 0; c < ENC_TB_RLEN; c++) { { const double4 w = zat(4 * c); tb[ENC_TB_RW + c] = make_double4(0.5 * w.x, 0.5 * w.y, 0.5 * w.z, 0.5 * w.w); } tb[ENC_TB_RZ + c] = scaled(c); tb[ENC_TB_RZ2 + c] = scaled(ENC_H - c); }
     }
     std::vector<uint16_t> tinv(n);
     u64 g = 1;
@@ -358,10 +358,12 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
 // The double-double pipeline carries ~2^-100 relative error (absolute ~2^-65 on these magnitudes; ~2^-59 on the fixed grid), the reference's EncoderBig 256
 // bits.  A coefficient whose exact value lies within 2^-40 of a rounding tie is counted (sfg_ctx_encoder_near_ties): the two
 // encoders can only disagree on such a coefficient, so a zero count PROVES the block was rounded as the reference rounds it.
+template <bool EXACT_TIES>
 __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {                // integer-valued double
     double nn = __builtin_rint(x.hi);
-    double diff = (x.hi - nn) + x.lo;
+    double diff = (x.hi - nn) + x.lo;                                                         // |diff| <= 1/2 + |x.lo|
     near_tie += __builtin_fabs(__builtin_fabs(diff) - 0.5) < 0x1p-40 ? 1u : 0u;
+    if (!EXACT_TIES) return nn + __builtin_rint(diff);      // = the rule below whenever |diff| != 1/2; an exact tie (impossible for integer slot values at Delta/n = 2^k) is counted above
     const bool up = (diff > 0.5) | ((diff == 0.5) & (nn >= 0)), dn = (diff < -0.5) | ((diff == -0.5) & (nn <= 0));      // (no short-circuit: selects, not branches)
     return nn + (up ? 1.0 : 0.0) - (dn ? 1.0 : 0.0);
 }
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         const int c = tid + 512 * i, pa = padj_fin(c), pb = padj_fin((h - c) & (h - 1));
         Ar[i].lo = RE[pa]; Ai[i].lo = IM[pa]; Br[i].lo = RE[pb]; Bi[i].lo = -IM[pb];
     }
-    // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c = zeta^-4c, zc = (Delta/n) zeta^-c, zh = (Delta/n) zeta^-(h-c)
+    // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c / 2 = zeta^-4c / 2, zc = (Delta/n) zeta^-c, zh = (Delta/n) zeta^-(h-c)
     auto recomb = [&](int c, dd Ar, dd Ai, dd Br, dd Bi) {
         // (genotype rows: A and B are sums on the fixed grid, so the recombination adds are exact two-flop grid adds as well)
         constexpr bool GRID = !F64IN;
@@ -469,8 +471,8 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         const double4 wo = nt ? make_double4(0.7 + c * 1e-9, 1e-18, 0.3, 1e-18) : tb[ENC_TB_RW + c];
         const double4 zc = nt ? make_double4(0.6 + c * 1e-9, 1e-18, 0.4, 1e-18) : tb[ENC_TB_RZ + c];
         dd Xr = half(radd(Ar, Br)), Xi = half(radd(Ai, Bi));
-        dd Dr = half(rsub(Ar, Br)), Di = half(rsub(Ai, Bi));
-        dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/(2i) = -i (A-B)/2
+        dd Dr = rsub(Ar, Br), Di = rsub(Ai, Bi);                     // (the table holds omega^-c / 2: exact halving, one product instead of four)
+        dd Or = Di, Oi = dd_neg(Dr);                                // (A-B)/i = -i (A-B)
         dd wor = dd_make(wo.x, wo.y), woi = dd_make(wo.z, wo.w);
         dd Yr = fx_dot2<GRID>(Or, wor, Oi, woi, -1.0), Yi = fx_dot2<GRID>(Or, woi, Oi, wor, 1.0);
         // W_c
@@ -478,8 +480,8 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
             dd zr = dd_make(zc.x, zc.y), zi = dd_make(zc.z, zc.w);
             dd wr = dd_dot2_raw(Wr, zr, Wi, zi, -1.0), wi = dd_dot2_raw(Wr, zi, Wi, zr, 1.0);       // (rounded next: no renormalisation needed)
-            pc[c] = dd_round_away(wr, near_tie);
-            if (c > 0) pc[n - c] = -dd_round_away(wi, near_tie);
+            pc[c] = dd_round_away<F64IN>(wr, near_tie);
+            if (c > 0) pc[n - c] = -dd_round_away<F64IN>(wi, near_tie);
         }
         // W_{h-c}  (c = 0 gives W_h)
         if (c < h / 2) {
@@ -488,8 +490,8 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
             dd zr = dd_make(zh.x, zh.y), zi = dd_make(zh.z, zh.w);
             dd wr = dd_dot2_raw(Wr, zr, Wi, zi, -1.0), wi = dd_dot2_raw(Wr, zi, Wi, zr, 1.0);       // (rounded next: no renormalisation needed)
-            pc[cc] = dd_round_away(wr, near_tie);
-            if (cc < h) pc[n - cc] = -dd_round_away(wi, near_tie);
+            pc[cc] = dd_round_away<F64IN>(wr, near_tie);
+            if (cc < h) pc[n - cc] = -dd_round_away<F64IN>(wi, near_tie);
         }
     };
 #pragma unroll
