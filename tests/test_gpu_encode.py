@@ -75,4 +75,7 @@ def test_encoder_near_tie_audit(env):
     ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, tie.ctypes.data_as(C.POINTER(C.c_double)), 1, out1.ctypes.data_as(C.POINTER(C.c_int64))), "encode")
     assert out1[0, 0] == 12346 and not out1[0, 1:].any()
     assert ctx.encoder_near_ties(reset=True) >= 1
+    ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, (-tie).ctypes.data_as(C.POINTER(C.c_double)), 1, out1.ctypes.data_as(C.POINTER(C.c_int64))), "encode")
+    assert out1[0, 0] == -12346 and not out1[0, 1:].any()                  # half away from zero on the negative side as well
+    assert ctx.encoder_near_ties(reset=True) >= 1
     assert ctx.encoder_near_ties() == 0
