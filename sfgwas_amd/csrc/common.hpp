@@ -221,6 +221,23 @@ __device__ __forceinline__ double u64_to_f64(u64 x) {            // exact for x 
 __device__ __forceinline__ u64 f64_to_u64(double x) {            // exact for integer 0 <= x < 2^52
     return (u64)__double_as_longlong(x + 4503599627370496.0) & 0x000FFFFFFFFFFFFFULL;
 }
+// 4 x 4 byte transpose with v_perm_b32: o[t] = {w0.b_t, w1.b_t, w2.b_t, w3.b_t}
+__device__ __forceinline__ void bytes_tr4(unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned (&o)[4]) {
+    const unsigned p0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), p1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+    const unsigned q0 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), q1 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+    o[0] = __builtin_amdgcn_perm(q0, p0, 0x05040100u); o[1] = __builtin_amdgcn_perm(q0, p0, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(q1, p1, 0x05040100u); o[3] = __builtin_amdgcn_perm(q1, p1, 0x07060302u);
+}
+// sum over 4 packed int8 of int8(x*x) (Go's uint64(row[j]*row[j]) / float64(int8(x*x)): the square wraps in int8): the dot product of the dword with
+// itself when it is < 128 - then no single square reached 128 - else byte by byte
+__device__ __forceinline__ int sq_sum4_i8(int w) {
+    const int sq = __builtin_amdgcn_sdot4(w, w, 0, false);
+    if (sq < 128) return sq;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int x = (int)(int8_t)(w >> (8 * k)); s += (int)(int8_t)(x * x); }
+    return s;
+}
 // packed-limb word (pack_limbs) of an integer-valued double 0 <= x < 2^36 straight from the bits of x + 2^52: 1 fp add + 4 integer ops
 __device__ __forceinline__ u64 pack_limbs_f64(double x) {
     const u64 b = (u64)__double_as_longlong(x + 4503599627370496.0);

@@ -87,14 +87,53 @@ static int launch_pt_zero(sfg_ctx *ctx, u64 *pt, size_t pitch_words, size_t seg_
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
-// P2: per-column sum and sum of squares after missing -> 0 (matmult.go:1292-1300)
+// P2: per-column sum and sum of squares after missing -> 0 (matmult.go:1292-1300).  A workgroup takes a 256-column strip of a chunk of rows:
+// thread = (16-byte column group tid & 15, row lane tid >> 4), so a wave's load is four rows of 256 contiguous bytes.  Four rows at a time are
+// byte-transposed in registers (v_perm_b32), so that a dword holds four rows of ONE column: negatives are cleared four at a time, the sum is one
+// v_dot4_i32_i8, the squares (Go: float64(int8(x*x)), wraps for x >= 12) the dot product of the dword with itself when that proves nothing wrapped.
+// Partial sums are integers: the fp64 atomics that combine the row chunks are exact.
+constexpr int CS_ROWS = 4096;                     // rows per workgroup (256 per thread: int32 partial sums)
 __global__ void __launch_bounds__(256) k_colsums(const int8_t *g, size_t nrow, size_t ncol, size_t ld, double *sum, double *sqsum) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= ncol) return;
+    __shared__ int red[2][16][256 + 1];
+    const int tid = threadIdx.x, cg = tid & 15, rl = tid >> 4;
+    const size_t col = (size_t)blockIdx.x * 256 + (size_t)cg * 16, r0 = (size_t)blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < nrow ? r0 + CS_ROWS : nrow;
+    int p1[16], p2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) p1[k] = p2[k] = 0;
+    const bool vec = col + 16 <= ncol && ((reinterpret_cast<uintptr_t>(g) | ld) & 15) == 0;
+    auto load = [&](size_t i) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i >= r1) return v;
+        if (vec) v = *reinterpret_cast<const uint4 *>(g + i * ld + col);
+        else if (col < ncol) { int8_t b[16]; for (int k = 0; k < 16; k++) b[k] = col + k < ncol ? g[i * ld + col + k] : (int8_t)0; v = *reinterpret_cast<uint4 *>(b); }
+        return v;
+    };
+    for (size_t i = r0 + rl; i < r1; i += 64) {               // rows i, i + 16, i + 32, i + 48
+        const uint4 v0 = load(i), v1 = load(i + 16), v2 = load(i + 32), v3 = load(i + 48);
+        const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w}, a3[4] = {v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned o[4]; bytes_tr4(a0[q], a1[q], a2[q], a3[q], o);                     // o[t]: column 4 q + t, four rows
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                unsigned w = o[t];
+                const unsigned m = w & 0x80808080u; w &= ~((m << 1) - (m >> 7));           // missing (negative) -> 0
+                p1[4 * q + t] = __builtin_amdgcn_sdot4((int)w, 0x01010101, p1[4 * q + t], false);
+                p2[4 * q + t] += sq_sum4_i8((int)w);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { red[0][rl][cg * 16 + k] = p1[k]; red[1][rl][cg * 16 + k] = p2[k]; }
+    __syncthreads();
     long long s1 = 0, s2 = 0;
-    for (size_t i = 0; i < nrow; i++) { int v = g[i * ld + j]; v = v < 0 ? 0 : v; s1 += v; s2 += (long long)(int8_t)(v * v); }   // Go: float64(int8(x*x)), wraps for |x| >= 12
-    if (sum) sum[j] = (double)s1;
-    if (sqsum) sqsum[j] = (double)s2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s1 += red[0][r][tid]; s2 += red[1][r][tid]; }
+    const size_t j = (size_t)blockIdx.x * 256 + tid;
+    if (j < ncol) {
+        if (sum) atomicAdd(&sum[j], (double)s1);
+        if (sqsum) atomicAdd(&sqsum[j], (double)s2);
+    }
 }
 
 // C6: crypto.DropLevel / eval.DropLevelNew (basics.go:806-824): keep the first level_out+1 moduli rows of each polynomial.
@@ -145,7 +184,8 @@ extern "C" int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_hos
     }
     SFG_TRY(sfg_ws_reserve(ctx, g->ncol * 16));
     double *ds = (double *)ctx->ws, *dq = ds + g->ncol;
-    hipLaunchKernelGGL(k_colsums, dim3((unsigned)((g->ncol + 255) / 256)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, ds, dq);
+    SFG_HIP(ctx, hipMemsetAsync(ds, 0, g->ncol * 16, ctx->stream));            // the row chunks are combined with (exact, integer-valued) fp64 atomics
+    hipLaunchKernelGGL(k_colsums, dim3((unsigned)((g->ncol + 255) / 256), (unsigned)((g->nrow + CS_ROWS - 1) / CS_ROWS)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, ds, dq);
     SFG_HIP(ctx, hipGetLastError());
     if (sum_host) SFG_HIP(ctx, hipMemcpyAsync(sum_host, ds, g->ncol * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (sqsum_host) SFG_HIP(ctx, hipMemcpyAsync(sqsum_host, dq, g->ncol * 8, hipMemcpyDeviceToHost, ctx->stream));

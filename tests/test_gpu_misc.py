@@ -62,11 +62,13 @@ def test_beaver_matmul(ctx, pid):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("nrow,ncol", [(1000, 777), (64, 256), (130, 5), (1, 1)])
-def test_sketch_and_moments(ctx, nrow, ncol):
+@pytest.mark.parametrize("nrow,ncol,full_range", [(1000, 777, False), (64, 256, False), (130, 5, False), (1, 1, False), (1037, 777, True), (200, 300, True)])
+def test_sketch_and_moments(ctx, nrow, ncol, full_range):
+    """full_range: arbitrary int8 values - squares wrap in int8 (Go: uint64(row[j]*row[j])) and sums go negative: the per-byte path of the moments and
+    the sign handling of the int8 matrix-core projection"""
     from sfgwas_amd import capi
     rnd = np.random.default_rng(nrow + ncol)
-    X = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+    X = (rnd.integers(-128, 128, (nrow, ncol)) if full_range else rnd.integers(-1, 3, (nrow, ncol))).astype(np.int8)
     kp = 15
     bucket = rnd.integers(0, kp, nrow).astype(np.int32)
     sgn = (rnd.integers(0, 2, nrow) * 2 - 1).astype(np.int8)
@@ -81,8 +83,10 @@ def test_sketch_and_moments(ctx, nrow, ncol):
     # P2 column sums (missing -> 0)
     sm = np.zeros(ncol); sq = np.zeros(ncol)
     ctx.check(capi.lib().sfg_geno_colsums(ctx.h, gh, sm.ctypes.data_as(C.POINTER(C.c_double)), sq.ctypes.data_as(C.POINTER(C.c_double))), "colsums")
-    g0 = np.where(X < 0, 0, X).astype(np.float64)
-    assert np.array_equal(sm, g0.sum(0)) and np.array_equal(sq, (g0 * g0).sum(0))
+    g0 = np.where(X < 0, 0, X).astype(np.int8)
+    with np.errstate(over="ignore"):
+        sq0 = (g0 * g0).astype(np.int8)                                   # the reference squares in int8 (wraps from 12 upwards) before float64()
+    assert np.array_equal(sm, g0.astype(np.float64).sum(0)) and np.array_equal(sq, sq0.astype(np.float64).sum(0))
     capi.lib().sfg_geno_free(ctx.h, gh)
 
 
