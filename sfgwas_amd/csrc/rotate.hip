@@ -305,7 +305,13 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
         int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
         const int src = in_index ? in_index[j] : j;
         if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
-        if (nrot == 0) { SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + (size_t)src * ctw, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream)); continue; }
+        if (nrot == 0) {                                    // not rotated: copied; runs of consecutive (source, slot) pairs in one copy
+            int run = 1;
+            while (j + run < nct && (nrot_host[j + run] % SFG_SLOTS) == 0 && (in_index ? in_index[j + run] : j + run) == src + run && src + run < nin) run++;
+            SFG_HIP(ctx, hipMemcpyAsync(out + j * ctw, in + (size_t)src * ctw, (size_t)run * ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            j += run - 1;
+            continue;
+        }
         u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);                 // basics.go:205: RotateNew(ct, slots - nrot)
         auto it = ctx->rotkeys().find(g);
         if (it == ctx->rotkeys().end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
@@ -330,7 +336,13 @@ int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double
         const int src = in_index ? in_index[j] : j;
         if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
         double *dst = outf + (size_t)j * 2 * ff.rowf;
-        if (nrot == 0) { SFG_TRY(launch_rot_to_f64(ctx, in + (size_t)src * ctw, 2, nl, L, dst)); continue; }
+        if (nrot == 0) {                                    // not rotated: converted from the input; runs of consecutive (source, slot) pairs in one launch
+            int run = 1;
+            while (j + run < nct && (nrot_host[j + run] % SFG_SLOTS) == 0 && (in_index ? in_index[j + run] : j + run) == src + run && src + run < nin) run++;
+            SFG_TRY(launch_rot_to_f64(ctx, in + (size_t)src * ctw, (size_t)2 * run, nl, L, dst));
+            j += run - 1;
+            continue;
+        }
         u64 g = sfg_galois_for_rotation(ctx, SFG_SLOTS - nrot);
         auto it = ctx->rotkeys().find(g);
         if (it == ctx->rotkeys().end()) SFG_FAIL(ctx, "rotate: no rotation key loaded for right-rotation by %d (galois element %llu)", nrot, g);
