@@ -140,23 +140,25 @@ __global__ void __launch_bounds__(256) k_ksw_extend(const u64 *c2, const u64 *ct
     }
 }
 
-// grid (N/256, nt, B). acc: [B][2][nt][N]; inidx[b] = which decomposed input feeds output b
+// grid (N/512, nt, B). acc: [B][2][nt][N]; inidx[b] = which decomposed input feeds output b.  Two coefficients per thread: 16-byte loads and stores
 __global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *const *keys, const int *inidx, u64 *acc, const KswConst *kcp, const ModConst *modc, int nmod) {
     const KswConst &kc = *kcp;
-    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y; const size_t b = blockIdx.z;
+    const int N = SFG_N, x = 2 * (blockIdx.x * 256 + threadIdx.x), t = blockIdx.y; const size_t b = blockIdx.z;
     const int tg = kc.tmod[t];
     const double q = modc[tg].q, qinv = modc[tg].qinv;
     const u64 *key = keys[b];
     const size_t bi = (size_t)inidx[b];
-    double a0 = 0.0, a1 = 0.0;
+    double a0x = 0.0, a0y = 0.0, a1x = 0.0, a1y = 0.0;
     for (int i = 0; i < kc.beta; i++) {
-        const double e = u64_to_f64(ext[((bi * kc.beta + i) * (size_t)kc.nt + t) * N + x]);
-        const double k0 = u64_to_f64(key[(((size_t)i * 2 + 0) * nmod + tg) * N + x]);
-        const double k1 = u64_to_f64(key[(((size_t)i * 2 + 1) * nmod + tg) * N + x]);
-        a0 += mulmod2(e, k0, q, qinv); a1 += mulmod2(e, k1, q, qinv);
+        const ulonglong2 ev = *reinterpret_cast<const ulonglong2 *>(ext + ((bi * kc.beta + i) * (size_t)kc.nt + t) * N + x);
+        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)i * 2 + 0) * nmod + tg) * N + x);
+        const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)i * 2 + 1) * nmod + tg) * N + x);
+        const double ex = u64_to_f64(ev.x), ey = u64_to_f64(ev.y);
+        a0x += mulmod2(ex, u64_to_f64(k0.x), q, qinv); a0y += mulmod2(ey, u64_to_f64(k0.y), q, qinv);
+        a1x += mulmod2(ex, u64_to_f64(k1.x), q, qinv); a1y += mulmod2(ey, u64_to_f64(k1.y), q, qinv);
     }
-    acc[((b * 2 + 0) * (size_t)kc.nt + t) * N + x] = f64_to_u64(canon(a0, q, qinv));
-    acc[((b * 2 + 1) * (size_t)kc.nt + t) * N + x] = f64_to_u64(canon(a1, q, qinv));
+    *reinterpret_cast<ulonglong2 *>(acc + ((b * 2 + 0) * (size_t)kc.nt + t) * N + x) = make_ulonglong2(f64_to_u64(canon(a0x, q, qinv)), f64_to_u64(canon(a0y, q, qinv)));
+    *reinterpret_cast<ulonglong2 *>(acc + ((b * 2 + 1) * (size_t)kc.nt + t) * N + x) = make_ulonglong2(f64_to_u64(canon(a1x, q, qinv)), f64_to_u64(canon(a1y, q, qinv)));
 }
 
 // grid (N/256, 2, B): special-prime rows of acc (already INTT'd) -> ext2 [B][2][nl][N] coefficient domain
@@ -278,7 +280,7 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
             const int nb = (int)(jobs.size() - c0 < (size_t)chunk ? jobs.size() - c0 : (size_t)chunk);
             const u64 **keys_d = keys_all + c0; const uint16_t **idx_d = idx_all + c0; u64 **out_d = out_all + c0; int *inidx_d = inidx_all + c0;
             // 3. inner product with the key
-            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 256, kc.nt, nb), dim3(256), 0, ctx->stream, extT, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
+            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 512, kc.nt, nb), dim3(256), 0, ctx->stream, extT, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
             SFG_HIP(ctx, hipGetLastError());
             // 4. ModDown: INTT special rows in place, extend to Q, NTT
             RowMap rm4; rm4.rpg = kc.np; rm4.gstride_in = (size_t)kc.nt * N; rm4.gstride_out = (size_t)kc.nt * N;
