@@ -229,6 +229,26 @@ int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, int ma
  * >= 91 ignored */
 int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, int max_level, int ncolb, int acc_giants, int giant_base,
                                   int g0, int g1, int accumulate, uint64_t *out_dev);
+/* ---- the baby-step rotation cache as an object (SURVEY.md §8e "builds the full rotation cache (or the rotation cache is built once and
+ * broadcast)"): rotCache[i][baby] = RotateRightWithEvaluator(A[i][bi], -baby) of matmult.go:1083-1119,1373-1377 in the MAC's fp64 operand layout
+ *     cache[bi - row0][baby < 91][i < s][poly < 2][rowf doubles]   followed by tail_doubles zeros,   job_doubles = 91 * 2 * rowf.
+ * Every rank of the output-sharded product Q*X multiplies by the cache of ALL operand block rows; rank r key-switches only the inputs
+ * (bi, i) of its job range (job = bi*s + i: the decomposition of an input is shared by its 91 rotations) into job-major staging
+ *     staged[job - job0][baby][poly][rowf],
+ * the ranks all-gather the staging buffers and scatter them into the cache layout.  All 91 baby steps are rotated (rotations the reference's
+ * active-baby table would skip meet zero plaintexts only), so every baby rotation key must be loaded (crypto.go:252-263 generates them all). */
+int sfg_rotcache_layout(sfg_ctx *ctx, int s, int max_level, size_t *job_doubles, size_t *tail_doubles);
+int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, int nbr, int job0, int job1, double *staged_dev);
+/* staged jobs [job0, job1) -> cache rows [row0, row0 + nrows); also zeroes the tail */
+int sfg_rotcache_scatter_dev(sfg_ctx *ctx, const double *staged_dev, int s, int max_level, int job0, int job1, int row0, int nrows, double *cache_dev);
+/* the cache of block rows [b0, b1) written in place (a rank's own rows of the contraction-sharded product Q'*X^T) */
+int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, int nbr, int b0, int b1, double *cache_dev);
+/* sfg_matmul_resident_range_dev / sfg_matmul_accumulate_dev on a prebuilt cache that covers exactly the operand block rows the call contracts
+ * over (X: all of them; X^T: [blk0, blk1) resp. [b0, b1)); inputs are taken to be at level max_level (the cache holds max_level moduli) */
+int sfg_matmul_resident_range_rc_dev(sfg_ctx *ctx, const double *cache_dev, int s, int max_level, const sfg_geno *g, unsigned flags,
+                                     int blk0, int blk1, uint64_t *out_dev);
+int sfg_matmul_accumulate_rc_dev(sfg_ctx *ctx, const double *cache_dev, int s, int max_level, const sfg_geno *g, unsigned flags,
+                                 int b0, int b1, int j0, int j1, int accumulate, uint64_t *acc_dev);
 /* after an integer all-reduce(sum) of partial outputs across ranks: canonical reduction mod q_l of [rows][L][N] */
 int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows_dev, size_t nrows_of_L, int L);
 

@@ -1047,10 +1047,11 @@ double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long lon
 
 /* cpu_baseline with the REFERENCE's data layout (matmult.go:1065-1068,1121-1129,1154-1168): one shared rotCache[i][baby]
  * (s*d ciphertexts), lazily reduced u128 accumulators accCache[i][giant] for ONE output block column (m_ct = 1), one plaintext per
- * diagonal, workers that take whole diagonals.  A giant step is owned by one thread (the reference locks accCacheMux[i][giant]
- * instead; ownership costs no lock traffic, so this flatters the CPU slightly).  Encode is excluded (cached-diagonal mode,
- * MatMult4StreamCompute): the plaintext words are random.  Returns u128 MACs per second over all threads. */
-double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double seconds, long long *macs_done) {
+ * diagonal.  The work items are the reference's lock units accCache[i][giant] (s*d = 1365 of them: every stated thread computes; the reference
+ * locks accCacheMux[i][giant] instead of owning it, and ownership costs no lock traffic, so this flatters the CPU slightly).  Encode is excluded
+ * (cached-diagonal mode, MatMult4StreamCompute): the plaintext words are random.  Returns u128 MACs per second over all threads;
+ * *threads_active = threads that executed at least one MAC. */
+double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double seconds, long long *macs_done, int *threads_active) {
     size_t ctw = (size_t)2 * (L + 1) * N, accw = (size_t)2 * L * N * 2;
     u64 **rot = malloc(sizeof(u64 *) * (size_t)s * d), **acc = malloc(sizeof(u64 *) * (size_t)s * d);
     for (size_t k = 0; k < (size_t)s * d; k++) { rot[k] = malloc(ctw * 8); acc[k] = NULL; }
@@ -1060,9 +1061,9 @@ double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double
         for (size_t x = 0; x < ctw; x++) rot[k][x] = orc_splitmix64(&st) >> 18;
         acc[k] = calloc(accw, 8);
     }
-    long long total = 0; int stop = 0;
+    long long total = 0; int stop = 0, active = 0;
     double t_begin = omp_get_wtime(), t_end;
-#pragma omp parallel num_threads(nthreads) reduction(+ : total)
+#pragma omp parallel num_threads(nthreads) reduction(+ : total, active)
     {
         u64 *pt = malloc((size_t)(L + 1) * N * 8);
         u64 st = 0x1234 + 77 * (u64)omp_get_thread_num();
@@ -1070,16 +1071,16 @@ double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double
         long long mine = 0;
         while (!stop) {
 #pragma omp for schedule(dynamic) nowait
-            for (int giant = 0; giant < d; giant++) {
-                for (int baby = 0; baby < d && !stop; baby++) {
-                    for (int i = 0; i < s; i++) {                       /* CPMultAccWithoutMRedV2(rotCache[i][baby], plainVec, accCache[i][giant]) */
-                        const u64 *rc = rot[(size_t)i * d + baby]; u64 *a = acc[(size_t)i * d + giant];
-                        for (int l = 0; l < L; l++) {
-                            orc_mul_coeffs_and_add128(rc + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
-                            orc_mul_coeffs_and_add128(rc + (size_t)(L + 1 + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
-                        }
+            for (int item = 0; item < s * d; item++) {                  /* item = accCache[i][giant] */
+                const int giant = item / s, i = item % s;
+                u64 *a = acc[(size_t)i * d + giant];
+                for (int baby = 0; baby < d && !stop; baby++) {         /* CPMultAccWithoutMRedV2(rotCache[i][baby], plainVec, accCache[i][giant]) */
+                    const u64 *rc = rot[(size_t)i * d + baby];
+                    for (int l = 0; l < L; l++) {
+                        orc_mul_coeffs_and_add128(rc + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
+                        orc_mul_coeffs_and_add128(rc + (size_t)(L + 1 + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
                     }
-                    mine += (long long)s * 2 * L * N;
+                    mine += (long long)2 * L * N;
                     if (omp_get_wtime() - t_begin >= seconds) {
 #pragma omp atomic write
                         stop = 1;
@@ -1087,13 +1088,14 @@ double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double
                 }
             }
         }
-        total += mine;
+        total += mine; active += mine > 0;
         free(pt);
     }
     t_end = omp_get_wtime();
     for (size_t k = 0; k < (size_t)s * d; k++) { free(rot[k]); free(acc[k]); }
     free(rot); free(acc);
     if (macs_done) *macs_done = total;
+    if (threads_active) *threads_active = active;
     return (double)total / (t_end - t_begin);
 }
 

@@ -85,6 +85,12 @@ def _sig(L):
         "sfg_matmul_finalize_dev": (i, [vp, vp, i, i, i, i, i, i, vp]),
         "sfg_matmul_finalize_slots_dev": (i, [vp, vp, i, i, i, i, i, i, i, i, vp]),
         "sfg_reduce_rows_dev": (i, [vp, vp, sz, i]),
+        "sfg_rotcache_layout": (i, [vp, i, i, C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_rotcache_build_jobs_dev": (i, [vp, vp, i, i, i, i, i, i, vp]),
+        "sfg_rotcache_scatter_dev": (i, [vp, vp, i, i, i, i, i, i, vp]),
+        "sfg_rotcache_build_rows_dev": (i, [vp, vp, i, i, i, i, i, i, vp]),
+        "sfg_matmul_resident_range_rc_dev": (i, [vp, vp, i, i, vp, C.c_uint, i, i, vp]),
+        "sfg_matmul_accumulate_rc_dev": (i, [vp, vp, i, i, vp, C.c_uint, i, i, i, i, i, vp]),
         "sfg_beaver_elem_dev": (i, [vp, i, i, u64p, vp, vp, vp, vp, vp, sz]),
         "sfg_beaver_elem": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, sz]),
         "sfg_beaver_matmul": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, i, i, i]),

@@ -33,7 +33,8 @@ int launch_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, size_t r0, size_t c0, si
 // rotate.hip
 int launch_rotate_right(sfg_ctx *ctx, const u64 *in, u64 *out, int nct, int level, const int *nrot_host);
 int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, int nct, int level, const int *nrot_host, const int *in_index);
-int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double *outf, int nct, int level, const int *nrot_host, const int *in_index, int L);
+int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double *outf, int nct, int level, const int *nrot_host, const int *in_index, int L,
+                                    const size_t *out_slot = nullptr);
 int launch_relinearize(sfg_ctx *ctx, const u64 *tmp, int nct, int level, const u64 *mid, u64 *out);
 int launch_ct_add(sfg_ctx *ctx, const u64 *a, const u64 *b, u64 *out, size_t nct, int level);
 // mac_dma.hip

@@ -440,8 +440,8 @@ extern "C" int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc, 
 }
 
 // SNP-block range [blk0, blk1) over the block columns of the STORED matrix: output columns for X, contraction rows for X^T
-extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
-                                             int blk0, int blk1, uint64_t *out) {
+static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
+                                 int blk0, int blk1, uint64_t *out, const double *rotf_ext) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->phases.clear();
     Shape sh = make_shape(g, flags);
@@ -457,8 +457,9 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     int jg = (int)(budget / ((size_t)d * accw * 8)); if (jg < 1) jg = 1;
     // Several column groups would each rebuild the rotation cache of every block row (91 key switches per input
     // ciphertext).  When the whole cache fits (48 GiB; Q*X at 100k x 1M: 13 block rows = 28 GB) it is built once here.
-    const double *rotf_all = nullptr, *rotsum_all = nullptr;
-    if (mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
+    const double *rotf_all = rotf_ext, *rotsum_all = nullptr;
+    if (rotf_ext && !mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    if (!rotf_ext && mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         const size_t rowf = (size_t)nplanes * N, per_row = (size_t)d * s * 2 * rowf;       // doubles per block row
@@ -513,6 +514,106 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
     if (overlap) SFG_TRY(sfg_stream_after(ctx, main_stream, ctx->aux_stream));      // outputs are complete in main-stream order
     return 0;
 }
+extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
+                                             int blk0, int blk1, uint64_t *out) {
+    return matmul_resident_range(ctx, A, s, in_level, max_level, g, flags, blk0, blk1, out, nullptr);
+}
+
+// ---------------------------------------------------------------- the rotation cache as an object (multi-GPU runs)
+// The baby-step rotation cache of a product (matmult.go:1083-1119, 1373-1377: rotCache[i][baby] = RotateRight(A[i][bi], -baby)) in the MAC's fp64
+// operand layout  cache[bi - row0][baby < 91][i < s][poly < 2][rowf]  (+ 3 zero k-slices).  Every rank of an output-sharded product (Q*X) needs the
+// cache of ALL operand block rows; instead of rebuilding it on every rank, rank r key-switches the inputs (bi, i) of its job range
+// (job = bi*s + i; the decomposition of an input is shared by its 91 rotations, so inputs - not baby steps - are the unit), the ranks all-gather
+// the job-major staging buffers and scatter them into the MAC layout.  All 91 baby steps are rotated (a superset of the reference's active table
+// whenever the operand has a ragged block only; rotations of inactive baby steps meet zero plaintexts), so the cache does not depend on a rank's window.
+static int rotcache_rowf(sfg_ctx *ctx, int L, size_t &rowf) {
+    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "rotation cache objects need the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "rotcache: max_level out of range");
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) return 1;
+    rowf = (size_t)nplanes * SFG_N; return 0;
+}
+extern "C" int sfg_rotcache_layout(sfg_ctx *ctx, int s, int max_level, size_t *job_doubles, size_t *tail_doubles) {
+    size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, max_level, rowf));
+    if (job_doubles) *job_doubles = (size_t)SFG_D * 2 * rowf;
+    if (tail_doubles) *tail_doubles = (size_t)3 * s * 2 * rowf;
+    return 0;
+}
+extern "C" int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int job0, int job1, double *staged) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const int N = SFG_N, d = SFG_D, L = max_level;
+    size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, L, rowf));
+    const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;
+    if (nl < L || in_level >= ctx->nq) SFG_FAIL(ctx, "rotcache: input level %d unusable with max_level = %d", in_level, max_level);
+    if (s < 1 || nbr < 1 || job0 < 0 || job1 > nbr * s || job0 > job1) SFG_FAIL(ctx, "rotcache: job range out of bounds");
+    const size_t ctw = (size_t)2 * nl * N;
+    constexpr int CH = 64;                                   // inputs per key-switch call
+    u64 *a_in = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "rc.in", (size_t)CH * ctw * 8, (void **)&a_in));
+    PhaseTimer t(ctx, "rotate");
+    for (int c0 = job0; c0 < job1; c0 += CH) {
+        const int nj = std::min(CH, job1 - c0);
+        for (int k = 0; k < nj; k++) {
+            const int job = c0 + k, bi = job / s, i = job % s;
+            const u64 *src = (const u64 *)A + ((size_t)i * nbr + bi) * 2 * nl_in * N;
+            if (nl == nl_in) SFG_HIP(ctx, hipMemcpyAsync(a_in + (size_t)k * ctw, src, ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            else hipLaunchKernelGGL(k_drop_level, dim3((unsigned)(2 * nl * (N / 256))), dim3(256), 0, ctx->stream, src, a_in + (size_t)k * ctw, nl_in, nl);
+        }
+        SFG_HIP(ctx, hipGetLastError());
+        std::vector<int> nrv((size_t)d * nj), inv((size_t)d * nj); std::vector<size_t> slot((size_t)d * nj);
+        for (int baby = 0; baby < d; baby++) for (int k = 0; k < nj; k++) {        // key-major job order, job-major output
+            nrv[(size_t)baby * nj + k] = -baby; inv[(size_t)baby * nj + k] = k; slot[(size_t)baby * nj + k] = (size_t)(c0 - job0 + k) * d + baby;
+        }
+        SFG_TRY(launch_rotate_right_indexed_f64(ctx, a_in, nj, staged, d * nj, lev, nrv.data(), inv.data(), L, slot.data()));
+    }
+    t.stop(1);
+    return 0;
+}
+extern "C" int sfg_rotcache_scatter_dev(sfg_ctx *ctx, const double *staged, int s, int max_level, int job0, int job1, int row0, int nrows, double *cache) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const int d = SFG_D;
+    size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, max_level, rowf));
+    if (s < 1 || nrows < 1 || job0 < row0 * s || job1 > (row0 + nrows) * s || job0 > job1) SFG_FAIL(ctx, "rotcache: job range outside the cache rows");
+    const size_t jw = (size_t)2 * rowf;
+    for (int job = job0; job < job1; job++) {
+        const int bi = job / s, i = job % s;
+        SFG_HIP(ctx, hipMemcpy2DAsync(cache + (((size_t)(bi - row0) * d) * s + i) * jw, (size_t)s * jw * 8, staged + (size_t)(job - job0) * d * jw, jw * 8, jw * 8, d,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    SFG_HIP(ctx, hipMemsetAsync(cache + (size_t)nrows * d * s * jw, 0, (size_t)3 * s * jw * 8, ctx->stream));   // k-slices a ragged last MAC chunk reads
+    return 0;
+}
+extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int b0, int b1, double *cache) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    const int N = SFG_N, d = SFG_D, L = max_level;
+    size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, L, rowf));
+    const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1;
+    if (nl < L || in_level >= ctx->nq) SFG_FAIL(ctx, "rotcache: input level %d unusable with max_level = %d", in_level, max_level);
+    if (s < 1 || b0 < 0 || b1 > nbr || b0 > b1) SFG_FAIL(ctx, "rotcache: block-row range out of bounds");
+    const size_t ctw = (size_t)2 * nl * N, per_row = (size_t)d * s * 2 * rowf;
+    u64 *a_row = nullptr, *rotc = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
+    SFG_TRY(sfg_scratch(ctx, "mm.rotc", 8, (void **)&rotc));
+    const std::vector<uint8_t> all(d, 1);
+    for (int bi = b0; bi < b1; bi++) SFG_TRY(build_rot_row_tab(ctx, (const u64 *)A, s, in_level + 1, nl, lev, L, nbr, bi, all, a_row, rotc, true, cache + (size_t)(bi - b0) * per_row));
+    SFG_HIP(ctx, hipMemsetAsync(cache + (size_t)(b1 - b0) * per_row, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream));
+    return 0;
+}
+// the products on a prebuilt cache that covers exactly the operand block rows the call contracts over ([0, nbr) for X, [blk0, blk1) / [b0, b1) for X^T)
+extern "C" int sfg_matmul_resident_range_rc_dev(sfg_ctx *ctx, const double *cache, int s, int max_level, const sfg_geno *g, unsigned flags,
+                                                int blk0, int blk1, uint64_t *out) {
+    if (!cache) SFG_FAIL(ctx, "matmul: null rotation cache");
+    return matmul_resident_range(ctx, nullptr, s, max_level, max_level, g, flags, blk0, blk1, out, cache);
+}
+extern "C" int sfg_matmul_accumulate_rc_dev(sfg_ctx *ctx, const double *cache, int s, int max_level, const sfg_geno *g, unsigned flags,
+                                            int b0, int b1, int j0, int j1, int accumulate, uint64_t *acc) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!cache) SFG_FAIL(ctx, "matmul: null rotation cache");
+    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    Shape sh = make_shape(g, flags);
+    return matmul_accumulate(ctx, nullptr, s, max_level, max_level, sh, flags, b0, b1, j0, j1, accumulate, (u64 *)acc, cache, nullptr);
+}
+
 extern "C" int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, uint64_t *out) {
     const size_t nb = (g->ncol + SFG_SLOTS - 1) / SFG_SLOTS;    // SNP blocks = block columns of the stored matrix
     return sfg_matmul_resident_range_dev(ctx, A, s, in_level, max_level, g, flags, 0, (int)nb, out);

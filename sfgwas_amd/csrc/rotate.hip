@@ -323,7 +323,9 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
 }
 // The same batch written as the MAC's fp64 operand rows: job j lands at outf + j * 2 * rowf (row pair of polynomials 0, 1), rowf = nplanes * N doubles.
 // Jobs that do not rotate (nrot == 0) are converted from their input.
-int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double *outf, int nct, int level, const int *nrot_host, const int *in_index, int L) {
+// out_slot (nullable): job j lands at outf + out_slot[j] * 2 * rowf instead of outf + j * 2 * rowf (sharded rotation-cache builds write job-major staging).
+int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double *outf, int nct, int level, const int *nrot_host, const int *in_index, int L,
+                                    const size_t *out_slot) {
     const int N = SFG_N, nl = level + 1;
     if (level < 0 || level >= ctx->nq || L > nl) SFG_FAIL(ctx, "rotate: level out of range");
     const size_t ctw = (size_t)2 * nl * N;
@@ -337,10 +339,10 @@ int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double
         int nrot = nrot_host[j] % SFG_SLOTS; if (nrot < 0) nrot += SFG_SLOTS;
         const int src = in_index ? in_index[j] : j;
         if (src < 0 || src >= nin) SFG_FAIL(ctx, "rotate: input index out of range");
-        double *dst = outf + (size_t)j * 2 * ff.rowf;
+        double *dst = outf + (out_slot ? out_slot[j] : (size_t)j) * 2 * ff.rowf;
         if (nrot == 0) {                                    // not rotated: converted from the input; runs of consecutive (source, slot) pairs in one launch
             int run = 1;
-            while (j + run < nct && (nrot_host[j + run] % SFG_SLOTS) == 0 && (in_index ? in_index[j + run] : j + run) == src + run && src + run < nin) run++;
+            while (!out_slot && j + run < nct && (nrot_host[j + run] % SFG_SLOTS) == 0 && (in_index ? in_index[j + run] : j + run) == src + run && src + run < nin) run++;
             SFG_TRY(launch_rot_to_f64(ctx, in + (size_t)src * ctw, (size_t)2 * run, nl, L, dst));
             j += run - 1;
             continue;

@@ -1,0 +1,90 @@
+"""bench.py's N > 1 path EXECUTED with world size > 1 on the one GPU a box has: `--backend gloo` stages the collectives through
+host memory, so several ranks can share a device (RCCL refuses that).  Everything but the transport is the code the driver's
+8-GPU run executes: per-rank SNP-block windows of one global matrix, per-rank ciphertext slices and seeds, the sharded
+rotation-cache build + all-gather + scatter, the per-column reduce-scatter windows over the padded giant axis, finalize of the
+owned giant slots, the all-reduce of the aligned partial outputs (pca.go:344,352).
+
+The bar: the SHA-256 digests of both products printed by every world size equal the single-process line's - every output
+word of Q*X and Q'*X^T is the same whatever the sharding."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--no-cpu-baseline", "--no-check", "--warmup", "0", "--steps", "1"]
+# ranks that share one GPU also share its 288 GB: smaller MAC groups / accumulator passes (results do not depend on either:
+# tests/test_gpu_properties.py), and Q'*X^T's rank-local rotation cache only when it is small
+SHARED_GPU_ENV = {"SFG_MM_GROUP": "4", "SFG_MM_ACC_BUDGET_MB": "4096", "SFG_BENCH_CACHE2_GB": "24"}
+_port = [29600]
+
+
+def bench_line(config, world=1, backend=None, env=None, force_coll=False):
+    e = dict(os.environ)
+    e.update(env or {})
+    args = ["bench.py", "--config", config, "--gpus", str(world)] + COMMON
+    if world == 1 and not force_coll:
+        cmd = [sys.executable] + args
+    else:
+        _port[0] += 1
+        if force_coll:
+            e["SFG_BENCH_FORCE_COLLECTIVES"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_port[0])] + args + (["--backend", backend] if backend else [])
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.fixture(scope="module")
+def plain():
+    cache = {}
+
+    def get(config):
+        if config not in cache:
+            cache[config] = bench_line(config)
+            assert cache[config]["n_gpus"] == 1 and cache[config]["config"]["collectives"] == "none"
+        return cache[config]
+    return get
+
+
+def same(a, b, what):
+    assert a["digests"]["out1_sha256"] == b["digests"]["out1_sha256"], f"{what}: Q*X differs from the single-process product"
+    assert a["digests"]["out2_sha256"] == b["digests"]["out2_sha256"], f"{what}: Q'*X^T differs from the single-process product"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c2_two_and_three_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain, world):
+    """10 000 x 100 000 (13 SNP blocks -> 6 + 7 resp. 4 + 4 + 5 per rank; the last rank holds the ragged block): sharded rotation
+    cache, column-pipelined reduce-scatter (the rank-local cache of Q'*X^T is small here)"""
+    got = bench_line("c2", world, "gloo", SHARED_GPU_ENV)
+    assert got["n_gpus"] == world and got["config"]["rotation_cache_QX"].startswith("sharded")
+    assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
+    same(plain("c2"), got, f"c2, {world} ranks")
+
+
+def test_c2_replicated_rotation_cache_and_unpipelined_reduce_scatter_give_the_same_digests(plain):
+    """the A/B switches of the two multi-GPU changes of round 3: every rank rebuilding the whole Q*X rotation cache, and the
+    reduce-scatters issued after the whole Q'*X^T accumulate (the path taken when a rank's own cache does not fit)"""
+    env = dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="replicated", SFG_BENCH_CACHE2_GB="0")
+    got = bench_line("c2", 2, "gloo", env)
+    assert got["config"]["rotation_cache_QX"] == "replicated" and got["config"]["QtXt_reduce_scatter"] == "after the product"
+    same(plain("c2"), got, "c2, 2 ranks, replicated cache")
+
+
+def test_c3_two_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain):
+    """50 000 x 500 000 (62 SNP blocks, 7 block rows of individuals): several MAC groups per rank, 7 reduce-scatter windows of which the last runs
+    past its block column, 46 giant slots per rank of which the last rank owns 45"""
+    got = bench_line("c3", 2, "gloo", SHARED_GPU_ENV)
+    assert got["n_gpus"] == 2
+    same(plain("c3"), got, "c3, 2 ranks")
+
+
+def test_collectives_path_at_world_size_1_over_rccl_matches_the_plain_path(plain):
+    """the same sequence over RCCL (backend nccl) with one rank: stream ordering between the library's kernels and the collectives
+    (bench.py once handed torch's default stream, handle 0 = "the context's own stream", to the library and the collectives read the accumulators early)"""
+    got = bench_line("c3", 1, "nccl", None, force_coll=True)
+    assert got["config"]["collectives"] == "RCCL"
+    same(plain("c3"), got, "c3, forced collectives at world size 1")
