@@ -10,9 +10,9 @@ on synthetic data, through the C-ABI of libsfgwas_hip.so, one process per GPU.
 Sharding (strong scaling, total work fixed): the genotype matrix is split by SNP block (8192 columns of X) across
 ranks; every rank generates exactly the window of the SAME global matrix it owns, so any world size multiplies the same
 matrix and the output digests in the JSON line are comparable between N = 1 and N > 1.
-  Q*X    : output-sharded.  The baby-step rotation cache (the same for every rank) is built in shards: each rank key-switches
-           1/world of the (block row, input) jobs, one all-gather, a scatter into the MAC layout (SFG_BENCH_ROTCACHE=replicated:
-           every rank rebuilds the whole cache instead - the A/B switch, identical digests).
+  Q*X    : output-sharded, no data-path collective: every rank builds the baby-step rotation cache of all inputs (72 ms of key
+           switching at 100k x 1M).  SFG_BENCH_ROTCACHE=sharded builds it in shards instead (each rank key-switches 1/world of the
+           (block row, input) jobs, one all-gather, a scatter into the MAC layout): identical digests, 25 GB into every rank.
   Q'*X^T : contraction-sharded.  Key switching is not bit-linear, so partial sums are combined BEFORE the giant-step
            rotations: reduce-scatter of the uint64 accumulators over the giant axis, one output block column at a time while the
            next column is being multiplied; each rank aligns its giant steps, and the aligned partial outputs (256 MB at
@@ -128,10 +128,13 @@ class Coll:
         def wait(self):
             pass
 
-    def __init__(self, dist, torch, backend):
-        self.dist, self.torch, self.host = dist, torch, backend == "gloo"
+    def __init__(self, dist, torch, backend, solo=None):
+        self.dist, self.torch, self.host, self.solo = dist, torch, backend == "gloo", solo
 
     def reduce_scatter(self, out, inp, async_op=False):
+        if self.solo:                                       # timing-only emulation of ONE rank of a larger world: its own slice, no peers
+            out.copy_(inp.view(self.solo[1], -1)[self.solo[0]])
+            return self._Done()
         if not self.host:
             w = self.dist.reduce_scatter_tensor(out, inp, async_op=async_op)
             return w if async_op else self._Done()
@@ -142,6 +145,9 @@ class Coll:
         return self._Done()
 
     def all_gather(self, out, inp):
+        if self.solo:
+            out.view(self.solo[1], -1)[self.solo[0]].copy_(inp)
+            return
         if not self.host:
             self.dist.all_gather_into_tensor(out, inp)
             return
@@ -150,6 +156,8 @@ class Coll:
         out.copy_(o)
 
     def all_reduce(self, t, op=None):
+        if self.solo:
+            return
         kw = {} if op is None else {"op": op}
         if not self.host:
             self.dist.all_reduce(t, **kw)
@@ -187,6 +195,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SFG_BENCH_SOLO=r/w: ONE process computes the share of rank r of a w-rank run, collectives replaced by local copies of its own slices.
+    # TIMING ONLY (the outputs are not a product): per-rank phase times of world sizes this pool cannot run, for the model in DESIGN.md §6.
+    solo = None
+    if os.environ.get("SFG_BENCH_SOLO"):
+        solo = tuple(int(x) for x in os.environ["SFG_BENCH_SOLO"].split("/"))
+        rank, world = solo
+        args.no_check = args.no_digest = args.no_cpu_baseline = True
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.backend == "gloo":
@@ -197,11 +212,16 @@ def main():
     force_coll = os.environ.get("SFG_BENCH_FORCE_COLLECTIVES") == "1"
     use_dist = world > 1 or (force_coll and "RANK" in os.environ)
     coll = None
-    if use_dist:
+    if solo:
+        coll = Coll(dist, torch, "solo", solo)
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
         coll = Coll(dist, torch, args.backend)
-    shard_rotcache = use_dist and os.environ.get("SFG_BENCH_ROTCACHE", "sharded") != "replicated"
+    # Q*X's rotation cache: every rank rebuilds it (default) or the ranks build 1/world each and all-gather (SFG_BENCH_ROTCACHE=sharded).  Measured at
+    # 100k x 1M (tools/r3_solo.sh, profiles/r03_solo_rank_phases_c4.jsonl): the whole build is 72 ms of key switching per rank, a 1/8 shard + scatter 19 ms,
+    # and the all-gather that replaces the difference moves 25 GB into every rank - more than 53 ms on 7 xGMI links.  Identical digests either way.
+    shard_rotcache = use_dist and os.environ.get("SFG_BENCH_ROTCACHE", "replicated") == "sharded"
 
     n_ind, m_snp = CONFIGS[args.config]
     nbr_x, mct_x = ceil_div(n_ind, SLOTS), ceil_div(m_snp, SLOTS)          # block rows / cols of X
@@ -289,18 +309,30 @@ def main():
                 a[1] += n
                 a[2] += max(lib.sfg_last_phase_bytes(ctx.h, ph.encode()), 0.0)
 
+    marks = []
+
+    def mark(name):                                     # wall-time split of a step on the bench stream (solo-rank timing runs only)
+        if solo:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            marks.append((name, e))
+
     def step():
+        mark("start")
         # (1) Q * X : output block columns of this rank
         if shard_rotcache:
             lib.sfg_ctx_clear_phases(ctx.h)
             chk(lib.sfg_rotcache_build_jobs_dev(ctx.h, C.c_void_p(A1.data_ptr()), KP, LEVEL, L, nbr_x, job0, job1, C.c_void_p(staged_mine.data_ptr())), "rotcache jobs")
             add_phases()
+            mark("QX rotation-cache shard (key switching)")
             coll.all_gather(staged_all, staged_mine)
             chk(lib.sfg_rotcache_scatter_dev(ctx.h, C.c_void_p(staged_all.data_ptr()), KP, L, 0, njobs, 0, nbr_x, C.c_void_p(cache_buf.data_ptr())), "rotcache scatter")
+            mark("QX scatter into the MAC layout (+ local copy standing in for the all-gather)")
             chk(lib.sfg_matmul_resident_range_rc_dev(ctx.h, C.c_void_p(cache_buf.data_ptr()), KP, L, gh, 0, 0, nblk_loc, C.c_void_p(out1.data_ptr())), "Q*X")
         else:
             chk(lib.sfg_matmul_resident_dev(ctx.h, C.c_void_p(A1.data_ptr()), KP, LEVEL, L, gh, 0, C.c_void_p(out1.data_ptr())), "Q*X")
         add_phases()
+        mark("QX product (encode + MAC + giant-step alignment)")
         # (2) Q' * X^T : contraction over this rank's SNP blocks, combined before the giant steps
         lib.sfg_ctx_clear_phases(ctx.h)
         if not use_dist:
@@ -312,6 +344,7 @@ def main():
         if pipe_cols:
             chk(lib.sfg_rotcache_build_rows_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP, LEVEL, L, nblk_loc, 0, nblk_loc, C.c_void_p(cache_buf.data_ptr())), "rotcache rows")
             add_phases()
+            mark("QtXt rotation cache of the rank's block rows (key switching)")
             works = []
             for j in range(nbr_x):                      # column j is multiplied while column j-1 is reduce-scattered (sums < world * 2^46)
                 buf = acc2[(j & 1) * colp: (j & 1) * colp + colp]
@@ -330,6 +363,7 @@ def main():
             add_phases()
             for j in range(nbr_x):                      # the window of the last giants runs into the next block column: those slots are ignored
                 coll.reduce_scatter(acc_mine[j].view(-1), acc2[j * col: j * col + colp])
+        mark("QtXt accumulate (encode + MAC; reduce-scatter stood in by a local copy)")
         lib.sfg_ctx_clear_phases(ctx.h)
         chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(acc_mine.data_ptr()), nbr_x * gpr * KP * 2, L), "reduce acc")
         chk(lib.sfg_matmul_finalize_slots_dev(ctx.h, C.c_void_p(acc_mine.data_ptr()), KP, L, nbr_x, gpr, g_lo, 0, gpr, 0,
@@ -337,9 +371,10 @@ def main():
         coll.all_reduce(out2)                           # aligned partial outputs of the ranks' giant shards
         chk(lib.sfg_reduce_rows_dev(ctx.h, C.c_void_p(out2.data_ptr()), KP * nbr_x * 2, L), "reduce out")
         add_phases()
+        mark("QtXt reduce + giant-step alignment of the owned giants")
 
     def barrier():
-        if use_dist:
+        if use_dist and not solo:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -352,7 +387,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
+    if use_dist and not solo:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         coll.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -393,6 +428,22 @@ def main():
                    "rotation_cache_QX": ("sharded build + all-gather" if shard_rotcache else ("replicated" if use_dist else "single rank")),
                    "QtXt_reduce_scatter": ("per output block column, overlapped" if (use_dist and pipe_cols) else ("after the product" if use_dist else "none"))},
     }
+    if solo:
+        torch.cuda.synchronize()
+        parts = {}
+        per = len(marks) // (args.warmup + args.steps)
+        for k in range(args.warmup * per, len(marks)):
+            if marks[k][0] != "start":
+                parts[marks[k][0]] = parts.get(marks[k][0], 0.0) + marks[k - 1][1].elapsed_time(marks[k][1]) / args.steps
+        print(json.dumps({"solo_rank_timing_only": f"rank {rank} of {world}", "config": args.config, "ms_per_step": 1e3 * dt / args.steps,
+                          "wall_ms_per_part": parts, "kernel_phases_ms_per_step": {k: v[0] / args.steps for k, v in phase_tot.items()},
+                          "bytes": {"all_gather_recv_per_rank": (world - 1) * jpr * jobw * 8 if shard_rotcache else 0,
+                                    "reduce_scatter_sent_per_rank": nbr_x * colp * 8 * (world - 1) // world,
+                                    "all_reduce_out2": KP * nbr_x * outw * 8},
+                          "note": "collectives replaced by local copies: the outputs are not a product"}), flush=True)
+        lib.sfg_geno_free(ctx.h, gh)
+        ctx.close()
+        return
     if rank == 0:
         if gate is not None:
             res["parity_gate"] = gate
@@ -449,7 +500,7 @@ def main():
         print(json.dumps(res), flush=True)
     lib.sfg_geno_free(ctx.h, gh)
     ctx.close()
-    if use_dist:
+    if use_dist and not solo:
         dist.destroy_process_group()
     if gate is not None and gate["status"] != "ok":
         raise SystemExit("parity gate FAILED: the HIP path differs from the oracle")

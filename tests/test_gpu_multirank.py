@@ -55,30 +55,39 @@ def same(a, b, what):
     assert a["digests"]["out2_sha256"] == b["digests"]["out2_sha256"], f"{what}: Q'*X^T differs from the single-process product"
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_c2_two_and_three_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain, world):
-    """10 000 x 100 000 (13 SNP blocks -> 6 + 7 resp. 4 + 4 + 5 per rank; the last rank holds the ragged block): sharded rotation
-    cache, column-pipelined reduce-scatter (the rank-local cache of Q'*X^T is small here)"""
-    got = bench_line("c2", world, "gloo", SHARED_GPU_ENV)
-    assert got["n_gpus"] == world and got["config"]["rotation_cache_QX"].startswith("sharded")
+def test_c2_two_ranks_share_the_gpu_with_a_sharded_rotation_cache_and_reproduce_the_single_process_digests(plain):
+    """10 000 x 100 000 (13 SNP blocks -> 6 + 7; the last rank holds the ragged block).  Q*X's rotation cache built in shards (15 of the 30
+    (block row, input) jobs per rank), all-gathered and scattered into the MAC layout; Q'*X^T one output block column at a time beside the previous
+    column's reduce-scatter"""
+    got = bench_line("c2", 2, "gloo", dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="sharded"))
+    assert got["n_gpus"] == 2 and got["config"]["rotation_cache_QX"].startswith("sharded")
     assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
-    same(plain("c2"), got, f"c2, {world} ranks")
+    same(plain("c2"), got, "c2, 2 ranks, sharded cache")
 
 
-def test_c2_replicated_rotation_cache_and_unpipelined_reduce_scatter_give_the_same_digests(plain):
-    """the A/B switches of the two multi-GPU changes of round 3: every rank rebuilding the whole Q*X rotation cache, and the
-    reduce-scatters issued after the whole Q'*X^T accumulate (the path taken when a rank's own cache does not fit)"""
-    env = dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="replicated", SFG_BENCH_CACHE2_GB="0")
-    got = bench_line("c2", 2, "gloo", env)
-    assert got["config"]["rotation_cache_QX"] == "replicated" and got["config"]["QtXt_reduce_scatter"] == "after the product"
-    same(plain("c2"), got, "c2, 2 ranks, replicated cache")
+def test_c2_three_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain):
+    """4 + 4 + 5 SNP blocks; 31 giant slots per rank (93 > 91: the last rank owns 29); the default multi-GPU configuration"""
+    got = bench_line("c2", 3, "gloo", SHARED_GPU_ENV)
+    assert got["n_gpus"] == 3 and got["config"]["rotation_cache_QX"] == "replicated"
+    assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
+    same(plain("c2"), got, "c2, 3 ranks")
+
+
+def test_c2_three_ranks_sharded_cache_and_unpipelined_reduce_scatter(plain):
+    """the other A/B switch: reduce-scatters issued after the whole Q'*X^T accumulate (the path a rank takes when its own rotation cache does not
+    fit), whose last window runs past its block column into the padding"""
+    env = dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="sharded", SFG_BENCH_CACHE2_GB="0")
+    got = bench_line("c2", 3, "gloo", env)
+    assert got["config"]["rotation_cache_QX"].startswith("sharded") and got["config"]["QtXt_reduce_scatter"] == "after the product"
+    same(plain("c2"), got, "c2, 3 ranks, sharded cache, unpipelined")
 
 
 def test_c3_two_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain):
     """50 000 x 500 000 (62 SNP blocks, 7 block rows of individuals): several MAC groups per rank, 7 reduce-scatter windows of which the last runs
-    past its block column, 46 giant slots per rank of which the last rank owns 45"""
-    got = bench_line("c3", 2, "gloo", SHARED_GPU_ENV)
-    assert got["n_gpus"] == 2
+    past its block column, 46 giant slots per rank of which the last rank owns 45; sharded rotation cache with a SHORT last shard (105 jobs = 53 + 52:
+    the all-gather is padded)"""
+    got = bench_line("c3", 2, "gloo", dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="sharded"))
+    assert got["n_gpus"] == 2 and got["config"]["rotation_cache_QX"].startswith("sharded")
     same(plain("c3"), got, "c3, 2 ranks")
 
 
