@@ -162,6 +162,17 @@ void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g);
  * (the script's assert) or wrong magic. */
 int sfg_geno_from_bed(sfg_ctx *ctx, const uint8_t *bed_host, size_t bed_bytes, size_t num_sample, size_t num_snp,
                       const uint8_t *row_filter, const uint8_t *col_filter, sfg_geno **out);
+/* PLINK 2 .pgen hard calls (the reference's shipped example data, config 1): replaces gwas/utilities.go:141 FilterMatrixFilePgen ->
+ * scripts/filterMatrixPgen.sh:12-18 (plink2 --pfile --keep --extract --indiv-sort none --make-bed, then plinkBedToBinary.py) for variants [v0, v1)
+ * of one file (v1 = 0: all).  pgen_host: the whole .pgen image (storage mode 0x10 or 0x02; hard calls only).  row_filter: one byte per sample of the
+ * .psam (the --keep list as a mask), col_filter: one byte per variant of [v0, v1) (the --extract list), zero = drop, NULL = keep all.
+ * Result: resident sample-major int8 (ALT allele count, missing = -1), i.e. the bytes of the temporary file GenoFileStream would read. */
+int sfg_pgen_dims(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, size_t *num_sample, size_t *num_variant);
+int sfg_geno_from_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, size_t v0, size_t v1,
+                       const uint8_t *row_filter, const uint8_t *col_filter, sfg_geno **out);
+/* scripts/preprocessing/computeGenoCounts.py (plink2 --keep --geno-counts, columns 5-10; the file behind geno_count_file, read at
+ * gwas/qualcontrol.go:595): counts_host[6][num_variant] uint32 = HOM_REF_CT, HET_REF_ALT_CTS, TWO_ALT_GENO_CTS, HAP_REF_CT, HAP_ALT_CTS, MISSING_CT */
+int sfg_pgen_geno_counts(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, const uint8_t *row_filter, uint32_t *counts_host);
 /* 2-bit packed residency (c4 is 25 GB instead of 100 GB; c5 fits 8 GPUs): codes 0, 1, 2 = the genotype, 3 = missing, 4 columns per byte.
  * Every product entry point takes a packed handle (blocks are expanded on the fly, ~1 % of a block's time); results are bit-identical.  Fails if a
  * value above 2 is present (the int8 layout stays available for such matrices).  Free the int8 handle afterwards to release its memory. */

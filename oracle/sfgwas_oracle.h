@@ -95,6 +95,12 @@ int orc_rotate_right(const orc_ring *r, const orc_rotkeys *keys, int level, cons
 int orc_bed_decode(const uint8_t *bed, size_t bed_bytes, size_t num_sample, size_t num_snp, int8_t *out);
 void orc_filter_matrix(const int8_t *in, size_t nrows, size_t ncols, const uint8_t *rf, const uint8_t *cf, int8_t *out);
 
+/* PLINK 2 .pgen hard calls (published PGEN specification restated; pinned by the reference's all.gcount.transpose.bin for record types 0 / 1) */
+int orc_pgen_index(const uint8_t *f, size_t bytes, uint32_t *nv_out, uint32_t *ns_out, uint64_t **off, uint32_t **len, uint8_t **vrt);
+int orc_pgen_decode_codes(const uint8_t *f, size_t bytes, uint32_t v0, uint32_t v1, uint8_t *genovec);
+int orc_pgen_to_int8(const uint8_t *f, size_t bytes, uint32_t v0, uint32_t v1, const uint8_t *row_filter, const uint8_t *col_filter, int8_t *out);
+int orc_pgen_geno_counts(const uint8_t *f, size_t bytes, const uint8_t *row_filter, uint32_t *counts);
+
 /* ---- remaining evaluator ops of crypto/basics.go used between the matmuls (C2-C4) ---- */
 void orc_ct_addsub(const orc_ring *r, int level, const uint64_t *a, const uint64_t *b, int sub, uint64_t *out);
 void orc_mulrelin(const orc_ring *r, int level, const uint64_t *a, const uint64_t *b, const uint64_t *rlk, uint64_t *out);

@@ -72,6 +72,9 @@ def _sig(L):
         "sfg_geno_free": (None, [vp, vp]),
         "sfg_geno_from_bed": (i, [vp, vp, sz, sz, sz, vp, vp, C.POINTER(vp)]),
         "sfg_geno_dims": (i, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_pgen_dims": (i, [vp, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_geno_from_pgen": (i, [vp, vp, sz, sz, sz, vp, vp, C.POINTER(vp)]),
+        "sfg_pgen_geno_counts": (i, [vp, vp, sz, vp, vp]),
         "sfg_geno_download": (i, [vp, vp, vp]),
         "sfg_geno_transpose": (i, [vp, vp, C.POINTER(vp)]),
         "sfg_geno_concat_cols": (i, [vp, C.POINTER(vp), i, C.POINTER(vp)]),
@@ -414,8 +417,32 @@ def _ctx_geno_from_bed(self, bed, num_sample, num_snp, row_filter=None, col_filt
     return g
 
 
+def _ctx_geno_from_pgen(self, img, v0=0, v1=0, row_filter=None, col_filter=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rf = None if row_filter is None else np.ascontiguousarray(row_filter, dtype=np.uint8)
+    cf = None if col_filter is None else np.ascontiguousarray(col_filter, dtype=np.uint8)
+    g = C.c_void_p()
+    self.check(lib().sfg_geno_from_pgen(self.h, img.ctypes.data_as(C.c_void_p), img.size, v0, v1,
+                                        None if rf is None else rf.ctypes.data_as(C.c_void_p),
+                                        None if cf is None else cf.ctypes.data_as(C.c_void_p), C.byref(g)), "geno_from_pgen")
+    return g
+
+
+def _ctx_pgen_geno_counts(self, img, row_filter=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ns, nv = C.c_size_t(), C.c_size_t()
+    self.check(lib().sfg_pgen_dims(self.h, img.ctypes.data_as(C.c_void_p), img.size, C.byref(ns), C.byref(nv)), "pgen_dims")
+    rf = None if row_filter is None else np.ascontiguousarray(row_filter, dtype=np.uint8)
+    out = np.empty((6, nv.value), dtype=np.uint32)
+    self.check(lib().sfg_pgen_geno_counts(self.h, img.ctypes.data_as(C.c_void_p), img.size, None if rf is None else rf.ctypes.data_as(C.c_void_p),
+                                          out.ctypes.data_as(C.c_void_p)), "pgen_geno_counts")
+    return out
+
+
 Context.geno_to_host = _ctx_geno_to_host
 Context.geno_from_bed = _ctx_geno_from_bed
+Context.geno_from_pgen = _ctx_geno_from_pgen
+Context.pgen_geno_counts = _ctx_pgen_geno_counts
 
 
 def _ctx_encode_vectors(self, values, level):

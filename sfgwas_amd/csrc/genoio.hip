@@ -8,9 +8,11 @@
 #include "kernels.hpp"
 #include <algorithm>
 
-// tile = 64 SNPs x 64 bytes (256 samples). grid (ceil(bps/64), ceil(num_snp/64)), 256 threads
+// tile = 64 SNPs x 64 bytes (256 samples). grid (ceil(bps/64), ceil(num_snp/64)), 256 threads.  lut: int8 value of 2-bit code c in byte c
+// (.bed: 00 -> 2, 01 -> -1, 10 -> 1, 11 -> 0 = BED_LUT; .pgen genotype codes: c -> c, 3 -> -1)
+constexpr unsigned BED_LUT = 0x0001FF02u;
 __global__ void __launch_bounds__(256) k_bed_decode(const uint8_t *bed, size_t bps, size_t num_sample, size_t num_snp,
-                                                    const int32_t *row_map, const int32_t *col_map, int8_t *out, size_t ld) {
+                                                    const int32_t *row_map, const int32_t *col_map, int8_t *out, size_t ld, unsigned lut) {
     __shared__ int8_t tile[256][65];                          // [sample][snp], padded
     const size_t b0 = (size_t)blockIdx.x * 64, j0 = (size_t)blockIdx.y * 64;
     const int t = threadIdx.x;
@@ -20,7 +22,7 @@ __global__ void __launch_bounds__(256) k_bed_decode(const uint8_t *bed, size_t b
         uint32_t v = 0;
         if (j0 + snp < num_snp && b0 + byte < bps) v = bed[(j0 + snp) * bps + b0 + byte];
 #pragma unroll
-        for (int k = 0; k < 4; k++) tile[byte * 4 + k][snp] = (int8_t)(0x0001FF02u >> (8 * ((v >> (2 * k)) & 3)));
+        for (int k = 0; k < 4; k++) tile[byte * 4 + k][snp] = (int8_t)(lut >> (8 * ((v >> (2 * k)) & 3)));
     }
     __syncthreads();
     for (int it = 0; it < 64; it++) {                          // 64 consecutive SNPs of one sample per wave
@@ -43,11 +45,15 @@ __global__ void __launch_bounds__(256) k_geno_transpose(const int8_t *in, size_t
 }
 
 // decode + filter + transpose of a packed SNP range already in HBM, on the given queue (stream.hip streams batches through this)
-int launch_bed_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
-                      int8_t *out, size_t ld) {
-    hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((bps + 63) / 64), (unsigned)((num_snp + 63) / 64)), dim3(256), 0, st, dbed, bps, num_sample, num_snp, rmap, cmap, out, ld);
+int launch_bed_decode_lut(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
+                          int8_t *out, size_t ld, unsigned lut) {
+    hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((bps + 63) / 64), (unsigned)((num_snp + 63) / 64)), dim3(256), 0, st, dbed, bps, num_sample, num_snp, rmap, cmap, out, ld, lut);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
+}
+int launch_bed_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
+                      int8_t *out, size_t ld) {
+    return launch_bed_decode_lut(ctx, st, dbed, bps, num_sample, num_snp, rmap, cmap, out, ld, BED_LUT);
 }
 // ---- 2-bit packed residency (100k x 1M is 25 GB instead of 100 GB; 500k x 10M fits 8 GPUs).  Codes 0, 1, 2 = the genotype,
 // 3 = missing; 4 consecutive columns per byte, low bits first; a row is ceil(ncol / 16) dwords.  The products expand one 8192 x 8192 block at a time
@@ -163,7 +169,7 @@ extern "C" int sfg_geno_from_bed(sfg_ctx *ctx, const uint8_t *bed_host, size_t b
     SFG_HIP(ctx, hipMalloc(&d, nr * nc));
     SFG_HIP(ctx, hipMemcpyAsync(dbed, bed_host + 3, num_snp * bps, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((bps + 63) / 64), (unsigned)((num_snp + 63) / 64)), dim3(256), 0, ctx->stream,
-                       dbed, bps, num_sample, num_snp, rmap, cmap, d, nc);
+                       dbed, bps, num_sample, num_snp, rmap, cmap, d, nc, BED_LUT);
     SFG_HIP(ctx, hipGetLastError());
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(dbed); (void)hipFree(rmap); (void)hipFree(cmap);

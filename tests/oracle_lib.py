@@ -88,6 +88,12 @@ def lib():
         L.orc_bed_decode.restype = C.c_int
         L.orc_bed_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_filter_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pgen_decode_codes.restype = C.c_int
+        L.orc_pgen_decode_codes.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_pgen_to_int8.restype = C.c_int
+        L.orc_pgen_to_int8.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pgen_geno_counts.restype = C.c_int
+        L.orc_pgen_geno_counts.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_scale_up_exact.restype = C.c_uint64
         L.orc_scale_up_exact.argtypes = [C.c_double, C.c_double, C.c_uint64]
         L.orc_mul_const.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, u64p, C.POINTER(C.c_double)]
@@ -352,3 +358,32 @@ def secret_ntt(ring, s_coeff):
         q = ring.moduli[j]
         rows[j] = ring.ntt(j, np.where(s_coeff < 0, q - 1, s_coeff.astype(np.int64)).astype(np.uint64))
     return rows
+
+
+# ---- PLINK 2 .pgen (oracle side)
+def pgen_dims(img):
+    return int(img[7:11].view("<u4")[0]), int(img[3:7].view("<u4")[0])          # samples, variants
+
+
+def pgen_geno_counts(img, row_filter=None):
+    ns, nv = pgen_dims(img)
+    out = np.zeros((6, nv), dtype=np.uint32)
+    rf = None if row_filter is None else np.ascontiguousarray(row_filter, dtype=np.uint8)
+    rc = lib().orc_pgen_geno_counts(img.ctypes.data, img.size, None if rf is None else rf.ctypes.data, out.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_pgen_geno_counts failed ({rc})")
+    return out
+
+
+def pgen_to_int8(img, v0=0, v1=None, row_filter=None, col_filter=None):
+    ns, nv = pgen_dims(img)
+    v1 = nv if v1 is None else v1
+    rf = None if row_filter is None else np.ascontiguousarray(row_filter, dtype=np.uint8)
+    cf = None if col_filter is None else np.ascontiguousarray(col_filter, dtype=np.uint8)
+    nr = ns if rf is None else int(np.count_nonzero(rf))
+    nc = v1 - v0 if cf is None else int(np.count_nonzero(cf))
+    out = np.empty((nr, nc), dtype=np.int8)
+    rc = lib().orc_pgen_to_int8(img.ctypes.data, img.size, v0, v1, None if rf is None else rf.ctypes.data, None if cf is None else cf.ctypes.data, out.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_pgen_to_int8 failed ({rc})")
+    return out

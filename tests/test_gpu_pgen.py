@@ -1,0 +1,124 @@
+"""Device .pgen decoding (sfgwas_amd/csrc/pgen.hip) and BASELINE config 1 on the reference's REAL example data.
+
+  * sfg_pgen_geno_counts over the 22 chromosome files of party 1 == the reference-held fixture all.gcount.transpose.bin
+    (config/configLocal.Party1.toml:15), all 100 000 SNPs: the device decoder is pinned by the reference itself;
+  * sfg_geno_from_pgen == the oracle's decode, with --keep / --extract style filters and variant windows, on the real files
+    and on synthetic files that contain every record type (tests/pgen_writer.py);
+  * MatMult4Stream with computeSquaredSum (assoc.go:424 form) on the decoded 1000 x 100 000 matrix of party 1: the column
+    sums / sums of squares equal het + 2 homalt / het + 4 homalt of the fixture, three block columns equal the oracle product."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import pgen_writer as pw
+from test_gpu_fullsize import Env, host_cts, SLOTS, N, L, LEVEL, SCALE
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def party1_images():
+    return [np.fromfile(os.path.join(GOLD, "example_party1", "geno", f"chr{c}.pgen"), dtype=np.uint8) for c in range(1, 23)]
+
+
+@pytest.fixture(scope="module")
+def env():
+    e = Env()
+    yield e
+    e.close()
+
+
+def test_device_geno_counts_of_party1_equal_the_reference_fixture(env):
+    ref = np.fromfile(os.path.join(GOLD, "example_party1", "all.gcount.transpose.bin"), dtype=np.uint32).reshape(6, -1)
+    got = np.concatenate([env.ctx.pgen_geno_counts(i) for i in party1_images()], axis=1)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    keep = np.random.default_rng(5).random(1000) < 0.6                    # plink2 --keep
+    img = party1_images()[3]
+    assert np.array_equal(env.ctx.pgen_geno_counts(img, keep), ol.pgen_geno_counts(img, keep))
+
+
+def test_device_decode_of_real_files_equals_the_oracle_with_filters_and_windows(env):
+    lib = env.capi.lib()
+    rnd = np.random.default_rng(17)
+    for c in (0, 10, 21):
+        img = party1_images()[c]
+        ns, nv = ol.pgen_dims(img)
+        g = env.ctx.geno_from_pgen(img)
+        assert np.array_equal(env.ctx.geno_to_host(g), ol.pgen_to_int8(img))
+        lib.sfg_geno_free(env.ctx.h, g)
+        rf, v0 = rnd.random(ns) < 0.8, int(rnd.integers(0, nv - 900))
+        cf = rnd.random(900) < 0.7
+        g = env.ctx.geno_from_pgen(img, v0, v0 + 900, rf, cf)
+        assert np.array_equal(env.ctx.geno_to_host(g), ol.pgen_to_int8(img, v0, v0 + 900, rf, cf))
+        lib.sfg_geno_free(env.ctx.h, g)
+
+
+@pytest.mark.parametrize("ns,nv,wmode,seed", [(1000, 300, 0, 1), (257, 200, 4, 2), (70001, 40, 6, 3), (5, 64, 1, 4), (4096, 150, 7, 5), (100000, 24, 7, 6)])
+def test_device_decodes_every_record_type(env, ns, nv, wmode, seed):
+    """types 0, 1, 2, 3, 4, 6, 7 (parity unpinned beyond 0 / 1: no reference data contains them), 1- to 3-byte sample ids, difflists of many
+    64-entry groups (one thread each), windows that start inside an LD-compressed run"""
+    lib = env.capi.lib()
+    codes, vrt = pw.synthetic(nv, ns, seed)
+    img = pw.write_pgen(codes, vrt, wmode=wmode)
+    want = np.where(codes == 3, -1, codes).astype(np.int8).T
+    assert np.array_equal(ol.pgen_to_int8(img), want)
+    g = env.ctx.geno_from_pgen(img)
+    assert np.array_equal(env.ctx.geno_to_host(g), want)
+    lib.sfg_geno_free(env.ctx.h, g)
+    assert np.array_equal(env.ctx.pgen_geno_counts(img), ol.pgen_geno_counts(img))
+    ld = [v for v in range(1, nv) if vrt[v] in (2, 3)]
+    if ld:
+        v0 = ld[len(ld) // 2]
+        v1 = min(nv, v0 + 7)
+        g = env.ctx.geno_from_pgen(img, v0, v1)
+        assert np.array_equal(env.ctx.geno_to_host(g), want[:, v0:v1])
+        lib.sfg_geno_free(env.ctx.h, g)
+
+
+def test_device_rejects_malformed_files(env):
+    codes, vrt = pw.synthetic(20, 100, 9)
+    img = pw.write_pgen(codes, vrt, wmode=5)
+    bad = img.copy(); bad[0] = 0
+    with pytest.raises(env.capi.SfgError, match="magic"):
+        env.ctx.geno_from_pgen(bad)
+    with pytest.raises(env.capi.SfgError, match="past the end|truncated"):
+        env.ctx.geno_from_pgen(img[:len(img) - 5].copy())
+    multi = pw.write_pgen(codes, np.zeros(20, dtype=np.uint8), wmode=5, extra_vrtype_bits=8)
+    with pytest.raises(env.capi.SfgError, match="multiallelic"):
+        env.ctx.geno_from_pgen(multi)
+    with pytest.raises(env.capi.SfgError, match="out of bounds"):
+        env.ctx.geno_from_pgen(img, 5, 21)
+    corrupt = img.copy(); corrupt[-3:] = 0xFF                                # a varint that never ends inside the last record
+    try:
+        g = env.ctx.geno_from_pgen(corrupt)                                  # either a clean error or a decode; never a fault
+        env.capi.lib().sfg_geno_free(env.ctx.h, g)
+    except env.capi.SfgError:
+        pass
+
+
+def test_config1_matmult4stream_on_the_real_example_data_of_party1(env):
+    """BASELINE configs[0] on its real input: the 22 .pgen files -> device decode -> one 1000 x 100 000 int8 matrix (mergeMatrices order = chromosome
+    order) -> MatMult4Stream(s = 13, computeSquaredSum) as assoc.go:424 calls it.  Sums pinned by the reference's genotype counts, products by the oracle."""
+    lib = env.capi.lib()
+    parts = [env.ctx.geno_from_pgen(i) for i in party1_images()]
+    arr = (C.c_void_p * len(parts))(*[p.value for p in parts])
+    g = C.c_void_p()
+    env.ctx.check(lib.sfg_geno_concat_cols(env.ctx.h, arr, len(parts), C.byref(g)), "concat")
+    geno = env.ctx.geno_to_host(g)
+    for p in parts:
+        lib.sfg_geno_free(env.ctx.h, p)
+    lib.sfg_geno_free(env.ctx.h, g)
+    assert geno.shape == (1000, 100_000)
+    ref = np.fromfile(os.path.join(GOLD, "example_party1", "all.gcount.transpose.bin"), dtype=np.uint32).reshape(6, -1).astype(np.float64)
+    s = 13                                                                  # ncov + 1 + npc + 2 (assoc.go:699-704)
+    A = host_cts(env.ring, s, 1, LEVEL, 21)
+    got, sm, sq = env.ctx.matmul_stream(A, LEVEL, L, geno, want_sums=True)
+    assert np.array_equal(sm, ref[1] + 2 * ref[2]) and np.array_equal(sq, ref[1] + 4 * ref[2])
+    m_ct = (geno.shape[1] - 1) // SLOTS + 1
+    assert got.shape == (s, m_ct, 2, L, N)
+    for j in (0, 5, m_ct - 1):
+        sub = np.ascontiguousarray(geno[:, j * SLOTS:(j + 1) * SLOTS])
+        want, _, _ = ol.matmult4stream(env.ring, env.keys, SCALE, A, LEVEL, L, sub, enc_prec=1)
+        assert np.array_equal(got[:, j], want[:, 0]), f"block column {j}"
