@@ -281,6 +281,17 @@ int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, in
 int sfg_refresh_finish_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, const uint64_t *h0agg_dev, const uint64_t *h1agg_dev,
                            const uint64_t *crs_dev, uint64_t *out_dev);
 
+/* The target-scale form, which is what the reference calls: mhe.go:251,315 GenShares(sk, levelStart, nParties, ct, parameters.Scale(), crp, ...) and
+ * mhe.go:257,330 Recode(ct, parameters.Scale()), on products whose scale is A.scale * Params.Scale() (matmult.go:44,92 -> :1045).  PARITY UNPINNED:
+ * restated from the published lattigo v2.2.0 dckks/refresh.go (the nearest upstream with the targetScale argument):
+ *   GenShares: recrypt share from Quo(mask * Int(target_scale), Int(ct_scale)) (big.Int.Quo, truncated towards zero); decrypt share from the mask itself
+ *   Recode:    x <- Quo(x * Int(target_scale), Int(ct_scale)) on the centred big integer, before the re-reduction into all nq moduli
+ * The caller sets the refreshed ciphertext's scale to target_scale.  mask_limbs <= 8 here. */
+int sfg_refresh_gen_shares_scaled_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, double ct_scale, double target_scale, const uint64_t *crs_dev,
+                                      const uint64_t *mask_dev, int mask_limbs, const int32_t *e0_dev, const int32_t *e1_dev, uint64_t *h0_dev, uint64_t *h1_dev);
+int sfg_refresh_finish_scaled_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, double ct_scale, double target_scale, const uint64_t *h0agg_dev,
+                                  const uint64_t *h1agg_dev, const uint64_t *crs_dev, uint64_t *out_dev);
+
 /* f-4 (partial): ring work of MPC.CMatToSS (mpc/ss.go:146-281): the masked decryption share of each ciphertext and NTT(mask), which the Go side
  * turns into the additive share with the fork's DecodeRVec (ss.go:253-262; fork-only encoder API, stays in Go).
  *   h0 [nct][level+1][N] = NTT(mask) + sk (.) c1 + NTT(e0)   (ss.go:222-236)      mask_ntt [nct][level+1][N] = NTT(mask)   (ctMask, ss.go:226) */

@@ -1325,6 +1325,83 @@ void orc_refresh_gen_shares(const orc_ring *r, int level, const uint64_t *ct, co
     }
     free(m); free(t);
 }
+/* ---- the target-scale form the reference actually calls (mhe.go:251,256-258,315,329-331: GenShares(..., ct, parameters.Scale(), crp, ...) and
+ * Recode(ct, parameters.Scale()) on products whose scale is A.scale * Delta, matmult.go:1045).  The fork's source is absent; the nearest PUBLISHED upstream
+ * that carries the targetScale argument is lattigo v2.2.0 dckks/refresh.go, restated here from memory of that file - PARITY UNPINNED:
+ *   inputScaleInt = Int(big.Float(ct.Scale())), outputScaleInt = Int(big.Float(targetScale))          (truncation of the float64 to an integer)
+ *   GenShares: shareDecrypt from mask as before; then mask <- Quo(mask * outputScaleInt, inputScaleInt) (big.Int.Quo: truncated towards zero),
+ *              shareRecrypt from the scaled mask.
+ *   Recode:    x = centred(PolyToBigint(INTT(c0)));  x <- Quo(x * outputScaleInt, inputScaleInt);  SetCoefficientsBigint at MaxLevel, NTT; scale = target. */
+static void obig_shl(obig *a, int k) { while (k > 0) { int s = k > 63 ? 63 : k; for (int i = ORC_BIG - 1; i >= 0; i--) a->w[i] = (a->w[i] << s) | (i ? a->w[i - 1] >> (64 - s) : 0); k -= s; } }
+static void obig_shr(obig *a, int k) { while (k > 0) { int s = k > 63 ? 63 : k; for (int i = 0; i < ORC_BIG; i++) a->w[i] = (a->w[i] >> s) | (i + 1 < ORC_BIG ? a->w[i + 1] << (64 - s) : 0); k -= s; } }
+static void obig_div_small(obig *a, u64 d) { u128 r = 0; for (int i = ORC_BIG - 1; i >= 0; i--) { u128 cur = (r << 64) | a->w[i]; a->w[i] = (u64)(cur / d); r = cur % d; } }
+/* Int(big.Float(f)) for a finite f >= 1 as m * 2^e with m < 2^53 */
+static void scale_int(double f, u64 *m, int *e) {
+    int ex; double fr = frexp(f, &ex);                              /* f = fr * 2^ex, 0.5 <= fr < 1 */
+    u64 mant = (u64)ldexp(fr, 53); ex -= 53;                        /* f = mant * 2^ex exactly */
+    if (ex < 0) { mant = -ex >= 64 ? 0 : mant >> (-ex); ex = 0; }
+    *m = mant; *e = ex;
+}
+/* |a| <- floor(|a| * Int(out) / Int(in)) */
+static void obig_rescale(obig *a, double out_scale, double in_scale) {
+    u64 mo, mi; int eo, ei; scale_int(out_scale, &mo, &eo); scale_int(in_scale, &mi, &ei);
+    obig_mul_small(a, mo);
+    if (eo >= ei) obig_shl(a, eo - ei); else obig_shr(a, ei - eo);
+    obig_div_small(a, mi);
+}
+void orc_refresh_gen_shares_scaled(const orc_ring *r, int level, const uint64_t *ct, double ct_scale, double target_scale, const uint64_t *sk, const uint64_t *crs,
+                                   const uint64_t *mask, int W, const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1) {
+    int N = r->N;
+    /* the recrypt share uses the rescaled mask: build its two's-complement limbs, then reuse the unscaled routine for each half */
+    u64 *mask2 = malloc((size_t)N * ORC_BIG * 8), *tmp = malloc((size_t)r->nq * N * 8);
+    for (int c = 0; c < N; c++) {
+        obig a; memset(&a, 0, sizeof a);
+        const u64 *src = mask + (size_t)c * W;
+        int neg = (int)(src[W - 1] >> 63);
+        for (int i = 0; i < W; i++) a.w[i] = neg ? ~src[i] : src[i];
+        if (neg) { obig one; obig_set(&one, 1); obig_add(&a, &one); for (int i = W; i < ORC_BIG; i++) a.w[i] = 0; }
+        obig_rescale(&a, target_scale, ct_scale);
+        if (neg) { for (int i = 0; i < ORC_BIG; i++) a.w[i] = ~a.w[i]; obig one; obig_set(&one, 1); obig_add(&a, &one); }
+        memcpy(mask2 + (size_t)c * ORC_BIG, a.w, ORC_BIG * 8);
+    }
+    orc_refresh_gen_shares(r, level, ct, sk, crs, mask, W, e0, e1, h0, tmp);              /* h0 from the mask itself */
+    u64 *h0b = malloc((size_t)(level + 1) * N * 8);
+    orc_refresh_gen_shares(r, level, ct, sk, crs, mask2, ORC_BIG, e0, e1, h0b, h1);        /* h1 from the rescaled mask */
+    free(mask2); free(tmp); free(h0b);
+}
+void orc_refresh_finish_scaled(const orc_ring *r, int level, const uint64_t *ct, double ct_scale, double target_scale, const uint64_t *h0agg, const uint64_t *h1agg,
+                               const uint64_t *crs, uint64_t *out) {
+    int N = r->N, nl = level + 1, nq = r->nq;
+    u64 *x = malloc((size_t)nl * N * 8);
+    for (int j = 0; j < nl; j++) {
+        for (int c = 0; c < N; c++) x[(size_t)j * N + c] = (ct[(size_t)j * N + c] + h0agg[(size_t)j * N + c]) % r->q[j];
+        orc_intt(r, j, x + (size_t)j * N);
+    }
+    obig Q, Qh, Qi[ORC_MAXMOD]; u64 inv[ORC_MAXMOD];
+    obig_set(&Q, 1); for (int i = 0; i < nl; i++) obig_mul_small(&Q, r->q[i]);
+    Qh = Q; obig_shr1(&Qh);
+    for (int i = 0; i < nl; i++) {
+        obig_set(&Qi[i], 1); for (int t = 0; t < nl; t++) if (t != i) obig_mul_small(&Qi[i], r->q[t]);
+        inv[i] = orc_invmod(obig_mod_small(&Qi[i], r->q[i]), r->q[i]);
+    }
+    for (int c = 0; c < N; c++) {
+        obig acc; obig_set(&acc, 0);
+        for (int i = 0; i < nl; i++) { obig t = Qi[i]; obig_mul_small(&t, orc_mulmod(x[(size_t)i * N + c], inv[i], r->q[i])); obig_add(&acc, &t); }
+        while (obig_cmp(&acc, &Q) >= 0) obig_sub(&acc, &Q);
+        int neg = obig_cmp(&acc, &Qh) >= 0;
+        if (neg) { obig t = Q; obig_sub(&t, &acc); acc = t; }
+        obig_rescale(&acc, target_scale, ct_scale);                 /* Quo(x * out, in): truncated towards zero = floor on the magnitude */
+        for (int j = 0; j < nq; j++) { u64 m = obig_mod_small(&acc, r->q[j]); out[(size_t)j * N + c] = neg && m ? r->q[j] - m : m; }
+    }
+    for (int j = 0; j < nq; j++) {
+        orc_ntt(r, j, out + (size_t)j * N);
+        for (int c = 0; c < N; c++) {
+            out[(size_t)j * N + c] = (out[(size_t)j * N + c] + h1agg[(size_t)j * N + c]) % r->q[j];
+            out[((size_t)nq + j) * N + c] = crs[(size_t)j * N + c];
+        }
+    }
+    free(x);
+}
 /* Decrypt + Recode + Recrypt on one ciphertext: ct [2][level+1][N], h0agg [level+1][N], h1agg [nq][N], crs [nq][N]; out [2][nq][N] (level nq-1) */
 void orc_refresh_finish(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs, uint64_t *out) {
     int N = r->N, nl = level + 1, nq = r->nq;

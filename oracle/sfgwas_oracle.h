@@ -181,6 +181,12 @@ void orc_refresh_gen_shares(const orc_ring *r, int level, const uint64_t *ct, co
 void orc_refresh_finish(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs,
                         uint64_t *out /*[2][nq][N]*/);
 
+/* the target-scale form the reference calls (mhe.go:315,330): lattigo v2.2.0 dckks/refresh.go restated, PARITY UNPINNED */
+void orc_refresh_gen_shares_scaled(const orc_ring *r, int level, const uint64_t *ct, double ct_scale, double target_scale, const uint64_t *sk, const uint64_t *crs,
+                                   const uint64_t *mask, int W, const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1);
+void orc_refresh_finish_scaled(const orc_ring *r, int level, const uint64_t *ct, double ct_scale, double target_scale, const uint64_t *h0agg, const uint64_t *h1agg,
+                               const uint64_t *crs, uint64_t *out);
+
 /* splitmix64 — the synthetic-data PRNG shared by oracle, tests, bench and device generators */
 uint64_t orc_splitmix64(uint64_t *state);
 

@@ -36,6 +36,8 @@ def _sig(L):
         "sfg_ct_mul_scalar_add_dev": (i, [vp, vp, u64p, vp, i, i]),
         "sfg_refresh_gen_shares_dev": (i, [vp, vp, i, i, vp, vp, i, vp, vp, vp, vp]),
         "sfg_refresh_finish_dev": (i, [vp, vp, i, i, vp, vp, vp, vp]),
+        "sfg_refresh_gen_shares_scaled_dev": (i, [vp, vp, i, i, d, d, vp, vp, i, vp, vp, vp, vp]),
+        "sfg_refresh_finish_scaled_dev": (i, [vp, vp, i, i, d, d, vp, vp, vp, vp]),
         "sfg_ckks_to_ss_share_dev": (i, [vp, vp, i, i, vp, i, vp, vp, vp]),
         "sfg_geno_pack": (i, [vp, vp, C.POINTER(vp)]),
         "sfg_geno_unpack": (i, [vp, vp, C.POINTER(vp)]),
@@ -215,12 +217,17 @@ class Context:
         assert sk_rows.shape == (self.nq, self.N)
         self.check(lib().sfg_ctx_load_secret_key(self.h, p64(sk_rows), int(montgomery)), "load_secret_key")
 
-    def refresh_gen_shares(self, cts, level, crs, mask_limbs, e0, e1):
-        """cts [nct][2][level+1][N], crs [nct][nq][N], mask_limbs [nct][N][W] uint64, e0/e1 [nct][N] int32 -> (h0 [nct][level+1][N], h1 [nct][nq][N])"""
+    def refresh_gen_shares(self, cts, level, crs, mask_limbs, e0, e1, scales=None):
+        """cts [nct][2][level+1][N], crs [nct][nq][N], mask_limbs [nct][N][W] uint64, e0/e1 [nct][N] int32 -> (h0 [nct][level+1][N], h1 [nct][nq][N]);
+        scales = (ciphertext scale, target scale) selects the target-scale form"""
         nct, W = cts.shape[0], mask_limbs.shape[-1]
         d = [self.to_device(np.ascontiguousarray(a)) for a in (cts, crs, mask_limbs, e0.astype(np.int32), e1.astype(np.int32))]
         h0, h1 = self.malloc(nct * (level + 1) * self.N * 8), self.malloc(nct * self.nq * self.N * 8)
-        self.check(lib().sfg_refresh_gen_shares_dev(self.h, d[0], nct, level, d[1], d[2], W, d[3], d[4], h0, h1), "refresh_gen_shares")
+        if scales is None:
+            self.check(lib().sfg_refresh_gen_shares_dev(self.h, d[0], nct, level, d[1], d[2], W, d[3], d[4], h0, h1), "refresh_gen_shares")
+        else:
+            self.check(lib().sfg_refresh_gen_shares_scaled_dev(self.h, d[0], nct, level, float(scales[0]), float(scales[1]), d[1], d[2], W, d[3], d[4], h0, h1),
+                       "refresh_gen_shares_scaled")
         out = self.to_host(h0, (nct, level + 1, self.N), np.uint64), self.to_host(h1, (nct, self.nq, self.N), np.uint64)
         for p_ in d + [h0, h1]:
             self.free(p_)
@@ -236,11 +243,14 @@ class Context:
             self.free(p_)
         return out
 
-    def refresh_finish(self, cts, level, h0agg, h1agg, crs):
+    def refresh_finish(self, cts, level, h0agg, h1agg, crs, scales=None):
         nct = cts.shape[0]
         d = [self.to_device(np.ascontiguousarray(a)) for a in (cts, h0agg, h1agg, crs)]
         o = self.malloc(nct * 2 * self.nq * self.N * 8)
-        self.check(lib().sfg_refresh_finish_dev(self.h, d[0], nct, level, d[1], d[2], d[3], o), "refresh_finish")
+        if scales is None:
+            self.check(lib().sfg_refresh_finish_dev(self.h, d[0], nct, level, d[1], d[2], d[3], o), "refresh_finish")
+        else:
+            self.check(lib().sfg_refresh_finish_scaled_dev(self.h, d[0], nct, level, float(scales[0]), float(scales[1]), d[1], d[2], d[3], o), "refresh_finish_scaled")
         out = self.to_host(o, (nct, 2, self.nq, self.N), np.uint64)
         for p_ in d + [o]:
             self.free(p_)

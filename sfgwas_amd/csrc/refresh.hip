@@ -107,6 +107,127 @@ __global__ void __launch_bounds__(256) k_recrypt(u64 *out, const u64 *h1, const 
     out[o + (size_t)nq * N] = crs[s];
 }
 
+// ---- target-scale form (what the reference calls: mhe.go:251,256-258,315,329-331 pass parameters.Scale() while the products they refresh carry
+// A.scale * Delta, matmult.go:1045).  lattigo v2.2.0 dckks/refresh.go restated (PARITY UNPINNED, see oracle/sfgwas_oracle.c):
+//   GenShares: the recrypt share is built from Quo(mask * Int(target), Int(ct scale));  Recode: x <- Quo(x * Int(target), Int(ct scale)) before the
+//   re-reduction into all nq moduli.  Quo truncates towards zero: floor on the magnitude, sign kept.  Int(float64) = m * 2^e exactly (m < 2^53), so the
+//   ratio is one multiplication by m_out, one shift by e_out - e_in and one short division by m_in on a 512-bit magnitude, one coefficient per lane.
+constexpr int BG = 8;                                    // 64-bit limbs of a device big integer
+struct ScaleRatio { u64 mo, mi; int sh; };               // |x| <- floor(|x| * mo * 2^sh / mi)
+__device__ __forceinline__ void bg_mul_add(u64 (&a)[BG], u64 m, u64 add) {          // a = a * m + add
+    u64 c = add;
+#pragma unroll
+    for (int i = 0; i < BG; i++) { const u64 lo = a[i] * m, hi = __umul64hi(a[i], m); const u64 s = lo + c; a[i] = s; c = hi + (s < lo); }
+}
+__device__ __forceinline__ void bg_rsub(u64 (&a)[BG], const u64 *b) {               // a = b - a   (b >= a)
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < BG; i++) { const u64 bi = b[i], d = bi - a[i], d2 = d - br; br = (bi < a[i]) | (d < br); a[i] = d2; }
+}
+__device__ __forceinline__ void bg_shift(u64 (&a)[BG], int sh) {                    // sh > 0: left, sh < 0: right (uniform per launch)
+    if (!sh) return;
+    u64 t[BG];
+    const int k = sh > 0 ? sh : -sh, ws = k >> 6, bs = k & 63;
+#pragma unroll
+    for (int i = 0; i < BG; i++) {
+        u64 v = 0;
+        if (sh > 0) { const int s0 = i - ws; const u64 hi = s0 >= 0 ? a[s0] : 0, lo = s0 - 1 >= 0 ? a[s0 - 1] : 0; v = bs ? (hi << bs) | (lo >> (64 - bs)) : hi; }
+        else { const int s0 = i + ws; const u64 lo = s0 < BG ? a[s0] : 0, hi = s0 + 1 < BG ? a[s0 + 1] : 0; v = bs ? (lo >> bs) | (hi << (64 - bs)) : lo; }
+        t[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BG; i++) a[i] = t[i];
+}
+__device__ __forceinline__ void bg_div_small(u64 (&a)[BG], u64 d) {                 // a = floor(a / d), d < 2^53: a byte at a time, r * 256 + byte < 2^61
+    if (d == 1) return;
+    u64 r = 0;
+#pragma unroll
+    for (int i = BG - 1; i >= 0; i--) {
+        u64 w = a[i], q = 0;
+#pragma unroll
+        for (int b = 7; b >= 0; b--) { r = (r << 8) | ((w >> (8 * b)) & 0xFF); const u64 qb = r / d; r -= qb * d; q = (q << 8) | qb; }
+        a[i] = q;
+    }
+}
+__device__ __forceinline__ void bg_rescale(u64 (&a)[BG], const ScaleRatio &sr) { bg_mul_add(a, sr.mo, 0); bg_shift(a, sr.sh); bg_div_small(a, sr.mi); }
+__device__ __forceinline__ double bg_mod(const u64 (&a)[BG], double q, double qinv) {   // Horner over 32-bit digits in exact fp64
+    const double B = canon(4294967296.0, q, qinv), Bq = B * qinv;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = BG - 1; i >= 0; i--) {
+        acc = canon(mulmod_lazy(acc, B, Bq, q) + (double)(unsigned)(a[i] >> 32), q, qinv);
+        acc = canon(mulmod_lazy(acc, B, Bq, q) + (double)(unsigned)a[i], q, qinv);
+    }
+    return acc;
+}
+// rows[(ct, j)][x] = (Quo(mask * out, in) + e)[ct][x] mod q_j for all nmod moduli.  grid (N/256, nct)
+__global__ void __launch_bounds__(256) k_bigint_rows_scaled(const u64 *mask, int W, const int *e, u64 *rows, int nmod, ScaleRatio sr, const ModConst *modc) {
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x; const size_t c = blockIdx.y;
+    const u64 *src = mask + (c * N + x) * (size_t)W;
+    const bool neg = (src[W - 1] >> 63) != 0;
+    u64 a[BG];
+#pragma unroll
+    for (int i = 0; i < BG; i++) a[i] = i < W ? (neg ? ~src[i] : src[i]) : 0;
+    if (neg) { u64 cy = 1; for (int i = 0; i < BG && cy; i++) { a[i] += cy; cy = a[i] == 0; } for (int i = W; i < BG; i++) a[i] = 0; }
+    bg_rescale(a, sr);
+    const double ev = (double)e[c * N + x];
+    for (int j = 0; j < nmod; j++) {
+        const double q = modc[j].q, qinv = modc[j].qinv;
+        double v = bg_mod(a, q, qinv);
+        if (neg) v = v == 0.0 ? 0.0 : q - v;
+        v += ev; v = v < 0.0 ? v + q : v; v = v >= q ? v - q : v;
+        rows[(c * nmod + j) * (size_t)N + x] = f64_to_u64(v);
+    }
+}
+struct RecodeBig { u64 Q[BG]; u64 qi[RF_MAXL]; };
+// Recode with the scale ratio: every one of the nq output rows comes from the rescaled big integer.  grid (N/256, nct)
+__global__ void __launch_bounds__(256) k_recode_scaled(const u64 *xin, u64 *out, RecodeConst rc, RecodeBig rb, ScaleRatio sr, const ModConst *modc) {
+    const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x; const size_t c = blockIdx.y;
+    const int nl = rc.nl, nq = rc.nq;
+    double v[RF_MAXL];
+    for (int i = 0; i < nl; i++) {
+        const double q = modc[i].q, qinv = modc[i].qinv;
+        double t = u64_to_f64(xin[(c * nl + i) * (size_t)N + x]);
+        for (int s = 0; s < i; s++) {
+            const double d = t - canon(v[s], q, qinv);
+            t = canon(mulmod_lazy(d, rc.inv[i][s], rc.inv[i][s] * qinv, q), q, qinv);
+        }
+        v[i] = t;
+    }
+    bool neg = true;
+    for (int i = nl - 1; i >= 0; i--) if (v[i] != rc.half[i]) { neg = v[i] > rc.half[i]; break; }
+    u64 a[BG];
+#pragma unroll
+    for (int i = 0; i < BG; i++) a[i] = 0;
+    a[0] = f64_to_u64(v[nl - 1]);
+    for (int i = nl - 2; i >= 0; i--) bg_mul_add(a, rb.qi[i], f64_to_u64(v[i]));      // x = v0 + q0 (v1 + q1 (v2 + ...))
+    if (neg) bg_rsub(a, rb.Q);                                                         // |x - Q|
+    bg_rescale(a, sr);
+    u64 *o = out + c * 2 * nq * (size_t)N + x;
+    for (int j = 0; j < nq; j++) {
+        const double q = modc[j].q, qinv = modc[j].qinv;
+        double r = bg_mod(a, q, qinv);
+        if (neg) r = r == 0.0 ? 0.0 : q - r;
+        o[(size_t)j * N] = f64_to_u64(r);
+    }
+}
+// Int(big.Float(f)) = m * 2^e, m < 2^53, for a finite scale f >= 1
+static int scale_int(sfg_ctx *ctx, double f, u64 &m, int &e) {
+    if (!(f >= 1.0) || f > 0x1p400) SFG_FAIL(ctx, "refresh: scale %g out of range", f);
+    int ex; const double fr = frexp(f, &ex);
+    m = (u64)ldexp(fr, 53); e = ex - 53;
+    if (e < 0) { m >>= -e; e = 0; }
+    return 0;
+}
+static int scale_ratio(sfg_ctx *ctx, int level, double ct_scale, double target_scale, ScaleRatio &sr) {
+    u64 mo, mi; int eo, ei;
+    SFG_TRY(scale_int(ctx, target_scale, mo, eo)); SFG_TRY(scale_int(ctx, ct_scale, mi, ei));
+    double bits = 0; for (int i = 0; i <= level; i++) bits += log2((double)ctx->q[i]);
+    if (bits + 54 + (eo > ei ? eo - ei : 0) > 64.0 * BG - 2) SFG_FAIL(ctx, "refresh: Q_level * target scale / ciphertext scale does not fit %d bits", 64 * BG);
+    sr.mo = mo; sr.mi = mi; sr.sh = eo - ei;
+    return 0;
+}
+
 static int refresh_check(sfg_ctx *ctx, int nct, int level) {
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "refresh: level %d out of range", level);
     if (level + 1 > RF_MAXL) SFG_FAIL(ctx, "refresh: more than %d moduli at the input level", RF_MAXL);
@@ -114,8 +235,21 @@ static int refresh_check(sfg_ctx *ctx, int nct, int level) {
     return 0;
 }
 
+static int refresh_gen_shares(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *crs, const uint64_t *mask, int W,
+                              const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1, const ScaleRatio *sr);
 extern "C" int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *crs, const uint64_t *mask, int W,
                                           const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1) {
+    return refresh_gen_shares(ctx, ct, nct, level, crs, mask, W, e0, e1, h0, h1, nullptr);
+}
+extern "C" int sfg_refresh_gen_shares_scaled_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, double ct_scale, double target_scale, const uint64_t *crs,
+                                                 const uint64_t *mask, int W, const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1) {
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "refresh: level %d out of range", level);
+    ScaleRatio sr; SFG_TRY(scale_ratio(ctx, level, ct_scale, target_scale, sr));
+    if (W > BG) SFG_FAIL(ctx, "refresh: mask limb count %d exceeds %d in the target-scale form", W, BG);
+    return refresh_gen_shares(ctx, ct, nct, level, crs, mask, W, e0, e1, h0, h1, &sr);
+}
+static int refresh_gen_shares(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *crs, const uint64_t *mask, int W,
+                              const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1, const ScaleRatio *sr) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     SFG_TRY(refresh_check(ctx, nct, level));
     if (!ctx->sh->sk_dev) SFG_FAIL(ctx, "refresh: no secret-key shard loaded (sfg_ctx_load_secret_key)");
@@ -130,7 +264,8 @@ extern "C" int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct, int 
     SFG_TRY(launch_ntt_fwd(ctx, (const u64 *)h0, (u64 *)h0, (size_t)nct * nl, p0));
     hipLaunchKernelGGL(k_share, dim3(N / 256, nl, nct), dim3(256), 0, ctx->stream, (const u64 *)h0, sk, (const u64 *)ct + (size_t)nl * N, (size_t)2 * nl * N, (u64 *)h0, nl, 0, ctx->modc);
     // h1: all nq moduli, against the common reference polynomial, negated
-    hipLaunchKernelGGL(k_bigint_rows, dim3(N / 256, nq, nct), dim3(256), 0, ctx->stream, (const u64 *)mask, W, (const int *)e1, (u64 *)h1, nq, ctx->modc);
+    if (sr) hipLaunchKernelGGL(k_bigint_rows_scaled, dim3(N / 256, nct), dim3(256), 0, ctx->stream, (const u64 *)mask, W, (const int *)e1, (u64 *)h1, nq, *sr, ctx->modc);
+    else hipLaunchKernelGGL(k_bigint_rows, dim3(N / 256, nq, nct), dim3(256), 0, ctx->stream, (const u64 *)mask, W, (const int *)e1, (u64 *)h1, nq, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     ModPattern p1; p1.period = nq; for (int j = 0; j < nq; j++) p1.m[j] = (int8_t)j;
     SFG_TRY(launch_ntt_fwd(ctx, (const u64 *)h1, (u64 *)h1, (size_t)nct * nq, p1));
@@ -191,8 +326,20 @@ static void recode_constants(const sfg_ctx *ctx, int level, RecodeConst &rc) {
     }
 }
 
+static int refresh_finish(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs,
+                          uint64_t *out, const ScaleRatio *sr);
 extern "C" int sfg_refresh_finish_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs,
                                       uint64_t *out) {
+    return refresh_finish(ctx, ct, nct, level, h0agg, h1agg, crs, out, nullptr);
+}
+extern "C" int sfg_refresh_finish_scaled_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, double ct_scale, double target_scale, const uint64_t *h0agg,
+                                             const uint64_t *h1agg, const uint64_t *crs, uint64_t *out) {
+    if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "refresh: level %d out of range", level);
+    ScaleRatio sr; SFG_TRY(scale_ratio(ctx, level, ct_scale, target_scale, sr));
+    return refresh_finish(ctx, ct, nct, level, h0agg, h1agg, crs, out, &sr);
+}
+static int refresh_finish(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *h0agg, const uint64_t *h1agg, const uint64_t *crs,
+                          uint64_t *out, const ScaleRatio *sr) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     SFG_TRY(refresh_check(ctx, nct, level));
     if (!nct) return 0;
@@ -206,7 +353,12 @@ extern "C" int sfg_refresh_finish_dev(sfg_ctx *ctx, const uint64_t *ct, int nct,
     SFG_TRY(launch_ntt_inv(ctx, x, x, (size_t)nct * nl, p0));
     // Recode into all nq moduli
     RecodeConst rc; recode_constants(ctx, level, rc);
-    hipLaunchKernelGGL(k_recode, dim3(N / 256, nct), dim3(256), 0, ctx->stream, (const u64 *)x, (u64 *)out, rc, ctx->modc);
+    if (sr) {
+        RecodeBig rb; memset(&rb, 0, sizeof rb);
+        HBig Q(1); for (int i = 0; i < nl; i++) { Q.mul_small(ctx->q[i]); rb.qi[i] = ctx->q[i]; }
+        for (size_t i = 0; i < Q.w.size() && i < (size_t)BG; i++) rb.Q[i] = Q.w[i];
+        hipLaunchKernelGGL(k_recode_scaled, dim3(N / 256, nct), dim3(256), 0, ctx->stream, (const u64 *)x, (u64 *)out, rc, rb, *sr, ctx->modc);
+    } else hipLaunchKernelGGL(k_recode, dim3(N / 256, nct), dim3(256), 0, ctx->stream, (const u64 *)x, (u64 *)out, rc, ctx->modc);
     SFG_HIP(ctx, hipGetLastError());
     ModPattern p1; p1.period = nq; for (int j = 0; j < nq; j++) p1.m[j] = (int8_t)j;
     RowMap rm; rm.rpg = nq; rm.gstride_in = rm.gstride_out = (size_t)2 * nq * N;           // polynomial 0 of every output ciphertext

@@ -331,6 +331,13 @@ inline DevCipherMatrix ToDevice(CryptoParams *cps, const CipherMatrix &A) {
     return m;
 }
 inline CipherMatrix ToHost(const DevCipherMatrix &m) { CipherMatrix out(m.rows); for (size_t i = 0; i < m.rows; i++) out[i] = ToHost(m.row(i)); return out; }
+// a resident CipherMatrix whose ciphertexts keep their OWN level and scale (crypto.CipherMatrix is [][]*ckks.Ciphertext): [row][col] one-ciphertext vectors
+using DevCipherCells = std::vector<std::vector<DevCipherVector>>;
+inline CipherMatrix ToHost(const DevCipherCells &c) {
+    CipherMatrix out(c.size());
+    for (size_t i = 0; i < c.size(); i++) for (const auto &v : c[i]) { CipherVector h = ToHost(v); out[i].insert(out[i].end(), h.begin(), h.end()); }
+    return out;
+}
 
 // crypto.DropLevel on device (basics.go:806-824)
 inline DevCipherVector DropLevelDev(const DevCipherVector &X, int outLevel) {
@@ -751,11 +758,12 @@ inline crypto::DevCipherMatrix QXLazyNormStreamLocal1(crypto::CryptoParams *cps,
     }
     return MatMult4StreamComputeDev(cps, st.QS, 5, Xcachefile, m_ct);
 }
-inline crypto::DevCipherMatrix QXLazyNormStreamLocal2(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &outBootstrapped, const QXLazyNormState &st,
-                                                      const crypto::DevCipherVector &XMean, int numInd, const std::vector<uint64_t> &qi) {
+// The result keeps PER-CIPHERTEXT level and scale, as the reference's [][]*ckks.Ciphertext does: MaskTrunc (basics.go:110-127) returns a full-slot
+// column untouched (level l, scale S) and multiplies + rescales only the ragged last column (level l-1, scale S * Delta / q_l), matmult.go:60-70.
+inline crypto::DevCipherCells QXLazyNormStreamLocal2(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &outBootstrapped, const QXLazyNormState &st,
+                                                     const crypto::DevCipherVector &XMean, int numInd, const std::vector<uint64_t> &qi) {
     const int slots = cps->GetSlots();
-    std::vector<std::vector<crypto::DevCipherVector>> cells(outBootstrapped.rows);
-    int outLevel = -1; double outScale = 0;
+    crypto::DevCipherCells cells(outBootstrapped.rows);
     for (size_t i = 0; i < outBootstrapped.rows; i++) {
         crypto::DevCipherVector QSm = crypto::InnerProdDev(cps, st.QS.row(i), XMean, qi);                     // value in all slots
         crypto::DevCipherVector d = crypto::CAddSubDev(cps, outBootstrapped.row(i), QSm, true);              // eval.Sub(out[i][j], QSm[i], out[i][j])
@@ -763,18 +771,9 @@ inline crypto::DevCipherMatrix QXLazyNormStreamLocal2(crypto::CryptoParams *cps,
             const int Nk = j + 1 < d.n ? slots : ((numInd - 1) % slots) + 1;
             crypto::DevCipherVector one = d; one.off = d.off + j * crypto::detail::ctWords(cps, d.level); one.n = 1;
             cells[i].push_back(crypto::MaskTruncDev(cps, one, Nk, qi));
-            if (j + 1 == d.n) { outLevel = cells[i].back().level; outScale = cells[i].back().scale; }
         }
     }
-    // MaskTrunc returns full-slot ciphertexts unchanged (one level higher than the masked tail, as in the reference): gather at the
-    // common (lowest) level only when the caller asks for a flat matrix
-    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, outBootstrapped.rows, outBootstrapped.cols, outLevel, outScale);
-    for (size_t i = 0; i < out.rows; i++) for (size_t j = 0; j < out.cols; j++) {
-        crypto::DevCipherVector c = cells[i][j];
-        if (c.level != outLevel) c = crypto::DropLevelDev(c, outLevel);
-        cps->check(sfg_memcpy_d2d(cps->ctx, out.row(i).ptr(j), c.ptr(), crypto::detail::ctWords(cps, outLevel) * 8), "d2d");
-    }
-    return out;
+    return cells;
 }
 // QXtLazyNormStream (matmult.go:83-116): part 1 = the product (:91), part 2 after the bootstrap (:95-111):
 //   out[i][j] = CMult(out[i][j] - CMultScalar(XMean, InnerSumAll(Q[i]))[j], XStdInv[j])
@@ -879,14 +878,18 @@ inline RefreshShares CollectiveBootstrapGenShares(crypto::CryptoParams *cps, con
     const size_t N = (size_t)cps->N();
     sh.h0 = std::make_shared<crypto::detail::DevBuf>(cps, sh.nct * (cm.level + 1) * N * 8);
     sh.h1 = std::make_shared<crypto::detail::DevBuf>(cps, sh.nct * cps->nq * N * 8);
-    cps->check(sfg_refresh_gen_shares_dev(cps->ctx, cm.buf->u(), (int)sh.nct, cm.level, rnd.crs, rnd.mask, rnd.maskLimbs, rnd.e0, rnd.e1, sh.h0->u(), sh.h1->u()), "RefreshProtocol.GenShares");
+    // mhe.go:315: GenShares(skShard, levelStart, nParties, cm[i][j], parameters.Scale(), crp, ...) - the target scale is ALWAYS Params.Scale(), whatever
+    // scale the ciphertexts carry (products arrive at A.scale * Delta, matmult.go:44,92)
+    cps->check(sfg_refresh_gen_shares_scaled_dev(cps->ctx, cm.buf->u(), (int)sh.nct, cm.level, cm.scale, cps->scale, rnd.crs, rnd.mask, rnd.maskLimbs, rnd.e0, rnd.e1,
+                                                 sh.h0->u(), sh.h1->u()), "RefreshProtocol.GenShares");
     return sh;
 }
-// mhe.go:329-346: Decrypt, Recode, Recrypt with the aggregated shares; the result is at MaxLevel with scale unchanged (scale == target scale)
+// mhe.go:329-346: Decrypt, Recode(cm[i][j], parameters.Scale()), Recrypt with the aggregated shares; the result is at MaxLevel with scale Params.Scale()
 inline crypto::DevCipherMatrix CollectiveBootstrapFinish(crypto::CryptoParams *cps, const crypto::DevCipherMatrix &cm, const uint64_t *h0agg, const uint64_t *h1agg,
                                                          const uint64_t *crs) {
-    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, cm.rows, cm.cols, cps->nq - 1, cm.scale);
-    cps->check(sfg_refresh_finish_dev(cps->ctx, cm.buf->u(), (int)(cm.rows * cm.cols), cm.level, h0agg, h1agg, crs, out.buf->u()), "RefreshProtocol.Decrypt/Recode/Recrypt");
+    crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, cm.rows, cm.cols, cps->nq - 1, cps->scale);
+    cps->check(sfg_refresh_finish_scaled_dev(cps->ctx, cm.buf->u(), (int)(cm.rows * cm.cols), cm.level, cm.scale, cps->scale, h0agg, h1agg, crs, out.buf->u()),
+               "RefreshProtocol.Decrypt/Recode/Recrypt");
     return out;
 }
 }  // namespace mpc

@@ -20,7 +20,7 @@ static void dumpDev(crypto::CryptoParams *cps, const std::string &fn, const void
 int main(int argc, char **argv) {
     try {
         const std::string dir = argv[1];
-        std::ifstream cs(dir + "/case.txt"); int rows, level, W; cs >> rows >> level >> W;
+        std::ifstream cs(dir + "/case.txt"); int rows, level, W; double ctScale; cs >> rows >> level >> W >> ctScale;   // ctScale: the scale the matrix arrives with (a product: A.scale * Delta)
         auto mod = readU64(dir + "/moduli.bin"); int nq = (int)mod[0], np = (int)mod[1];
         std::vector<uint64_t> qi(mod.begin() + 2, mod.begin() + 2 + nq), pi(mod.begin() + 2 + nq, mod.begin() + 2 + nq + np);
         const double SC = 17179869184.0;
@@ -28,8 +28,8 @@ int main(int argc, char **argv) {
         const size_t N = (size_t)cps->N();
         cps->check(sfg_ctx_load_secret_key(cps->ctx, readU64(dir + "/sk.bin").data(), 0), "load sk");
         // cm arrives with its first ciphertext one level higher: FlattenLevels (mhe.go:313) drops it
-        auto hi = gwas::unflatten(readU64(dir + "/cm_first_hi.bin"), 1, 1, level + 1, SC, (int)N);
-        auto lo = gwas::unflatten(readU64(dir + "/cm_rest.bin"), rows - 1, 1, level, SC, (int)N);
+        auto hi = gwas::unflatten(readU64(dir + "/cm_first_hi.bin"), 1, 1, level + 1, ctScale, (int)N);
+        auto lo = gwas::unflatten(readU64(dir + "/cm_rest.bin"), rows - 1, 1, level, ctScale, (int)N);
         crypto::CipherMatrix cm; cm.push_back(hi[0]); for (auto &r : lo) cm.push_back(r);
         auto flat = crypto::FlattenLevels(cps.get(), cm);
         if (flat.second != level) throw std::runtime_error("FlattenLevels: wrong minimum level");
@@ -53,6 +53,7 @@ int main(int argc, char **argv) {
         auto h0agg = toDev(cps.get(), readU64(dir + "/h0agg.bin")); auto h1agg = toDev(cps.get(), readU64(dir + "/h1agg.bin"));
         crypto::DevCipherMatrix out = mpc::CollectiveBootstrapFinish(cps.get(), dcm, h0agg.u(), h1agg.u(), crs.u());
         if (out.level != nq - 1) throw std::runtime_error("bootstrap output is not at MaxLevel");
+        if (out.scale != SC) throw std::runtime_error("bootstrap output is not at Params.Scale()");
         dumpDev(cps.get(), dir + "/out.bin", out.buf->u(), (size_t)rows * 2 * nq * N);
         // eval.MultByConstAndAdd through the mirror: cases "<constant> <level0> <scale0> <levelOut> <scaleOut>" on 2-ciphertext vectors
         {

@@ -39,8 +39,8 @@ int main(int argc, char **argv) {
         crypto::DevCipherMatrix prod = gwas::QXLazyNormStreamLocal1(cps.get(), Q, dir + "/cache_X", m_ct, XStdInv, qi, st);
         writeU64(dir + "/qx_part1.bin", gwas::flattenCipherMatrix(crypto::ToHost(prod)));
         // BootstrapMatAll (mhe.go:351) would refresh `prod` here over the network; the test passes it through unchanged
-        crypto::DevCipherMatrix fin = gwas::QXLazyNormStreamLocal2(cps.get(), prod, st, XMean, (int)ncol, qi);
-        std::cout << "QX level " << fin.level << std::endl;
+        crypto::DevCipherCells fin = gwas::QXLazyNormStreamLocal2(cps.get(), prod, st, XMean, (int)ncol, qi);
+        std::cout << "QX level " << fin[0].back().level << std::endl;
         writeU64(dir + "/qx_final.bin", gwas::flattenCipherMatrix(crypto::ToHost(fin)));
         // ---- QXtLazyNormStream on the transposed cache: Q2 is kp x (cols of X)
         auto Q2h = gwas::unflatten(readU64(dir + "/Q2.bin"), s, m_ct, qlevel, SC, N);

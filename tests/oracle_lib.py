@@ -129,6 +129,8 @@ def lib():
         L.orc_bigint_to_rns.argtypes = [C.c_void_p, C.c_int, u64p, C.c_int, u64p]
         L.orc_refresh_gen_shares.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, u64p]
         L.orc_refresh_finish.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p, u64p]
+        L.orc_refresh_gen_shares_scaled.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, C.c_double, u64p, u64p, u64p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, u64p]
+        L.orc_refresh_finish_scaled.argtypes = [C.c_void_p, C.c_int, u64p, C.c_double, C.c_double, u64p, u64p, u64p, u64p]
         L.orc_sketch.argtypes = [C.POINTER(C.c_int8), C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.c_int,
                                  C.POINTER(C.c_double), u64p, u64p]
     return _lib
@@ -348,6 +350,22 @@ def refresh_finish(ring, level, ct, h0agg, h1agg, crs):
     out = np.zeros((2, ring.nq, ring.N), dtype=np.uint64)
     lib().orc_refresh_finish(ring.h, level, p64(np.ascontiguousarray(ct)), p64(np.ascontiguousarray(h0agg)), p64(np.ascontiguousarray(h1agg)),
                              p64(np.ascontiguousarray(crs)), p64(out))
+    return out
+
+
+def refresh_gen_shares_scaled(ring, level, ct, ct_scale, target_scale, sk, crs, mask_limbs, e0, e1):
+    h0 = np.zeros((level + 1, ring.N), dtype=np.uint64)
+    h1 = np.zeros((ring.nq, ring.N), dtype=np.uint64)
+    lib().orc_refresh_gen_shares_scaled(ring.h, level, p64(np.ascontiguousarray(ct)), float(ct_scale), float(target_scale), p64(np.ascontiguousarray(sk)),
+                                        p64(np.ascontiguousarray(crs)), p64(np.ascontiguousarray(mask_limbs)), mask_limbs.shape[1],
+                                        pi32(np.ascontiguousarray(e0)), pi32(np.ascontiguousarray(e1)), p64(h0), p64(h1))
+    return h0, h1
+
+
+def refresh_finish_scaled(ring, level, ct, ct_scale, target_scale, h0agg, h1agg, crs):
+    out = np.zeros((2, ring.nq, ring.N), dtype=np.uint64)
+    lib().orc_refresh_finish_scaled(ring.h, level, p64(np.ascontiguousarray(ct)), float(ct_scale), float(target_scale), p64(np.ascontiguousarray(h0agg)),
+                                    p64(np.ascontiguousarray(h1agg)), p64(np.ascontiguousarray(crs)), p64(out))
     return out
 
 

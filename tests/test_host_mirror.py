@@ -13,13 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "sfgwas_amd", "lib")
 
 
-def build(name):
+def build(name, with_oracle=False):
+    """with_oracle: the test program also links the CPU oracle (used as a key generator only)"""
     src = os.path.join(ROOT, "tests", "host", name + ".cpp")
     exe = os.path.join(ROOT, "tests", "host", "_build_" + name)
     hdr = os.path.join(ROOT, "sfgwas_amd", "host", "gwas.hpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        odir = os.path.join(ROOT, "oracle", "_build")
+        extra = ["-L" + odir, "-loracle", "-Wl,-rpath," + odir] if with_oracle else []
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe, src, "-L" + LIBDIR, "-lsfgwas_hip", "-Wl,-rpath," + LIBDIR,
-                               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+                               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"] + extra)
     return exe
 
 
@@ -449,7 +452,8 @@ def test_collective_bootstrap_local_halves_flatten_and_concat_match_the_oracle(t
     h0agg = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(level + 1)]) for _ in range(rows)])
     h1agg = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(ring.nq)]) for _ in range(rows)])
     h0agg.tofile(tmp_path / "h0agg.bin"); h1agg.tofile(tmp_path / "h1agg.bin")
-    (tmp_path / "case.txt").write_text(f"{rows} {level} {W}\n")
+    ct_scale = 2.0 ** 68 / ring.moduli[5] * 2.0 ** 34            # CMult(Q, XStdInv) rescaled once, then the product's Delta (matmult.go:36-44): not a power of two
+    (tmp_path / "case.txt").write_text(f"{rows} {level} {W} {ct_scale!r}\n")
     # eval.MultByConstAndAdd cases (pca.go:264: integer constant; qrfact.go:195,280: -2/N): (constant, level0, scale0, levelOut, scaleOut)
     SC = 2.0 ** 34
     mb = [(-3.0, 4, SC, 4, SC), (-2.0 / 3000.0, 4, SC * 1.0001, 4, SC), (5.0, 3, SC, 5, SC * 64.0), (-7.0, 4, SC * 1000.0, 4, SC), (0.375, 2, SC, 2, SC * 2.0 ** 40)]
@@ -477,6 +481,155 @@ def test_collective_bootstrap_local_halves_flatten_and_concat_match_the_oracle(t
     h0, h1 = ld("h0.bin", (rows, level + 1, ring.N)), ld("h1.bin", (rows, ring.nq, ring.N))
     got = ld("out.bin", (rows, 2, ring.nq, ring.N))
     for i in range(rows):
-        w0, w1 = ol.refresh_gen_shares(ring, level, cm[i], sk, crs[i], limbs[i], e0[i], e1[i])
+        w0, w1 = ol.refresh_gen_shares_scaled(ring, level, cm[i], ct_scale, 2.0 ** 34, sk, crs[i], limbs[i], e0[i], e1[i])
         assert np.array_equal(h0[i], w0) and np.array_equal(h1[i], w1), f"GenShares of ciphertext {i}"
-        assert np.array_equal(got[i], ol.refresh_finish(ring, level, cm[i], h0agg[i], h1agg[i], crs[i])), f"Decrypt/Recode/Recrypt of ciphertext {i}"
+        assert np.array_equal(got[i], ol.refresh_finish_scaled(ring, level, cm[i], ct_scale, 2.0 ** 34, h0agg[i], h1agg[i], crs[i])), f"Decrypt/Recode/Recrypt of ciphertext {i}"
+
+
+# ---------------------------------------------------------------- one power iteration's local segments, real keys, bootstraps at the target scale
+def _orc_cmult_vec(ring, level, scale_a, scale_b, A, B, rlk):
+    """crypto.CMult on vectors with length-1 broadcast: list of (ct, level, scale)"""
+    n = max(len(A), len(B))
+    return [_orc_cmult(ring, level, scale_a * scale_b, A[k % len(A)], B[k % len(B)], rlk) for k in range(n)]
+
+
+def _bootstrap1(ring, level, ct, ct_scale, sk, mask, e0, e1, crs):
+    """one party: its own shares are the aggregate (mhe.go:313-331 at the target scale Params.Scale())"""
+    h0, h1 = ol.refresh_gen_shares_scaled(ring, level, ct, ct_scale, 2.0 ** 34, sk, crs, mask, e0, e1)
+    return ol.refresh_finish_scaled(ring, level, ct, ct_scale, 2.0 ** 34, h0, h1, crs)
+
+
+@pytest.mark.gpu
+def test_power_iteration_local_segments_with_bootstraps_at_two_block_rows_and_columns(tmp_path):
+    """pca.go:339-353 local work at n_ind = 8192 + 45, m_snp = 8192 + 33 (nbr = m_ct = 2, ragged second blocks), kp = 2, REAL keys from a toy secret:
+    QXtLazyNormStream part 1 -> bootstrap (levels 4 -> 9, scale A.scale * Delta -> Delta) -> part 2 -> bootstrap -> QXLazyNormStream part 1 -> bootstrap
+    -> part 2 with MaskTrunc on the ragged column only: the result carries per-ciphertext levels and scales (matmult.go:60-70).
+    (a) every dumped word equals the oracle's replay of the same composition; (b) the final cells DECRYPT, at their own scales, to
+    (QS X^T - (QS m) 1^T) with zeros in the tail slots - the decode-level check of the scale bookkeeping."""
+    import pyref
+    from sfgwas_amd import capi
+    capi.lib()
+    ol.build_oracle()
+    exe = build("host_poweriter_test", with_oracle=True)
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    slots, d, SC, top = 8192, 91, 2.0 ** 34, 9
+    n_ind, m_snp, s, W, seed = slots + 45, slots + 33, 2, 4, 31337
+    nbr, mct = 2, 2
+    rnd = np.random.default_rng(2024)
+    geno = rnd.integers(-1, 3, (n_ind, m_snp)).astype(np.int8)
+    geno.tofile(tmp_path / "geno.bin")
+    G = np.where(geno < 0, 0, geno).astype(np.float64)
+    sec = ring.gen_secret(seed)
+    sk = ol.secret_ntt(ring, sec)
+    keys = ol.RotKeys(ring)
+    steps = sorted(set(range(1, d)) | {g * d for g in range(1, d) if g * d < slots} | {1 << k for k in range(13)})
+    for k in steps:
+        g = ring.galois(k)
+        keys.add(g, ring.gen_rotkey(sec, g, 5000 + k))
+    rlk = np.zeros(ring.key_words(), dtype=np.uint64)
+    ol.lib().orc_gen_rlk(ring.h, ol.pi8(sec), 4999, ol.p64(rlk))
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    (tmp_path / "case.txt").write_text(f"{n_ind} {m_snp} {s} {W} {seed}\n")
+    # plaintext inputs: Q kp x n_ind, SNP means / inverse standard deviations
+    Qp = rnd.normal(size=(s, n_ind)) / 64.0
+    mean = G.mean(0)
+    sinv = 1.0 / np.maximum(G.std(0), 0.25)
+
+    def enc_vec(v, n_ct, seed0):
+        pad = np.zeros(n_ct * slots); pad[:len(v)] = v
+        return np.stack([ring.encrypt(sec, top, ring.encode_coeffs(pad[k * slots:(k + 1) * slots], SC), seed0 + k) for k in range(n_ct)])
+    Q = np.stack([enc_vec(Qp[i], nbr, 100 + 10 * i) for i in range(s)])
+    XMean, XStdInv = enc_vec(mean, mct, 300), enc_vec(sinv, mct, 400)
+    Q.tofile(tmp_path / "Q.bin"); XMean.tofile(tmp_path / "XMean.bin"); XStdInv.tofile(tmp_path / "XStdInv.bin")
+
+    def randomness(tag, nct, level):
+        Ql = 1
+        for q in ring.moduli[:level + 1]:
+            Ql *= q
+        bound = Ql // 4
+        masks = np.zeros((nct, ring.N, W), dtype=np.uint64)
+        for c in range(nct):
+            vals = []
+            for _ in range(ring.N):
+                m = int.from_bytes(rnd.bytes(40), "little") % bound
+                vals.append(m - bound if m >= bound >> 1 else m)
+            masks[c] = ol.bigints_to_limbs(vals, W)
+        crs = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(ring.nq)]) for _ in range(nct)])
+        e0 = rnd.integers(-19, 20, (nct, ring.N)).astype(np.int32); e1 = rnd.integers(-19, 20, (nct, ring.N)).astype(np.int32)
+        masks.tofile(tmp_path / f"{tag}_mask.bin"); crs.tofile(tmp_path / f"{tag}_crs.bin")
+        np.concatenate([e0.reshape(-1), e1.reshape(-1)]).tofile(tmp_path / f"{tag}_e.bin")
+        return masks, crs, e0, e1
+    rA = randomness("bootA", s * mct, 4)
+    lvlA_out = 7                                     # Q1m = CMultScalar at 9 -> 8; Sub at 8; CMult with XStdInv + rescale -> 7
+    rM = randomness("bootM", s * mct, lvlA_out)
+    rB = randomness("bootB", s * nbr, 4)
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+    meta = {ln.split()[0]: ln.split()[1:] for ln in (tmp_path / "meta.txt").read_text().splitlines()}
+
+    def ld(name):
+        r, c, lvl, sc = int(meta[name][0]), int(meta[name][1]), int(meta[name][2]), float(meta[name][3])
+        return np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint64).reshape(r, c, 2, lvl + 1, ring.N), lvl, sc
+    # ---------------- oracle replay, A
+    prodA, _, _ = ol.matmult4stream(ring, keys, SC, Q, top, 5, geno, enc_prec=1)
+    got, lvl, sc = ld("a_prod")
+    assert lvl == 4 and sc == SC * SC and np.array_equal(got, prodA), "A: product"
+    bootA = np.stack([np.stack([_bootstrap1(ring, 4, prodA[i, j], SC * SC, sk, rA[0][i * mct + j], rA[2][i * mct + j], rA[3][i * mct + j], rA[1][i * mct + j])
+                                for j in range(mct)]) for i in range(s)])
+    got, lvl, sc = ld("a_boot")
+    assert lvl == top and sc == SC and np.array_equal(got, bootA), "A: bootstrap at the target scale"
+    outA, scA = [], None
+    for i in range(s):
+        row_sum = _orc_innersum(ring, keys, top, list(Q[i]))
+        q1m = _orc_cmult_vec(ring, top, SC, SC, list(XMean), [row_sum], rlk)
+        l1 = q1m[0][1]
+        dct = [_orc_sub(ring, l1, _drop(bootA[i, j], l1), q1m[j][0]) for j in range(mct)]
+        res = _orc_cmult_vec(ring, l1, SC, SC, dct, [_drop(x, l1) for x in XStdInv], rlk)
+        outA.append(np.stack([r[0] for r in res])); lA, scA = res[0][1], res[0][2]
+    outA = np.stack(outA)
+    got, lvl, sc = ld("a_out")
+    assert lvl == lA == lvlA_out and sc == scA and np.array_equal(got, outA), "A: lazy normalisation after the bootstrap"
+    Q1 = np.stack([np.stack([_bootstrap1(ring, lA, outA[i, j], scA, sk, rM[0][i * mct + j], rM[2][i * mct + j], rM[3][i * mct + j], rM[1][i * mct + j])
+                             for j in range(mct)]) for i in range(s)])
+    got, lvl, sc = ld("q1")
+    assert lvl == top and sc == SC and np.array_equal(got, Q1), "bootstrap between the two products (scale not a power of two -> Delta)"
+    # ---------------- oracle replay, B
+    QS = [_orc_cmult_vec(ring, top, SC, SC, list(Q1[i]), list(XStdInv), rlk) for i in range(s)]
+    lQS, scQS = QS[0][0][1], QS[0][0][2]
+    QSm = np.stack([np.stack([c[0] for c in QS[i]]) for i in range(s)])
+    prodB, _, _ = ol.matmult4stream(ring, keys, SC, QSm, lQS, 5, np.ascontiguousarray(geno.T), enc_prec=1)
+    got, lvl, sc = ld("b_prod")
+    assert lvl == 4 and sc == scQS * SC and np.array_equal(got, prodB), "B: product"
+    bootB = np.stack([np.stack([_bootstrap1(ring, 4, prodB[i, j], scQS * SC, sk, rB[0][i * nbr + j], rB[2][i * nbr + j], rB[3][i * nbr + j], rB[1][i * nbr + j])
+                                for j in range(nbr)]) for i in range(s)])
+    got, lvl, sc = ld("b_boot")
+    assert lvl == top and sc == SC and np.array_equal(got, bootB), "B: bootstrap"
+    mask = np.zeros(slots); mask[:((n_ind - 1) % slots) + 1] = 1.0
+    # plaintext of the whole chain
+    R1 = (Qp @ G - np.outer(Qp.sum(1), mean)) * sinv
+    QSp = R1 * sinv
+    R2 = QSp @ G.T - np.outer(QSp @ mean, np.ones(n_ind))
+    for i in range(s):
+        prods = _orc_cmult_vec(ring, lQS, scQS, SC, [c[0] for c in QS[i]], [_drop(x, lQS) for x in XMean], rlk)
+        l2, s2 = prods[0][1], prods[0][2]
+        qsm = _orc_innersum(ring, keys, l2, [p[0] for p in prods])
+        for j in range(nbr):
+            dct = _orc_sub(ring, l2, _drop(bootB[i, j], l2), qsm)
+            name = f"b_out_{i}_{j}"
+            got, lvl, sc = ld(name)
+            if j + 1 < nbr:                                      # full-slot column: MaskTrunc returns it untouched
+                want, wl, ws = dct, l2, SC
+            else:
+                mp = np.zeros_like(dct)
+                mpt = ring.encode_ntt(mask, SC, l2 + 1)
+                ol.lib().orc_mul_plain(ring.h, l2, ol.p64(dct), ol.p64(mpt), ol.p64(mp))
+                want, wl, ws = _orc_rescale_loop(ring, mp, l2, SC * SC)
+            assert lvl == wl and sc == ws, f"{name}: level / scale bookkeeping ({lvl}, {sc}) vs ({wl}, {ws})"
+            assert np.array_equal(got[0, 0], want), f"{name}: words"
+            # decode-level check at the ciphertext's OWN scale
+            res = ring.decrypt_residues(sec, lvl, got[0, 0])
+            big = pyref.crt_centered([res[m] for m in range(3)], ring.moduli[:3])
+            dec = pyref.decode(np.array([float(x) for x in big]) / sc, ring.N).real
+            ref = np.zeros(slots); seg = R2[i, j * slots:(j + 1) * slots]; ref[:len(seg)] = seg
+            assert np.max(np.abs(dec - ref)) < 2e-3 * max(1.0, np.max(np.abs(R2))), f"{name}: decrypted values off by {np.max(np.abs(dec - ref))}"
+    assert int(meta["b_out_0_0"][2]) == int(meta["b_out_0_1"][2]) + 1, "the full column must stay one level above the masked tail"
