@@ -48,6 +48,7 @@ struct CryptoParams {             // crypto.go:32-60 (the parts the hot path tou
     sfg_ctx *ctx = nullptr;
     int logN = 14, nq = 0, np = 0;
     double scale = 0;
+    std::vector<uint64_t> qi;                                        // ciphertext moduli q_0..q_{nq-1} (Params.Qi())
     std::shared_ptr<ResidentTable> resident = std::make_shared<ResidentTable>();
     int N() const { return 1 << logN; }
     int GetSlots() const { return N() / 2; }                         // crypto.go:282-284
@@ -65,7 +66,7 @@ struct CryptoParams {             // crypto.go:32-60 (the parts the hot path tou
     std::unique_ptr<CryptoParams> Fork() {
         auto c = std::make_unique<CryptoParams>();
         check(sfg_ctx_fork(ctx, &c->ctx), "sfg_ctx_fork");
-        c->logN = logN; c->nq = nq; c->np = np; c->scale = scale; c->resident = resident;
+        c->logN = logN; c->nq = nq; c->np = np; c->scale = scale; c->qi = qi; c->resident = resident;
         return c;
     }
 };
@@ -77,7 +78,7 @@ inline std::unique_ptr<CryptoParams> NewCryptoParams(int device, int logN, const
     std::vector<uint64_t> mod(qi); mod.insert(mod.end(), pi.begin(), pi.end());
     if (sfg_ctx_create(&cps->ctx, device, logN, (int)qi.size(), (int)pi.size(), mod.data(), psi, scale))
         throw std::runtime_error(std::string("sfg_ctx_create: ") + sfg_last_error(nullptr));
-    cps->logN = logN; cps->nq = (int)qi.size(); cps->np = (int)pi.size(); cps->scale = scale;
+    cps->logN = logN; cps->nq = (int)qi.size(); cps->np = (int)pi.size(); cps->scale = scale; cps->qi = qi;
     return cps;
 }
 // cryptoParams.RotKs (crypto.go:50): one switching key per Galois element, [beta][2][nq+np][N]
@@ -406,11 +407,25 @@ inline DevCipherVector CMultDev(CryptoParams *cps, DevCipherVector X, DevCipherV
     return detail::rescaleDev(o, cps->scale, qi);
 }
 inline DevCipherVector CMultScalarDev(CryptoParams *cps, const DevCipherVector &X, const DevCipherVector &ct, const std::vector<uint64_t> &qi) { return CMultDev(cps, X, ct, qi); }   // :553-566
-inline DevCipherVector CAddSubDev(CryptoParams *cps, DevCipherVector X, DevCipherVector Y, bool sub) {                               // :568-590, eval.Sub with a broadcast operand
+// eval.Add / Sub (CAdd / CSub :568-590; eval.Sub at matmult.go:56,102).  lattigo's evaluateInPlace first matches the scales: the operand with the SMALLER scale is
+// multiplied by floor(scale ratio) when that exceeds 1 (an integer MultByConst) and the result carries the larger scale - restated from lattigo v2.1/v2.2
+// ckks/evaluator.go, parity unpinned.  It matters on the reference's own path: CMult at level 9 of PN14QP438 does not rescale (q_9 > 2^35, so
+// 2^68 < Delta * q_9 / 2), and QXtLazyNormStream then subtracts a scale-2^68 ciphertext from a freshly bootstrapped scale-2^34 one.
+inline DevCipherVector CAddSubDev(CryptoParams *cps, DevCipherVector X, DevCipherVector Y, bool sub) {
     const size_t n = std::max(X.n, Y.n);
     alignLevels(X, Y);
     X = detail::broadcast(X, n); Y = detail::broadcast(Y, n);
-    DevCipherVector o = NewDevCipherVector(cps, n, X.level, X.scale);
+    auto mulByInt = [&](const DevCipherVector &v, double k, double newScale) {
+        std::vector<uint64_t> sc(v.level + 1);
+        for (int m = 0; m <= v.level; m++) sc[m] = scaleUpExact(k, 1.0, cps->qi[m]) % cps->qi[m];
+        DevCipherVector o = NewDevCipherVector(cps, v.n, v.level, newScale);
+        cps->check(sfg_ct_mul_scalar_dev(cps->ctx, v.ptr(), sc.data(), o.ptr(), (int)v.n, v.level), "MultByConst (scale matching)");
+        return o;
+    };
+    double outScale = X.scale;
+    if (X.scale > Y.scale && std::floor(X.scale / Y.scale) > 1) Y = mulByInt(Y, std::floor(X.scale / Y.scale), X.scale);
+    else if (Y.scale > X.scale && std::floor(Y.scale / X.scale) > 1) { X = mulByInt(X, std::floor(Y.scale / X.scale), Y.scale); outScale = Y.scale; }
+    DevCipherVector o = NewDevCipherVector(cps, n, X.level, outScale);
     cps->check((sub ? sfg_ct_sub_dev : sfg_ct_add_dev)(cps->ctx, X.ptr(), Y.ptr(), o.ptr(), (int)n, X.level), "CAdd/CSub");
     return o;
 }

@@ -260,7 +260,7 @@ def test_lazy_norm_and_aatb_compositions_stay_on_device_and_match_the_oracle(tmp
     for i in range(s):
         cm, l2, s2 = _orc_cmult(ring, lvl, sc * SC, QS[i][0], XMean, rlk)
         qsm = _orc_innersum(ring, keys, l2, [cm])
-        dct = _orc_sub(ring, 4, prod[i, 0], _drop(qsm, 4))
+        dct = _r_sub(ring, _Ct(prod[i, 0], 4, sc * SC), _Ct(qsm, l2, s2)).a        # eval.Sub matches the scales first (here: no bootstrap in between, ratio ~2^34)
         mp = np.zeros_like(dct)
         mpt = ring.encode_ntt(mask, SC, 5)
         ol.lib().orc_mul_plain(ring.h, 4, ol.p64(dct), ol.p64(mpt), ol.p64(mp))
@@ -274,7 +274,7 @@ def test_lazy_norm_and_aatb_compositions_stay_on_device_and_match_the_oracle(tmp
     for i in range(s):
         row_sum = _orc_innersum(ring, keys, qlevel, [Q2[i, 0]])
         q1m, l3, s3 = _orc_cmult(ring, qlevel, SC * SC, XMean2, row_sum, rlk)
-        dct = _orc_sub(ring, 4, prod2[i, 0], _drop(q1m, 4))
+        dct = _r_sub(ring, _Ct(prod2[i, 0], 4, SC * SC), _Ct(q1m, l3, s3)).a
         fin2.append(_orc_cmult(ring, 4, SC * SC * SC, dct, _drop(XStdInv2, 4), rlk)[0])
     want2 = np.stack(fin2)
     got2 = np.fromfile(tmp_path / "qxt_final.bin", dtype=np.uint64).reshape(want2.shape)
@@ -487,24 +487,72 @@ def test_collective_bootstrap_local_halves_flatten_and_concat_match_the_oracle(t
 
 
 # ---------------------------------------------------------------- one power iteration's local segments, real keys, bootstraps at the target scale
-def _orc_cmult_vec(ring, level, scale_a, scale_b, A, B, rlk):
-    """crypto.CMult on vectors with length-1 broadcast: list of (ct, level, scale)"""
-    n = max(len(A), len(B))
-    return [_orc_cmult(ring, level, scale_a * scale_b, A[k % len(A)], B[k % len(B)], rlk) for k in range(n)]
+class _Ct:
+    """oracle-side ciphertext with lattigo's bookkeeping: residues [2][level+1][N], level, scale"""
+    def __init__(self, a, level, scale):
+        self.a, self.level, self.scale = np.ascontiguousarray(a), level, scale
 
 
-def _bootstrap1(ring, level, ct, ct_scale, sk, mask, e0, e1, crs):
+def _r_drop(x, level):
+    return x if x.level == level else _Ct(_drop(x.a, level), level, x.scale)
+
+
+def _r_cmult(ring, x, y, rlk, SC):
+    """crypto.CMult: MulRelinNew at the lower level + eval.Rescale(ct, Params.Scale(), ct)"""
+    l = min(x.level, y.level)
+    ct, lvl, sc = _orc_cmult(ring, l, x.scale * y.scale, _r_drop(x, l).a, _r_drop(y, l).a, rlk, SC)
+    return _Ct(ct, lvl, sc)
+
+
+def _r_mul_int(ring, x, k, new_scale):
+    out = np.zeros_like(x.a); sm = C.c_double(0)
+    ol.lib().orc_mul_const(ring.h, x.level, ol.p64(x.a), float(k), ol.p64(out), C.byref(sm))
+    assert sm.value == 1.0                                            # an integer constant does not change the scale
+    return _Ct(out, x.level, new_scale)
+
+
+def _r_sub(ring, x, y):
+    """eval.Sub with lattigo's scale matching (the operand with the smaller scale times floor(ratio) when > 1; result at the larger scale)"""
+    l = min(x.level, y.level)
+    x, y = _r_drop(x, l), _r_drop(y, l)
+    out_scale = x.scale
+    if x.scale > y.scale and np.floor(x.scale / y.scale) > 1:
+        y = _r_mul_int(ring, y, np.floor(x.scale / y.scale), x.scale)
+    elif y.scale > x.scale and np.floor(y.scale / x.scale) > 1:
+        x = _r_mul_int(ring, x, np.floor(y.scale / x.scale), y.scale); out_scale = y.scale
+    return _Ct(_orc_sub(ring, l, x.a, y.a), l, out_scale)
+
+
+def _r_innersum(ring, keys, xs):
+    return _Ct(_orc_innersum(ring, keys, xs[0].level, [x.a for x in xs]), xs[0].level, xs[0].scale)
+
+
+def _r_masktrunc(ring, x, nkeep, SC):
+    if nkeep == ring.slots:
+        return x
+    mask = np.zeros(ring.slots); mask[:nkeep] = 1.0
+    mp = np.zeros_like(x.a)
+    mpt = ring.encode_ntt(mask, SC, x.level + 1)
+    ol.lib().orc_mul_plain(ring.h, x.level, ol.p64(x.a), ol.p64(mpt), ol.p64(mp))
+    ct, lvl, sc = _orc_rescale_loop(ring, mp, x.level, x.scale * SC, SC)
+    return _Ct(ct, lvl, sc)
+
+
+def _r_bootstrap(ring, x, sk, rnd_set, k, SC):
     """one party: its own shares are the aggregate (mhe.go:313-331 at the target scale Params.Scale())"""
-    h0, h1 = ol.refresh_gen_shares_scaled(ring, level, ct, ct_scale, 2.0 ** 34, sk, crs, mask, e0, e1)
-    return ol.refresh_finish_scaled(ring, level, ct, ct_scale, 2.0 ** 34, h0, h1, crs)
+    masks, crs, e0, e1 = rnd_set
+    h0, h1 = ol.refresh_gen_shares_scaled(ring, x.level, x.a, x.scale, SC, sk, crs[k], masks[k], e0[k], e1[k])
+    return _Ct(ol.refresh_finish_scaled(ring, x.level, x.a, x.scale, SC, h0, h1, crs[k]), ring.nq - 1, SC)
 
 
 @pytest.mark.gpu
 def test_power_iteration_local_segments_with_bootstraps_at_two_block_rows_and_columns(tmp_path):
     """pca.go:339-353 local work at n_ind = 8192 + 45, m_snp = 8192 + 33 (nbr = m_ct = 2, ragged second blocks), kp = 2, REAL keys from a toy secret:
-    QXtLazyNormStream part 1 -> bootstrap (levels 4 -> 9, scale A.scale * Delta -> Delta) -> part 2 -> bootstrap -> QXLazyNormStream part 1 -> bootstrap
+    QXtLazyNormStream part 1 -> bootstrap (level 4 -> 9, scale A.scale * Delta -> Delta) -> part 2 -> bootstrap -> QXLazyNormStream part 1 -> bootstrap
     -> part 2 with MaskTrunc on the ragged column only: the result carries per-ciphertext levels and scales (matmult.go:60-70).
-    (a) every dumped word equals the oracle's replay of the same composition; (b) the final cells DECRYPT, at their own scales, to
+    Inputs are fresh (level 9), so the reference's own corner applies: CMult at level 9 does not rescale (q_9 > 2^35) and eval.Sub has to match a
+    scale-2^68 operand with a scale-2^34 one.
+    (a) every dumped word, level and scale equals the oracle's replay of the same composition; (b) the final cells DECRYPT, at their own scales, to
     (QS X^T - (QS m) 1^T) with zeros in the tail slots - the decode-level check of the scale bookkeeping."""
     import pyref
     from sfgwas_amd import capi
@@ -530,7 +578,6 @@ def test_power_iteration_local_segments_with_bootstraps_at_two_block_rows_and_co
     ol.lib().orc_gen_rlk(ring.h, ol.pi8(sec), 4999, ol.p64(rlk))
     np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
     (tmp_path / "case.txt").write_text(f"{n_ind} {m_snp} {s} {W} {seed}\n")
-    # plaintext inputs: Q kp x n_ind, SNP means / inverse standard deviations
     Qp = rnd.normal(size=(s, n_ind)) / 64.0
     mean = G.mean(0)
     sinv = 1.0 / np.maximum(G.std(0), 0.25)
@@ -559,77 +606,63 @@ def test_power_iteration_local_segments_with_bootstraps_at_two_block_rows_and_co
         masks.tofile(tmp_path / f"{tag}_mask.bin"); crs.tofile(tmp_path / f"{tag}_crs.bin")
         np.concatenate([e0.reshape(-1), e1.reshape(-1)]).tofile(tmp_path / f"{tag}_e.bin")
         return masks, crs, e0, e1
+    # ---------------- oracle replay first (it fixes the level the second bootstrap's masks must be drawn for), A
+    cQ = [[_Ct(Q[i, b], top, SC) for b in range(nbr)] for i in range(s)]
+    cMean, cSinv = [_Ct(x, top, SC) for x in XMean], [_Ct(x, top, SC) for x in XStdInv]
+    prodA, _, _ = ol.matmult4stream(ring, keys, SC, Q, top, 5, geno, enc_prec=1)
     rA = randomness("bootA", s * mct, 4)
-    lvlA_out = 7                                     # Q1m = CMultScalar at 9 -> 8; Sub at 8; CMult with XStdInv + rescale -> 7
-    rM = randomness("bootM", s * mct, lvlA_out)
+    bootA = [[_r_bootstrap(ring, _Ct(prodA[i, j], 4, SC * SC), sk, rA, i * mct + j, SC) for j in range(mct)] for i in range(s)]
+    outA = []
+    for i in range(s):
+        row_sum = _r_innersum(ring, keys, cQ[i])
+        q1m = [_r_cmult(ring, cMean[j], row_sum, rlk, SC) for j in range(mct)]
+        outA.append([_r_cmult(ring, _r_sub(ring, bootA[i][j], q1m[j]), cSinv[j], rlk, SC) for j in range(mct)])
+    lA, scA = outA[0][0].level, outA[0][0].scale
+    assert q1m[0].level == top and q1m[0].scale == SC * SC, "the corner this test is about: CMult at level 9 must not rescale"
+    rM = randomness("bootM", s * mct, lA)
+    Q1 = [[_r_bootstrap(ring, outA[i][j], sk, rM, i * mct + j, SC) for j in range(mct)] for i in range(s)]
+    # B
+    QS = [[_r_cmult(ring, Q1[i][j], cSinv[j], rlk, SC) for j in range(mct)] for i in range(s)]
+    lQS, scQS = QS[0][0].level, QS[0][0].scale
+    prodB, _, _ = ol.matmult4stream(ring, keys, SC, np.stack([np.stack([c.a for c in QS[i]]) for i in range(s)]), lQS, 5, np.ascontiguousarray(geno.T), enc_prec=1)
     rB = randomness("bootB", s * nbr, 4)
+    bootB = [[_r_bootstrap(ring, _Ct(prodB[i, j], 4, scQS * SC), sk, rB, i * nbr + j, SC) for j in range(nbr)] for i in range(s)]
+    fin = []
+    for i in range(s):
+        qsm = _r_innersum(ring, keys, [_r_cmult(ring, QS[i][j], cMean[j], rlk, SC) for j in range(mct)])
+        fin.append([_r_masktrunc(ring, _r_sub(ring, bootB[i][j], qsm), slots if j + 1 < nbr else ((n_ind - 1) % slots) + 1, SC) for j in range(nbr)])
+    # ---------------- the device-resident chain
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
     meta = {ln.split()[0]: ln.split()[1:] for ln in (tmp_path / "meta.txt").read_text().splitlines()}
 
-    def ld(name):
+    def check(name, cells):
         r, c, lvl, sc = int(meta[name][0]), int(meta[name][1]), int(meta[name][2]), float(meta[name][3])
-        return np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint64).reshape(r, c, 2, lvl + 1, ring.N), lvl, sc
-    # ---------------- oracle replay, A
-    prodA, _, _ = ol.matmult4stream(ring, keys, SC, Q, top, 5, geno, enc_prec=1)
-    got, lvl, sc = ld("a_prod")
-    assert lvl == 4 and sc == SC * SC and np.array_equal(got, prodA), "A: product"
-    bootA = np.stack([np.stack([_bootstrap1(ring, 4, prodA[i, j], SC * SC, sk, rA[0][i * mct + j], rA[2][i * mct + j], rA[3][i * mct + j], rA[1][i * mct + j])
-                                for j in range(mct)]) for i in range(s)])
-    got, lvl, sc = ld("a_boot")
-    assert lvl == top and sc == SC and np.array_equal(got, bootA), "A: bootstrap at the target scale"
-    outA, scA = [], None
-    for i in range(s):
-        row_sum = _orc_innersum(ring, keys, top, list(Q[i]))
-        q1m = _orc_cmult_vec(ring, top, SC, SC, list(XMean), [row_sum], rlk)
-        l1 = q1m[0][1]
-        dct = [_orc_sub(ring, l1, _drop(bootA[i, j], l1), q1m[j][0]) for j in range(mct)]
-        res = _orc_cmult_vec(ring, l1, SC, SC, dct, [_drop(x, l1) for x in XStdInv], rlk)
-        outA.append(np.stack([r[0] for r in res])); lA, scA = res[0][1], res[0][2]
-    outA = np.stack(outA)
-    got, lvl, sc = ld("a_out")
-    assert lvl == lA == lvlA_out and sc == scA and np.array_equal(got, outA), "A: lazy normalisation after the bootstrap"
-    Q1 = np.stack([np.stack([_bootstrap1(ring, lA, outA[i, j], scA, sk, rM[0][i * mct + j], rM[2][i * mct + j], rM[3][i * mct + j], rM[1][i * mct + j])
-                             for j in range(mct)]) for i in range(s)])
-    got, lvl, sc = ld("q1")
-    assert lvl == top and sc == SC and np.array_equal(got, Q1), "bootstrap between the two products (scale not a power of two -> Delta)"
-    # ---------------- oracle replay, B
-    QS = [_orc_cmult_vec(ring, top, SC, SC, list(Q1[i]), list(XStdInv), rlk) for i in range(s)]
-    lQS, scQS = QS[0][0][1], QS[0][0][2]
-    QSm = np.stack([np.stack([c[0] for c in QS[i]]) for i in range(s)])
-    prodB, _, _ = ol.matmult4stream(ring, keys, SC, QSm, lQS, 5, np.ascontiguousarray(geno.T), enc_prec=1)
-    got, lvl, sc = ld("b_prod")
-    assert lvl == 4 and sc == scQS * SC and np.array_equal(got, prodB), "B: product"
-    bootB = np.stack([np.stack([_bootstrap1(ring, 4, prodB[i, j], scQS * SC, sk, rB[0][i * nbr + j], rB[2][i * nbr + j], rB[3][i * nbr + j], rB[1][i * nbr + j])
-                                for j in range(nbr)]) for i in range(s)])
-    got, lvl, sc = ld("b_boot")
-    assert lvl == top and sc == SC and np.array_equal(got, bootB), "B: bootstrap"
-    mask = np.zeros(slots); mask[:((n_ind - 1) % slots) + 1] = 1.0
+        got = np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint64).reshape(r, c, 2, lvl + 1, ring.N)
+        for i in range(r):
+            for j in range(c):
+                w = cells[i][j]
+                assert (lvl, sc) == (w.level, w.scale), f"{name}[{i}][{j}]: level / scale ({lvl}, {sc!r}) vs the replay's ({w.level}, {w.scale!r})"
+                assert np.array_equal(got[i, j], w.a), f"{name}[{i}][{j}]: words"
+        return got
+    check("a_prod", [[_Ct(prodA[i, j], 4, SC * SC) for j in range(mct)] for i in range(s)])
+    check("a_boot", bootA)
+    check("a_out", outA)
+    check("q1", Q1)
+    check("b_prod", [[_Ct(prodB[i, j], 4, scQS * SC) for j in range(nbr)] for i in range(s)])
+    check("b_boot", bootB)
     # plaintext of the whole chain
     R1 = (Qp @ G - np.outer(Qp.sum(1), mean)) * sinv
     QSp = R1 * sinv
     R2 = QSp @ G.T - np.outer(QSp @ mean, np.ones(n_ind))
     for i in range(s):
-        prods = _orc_cmult_vec(ring, lQS, scQS, SC, [c[0] for c in QS[i]], [_drop(x, lQS) for x in XMean], rlk)
-        l2, s2 = prods[0][1], prods[0][2]
-        qsm = _orc_innersum(ring, keys, l2, [p[0] for p in prods])
         for j in range(nbr):
-            dct = _orc_sub(ring, l2, _drop(bootB[i, j], l2), qsm)
             name = f"b_out_{i}_{j}"
-            got, lvl, sc = ld(name)
-            if j + 1 < nbr:                                      # full-slot column: MaskTrunc returns it untouched
-                want, wl, ws = dct, l2, SC
-            else:
-                mp = np.zeros_like(dct)
-                mpt = ring.encode_ntt(mask, SC, l2 + 1)
-                ol.lib().orc_mul_plain(ring.h, l2, ol.p64(dct), ol.p64(mpt), ol.p64(mp))
-                want, wl, ws = _orc_rescale_loop(ring, mp, l2, SC * SC)
-            assert lvl == wl and sc == ws, f"{name}: level / scale bookkeeping ({lvl}, {sc}) vs ({wl}, {ws})"
-            assert np.array_equal(got[0, 0], want), f"{name}: words"
-            # decode-level check at the ciphertext's OWN scale
-            res = ring.decrypt_residues(sec, lvl, got[0, 0])
-            big = pyref.crt_centered([res[m] for m in range(3)], ring.moduli[:3])
+            got = check(name, [[fin[i][j]]])
+            lvl, sc = fin[i][j].level, fin[i][j].scale
+            res = ring.decrypt_residues(sec, lvl, got[0, 0])                       # decode-level check at the ciphertext's OWN scale
+            big = pyref.crt_centered([res[m] for m in range(4)], ring.moduli[:4])
             dec = pyref.decode(np.array([float(x) for x in big]) / sc, ring.N).real
             ref = np.zeros(slots); seg = R2[i, j * slots:(j + 1) * slots]; ref[:len(seg)] = seg
             assert np.max(np.abs(dec - ref)) < 2e-3 * max(1.0, np.max(np.abs(R2))), f"{name}: decrypted values off by {np.max(np.abs(dec - ref))}"
-    assert int(meta["b_out_0_0"][2]) == int(meta["b_out_0_1"][2]) + 1, "the full column must stay one level above the masked tail"
+    assert fin[0][0].level == fin[0][1].level + 1 and fin[0][0].scale != fin[0][1].scale, "the full column stays one level above the masked tail, at its own scale"
