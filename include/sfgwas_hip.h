@@ -46,9 +46,14 @@ int sfg_ctx_fork(sfg_ctx *parent, sfg_ctx **out);
 void sfg_ctx_destroy(sfg_ctx *ctx);
 const char *sfg_last_error(const sfg_ctx *ctx);     /* ctx may be NULL: error of a failed sfg_ctx_create */
 int sfg_ctx_synchronize(sfg_ctx *ctx);
-/* run all subsequent work of this context on the given hipStream_t.  NULL selects the context's OWN (non-blocking) stream, not HIP's default stream:
- * a caller that orders other work (RCCL collectives, torch ops) against the library must hand over an explicit stream, or call sfg_ctx_synchronize. */
+/* sfg_ctx_synchronize waits for every queue of the context (main, own, auxiliary key-switch queue).  It - like sfg_memcpy_d2h and the host-pointer product
+ * entry points - FAILS while an encoder coefficient within 2^-50 of a rounding tie is outstanding (see sfg_ctx_encoder_near_ties): results whose
+ * bit-exactness with the reference's 256-bit encoder cannot be proven do not leave the device silently. */
+/* run all subsequent work of this context on the given hipStream_t, so that a caller can order other work (RCCL collectives, torch ops) against the
+ * library.  The handle must be an explicit stream: NULL is HIP's default stream and is refused.  sfg_ctx_use_own_stream returns to the context's own
+ * (non-blocking) queue. */
 int sfg_ctx_set_stream(sfg_ctx *ctx, void *hip_stream);
+int sfg_ctx_use_own_stream(sfg_ctx *ctx);
 
 /* rotation key of one Galois element (cryptoParams.RotKs, crypto.go:50; generated at mhe.go:73, crypto.go:232-275).
  * key_host: [beta][2][nq+np][N], beta = ceil(nq/np), NTT domain; montgomery_form != 0 if the words are in
@@ -95,8 +100,12 @@ int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, in
  * matmult.go:1019,1421); the device computes the same reals in double-double (better than 2^-58 absolute here).  The two can only round a
  * coefficient differently when its exact value lies within that distance of a tie; every coefficient within 2^-40 of a tie is counted
  * per context.  count == 0 after a call proves that call's plaintexts are the reference's, bit for bit; a non-zero count (expected
- * about once per 2 * 10^11 coefficients) names a call whose result should be re-derived with the CPU big-float encoder. */
+ * about once per 2 * 10^11 coefficients) is informational - the pipeline's own error is ~2^-59.  A coefficient within 2^-50 of a tie (about once per
+ * 10^15) is NOT tolerated: every synchronising entry point fails until the counters are reset, and the affected products must be re-derived with a
+ * big-float encoder on the host. */
 int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset);
+/* test hook for the failure path above: marks n coefficients as too close to a tie */
+int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n);
 /* crypto.EncodeFloatVector (crypto.go:398-420; behind Mask / MaskTrunc / MaskWithScaling, basics.go:110-172, and
  * CPMult operands): nvec real slot vectors [nvec][slots] (host) -> NTT-domain plaintexts pt_dev[nvec][level+1][N]
  * at the context's default scale. The reference encodes at MaxLevel; a product at a lower level reads the first rows. */

@@ -106,8 +106,7 @@ struct sfg_ctx {
     std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
     std::string err;
     std::map<std::string, PhaseStat> phases;
-    unsigned long long enc_near_ties = 0;   // encoder coefficients within 2^-40 of a rounding tie, recomputed in triple-double (encode.hip)
-    void *tie_count_dev = nullptr;
+    void *tie_count_dev = nullptr;          // two counters: encoder coefficients within 2^-40 of a rounding tie (audit) and within 2^-50 (sticky failure, sfg_encoder_check)
     hipStream_t main_stream() const { return user_stream ? user_stream : own_stream; }
     std::map<u64, RotKey> &rotkeys() { return sh->rotkeys; }
     const std::map<u64, RotKey> &rotkeys() const { return sh->rotkeys; }
@@ -117,6 +116,8 @@ struct sfg_ctx {
 
 // synchronise every queue of the context (before freeing / reusing memory either queue may still read)
 int sfg_sync_all(sfg_ctx *ctx);
+// after a sync: non-zero while an encoder coefficient too close to a rounding tie is outstanding (encode.hip)
+int sfg_encoder_check(sfg_ctx *ctx);
 
 extern thread_local std::string g_create_error;
 

@@ -58,7 +58,7 @@ static const char *ctx_exec_init(sfg_ctx *ctx) {
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     ctx->pin_bytes = 64u << 20;
     if (hipHostMalloc((void **)&ctx->pin, ctx->pin_bytes, hipHostMallocDefault) != hipSuccess) return "hipHostMalloc failed";
-    if (hipMalloc(&ctx->tie_count_dev, 8) != hipSuccess || hipMemset(ctx->tie_count_dev, 0, 8) != hipSuccess) return "hipMalloc failed";
+    if (hipMalloc(&ctx->tie_count_dev, 16) != hipSuccess || hipMemset(ctx->tie_count_dev, 0, 16) != hipSuccess) return "hipMalloc failed";
     return nullptr;
 }
 
@@ -180,10 +180,16 @@ extern "C" const char *sfg_last_error(const sfg_ctx *ctx) { return ctx ? ctx->er
 
 extern "C" int sfg_ctx_synchronize(sfg_ctx *ctx) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    SFG_TRY(sfg_sync_all(ctx));                        // the main queue, the context's own queue and the auxiliary (key-switch) queue
+    return sfg_encoder_check(ctx);
 }
-extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) { ctx->user_stream = (hipStream_t)s; ctx->stream = ctx->main_stream(); return 0; }
+// An explicit stream only: the handle 0 is HIP's (and torch's) DEFAULT stream, which the library cannot be ordered against by accident - it used to
+// mean "the context's own stream" and silently left collectives / torch ops unordered.  sfg_ctx_use_own_stream goes back to the private queue.
+extern "C" int sfg_ctx_set_stream(sfg_ctx *ctx, void *s) {
+    if (!s) SFG_FAIL(ctx, "sfg_ctx_set_stream: a NULL handle is HIP's default stream - create an explicit (non-default) stream, or call sfg_ctx_use_own_stream");
+    ctx->user_stream = (hipStream_t)s; ctx->stream = ctx->main_stream(); return 0;
+}
+extern "C" int sfg_ctx_use_own_stream(sfg_ctx *ctx) { ctx->user_stream = nullptr; ctx->stream = ctx->main_stream(); return 0; }
 int sfg_sync_all(sfg_ctx *ctx) {
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->user_stream && ctx->user_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->user_stream));
@@ -234,7 +240,8 @@ extern "C" int sfg_memcpy_h2d(sfg_ctx *ctx, void *d, const void *s, size_t n) {
     SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
 }
 extern "C" int sfg_memcpy_d2h(sfg_ctx *ctx, void *d, const void *s, size_t n) {
-    SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+    SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return sfg_encoder_check(ctx);                     // results leave the device here: refuse while an unprovable encoder rounding is outstanding
 }
 
 void sfg_phases_resolve(sfg_ctx *ctx) {

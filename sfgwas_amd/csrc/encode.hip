@@ -358,11 +358,15 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
 // The double-double pipeline carries ~2^-100 relative error (absolute ~2^-65 on these magnitudes; ~2^-59 on the fixed grid), the reference's EncoderBig 256
 // bits.  A coefficient whose exact value lies within 2^-40 of a rounding tie is counted (sfg_ctx_encoder_near_ties): the two
 // encoders can only disagree on such a coefficient, so a zero count PROVES the block was rounded as the reference rounds it.
+// A second, sticky counter takes the coefficients within 2^-50 of a tie (2^8 times the pipeline's error estimate, about once per 10^15
+// coefficients): while it is non-zero every synchronising entry point FAILS (sfg_encoder_check) - the contract is bit-exactness, and such a
+// coefficient has to be re-derived by a big-float encoder on the host before the product may be used.
 template <bool EXACT_TIES>
 __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {                // integer-valued double
     double nn = __builtin_rint(x.hi);
     double diff = (x.hi - nn) + x.lo;                                                         // |diff| <= 1/2 + |x.lo|
-    near_tie += __builtin_fabs(__builtin_fabs(diff) - 0.5) < 0x1p-40 ? 1u : 0u;
+    const double tie_dist = __builtin_fabs(__builtin_fabs(diff) - 0.5);
+    near_tie += (tie_dist < 0x1p-40 ? 1u : 0u) + (tie_dist < 0x1p-50 ? 0x10000u : 0u);      // low half: audit band; high half: band inside which the call FAILS
     if (!EXACT_TIES) return nn + __builtin_rint(diff);      // = the rule below whenever |diff| != 1/2; an exact tie (impossible for integer slot values at Delta/n = 2^k) is counted above
     const bool up = (diff > 0.5) | ((diff == 0.5) & (nn >= 0)), dn = (diff < -0.5) | ((diff == -0.5) & (nn <= 0));      // (no short-circuit: selects, not branches)
     return nn + (up ? 1.0 : 0.0) - (dn ? 1.0 : 0.0);
@@ -497,7 +501,7 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
     for (int i = 0; i < 4; i++) recomb(tid + 512 * i, Ar[i], Ai[i], Br[i], Bi[i]);
     if (tid == 0) recomb(h / 2, Ar[4], Ai[4], Br[4], Bi[4]);
-    if (near_tie) atomicAdd(tie_count, (unsigned long long)near_tie);
+    if (near_tie) { atomicAdd(tie_count, (unsigned long long)(near_tie & 0xFFFFu)); if (near_tie >> 16) atomicAdd(tie_count + 1, (unsigned long long)(near_tie >> 16)); }
 }
 
 static int enc_pc_scratch(sfg_ctx *ctx, size_t nplain, double **pc) {
@@ -606,6 +610,22 @@ extern "C" int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     SFG_TRY(sfg_sync_all(ctx));
     SFG_HIP(ctx, hipMemcpy(count, ctx->tie_count_dev, 8, hipMemcpyDeviceToHost));
-    if (reset) SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 8));
+    if (reset) SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 16));
+    return 0;
+}
+
+// after a synchronisation of the context's queue: fail while a coefficient too close to a rounding tie to be proven equal to the reference's
+// EncoderBig rounding is outstanding (reset with sfg_ctx_encoder_near_ties(ctx, &n, 1) once the affected product has been re-derived)
+int sfg_encoder_check(sfg_ctx *ctx) {
+    unsigned long long c[2] = {0, 0};
+    SFG_HIP(ctx, hipMemcpy(c, ctx->tie_count_dev, 16, hipMemcpyDeviceToHost));
+    if (c[1]) SFG_FAIL(ctx, "encoder: %llu coefficient(s) within 2^-50 of a rounding tie - the double-double encoder cannot prove them rounded as the reference's 256-bit "
+                            "EncoderBig rounds; re-derive the products of this context since the last reset with a big-float encoder (sfg_ctx_encoder_near_ties resets)", c[1]);
+    return 0;
+}
+extern "C" int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n) {      // test hook: pretend n such coefficients were seen
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long c[2] = {0, n};
+    SFG_HIP(ctx, hipMemcpy((unsigned long long *)ctx->tie_count_dev + 1, c + 1, 8, hipMemcpyHostToDevice));
     return 0;
 }

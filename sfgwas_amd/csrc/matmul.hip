@@ -637,6 +637,7 @@ extern "C" int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, in
                 hipStreamSynchronize(ctx->stream) != hipSuccess)) { rc = 1; ctx->err = "matmul_stream: download failed"; }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dA); (void)hipFree(dO); sfg_geno_free(ctx, g);
+    if (!rc) rc = sfg_encoder_check(ctx);
     return rc;
 }
 

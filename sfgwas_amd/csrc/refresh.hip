@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_recrypt(u64 *out, const u64 *h1, const 
 }
 
 // ---- target-scale form (what the reference calls: mhe.go:251,256-258,315,329-331 pass parameters.Scale() while the products they refresh carry
-// A.scale * Delta, matmult.go:1045).  lattigo v2.2.0 dckks/refresh.go restated (PARITY UNPINNED, see oracle/sfgwas_oracle.c):
+// A.scale * Delta, matmult.go:1045).  lattigo v2.2.0 dckks/refresh.go restated (PARITY UNPINNED; the CPU checker under oracle/ states it function by function):
 //   GenShares: the recrypt share is built from Quo(mask * Int(target), Int(ct scale));  Recode: x <- Quo(x * Int(target), Int(ct scale)) before the
 //   re-reduction into all nq moduli.  Quo truncates towards zero: floor on the magnitude, sign kept.  Int(float64) = m * 2^e exactly (m < 2^53), so the
 //   ratio is one multiplication by m_out, one shift by e_out - e_in and one short division by m_in on a 512-bit magnitude, one coefficient per lane.

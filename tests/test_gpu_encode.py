@@ -74,8 +74,33 @@ def test_encoder_near_tie_audit(env):
     out1 = np.zeros((1, ctx.N), dtype=np.int64)
     ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, tie.ctypes.data_as(C.POINTER(C.c_double)), 1, out1.ctypes.data_as(C.POINTER(C.c_int64))), "encode")
     assert out1[0, 0] == 12346 and not out1[0, 1:].any()
+    # an exact tie is also inside the 2^-50 band: until the counters are reset, every synchronising entry point refuses (bit-exactness cannot be proven)
+    with pytest.raises(capi.SfgError, match="rounding tie"):
+        ctx.sync()
     assert ctx.encoder_near_ties(reset=True) >= 1
+    ctx.sync()
     ctx.check(capi.lib().sfg_encode_coeffs_host(ctx.h, (-tie).ctypes.data_as(C.POINTER(C.c_double)), 1, out1.ctypes.data_as(C.POINTER(C.c_int64))), "encode")
     assert out1[0, 0] == -12346 and not out1[0, 1:].any()                  # half away from zero on the negative side as well
     assert ctx.encoder_near_ties(reset=True) >= 1
     assert ctx.encoder_near_ties() == 0
+
+
+def test_unprovable_encoder_rounding_fails_synchronising_calls_until_reset(env):
+    """the failure path of the near-tie policy: sfg_ctx_synchronize and downloads fail while the 2^-50 counter is non-zero"""
+    from sfgwas_amd import capi
+    ctx = env[0] if isinstance(env, tuple) else env
+    ctx.encoder_near_ties(reset=True)
+    p = ctx.malloc(64)
+    ctx.check(capi.lib().sfg_ctx_encoder_inject_unsafe_for_test(ctx.h, 3), "inject")
+    with pytest.raises(capi.SfgError, match="3 coefficient"):
+        ctx.sync()
+    with pytest.raises(capi.SfgError, match="rounding tie"):
+        ctx.to_host(p, (8,), np.uint64)
+    ctx.encoder_near_ties(reset=True)
+    ctx.sync()
+    ctx.to_host(p, (8,), np.uint64)
+    ctx.free(p)
+    # stream rules: the default stream (NULL) is refused, the own queue is one call away
+    assert capi.lib().sfg_ctx_set_stream(ctx.h, None) != 0
+    assert b"default stream" in capi.lib().sfg_last_error(ctx.h)
+    assert capi.lib().sfg_ctx_use_own_stream(ctx.h) == 0
