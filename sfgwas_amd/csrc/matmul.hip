@@ -704,7 +704,11 @@ extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int
     for (int bi = 0; bi < nbr; bi++) {
         if (dc_open(ctx, std::string(prefix) + "_" + std::to_string(bi) + ".bin", &files[bi], hdrs[bi])) { close_all(); return 1; }
         const DiagCacheHdr &h = hdrs[bi];
-        if (h.n != (uint64_t)N || h.numModuli < (uint64_t)L || h.vectorLen != hdrs[0].vectorLen || h.vectorLen < 1 || h.rowSize != 4 + (1 + h.n * h.numModuli * 8) * h.vectorLen) {
+        // a corrupt or hostile header must not size an allocation: moduli bounded by the ring, block columns by the largest matrix the slots can index,
+        // the record size by the formula AND by the file itself
+        long fsize = -1; { const long here = ftell(files[bi]); if (!fseek(files[bi], 0, SEEK_END)) fsize = ftell(files[bi]); fseek(files[bi], here, SEEK_SET); }
+        if (h.n != (uint64_t)N || h.numModuli < (uint64_t)L || h.numModuli > (uint64_t)ctx->nmod || h.vectorLen != hdrs[0].vectorLen || h.vectorLen < 1 ||
+            h.vectorLen > (1u << 20) || h.rowSize != 4 + (1 + h.n * h.numModuli * 8) * h.vectorLen || fsize < 0 || h.rowSize > (uint64_t)fsize) {
             close_all(); SFG_FAIL(ctx, "matmul_from_cache: %s_%d.bin does not match this ring (n = %llu, numModuli = %llu, vectorLen = %llu)", prefix, bi,
                                   (unsigned long long)h.n, (unsigned long long)h.numModuli, (unsigned long long)h.vectorLen);
         }
@@ -743,7 +747,7 @@ extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int
         for (int bi = 0; bi < nbr && !rc; bi++) {
             const DiagCacheHdr &h = hdrs[bi]; FILE *f = files[bi];
             fseek(f, h.data_pos, SEEK_SET);
-            rec.resize(h.rowSize);
+            try { rec.resize(h.rowSize); } catch (const std::exception &) { ctx->err = "matmul_from_cache: out of host memory for a record"; rc = 1; break; }
             rc = build_rot_row_tab(ctx, (const u64 *)A, s, nl_in, nl, lev, L, nbr, bi, h.baby, a_row, rotc, true, rotf);       // matmult.go:1083-1119
             if (!rc && hipMemsetAsync(rotf + (size_t)d * s * 2 * rowf, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream) != hipSuccess) rc = 1;
             if (!rc && packed_mask) rc = launch_rot_sum(ctx, rotf, (size_t)s * 2, d, L, rotsum);
