@@ -205,6 +205,7 @@ int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *
  * flags: SFG_SQUARE squares genotypes after missing->0 (matmult.go:1301-1303); SFG_TRANSPOSE multiplies by X^T. */
 #define SFG_SQUARE 1u
 #define SFG_TRANSPOSE 2u
+#define SFG_STREAM_DIRECT 4u      /* sfg_assoc_stream_bed only: read the file with O_DIRECT (4096-byte aligned ranges, no page cache) */
 int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,
                             const sfg_geno *g, unsigned flags, uint64_t *out_dev);
 /* MatMult4StreamCompute on the reference's OWN on-disk cache (matmult.go:1043-1236 reading the DiagCache files that
@@ -225,7 +226,10 @@ int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level,
  * all.  A batch is one contiguous byte range of the file: read by a reader thread into pinned memory while the GPU multiplies the previous batch,
  * moved to HBM as packed 2-bit codes, decoded / filtered / transposed on the device.  A_dev: [s][ceil(kept_samples / slots)] ciphertexts;
  * out_dev: [s][out_ct_capacity][2][max_level][N]; *out_ct = sum over batches of ceil(kept / slots).  sum_host / sqsum_host (optional):
- * [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).  flags: SFG_SQUARE. */
+ * [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).  flags: SFG_SQUARE, SFG_STREAM_DIRECT.
+ * The baby-step rotation cache of `A` (rotCache[i][baby], matmult.go:1373-1377 - a function of A alone, rebuilt by the reference in every MatMult4Stream
+ * call) is built ONCE per call and shared by all batches when it fits (1.86 GB per block row at s = 13; SFG_ASSOC_ROTCACHE_MB, 0 = per batch).
+ * A Go shim that keeps calling per batch gets the same saving from sfg_rotcache_build_rows_dev + sfg_matmul_resident_range_rc_dev. */
 int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
                          size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                          uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);

@@ -15,6 +15,7 @@ _lib = None
 
 SFG_SQUARE = 1
 SFG_TRANSPOSE = 2
+SFG_STREAM_DIRECT = 4
 
 
 class SfgError(RuntimeError):

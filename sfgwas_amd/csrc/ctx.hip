@@ -35,6 +35,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
     c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
     if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
+    if (const char *e = env("SFG_ASSOC_ROTCACHE_MB")) c.assoc_cache_budget = (size_t)atoll(e) << 20;
     if (const char *e = env("SFG_KSW_BUDGET_MB")) { c.ksw_budget = (size_t)atoll(e) << 20; if (c.ksw_budget < (16ULL << 20)) c.ksw_budget = 16ULL << 20; }
     if (const char *e = env("SFG_ENC_BATCH")) { c.enc_batch = atoi(e); if (c.enc_batch < 64) c.enc_batch = 64; if (c.enc_batch > 8192) c.enc_batch = 8192; }
 }

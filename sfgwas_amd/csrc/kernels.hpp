@@ -50,3 +50,6 @@ bool mac_use_dma(const sfg_ctx *ctx);
 // mac_bc.hip (same contract as launch_mac_dma; small-modulus plaintext rows packed)
 int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st,
                   const double *rotsum);
+// matmul.hip: the baby-step rotation cache of block rows [b0, b1) in the MAC layout; tabs = per-row active-baby flags (null: all 91)
+int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, int nbr, int b0, int b1, const std::vector<std::vector<uint8_t>> *tabs, double *cache);
+int sfg_diag_bool(int r, int c, int dim, int index);

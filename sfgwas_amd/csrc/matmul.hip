@@ -583,7 +583,8 @@ extern "C" int sfg_rotcache_scatter_dev(sfg_ctx *ctx, const double *staged, int 
     SFG_HIP(ctx, hipMemsetAsync(cache + (size_t)nrows * d * s * jw, 0, (size_t)3 * s * jw * 8, ctx->stream));   // k-slices a ragged last MAC chunk reads
     return 0;
 }
-extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int b0, int b1, double *cache) {
+// tabs (nullable): per block row of [b0, b1) the 91 active-baby flags (matmult.go:1326-1336; a superset is always right); null = all 91
+int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, int nbr, int b0, int b1, const std::vector<std::vector<uint8_t>> *tabs, double *cache) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     const int N = SFG_N, d = SFG_D, L = max_level;
     size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, L, rowf));
@@ -595,10 +596,16 @@ extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int 
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", 8, (void **)&rotc));
     const std::vector<uint8_t> all(d, 1);
-    for (int bi = b0; bi < b1; bi++) SFG_TRY(build_rot_row_tab(ctx, (const u64 *)A, s, in_level + 1, nl, lev, L, nbr, bi, all, a_row, rotc, true, cache + (size_t)(bi - b0) * per_row));
+    for (int bi = b0; bi < b1; bi++)
+        SFG_TRY(build_rot_row_tab(ctx, A, s, in_level + 1, nl, lev, L, nbr, bi, tabs ? (*tabs)[bi - b0] : all, a_row, rotc, true, cache + (size_t)(bi - b0) * per_row));
     SFG_HIP(ctx, hipMemsetAsync(cache + (size_t)(b1 - b0) * per_row, 0, (size_t)3 * s * 2 * rowf * 8, ctx->stream));
     return 0;
 }
+extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int b0, int b1, double *cache) {
+    return rotcache_build_rows_tab(ctx, (const u64 *)A, s, in_level, max_level, nbr, b0, b1, nullptr, cache);
+}
+// GetDiagBool (matmult.go:627-631) for other translation units
+int sfg_diag_bool(int r, int c, int dim, int index) { return diag_bool(r, c, dim, index); }
 // the products on a prebuilt cache that covers exactly the operand block rows the call contracts over ([0, nbr) for X, [blk0, blk1) / [b0, b1) for X^T)
 extern "C" int sfg_matmul_resident_range_rc_dev(sfg_ctx *ctx, const double *cache, int s, int max_level, const sfg_geno *g, unsigned flags,
                                                 int blk0, int blk1, uint64_t *out) {

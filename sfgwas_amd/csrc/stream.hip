@@ -7,10 +7,19 @@
 // (bps = ceil(num_sample / 4) bytes per SNP), read with pread() into pinned memory by a reader thread while the GPU works on the previous
 // batch, copied to HBM as packed 2-bit codes (4x less than int8 over PCIe), decoded / filtered / transposed on the device
 // (k_bed_decode, pinned by the reference scripts' outputs in tests/test_input_formats.py), multiplied, concatenated.  A .pgen file is
-// converted once with `plink2 --make-bed` (the reference already depends on plink2 for this path).
+// converted once with `plink2 --make-bed` (the reference already depends on plink2 for this path), or decoded natively (pgen.hip).
+//
+// Every batch multiplies the SAME ciphertext matrix `mat` (GenoBlockMult(b, concat, ...) walks all chromosome batches with one concat, assoc.go:714-718;
+// gWY's four calls per block likewise), and the reference recomputes rotCache[i][baby] = RotateRight(mat[i][bi], -baby) inside every MatMult4Stream call
+// (matmult.go:1373-1377) - 90 key switches per input ciphertext, which at one block column per batch are the LARGEST item of a batch (47 % of the kernel
+// time at 500 000 x 8192, s = 13).  The rotations depend on `mat` only, so one call builds the baby-step rotation cache once (the same key switches, the
+// same bits; 1.86 GB per block row at s = 13: 115 GB for 500 000 samples) and every batch multiplies against it (SFG_ASSOC_ROTCACHE_MB=0 restores the
+// per-batch rebuild; a cache that exceeds the budget falls back to it).
 #include "common.hpp"
 #include "kernels.hpp"
+#include <algorithm>
 #include <condition_variable>
+#include <cerrno>
 #include <fcntl.h>
 #include <mutex>
 #include <sys/stat.h>
@@ -34,16 +43,19 @@ std::vector<Batch> make_batches(const uint8_t *col_filter, size_t num_snp, size_
 }
 struct Reader {                                        // fills pinned slot k & 1 with the bytes of batch k, one batch ahead of the consumer
     int fd; size_t bps; const std::vector<Batch> *bt; uint8_t *slot[2];
+    bool direct = false; size_t lead[2] = {0, 0};       // O_DIRECT: 4096-byte aligned file ranges; the batch starts `lead` bytes into its slot
     std::mutex mu; std::condition_variable cv; long filled = -1, released = -1; bool failed = false; std::string err;
     void run() {
         for (size_t k = 0; k < bt->size(); k++) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return (long)k - 2 <= released; }); }      // slot k & 1 was last used by batch k - 2
-            const Batch &b = (*bt)[k]; size_t want = b.nsnp * bps, got = 0; const off_t off = 3 + (off_t)(b.snp0 * bps);
+            const Batch &b = (*bt)[k]; const off_t off = 3 + (off_t)(b.snp0 * bps), a0 = direct ? off & ~(off_t)4095 : off;
+            const size_t ld = (size_t)(off - a0), want = ld + b.nsnp * bps, want_al = direct ? (want + 4095) & ~(size_t)4095 : want; size_t got = 0;
             while (got < want) {
-                ssize_t r = pread(fd, slot[k & 1] + got, want - got, off + (off_t)got);
+                ssize_t r = pread(fd, slot[k & 1] + got, want_al - got, a0 + (off_t)got);
                 if (r <= 0) { std::lock_guard<std::mutex> lk(mu); failed = true; err = "short read from the .bed file"; cv.notify_all(); return; }
                 got += (size_t)r;
             }
+            lead[k & 1] = ld;
             { std::lock_guard<std::mutex> lk(mu); filled = (long)k; }
             cv.notify_all();
         }
@@ -62,8 +74,13 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
     if (!num_sample || !num_snp || !batch_snps) SFG_FAIL(ctx, "assoc_stream_bed: bad dimensions");
     if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_stream_bed: batches are multiplied as X (samples x SNPs)");
     const size_t bps = (num_sample + 3) / 4, N = SFG_N, slots = SFG_SLOTS, L = (size_t)max_level;
-    const int fd = open(bed_path, O_RDONLY);
-    if (fd < 0) SFG_FAIL(ctx, "assoc_stream_bed: cannot open %s", bed_path);                     // os.Open panics in the reference (filestream.go:59-61)
+    const bool direct = (flags & SFG_STREAM_DIRECT) != 0;                                        // bypass the page cache: what a 5 TB scan from NVMe sees
+    const int fd = open(bed_path, direct ? O_RDONLY | O_DIRECT : O_RDONLY);
+    if (fd < 0) {
+        if (direct && errno == EINVAL) SFG_FAIL(ctx, "assoc_stream_bed: the file system of %s does not support O_DIRECT", bed_path);
+        SFG_FAIL(ctx, "assoc_stream_bed: cannot open %s", bed_path);                            // os.Open panics in the reference (filestream.go:59-61)
+    }
+    flags &= ~SFG_STREAM_DIRECT;
     struct stat stt; uint8_t magic[3] = {0, 0, 0};
     if (fstat(fd, &stt) || pread(fd, magic, 3, 0) != 3) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: cannot read %s", bed_path); }
     if ((size_t)stt.st_size != 3 + num_snp * bps) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: file holds %zu bytes, expected 3 + %zu x %zu", (size_t)stt.st_size, num_snp, bps); }
@@ -80,13 +97,14 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
     if (!nr) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: the row filter keeps nothing"); }
     int rc = 0;
     int32_t *rmap = nullptr, *cmap[2] = {nullptr, nullptr}; uint8_t *hb[2] = {nullptr, nullptr}, *db[2] = {nullptr, nullptr}; int8_t *gb[2] = {nullptr, nullptr};
+    double *rotbuf = nullptr;
     u64 *tmp = nullptr; hipStream_t copy = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     const size_t ctw = 2 * L * N, max_ct = (max_kept + slots - 1) / slots;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(ctx->stream); if (copy) (void)hipStreamSynchronize(copy);
         for (int i = 0; i < 2; i++) { (void)hipHostFree(hb[i]); (void)hipFree(db[i]); (void)hipFree(gb[i]); (void)hipFree(cmap[i]);
             if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_free[i]) (void)hipEventDestroy(ev_free[i]); }
-        (void)hipFree(rmap); (void)hipFree(tmp); if (copy) (void)hipStreamDestroy(copy); close(fd);
+        (void)hipFree(rmap); (void)hipFree(tmp); (void)hipFree(rotbuf); if (copy) (void)hipStreamDestroy(copy); close(fd);
     };
 #define ST_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; snprintf(_b, sizeof _b, "assoc_stream_bed: %s failed: %s", #call, hipGetErrorString(_e)); ctx->err = _b; rc = 1; } } while (0)
     ST_HIP(hipMalloc(&rmap, num_sample * sizeof(int32_t)));
@@ -94,7 +112,7 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
     if (!rc) ST_HIP(hipMalloc(&tmp, (size_t)s * max_ct * ctw * 8));
     if (!rc) ST_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
     for (int i = 0; i < 2 && !rc; i++) {
-        ST_HIP(hipHostMalloc((void **)&hb[i], max_nsnp * bps, hipHostMallocDefault));
+        ST_HIP(hipHostMalloc((void **)&hb[i], max_nsnp * bps + 8192, hipHostMallocDefault));       // + the alignment slack of O_DIRECT ranges
         if (!rc) ST_HIP(hipMalloc(&db[i], max_nsnp * bps));
         if (!rc) ST_HIP(hipMalloc(&gb[i], nr * max_kept));
         if (!rc) ST_HIP(hipMalloc(&cmap[i], max_nsnp * sizeof(int32_t)));
@@ -103,7 +121,34 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
     }
     if (rc) { cleanup(); return rc; }
-    Reader rd; rd.fd = fd; rd.bps = bps; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1];
+    // ---- the baby-step rotation cache of `mat`, once for all batches of the call
+    const double *rotcache = nullptr;
+    {
+        size_t jobw = 0, tailw = 0;
+        const int nbr = (int)((nr + slots - 1) / slots);
+        if (ctx->cfg.assoc_cache_budget && mac_use_dma(ctx) && !sfg_rotcache_layout(ctx, s, max_level, &jobw, &tailw)) {
+            const size_t words = (size_t)nbr * s * jobw + tailw;
+            if (words * 8 <= ctx->cfg.assoc_cache_budget) {
+                if (hipMalloc(&rotbuf, words * 8) == hipSuccess) {       // freed when the call returns (a context-pool buffer of this size would starve the next product)
+                    // active baby steps (matmult.go:1326-1336) of every block row, united over the block-column widths the batches have
+                    std::vector<size_t> widths;
+                    for (const Batch &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
+                    std::vector<std::vector<uint8_t>> tabs(nbr, std::vector<uint8_t>(SFG_D, 0));
+                    for (int bi = 0; bi < nbr; bi++) {
+                        const int rows = (int)(std::min((size_t)(bi + 1) * slots, nr) - (size_t)bi * slots);
+                        for (int shift = 0; shift < SFG_SLOTS; shift++) {
+                            if (tabs[bi][shift % SFG_D]) continue;
+                            for (size_t w : widths) if (sfg_diag_bool(rows, (int)w, SFG_SLOTS, -shift)) { tabs[bi][shift % SFG_D] = 1; break; }
+                        }
+                    }
+                    rc = rotcache_build_rows_tab(ctx, (const u64 *)A_dev, s, in_level, max_level, nbr, 0, nbr, &tabs, rotbuf);
+                    if (!rc) rotcache = rotbuf;
+                } else { rotbuf = nullptr; (void)hipGetLastError(); }      // no room: per-batch rotations
+            }
+        }
+        if (rc) { cleanup(); return rc; }
+    }
+    Reader rd; rd.fd = fd; rd.bps = bps; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
     std::thread reader([&rd] { rd.run(); });
     std::vector<int32_t> cmap_h(max_nsnp);
     size_t out_shift = 0;
@@ -114,7 +159,7 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
         for (size_t j = 0; j < b.nsnp; j++) cmap_h[j] = (!col_filter || col_filter[b.snp0 + j]) ? (int32_t)kc++ : -1;
         // copy queue: packed bytes and column map of batch k into slot sl (free once the product of batch k - 2 has run), decode into gb[sl]
         if (k >= 2) ST_HIP(hipStreamWaitEvent(copy, ev_free[sl], 0));
-        if (!rc) ST_HIP(hipMemcpyAsync(db[sl], hb[sl], b.nsnp * bps, hipMemcpyHostToDevice, copy));
+        if (!rc) ST_HIP(hipMemcpyAsync(db[sl], hb[sl] + rd.lead[sl], b.nsnp * bps, hipMemcpyHostToDevice, copy));
         if (!rc) ST_HIP(hipMemcpyAsync(cmap[sl], cmap_h.data(), b.nsnp * sizeof(int32_t), hipMemcpyHostToDevice, copy));
         if (!rc) ST_HIP(hipEventRecord(ev_h2d[sl], copy));
         if (!rc) rc = launch_bed_decode(ctx, copy, db[sl], bps, num_sample, b.nsnp, rmap, cmap[sl], gb[sl], b.kept);
@@ -126,7 +171,8 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
         ST_HIP(hipStreamWaitEvent(ctx->stream, ev_ready[sl], 0));
         sfg_geno g; g.dev = gb[sl]; g.nrow = nr; g.ncol = b.kept; g.ld = b.kept; g.owned = false;
         const size_t nct = (b.kept + slots - 1) / slots;
-        if (!rc) rc = sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, &g, flags, (uint64_t *)tmp);
+        if (!rc) rc = rotcache ? sfg_matmul_resident_range_rc_dev(ctx, rotcache, s, max_level, &g, flags, 0, (int)nct, (uint64_t *)tmp)
+                               : sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, &g, flags, (uint64_t *)tmp);
         for (int i = 0; i < s && !rc; i++)
             ST_HIP(hipMemcpyAsync(out_dev + ((size_t)i * out_ct_capacity + out_shift) * ctw, tmp + (size_t)i * nct * ctw, nct * ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (!rc && (sum_host || sqsum_host)) {

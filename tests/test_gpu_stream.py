@@ -84,3 +84,75 @@ def test_stream_bed_batches_match_oracle(tmp_path, square):
     with pytest.raises(capi.SfgError, match="expected 3 \\+"):
         ctx.check(capi.lib().sfg_assoc_stream_bed(ctx.h, path.encode(), ns + 4, nv, None, None, batch, dA.p, s, level, maxl, 0, dout.p, cap, C.byref(got_ct), None, None), "x")
     dA.free(); dout.free(); ctx.close()
+
+
+def _ctx_with_env(capi, **env):
+    """the library reads its switches once, in sfg_ctx_create"""
+    import os
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return capi.Context(ol.Q_PN14, ol.P_PN14)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_gwy_four_call_sequence_over_sixteen_streamed_batches(tmp_path):
+    """The logistic path's gWY (assoc.go:1338,1375,1404,1422) calls GenoBlockMult four times per block with s = ncov, 1 (square = true), 1, 1 on the SAME
+    batches.  16 batches of 64 kept SNPs streamed from one .bed: every call with the call-wide baby-step rotation cache (the default), without it
+    (SFG_ASSOC_ROTCACHE_MB=0: the reference's per-batch rebuild) and, where the file system allows, with O_DIRECT reads - identical words; batch 5
+    of every call against the oracle."""
+    from sfgwas_amd import capi
+    ns, nv, batch, level, maxl, ncov = 300, 1100, 64, 5, 5, 5
+    rnd = np.random.default_rng(23)
+    geno = rnd.choice(np.array([2, -1, 1, 0], dtype=np.int8), size=(ns, nv), p=[0.2, 0.05, 0.35, 0.4])
+    colf = (rnd.random(nv) < 0.95).astype(np.uint8)
+    path = str(tmp_path / "chr2.bed")
+    write_bed(path, geno)
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    slots, d = ring.slots, 91
+    shifts = set(range(ns)) | set(range(slots - batch + 1, slots))
+    rots = sorted({sh % d for sh in shifts if sh % d} | {(sh // d) * d for sh in shifts if sh // d})
+    ctxs = {"cached": capi.Context(ol.Q_PN14, ol.P_PN14), "per_batch": _ctx_with_env(capi, SFG_ASSOC_ROTCACHE_MB=0)}
+    for k in rots:
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 900 + k)
+        keys.add(g, key)
+        for c in ctxs.values():
+            c.load_rotkey(g, key)
+    bt = batches(colf, batch)
+    assert len(bt) >= 16
+    cap = len(bt)
+    calls = [(ncov, False, 61), (1, True, 62), (1, False, 63), (1, False, 64)]            # (s, square, seed): WzBT, w (squared genotypes), yTilde, WzZTwZInvZTy
+    for s, square, seed in calls:
+        A = np.stack([np.stack([ring.fill_uniform(level, seed * 10 + i)]) for i in range(s)])
+        outs = {}
+        for name, ctx in ctxs.items():
+            for direct in ((False, True) if name == "cached" else (False,)):
+                dA = capi.DevArray.from_host(ctx, A)
+                dout = capi.DevArray(ctx, (s, cap, 2, maxl, ring.N))
+                got_ct = C.c_size_t()
+                flags = (capi.SFG_SQUARE if square else 0) | (capi.SFG_STREAM_DIRECT if direct else 0)
+                rc = capi.lib().sfg_assoc_stream_bed(ctx.h, path.encode(), ns, nv, None, colf.ctypes.data_as(C.c_void_p), batch, dA.p, s, level, maxl, flags,
+                                                     dout.p, cap, C.byref(got_ct), None, None)
+                if rc and direct and b"O_DIRECT" in capi.lib().sfg_last_error(ctx.h):
+                    dA.free(); dout.free()
+                    continue                                                              # tmpfs and friends: no O_DIRECT
+                ctx.check(rc, "assoc_stream_bed")
+                assert got_ct.value == len(bt)
+                outs[(name, direct)] = dout.host()
+                dA.free(); dout.free()
+        ref = outs[("cached", False)]
+        for key_, o in outs.items():
+            assert np.array_equal(o, ref), f"s={s} square={square}: {key_} differs from the cached path"
+        a, b = bt[5]
+        sub = np.ascontiguousarray(geno[:, a:b][:, colf[a:b].astype(bool)])
+        want, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, maxl, sub, square=square, enc_prec=1)
+        assert np.array_equal(ref[:, 5:6], want), f"s={s} square={square}: batch 5 vs the oracle"
+    for c in ctxs.values():
+        c.close()

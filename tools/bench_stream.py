@@ -32,13 +32,33 @@ nbatch = (a.snps + a.batch - 1) // a.batch
 cap = nbatch * ((a.batch - 1) // P.SLOTS + 1)
 out = capi.DevArray(ctx, (a.s, cap, 2, P.MAX_LEVEL, P.N))
 got = C.c_size_t()
-def run():
+def run(flags=0):
     t = time.time()
-    ctx.check(L.sfg_assoc_stream_bed(ctx.h, path.encode(), a.samples, a.snps, None, None, a.batch, A.p, a.s, P.MAX_LEVEL, P.MAX_LEVEL, 0, out.p, cap, C.byref(got), None, None), "stream")
+    ctx.check(L.sfg_assoc_stream_bed(ctx.h, path.encode(), a.samples, a.snps, None, None, a.batch, A.p, a.s, P.MAX_LEVEL, P.MAX_LEVEL, flags, out.p, cap, C.byref(got), None, None), "stream")
     ctx.sync()
     return time.time() - t
 run()                                  # warm-up: scratch pools, page cache
 dt = min(run(), run())
+try:                                   # the same with O_DIRECT reads: the disk, not the page cache
+    dt_direct = min(run(capi.SFG_STREAM_DIRECT), run(capi.SFG_STREAM_DIRECT))
+except capi.SfgError as e:
+    dt_direct = None; direct_err = str(e)[:120]
+if os.environ.get("SFG_ASSOC_ROTCACHE_MB") != "0":      # the per-batch rotation rebuild of round 2, for the A/B: a second context that reads the switch
+    os.environ["SFG_ASSOC_ROTCACHE_MB"] = "0"
+    ctx0 = capi.Context(P.Q_PN14, P.P_PN14)
+    ctx0.check(L.sfg_fill_rotkeys_synthetic(ctx0.h, (C.c_int * len(rots))(*rots), len(rots), 0xBEEF), "keys")
+    A0 = ctx0.fill_uniform_cts(a.s * nbr, P.MAX_LEVEL, 0xC1F3); out0 = capi.DevArray(ctx0, (a.s, cap, 2, P.MAX_LEVEL, P.N))
+    def run0():
+        t = time.time()
+        ctx0.check(L.sfg_assoc_stream_bed(ctx0.h, path.encode(), a.samples, a.snps, None, None, a.batch, A0.p, a.s, P.MAX_LEVEL, P.MAX_LEVEL, 0, out0.p, cap, C.byref(got), None, None), "stream")
+        ctx0.sync()
+        return time.time() - t
+    run0(); dt_rebuild = min(run0(), run0())
+    run()                              # `out` again from the cached path (the O_DIRECT runs wrote the same words)
+    same = bool(np.array_equal(out0.host(), out.host()))
+    A0.free(); out0.free(); ctx0.close()
+else:
+    dt_rebuild, same = None, None
 # the same products from an HBM-resident int8 batch (no file, no decode): the compute floor
 gd, gh = ctx.fill_geno(a.samples, a.batch, 0x5F6A)
 o2 = capi.DevArray(ctx, (a.s, (a.batch - 1) // P.SLOTS + 1, 2, P.MAX_LEVEL, P.N))
@@ -51,5 +71,10 @@ macs = a.samples * a.snps * a.s * 2 * P.MAX_LEVEL * 2
 print(json.dumps({"workload": f"assoc batches streamed from a .bed: {a.samples} samples x {a.snps} SNPs, batch {a.batch}, s={a.s}", "batches": nbatch,
                   "s_per_batch_streamed": dt / nbatch, "s_per_batch_resident_int8": dt_res / nbatch, "useful_ring_macs_per_s_streamed": macs / dt,
                   "file_GBps": (a.snps * bps) / dt / 1e9, "file_bytes": a.snps * bps, "file_write_s": t_write,
-                  "note": "file was just written: reads are served by the page cache unless it was evicted"}))
+                  "s_per_batch_streamed_O_DIRECT": None if dt_direct is None else dt_direct / nbatch,
+                  "file_GBps_O_DIRECT": None if dt_direct is None else (a.snps * bps) / dt_direct / 1e9,
+                  "s_per_batch_streamed_rotations_rebuilt_per_batch": None if dt_rebuild is None else dt_rebuild / nbatch,
+                  "outputs_identical_with_and_without_the_call_wide_rotation_cache": same,
+                  "note": "buffered reads of a file that was just written come from the page cache; the O_DIRECT figures are the storage device's; "
+                          "the resident figure rebuilds the rotation cache per call (one call = one batch there)"}))
 os.remove(path)
