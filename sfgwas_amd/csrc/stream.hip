@@ -75,14 +75,16 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
     if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_stream_bed: batches are multiplied as X (samples x SNPs)");
     const size_t bps = (num_sample + 3) / 4, N = SFG_N, slots = SFG_SLOTS, L = (size_t)max_level;
     const bool direct = (flags & SFG_STREAM_DIRECT) != 0;                                        // bypass the page cache: what a 5 TB scan from NVMe sees
-    const int fd = open(bed_path, direct ? O_RDONLY | O_DIRECT : O_RDONLY);
-    if (fd < 0) {
-        if (direct && errno == EINVAL) SFG_FAIL(ctx, "assoc_stream_bed: the file system of %s does not support O_DIRECT", bed_path);
-        SFG_FAIL(ctx, "assoc_stream_bed: cannot open %s", bed_path);                            // os.Open panics in the reference (filestream.go:59-61)
-    }
+    int fd = open(bed_path, O_RDONLY);
+    if (fd < 0) SFG_FAIL(ctx, "assoc_stream_bed: cannot open %s", bed_path);                     // os.Open panics in the reference (filestream.go:59-61)
     flags &= ~SFG_STREAM_DIRECT;
     struct stat stt; uint8_t magic[3] = {0, 0, 0};
     if (fstat(fd, &stt) || pread(fd, magic, 3, 0) != 3) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: cannot read %s", bed_path); }
+    if (direct) {                                      // the header was read through the page cache; the batches go around it
+        close(fd);
+        fd = open(bed_path, O_RDONLY | O_DIRECT);
+        if (fd < 0) SFG_FAIL(ctx, "assoc_stream_bed: the file system of %s does not support O_DIRECT", bed_path);
+    }
     if ((size_t)stt.st_size != 3 + num_snp * bps) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: file holds %zu bytes, expected 3 + %zu x %zu", (size_t)stt.st_size, num_snp, bps); }
     if (magic[0] != 0x6C || magic[1] != 0x1B || magic[2] != 0x01) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: not a SNP-major PLINK .bed"); }
     const std::vector<Batch> bt = make_batches(col_filter, num_snp, batch_snps);
