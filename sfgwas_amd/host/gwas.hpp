@@ -519,6 +519,43 @@ inline DevCipherVector CInverseDev(CryptoParams *cps, const DevCipherVector &X, 
     return res;
 }
 inline DevCipherVector viewOne(const DevCipherVector &v, size_t j) { DevCipherVector o = v; o.off = v.off + j * detail::ctWords(v.cps, v.level); o.n = 1; return o; }
+// eval.MultByConstNew (crypto.CMultConst, basics.go:480-497): a constant with a fractional part is scaled by q_level and the scale grows by it; no rescale
+inline DevCipherVector CMultConstDev(CryptoParams *cps, const DevCipherVector &X, double constant) {
+    double scale = 1.0;
+    if (constant != 0 && constant - (double)(long long)constant != 0) scale = (double)cps->qi[X.level];
+    std::vector<uint64_t> sc(X.level + 1, 0);
+    for (int m = 0; m <= X.level; m++) sc[m] = constant != 0 ? scaleUpExact(constant, scale, cps->qi[m]) : 0;
+    DevCipherVector o = NewDevCipherVector(cps, X.n, X.level, X.scale * scale);
+    cps->check(sfg_ct_mul_scalar_dev(cps->ctx, X.ptr(), sc.data(), o.ptr(), (int)X.n, X.level), "CMultConst");
+    return o;
+}
+// crypto.Rebalance (basics.go:248-255): InnerSumAll of the one ciphertext, times 1 / slots
+inline DevCipherVector RebalanceDev(CryptoParams *cps, const DevCipherVector &ct) { return CMultConstDev(cps, InnerSumAllDev(cps, ct), 1.0 / (double)cps->GetSlots()); }
+
+// ---- vectors whose ciphertexts keep their OWN level and scale (a crypto.CipherVector is []*ckks.Ciphertext: NetDQRenc's Householder vector has one
+// ciphertext - the one that received alphaScaled - below the others, qrfact.go:166-169).  Element-wise ops act pairwise at the lower level of each pair.
+using CellVec = std::vector<DevCipherVector>;                           // every element: n == 1
+inline CellVec cellsOf(const DevCipherVector &v) { CellVec c; for (size_t j = 0; j < v.n; j++) c.push_back(viewOne(v, j)); return c; }
+inline CellVec CMultCells(CryptoParams *cps, const CellVec &X, const CellVec &Y) {      // crypto.CMult with its length-1 broadcast (basics.go:386-427)
+    const size_t n = std::max(X.size(), Y.size()); CellVec o;
+    if ((X.size() != n && X.size() != 1) || (Y.size() != n && Y.size() != 1)) throw std::runtime_error("CMult: vector lengths differ");
+    for (size_t k = 0; k < n; k++) o.push_back(CMultDev(cps, X[X.size() == 1 ? 0 : k], Y[Y.size() == 1 ? 0 : k], cps->qi));
+    return o;
+}
+inline CellVec CAddCells(CryptoParams *cps, const CellVec &X, const CellVec &Y) {       // crypto.CAdd (basics.go:568-578)
+    if (X.size() != Y.size()) throw std::runtime_error("CAdd: vector lengths differ");
+    CellVec o; for (size_t k = 0; k < X.size(); k++) o.push_back(CAddSubDev(cps, X[k], Y[k], false));
+    return o;
+}
+// crypto.InnerSumAll (basics.go:278-292): vecsum = X[0]; eval.Add(X[i], vecsum, vecsum) for i >= 1 (each at the lower level of the pair, with lattigo's scale
+// matching; an unmatched pair keeps vecsum's scale), then 13 rotate-and-add steps.  (That a binary op yields the LOWER level is this restatement's reading
+// of lattigo's evaluateInPlace - parity unpinned.)
+inline DevCipherVector InnerSumAllCells(CryptoParams *cps, const CellVec &X) {
+    DevCipherVector vecsum = X[0];
+    for (size_t k = 1; k < X.size(); k++) vecsum = CAddSubDev(cps, vecsum, X[k], false);
+    return InnerSumAllDev(cps, vecsum);
+}
+inline CipherVector ToHost(const CellVec &c) { CipherVector out; for (const auto &v : c) { CipherVector h = ToHost(v); out.insert(out.end(), h.begin(), h.end()); } return out; }
 }  // namespace crypto
 
 namespace gwas {
@@ -821,6 +858,57 @@ inline void DCMatMulAAtBLocal2(crypto::CryptoParams *cps, const crypto::DevCiphe
         crypto::DevCipherVector ccTQ = crypto::CMultDev(cps, Ac, one, qi);
         out[j] = out[j].n ? crypto::CAddSubDev(cps, out[j], ccTQ, false) : ccTQ;                             // out starts as CZeroMat (fresh zero encryptions, added by the Go side)
     }
+}
+
+// ---------------------------------------------------------------- f-2: NetDQRenc (gwas/qrfact.go:47-316), the LOCAL segments of one column step
+// Between them sit MPC rounds that stay in Go (AggregateSharesCT, CiphertextToSS, SqrtAndSqrtInverse, IsPositive, SSMultElemVec, Trunc, SStoCiphertext,
+// AggregateCVec, BootstrapMatAll).  Forward column (qrfact.go:75-216):
+//   F1  zloc = SqSum(A[0]); uvec = copy of A[0]                                                                  (:91-93)
+//   F2  alphaScaled = Mask(Rebalance(alphaScaled), slotid, false); zNewSqrtInv = Rebalance(zNewSqrtInv)          (:136-141)
+//       uvec = CMultScalar(uvec, zNewSqrtInv); the owner of the pivot row: uvec[ctid] += Mask(alphaScaled, slotid, false)   (:159-165)
+//   F3  DCMatMulAAtB(vMat = {uvec}, A) = cTQloc[j] = InnerSumAll(CMult(uvec, A[j])) | AggregateCVec | out[j] = CMult(uvec, {cTQ[j]})   (:176-189, matmult.go:121-156)
+//       A[c][ci] += vvTA[c][ci] * (-2 / N)   (eval.MultByConstAndAdd, :193-200)
+//   F4  after BootstrapMatAll: A = A[1:]; the pivot row is masked out of every remaining column; FlattenLevels                (:202-215)
+// Backward column (:236-285): the same DCMatMulAAtB with Mask(vList[j][ctid], slotid, false) as the inner function of the leftmost column, then
+//   Q[j + c] += vvTQ[c] * (-2 scalar), scalar = 1/sqrt(N) for c = 0 and 1/N otherwise.
+inline crypto::DevCipherVector NetDQRencF1(crypto::CryptoParams *cps, const crypto::CellVec &A0) {
+    return crypto::InnerSumAllCells(cps, crypto::CMultCells(cps, A0, A0));                                        // crypto.SqSum = InnerProd(X, X), basics.go:355-358
+}
+inline crypto::CellVec NetDQRencF2(crypto::CryptoParams *cps, const crypto::CellVec &A0, const crypto::DevCipherVector &alphaScaledIn, const crypto::DevCipherVector &zNewSqrtInvIn,
+                                   bool ownsPivot, int ctid, int slotid) {
+    crypto::DevCipherVector alphaScaled = crypto::MaskDev(cps, crypto::RebalanceDev(cps, alphaScaledIn), slotid, false, cps->qi);
+    crypto::DevCipherVector zNewSqrtInv = crypto::RebalanceDev(cps, zNewSqrtInvIn);
+    crypto::CellVec uvec = crypto::CMultCells(cps, A0, crypto::CellVec{zNewSqrtInv});
+    if (ownsPivot) {
+        alphaScaled = crypto::MaskDev(cps, alphaScaled, slotid, false, cps->qi);
+        uvec[ctid] = crypto::CAddSubDev(cps, uvec[ctid], alphaScaled, false);                                     // crypto.Add, basics.go:174-181
+    }
+    return uvec;
+}
+// the local half of DCMatMulAAtB before AggregateCVec; pivotMask >= 0: the backward pass's inner function for j = 0 (Mask(a[ctid], slotid, false), or an
+// encryption of zero supplied by the Go side when this party does not own the pivot row - pass ownsPivot = false and the result omits entry 0)
+inline std::vector<crypto::DevCipherVector> NetDQRencInner(crypto::CryptoParams *cps, const crypto::CellVec &v, const std::vector<crypto::CellVec> &B, bool backward, bool ownsPivot, int ctid, int slotid) {
+    std::vector<crypto::DevCipherVector> cTQloc(B.size());
+    for (size_t j = 0; j < B.size(); j++) {
+        if (backward && j == 0) { if (ownsPivot) cTQloc[0] = crypto::InnerSumAllCells(cps, crypto::CellVec{crypto::MaskDev(cps, v[ctid], slotid, false, cps->qi)}); continue; }
+        cTQloc[j] = crypto::InnerSumAllCells(cps, crypto::CMultCells(cps, v, B[j]));
+    }
+    return cTQloc;
+}
+// after AggregateCVec: out[j] = CMult(v, {cTQ[j]}) (added onto CZeroMat by the Go side), then M[j] += out[j] * constants[j] (eval.MultByConstAndAdd per ciphertext)
+inline void NetDQRencUpdate(crypto::CryptoParams *cps, const crypto::CellVec &v, const std::vector<crypto::DevCipherVector> &cTQ, std::vector<crypto::CellVec> &M, const std::vector<double> &constants) {
+    for (size_t j = 0; j < cTQ.size(); j++) {
+        crypto::CellVec vv = crypto::CMultCells(cps, v, crypto::CellVec{cTQ[j]});
+        for (size_t ci = 0; ci < vv.size(); ci++) crypto::MultByConstAndAddDev(cps, vv[ci], constants[j], M[j][ci], cps->qi);
+    }
+}
+// F4 on the bootstrapped matrix (one level): drop the first column, mask the pivot row out of the pivot owner's ciphertext, FlattenLevels
+inline std::vector<crypto::CellVec> NetDQRencF4(crypto::CryptoParams *cps, const std::vector<crypto::CellVec> &Aboot, bool ownsPivot, int ctid, int slotid) {
+    std::vector<crypto::CellVec> A(Aboot.begin() + 1, Aboot.end());
+    if (ownsPivot) for (auto &col : A) col[ctid] = crypto::MaskDev(cps, col[ctid], slotid, true, cps->qi);
+    int lvl = 1 << 30; for (auto &col : A) for (auto &c : col) lvl = std::min(lvl, c.level);
+    for (auto &col : A) for (auto &c : col) if (c.level != lvl) c = crypto::DropLevelDev(c, lvl);                // crypto.FlattenLevels, basics.go:514-531
+    return A;
 }
 
 // ---------------------------------------------------------------- A14: ciphertext x ciphertext matrix helpers of the logistic path

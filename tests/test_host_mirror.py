@@ -666,3 +666,159 @@ def test_power_iteration_local_segments_with_bootstraps_at_two_block_rows_and_co
             ref = np.zeros(slots); seg = R2[i, j * slots:(j + 1) * slots]; ref[:len(seg)] = seg
             assert np.max(np.abs(dec - ref)) < 2e-3 * max(1.0, np.max(np.abs(R2))), f"{name}: decrypted values off by {np.max(np.abs(dec - ref))}"
     assert fin[0][0].level == fin[0][1].level + 1 and fin[0][0].scale != fin[0][1].scale, "the full column stays one level above the masked tail, at its own scale"
+
+
+# ---------------------------------------------------------------- f-2: NetDQRenc local segments (forward + backward column), two ciphertexts per column
+def _r_add(ring, x, y):
+    """eval.Add with lattigo's scale matching"""
+    l = min(x.level, y.level)
+    x, y = _r_drop(x, l), _r_drop(y, l)
+    out_scale = x.scale
+    if x.scale > y.scale and np.floor(x.scale / y.scale) > 1:
+        y = _r_mul_int(ring, y, np.floor(x.scale / y.scale), x.scale)
+    elif y.scale > x.scale and np.floor(y.scale / x.scale) > 1:
+        x = _r_mul_int(ring, x, np.floor(y.scale / x.scale), y.scale); out_scale = y.scale
+    out = np.zeros_like(x.a)
+    ol.lib().orc_ct_addsub(ring.h, l, ol.p64(x.a), ol.p64(y.a), 0, ol.p64(out))
+    return _Ct(out, l, out_scale)
+
+
+def _r_innersum_cells(ring, keys, xs):
+    """crypto.InnerSumAll: vecsum = X[0]; eval.Add(X[i], vecsum, vecsum); then the rotate-and-add ladder"""
+    vs = xs[0]
+    for x in xs[1:]:
+        vs = _r_add(ring, vs, x)
+    return _Ct(_orc_innersum(ring, keys, vs.level, [vs.a]), vs.level, vs.scale)
+
+
+def _r_mul_const(ring, x, constant):
+    """eval.MultByConstNew: a fractional constant is scaled by q_level"""
+    out = np.zeros_like(x.a); sm = C.c_double(0)
+    ol.lib().orc_mul_const(ring.h, x.level, ol.p64(x.a), float(constant), ol.p64(out), C.byref(sm))
+    return _Ct(out, x.level, x.scale * sm.value)
+
+
+def _r_mask(ring, x, index, keep_rest, SC):
+    m = np.full(ring.slots, 1.0 if keep_rest else 0.0); m[index] = 0.0 if keep_rest else 1.0
+    mp = np.zeros_like(x.a)
+    mpt = ring.encode_ntt(m, SC, x.level + 1)
+    ol.lib().orc_mul_plain(ring.h, x.level, ol.p64(x.a), ol.p64(mpt), ol.p64(mp))
+    ct, lvl, sc = _orc_rescale_loop(ring, mp, x.level, x.scale * SC, SC)
+    return _Ct(ct, lvl, sc)
+
+
+def _r_rebalance(ring, keys, x):
+    return _r_mul_const(ring, _r_innersum_cells(ring, keys, [x]), 1.0 / ring.slots)
+
+
+def _r_mbca(ring, ct0, constant, out):
+    """eval.MultByConstAndAdd(ct0, constant, ctOut): both at the lower level, scales matched by the restated rule (orc_mul_const_and_add)"""
+    l = min(ct0.level, out.level)
+    a, o = _r_drop(ct0, l).a.copy(), _r_drop(out, l).a.copy()
+    sc = C.c_double(out.scale)
+    ol.lib().orc_mul_const_and_add(ring.h, l, ol.p64(a), ct0.scale, float(constant), ol.p64(o), C.byref(sc))
+    return _Ct(o, l, sc.value)
+
+
+@pytest.mark.gpu
+def test_netdqrenc_forward_and_backward_column_segments_match_the_oracle(tmp_path):
+    """qrfact.go:75-216 (forward column: SqSum, Householder vector from alphaScaled / zNewSqrtInv, DCMatMulAAtB halves, MultByConstAndAdd(-2/N),
+    bootstrap at the target scale, pivot-row Mask, FlattenLevels) and :236-285 (backward column on a Q slice) as device-resident sequences, columns of
+    two ciphertexts, pivot in the SECOND ciphertext - so the Householder vector has mixed levels.  Every dumped word, level and scale vs the oracle replay."""
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_qr_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rnd = np.random.default_rng(99)
+    ncols, nct, ctid, slotid, W, level, totN, SC, slots = 3, 2, 1, 5, 4, 9, 20000.0, 2.0 ** 34, 8192
+    blob = [np.array([13], dtype=np.uint64)]
+    for k in [1 << t for t in range(13)]:                       # InnerSumAll: left rotations by 2^k (basics.go:236-246)
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 700 + k)
+        keys.add(g, key)
+        blob += [np.array([g], dtype=np.uint64), key.reshape(-1)]
+    np.concatenate(blob).tofile(tmp_path / "keys.bin")
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    rlk = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 998); rlk.tofile(tmp_path / "rlk.bin")
+    sk = ol.secret_ntt(ring, ring.gen_secret(8)); sk.tofile(tmp_path / "sk.bin")
+    A = np.stack([np.stack([ring.fill_uniform(level, 1000 + 10 * c + ci) for ci in range(nct)]) for c in range(ncols)])
+    Q = np.stack([np.stack([ring.fill_uniform(level, 2000 + 10 * c + ci) for ci in range(nct)]) for c in range(ncols)])
+    alpha, zinv = ring.fill_uniform(level, 3001), ring.fill_uniform(level, 3002)
+    A.tofile(tmp_path / "A.bin"); Q.tofile(tmp_path / "Q.bin"); alpha.tofile(tmp_path / "alpha.bin"); zinv.tofile(tmp_path / "zinv.bin")
+    (tmp_path / "case.txt").write_text(f"{ncols} {nct} {ctid} {slotid} {W} {level} {totN!r}\n")
+    # ---- oracle replay up to the bootstrap (its level fixes the mask bound)
+    cA = [[_Ct(A[c, ci], level, SC) for ci in range(nct)] for c in range(ncols)]
+    cQ = [[_Ct(Q[c, ci], level, SC) for ci in range(nct)] for c in range(ncols)]
+    want = {}
+    want["f1_zloc"] = _r_innersum_cells(ring, keys, [_r_cmult(ring, x, x, rlk, SC) for x in cA[0]])
+    al = _r_mask(ring, _r_rebalance(ring, keys, _Ct(alpha, level, SC)), slotid, False, SC)
+    zi = _r_rebalance(ring, keys, _Ct(zinv, level, SC))
+    uvec = [_r_cmult(ring, x, zi, rlk, SC) for x in cA[0]]
+    uvec[ctid] = _r_add(ring, uvec[ctid], _r_mask(ring, al, slotid, False, SC))
+    for ci in range(nct):
+        want[f"f2_uvec_{ci}"] = uvec[ci]
+    assert uvec[0].level != uvec[1].level, "the pivot ciphertext of the Householder vector sits below the other one: the mixed-level case"
+
+    def inner(v, B, backward):
+        out = []
+        for j in range(len(B)):
+            if backward and j == 0:
+                out.append(_r_innersum_cells(ring, keys, [_r_mask(ring, v[ctid], slotid, False, SC)]))
+            else:
+                out.append(_r_innersum_cells(ring, keys, [_r_cmult(ring, v[ci], B[j][ci], rlk, SC) for ci in range(nct)]))
+        return out
+
+    def update(v, cTQ, M, consts):
+        for j in range(len(cTQ)):
+            for ci in range(nct):
+                M[j][ci] = _r_mbca(ring, _r_cmult(ring, v[ci], cTQ[j], rlk, SC), consts[j], M[j][ci])
+    ctq = inner(uvec, cA, False)
+    for j in range(ncols):
+        want[f"f3_ctq_{j}"] = ctq[j]
+    update(uvec, ctq, cA, [-2.0 / totN] * ncols)
+    for c in range(ncols):
+        for ci in range(nct):
+            want[f"f3_A_{c}_{ci}"] = cA[c][ci]
+    lvl = min(x.level for col in cA for x in col)
+    Ql = 1
+    for q in ring.moduli[:lvl + 1]:
+        Ql *= q
+    bound = Ql // 4
+    nb = ncols * nct
+    masks = np.zeros((nb, ring.N, W), dtype=np.uint64)
+    for k in range(nb):
+        vals = []
+        for _ in range(ring.N):
+            m = int.from_bytes(rnd.bytes(40), "little") % bound
+            vals.append(m - bound if m >= bound >> 1 else m)
+        masks[k] = ol.bigints_to_limbs(vals, W)
+    crs = np.stack([np.stack([rnd.integers(0, ring.moduli[j], ring.N, dtype=np.uint64) for j in range(ring.nq)]) for _ in range(nb)])
+    e0 = rnd.integers(-19, 20, (nb, ring.N)).astype(np.int32); e1 = rnd.integers(-19, 20, (nb, ring.N)).astype(np.int32)
+    masks.tofile(tmp_path / "bootF_mask.bin"); crs.tofile(tmp_path / "bootF_crs.bin")
+    np.concatenate([e0.reshape(-1), e1.reshape(-1)]).tofile(tmp_path / "bootF_e.bin")
+    Ab = [[_r_bootstrap(ring, _r_drop(cA[c][ci], lvl), sk, (masks, crs, e0, e1), c * nct + ci, SC) for ci in range(nct)] for c in range(ncols)]
+    A4 = [list(col) for col in Ab[1:]]
+    for col in A4:
+        col[ctid] = _r_mask(ring, col[ctid], slotid, True, SC)
+    l4 = min(x.level for col in A4 for x in col)
+    for c, col in enumerate(A4):
+        for ci in range(nct):
+            want[f"f4_A_{c}_{ci}"] = _r_drop(col[ci], l4)
+    ctqb = inner(uvec, cQ, True)
+    for j in range(ncols):
+        want[f"b_ctq_{j}"] = ctqb[j]
+    update(uvec, ctqb, cQ, [-2.0 / np.sqrt(totN)] + [-2.0 / totN] * (ncols - 1))
+    for c in range(ncols):
+        for ci in range(nct):
+            want[f"b_Q_{c}_{ci}"] = cQ[c][ci]
+    # ---- the device-resident sequence
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+    meta = {ln.split()[0]: ln.split()[1:] for ln in (tmp_path / "meta.txt").read_text().splitlines()}
+    assert set(meta) == set(want)
+    for name, w in want.items():
+        lvl_, sc_ = int(meta[name][0]), float(meta[name][1])
+        assert (lvl_, sc_) == (w.level, w.scale), f"{name}: level / scale ({lvl_}, {sc_!r}) vs the replay's ({w.level}, {w.scale!r})"
+        got = np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint64).reshape(2, lvl_ + 1, ring.N)
+        assert np.array_equal(got, w.a), f"{name}: words"
