@@ -233,6 +233,12 @@ int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level,
 int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
                          size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                          uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
+/* the same scan over one chromosome's .pgen image - BASELINE config 1's path (assoc.go:371-416 with isPgen): per batch of `batch_snps` kept variants
+ * FilterMatrixFilePgen (plink2 + plinkBedToBinary.py) + MatMult4Stream, decoded natively on the device (sfg_geno_from_pgen).  row_filter: one byte per
+ * sample (the --keep list), col_filter: one byte per variant of the file (snpFilt).  Layout of out_dev / sum_host / sqsum_host as above. */
+int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
+                   const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                   uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
 /* sharding hooks for one-process-per-GPU runs: restrict a resident product to block columns
  * [j0, j1) of the output (X: SNP-column blocks) or block rows [b0, b1) of the contraction (X^T) */
 int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,

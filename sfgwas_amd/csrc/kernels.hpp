@@ -53,3 +53,5 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
 // matmul.hip: the baby-step rotation cache of block rows [b0, b1) in the MAC layout; tabs = per-row active-baby flags (null: all 91)
 int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, int nbr, int b0, int b1, const std::vector<std::vector<uint8_t>> *tabs, double *cache);
 int sfg_diag_bool(int r, int c, int dim, int index);
+// stream.hip: the call-wide rotation cache of an association scan (nullptr in *out = not applicable; caller hipFree()s)
+int assoc_build_rotcache(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, double **out);

@@ -272,3 +272,58 @@ extern "C" int sfg_pgen_geno_counts(sfg_ctx *ctx, const uint8_t *pgen_host, size
     (void)hipFree(rows.buf); (void)hipFree(dk); (void)hipFree(dc);
     return rc;
 }
+
+// GenoBlockMult over one chromosome's .pgen (gwas/assoc.go:340-420) - what config 1 runs: per batch of `batch_snps` KEPT variants FilterMatrixFilePgen +
+// NewGenoFileStream + MatMult4Stream(cps, mat, X, 5, false, square, nproc), outputs concatenated (crypto.ConcatCipherMatrix).  pgen_host: the file image
+// (mmap it for large files); row_filter: one byte per sample (the --keep list), col_filter: one byte per variant (snpFilt), NULL = keep all.
+// Same output layout and column sums as sfg_assoc_stream_bed; the baby-step rotation cache of A is built once for all batches.
+extern "C" int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
+                              const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                              uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!batch_snps) SFG_FAIL(ctx, "assoc_pgen: bad batch size");
+    if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_pgen: batches are multiplied as X (samples x SNPs)");
+    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, ix));
+    const size_t slots = SFG_SLOTS, N = SFG_N, ctw = (size_t)2 * max_level * N;
+    struct B { size_t v0, v1, kept; };
+    std::vector<B> bt; size_t start = 0, counter = 0;                     // assoc.go:371-416: a batch closes at batch_snps kept variants or at the end of the file
+    for (size_t idx = 0; idx < ix.nv; idx++) {
+        if (!col_filter || col_filter[idx]) counter++;
+        if (counter == batch_snps || (idx == (size_t)ix.nv - 1 && counter > 0)) { bt.push_back({start, idx + 1, counter}); start = idx + 1; counter = 0; }
+    }
+    size_t total_ct = 0, max_kept = 0, nr = 0;
+    for (const B &b : bt) { total_ct += (b.kept + slots - 1) / slots; max_kept = std::max(max_kept, b.kept); }
+    for (uint32_t i = 0; i < ix.ns; i++) nr += !row_filter || row_filter[i];
+    if (out_ct) *out_ct = total_ct;
+    if (bt.empty()) return 0;
+    if (!nr) SFG_FAIL(ctx, "assoc_pgen: the row filter keeps nothing");
+    if (total_ct > out_ct_capacity) SFG_FAIL(ctx, "assoc_pgen: output needs %zu ciphertexts per row, capacity %zu", total_ct, out_ct_capacity);
+    std::vector<size_t> widths;
+    for (const B &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
+    double *rotbuf = nullptr; u64 *tmp = nullptr;
+    SFG_TRY(assoc_build_rotcache(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, &rotbuf));
+    int rc = 0;
+    if (hipMalloc(&tmp, (size_t)s * ((max_kept + slots - 1) / slots) * ctw * 8) != hipSuccess) { ctx->err = "assoc_pgen: out of device memory"; rc = 1; }
+    size_t out_shift = 0;
+    for (size_t k = 0; k < bt.size() && !rc; k++) {
+        const B &b = bt[k];
+        sfg_geno *g = nullptr;
+        rc = sfg_geno_from_pgen(ctx, pgen_host, pgen_bytes, b.v0, b.v1, row_filter, col_filter ? col_filter + b.v0 : nullptr, &g);
+        if (rc) break;
+        const size_t nct = (b.kept + slots - 1) / slots;
+        rc = rotbuf ? sfg_matmul_resident_range_rc_dev(ctx, rotbuf, s, max_level, g, flags, 0, (int)nct, (uint64_t *)tmp)
+                    : sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, g, flags, (uint64_t *)tmp);
+        for (int i = 0; i < s && !rc; i++)
+            if (hipMemcpyAsync(out_dev + ((size_t)i * out_ct_capacity + out_shift) * ctw, tmp + (size_t)i * nct * ctw, nct * ctw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "assoc_pgen: copy failed"; rc = 1; }
+        if (!rc && (sum_host || sqsum_host)) {
+            if (sum_host) std::fill(sum_host + out_shift * slots, sum_host + (out_shift + nct) * slots, 0.0);
+            if (sqsum_host) std::fill(sqsum_host + out_shift * slots, sqsum_host + (out_shift + nct) * slots, 0.0);
+            rc = sfg_geno_colsums(ctx, g, sum_host ? sum_host + out_shift * slots : nullptr, sqsum_host ? sqsum_host + out_shift * slots : nullptr);
+        }
+        sfg_geno_free(ctx, g);                                            // synchronises the queue: tmp and the batch matrix are done with
+        out_shift += nct;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp); (void)hipFree(rotbuf);
+    return rc;
+}

@@ -65,6 +65,32 @@ struct Reader {                                        // fills pinned slot k & 
 };
 }  // namespace
 
+// The baby-step rotation cache of the ciphertext matrix every batch of an association scan multiplies (see the header comment): *out = nullptr when the
+// cache is switched off, does not fit the budget or the device (the caller then lets every product build its own rotations).  widths: the distinct
+// block-column widths of the batches, for the active-baby tables (matmult.go:1326-1336).  The caller hipFree()s *out.
+int assoc_build_rotcache(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, double **out) {
+    *out = nullptr;
+    const size_t slots = SFG_SLOTS;
+    size_t jobw = 0, tailw = 0;
+    const int nbr = (int)((nr + slots - 1) / slots);
+    if (!ctx->cfg.assoc_cache_budget || !mac_use_dma(ctx) || sfg_rotcache_layout(ctx, s, max_level, &jobw, &tailw)) { ctx->err.clear(); return 0; }
+    const size_t words = (size_t)nbr * s * jobw + tailw;
+    if (words * 8 > ctx->cfg.assoc_cache_budget) return 0;
+    double *buf = nullptr;
+    if (hipMalloc(&buf, words * 8) != hipSuccess) { (void)hipGetLastError(); return 0; }      // no room: per-batch rotations
+    std::vector<std::vector<uint8_t>> tabs(nbr, std::vector<uint8_t>(SFG_D, 0));
+    for (int bi = 0; bi < nbr; bi++) {
+        const int rows = (int)(std::min((size_t)(bi + 1) * slots, nr) - (size_t)bi * slots);
+        for (int shift = 0; shift < SFG_SLOTS; shift++) {
+            if (tabs[bi][shift % SFG_D]) continue;
+            for (size_t w : widths) if (sfg_diag_bool(rows, (int)w, SFG_SLOTS, -shift)) { tabs[bi][shift % SFG_D] = 1; break; }
+        }
+    }
+    const int rc = rotcache_build_rows_tab(ctx, A_dev, s, in_level, max_level, nbr, 0, nbr, &tabs, buf);
+    if (rc) { (void)hipFree(buf); return rc; }
+    *out = buf; return 0;
+}
+
 // out_dev: [s][out_ct_capacity][2][max_level][N]; *out_ct = sum over batches of ceil(kept / slots) (the width ConcatCipherMatrix would give).
 // sum_host / sqsum_host: optional [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).
 extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
@@ -126,29 +152,11 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
     // ---- the baby-step rotation cache of `mat`, once for all batches of the call
     const double *rotcache = nullptr;
     {
-        size_t jobw = 0, tailw = 0;
-        const int nbr = (int)((nr + slots - 1) / slots);
-        if (ctx->cfg.assoc_cache_budget && mac_use_dma(ctx) && !sfg_rotcache_layout(ctx, s, max_level, &jobw, &tailw)) {
-            const size_t words = (size_t)nbr * s * jobw + tailw;
-            if (words * 8 <= ctx->cfg.assoc_cache_budget) {
-                if (hipMalloc(&rotbuf, words * 8) == hipSuccess) {       // freed when the call returns (a context-pool buffer of this size would starve the next product)
-                    // active baby steps (matmult.go:1326-1336) of every block row, united over the block-column widths the batches have
-                    std::vector<size_t> widths;
-                    for (const Batch &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
-                    std::vector<std::vector<uint8_t>> tabs(nbr, std::vector<uint8_t>(SFG_D, 0));
-                    for (int bi = 0; bi < nbr; bi++) {
-                        const int rows = (int)(std::min((size_t)(bi + 1) * slots, nr) - (size_t)bi * slots);
-                        for (int shift = 0; shift < SFG_SLOTS; shift++) {
-                            if (tabs[bi][shift % SFG_D]) continue;
-                            for (size_t w : widths) if (sfg_diag_bool(rows, (int)w, SFG_SLOTS, -shift)) { tabs[bi][shift % SFG_D] = 1; break; }
-                        }
-                    }
-                    rc = rotcache_build_rows_tab(ctx, (const u64 *)A_dev, s, in_level, max_level, nbr, 0, nbr, &tabs, rotbuf);
-                    if (!rc) rotcache = rotbuf;
-                } else { rotbuf = nullptr; (void)hipGetLastError(); }      // no room: per-batch rotations
-            }
-        }
+        std::vector<size_t> widths;
+        for (const Batch &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
+        rc = assoc_build_rotcache(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, &rotbuf);
         if (rc) { cleanup(); return rc; }
+        rotcache = rotbuf;
     }
     Reader rd; rd.fd = fd; rd.bps = bps; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
     std::thread reader([&rd] { rd.run(); });

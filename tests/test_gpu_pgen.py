@@ -122,3 +122,39 @@ def test_config1_matmult4stream_on_the_real_example_data_of_party1(env):
         sub = np.ascontiguousarray(geno[:, j * SLOTS:(j + 1) * SLOTS])
         want, _, _ = ol.matmult4stream(env.ring, env.keys, SCALE, A, LEVEL, L, sub, enc_prec=1)
         assert np.array_equal(got[:, j], want[:, 0]), f"block column {j}"
+
+
+def test_genoblockmult_over_a_real_chromosome_pgen_in_batches(env):
+    """assoc.go:371-416 with isPgen on the reference's chr22 of party 1 (4545 variants x 1000 samples): batches of 1000 KEPT variants, --keep / snpFilt
+    style filters, MatMult4Stream per batch with computeSquaredSum, ConcatCipherMatrix layout - sfg_assoc_pgen vs the oracle run on the matrices the
+    oracle decodes from the same file"""
+    lib = env.capi.lib()
+    img = party1_images()[21]
+    ns, nv = ol.pgen_dims(img)
+    rnd = np.random.default_rng(77)
+    rowf = (rnd.random(ns) < 0.95).astype(np.uint8); colf = (rnd.random(nv) < 0.9).astype(np.uint8)
+    batch, s = 1000, 2
+    bt, start, counter = [], 0, 0
+    for idx in range(nv):
+        counter += int(colf[idx])
+        if counter == batch or (idx == nv - 1 and counter > 0):
+            bt.append((start, idx + 1)); start, counter = idx + 1, 0
+    assert len(bt) == 5
+    A = host_cts(env.ring, s, 1, LEVEL, 31)
+    cap = len(bt)
+    dA = env.capi.DevArray.from_host(env.ctx, A)
+    dout = env.capi.DevArray(env.ctx, (s, cap, 2, L, N))
+    sums = np.full(cap * SLOTS, -7.0); sq = np.full(cap * SLOTS, -7.0)
+    got_ct = C.c_size_t()
+    env.ctx.check(lib.sfg_assoc_pgen(env.ctx.h, img.ctypes.data_as(C.c_void_p), img.size, rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch,
+                                     dA.p, s, LEVEL, L, 0, dout.p, cap, C.byref(got_ct), sums.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p)), "assoc_pgen")
+    assert got_ct.value == cap
+    out = dout.host()
+    full = ol.pgen_to_int8(img)
+    for k, (a, b) in enumerate(bt):
+        sub = np.ascontiguousarray(full[rowf.astype(bool)][:, a:b][:, colf[a:b].astype(bool)])
+        want, wsum, wsq = ol.matmult4stream(env.ring, env.keys, SCALE, A, LEVEL, L, sub, compute_sqsum=True, enc_prec=1)
+        assert np.array_equal(out[:, k:k + 1], want), f"batch {k}"
+        assert np.array_equal(sums[k * SLOTS: k * SLOTS + sub.shape[1]], wsum) and np.array_equal(sq[k * SLOTS: k * SLOTS + sub.shape[1]], wsq)
+        assert not sums[k * SLOTS + sub.shape[1]: (k + 1) * SLOTS].any()
+    dA.free(); dout.free()
