@@ -209,3 +209,26 @@ def test_checker_logic_on_vectors_generated_by_the_oracle_itself():
     check_ring_ntt(fx, "small")
     check_encode(fx, "small")
     check_small_ring_ops(fx)
+
+
+@needs_fixture
+def test_collective_bootstrap_recode_at_the_target_scale(fx):
+    """mpc/mhe.go:256-258 on one party: Recode(ct, parameters.Scale()) as a function of the Decrypt output, and Recrypt - pins the scale ratio and the
+    truncation rule of oracle/sfgwas_oracle.c orc_refresh_finish_scaled (restated from lattigo v2.2.0, the fork's source being absent)"""
+    tag = "small"
+    ring, q, p = ring_of(fx, tag)
+    if tag + ".refresh.in.c0" not in fx:
+        pytest.skip("fixture file predates the refresh dump")
+    level = fx[tag + ".refresh.in.c0"].shape[0] - 1
+    ct_scale, target = float(fx[tag + ".refresh.in.scale"][0]), float(fx[tag + ".scale"][0])
+    nq = len(q)
+    # Decrypt output -> Recode: feed the dumped c0 + h0 as "ct with zero shares"
+    dec = np.zeros((2, level + 1, ring.N), dtype=np.uint64); dec[0] = fx[tag + ".refresh.decrypted_c0"]
+    zero0 = np.zeros((level + 1, ring.N), dtype=np.uint64); zero1 = np.zeros((nq, ring.N), dtype=np.uint64)
+    out = ol.refresh_finish_scaled(ring, level, dec, ct_scale, target, zero0, zero1, zero1)
+    assert np.array_equal(out[0], fx[tag + ".refresh.recoded_c0"]), "Recode at the target scale"
+    assert float(fx[tag + ".refresh.recoded_scale"][0]) == target
+    # the whole finish with the dumped shares
+    cin = np.stack([fx[tag + ".refresh.in.c0"], fx[tag + ".refresh.in.c1"]])
+    full = ol.refresh_finish_scaled(ring, level, cin, ct_scale, target, fx[tag + ".refresh.h0"], fx[tag + ".refresh.h1"], fx[tag + ".refresh.crp"])
+    assert np.array_equal(full[0], fx[tag + ".refresh.out.c0"]) and np.array_equal(full[1], fx[tag + ".refresh.out.c1"])

@@ -16,6 +16,7 @@ import (
 	"os"
 
 	"github.com/ldsec/lattigo/v2/ckks"
+	"github.com/ldsec/lattigo/v2/dckks"
 	"github.com/ldsec/lattigo/v2/ring"
 )
 
@@ -166,6 +167,35 @@ func run(tag string, params *ckks.Parameters, level uint64, withKeys bool) {
 	ct(tag+".addconst_0p5", ac)
 	sum := eval.AddNew(a, b)
 	ct(tag+".add", sum)
+	// --- collective bootstrap, local work, at the scales the reference uses (mpc/mhe.go:245-258 with one party): a product at scale Delta^2 is
+	// refreshed to parameters.Scale().  GenShares draws its mask internally; what the dump pins is (i) Recode as a function of the Decrypt output
+	// (scale ratio and truncation rule) and (ii) the relation between the two shares (h0 - sk*c1 vs -h1 - sk*crp carry mask and scaled mask).
+	{
+		refProtocol := dckks.NewRefreshProtocol(params)
+		in := eval.MulRelinNew(a, b) // scale Delta^2, level `level`
+		ct(tag+".refresh.in", in)
+		levelStart := in.Level()
+		refShare1, refShare2 := refProtocol.AllocateShares(levelStart) // mhe.go:246
+		ringQ, _ := ring.NewRing(params.N(), params.Qi())
+		crp := ringQ.NewPoly() // stands for crpGen.ReadNew(), mhe.go:248
+		cst := uint64(0xC0FFEE)
+		for l := range crp.Coeffs {
+			for j := range crp.Coeffs[l] {
+				crp.Coeffs[l][j] = splitmix(&cst) % ringQ.Modulus[l]
+			}
+		}
+		poly(tag+".refresh.crp", crp, len(crp.Coeffs))
+		refProtocol.GenShares(sk.Value, levelStart, 1, in, params.Scale(), crp, refShare1, refShare2) // mhe.go:251
+		poly(tag+".refresh.h0", (*ring.Poly)(refShare1), int(levelStart)+1)
+		poly(tag+".refresh.h1", (*ring.Poly)(refShare2), int(params.MaxLevel())+1)
+		refProtocol.Decrypt(in, refShare1) // mhe.go:256 (one party: the aggregate is the share)
+		poly(tag+".refresh.decrypted_c0", in.Value()[0], int(levelStart)+1)
+		refProtocol.Recode(in, params.Scale()) // mhe.go:257
+		poly(tag+".refresh.recoded_c0", in.Value()[0], int(params.MaxLevel())+1)
+		f64s(tag+".refresh.recoded_scale", []float64{in.Scale()})
+		refProtocol.Recrypt(in, crp, refShare2) // mhe.go:258
+		ct(tag+".refresh.out", in)
+	}
 	// decrypted slots of the rotation (sanity, fp64): crypto.go:451-455
 	dec := ckks.NewDecryptor(params, sk)
 	vals := enc.Decode(dec.DecryptNew(eval.RotateNew(a, 1)), params.LogSlots())
