@@ -464,7 +464,7 @@ def main():
             hbm_alg = alg_step * args.steps / dt / 1e9
             traffic, traffic_src = None, None
             try:        # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_pmc.sh), committed file
-                for name in ("r02_pmc_traffic_per_launch.json", "r01_pmc_traffic_per_launch.json"):
+                for name in ("r03_pmc_traffic_per_launch.json", "r02_pmc_traffic_per_launch.json", "r01_pmc_traffic_per_launch.json"):
                     path = os.path.join(ROOT, "profiles", name)
                     if not os.path.exists(path):
                         continue
