@@ -317,6 +317,14 @@ int sfg_refresh_finish_scaled_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct,
 int sfg_ckks_to_ss_share_dev(sfg_ctx *ctx, const uint64_t *ct_dev, int nct, int level, const uint64_t *mask_dev, int mask_limbs, const int32_t *e0_dev,
                              uint64_t *h0_dev, uint64_t *mask_ntt_dev);
 
+/* f-4: the share algebra of MPC.SSToCMat that does not need the fork (mpc/ss.go:84-110; EncodeRVecNew, :125, and the encryption stay in Go).
+ * Field elements as in the Beaver products.  rand_dev: the ring.RandInt(bound) draws of the caller (< bound), bound_host = Modulus / (4 (nParty - 1)):
+ *   mask = rand >= bound / 2 ? rand - bound : rand  (mod p, :90-99);   rm_masked = rm - mask (:101-102, what RevealSymMat then opens)
+ * and, on the hub party after the reveal, share = revealed + mask (:104-106). */
+int sfg_ss_mask_dev(sfg_ctx *ctx, int limbs, const uint64_t *modulus_host, const uint64_t *bound_host, const uint64_t *rm_dev, const uint64_t *rand_dev,
+                    uint64_t *rm_masked_dev, uint64_t *mask_dev, size_t n);
+int sfg_ss_hub_share_dev(sfg_ctx *ctx, int limbs, const uint64_t *modulus_host, const uint64_t *revealed_dev, const uint64_t *mask_dev, uint64_t *share_dev, size_t n);
+
 /* ---- B1-B3: Beaver local products (mpc/beavermult.go:94-147) over a prime field of `limbs` 64-bit LE limbs ---- */
 int sfg_beaver_elem_dev(sfg_ctx *ctx, int pid, int limbs, const uint64_t *modulus_host,
                         const uint64_t *ar_dev, const uint64_t *am_dev, const uint64_t *br_dev, const uint64_t *bm_dev,

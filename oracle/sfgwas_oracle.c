@@ -1003,6 +1003,27 @@ void orc_beaver_matmul(int pid, int n, const u64 *p, const u64 *ar, const u64 *a
     if (pid == 1) f_matmul_acc(out, ar, br, p, n, m, k, nn);                   /* :143-145 */
 }
 
+/* f-4: the share algebra of MPC.SSToCMat that does not need the fork (mpc/ss.go:84-110).  rand = ring.RandInt(bound) values (< bound), `n` limbs each.
+ *   mask = FromBigInt(rand); if rand >= bound >> 1: mask -= FromBigInt(bound)      (:90-99)          rm_masked = rm - mask   (:101-102) */
+void orc_ss_mask(int n, const u64 *p, const u64 *bound, const u64 *rm, const u64 *rand, u64 *rm_masked, u64 *mask, size_t cnt) {
+    u64 half[BL], zero[BL];
+    memset(zero, 0, sizeof zero);
+    for (int j = 0; j < n; j++) half[j] = (bound[j] >> 1) | (j + 1 < n ? bound[j + 1] << 63 : 0);
+    for (size_t e = 0; e < cnt; e++) {
+        u64 m[BL], t[BL];
+        memcpy(m, rand + e * n, 8 * n);
+        if (big_cmp(m, half, n) >= 0) { big_sub(t, bound, m, n); big_sub(m, p, t, n); }       /* FromBigInt(rand) - FromBigInt(bound) mod p */
+        memcpy(mask + e * n, m, 8 * n);
+        if (big_cmp(rm + e * n, m, n) >= 0) big_sub(t, rm + e * n, m, n);                     /* rm - mask mod p */
+        else { big_sub(t, m, rm + e * n, n); big_sub(t, p, t, n); }
+        memcpy(rm_masked + e * n, t, 8 * n);
+    }
+}
+/* share = revealed + mask on the hub party (:104-106) */
+void orc_ss_hub_share(int n, const u64 *p, const u64 *revealed, const u64 *mask, u64 *share, size_t cnt) {
+    for (size_t e = 0; e < cnt; e++) f_add(share + e * n, revealed + e * n, mask + e * n, p, n);
+}
+
 /* ------------------------------------------------------------------ sketch (pca.go:152-162) */
 void orc_sketch(const int8_t *X, size_t nrow, size_t ncol, const int32_t *bucket, const int8_t *sgn, int kp, double *sk, u64 *xsum, u64 *x2sum) {
     memset(sk, 0, 8 * (size_t)kp * ncol); memset(xsum, 0, 8 * ncol); memset(x2sum, 0, 8 * ncol);

@@ -174,6 +174,10 @@ void orc_beaver_matmul(int pid, int limbs, const uint64_t *mod, const uint64_t *
 void orc_sketch(const int8_t *X, size_t nrow, size_t ncol, const int32_t *bucket, const int8_t *sgn, int kp,
                 double *sketch /*kp x ncol*/, uint64_t *xsum, uint64_t *x2sum);
 
+/* f-4: fork-independent share algebra of MPC.SSToCMat (mpc/ss.go:84-110) */
+void orc_ss_mask(int limbs, const uint64_t *mod, const uint64_t *bound, const uint64_t *rm, const uint64_t *rand, uint64_t *rm_masked, uint64_t *mask, size_t n);
+void orc_ss_hub_share(int limbs, const uint64_t *mod, const uint64_t *revealed, const uint64_t *mask, uint64_t *share, size_t n);
+
 /* ---- collective bootstrap, local work (mpc/mhe.go:222-348 -> lattigo v2.1.0 dckks/refresh.go; PARITY UNPINNED, see the .c file) ---- */
 void orc_bigint_to_rns(const orc_ring *r, int nmod, const uint64_t *limbs /*[N][W] two's complement*/, int W, uint64_t *out /*[nmod][N]*/);
 void orc_refresh_gen_shares(const orc_ring *r, int level, const uint64_t *ct, const uint64_t *sk, const uint64_t *crs, const uint64_t *mask, int W,

@@ -101,6 +101,8 @@ def _sig(L):
         "sfg_matmul_resident_range_rc_dev": (i, [vp, vp, i, i, vp, C.c_uint, i, i, vp]),
         "sfg_matmul_accumulate_rc_dev": (i, [vp, vp, i, i, vp, C.c_uint, i, i, i, i, i, vp]),
         "sfg_beaver_elem_dev": (i, [vp, i, i, u64p, vp, vp, vp, vp, vp, sz]),
+        "sfg_ss_mask_dev": (i, [vp, i, u64p, u64p, vp, vp, vp, vp, sz]),
+        "sfg_ss_hub_share_dev": (i, [vp, i, u64p, vp, vp, vp, sz]),
         "sfg_beaver_elem": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, sz]),
         "sfg_beaver_matmul": (i, [vp, i, i, u64p, u64p, u64p, u64p, u64p, u64p, i, i, i]),
         "sfg_sketch": (i, [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int8), i, C.POINTER(d), u64p, u64p]),

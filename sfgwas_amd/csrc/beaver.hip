@@ -271,3 +271,70 @@ extern "C" int sfg_beaver_matmul(sfg_ctx *ctx, int pid, int limbs, const uint64_
     if (m < 1 || k < 1 || n < 1) SFG_FAIL(ctx, "beaver_matmul: bad dimensions");
     return beaver_host_common(ctx, pid, limbs, mod, ar, am, br, bm, out, (size_t)m * k, (size_t)k * n, (size_t)m * n, m, k, n);
 }
+
+// ---------------------------------------------------------------- f-4: the share algebra of MPC.SSToCMat that does not need the fork (mpc/ss.go:84-110)
+//   mask[i][j] = FromBigInt(tmp); if tmp >= bound / 2: mask -= FromBigInt(bound)          (:90-99; tmp = ring.RandInt(bound) stays with the caller)
+//   rmMask = rm - mask                                                                      (:101-102, before RevealSymMat)
+//   share  = hub ? revealed + mask : mask                                                   (:104-110, after RevealSymMat)
+// Field elements as in the Beaver products: `limbs` little-endian 64-bit words, any odd modulus.  One element per lane, streaming (16 / 32 B per operand).
+// mode 0: out = a - recentre(b)   (a = rm, b = raw mask tmp < bound)      mask_out (nullable) = recentre(b)
+// mode 1: out = a + b             (a = revealed, b = mask)
+template <int NW>
+__global__ void __launch_bounds__(256) k_ss_share(int mode, FieldConst f, FieldConst bnd /* p = bound, r2 = bound / 2 */, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t *mask_out, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        uint32_t x[NW], y[NW], r[NW];
+        const uint32_t *pa = reinterpret_cast<const uint32_t *>(a) + e * NW, *pb = reinterpret_cast<const uint32_t *>(b) + e * NW;
+#pragma unroll
+        for (int j = 0; j < NW; j++) { x[j] = pa[j]; y[j] = pb[j]; }
+        if (mode == 0) {
+            bool ge = true;                                            // tmp.Cmp(boundHalf) >= 0
+#pragma unroll
+            for (int j = NW - 1; j >= 0; j--) { if (y[j] != bnd.r2[j]) { ge = y[j] > bnd.r2[j]; break; } }
+            if (ge) {                                                  // mask = tmp - bound mod p  =  p - (bound - tmp)   (bound - tmp in (0, bound / 2] < p)
+                uint32_t d[NW]; u64 br = 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) { u64 v = (u64)bnd.p[j] - y[j] - br; d[j] = (uint32_t)v; br = (v >> 32) & 1; }
+                br = 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) { u64 v = (u64)f.p[j] - d[j] - br; y[j] = (uint32_t)v; br = (v >> 32) & 1; }
+            }
+            if (mask_out) { uint32_t *pm = reinterpret_cast<uint32_t *>(mask_out) + e * NW;
+#pragma unroll
+                for (int j = 0; j < NW; j++) pm[j] = y[j]; }
+            // x - y mod p
+            u64 br = 0;
+#pragma unroll
+            for (int j = 0; j < NW; j++) { u64 v = (u64)x[j] - y[j] - br; r[j] = (uint32_t)v; br = (v >> 32) & 1; }
+            if (br) { u64 c = 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) { u64 v = (u64)r[j] + f.p[j] + c; r[j] = (uint32_t)v; c = v >> 32; } }
+        } else f_add<NW>(x, y, f, r);
+        uint32_t *po = reinterpret_cast<uint32_t *>(out) + e * NW;
+#pragma unroll
+        for (int j = 0; j < NW; j++) po[j] = r[j];
+    }
+}
+static int ss_share(sfg_ctx *ctx, int mode, int limbs, const uint64_t *mod, const uint64_t *bound, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t *mask_out, size_t n) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!n) return 0;
+    FieldConst f; SFG_TRY(field_setup(ctx, limbs, mod, f));
+    FieldConst bd; memset(&bd, 0, sizeof bd);
+    if (mode == 0) {
+        if (!bound) SFG_FAIL(ctx, "ss_share: no bound");
+        for (int j = 0; j < limbs; j++) { bd.p[2 * j] = (uint32_t)bound[j]; bd.p[2 * j + 1] = (uint32_t)(bound[j] >> 32); }
+        for (int j = 0; j < limbs; j++) { const uint64_t h = (bound[j] >> 1) | (j + 1 < limbs ? bound[j + 1] << 63 : 0); bd.r2[2 * j] = (uint32_t)h; bd.r2[2 * j + 1] = (uint32_t)(h >> 32); }
+        for (int j = limbs - 1; j >= 0; j--) { if (bound[j] != mod[j]) { if (bound[j] > mod[j]) SFG_FAIL(ctx, "ss_share: bound exceeds the field modulus"); break; } }
+    }
+    size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (limbs == 2) hipLaunchKernelGGL(k_ss_share<4>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mode, f, bd, a, b, out, mask_out, n);
+    else hipLaunchKernelGGL(k_ss_share<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, mode, f, bd, a, b, out, mask_out, n);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+extern "C" int sfg_ss_mask_dev(sfg_ctx *ctx, int limbs, const uint64_t *modulus_host, const uint64_t *bound_host, const uint64_t *rm_dev, const uint64_t *rand_dev,
+                               uint64_t *rm_masked_dev, uint64_t *mask_dev, size_t n) {
+    return ss_share(ctx, 0, limbs, modulus_host, bound_host, rm_dev, rand_dev, rm_masked_dev, mask_dev, n);
+}
+extern "C" int sfg_ss_hub_share_dev(sfg_ctx *ctx, int limbs, const uint64_t *modulus_host, const uint64_t *revealed_dev, const uint64_t *mask_dev, uint64_t *share_dev, size_t n) {
+    return ss_share(ctx, 1, limbs, modulus_host, nullptr, revealed_dev, mask_dev, share_dev, nullptr, n);
+}

@@ -126,6 +126,8 @@ def lib():
         L.orc_diagcache_close.argtypes = [C.c_void_p]
         L.orc_beaver_elem.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_size_t]
         L.orc_beaver_matmul.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int, C.c_int, C.c_int]
+        L.orc_ss_mask.argtypes = [C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_size_t]
+        L.orc_ss_hub_share.argtypes = [C.c_int, u64p, u64p, u64p, u64p, C.c_size_t]
         L.orc_bigint_to_rns.argtypes = [C.c_void_p, C.c_int, u64p, C.c_int, u64p]
         L.orc_refresh_gen_shares.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, u64p]
         L.orc_refresh_finish.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p, u64p]

@@ -46,6 +46,43 @@ def test_beaver_elem_matches_oracle_and_bigint(ctx, limbs, p, pid):
         assert sum(int(got[i, k]) << (64 * k) for k in range(limbs)) == e
 
 
+@pytest.mark.parametrize("limbs,p,nparty", [(2, (1 << 127) - 1, 3), (4, (1 << 255) - 19, 3), (4, (1 << 255) - 19, 2), (2, (1 << 127) - 735, 4)])
+def test_ss_to_cmat_share_algebra_matches_oracle_and_bigint(ctx, limbs, p, nparty):
+    """mpc/ss.go:84-110 (SSToCMat): mask recentring around bound = p / (4 (nParty - 1)), rm - mask, and the hub's revealed + mask - the device kernel vs the
+    oracle and vs Python integers, with draws at 0, bound / 2 - 1, bound / 2 and bound - 1"""
+    from sfgwas_amd import capi
+    rnd = random.Random(limbs * 100 + nparty)
+    n = 4000
+    bound = p // (4 * (nparty - 1))
+    half = bound >> 1
+    rm = [rnd.randrange(p) for _ in range(n)]
+    tmp = [rnd.randrange(bound) for _ in range(n)]
+    tmp[:4] = [0, half - 1, half, bound - 1]
+    rm[:4] = [0, p - 1, 5, half]
+    A = lambda v: np.array([_limbs(x, limbs) for x in v], dtype=np.uint64)
+    mod, bnd = np.array(_limbs(p, limbs), dtype=np.uint64), np.array(_limbs(bound, limbs), dtype=np.uint64)
+    d_rm, d_tmp = ctx.to_device(A(rm)), ctx.to_device(A(tmp))
+    d_out, d_mask, d_share = ctx.malloc(n * limbs * 8), ctx.malloc(n * limbs * 8), ctx.malloc(n * limbs * 8)
+    ctx.check(capi.lib().sfg_ss_mask_dev(ctx.h, limbs, capi.p64(mod), capi.p64(bnd), d_rm, d_tmp, d_out, d_mask, n), "ss_mask")
+    got_masked, got_mask = ctx.to_host(d_out, (n, limbs), np.uint64), ctx.to_host(d_mask, (n, limbs), np.uint64)
+    w_masked, w_mask = np.zeros((n, limbs), dtype=np.uint64), np.zeros((n, limbs), dtype=np.uint64)
+    ol.lib().orc_ss_mask(limbs, ol.p64(mod), ol.p64(bnd), ol.p64(A(rm)), ol.p64(A(tmp)), ol.p64(w_masked), ol.p64(w_mask), n)
+    assert np.array_equal(got_masked, w_masked) and np.array_equal(got_mask, w_mask)
+    val = lambda row: sum(int(row[k]) << (64 * k) for k in range(limbs))
+    for i in list(range(8)) + list(range(8, n, 131)):
+        m = (tmp[i] - bound) % p if tmp[i] >= half else tmp[i]
+        assert val(got_mask[i]) == m and val(got_masked[i]) == (rm[i] - m) % p
+    # hub: share = revealed + mask; with revealed = rm - mask the hub's share is rm again
+    ctx.check(capi.lib().sfg_ss_hub_share_dev(ctx.h, limbs, capi.p64(mod), d_out, d_mask, d_share, n), "ss_hub_share")
+    share = ctx.to_host(d_share, (n, limbs), np.uint64)
+    assert np.array_equal(share, A(rm))
+    w_share = np.zeros((n, limbs), dtype=np.uint64)
+    ol.lib().orc_ss_hub_share(limbs, ol.p64(mod), ol.p64(w_masked), ol.p64(w_mask), ol.p64(w_share), n)
+    assert np.array_equal(share, w_share)
+    for q in (d_rm, d_tmp, d_out, d_mask, d_share):
+        ctx.free(q)
+
+
 @pytest.mark.parametrize("pid", [0, 1, 2])
 def test_beaver_matmul(ctx, pid):
     from sfgwas_amd import capi
