@@ -393,6 +393,8 @@ def main():
         dt = float(t.item())
 
     near_ties = ctx.encoder_near_ties()                    # rounding audit of every encode since context creation (gate, warm-up, timed steps)
+    unprovable = C.c_ulonglong()
+    chk(lib.sfg_ctx_encoder_unprovable(ctx.h, C.byref(unprovable)), "encoder_unprovable")
     # ---- output digests, outside the timed region: SHA-256 over the per-ciphertext SHA-256s in global [i][j] order
     digests = None
     if not args.no_digest:
@@ -449,8 +451,9 @@ def main():
             res["parity_gate"] = gate
         if digests is not None:
             res["digests"] = digests
-        res["encoder_near_ties"] = {"count": near_ties, "what": "encoder coefficients within 2^-40 of a rounding tie on rank 0 (0 = every plaintext provably "
-                                                                 "rounded as the reference's 256-bit EncoderBig rounds it)"}
+        res["encoder_near_ties"] = {"count": near_ties, "within_2^-50": unprovable.value, "what": "encoder coefficients within 2^-40 of a rounding tie on rank 0 (0 = every plaintext provably "
+                                                                 "rounded as the reference's 256-bit EncoderBig rounds it); a non-zero within_2^-50 count makes the library's synchronising entry points fail "
+                                                                 "(about once per 10^15 coefficients; 2 x 10^11 per step here)"}
         # ---- roofline of the dominant kernel (k_mac_dma, small-modulus instance)
         ms_small, n_small, by_small = phase_tot.get("mac_small", [0.0, 0, 0.0])
         if n_small:

@@ -104,6 +104,8 @@ int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, in
  * 10^15) is NOT tolerated: every synchronising entry point fails until the counters are reset, and the affected products must be re-derived with a
  * big-float encoder on the host. */
 int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset);
+/* the coefficients within 2^-50 of a tie seen since the last reset (the condition that makes the synchronising entry points fail) */
+int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *count);
 /* test hook for the failure path above: marks n coefficients as too close to a tie */
 int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n);
 /* crypto.EncodeFloatVector (crypto.go:398-420; behind Mask / MaskTrunc / MaskWithScaling, basics.go:110-172, and

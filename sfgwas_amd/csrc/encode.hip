@@ -623,6 +623,13 @@ int sfg_encoder_check(sfg_ctx *ctx) {
                             "EncoderBig rounds; re-derive the products of this context since the last reset with a big-float encoder (sfg_ctx_encoder_near_ties resets)", c[1]);
     return 0;
 }
+// the sticky 2^-50 counter behind sfg_encoder_check (not reset)
+extern "C" int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *count) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFG_HIP(ctx, hipMemcpy(count, (unsigned long long *)ctx->tie_count_dev + 1, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n) {      // test hook: pretend n such coefficients were seen
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long c[2] = {0, n};
