@@ -306,8 +306,8 @@ template <bool BIG, int ROWS> static int bc_set_attr(sfg_ctx *ctx) {
     return 0;
 }
 int mac_bc_set_attrs(sfg_ctx *ctx) {
-    SFG_TRY((bc_set_attr<false, 30>(ctx))); SFG_TRY((bc_set_attr<false, 16>(ctx))); SFG_TRY((bc_set_attr<false, 4>(ctx)));
-    SFG_TRY((bc_set_attr<true, 30>(ctx))); SFG_TRY((bc_set_attr<true, 16>(ctx))); SFG_TRY((bc_set_attr<true, 4>(ctx)));
+    SFG_TRY((bc_set_attr<false, 30>(ctx))); SFG_TRY((bc_set_attr<false, 26>(ctx))); SFG_TRY((bc_set_attr<false, 16>(ctx))); SFG_TRY((bc_set_attr<false, 10>(ctx))); SFG_TRY((bc_set_attr<false, 4>(ctx)));
+    SFG_TRY((bc_set_attr<true, 30>(ctx))); SFG_TRY((bc_set_attr<true, 26>(ctx))); SFG_TRY((bc_set_attr<true, 16>(ctx))); SFG_TRY((bc_set_attr<true, 10>(ctx))); SFG_TRY((bc_set_attr<true, 4>(ctx)));
     return 0;
 }
 template <bool BIG, int ROWS> static void bc_launch(sfg_ctx *ctx, dim3 grid, const BcArgs &a) {
@@ -352,8 +352,11 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
             const int nslab = (st.pt_half ? N / BC_CL / 2 : N / BC_CL) * a.nl, ngrp = (nslab + 7) / 8;
             dim3 grid((unsigned)(ngrp * 8 * a.ntile * (st.pt_half ? 2 : 1)));
             PhaseTimer t(ctx, big ? "mac_big" : "mac_small");
-            if (big) { if (rows > 16) bc_launch<true, 30>(ctx, grid, a); else if (rows > 4) bc_launch<true, 16>(ctx, grid, a); else bc_launch<true, 4>(ctx, grid, a); }
-            else { if (rows > 16) bc_launch<false, 30>(ctx, grid, a); else if (rows > 4) bc_launch<false, 16>(ctx, grid, a); else bc_launch<false, 4>(ctx, grid, a); }
+            // row-count instances: 30 (kp = 15, PCA), 26 (s = 13 = ncov + 1 + npc + 2: the association scan's concat, assoc.go:699-704), 16, 10 (s = ncov = 5, gWY), 4 (s <= 2)
+            if (big) { if (rows > 26) bc_launch<true, 30>(ctx, grid, a); else if (rows > 16) bc_launch<true, 26>(ctx, grid, a); else if (rows > 10) bc_launch<true, 16>(ctx, grid, a);
+                       else if (rows > 4) bc_launch<true, 10>(ctx, grid, a); else bc_launch<true, 4>(ctx, grid, a); }
+            else { if (rows > 26) bc_launch<false, 30>(ctx, grid, a); else if (rows > 16) bc_launch<false, 26>(ctx, grid, a); else if (rows > 10) bc_launch<false, 16>(ctx, grid, a);
+                   else if (rows > 4) bc_launch<false, 10>(ctx, grid, a); else bc_launch<false, 4>(ctx, grid, a); }
             SFG_HIP(ctx, hipGetLastError());
             {   // algorithmic bytes of this launch (as launch_mac_dma): fp64 rot operand + plaintext words + accumulators written (and read when accumulating)
                 const double nlm = (double)(e - l), rw = big ? 2.0 : 1.0, pw = st.pt_half ? 0.5 : 1.0;

@@ -48,7 +48,7 @@ def rand_rows(rnd, shape_prefix, L, moduli, N):
     return a
 
 
-@pytest.mark.parametrize("K,R,Ncols,L", [(20, 6, 5, 5), (9, 30, 33, 5), (3, 32, 2, 2), (1, 1, 1, 1), (91, 4, 3, 6)])
+@pytest.mark.parametrize("K,R,Ncols,L", [(20, 6, 5, 5), (9, 30, 33, 5), (3, 32, 2, 2), (1, 1, 1, 1), (91, 4, 3, 6), (37, 26, 7, 5), (13, 10, 3, 5), (6, 22, 35, 5), (5, 17, 2, 6)])
 def test_mac_random_bit_exact(env, K, R, Ncols, L):
     ctx = env
     rnd = np.random.default_rng(K * 1000 + R)
