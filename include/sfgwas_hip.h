@@ -213,7 +213,10 @@ int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_l
 /* MatMult4StreamCompute on the reference's OWN on-disk cache (matmult.go:1043-1236 reading the DiagCache files that
  * MatMult4StreamPreprocess of a CPU party wrote, filestream.go:19-282): files <prefix>_<bi>.bin for bi < nbr hold NTT + Montgomery-form
  * plaintexts as big-endian words; they are streamed, converted on the device and multiplied without re-encoding.  out: s x vectorLen
- * ciphertexts, as sfg_matmul_resident_dev.  Fails like the reference when a file is missing (os.Open panics, filestream.go:59-61). */
+ * ciphertexts, as sfg_matmul_resident_dev.  Fails like the reference when a file is missing (os.Open panics, filestream.go:59-61).
+ * Header fields are validated against the ring and the file size before anything is allocated.  Records are expected in the order
+ * MatMult4StreamPreprocess writes them (increasing shift, matmult.go:1001-1035): the records of one giant step then form ONE MAC launch; any
+ * other order still gives the right sums, at one upload + launch per change of giant step. */
 int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, const char *cache_prefix, int nbr, uint64_t *out_dev);
 /* header of <prefix>_<block_row>.bin: {vectorLen (= block columns), level, scale (f64 bits), n, numModuli, rowSize} */
 int sfg_diagcache_header(sfg_ctx *ctx, const char *cache_prefix, int block_row, uint64_t hdr[6]);
