@@ -291,7 +291,7 @@ def main():
     cache_buf = torch.empty(max(cache1_w, cache2_w, 1), dtype=torch.float64, device=dev)        # cache1 (Q*X) and cache2 (Q'*X^T) are never live together
     staged_mine = torch.zeros(jpr * jobw if shard_rotcache else 1, dtype=torch.float64, device=dev)
     # one buffer for the gathered staging (Q*X) and the accumulators (Q'*X^T): never live together
-    acc_w = 2 * colp if pipe_cols else (nbr_x * D + (world * gpr - D)) * KP * outw
+    acc_w = 2 * colp if pipe_cols else ((nbr_x * D + (world * gpr - D)) * KP * outw if use_dist else 8)
     big = torch.zeros(max(world * jpr * jobw if shard_rotcache else 0, acc_w) * 8, dtype=torch.uint8, device=dev)
     staged_all = big.view(torch.float64)[: world * jpr * jobw] if shard_rotcache else None
     acc2 = big.view(torch.int64)[:acc_w]
@@ -335,10 +335,8 @@ def main():
         mark("QX product (encode + MAC + giant-step alignment)")
         # (2) Q' * X^T : contraction over this rank's SNP blocks, combined before the giant steps
         lib.sfg_ctx_clear_phases(ctx.h)
-        if not use_dist:
-            chk(lib.sfg_matmul_accumulate_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP, LEVEL, L, gh, capi.SFG_TRANSPOSE,
-                                              0, nblk_loc, 0, nbr_x, 0, C.c_void_p(acc2.data_ptr())), "Q'*X^T accumulate")
-            chk(lib.sfg_matmul_finalize_dev(ctx.h, C.c_void_p(acc2.data_ptr()), KP, L, nbr_x, 0, D, 0, C.c_void_p(out2.data_ptr())), "finalize")
+        if not use_dist:                                # one rank: the one-shot product (the library's own accumulators; tests/test_gpu_properties.py: = accumulate + finalize)
+            chk(lib.sfg_matmul_resident_dev(ctx.h, C.c_void_p(A2.data_ptr()), KP, LEVEL, L, gh, capi.SFG_TRANSPOSE, C.c_void_p(out2.data_ptr())), "Q'*X^T")
             add_phases()
             return
         if pipe_cols:

@@ -46,6 +46,7 @@ struct SfgConfig {
     bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
+    bool mm_group_auto = true;     //                       (unset) 16 block rows per launch when the plaintext panel and the rotation operands of such a group fit the free HBM, else 8
     size_t acc_budget = 24ULL << 30;   // SFG_MM_ACC_BUDGET_MB
     bool no_overlap = false;       // SFG_MM_NO_OVERLAP     single queue
     bool ntt_fwd_full = false;     // SFG_NTT_FWD_IMPL=full   one 512-thread workgroup per row for the general forward NTT (instead of two half-row workgroups)

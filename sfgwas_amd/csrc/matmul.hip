@@ -259,8 +259,28 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // G block rows share one MAC launch (K = G*91): accumulators are written once per group instead of
     // read-modify-written per block.  Bounded by scratch: ~4.9 GB per block row at s = 15.
     int G = 1;
-    if (dma) { G = ctx->cfg.mm_group; if (G > b1 - b0) G = b1 - b0; }
     const size_t nplain = (size_t)d * d;                     // 8281 >= 8192 slots per block row: the tail stays zero
+    if (dma) {
+        G = ctx->cfg.mm_group;
+        // 16 (24) block rows per launch halve (third) the accumulator read-modify-writes and the per-launch prologues (16: -1.7 % at 100k x 1M, identical bits) but
+        // need a 43 (65) GB plaintext panel and, for the pipelined rotation caches, 2 x 34.5 (52) GB of operands: taken only when that fits beside what is resident
+        if (ctx->cfg.mm_group_auto && b1 - b0 > G) {
+            std::vector<int> po, ib; const int npl = mac_dma_planes(ctx, L, po, ib);
+            size_t have = 0, total = 0;
+            if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
+                for (const char *nm : {"mm.pt", "mm.rotf"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
+                for (int cand : {24, 16}) {
+                    const int G2 = std::min(cand, b1 - b0);
+                    if (G2 <= G) break;
+                    const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
+                    size_t need = (size_t)G2 * nplain * L * ((size_t)N / 2) * 8;
+                    if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
+                    if (need + (12ULL << 30) <= have) { G = G2; break; }
+                }
+            }
+        }
+        if (G > b1 - b0) G = b1 - b0;
+    }
     u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr, *rotsum = nullptr; size_t rowf = 0;
     const unsigned packed_mask = dma ? mac_dma_packed_mask(ctx, L) : 0u;      // small-modulus plaintext rows in the packed-limb format
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
