@@ -97,3 +97,12 @@ def test_collectives_path_at_world_size_1_over_rccl_matches_the_plain_path(plain
     got = bench_line("c3", 1, "nccl", None, force_coll=True)
     assert got["config"]["collectives"] == "RCCL"
     same(plain("c3"), got, "c3, forced collectives at world size 1")
+
+
+def test_pipelined_and_sharded_sequences_over_rccl_at_world_size_1(plain):
+    """the round-3 additions over the real transport: all_gather_into_tensor of the sharded rotation cache and the ASYNC per-column reduce-scatters
+    (RCCL's own stream, work.wait() before a column buffer is reused) with one rank, 10 000 x 100 000"""
+    got = bench_line("c2", 1, "nccl", {"SFG_BENCH_ROTCACHE": "sharded"}, force_coll=True)
+    assert got["config"]["collectives"] == "RCCL" and got["config"]["rotation_cache_QX"].startswith("sharded")
+    assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
+    same(plain("c2"), got, "c2, forced RCCL collectives, sharded cache, pipelined reduce-scatter")
