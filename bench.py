@@ -474,6 +474,11 @@ def main():
                         ks = [k for k in pm if k.startswith("void k_mac_bc<false") or k.startswith("void k_mac_dma<false")]
                         best = max(ks, key=lambda k: pm[k]["launches"])
                         traffic, traffic_src = pm[best]["hbm_bytes_per_launch"], f"profiles/{name} (static: separate --pmc passes, not measured in this run)"
+                        ref_alg = pm.get("_alg_bytes_per_launch_at_measurement")
+                        if ref_alg:      # the passes ran at another launch size (SFG_MM_GROUP): same over-fetch ratio, this run's bytes per launch
+                            traffic *= (by_small / n_small) / ref_alg
+                            traffic_src += f"; measured at SFG_MM_GROUP={pm.get('_mm_group')} ({pm[best]['hbm_bytes_per_launch'] / ref_alg:.3f} x the algorithmic bytes) and scaled to this run's launch size"
+
                         break
             except Exception:
                 pass
