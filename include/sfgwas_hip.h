@@ -244,6 +244,12 @@ int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, 
 int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
                    const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                    uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
+/* ... and straight from the .pgen on disk (config 5: 10 M SNPs per party, the file does not fit host memory as one image): the header tables are read once,
+ * every batch is the contiguous byte range of its variant records (plus the LD base its first records may need), read ahead by a reader thread into pinned
+ * memory (SFG_STREAM_DIRECT: O_DIRECT) while the GPU works on the previous batch.  Sample and variant counts come from the file's header. */
+int sfg_assoc_stream_pgen(sfg_ctx *ctx, const char *pgen_path, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
+                          const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                          uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
 /* sharding hooks for one-process-per-GPU runs: restrict a resident product to block columns
  * [j0, j1) of the output (X: SNP-column blocks) or block rows [b0, b1) of the contraction (X^T) */
 int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level,

@@ -46,6 +46,7 @@ def _sig(L):
         "sfg_geno_pack": (i, [vp, vp, C.POINTER(vp)]),
         "sfg_geno_unpack": (i, [vp, vp, C.POINTER(vp)]),
         "sfg_assoc_stream_bed": (i, [vp, C.c_char_p, sz, sz, vp, vp, sz, vp, i, i, i, C.c_uint, vp, sz, C.POINTER(sz), vp, vp]),
+        "sfg_assoc_stream_pgen": (i, [vp, C.c_char_p, vp, vp, sz, vp, i, i, i, C.c_uint, vp, sz, C.POINTER(sz), vp, vp]),
         "sfg_assoc_pgen": (i, [vp, vp, sz, vp, vp, sz, vp, i, i, i, C.c_uint, vp, sz, C.POINTER(sz), vp, vp]),
         "sfg_ctx_has_rotkey": (i, [vp, u64]),
         "sfg_ctx_export_rotkey": (i, [vp, u64, u64p]),

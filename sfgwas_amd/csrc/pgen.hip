@@ -16,9 +16,27 @@
 #include "kernels.hpp"
 #include <algorithm>
 
-struct PgenIndex { uint32_t nv = 0, ns = 0; std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint8_t> vrt; };
+#include "pgen.hpp"
 
-static int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, PgenIndex &ix) {
+// bytes of the header (magic .. end of the per-block tables) from the first 12 bytes of a file; 0 = not a supported .pgen
+size_t pgen_header_bytes(const uint8_t *f12) {
+    if (f12[0] != 0x6C || f12[1] != 0x1B) return 0;
+    if (f12[2] == 0x02) return 12;
+    if (f12[2] != 0x10) return 0;
+    const uint64_t nv = (uint64_t)f12[3] | (uint64_t)f12[4] << 8 | (uint64_t)f12[5] << 16 | (uint64_t)f12[6] << 24;
+    const unsigned ctrl = f12[11], wmode = ctrl & 15, ac_bytes = (ctrl >> 4) & 3, nonref = ctrl >> 6;
+    if (wmode > 7) return 0;
+    const unsigned vbits = wmode < 4 ? 4 : 8, lb = (wmode & 3) + 1;
+    const uint64_t nblk = (nv + 65535) / 65536;
+    size_t p = 12 + 8 * nblk;
+    for (uint64_t b = 0; b < nblk; b++) {
+        const uint64_t cnt = std::min<uint64_t>(65536, nv - b * 65536);
+        p += (vbits == 4 ? (cnt + 1) / 2 : cnt) + cnt * lb + cnt * ac_bytes + (nonref == 3 ? (cnt + 7) / 8 : 0);
+    }
+    return p;
+}
+// f: at least the header bytes (`bytes` of them are readable); file_bytes: the size of the whole file, against which the record table is validated
+int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, size_t file_bytes, PgenIndex &ix) {
     if (!f || bytes < 12 || f[0] != 0x6C || f[1] != 0x1B) SFG_FAIL(ctx, "pgen: not a PLINK 2 .pgen (bad magic)");
     auto u32 = [&](size_t p) { return (uint32_t)f[p] | (uint32_t)f[p + 1] << 8 | (uint32_t)f[p + 2] << 16 | (uint32_t)f[p + 3] << 24; };
     ix.nv = u32(3); ix.ns = u32(7);
@@ -26,7 +44,7 @@ static int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, PgenIndex &i
     ix.off.resize(ix.nv); ix.len.resize(ix.nv); ix.vrt.resize(ix.nv);
     if (f[2] == 0x02) {
         const uint64_t bps = ((uint64_t)ix.ns + 3) / 4;
-        if (bytes < 12 + (uint64_t)ix.nv * bps) SFG_FAIL(ctx, "pgen: truncated fixed-width file");
+        if (file_bytes < 12 + (uint64_t)ix.nv * bps) SFG_FAIL(ctx, "pgen: truncated fixed-width file");
         for (uint32_t v = 0; v < ix.nv; v++) { ix.off[v] = 12 + (uint64_t)v * bps; ix.len[v] = (uint32_t)bps; ix.vrt[v] = 0; }
         return 0;
     }
@@ -49,7 +67,7 @@ static int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, PgenIndex &i
         for (uint32_t k = 0; k < cnt; k++) {
             uint32_t x = 0; for (unsigned j = 0; j < lb; j++) x |= (uint32_t)f[p + (size_t)k * lb + j] << (8 * j);
             ix.len[v0 + k] = x; ix.off[v0 + k] = cur; cur += x;
-            if (cur > bytes) SFG_FAIL(ctx, "pgen: record %u runs past the end of the file", v0 + k);
+            if (cur > file_bytes) SFG_FAIL(ctx, "pgen: record %u runs past the end of the file", v0 + k);
         }
         p += (size_t)cnt * lb + (size_t)cnt * ac_bytes;
         if (nonref == 3) p += (cnt + 7) / 8;
@@ -178,50 +196,77 @@ __global__ void __launch_bounds__(256) k_pgen_counts(const uint8_t *rows, size_t
 int launch_bed_decode_lut(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
                           int8_t *out, size_t ld, unsigned lut);
 
-// decodes variants [v0, v1) (plus, in front, the LD base the first of them may need) into device rows; returns the rows of [v0, v1)
-struct PgenRows { uint8_t *buf = nullptr; uint8_t *rows = nullptr; size_t pitch = 0; };
-static int pgen_decode_window(sfg_ctx *ctx, const uint8_t *f, size_t bytes, const PgenIndex &ix, size_t v0, size_t v1, PgenRows &out) {
+// the variants a window [v0, v1) needs on the device: [start, v1) with start <= v0 the LD base of the first ones; record offsets relative to the window's
+// first byte f0, LD-base row per record
+int pgen_window(sfg_ctx *ctx, const PgenIndex &ix, size_t file_bytes, size_t v0, size_t v1, PgenWindow &w) {
     if (v0 >= v1 || v1 > ix.nv) SFG_FAIL(ctx, "pgen: variant range [%zu, %zu) out of bounds (%u variants)", v0, v1, ix.nv);
     size_t start = v0;
     while (start > 0 && (ix.vrt[start] & 6) == 2) start--;
     if ((ix.vrt[start] & 6) == 2) SFG_FAIL(ctx, "pgen: the first variant is LD-compressed");
-    const size_t nr = v1 - start, pitch = ((((size_t)ix.ns + 3) / 4) + 3) & ~(size_t)3;
-    const uint64_t f0 = ix.off[start], f1 = ix.off[v1 - 1] + ix.len[v1 - 1];
-    if (f1 > bytes || f0 > f1) SFG_FAIL(ctx, "pgen: record table inconsistent with the file size");
-    std::vector<uint64_t> off(nr); std::vector<uint32_t> ldb(nr, 0xFFFFFFFFu); uint32_t last = 0;
-    for (size_t r = 0; r < nr; r++) {
-        off[r] = ix.off[start + r] - f0;
-        if ((ix.vrt[start + r] & 6) == 2) ldb[r] = last; else last = (uint32_t)r;
+    w.start = start; w.nr = v1 - start; w.lead = v0 - start;
+    w.f0 = ix.off[start]; w.f1 = ix.off[v1 - 1] + ix.len[v1 - 1];
+    if (w.f1 > file_bytes || w.f0 > w.f1) SFG_FAIL(ctx, "pgen: record table inconsistent with the file size");
+    w.off.resize(w.nr); w.ldb.assign(w.nr, 0xFFFFFFFFu); uint32_t last = 0;
+    for (size_t r = 0; r < w.nr; r++) {
+        w.off[r] = ix.off[start + r] - w.f0;
+        if ((ix.vrt[start + r] & 6) == 2) w.ldb[r] = last; else last = (uint32_t)r;
     }
-    // one allocation: rows | file bytes | off | len | vrt | ldbase | err
-    const size_t fb = (size_t)(f1 - f0);
+    return 0;
+}
+size_t pgen_pitch(const PgenIndex &ix) { return ((((size_t)ix.ns + 3) / 4) + 3) & ~(size_t)3; }
+// descriptor block of a window on the device: off | len | vrt | ldbase | err, `bytes` = pgen_desc_bytes(nr)
+size_t pgen_desc_bytes(size_t nr) { auto al = [](size_t x) { return (x + 255) & ~(size_t)255; }; return al(nr * 8) + al(nr * 4) + al(nr) + al(nr * 4) + 256; }
+int pgen_upload_desc(sfg_ctx *ctx, hipStream_t st, const PgenIndex &ix, const PgenWindow &w, uint8_t *desc) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_file = al(nr * pitch), o_off = o_file + al(fb + 8), o_len = o_off + al(nr * 8), o_vrt = o_len + al(nr * 4), o_ldb = o_vrt + al(nr), o_err = o_ldb + al(nr * 4);
+    const size_t nr = w.nr, o_len = al(nr * 8), o_vrt = o_len + al(nr * 4), o_ldb = o_vrt + al(nr), o_err = o_ldb + al(nr * 4);
+    SFG_HIP(ctx, hipMemcpyAsync(desc, w.off.data(), nr * 8, hipMemcpyHostToDevice, st));
+    SFG_HIP(ctx, hipMemcpyAsync(desc + o_len, ix.len.data() + w.start, nr * 4, hipMemcpyHostToDevice, st));
+    SFG_HIP(ctx, hipMemcpyAsync(desc + o_vrt, ix.vrt.data() + w.start, nr, hipMemcpyHostToDevice, st));
+    SFG_HIP(ctx, hipMemcpyAsync(desc + o_ldb, w.ldb.data(), nr * 4, hipMemcpyHostToDevice, st));
+    SFG_HIP(ctx, hipMemsetAsync(desc + o_err, 0, 4, st));
+    return 0;
+}
+// the two decode passes of a window whose bytes and descriptors are on the device; rows: [nr][pitch].  *err_dev (returned) holds the error flags afterwards
+int launch_pgen_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *file_dev, const uint8_t *desc, size_t nr, uint32_t ns, size_t pitch, uint8_t *rows, const int **err_dev) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_len = al(nr * 8), o_vrt = o_len + al(nr * 4), o_ldb = o_vrt + al(nr), o_err = o_ldb + al(nr * 4);
+    for (int pass = 0; pass < 2; pass++) {
+        hipLaunchKernelGGL(k_pgen_decode, dim3((unsigned)nr), dim3(256), 0, st, file_dev, (const uint64_t *)desc, (const uint32_t *)(desc + o_len), desc + o_vrt,
+                           (const uint32_t *)(desc + o_ldb), ns, pitch, rows, pass, (int *)(desc + o_err));
+        SFG_HIP(ctx, hipGetLastError());
+    }
+    if (err_dev) *err_dev = (const int *)(desc + o_err);
+    return 0;
+}
+int pgen_decode_error(sfg_ctx *ctx, int herr) {
+    if (!herr) return 0;
+    if (herr & PGEN_ERR_MULTIALLELIC) SFG_FAIL(ctx, "pgen: multiallelic hard calls present (plink2 --make-bed refuses them as well; split them first)");
+    if (herr & PGEN_ERR_TYPE) SFG_FAIL(ctx, "pgen: record type 5 is not defined by the PGEN specification");
+    SFG_FAIL(ctx, "pgen: malformed variant record");
+}
+
+// decodes variants [v0, v1) of a file image in host memory into device rows; returns the rows of [v0, v1)
+struct PgenRows { uint8_t *buf = nullptr; uint8_t *rows = nullptr; size_t pitch = 0; };
+static int pgen_decode_window(sfg_ctx *ctx, const uint8_t *f, size_t bytes, const PgenIndex &ix, size_t v0, size_t v1, PgenRows &out) {
+    PgenWindow w; SFG_TRY(pgen_window(ctx, ix, bytes, v0, v1, w));
+    const size_t pitch = pgen_pitch(ix), fb = (size_t)(w.f1 - w.f0);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_file = al(w.nr * pitch), o_desc = o_file + al(fb + 8);            // one allocation: rows | file bytes | descriptors
     uint8_t *d = nullptr;
-    SFG_HIP(ctx, hipMalloc(&d, o_err + 256));
-    int rc = 0, herr = 0;
-    auto cp = [&](size_t o, const void *src, size_t n) { if (!rc && n && hipMemcpyAsync(d + o, src, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1; };
-    cp(o_file, f + f0, fb); cp(o_off, off.data(), nr * 8); cp(o_len, ix.len.data() + start, nr * 4); cp(o_vrt, ix.vrt.data() + start, nr); cp(o_ldb, ldb.data(), nr * 4);
-    if (!rc && hipMemsetAsync(d + o_err, 0, 4, ctx->stream) != hipSuccess) rc = 1;
-    for (int pass = 0; pass < 2 && !rc; pass++) {
-        hipLaunchKernelGGL(k_pgen_decode, dim3((unsigned)nr), dim3(256), 0, ctx->stream, d + o_file, (const uint64_t *)(d + o_off), (const uint32_t *)(d + o_len), d + o_vrt,
-                           (const uint32_t *)(d + o_ldb), ix.ns, pitch, d, pass, (int *)(d + o_err));
-        if (hipGetLastError() != hipSuccess) rc = 1;
-    }
-    if (!rc && (hipMemcpyAsync(&herr, d + o_err, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = 1;   // the host vectors are done with, too
-    if (rc) { (void)hipFree(d); SFG_FAIL(ctx, "pgen: device decode failed to launch"); }
-    if (herr) {
-        (void)hipFree(d);
-        if (herr & PGEN_ERR_MULTIALLELIC) SFG_FAIL(ctx, "pgen: multiallelic hard calls present (plink2 --make-bed refuses them as well; split them first)");
-        if (herr & PGEN_ERR_TYPE) SFG_FAIL(ctx, "pgen: record type 5 is not defined by the PGEN specification");
-        SFG_FAIL(ctx, "pgen: malformed variant record");
-    }
-    out.buf = d; out.rows = d + (v0 - start) * pitch; out.pitch = pitch;
+    SFG_HIP(ctx, hipMalloc(&d, o_desc + pgen_desc_bytes(w.nr)));
+    int rc = 0, herr = 0; const int *err_dev = nullptr;
+    if (hipMemcpyAsync(d + o_file, f + w.f0, fb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
+    if (!rc) rc = pgen_upload_desc(ctx, ctx->stream, ix, w, d + o_desc);
+    if (!rc) rc = launch_pgen_decode(ctx, ctx->stream, d + o_file, d + o_desc, w.nr, ix.ns, pitch, d, &err_dev);
+    if (!rc && (hipMemcpyAsync(&herr, err_dev, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = 1;   // the host vectors are done with, too
+    if (rc) { (void)hipFree(d); if (ctx->err.empty()) ctx->err = "pgen: device decode failed to launch"; return 1; }
+    if (pgen_decode_error(ctx, herr)) { (void)hipFree(d); return 1; }
+    out.buf = d; out.rows = d + w.lead * pitch; out.pitch = pitch;
     return 0;
 }
 
 extern "C" int sfg_pgen_dims(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, size_t *num_sample, size_t *num_variant) {
-    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, ix));
+    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, pgen_bytes, ix));
     if (num_sample) *num_sample = ix.ns;
     if (num_variant) *num_variant = ix.nv;
     return 0;
@@ -241,7 +286,7 @@ static int make_map32(sfg_ctx *ctx, const uint8_t *filt, size_t n, int32_t **dev
 extern "C" int sfg_geno_from_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, size_t v0, size_t v1,
                                   const uint8_t *row_filter, const uint8_t *col_filter, sfg_geno **out) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, ix));
+    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, pgen_bytes, ix));
     if (v1 == 0) v1 = ix.nv;                                       // [0, 0) = the whole file
     PgenRows rows; SFG_TRY(pgen_decode_window(ctx, pgen_host, pgen_bytes, ix, v0, v1, rows));
     int32_t *rmap = nullptr, *cmap = nullptr; size_t nr = 0, nc = 0; int8_t *d = nullptr;
@@ -259,7 +304,7 @@ extern "C" int sfg_geno_from_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t
 
 extern "C" int sfg_pgen_geno_counts(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, const uint8_t *row_filter, uint32_t *counts_host) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, ix));
+    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, pgen_bytes, ix));
     PgenRows rows; SFG_TRY(pgen_decode_window(ctx, pgen_host, pgen_bytes, ix, 0, ix.nv, rows));
     std::vector<unsigned> keep(rows.pitch / 4, 0u);
     for (uint32_t i = 0; i < ix.ns; i++) if (!row_filter || row_filter[i]) keep[i >> 4] |= 1u << (2 * (i & 15));
@@ -283,7 +328,7 @@ extern "C" int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pge
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (!batch_snps) SFG_FAIL(ctx, "assoc_pgen: bad batch size");
     if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_pgen: batches are multiplied as X (samples x SNPs)");
-    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, ix));
+    PgenIndex ix; SFG_TRY(pgen_index(ctx, pgen_host, pgen_bytes, pgen_bytes, ix));
     const size_t slots = SFG_SLOTS, N = SFG_N, ctw = (size_t)2 * max_level * N;
     struct B { size_t v0, v1, kept; };
     std::vector<B> bt; size_t start = 0, counter = 0;                     // assoc.go:371-416: a batch closes at batch_snps kept variants or at the end of the file

@@ -17,6 +17,7 @@
 // per-batch rebuild; a cache that exceeds the budget falls back to it).
 #include "common.hpp"
 #include "kernels.hpp"
+#include "pgen.hpp"
 #include <algorithm>
 #include <condition_variable>
 #include <cerrno>
@@ -29,9 +30,11 @@
 // genoio.hip
 int launch_bed_decode(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
                       int8_t *out, size_t ld);
+int launch_bed_decode_lut(sfg_ctx *ctx, hipStream_t st, const uint8_t *dbed, size_t bps, size_t num_sample, size_t num_snp, const int32_t *rmap, const int32_t *cmap,
+                          int8_t *out, size_t ld, unsigned lut);
 
 namespace {
-struct Batch { size_t snp0, nsnp, kept; };            // file SNPs [snp0, snp0 + nsnp), `kept` of them pass the filter
+struct Batch { size_t snp0, nsnp, kept; off_t off = 0; size_t bytes = 0; };            // file SNPs [snp0, snp0 + nsnp), `kept` of them pass the filter; their bytes in the file
 // assoc.go:371-416: a batch closes when `batch_snps` kept SNPs have been seen or the file ends with a non-empty batch
 std::vector<Batch> make_batches(const uint8_t *col_filter, size_t num_snp, size_t batch_snps) {
     std::vector<Batch> b; size_t start = 0, counter = 0;
@@ -42,17 +45,17 @@ std::vector<Batch> make_batches(const uint8_t *col_filter, size_t num_snp, size_
     return b;
 }
 struct Reader {                                        // fills pinned slot k & 1 with the bytes of batch k, one batch ahead of the consumer
-    int fd; size_t bps; const std::vector<Batch> *bt; uint8_t *slot[2];
+    int fd; const std::vector<Batch> *bt; uint8_t *slot[2];
     bool direct = false; size_t lead[2] = {0, 0};       // O_DIRECT: 4096-byte aligned file ranges; the batch starts `lead` bytes into its slot
     std::mutex mu; std::condition_variable cv; long filled = -1, released = -1; bool failed = false; std::string err;
     void run() {
         for (size_t k = 0; k < bt->size(); k++) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return (long)k - 2 <= released; }); }      // slot k & 1 was last used by batch k - 2
-            const Batch &b = (*bt)[k]; const off_t off = 3 + (off_t)(b.snp0 * bps), a0 = direct ? off & ~(off_t)4095 : off;
-            const size_t ld = (size_t)(off - a0), want = ld + b.nsnp * bps, want_al = direct ? (want + 4095) & ~(size_t)4095 : want; size_t got = 0;
+            const Batch &b = (*bt)[k]; const off_t off = b.off, a0 = direct ? off & ~(off_t)4095 : off;
+            const size_t ld = (size_t)(off - a0), want = ld + b.bytes, want_al = direct ? (want + 4095) & ~(size_t)4095 : want; size_t got = 0;
             while (got < want) {
                 ssize_t r = pread(fd, slot[k & 1] + got, want_al - got, a0 + (off_t)got);
-                if (r <= 0) { std::lock_guard<std::mutex> lk(mu); failed = true; err = "short read from the .bed file"; cv.notify_all(); return; }
+                if (r <= 0) { std::lock_guard<std::mutex> lk(mu); failed = true; err = "short read from the genotype file"; cv.notify_all(); return; }
                 got += (size_t)r;
             }
             lead[k & 1] = ld;
@@ -93,57 +96,86 @@ int assoc_build_rotcache(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, in
 
 // out_dev: [s][out_ct_capacity][2][max_level][N]; *out_ct = sum over batches of ceil(kept / slots) (the width ConcatCipherMatrix would give).
 // sum_host / sqsum_host: optional [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).
-extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
-                                    size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
-                                    uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+// One engine for both on-disk formats: a batch is a contiguous byte range of the file (.bed: nsnp * bps bytes; .pgen: the variant records of the batch, preceded by
+// the LD base its first records may need), read ahead by the reader thread, copied as it is, decoded on the copy queue into the batch's int8 matrix.
+enum { FMT_BED = 0, FMT_PGEN = 1 };
+static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                               size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                               uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    if (!num_sample || !num_snp || !batch_snps) SFG_FAIL(ctx, "assoc_stream_bed: bad dimensions");
-    if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_stream_bed: batches are multiplied as X (samples x SNPs)");
-    const size_t bps = (num_sample + 3) / 4, N = SFG_N, slots = SFG_SLOTS, L = (size_t)max_level;
+    const char *who = fmt == FMT_BED ? "assoc_stream_bed" : "assoc_stream_pgen";
+    if (!batch_snps) SFG_FAIL(ctx, "%s: bad dimensions", who);
+    if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "%s: batches are multiplied as X (samples x SNPs)", who);
+    const size_t N = SFG_N, slots = SFG_SLOTS, L = (size_t)max_level;
     const bool direct = (flags & SFG_STREAM_DIRECT) != 0;                                        // bypass the page cache: what a 5 TB scan from NVMe sees
-    int fd = open(bed_path, O_RDONLY);
-    if (fd < 0) SFG_FAIL(ctx, "assoc_stream_bed: cannot open %s", bed_path);                     // os.Open panics in the reference (filestream.go:59-61)
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) SFG_FAIL(ctx, "%s: cannot open %s", who, path);                                  // os.Open panics in the reference (filestream.go:59-61)
     flags &= ~SFG_STREAM_DIRECT;
-    struct stat stt; uint8_t magic[3] = {0, 0, 0};
-    if (fstat(fd, &stt) || pread(fd, magic, 3, 0) != 3) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: cannot read %s", bed_path); }
+    struct stat stt; uint8_t head[12] = {0};
+    if (fstat(fd, &stt) || pread(fd, head, 12, 0) < 3) { close(fd); SFG_FAIL(ctx, "%s: cannot read %s", who, path); }
+    PgenIndex ix; std::vector<PgenWindow> win;
+    size_t bps = 0, pitch = 0;
+    if (fmt == FMT_BED) {
+        if (!num_sample || !num_snp) { close(fd); SFG_FAIL(ctx, "%s: bad dimensions", who); }
+        bps = (num_sample + 3) / 4; pitch = bps;
+        if ((size_t)stt.st_size != 3 + num_snp * bps) { close(fd); SFG_FAIL(ctx, "%s: file holds %zu bytes, expected 3 + %zu x %zu", who, (size_t)stt.st_size, num_snp, bps); }
+        if (head[0] != 0x6C || head[1] != 0x1B || head[2] != 0x01) { close(fd); SFG_FAIL(ctx, "%s: not a SNP-major PLINK .bed", who); }
+    } else {
+        const size_t hb = (size_t)stt.st_size >= 12 ? pgen_header_bytes(head) : 0;
+        if (!hb || hb > (size_t)stt.st_size) { close(fd); SFG_FAIL(ctx, "%s: %s is not a PLINK 2 .pgen in a supported storage mode", who, path); }
+        std::vector<uint8_t> hdr(hb);
+        if (pread(fd, hdr.data(), hb, 0) != (ssize_t)hb) { close(fd); SFG_FAIL(ctx, "%s: cannot read the header of %s", who, path); }
+        if (pgen_index(ctx, hdr.data(), hb, (size_t)stt.st_size, ix)) { close(fd); return 1; }
+        num_sample = ix.ns; num_snp = ix.nv; pitch = pgen_pitch(ix);
+    }
     if (direct) {                                      // the header was read through the page cache; the batches go around it
         close(fd);
-        fd = open(bed_path, O_RDONLY | O_DIRECT);
-        if (fd < 0) SFG_FAIL(ctx, "assoc_stream_bed: the file system of %s does not support O_DIRECT", bed_path);
+        fd = open(path, O_RDONLY | O_DIRECT);
+        if (fd < 0) SFG_FAIL(ctx, "%s: the file system of %s does not support O_DIRECT", who, path);
     }
-    if ((size_t)stt.st_size != 3 + num_snp * bps) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: file holds %zu bytes, expected 3 + %zu x %zu", (size_t)stt.st_size, num_snp, bps); }
-    if (magic[0] != 0x6C || magic[1] != 0x1B || magic[2] != 0x01) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: not a SNP-major PLINK .bed"); }
-    const std::vector<Batch> bt = make_batches(col_filter, num_snp, batch_snps);
-    size_t total_ct = 0, max_nsnp = 0, max_kept = 0;
-    for (const Batch &b : bt) { total_ct += (b.kept + slots - 1) / slots; max_nsnp = std::max(max_nsnp, b.nsnp); max_kept = std::max(max_kept, b.kept); }
+    std::vector<Batch> bt = make_batches(col_filter, num_snp, batch_snps);
+    size_t total_ct = 0, max_bytes = 0, max_rows = 0, max_nsnp = 0, max_kept = 0;
+    if (fmt == FMT_PGEN) win.resize(bt.size());
+    for (size_t k = 0; k < bt.size(); k++) {
+        Batch &b = bt[k];
+        if (fmt == FMT_BED) { b.off = 3 + (off_t)(b.snp0 * bps); b.bytes = b.nsnp * bps; max_rows = std::max(max_rows, b.nsnp); }
+        else {
+            if (pgen_window(ctx, ix, (size_t)stt.st_size, b.snp0, b.snp0 + b.nsnp, win[k])) { close(fd); return 1; }
+            b.off = (off_t)win[k].f0; b.bytes = (size_t)(win[k].f1 - win[k].f0); max_rows = std::max(max_rows, win[k].nr);
+        }
+        total_ct += (b.kept + slots - 1) / slots; max_bytes = std::max(max_bytes, b.bytes); max_nsnp = std::max(max_nsnp, b.nsnp); max_kept = std::max(max_kept, b.kept);
+    }
     if (out_ct) *out_ct = total_ct;
     if (bt.empty()) { close(fd); return 0; }
-    if (total_ct > out_ct_capacity) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: output needs %zu ciphertexts per row, capacity %zu", total_ct, out_ct_capacity); }
+    if (total_ct > out_ct_capacity) { close(fd); SFG_FAIL(ctx, "%s: output needs %zu ciphertexts per row, capacity %zu", who, total_ct, out_ct_capacity); }
     // row map once; column maps per batch
     std::vector<int32_t> rmap_h(num_sample); size_t nr = 0;
     for (size_t i = 0; i < num_sample; i++) rmap_h[i] = (!row_filter || row_filter[i]) ? (int32_t)nr++ : -1;
-    if (!nr) { close(fd); SFG_FAIL(ctx, "assoc_stream_bed: the row filter keeps nothing"); }
+    if (!nr) { close(fd); SFG_FAIL(ctx, "%s: the row filter keeps nothing", who); }
     int rc = 0;
-    int32_t *rmap = nullptr, *cmap[2] = {nullptr, nullptr}; uint8_t *hb[2] = {nullptr, nullptr}, *db[2] = {nullptr, nullptr}; int8_t *gb[2] = {nullptr, nullptr};
+    int32_t *rmap = nullptr, *cmap[2] = {nullptr, nullptr}; uint8_t *hb[2] = {nullptr, nullptr}, *db[2] = {nullptr, nullptr}, *rows[2] = {nullptr, nullptr}, *desc[2] = {nullptr, nullptr};
+    int8_t *gb[2] = {nullptr, nullptr}; int *herr = nullptr;
     double *rotbuf = nullptr;
     u64 *tmp = nullptr; hipStream_t copy = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     const size_t ctw = 2 * L * N, max_ct = (max_kept + slots - 1) / slots;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(ctx->stream); if (copy) (void)hipStreamSynchronize(copy);
-        for (int i = 0; i < 2; i++) { (void)hipHostFree(hb[i]); (void)hipFree(db[i]); (void)hipFree(gb[i]); (void)hipFree(cmap[i]);
+        for (int i = 0; i < 2; i++) { (void)hipHostFree(hb[i]); (void)hipFree(db[i]); (void)hipFree(gb[i]); (void)hipFree(cmap[i]); (void)hipFree(rows[i]); (void)hipFree(desc[i]);
             if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_free[i]) (void)hipEventDestroy(ev_free[i]); }
-        (void)hipFree(rmap); (void)hipFree(tmp); (void)hipFree(rotbuf); if (copy) (void)hipStreamDestroy(copy); close(fd);
+        (void)hipFree(rmap); (void)hipFree(tmp); (void)hipFree(rotbuf); (void)hipHostFree(herr); if (copy) (void)hipStreamDestroy(copy); close(fd);
     };
-#define ST_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; snprintf(_b, sizeof _b, "assoc_stream_bed: %s failed: %s", #call, hipGetErrorString(_e)); ctx->err = _b; rc = 1; } } while (0)
+#define ST_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; snprintf(_b, sizeof _b, "%s: %s failed: %s", who, #call, hipGetErrorString(_e)); ctx->err = _b; rc = 1; } } while (0)
     ST_HIP(hipMalloc(&rmap, num_sample * sizeof(int32_t)));
     if (!rc) ST_HIP(hipMemcpy(rmap, rmap_h.data(), num_sample * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!rc) ST_HIP(hipMalloc(&tmp, (size_t)s * max_ct * ctw * 8));
     if (!rc) ST_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    if (!rc && fmt == FMT_PGEN) ST_HIP(hipHostMalloc((void **)&herr, 2 * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < 2 && !rc; i++) {
-        ST_HIP(hipHostMalloc((void **)&hb[i], max_nsnp * bps + 8192, hipHostMallocDefault));       // + the alignment slack of O_DIRECT ranges
-        if (!rc) ST_HIP(hipMalloc(&db[i], max_nsnp * bps));
+        ST_HIP(hipHostMalloc((void **)&hb[i], max_bytes + 8192, hipHostMallocDefault));       // + the alignment slack of O_DIRECT ranges
+        if (!rc) ST_HIP(hipMalloc(&db[i], max_bytes + 16));
         if (!rc) ST_HIP(hipMalloc(&gb[i], nr * max_kept));
         if (!rc) ST_HIP(hipMalloc(&cmap[i], max_nsnp * sizeof(int32_t)));
+        if (!rc && fmt == FMT_PGEN) { ST_HIP(hipMalloc(&rows[i], max_rows * pitch)); if (!rc) ST_HIP(hipMalloc(&desc[i], pgen_desc_bytes(max_rows))); }
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
@@ -158,24 +190,32 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
         if (rc) { cleanup(); return rc; }
         rotcache = rotbuf;
     }
-    Reader rd; rd.fd = fd; rd.bps = bps; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
+    Reader rd; rd.fd = fd; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
     std::thread reader([&rd] { rd.run(); });
     std::vector<int32_t> cmap_h(max_nsnp);
     size_t out_shift = 0;
     for (size_t k = 0; k < bt.size() && !rc; k++) {
         const Batch &b = bt[k]; const int sl = (int)(k & 1);
-        if (!rd.wait_filled(k)) { ctx->err = "assoc_stream_bed: " + rd.err; rc = 1; break; }
+        if (!rd.wait_filled(k)) { ctx->err = std::string(who) + ": " + rd.err; rc = 1; break; }
         size_t kc = 0;
         for (size_t j = 0; j < b.nsnp; j++) cmap_h[j] = (!col_filter || col_filter[b.snp0 + j]) ? (int32_t)kc++ : -1;
-        // copy queue: packed bytes and column map of batch k into slot sl (free once the product of batch k - 2 has run), decode into gb[sl]
+        // copy queue: file bytes and column map of batch k into slot sl (free once the product of batch k - 2 has run), decode into gb[sl]
         if (k >= 2) ST_HIP(hipStreamWaitEvent(copy, ev_free[sl], 0));
-        if (!rc) ST_HIP(hipMemcpyAsync(db[sl], hb[sl] + rd.lead[sl], b.nsnp * bps, hipMemcpyHostToDevice, copy));
+        if (!rc) ST_HIP(hipMemcpyAsync(db[sl], hb[sl] + rd.lead[sl], b.bytes, hipMemcpyHostToDevice, copy));
         if (!rc) ST_HIP(hipMemcpyAsync(cmap[sl], cmap_h.data(), b.nsnp * sizeof(int32_t), hipMemcpyHostToDevice, copy));
+        if (!rc && fmt == FMT_PGEN) rc = pgen_upload_desc(ctx, copy, ix, win[k], desc[sl]);
         if (!rc) ST_HIP(hipEventRecord(ev_h2d[sl], copy));
-        if (!rc) rc = launch_bed_decode(ctx, copy, db[sl], bps, num_sample, b.nsnp, rmap, cmap[sl], gb[sl], b.kept);
+        if (!rc && fmt == FMT_BED) rc = launch_bed_decode(ctx, copy, db[sl], bps, num_sample, b.nsnp, rmap, cmap[sl], gb[sl], b.kept);
+        if (!rc && fmt == FMT_PGEN) {
+            const int *err_dev = nullptr;
+            rc = launch_pgen_decode(ctx, copy, db[sl], desc[sl], win[k].nr, ix.ns, pitch, rows[sl], &err_dev);
+            if (!rc) rc = launch_bed_decode_lut(ctx, copy, rows[sl] + win[k].lead * pitch, pitch, num_sample, b.nsnp, rmap, cmap[sl], gb[sl], b.kept, 0xFF020100u);
+            if (!rc) ST_HIP(hipMemcpyAsync(&herr[sl], err_dev, sizeof(int), hipMemcpyDeviceToHost, copy));
+        }
         if (!rc) ST_HIP(hipEventRecord(ev_ready[sl], copy));
-        if (!rc) ST_HIP(hipEventSynchronize(ev_h2d[sl]));          // the pinned slot (and cmap_h) may be refilled: ~tens of ms, the previous product is still running
+        if (!rc) ST_HIP(hipEventSynchronize(fmt == FMT_PGEN ? ev_ready[sl] : ev_h2d[sl]));   // the pinned slot (and cmap_h, the descriptors) may be refilled; the previous product is still running
         rd.release(k);
+        if (!rc && fmt == FMT_PGEN) rc = pgen_decode_error(ctx, herr[sl]);
         if (rc) break;
         // compute queue: the product of batch k (MatMult4Stream(cps, mat, X, maxLevel, false, square, nproc), assoc.go:395), rows copied into place
         ST_HIP(hipStreamWaitEvent(ctx->stream, ev_ready[sl], 0));
@@ -198,4 +238,18 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
     reader.join();
     cleanup();
     return rc;
+}
+extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                                    size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                                    uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    return assoc_stream_common(ctx, FMT_BED, bed_path, num_sample, num_snp, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
+                               sum_host, sqsum_host);
+}
+// the same scan straight from a PLINK 2 .pgen on disk (the reference's input at config 5: 10 M SNPs per party do not fit host memory as one image); sample and
+// variant counts come from the file's header
+extern "C" int sfg_assoc_stream_pgen(sfg_ctx *ctx, const char *pgen_path, const uint8_t *row_filter, const uint8_t *col_filter,
+                                     size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                                     uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    return assoc_stream_common(ctx, FMT_PGEN, pgen_path, 0, 0, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
+                               sum_host, sqsum_host);
 }

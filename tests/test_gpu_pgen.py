@@ -158,3 +158,53 @@ def test_genoblockmult_over_a_real_chromosome_pgen_in_batches(env):
         assert np.array_equal(sums[k * SLOTS: k * SLOTS + sub.shape[1]], wsum) and np.array_equal(sq[k * SLOTS: k * SLOTS + sub.shape[1]], wsq)
         assert not sums[k * SLOTS + sub.shape[1]: (k + 1) * SLOTS].any()
     dA.free(); dout.free()
+
+
+def test_streamed_pgen_scan_equals_the_in_memory_scan_and_the_oracle(env, tmp_path):
+    """sfg_assoc_stream_pgen (reader thread, byte ranges of variant records, O_DIRECT where the file system has it) on (a) the reference's chr22 and
+    (b) a synthetic file with every record type whose batches start inside LD-compressed runs - same words as sfg_assoc_pgen, one batch of each vs the oracle"""
+    lib = env.capi.lib()
+    rnd = np.random.default_rng(5)
+    codes, vrt = pw.synthetic(900, 777, 11)
+    cases = [("chr22", party1_images()[21], 1000, os.path.join(GOLD, "example_party1", "geno", "chr22.pgen")),
+             ("synthetic", pw.write_pgen(codes, vrt, wmode=5), 128, None)]
+    for name, img, batch, path in cases:
+        if path is None:
+            path = str(tmp_path / (name + ".pgen")); img.tofile(path)
+        ns, nv = ol.pgen_dims(img)
+        rowf = (rnd.random(ns) < 0.9).astype(np.uint8); colf = (rnd.random(nv) < 0.93).astype(np.uint8)
+        s = 2
+        A = host_cts(env.ring, s, 1, LEVEL, 41)
+        dA = env.capi.DevArray.from_host(env.ctx, A)
+        nb = -(-int(colf.sum()) // batch)
+        outs = []
+        for mode in ("memory", "stream", "direct"):
+            dout = env.capi.DevArray(env.ctx, (s, nb, 2, L, N))
+            sums = np.zeros(nb * SLOTS); got_ct = C.c_size_t()
+            if mode == "memory":
+                rc = lib.sfg_assoc_pgen(env.ctx.h, img.ctypes.data_as(C.c_void_p), img.size, rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch,
+                                        dA.p, s, LEVEL, L, 0, dout.p, nb, C.byref(got_ct), sums.ctypes.data_as(C.c_void_p), None)
+            else:
+                flags = env.capi.SFG_STREAM_DIRECT if mode == "direct" else 0
+                rc = lib.sfg_assoc_stream_pgen(env.ctx.h, path.encode(), rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch,
+                                               dA.p, s, LEVEL, L, flags, dout.p, nb, C.byref(got_ct), sums.ctypes.data_as(C.c_void_p), None)
+                if rc and mode == "direct" and b"O_DIRECT" in lib.sfg_last_error(env.ctx.h):
+                    dout.free(); continue
+            env.ctx.check(rc, mode)
+            assert got_ct.value == nb
+            outs.append((mode, dout.host(), sums.copy()))
+            dout.free()
+        for mode, o, sm in outs[1:]:
+            assert np.array_equal(o, outs[0][1]) and np.array_equal(sm, outs[0][2]), f"{name}: {mode} differs from the in-memory scan"
+        # batch 1 against the oracle
+        kept = np.flatnonzero(colf)
+        cols = kept[batch:2 * batch]
+        full = ol.pgen_to_int8(img)
+        sub = np.ascontiguousarray(full[rowf.astype(bool)][:, cols])
+        want, wsum, _ = ol.matmult4stream(env.ring, env.keys, SCALE, A, LEVEL, L, sub, compute_sqsum=True, enc_prec=1)
+        assert np.array_equal(outs[0][1][:, 1:2], want), f"{name}: batch 1 vs the oracle"
+        assert np.array_equal(outs[0][2][SLOTS: SLOTS + len(cols)], wsum)
+        dA.free()
+    with pytest.raises(env.capi.SfgError, match="not a PLINK 2 .pgen|cannot read"):
+        bad = str(tmp_path / "bad.pgen"); open(bad, "wb").write(b"\x6c\x1b\x01" + bytes(20))
+        env.ctx.check(lib.sfg_assoc_stream_pgen(env.ctx.h, bad.encode(), None, None, 10, None, 1, LEVEL, L, 0, None, 0, None, None, None), "bad")
