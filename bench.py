@@ -376,8 +376,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Plaintext coefficient cache (sfg_geno_set_plaintext_cache): enabled after the FIRST warm-up step, when every scratch pool has its final size, with what HBM
+    # is then left beyond a reserve.  Blocks it holds skip skew + FFT in Q'*X^T of the same step and in both products of later steps (the reference keeps the
+    # encoded diagonals across iterations too: MatMult4StreamPreprocess writes them to disk once, gwas/matmult.go:1228).  SFG_BENCH_PT_CACHE_GB=0 disables, a number caps.
+    pt_cache = {"blocks": 0, "bytes": 0}
+
+    def enable_pt_cache():
+        want = os.environ.get("SFG_BENCH_PT_CACHE_GB", "auto")
+        if want == "0":
+            return
+        torch.cuda.synchronize()
+        free, _total = torch.cuda.mem_get_info(dev)
+        budget = free - (16 << 30)
+        if want != "auto":
+            budget = min(budget, int(float(want) * (1 << 30)))
+        if budget >= (1 << 29):
+            chk(lib.sfg_geno_set_plaintext_cache(ctx.h, gh, C.c_size_t(budget)), "plaintext cache")
+            pt_cache["budget"] = budget
+
+    for w in range(args.warmup):
         step()
+        if w == 0:
+            enable_pt_cache()
     phase_tot.clear()
     barrier()
     t0 = time.perf_counter()
@@ -390,6 +410,10 @@ def main():
         coll.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if "budget" in pt_cache:
+        nb_, by_, hi_, fi_ = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        chk(lib.sfg_geno_plaintext_cache_stats(ctx.h, gh, C.byref(nb_), C.byref(by_), C.byref(hi_), C.byref(fi_)), "plaintext cache stats")
+        pt_cache.update(blocks=nb_.value, bytes=by_.value, hits=hi_.value, fills=fi_.value)
     near_ties = ctx.encoder_near_ties()                    # rounding audit of every encode since context creation (gate, warm-up, timed steps)
     unprovable = C.c_ulonglong()
     chk(lib.sfg_ctx_encoder_unprovable(ctx.h, C.byref(unprovable)), "encoder_unprovable")
@@ -425,6 +449,8 @@ def main():
                    "parallelism": f"snp-block x{world}", "power_iter_wall_s": dt / args.steps,
                    "genotype_residency": "2-bit packed (sfg_geno_pack)" if args.packed_geno else "int8",
                    "collectives": (("RCCL" if args.backend == "nccl" else "gloo, host-staged (rehearsal: ranks may share a GPU; timing not meaningful)") if use_dist else "none"),
+                   "plaintext_cache": (f"{pt_cache['blocks']} of {nblk_loc * nbr_x} blocks of this rank ({pt_cache['bytes'] / 2**30:.1f} GiB of HBM left after the first warm-up step; "
+                                       f"{pt_cache.get('hits', 0)} block encodes served from it, {pt_cache.get('fills', 0)} filled)" if "budget" in pt_cache else "off"),
                    "rotation_cache_QX": ("sharded build + all-gather" if shard_rotcache else ("replicated" if use_dist else "single rank")),
                    "QtXt_reduce_scatter": ("per output block column, overlapped" if (use_dist and pipe_cols) else ("after the product" if use_dist else "none"))},
     }
@@ -440,6 +466,7 @@ def main():
                           "bytes": {"all_gather_recv_per_rank": (world - 1) * jpr * jobw * 8 if shard_rotcache else 0,
                                     "reduce_scatter_sent_per_rank": nbr_x * colp * 8 * (world - 1) // world,
                                     "all_reduce_out2": KP * nbr_x * outw * 8},
+                          "plaintext_cache": pt_cache,
                           "note": "collectives replaced by local copies: the outputs are not a product"}), flush=True)
         lib.sfg_geno_free(ctx.h, gh)
         ctx.close()

@@ -166,6 +166,14 @@ int sfg_ct_innersum_dev(sfg_ctx *ctx, const uint64_t *in_dev, int nct, int level
 int sfg_geno_upload(sfg_ctx *ctx, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
 int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *geno_dev, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
 void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g);
+/* Plaintext coefficient cache of a resident matrix - the device-memory counterpart of the reference's on-disk DiagCache (MatMult4StreamPreprocess,
+ * gwas/matmult.go:1228-1334, read back per iteration at :1386-1400).  After this call the products over `g` keep, per 8192 x 8192 block (and per SFG_SQUARE
+ * flavour), the encoder's rounded coefficient rows (512 MB) until max_bytes are held; a later product over a cached block - in EITHER orientation: the
+ * diagonals of the transposed block are slot rotations of the cached ones, i.e. automorphism images of the cached plaintexts - skips the skew and the FFT and
+ * produces the same words.  max_bytes = 0 drops the cache.  The matrix must not change while cached; only `ctx` may multiply with `g` meanwhile.
+ * sfg_geno_plaintext_cache_stats: blocks held, bytes held, block encodes served from the cache, blocks filled (any pointer may be NULL). */
+int sfg_geno_set_plaintext_cache(sfg_ctx *ctx, const sfg_geno *g, size_t max_bytes);
+int sfg_geno_plaintext_cache_stats(sfg_ctx *ctx, const sfg_geno *g, size_t *blocks, size_t *bytes, size_t *hits, size_t *fills);
 /* Input pipeline on the device (replaces the per-batch shell-outs of assoc.go:389 to the Python converters under scripts/):
  * scripts/plinkBedToBinary.py + filterMatrix.py: `bed_host` is a whole SNP-major PLINK .bed image (3 magic bytes +
  * ceil(num_sample/4) bytes per SNP; codes 00->2, 01->-1, 10->1, 11->0); rows (samples) / columns (SNPs) whose filter

@@ -78,6 +78,8 @@ def _sig(L):
         "sfg_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_from_device": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_free": (None, [vp, vp]),
+        "sfg_geno_set_plaintext_cache": (i, [vp, vp, C.c_size_t]),
+        "sfg_geno_plaintext_cache_stats": (i, [vp, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "sfg_geno_from_bed": (i, [vp, vp, sz, sz, sz, vp, vp, C.POINTER(vp)]),
         "sfg_geno_dims": (i, [vp, C.POINTER(sz), C.POINTER(sz)]),
         "sfg_pgen_dims": (i, [vp, vp, sz, C.POINTER(sz), C.POINTER(sz)]),

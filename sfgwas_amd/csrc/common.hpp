@@ -38,6 +38,15 @@ struct sfg_geno {
     size_t nrow = 0, ncol = 0, ld = 0;
     bool owned = false;
     bool packed = false;                   // codes 0, 1, 2 = the genotype, 3 = missing (sfg_geno_pack)
+    // plaintext coefficient cache (sfg_geno_set_plaintext_cache, matmul.hip): per stored block (and SFG_SQUARE) the encoder's rounded coefficient rows,
+    // [8192 shifts][N/2] doubles = 512 MB, kept from the first product that touches the block; later products over it in EITHER orientation skip skew + FFT
+    struct PtcEntry { double *slot; bool transposed; };
+    mutable std::map<uint64_t, PtcEntry> ptc;
+    mutable size_t ptc_budget = 0, ptc_used = 0;
+    mutable double *ptc_arena = nullptr;   // ONE allocation of ptc_budget bytes, slots carved in order
+    mutable uint32_t *ptc_perm = nullptr;  // device [8192]: shift t of the other orientation = cached row u | g << 16, image under X -> X^g (k_ntt_half3<true>)
+    mutable const void *ptc_owner = nullptr;   // the context whose stream orders the fills before the hits
+    mutable size_t ptc_hits = 0, ptc_fills = 0;
 };
 
 // A/B and diagnostic switches: read ONCE from the environment by sfg_ctx_create (never on the launch path)

@@ -522,20 +522,24 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
 // half_rows + G > 0: `pt` is the base of a grouped panel and rows are scattered by PanelMap (half rows only)
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask) {
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask, const PcCache *pcache) {
     EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
     const int BATCH = ctx->cfg.enc_batch;                 // plaintexts per FFT / NTT launch pair (SFG_ENC_BATCH)
+    const int cmode = pcache && pcache->slot && half_rows && G > 0 ? pcache->mode : 0;
     double *pc = nullptr;
-    SFG_TRY(enc_pc_scratch(ctx, (size_t)(nshift < BATCH ? nshift : BATCH), &pc));
+    if (!cmode) SFG_TRY(enc_pc_scratch(ctx, (size_t)(nshift < BATCH ? nshift : BATCH), &pc));
     for (int s0 = 0; s0 < nshift; s0 += BATCH) {
         const int nb = nshift - s0 < BATCH ? nshift - s0 : BATCH;
-        {
+        if (cmode == 1) pc = pcache->slot + (size_t)(shift0 + s0) * SFG_SLOTS;          // the coefficient rows of these shifts live in the cache slot
+        if (cmode <= 1) {
             PhaseTimer t(ctx, "encode", false);
             hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->tb, et->tinv, pc, (unsigned long long *)ctx->tie_count_dev);
             SFG_HIP(ctx, hipGetLastError());
         }
-        if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
+        if (cmode == 2) pc = pcache->slot + (size_t)(shift0 + s0) * SFG_SLOTS;
+        if (cmode == 3) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm)); }
+        else if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
         else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));
     }

@@ -171,10 +171,64 @@ extern "C" int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *dev, size_t nrow
     sfg_geno *g = new sfg_geno(); g->dev = dev; g->nrow = nrow; g->ncol = ncol; g->ld = ld; g->owned = false;
     *out = g; return 0;
 }
+static void ptc_drop(sfg_ctx *ctx, const sfg_geno *g) {
+    if (g->ptc.empty() && !g->ptc_perm) return;
+    (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
+    g->ptc.clear(); g->ptc_used = 0;
+    if (g->ptc_arena) { (void)hipFree(g->ptc_arena); g->ptc_arena = nullptr; }
+    if (g->ptc_perm) { (void)hipFree(g->ptc_perm); g->ptc_perm = nullptr; }
+}
 extern "C" void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g) {
     if (!g) return;
+    ptc_drop(ctx, g);
     if (g->owned) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); (void)hipFree((void *)g->dev); }
     delete g;
+}
+// Plaintext coefficient cache of a resident matrix: up to max_bytes of HBM (512 MB per 8192 x 8192 block and SFG_SQUARE flavour), filled by the products that
+// run after this call, hit by every later product over the same block - Q.X of the next power iteration, and Q'.X^T of this one: the diagonals of the transposed
+// block are rotations of the cached ones (D'_t = rotL_t(D_{n-t})), a rotation of the slots is an automorphism of the plaintext, and the encoder's rounding
+// commutes with it, so the NTT reads the cached row through a signed index permutation and produces the words a fresh encode would.  max_bytes = 0 drops it.
+// The caller promises the matrix does not change while cached, and that `ctx` (its current stream) is the only context multiplying with this handle.
+extern "C" int sfg_geno_set_plaintext_cache(sfg_ctx *ctx, const sfg_geno *g, size_t max_bytes) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!g) SFG_FAIL(ctx, "sfg_geno_set_plaintext_cache: null matrix");
+    if (!max_bytes) { ptc_drop(ctx, g); g->ptc_budget = 0; g->ptc_owner = nullptr; return 0; }
+    if (g->ptc_owner && g->ptc_owner != (const void *)ctx) SFG_FAIL(ctx, "sfg_geno_set_plaintext_cache: the cache of this matrix belongs to another context (drop it there first)");
+    if (!g->ptc_perm) {
+        const int n = SFG_SLOTS, d = SFG_D; const unsigned M = 2u * SFG_N;
+        std::vector<uint32_t> tab(n);
+        std::vector<unsigned> pow5(n); pow5[0] = 1; for (int k = 1; k < n; k++) pow5[k] = (unsigned)(((u64)pow5[k - 1] * 5u) % M);     // 5 has order N/2 = n mod 2N
+        for (int t = 0; t < n; t++) {
+            const int u = (n - t) % n, k = ((t % d) + d * (u / d)) % n;
+            tab[t] = (uint32_t)u | (uint32_t)pow5[k] << 16;                       // g = 5^k mod 2N  (< 2^15)
+        }
+        uint32_t *dv = nullptr;
+        SFG_HIP(ctx, hipMalloc((void **)&dv, (size_t)n * 4));
+        if (hipMemcpy(dv, tab.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dv); SFG_FAIL(ctx, "sfg_geno_set_plaintext_cache: table upload failed"); }
+        g->ptc_perm = dv;
+    }
+    const size_t slot_bytes = (size_t)SFG_SLOTS * SFG_SLOTS * 8, want = max_bytes / slot_bytes * slot_bytes;
+    if (want != g->ptc_budget || !g->ptc_arena) {            // (re)sized: what was cached goes
+        (void)hipStreamSynchronize(ctx->stream);
+        g->ptc.clear(); g->ptc_used = 0;
+        if (g->ptc_arena) { (void)hipFree(g->ptc_arena); g->ptc_arena = nullptr; }
+        g->ptc_budget = 0;
+        if (!want) SFG_FAIL(ctx, "sfg_geno_set_plaintext_cache: max_bytes is less than one block (%zu bytes)", slot_bytes);
+        void *a = nullptr;
+        if (hipMalloc(&a, want) != hipSuccess) { (void)hipGetLastError(); SFG_FAIL(ctx, "sfg_geno_set_plaintext_cache: cannot allocate %zu bytes", want); }
+        g->ptc_arena = (double *)a; g->ptc_budget = want;
+    }
+    g->ptc_owner = ctx;
+    return 0;
+}
+// blocks cached / bytes held / hits and fills since the cache was enabled
+extern "C" int sfg_geno_plaintext_cache_stats(sfg_ctx *ctx, const sfg_geno *g, size_t *blocks, size_t *bytes, size_t *hits, size_t *fills) {
+    if (!g) SFG_FAIL(ctx, "sfg_geno_plaintext_cache_stats: null matrix");
+    if (blocks) *blocks = g->ptc.size();
+    if (bytes) *bytes = g->ptc_used;
+    if (hits) *hits = g->ptc_hits;
+    if (fills) *fills = g->ptc_fills;
+    return 0;
 }
 extern "C" int sfg_geno_colsums(sfg_ctx *ctx, const sfg_geno *g, double *sum_host, double *sqsum_host) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
@@ -342,7 +396,23 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             const int nc = sh.cols_of(bj);
             for (int g = 0; g < ng && !rc; g++) {
                 const int bi = bg + g, nr = sh.rows_of(bi);
-                {
+                // plaintext coefficient cache of the stored block (sfg_geno_set_plaintext_cache)
+                PcCache pcc; uint64_t ptc_key = 0; bool ptc_new = false;
+                if (dma && sh.g->ptc_budget && sh.g->ptc_owner == (const void *)ctx) {
+                    const uint64_t sr = sh.transposed ? bj : bi, sc = sh.transposed ? bi : bj;
+                    ptc_key = sr << 33 | sc << 1 | ((flags & SFG_SQUARE) ? 1u : 0u);
+                    const size_t slot_bytes = (size_t)SFG_SLOTS * SFG_SLOTS * 8;
+                    auto it = sh.g->ptc.find(ptc_key);
+                    if (it != sh.g->ptc.end()) { pcc.slot = it->second.slot; pcc.mode = it->second.transposed == sh.transposed ? 2 : 3; pcc.perm = sh.g->ptc_perm; sh.g->ptc_hits++; }
+                    else if (sh.g->ptc_used + slot_bytes <= sh.g->ptc_budget) {
+                        double *slot = sh.g->ptc_arena + sh.g->ptc_used / 8;
+                        sh.g->ptc[ptc_key] = sfg_geno::PtcEntry{slot, sh.transposed}; sh.g->ptc_used += slot_bytes; sh.g->ptc_fills++;
+                        pcc.slot = slot; pcc.mode = 1; ptc_new = true;
+                    }
+                }
+                // (a failed fill is the newest slot of the arena: give it back)
+                auto ptc_undo = [&]() { if (ptc_new) { auto it = sh.g->ptc.find(ptc_key); if (it != sh.g->ptc.end()) { sh.g->ptc.erase(it); sh.g->ptc_used -= (size_t)SFG_SLOTS * SFG_SLOTS * 8; } ptc_new = false; } };
+                if (pcc.mode < 2) {
                     PhaseTimer t(ctx, "skew");
                     if (sh.g->packed) {        // expand the stored block (rows x cols as stored) into the int8 staging block, then skew as usual
                         const size_t sr0 = (size_t)(sh.transposed ? bj : bi) * SFG_SLOTS, sc0 = (size_t)(sh.transposed ? bi : bj) * SFG_SLOTS;
@@ -351,7 +421,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     } else rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, (flags & SFG_SQUARE) ? 1 : 0, skew);
                     t.stop(1);
                 }
-                if (rc) break;
+                if (rc) { ptc_undo(); break; }
                 // existing diagonals of this block form at most two runs of shifts: [0, nr) and (n - nc, n)  (GetDiagBool)
                 int runs[2][2]; int nruns = 0;
                 if (nr + nc > SFG_SLOTS) { runs[0][0] = 0; runs[0][1] = SFG_SLOTS; nruns = 1; }
@@ -363,15 +433,16 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 } else {           // ragged block: all 91 x 91 slots of this block row
                     rc = launch_pt_zero(ctx, pt + (size_t)g * d * plw, (size_t)ng * d * plw, (size_t)d * plw, d, L, prow, packed_mask);
                 }
-                if (rc) break;
+                if (rc) { ptc_undo(); break; }
                 {
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask);
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask, pcc.mode ? &pcc : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
                     t.stop(nruns);
                 }
+                if (rc) ptc_undo();
             }
             if (rc) break;
             {

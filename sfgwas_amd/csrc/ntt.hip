@@ -246,17 +246,20 @@ constexpr int H3_LDS_BYTES = H3_DOUBLES * 8;      // 34,816 B: four workgroups p
 // The 13 stages that follow the first Cooley-Tukey stage, on ONE half (hs = 0: indices [0, n), hs = 1: [n, N)) of a row: after stage 1 the
 // halves are independent size-n transforms whose twiddles sit hs * (m / 2) further in each stage's table (tw[m + i], i in [hs m/2, (hs+1) m/2)).
 // first(j) returns the stage-1 output r_j of this half, j < n; store(j, x) receives the lazy result of output index hs * n + j.
-template <class First, class Store>
-__device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store, double *lds, const double *tw, const double2 *pack, double q, double qinv, int tid) {
+struct NoFill {};
+template <class First, class Store, class Fill = NoFill>
+__device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store, double *lds, const double *tw, const double2 *pack, double q, double qinv, int tid, Fill fill = Fill()) {
     double v[32];
     const int a_b = tid >> 4, c_b = tid & 15;                  // phase B identity
     // ---- phase A (two columns) interleaved with the two A->B rounds
     // (both columns' stage-1 values are formed up front: all 64 input loads are in flight together and their latency is paid once)
     double w2[2][16];
+    if constexpr (std::is_same<Fill, NoFill>::value) {
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+        for (int h = 0; h < 2; h++)
 #pragma unroll
-        for (int a = 0; a < 16; a++) w2[h][a] = first(a * 512 + tid + 256 * h);
+            for (int a = 0; a < 16; a++) w2[h][a] = first(a * 512 + tid + 256 * h);
+    } else fill(w2);                                           // the stage-1 values arrive some other way (k_ntt_half3<true>); returns after a workgroup barrier
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         double (&w)[16] = w2[h];
@@ -324,7 +327,13 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
         }
     }
 }
-__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
+// PERM: the coefficient rows come from the plaintext cache of the block in its OTHER orientation (matmul.hip): plaintext t of this product is the automorphism
+// image X -> X^g of cached row u (perm[t] = u | g << 16): coefficient i of the row becomes coefficient i g mod 2N of the image (>= N: minus coefficient - N), and a
+// row is stored as its first N/2 coefficients (p_{N-c} = -p_c, p_{N/2} = 0).  The rounding of the encoder commutes with this signed permutation, so the NTT input is
+// the very integer polynomial a fresh encode of the rotated diagonal would give.
+template <bool PERM>
+__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
+                                                      const uint32_t *perm) {
     extern __shared__ double lds[];
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     size_t row; int m;
@@ -333,9 +342,46 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
     const double2 *pack = pack_all + (size_t)m * (N / 2);
     const double q = modc[m].q, qinv = modc[m].qinv;
     const double *pc = pc_all + (row / L) * (size_t)n;
+    unsigned gal = 1;
+    if (PERM) { const uint32_t e = perm[pm.shift0 + (int)(row / L)]; pc = pc_all + (size_t)(e & 0xFFFFu) * n; gal = e >> 16; }
     const double W = tw[1], Wq = W * qinv;
     // stage 1 on the antisymmetric input: r_j = p_j + W p_{n+j} = p_j - W p_{n-j}, r_0 = p_0
     auto first = [&](int j) { const double lo = pc[j], hi = j == 0 ? 0.0 : pc[n - j]; return lo - mulmod_lazy(hi, W, Wq, q); };
+    // PERM: source driven.  A thread reads the pairs (p_i, p_{n-i}), i = tid + 256 k < n/2, coalesced.  p_i is coefficient raw = i g mod 2N of the image, i.e.
+    // +-coefficient J of its stored half (quadrants of raw: [0,n] J = raw, +; (n,N) J = N - raw, -; [N,N+n] J = raw - N, -; (N+n,2N) J = 2N - raw, +), and
+    // because g = 1 mod 4 its partner p_{n-i} is coefficient n - J (signs +, +, -, -): the pair yields r_J and r_{n-J}.  The 8192 stage-1 values then go to
+    // their phase-A owners through the (not yet used) A->B image, one column half per round: odd g makes the scattered writes bank-conflict free.
+    auto fill = [&](double (&w2)[2][16]) {
+        double rA[16], rB[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = tid + 256 * k;
+            const double lo = pc[i], hi = i == 0 ? 0.0 : pc[n - i];
+            const unsigned qd = (((unsigned)i * gal) & (2u * N - 1u)) >> 13;
+            const double ca = (qd == 1u || qd == 2u) ? -lo : lo, cb = qd >= 2u ? -hi : hi;
+            rA[k] = ca - mulmod_lazy(cb, W, Wq, q);
+            rB[k] = cb - mulmod_lazy(ca, W, Wq, q);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned raw = ((unsigned)(tid + 256 * k) * gal) & (2u * N - 1u), qd = raw >> 13;
+                const int J = qd == 0u ? (int)raw : qd == 1u ? N - (int)raw : qd == 2u ? (int)raw - N : 2 * N - (int)raw, Jb = n - J;
+                if (((J >> 8) & 1) == h && J < n) lds[(J >> 9) * H3_ROWA + (J & 255)] = rA[k];
+                if (((Jb >> 8) & 1) == h && Jb < n) lds[(Jb >> 9) * H3_ROWA + (Jb & 255)] = rB[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 16; a++) w2[h][a] = lds[a * H3_ROWA + tid];
+            __syncthreads();
+        }
+        if (tid == 0) {                                          // the self-paired middle coefficient p_{n/2} -> r_{n/2}: thread 0's own slot (a = 8, column 0)
+            const double mid = pc[n / 2];
+            const double c = ((((unsigned)(n / 2) * gal) & (2u * N - 1u)) >> 13) >= 2u ? -mid : mid;
+            w2[0][8] = c - mulmod_lazy(c, W, Wq, q);
+        }
+    };
     // destination plaintext slot inside a (possibly multi-block-row) panel: see PanelMap
     const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
     const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
@@ -345,8 +391,14 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
     if (SFG_NTT_DIAG == 1) { ntt_half3_body(0, first, [&](int j, double x) { if (x == 0.123) out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid); return; }
     if (SFG_NTT_DIAG == 2) { ntt_half3_body(0, first, [&](int j, double x) { out[j] = (u64)__double_as_longlong(x); }, lds, tw, pack, q, qinv, tid); return; }
 #endif
-    if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
-    else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+    if constexpr (PERM) {
+        if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid, fill);
+        else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid, fill);
+    } else {
+        (void)fill;
+        if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+        else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+    }
 }
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
 // CU, instead of one 512-thread workgroup holding a 132 KiB image.  Each half reads both halves of the input (the second read is an L2 hit: the two
@@ -384,7 +436,8 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
@@ -411,10 +464,12 @@ int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, in
     return 0;
 }
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
-int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm) {
+int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm) {
     if (!nplain) return 0;
-    if (ctx->cfg.ntt_half_full) hipLaunchKernelGGL(k_ntt_half, dim3((unsigned)((nplain + 7) / 8 * 8 * L)), dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
-    else hipLaunchKernelGGL(k_ntt_half3, dim3((unsigned)((nplain + 7) / 8 * 8 * L)), dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    const dim3 grid((unsigned)((nplain + 7) / 8 * 8 * L));
+    if (perm) hipLaunchKernelGGL(k_ntt_half3<true>, grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
+    else if (ctx->cfg.ntt_half_full) hipLaunchKernelGGL(k_ntt_half, grid, dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+    else hipLaunchKernelGGL(k_ntt_half3<false>, grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
