@@ -532,6 +532,144 @@ inline DevCipherVector CMultConstDev(CryptoParams *cps, const DevCipherVector &X
 // crypto.Rebalance (basics.go:248-255): InnerSumAll of the one ciphertext, times 1 / slots
 inline DevCipherVector RebalanceDev(CryptoParams *cps, const DevCipherVector &ct) { return CMultConstDev(cps, InnerSumAllDev(cps, ct), 1.0 / (double)cps->GetSlots()); }
 
+// ---- ckks.Approximate + eval.EvaluateCheby (crypto/basics.go:613-626, 723-768; mpc/mhe.go:634-667 SigmoidApprox, called from gwas/assoc.go:1045) on device vectors.
+// PARITY UNPINNED.  The algorithm lives in the lattigo fork, which is absent; this restates the published lattigo v2.1 / v2.2 ckks/polynomial_evaluation.go:
+//   * the power basis T_2 .. T_{2^logSplit - 1}, T_{2^logSplit}, .., T_{2^(logDegree-1)} by T_n = 2 T_a T_b - T_{a-b}, a = ceil(n/2), b = floor(n/2): MulRelinNew,
+//     Rescale(params.Scale()), Add to itself, AddConst(-1) or Sub;
+//   * the recursive split p = q T_{2^k} + r in the Chebyshev basis (q_0 = c_k, q_j = 2 c_{k+j}, r_{k-j} -= c_{k+j}), the scale the q branch must come out with
+//     = targetScale * q_level / T.scale so that the Rescale after MulRelin(q, T) lands on targetScale;
+//   * the leaves: a zero ciphertext at the level of T_deg and scale targetScale * q_level, AddConst(c_0), MultByGaussianIntegerAndAdd(T_k, int64(c_k * targetScale *
+//     q_level / T_k.scale)) for every |c_k| > 1e-14, Rescale;
+//   * the re-split of a leading leaf (lead && logSplit > 1 && maxDeg mod 2^(logSplit+1) > 2^(logSplit-1)) with logDegree = bitlen(deg), logSplit = logDegree / 2.
+// One thing is NOT lattigo's text: lattigo predicts the level at which MulRelin(q, T) will run from a heuristic on maxDeg that could not be recalled with
+// confidence; here that level is computed exactly by a dry run of the same recursion (mulLevel below), which is what the heuristic exists to predict.
+struct ChebyPoly { std::vector<double> c; uint64_t maxDeg = 0; bool lead = false; uint64_t Degree() const { return (uint64_t)c.size() - 1; } };
+struct ChebyshevInterpolation { ChebyPoly poly; double a = 0, b = 0; };
+// ckks.Approximate: interpolation at the degree+1 Chebyshev nodes of [a, b] (real functions only: the reference's Sigmoid, Sqrt, invSqrt, inv).
+// libm's cos stands in for Go's math.Cos: the last bit of a node may differ.
+template <class F> inline ChebyshevInterpolation Approximate(F f, double a, double b, int degree) {
+    const int n = degree + 1;
+    std::vector<double> nodes(n), fi(n);
+    for (int k = 1; k <= n; k++) nodes[k - 1] = 0.5 * (a + b) + 0.5 * (b - a) * std::cos(((double)k - 0.5) * (3.141592653589793 / (double)n));
+    for (int i = 0; i < n; i++) fi[i] = f(nodes[i]);
+    ChebyshevInterpolation ch; ch.a = a; ch.b = b; ch.poly.c.assign(n, 0.0); ch.poly.maxDeg = (uint64_t)degree; ch.poly.lead = true;
+    for (int i = 0; i < n; i++) {
+        const double u = (2 * nodes[i] - a - b) / (b - a);
+        double Tprev = 1, T = u;
+        for (int j = 0; j < n; j++) { ch.poly.c[j] += fi[i] * Tprev; const double Tnext = 2 * u * T - Tprev; Tprev = T; T = Tnext; }
+    }
+    ch.poly.c[0] /= (double)n;
+    for (int i = 1; i < n; i++) ch.poly.c[i] *= 2.0 / (double)n;
+    return ch;
+}
+inline double Sigmoid(double x) { return 1.0 / (1 + std::exp(-x)); }                  // mhe.go:675-677
+namespace detail {
+inline uint64_t bitLen(uint64_t x) { uint64_t n = 0; while (x) { n++; x >>= 1; } return n; }
+inline void splitCoeffsCheby(const ChebyPoly &p, uint64_t split, ChebyPoly &q, ChebyPoly &r) {
+    r = ChebyPoly(); r.c.assign(p.c.begin(), p.c.begin() + split);
+    r.maxDeg = p.maxDeg == p.Degree() ? split - 1 : p.maxDeg - (p.Degree() - split + 1);
+    q = ChebyPoly(); q.c.assign(p.Degree() - split + 1, 0.0); q.maxDeg = p.maxDeg; q.lead = p.lead;
+    q.c[0] = p.c[split];
+    for (uint64_t i = split + 1, j = 1; i < p.Degree() + 1; i++, j++) { q.c[i - split] = 2 * p.c[i]; r.c[split - j] -= p.c[i]; }
+}
+inline DevCipherVector mulRelinDev(CryptoParams *cps, DevCipherVector X, DevCipherVector Y) {           // eval.MulRelin without the Rescale
+    alignLevels(X, Y);
+    DevCipherVector o = NewDevCipherVector(cps, X.n, X.level, X.scale * Y.scale);
+    cps->check(sfg_ct_mulrelin_dev(cps->ctx, X.ptr(), Y.ptr(), o.ptr(), (int)X.n, X.level), "MulRelin");
+    return o;
+}
+struct ChebyEval {
+    CryptoParams *cps; std::map<uint64_t, DevCipherVector> C;
+    const std::vector<uint64_t> &qi() const { return cps->qi; }
+    void powerBasis(uint64_t n) {
+        if (C.count(n)) return;
+        const uint64_t a = (n + 1) / 2, b = n >> 1, c = a - b;
+        powerBasis(a); powerBasis(b); if (c) powerBasis(c);
+        DevCipherVector t = CMultDev(cps, C.at(a), C.at(b), qi());                       // MulRelinNew + Rescale(params.Scale())
+        t = CAddSubDev(cps, t, t, false);
+        t = c == 0 ? AddConstDev(cps, t, -1.0, qi()) : CAddSubDev(cps, t, C.at(c), true);
+        C[n] = t;
+    }
+    static bool resplit(const ChebyPoly &p, uint64_t logSplit) { return p.lead && logSplit > 1 && p.maxDeg % (1ULL << (logSplit + 1)) > (1ULL << (logSplit - 1)); }
+    static uint64_t nextPower(const ChebyPoly &p, uint64_t logSplit) { uint64_t np = 1ULL << logSplit; while (np < (p.Degree() >> 1) + 1) np <<= 1; return np; }
+    // level the result of recurse() will have (every Rescale of the recursion divides by exactly one modulus: checked where it happens)
+    int outLevel(const ChebyPoly &p, uint64_t logSplit, uint64_t logDegree, int *mulLevelOut = nullptr) const {
+        if (p.Degree() < (1ULL << logSplit)) {
+            if (resplit(p, logSplit)) { const uint64_t ld = bitLen(p.Degree()); return outLevel(p, ld >> 1, ld); }
+            return C.at(p.Degree() ? p.Degree() : 1).level - 1;
+        }
+        const uint64_t np = nextPower(p, logSplit);
+        ChebyPoly q, r; splitCoeffsCheby(p, np, q, r);
+        int lq = outLevel(q, logSplit, logDegree); const int lr = outLevel(r, logSplit, logDegree);
+        if (lq > lr) lq = lr + 1;
+        const int lm = std::min(lq, C.at(np).level);
+        if (mulLevelOut) *mulLevelOut = lm;
+        return lm > lr ? std::min(lm - 1, lr) : std::min(lm, lr) - 1;
+    }
+    DevCipherVector leaf(double targetScale, const ChebyPoly &p) {
+        const DevCipherVector &top = C.at(p.Degree() ? p.Degree() : 1);
+        const int level = top.level; const double currentQi = (double)qi()[level];
+        DevCipherVector res = NewDevCipherVector(cps, top.n, level, targetScale * currentQi);
+        cps->check(sfg_ct_sub_dev(cps->ctx, top.ptr(), top.ptr(), res.ptr(), (int)top.n, level), "zero ciphertext");
+        if (std::fabs(p.c[0]) > 1e-14) res = AddConstDev(cps, res, p.c[0], qi());
+        for (uint64_t key = p.Degree(); key > 0; key--) {
+            if (!(std::fabs(p.c[key]) > 1e-14)) continue;
+            const DevCipherVector &T = C.at(key);
+            const double constScale = targetScale * currentQi / T.scale;
+            const long long cReal = (long long)(p.c[key] * constScale);                  // Go's int64(): toward zero
+            std::vector<uint64_t> sc(level + 1);
+            for (int m = 0; m <= level; m++) { const long long q = (long long)qi()[m]; sc[m] = (uint64_t)(((cReal % q) + q) % q); }
+            DevCipherVector Tl = T.level > level ? DropLevelDev(T, level) : T;
+            cps->check(sfg_ct_mul_scalar_add_dev(cps->ctx, Tl.ptr(), sc.data(), res.ptr(), (int)res.n, level), "MultByGaussianIntegerAndAdd");
+        }
+        return rescaleOnce(res);
+    }
+    DevCipherVector rescaleOnce(const DevCipherVector &x) {
+        DevCipherVector o = rescaleDev(x, cps->scale, qi());
+        if (o.level != x.level - 1) throw std::runtime_error("EvaluateCheby: a Rescale of the recursion did not divide by exactly one modulus (scale out of range)");
+        return o;
+    }
+    DevCipherVector recurse(double targetScale, uint64_t logSplit, uint64_t logDegree, const ChebyPoly &p) {
+        if (p.Degree() < (1ULL << logSplit)) {
+            if (resplit(p, logSplit)) { const uint64_t ld = bitLen(p.Degree()); return recurse(targetScale, ld >> 1, ld, p); }
+            return leaf(targetScale, p);
+        }
+        const uint64_t np = nextPower(p, logSplit);
+        ChebyPoly q, r; splitCoeffsCheby(p, np, q, r);
+        int lm = 0; outLevel(p, logSplit, logDegree, &lm);
+        const DevCipherVector &T = C.at(np);
+        DevCipherVector res = recurse(targetScale * (double)qi()[lm] / T.scale, logSplit, logDegree, q);
+        DevCipherVector tmp = recurse(targetScale, logSplit, logDegree, r);
+        if (res.level > tmp.level && res.level != tmp.level + 1) res = DropLevelDev(res, tmp.level + 1);
+        res = mulRelinDev(cps, res, T);
+        if (res.level != lm) throw std::runtime_error("EvaluateCheby: level prediction of the dry run failed");
+        if (res.level > tmp.level) return CAddSubDev(cps, rescaleOnce(res), tmp, false);
+        return rescaleOnce(CAddSubDev(cps, res, tmp, false));
+    }
+};
+}  // namespace detail
+// eval.EvaluateCheby(op, cheby, targetScale): op must already carry the change of variable 2/(b-a) x + (-a-b)/(b-a)
+inline DevCipherVector EvaluateChebyDev(CryptoParams *cps, const DevCipherVector &op, const ChebyshevInterpolation &cheby, double targetScale) {
+    const uint64_t logDegree = detail::bitLen(cheby.poly.Degree()), logSplit = logDegree >> 1;
+    if (op.level < (int)std::ceil(std::log2((double)(cheby.poly.Degree() + 1))) + 1) throw std::runtime_error("EvaluateCheby: not enough levels");
+    detail::ChebyEval ev{cps, {}};
+    ev.C[1] = op;
+    for (uint64_t i = 2; i < (1ULL << logSplit); i++) ev.powerBasis(i);
+    for (uint64_t i = logSplit; i < logDegree; i++) ev.powerBasis(1ULL << i);
+    return ev.recurse(targetScale, logSplit, logDegree, cheby.poly);
+}
+// crypto.ChebyApproximation (basics.go:613-626): EvaluateCheby at the ciphertexts' own scale
+inline DevCipherVector ChebyApproximationDev(CryptoParams *cps, const DevCipherVector &X, const ChebyshevInterpolation &cheby) { return EvaluateChebyDev(cps, X, cheby, X.scale); }
+// mpc.SigmoidApprox / CSigmoidApprox without their network step (mhe.go:634-667): the caller bootstraps first when SigmoidNeedsBootstrap says so (:641-645)
+inline bool SigmoidNeedsBootstrap(int level, int degree) { return level < (int)std::ceil(std::log2((double)(degree + 1)) + 1) + 2; }
+inline DevCipherVector CSigmoidApproxLocal(CryptoParams *cps, const DevCipherVector &ctIn, double A, double B, int degree) {
+    if (degree == 0) throw std::runtime_error("CSigmoidApprox: Degree == 0 is the decrypt-and-recompute debugging branch (mhe.go:621-632), not a device computation");
+    const ChebyshevInterpolation cheby = Approximate(Sigmoid, A, B, degree);
+    DevCipherVector y = detail::rescaleDev(CMultConstDev(cps, ctIn, 2 / (B - A)), cps->scale, cps->qi);      // MultByConstNew + Rescale(params.Scale())
+    y = AddConstDev(cps, y, (-A - B) / (B - A), cps->qi);
+    return EvaluateChebyDev(cps, y, cheby, y.scale);
+}
+
 // ---- vectors whose ciphertexts keep their OWN level and scale (a crypto.CipherVector is []*ckks.Ciphertext: NetDQRenc's Householder vector has one
 // ciphertext - the one that received alphaScaled - below the others, qrfact.go:166-169).  Element-wise ops act pairwise at the lower level of each pair.
 using CellVec = std::vector<DevCipherVector>;                           // every element: n == 1

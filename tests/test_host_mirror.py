@@ -822,3 +822,194 @@ def test_netdqrenc_forward_and_backward_column_segments_match_the_oracle(tmp_pat
         assert (lvl_, sc_) == (w.level, w.scale), f"{name}: level / scale ({lvl_}, {sc_!r}) vs the replay's ({w.level}, {w.scale!r})"
         got = np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint64).reshape(2, lvl_ + 1, ring.N)
         assert np.array_equal(got, w.a), f"{name}: words"
+
+
+# ---------------------------------------------------------------- f-5: CSigmoidApprox = change of variable + eval.EvaluateCheby (mhe.go:634-667), parity unpinned
+def _r_add_const(ring, x, c):
+    out = np.zeros_like(x.a)
+    ol.lib().orc_add_const(ring.h, x.level, ol.p64(x.a), C.c_double(c), C.c_double(x.scale), ol.p64(out))
+    return _Ct(out, x.level, x.scale)
+
+
+def _r_rescale_once(ring, x, SC):
+    ct, lvl, sc = _orc_rescale_loop(ring, x.a, x.level, x.scale, SC)
+    assert lvl == x.level - 1
+    return _Ct(ct, lvl, sc)
+
+
+def _r_mulrelin(ring, x, y, rlk):
+    l = min(x.level, y.level)
+    a, b = _r_drop(x, l).a, _r_drop(y, l).a
+    mr = np.zeros_like(a)
+    ol.lib().orc_mulrelin(ring.h, l, ol.p64(a), ol.p64(b), ol.p64(rlk), ol.p64(mr))
+    return _Ct(mr, l, x.scale * y.scale)
+
+
+class _Poly:
+    def __init__(self, c, max_deg, lead):
+        self.c, self.max_deg, self.lead = list(c), max_deg, lead
+
+    @property
+    def deg(self):
+        return len(self.c) - 1
+
+
+def _cheby_split(p, split):
+    r = _Poly(p.c[:split], split - 1 if p.max_deg == p.deg else p.max_deg - (p.deg - split + 1), False)
+    q = _Poly([0.0] * (p.deg - split + 1), p.max_deg, p.lead)
+    q.c[0] = p.c[split]
+    for j, i in enumerate(range(split + 1, p.deg + 1), start=1):
+        q.c[i - split] = 2 * p.c[i]
+        r.c[split - j] -= p.c[i]
+    return q, r
+
+
+class _ChebyReplay:
+    """lattigo v2.1 / v2.2 EvaluateCheby restated a second time, on oracle ciphertexts (the device mirror is sfgwas_amd/host/gwas.hpp detail::ChebyEval)"""
+    def __init__(self, ring, rlk, SC, op):
+        self.ring, self.rlk, self.SC, self.C = ring, rlk, SC, {1: op}
+        self.n_mul = 0
+
+    def power(self, n):
+        if n in self.C:
+            return
+        a, b = (n + 1) // 2, n // 2
+        c = a - b
+        self.power(a); self.power(b)
+        if c:
+            self.power(c)
+        t = _r_cmult(self.ring, self.C[a], self.C[b], self.rlk, self.SC); self.n_mul += 1
+        t = _r_add(self.ring, t, t)
+        self.C[n] = _r_add_const(self.ring, t, -1.0) if c == 0 else _r_sub(self.ring, t, self.C[c])
+
+    @staticmethod
+    def resplit(p, log_split):
+        return p.lead and log_split > 1 and p.max_deg % (1 << (log_split + 1)) > (1 << (log_split - 1))
+
+    @staticmethod
+    def next_power(p, log_split):
+        np_ = 1 << log_split
+        while np_ < (p.deg >> 1) + 1:
+            np_ <<= 1
+        return np_
+
+    def out_level(self, p, log_split, log_degree):
+        """(level of the result, level of the MulRelin with the power-basis element)"""
+        if p.deg < (1 << log_split):
+            if self.resplit(p, log_split):
+                ld = p.deg.bit_length()
+                return self.out_level(p, ld >> 1, ld)
+            return self.C[p.deg or 1].level - 1, None
+        np_ = self.next_power(p, log_split)
+        q, r = _cheby_split(p, np_)
+        lq, lr = self.out_level(q, log_split, log_degree)[0], self.out_level(r, log_split, log_degree)[0]
+        if lq > lr:
+            lq = lr + 1
+        lm = min(lq, self.C[np_].level)
+        return (min(lm - 1, lr) if lm > lr else min(lm, lr) - 1), lm
+
+    def leaf(self, target, p):
+        top = self.C[p.deg or 1]
+        qi = float(self.ring.moduli[top.level])
+        res = _Ct(np.zeros_like(top.a), top.level, target * qi)
+        if abs(p.c[0]) > 1e-14:
+            res = _r_add_const(self.ring, res, p.c[0])
+        for key in range(p.deg, 0, -1):
+            if not abs(p.c[key]) > 1e-14:
+                continue
+            T = self.C[key]
+            c_real = int(p.c[key] * (target * qi / T.scale))                  # toward zero, as Go's int64()
+            term = _r_mul_int(self.ring, _r_drop(T, top.level), c_real, res.scale)
+            out = np.zeros_like(res.a)
+            ol.lib().orc_ct_addsub(self.ring.h, top.level, ol.p64(res.a), ol.p64(term.a), 0, ol.p64(out))
+            res = _Ct(out, top.level, res.scale)
+        return _r_rescale_once(self.ring, res, self.SC)
+
+    def recurse(self, target, log_split, log_degree, p):
+        if p.deg < (1 << log_split):
+            if self.resplit(p, log_split):
+                ld = p.deg.bit_length()
+                return self.recurse(target, ld >> 1, ld, p)
+            return self.leaf(target, p)
+        np_ = self.next_power(p, log_split)
+        q, r = _cheby_split(p, np_)
+        lm = self.out_level(p, log_split, log_degree)[1]
+        T = self.C[np_]
+        res = self.recurse(target * float(self.ring.moduli[lm]) / T.scale, log_split, log_degree, q)
+        tmp = self.recurse(target, log_split, log_degree, r)
+        if res.level > tmp.level:
+            res = _r_drop(res, tmp.level + 1)
+        res = _r_mulrelin(self.ring, res, T, self.rlk); self.n_mul += 1
+        assert res.level == lm
+        if res.level > tmp.level:
+            return _r_add(self.ring, _r_rescale_once(self.ring, res, self.SC), tmp)
+        return _r_rescale_once(self.ring, _r_add(self.ring, res, tmp), self.SC)
+
+    def evaluate(self, coeffs, target):
+        p = _Poly(coeffs, len(coeffs) - 1, True)
+        log_degree = p.deg.bit_length(); log_split = log_degree >> 1
+        for i in range(2, 1 << log_split):
+            self.power(i)
+        for i in range(log_split, log_degree):
+            self.power(1 << i)
+        return self.recurse(target, log_split, log_degree, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree,A,B", [(14, -6.0, 6.0), (62, -10.0, 10.0)])
+def test_sigmoid_approximation_change_of_variable_and_evaluate_cheby(tmp_path, degree, A, B):
+    """mpc.CSigmoidApprox's local computation (mhe.go:634-667; Degree = 62 on [-10, 10] is configGlobal.toml's default) on device vectors, real keys:
+    (a) words, level and scale equal an oracle replay of every evaluator step of the restated EvaluateCheby (unpinned against lattigo itself);
+    (b) the result decrypts to the sigmoid within the interpolation error; (c) the level budget is the documented ceil(log2(deg + 1)) + 1 (+ 1 for the
+    change of variable), with the leading branch evaluated one level higher (the re-split)."""
+    import pyref
+    from sfgwas_amd import capi
+    capi.lib()
+    ol.build_oracle()
+    exe = build("host_sigmoid_test", with_oracle=True)
+    # A chain with q_i ~ Delta (34-bit primes under the 2^34 scale, as PN15 / PN16 pair 40 / 45-bit primes with their scales): every MulRelin + Rescale divides
+    # by exactly one modulus.  On PN14QP438 itself (35-bit primes, 2^34 scale) lattigo's Rescale rule skips the division whenever q > 2^35 (T_2 would keep scale
+    # 2^68 and its leaf constant one bit), so EvaluateCheby is not meaningful there and the mirror refuses ("scale out of range") instead of returning noise.
+    Q, Pp = ol.small_primes(14, 46, 1) + ol.small_primes(14, 34, 9), ol.small_primes(14, 43, 2)
+    ring = ol.Ring(14, Q, Pp)
+    slots, SC, top, seed, nct = 8192, 2.0 ** 34, 9, 4242, 2
+    sec = ring.gen_secret(seed)
+    rlk = np.zeros(ring.key_words(), dtype=np.uint64)
+    ol.lib().orc_gen_rlk(ring.h, ol.pi8(sec), 4999, ol.p64(rlk))
+    np.array([len(Q), len(Pp)] + Q + Pp, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    (tmp_path / "case.txt").write_text(f"{nct} {top} {degree} {A} {B} {seed}\n")
+    rnd = np.random.default_rng(degree)
+    xs = rnd.uniform(0.9 * A, 0.9 * B, (nct, slots))
+    X = np.stack([ring.encrypt(sec, top, ring.encode_coeffs(xs[k], SC), 700 + k) for k in range(nct)])
+    X.tofile(tmp_path / "x.bin")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+    coeffs = np.fromfile(tmp_path / "coeffs.bin", dtype=np.float64)
+    # ckks.Approximate, recomputed: the nodes' cosines may differ in the last bit between libm and numpy, the coefficients by ~1e-16
+    n = degree + 1
+    nodes = 0.5 * (A + B) + 0.5 * (B - A) * np.cos((np.arange(1, n + 1) - 0.5) * (np.pi / n))
+    u = (2 * nodes - A - B) / (B - A)
+    Tm = np.polynomial.chebyshev.chebvander(u, degree)
+    mine = (1.0 / (1 + np.exp(-nodes))) @ Tm * (2.0 / n); mine[0] /= 2
+    assert coeffs.shape == (n,) and np.max(np.abs(coeffs - mine)) < 1e-13
+    n_out, lvl, sc = (tmp_path / "meta.txt").read_text().split()
+    got = np.fromfile(tmp_path / "y.bin", dtype=np.uint64).reshape(nct, 2, int(lvl) + 1, ring.N)
+    depth = int(np.ceil(np.log2(degree + 1))) + 1
+    assert top - 1 - int(lvl) <= depth, f"EvaluateCheby used {top - 1 - int(lvl)} levels, documented bound {depth}"
+    for k in range(nct):
+        x = _Ct(X[k], top, SC)
+        y = _r_mul_const(ring, x, 2 / (B - A))
+        y = _r_rescale_once(ring, y, SC)
+        y = _r_add_const(ring, y, (-A - B) / (B - A))
+        rep = _ChebyReplay(ring, rlk, SC, y)
+        w = rep.evaluate(list(coeffs), y.scale)
+        assert (int(lvl), float(sc)) == (w.level, w.scale), f"level / scale ({lvl}, {sc}) vs the replay's ({w.level}, {w.scale!r})"
+        assert np.array_equal(got[k], w.a), f"ciphertext {k}: words"
+        res = ring.decrypt_residues(sec, w.level, got[k])
+        nm = min(4, w.level + 1)
+        big = pyref.crt_centered([res[m] for m in range(nm)], ring.moduli[:nm])
+        dec = pyref.decode(np.array([float(v) for v in big]) / w.scale, ring.N).real
+        ref = 1.0 / (1 + np.exp(-xs[k]))
+        cheb = np.polynomial.chebyshev.chebval((2 * xs[k] - A - B) / (B - A), coeffs)
+        assert np.max(np.abs(dec - cheb)) < 2e-4, f"decrypted values are off the interpolant by {np.max(np.abs(dec - cheb))}"
+        assert np.max(np.abs(dec - ref)) < (2e-2 if degree < 20 else 2e-3), f"decrypted values are off the sigmoid by {np.max(np.abs(dec - ref))}"
