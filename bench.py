@@ -383,6 +383,8 @@ def main():
 
     def enable_pt_cache():
         want = os.environ.get("SFG_BENCH_PT_CACHE_GB", "auto")
+        if want == "auto" and use_dist and args.backend == "gloo" and not solo:
+            want = "0"                                  # rehearsal: the ranks share one GPU, "what is free" is not this rank's to take
         if want == "0":
             return
         torch.cuda.synchronize()
