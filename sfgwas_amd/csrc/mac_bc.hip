@@ -328,6 +328,10 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
         while (l < L) {
             const bool big = is_big[l]; int e = l; while (e < L && is_big[e] == (int)big) e++;
             if (!big && !st.pt_packed) SFG_FAIL(ctx, "sfg_mac: the broadcast MAC needs packed-limb plaintext rows for the small moduli");
+            if (!big && ctx->cfg.mac_i8 && st.pt_half) {            // SFG_MAC_IMPL=i8 (experimental): the small moduli on the int8 matrix core, mac_i8.hip
+                SFG_TRY(launch_mac_i8_small(ctx, rotf, rows_per_k * rowf, rowf, plane_of[l], pt, out, K, R, r0, Ncols, l, e - l, accumulate, st));
+                l = e; continue;
+            }
             BcArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev();
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = st.pt_half ? N / 2 : N; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;

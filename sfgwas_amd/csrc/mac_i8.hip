@@ -1,0 +1,198 @@
+// The ring MAC of the small (< 2^36) moduli on the int8 matrix core (SFG_MAC_IMPL=i8; experimental, not the default).
+// Same contract as the small-modulus launches of launch_mac_bc: out[n][r][l][x] (+)= sum_k pt[k][n][l][x'] * rotf[k][r][plane l][x] mod q_l, x' = x or N-1-x.
+//
+// Per coefficient x that is a 32 x 96 x K GEMM over exact integers.  Both operands are written as five signed base-256 digits (pt canonical < 2^36, rot centred
+// < 2^35 in magnitude: the top digit stays within +-9), the 25 digit products of a k-step go through v_mfma_i32_16x16x64_i8 into NINE int32 sums per output - one per
+// digit-weight a + b, each |sum| <= 5 K 2^14 < 2^31 for K < 26 000 - and the nine are recombined mod q by Horner in the epilogue.  Nothing is rounded anywhere.
+//
+// The matrix instruction contracts over k, so a lane needs 16 consecutive k of ONE coefficient; the product's operands are coefficient-contiguous (a plaintext NTT
+// owns all coefficients of one k).  Hence two transposition kernels into MFMA register order (1 KiB = 64 lanes x 16 bytes per operand tile, chunk of 64 k and digit):
+//   k_i8_pack_rot  rotf planes  -> A [m][x < N][ch][rt 2][a 5][1 KiB]       once per rot operand (a group's rotation cache serves every block column)
+//   k_i8_pack_pt   panel words  -> B [m][c < N/2][jt][ch][b 5][1 KiB]       once per launch
+// and the MAC proper streams both from global memory without LDS: a wave owns one coefficient pair (c, N-1-c share the plaintext word: the pt tile is loaded once for
+// 64 rows) x 16 columns = 4 row tiles x 9 weights = 36 accumulator tiles; the <= 6 column waves of a pair form a workgroup and share the rot tiles through the cache.
+// Results leave in tile order (T [m][c][half][jt][rt][lane][4]) and k_i8_untile adds them into the canonical accumulators with coefficient-contiguous runs.
+#include "common.hpp"
+#include "kernels.hpp"
+#include <algorithm>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int I8_ND = 5;                   // digits per operand word
+constexpr int I8_PC = 8;                   // coefficients per packing workgroup (64-byte source runs)
+
+// five signed base-256 digits of an integer |v| < 2^39 (two's complement arithmetic shift)
+__device__ __forceinline__ void i8_digits(long long v, int8_t d[I8_ND]) {
+#pragma unroll
+    for (int i = 0; i < I8_ND; i++) { const long long lo = ((v + 128) & 255) - 128; d[i] = (int8_t)lo; v = (v - lo) >> 8; }
+}
+// byte offset of element (row-or-column i < 16, kk < 64) inside a 1 KiB operand tile: lane = i + 16 (kk / 16), byte kk % 16
+__device__ __forceinline__ int i8_tile_off(int i, int kk) { return ((i + 16 * (kk >> 4)) << 4) + (kk & 15); }
+
+struct I8Args {
+    const double *rotf; const u64 *pt; u64 *out;
+    size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
+    int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt;
+    int8_t *A, *B; u64 *T;
+};
+
+// ---- rot planes -> A.  workgroup = (modulus m, chunk ch, 8 coefficients): 64 k x 32 rows x 8 coefficients through an 80 KiB digit image
+__global__ void __launch_bounds__(256) k_i8_pack_rot(I8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 8][rt 2][a 5][1 KiB]
+    const int N = SFG_N, tid = threadIdx.x;
+    const int xb = blockIdx.x % (N / I8_PC), ch = (blockIdx.x / (N / I8_PC)) % a.nch, m = blockIdx.x / (N / I8_PC) / a.nch;
+    const int x0 = xb * I8_PC, cc = tid & (I8_PC - 1);
+    const double *src = a.rotf + (size_t)(a.plane0 + m) * N + x0 + cc;
+    for (int p = tid / I8_PC; p < 64 * 32; p += 256 / I8_PC) {
+        const int kk = p >> 5, r = p & 31, k = ch * 64 + kk;
+        long long v = 0;
+        if (k < a.K && a.r0 + r < a.R && r < 32) v = (long long)src[(size_t)k * a.rotf_k_stride + (size_t)(a.r0 + r) * a.rotf_r_stride];
+        int8_t d[I8_ND]; i8_digits(v, d);
+        int8_t *o = img + cc * (2 * I8_ND * 1024) + (r >> 4) * (I8_ND * 1024) + i8_tile_off(r & 15, kk);
+#pragma unroll
+        for (int i = 0; i < I8_ND; i++) o[i * 1024] = d[i];
+    }
+    __syncthreads();
+    for (int c2 = 0; c2 < I8_PC; c2++) {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.A + ((((size_t)m * N + x0 + c2) * a.nch + ch) * 2 * I8_ND) * 1024);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(img + c2 * (2 * I8_ND * 1024));
+        for (int i = tid; i < 2 * I8_ND * 64; i += 256) dst[i] = s4[i];
+    }
+}
+// ---- panel words -> B.  workgroup = (modulus m, column tile jt, chunk ch, 8 coefficients): 64 k x 16 columns x 8 coefficients through a 40 KiB digit image
+__global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 8][b 5][1 KiB]
+    const int H = SFG_N / 2, tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int cb = b % (H / I8_PC); b /= H / I8_PC;
+    const int ch = b % a.nch; b /= a.nch;
+    const int jt = b % a.njt, m = b / a.njt;
+    const int c0 = cb * I8_PC, cc = tid & (I8_PC - 1);
+    const u64 *src = a.pt + (size_t)(a.l0 + m) * a.pt_l_stride + c0 + cc;
+    for (int p = tid / I8_PC; p < 64 * 16; p += 256 / I8_PC) {
+        const int kk = p >> 4, j = p & 15, k = ch * 64 + kk, n = jt * 16 + j;
+        long long v = 0;
+        if (k < a.K && n < a.Ncols) {
+            const u64 w = src[(size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride];
+            v = (long long)((w & 0xFFFULL) | (((w >> 16) & 0xFFFULL) << 12) | ((w >> 32) << 24));       // packed-limb panel word (pack_limbs)
+        }
+        int8_t d[I8_ND]; i8_digits(v, d);
+        int8_t *o = img + cc * (I8_ND * 1024) + i8_tile_off(j, kk);
+#pragma unroll
+        for (int i = 0; i < I8_ND; i++) o[i * 1024] = d[i];
+    }
+    __syncthreads();
+    for (int c2 = 0; c2 < I8_PC; c2++) {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.B + (((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * I8_ND) * 1024);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(img + c2 * (I8_ND * 1024));
+        for (int i = tid; i < I8_ND * 64; i += 256) dst[i] = s4[i];
+    }
+}
+// ---- the MAC.  grid = nl * N/2 workgroups of njt waves
+__global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *modc) {
+    const int N = SFG_N, H = N / 2;
+    const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6;
+    const int c = blockIdx.x % H, m = blockIdx.x / H;
+    const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
+    v4i acc[4][9];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s = 0; s < 9; s++) acc[t][s] = (v4i){0, 0, 0, 0};
+    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * I8_ND * 64 + lane;
+    const uint4 *A0 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + c) * a.nch) * 2 * I8_ND * 64 + lane;
+    const uint4 *A1 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + (N - 1 - c)) * a.nch) * 2 * I8_ND * 64 + lane;
+#pragma unroll 1
+    for (int ch = 0; ch < a.nch; ch++) {
+        v4i b[I8_ND];
+#pragma unroll
+        for (int d = 0; d < I8_ND; d++) { const uint4 w = Bp[(size_t)(ch * I8_ND + d) * 64]; b[d] = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint4 *Ap = (t < 2 ? A0 : A1) + (size_t)((ch * 2 + (t & 1)) * I8_ND) * 64;
+#pragma unroll
+            for (int x = 0; x < I8_ND; x++) {
+                const uint4 w = Ap[(size_t)x * 64];
+                const v4i av = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+#pragma unroll
+                for (int d = 0; d < I8_ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[d], acc[t][x + d], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                 // the column waves of a pair stay within one chunk of each other: the rot tiles come from HBM once
+    }
+    // sum_s D_s 256^s mod q by Horner: |r| <= q/2 and |D| < 2^31, so r 256 + D is exact in fp64; then canonical
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * a.njt + jt) * 2 + (t & 1)) * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            double r = (double)acc[t][8][e];
+#pragma unroll
+            for (int s = 7; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
+            if (r < 0) r += q;
+            o[e] = (u64)r;
+        }
+    }
+}
+// ---- tile-ordered results -> canonical accumulators.  workgroup = (m, 16 coefficient pairs, half, jt, rt): 256 (n, r) rows x 16 coefficients through LDS
+__global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *modc) {
+    __shared__ u64 img[16][257];
+    const int N = SFG_N, H = N / 2, tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int rt = b & 1; b >>= 1;
+    const int jt = b % a.njt; b /= a.njt;
+    const int half = b & 1; b >>= 1;
+    const int cb = b % (H / 16), m = b / (H / 16);
+    const double q = modc[a.l0 + m].q;
+    for (int cc = 0; cc < 16; cc++) {
+        const u64 *src = a.T + (((((size_t)m * H + cb * 16 + cc) * 2 + half) * a.njt + jt) * 2 + rt) * 256;
+        img[cc][tid] = src[tid];                                       // tid = lane * 4 + e
+    }
+    __syncthreads();
+    // element (lane, e) of a tile: column j = lane & 15, row i = (lane >> 4) * 4 + e
+    const int cc = tid & 15;
+    const int x = half ? N - 1 - (cb * 16 + cc) : cb * 16 + cc;
+    for (int p = tid >> 4; p < 256; p += 16) {
+        const int lane = p >> 2, e = p & 3, n = jt * 16 + (lane & 15), r = a.r0 + rt * 16 + (lane >> 4) * 4 + e;
+        if (n >= a.Ncols || r >= a.R) continue;
+        u64 *o = a.out + (size_t)n * a.out_n_stride + (size_t)r * a.out_r_stride + (size_t)(a.l0 + m) * N + x;
+        double v = (double)img[cc][p];
+        if (a.accumulate) { v += (double)*o; if (v >= q) v -= q; }
+        *o = (u64)v;
+    }
+}
+
+int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
+                        int l0, int nl, int accumulate, const MacStrides &st) {
+    const int N = SFG_N, H = N / 2;
+    if (!st.pt_half || !st.pt_packed) SFG_FAIL(ctx, "sfg_mac (i8): needs half-row packed-limb plaintext rows");
+    if (Ncols > 96) SFG_FAIL(ctx, "sfg_mac (i8): more than 96 columns per launch");
+    if (K >= 26000) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums");
+    I8Args a;
+    a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
+    a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = H; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
+    a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
+    a.nch = (K + 63) / 64; a.njt = (Ncols + 15) / 16;
+    const size_t nA = (size_t)nl * N * a.nch * 2 * I8_ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * I8_ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
+    SFG_TRY(sfg_scratch(ctx, "mi8.A", nA, (void **)&a.A));
+    SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
+    SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
+    static bool attr_set = false;
+    if (!attr_set) {
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * I8_ND * 1024));
+        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_pt, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * I8_ND * 1024));
+        attr_set = true;
+    }
+    { PhaseTimer t(ctx, "mac_i8_pack_rot");
+      hipLaunchKernelGGL(k_i8_pack_rot, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * I8_ND * 1024, ctx->stream, a);
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1); }
+    { PhaseTimer t(ctx, "mac_i8_pack_pt");
+      hipLaunchKernelGGL(k_i8_pack_pt, dim3((unsigned)((size_t)nl * a.njt * a.nch * (H / I8_PC))), dim3(256), I8_PC * I8_ND * 1024, ctx->stream, a);
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1); }
+    { PhaseTimer t(ctx, "mac_small");
+      hipLaunchKernelGGL(k_mac_i8, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
+      SFG_HIP(ctx, hipGetLastError());
+      hipLaunchKernelGGL(k_i8_untile, dim3((unsigned)((size_t)nl * (H / 16) * 2 * a.njt * 2)), dim3(256), 0, ctx->stream, a, ctx->modc);
+      SFG_HIP(ctx, hipGetLastError()); t.stop(2); }
+    return 0;
+}

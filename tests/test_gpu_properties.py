@@ -146,13 +146,13 @@ np.save(sys.argv[1], h)
 def test_group_size_and_mac_kernel_invariance(tmp_path):
     """the same product in separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8, the register-staged MAC, and a small
     accumulator budget (one block column per pass -> the product-wide rotation cache is built once and reused), the round-1 LDS-DMA MAC in both
-    workgroup shapes, the plain plaintext panel, the full-image NTT kernels"""
+    workgroup shapes, the plain plaintext panel, the full-image NTT kernels, the experimental int8 matrix-core MAC (SFG_MAC_IMPL=i8)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"}),
                        ("budget", {"SFG_MM_ACC_BUDGET_MB": "300"}), ("budget_g1", {"SFG_MM_ACC_BUDGET_MB": "300", "SFG_MM_GROUP": "1"}),
                        ("dma", {"SFG_MAC_IMPL": "dma"}), ("dma_wc2", {"SFG_MAC_IMPL": "dma", "SFG_MAC_WC": "2"}), ("plain_pt", {"SFG_MAC_PT": "plain"}),
-                       ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"})]:
+                       ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"}), ("i8", {"SFG_MAC_IMPL": "i8"}), ("i8_g1", {"SFG_MAC_IMPL": "i8", "SFG_MM_GROUP": "1"})]:
         f = str(tmp_path / (name + ".npy"))
         e = dict(os.environ); e.update(envv)
         r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
@@ -164,6 +164,7 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     assert np.array_equal(outs[0], outs[5]) and np.array_equal(outs[0], outs[6]), "DPP-broadcast and 8 x 3-tile LDS-DMA MAC kernels (4- / 8-wave workgroups) disagree"
     assert np.array_equal(outs[0], outs[7]), "packed-limb and plain plaintext panels disagree"
     assert np.array_equal(outs[0], outs[8]), "split and full-image NTT kernels disagree"
+    assert np.array_equal(outs[0], outs[9]) and np.array_equal(outs[0], outs[10]), "the experimental int8 matrix-core MAC (five signed base-256 digits, nine int32 sums) disagrees"
     assert outs[0].any()
 
 
