@@ -23,6 +23,7 @@ int mac_dma_set_attrs(sfg_ctx *ctx);
 int mac_bc_set_attrs(sfg_ctx *ctx);
 int ntt_set_attrs(sfg_ctx *ctx);
 int encode_set_attrs(sfg_ctx *ctx);
+int mac_i8_set_attrs(sfg_ctx *ctx);
 
 static void read_config(SfgConfig &c) {
     auto env = [](const char *n) { return getenv(n); };
@@ -132,7 +133,7 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     ctx_bind_shared(ctx, sh);
     if (sfg_encoder_init(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
     // dynamic-LDS limits are per (function, device): set here for this context's device, not behind process-wide flags
-    if (mac_dma_set_attrs(ctx) || mac_bc_set_attrs(ctx) || ntt_set_attrs(ctx) || encode_set_attrs(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
+    if (mac_dma_set_attrs(ctx) || mac_bc_set_attrs(ctx) || ntt_set_attrs(ctx) || encode_set_attrs(ctx) || mac_i8_set_attrs(ctx)) { std::string e = ctx->err; return fail(e.c_str()); }
     *out = ctx;
     return 0;
 }

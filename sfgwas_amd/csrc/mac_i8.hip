@@ -162,6 +162,11 @@ __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *mod
     }
 }
 
+int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (ctx.hip)
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * I8_ND * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_pt, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * I8_ND * 1024));
+    return 0;
+}
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                         int l0, int nl, int accumulate, const MacStrides &st) {
     const int N = SFG_N, H = N / 2;
@@ -177,12 +182,6 @@ int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, 
     SFG_TRY(sfg_scratch(ctx, "mi8.A", nA, (void **)&a.A));
     SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
-    static bool attr_set = false;
-    if (!attr_set) {
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * I8_ND * 1024));
-        SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_pt, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * I8_ND * 1024));
-        attr_set = true;
-    }
     { PhaseTimer t(ctx, "mac_i8_pack_rot");
       hipLaunchKernelGGL(k_i8_pack_rot, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * I8_ND * 1024, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1); }
