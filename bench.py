@@ -300,7 +300,7 @@ def main():
     phase_tot = {}
 
     def add_phases():
-        for ph in ("rotate", "skew", "encode", "mac", "mac_small", "mac_big"):
+        for ph in ("rotate", "skew", "encode", "mac", "mac_small", "mac_big", "ntt_plain", "ntt_plain_all", "mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile"):
             ms = ctx.phase_ms(ph)
             if ms >= 0:
                 n = lib.sfg_last_phase_launches(ctx.h, ph.encode())
@@ -481,9 +481,56 @@ def main():
         res["encoder_near_ties"] = {"count": near_ties, "within_2^-50": unprovable.value, "what": "encoder coefficients within 2^-40 of a rounding tie on rank 0 (0 = every plaintext provably "
                                                                  "rounded as the reference's 256-bit EncoderBig rounds it); a non-zero within_2^-50 count makes the library's synchronising entry points fail "
                                                                  "(about once per 10^15 coefficients; 2 x 10^11 per step here)"}
-        # ---- roofline of the dominant kernel (k_mac_dma, small-modulus instance)
+        # ---- roofline of the dominant kernel
         ms_small, n_small, by_small = phase_tot.get("mac_small", [0.0, 0, 0.0])
-        if n_small:
+        if n_small and "mac_i8_pack_pt" in phase_tot:
+            # default build: the small-modulus MAC runs on the int8 matrix core (mac_i8.hip) and is HBM bound; the kernel with the largest total time in the
+            # timed region is then the panel NTT (fp64 vector issue bound).  Both are measured live (HIP events on the library's stream; the NTT on every 16th
+            # of its ~50 000 launches per step, all launches counted) and the larger total is reported as `roofline`, the other one inside it.
+            ms_ntt, n_ntt, by_ntt = phase_tot.get("ntt_plain", [0.0, 0, 0.0])
+            n_ntt_all = phase_tot.get("ntt_plain_all", [0.0, 0, 0.0])[1]
+            ntt_avg_ms = ms_ntt / max(n_ntt, 1)
+            ntt_total_ms = ntt_avg_ms * n_ntt_all
+            bytes_per_plain = (N // 2) * (8 + 5 * (L - 1) + 8)                   # coefficient row in, five digit planes per small modulus + one word row out
+            plains_per_launch = (by_ntt / max(n_ntt, 1)) / bytes_per_plain
+            NTT_FP64_INSTR = 2016                                               # fp64 vector instructions per thread of k_ntt_half3 (static count of the gfx950 ISA)
+            ntt_instr_s = plains_per_launch * L * 256 * NTT_FP64_INSTR / (ntt_avg_ms * 1e-3) if n_ntt else 0.0
+            ntt_blk = {"bound": "valu_fp64", "achieved": 2.0 * ntt_instr_s / 1e12, "peak": 2.0 * FP64_VALU_SPEC_FMA_S / 1e12, "unit": "TFLOP/s",
+                       "frac": ntt_instr_s / FP64_VALU_SPEC_FMA_S, "kernel": "k_ntt_half3<false, true>", "avg_launch_ms": ntt_avg_ms, "launches": n_ntt_all,
+                       "launches_timed": n_ntt, "total_ms_in_timed_region": ntt_total_ms,
+                       "what": "plaintext (panel) NTT: 2016 fp64 vector instructions per thread and (plaintext, modulus) row (13 stages x 16 butterflies x 8 + the degenerate first "
+                               "stage + canonicalisation), one issue slot = 64 lanes counted as 2 flop (FMA-equivalent; the mix is mul, rndne, fma, add) against the fp64 vector peak "
+                               "256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz",
+                       "hbm": {"alg_bytes_per_launch": by_ntt / max(n_ntt, 1), "achieved_GBps": (by_ntt / max(ms_ntt, 1e-9)) / 1e6, "peak_GBps": HBM_PEAK_GBS,
+                               "frac": (by_ntt / max(ms_ntt, 1e-9)) / 1e6 / HBM_PEAK_GBS}}
+            mac_gbps = by_small / (ms_small * 1e-3) / 1e9
+            padded_macs_s = 2 * nbr_x * mct_x * D * D * 2 * KP * (L - 1) * N * args.steps / world / (ms_small * 1e-3)
+            mac_blk = {"bound": "hbm", "achieved": mac_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mac_gbps / HBM_PEAK_GBS, "kernel": "k_mac_i8",
+                       "avg_launch_ms": ms_small / n_small, "launches": n_small, "total_ms_in_timed_region": ms_small, "alg_bytes_per_launch": by_small / n_small,
+                       "padded_ring_macs_per_s_in_kernel": padded_macs_s, "int8_macs_per_s_in_kernel": 25.0 * padded_macs_s * (32 * 96) / (30 * 91),
+                       "what": "ring MAC of the four 35-bit moduli on v_mfma_i32_16x16x64_i8: operands as five signed base-256 digits, 25 digit products per ring-MAC into nine "
+                               "int32 sums, Horner mod q in the epilogue (exact); bytes = both k-contiguous digit streams read once + tile-ordered results written",
+                       "helpers_ms_per_step": {k: phase_tot[k][0] / args.steps for k in ("mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile") if k in phase_tot}}
+            dom, other = (ntt_blk, mac_blk) if ntt_total_ms >= ms_small else (mac_blk, ntt_blk)
+            alg_step = 2 * n_ind * m_snp + (KP * nbr_x + KP * mct_x) * ctw * 8 + (KP * mct_x + KP * nbr_x) * outw * 8
+            hbm_alg = alg_step * args.steps / dt / 1e9
+            traffic, traffic_src = None, "no counter pass of this kernel in profiles/"
+            try:
+                path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_per_launch_i8.json")
+                if os.path.exists(path):
+                    pm = json.load(open(path))
+                    ks = [k for k in pm if dom["kernel"].split("<")[0] in k and not k.startswith("_")]
+                    if ks:
+                        best = max(ks, key=lambda k: pm[k]["launches"])
+                        traffic = pm[best]["hbm_bytes_per_launch"]
+                        traffic_src = (f"profiles/r03_pmc_traffic_per_launch_i8.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at config {pm.get('_config')}; "
+                                       "this kernel's launch shape - 1024 plaintexts x 5 moduli - is the same at every config)")
+            except Exception:
+                pass
+            res["roofline"] = dict(dom, traffic=traffic, traffic_source=traffic_src, second_kernel=other,
+                                   hbm_algorithmic={"bytes_per_step": alg_step, "achieved_GBps": hbm_alg, "frac": hbm_alg / HBM_PEAK_GBS,
+                                                    "what": "SURVEY §8(d): int8 genotypes once per product + ciphertexts in/out, divided by the WHOLE step time"})
+        elif n_small:
             nl_small = L - 1
             avg_ms = ms_small / n_small
             achieved = by_small / (ms_small * 1e-3) / 1e9

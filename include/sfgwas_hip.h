@@ -285,7 +285,9 @@ int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, 
  * (bi, i) of its job range (job = bi*s + i: the decomposition of an input is shared by its 91 rotations) into job-major staging
  *     staged[job - job0][baby][poly][rowf],
  * the ranks all-gather the staging buffers and scatter them into the cache layout.  All 91 baby steps are rotated (rotations the reference's
- * active-baby table would skip meet zero plaintexts only), so every baby rotation key must be loaded (crypto.go:252-263 generates them all). */
+ * active-baby table would skip meet zero plaintexts only), so every baby rotation key must be loaded (crypto.go:252-263 generates them all).
+ * A cache must be (re)written through these entry points only: the MAC keeps a transposed copy of the operand it last multiplied with, keyed by the cache
+ * pointer and a generation count that sfg_rotcache_scatter_dev / sfg_rotcache_build_rows_dev advance. */
 int sfg_rotcache_layout(sfg_ctx *ctx, int s, int max_level, size_t *job_doubles, size_t *tail_doubles);
 int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, int nbr, int job0, int job1, double *staged_dev);
 /* staged jobs [job0, job1) -> cache rows [row0, row0 + nrows); also zeroes the tail */

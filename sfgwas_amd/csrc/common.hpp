@@ -53,7 +53,7 @@ struct sfg_geno {
 struct SfgConfig {
     bool mac_reg = false;          // SFG_MAC_IMPL=reg      register-staged MAC kernel (mac.hip)
     bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
-    bool mac_i8 = false;           // SFG_MAC_IMPL=i8       (experimental) small moduli on the int8 matrix core (mac_i8.hip), big ones on the DPP-broadcast kernel
+    bool mac_i8 = true;            // SFG_MAC_IMPL=bc       the DPP-broadcast fp64 kernel for every modulus (round 2's MAC) instead of: small moduli on the int8 matrix core (mac_i8.hip), the 46-bit one on the DPP-broadcast kernel
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
     bool mm_group_auto = true;     //                       (unset) 16 block rows per launch when the plaintext panel and the rotation operands of such a group fit the free HBM, else 8
@@ -104,6 +104,9 @@ struct sfg_ctx {
     ModConst *modc = nullptr;
     ModConst modc_host[SFG_MAXMOD];
     SfgConfig cfg;
+    // int8 MAC (mac_i8.hip): generation of the fp64 rot operands - bumped by whoever rewrites a rotation cache - and the two transposed copies keyed by it
+    unsigned ntt_plain_seq = 0;      // sampling counter of the panel-NTT phase timer (encode.hip)
+    u64 i8_gen = 1; const void *i8_src[2] = {nullptr, nullptr}; u64 i8_sig[2][2] = {{0, 0}, {0, 0}}; int i8_next = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t user_stream = nullptr;   // installed by sfg_ctx_set_stream (nullptr = own_stream is the main queue)
     hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC

@@ -538,10 +538,18 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
             SFG_HIP(ctx, hipGetLastError());
         }
         if (cmode == 2) pc = pcache->slot + (size_t)(shift0 + s0) * SFG_SLOTS;
+        // the panel NTT is timed on a sample (every 16th launch carries an event pair: 50 000 launches per power iteration) and counted in full
+        const bool sampled = half_rows && G > 0 && (ctx->ntt_plain_seq++ & 15) == 0;
+        PhaseTimer tn(ctx, "ntt_plain", sampled);
+        if (half_rows && G > 0) { PhaseStat &all = ctx->phases["ntt_plain_all"]; all.launches += 1; }
         if (cmode == 3) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm)); }
         else if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
         else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));
+        if (sampled) {      // algorithmic bytes: the coefficient row in, L output rows of N/2 words (or five digit planes of N/2 bytes for the int8 MAC's moduli)
+            double wr = 0; for (int l = 0; l < L; l++) wr += ((packed_mask >> 31) && ((packed_mask >> l) & 1u)) ? 5.0 : 8.0;
+            tn.stop(1, (double)nb * (SFG_N / 2) * (8.0 + wr));
+        }
     }
     return 0;
 }

@@ -11,7 +11,7 @@ struct RowMap { int rpg; size_t gstride_in, gstride_out; };
 // where the plaintext of diagonal `shift` (= shift0 + index in the batch) of block row g lands inside a panel that holds G
 // block rows: slot ((shift / 91) * G + g) * 91 + shift % 91, i.e. [giant][g][baby] so that k = g*91 + baby is contiguous.
 // G == 0: dense (slot = index in the batch)
-struct PanelMap { int G, g, shift0; unsigned packed_mask = 0; };   // packed_mask bit l: rows of modulus l are written as packed-limb words (mac_dma.hip)
+struct PanelMap { int G, g, shift0; unsigned packed_mask = 0; };   // packed_mask bit l: rows of modulus l are written as packed-limb words (mac_dma.hip); bit 31: as digit planes instead (mac_i8.hip)
 
 // ntt.hip
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
@@ -22,7 +22,7 @@ int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 // mac.hip
-struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; };   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
+struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; };   // pt_digits: packed rows hold five digit planes (int8 MAC)   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                         int l0, int nl, int accumulate, const MacStrides &st);       // mac_i8.hip
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate);

@@ -320,6 +320,7 @@ int mac_dma_planes(sfg_ctx *ctx, int L, std::vector<int> &plane_of, std::vector<
 
 // convert nrows polynomial rows [nrows][nl_rot][N] (ciphertexts are two consecutive rows) to the fp64 operand form rotf[nrows][nplanes*N]
 int launch_rot_to_f64(sfg_ctx *ctx, const u64 *rot, size_t nrows, int nl_rot, int L, double *rotf) {
+    ctx->i8_gen++;                  // (as launch_rotate_right_indexed_f64)
     const int centre = mac_dma_packed_mask(ctx, L) != 0;
     const int N = SFG_N;
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);

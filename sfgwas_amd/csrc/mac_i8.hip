@@ -32,7 +32,7 @@ __device__ __forceinline__ int i8_tile_off(int i, int kk) { return ((i + 16 * (k
 struct I8Args {
     const double *rotf; const u64 *pt; u64 *out;
     size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
-    int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt;
+    int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt, pt_digits;
     int8_t *A, *B; u64 *T;
 };
 
@@ -59,33 +59,85 @@ __global__ void __launch_bounds__(256) k_i8_pack_rot(I8Args a) {
         for (int i = tid; i < 2 * I8_ND * 64; i += 256) dst[i] = s4[i];
     }
 }
-// ---- panel words -> B.  workgroup = (modulus m, column tile jt, chunk ch, 8 coefficients): 64 k x 16 columns x 8 coefficients through a 40 KiB digit image
+// ---- panel words -> B.  workgroup = (modulus m, column tile jt, 16 k, 32 coefficients): 256 (k, column) rows of 256 contiguous bytes in, 160 pieces of 256
+// contiguous bytes out (the 16-k quarter of a 1 KiB tile).  A thread takes four consecutive k of one (column, coefficient), so a digit of the four is one dword.
+constexpr int I8_PP = 32;                                   // coefficients per workgroup
+constexpr int I8_PSTR = I8_ND * 256 + 4;                    // bytes per coefficient in the image (+ 4: lanes = coefficients fall on distinct banks)
 __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
-    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 8][b 5][1 KiB]
+    __shared__ __attribute__((aligned(16))) unsigned char img[I8_PP * I8_PSTR];       // [cc 32][b 5][j 16][kk 16]
     const int H = SFG_N / 2, tid = threadIdx.x;
     int b = blockIdx.x;
-    const int cb = b % (H / I8_PC); b /= H / I8_PC;
-    const int ch = b % a.nch; b /= a.nch;
+    const int cb = b % (H / I8_PP); b /= H / I8_PP;
+    const int kq = b % (a.nch * 4); b /= a.nch * 4;
     const int jt = b % a.njt, m = b / a.njt;
-    const int c0 = cb * I8_PC, cc = tid & (I8_PC - 1);
+    const int c0 = cb * I8_PP, cc = tid & (I8_PP - 1), slot = tid >> 5;
     const u64 *src = a.pt + (size_t)(a.l0 + m) * a.pt_l_stride + c0 + cc;
-    for (int p = tid / I8_PC; p < 64 * 16; p += 256 / I8_PC) {
-        const int kk = p >> 4, j = p & 15, k = ch * 64 + kk, n = jt * 16 + j;
-        long long v = 0;
-        if (k < a.K && n < a.Ncols) {
-            const u64 w = src[(size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride];
-            v = (long long)((w & 0xFFFULL) | (((w >> 16) & 0xFFFULL) << 12) | ((w >> 32) << 24));       // packed-limb panel word (pack_limbs)
-        }
-        int8_t d[I8_ND]; i8_digits(v, d);
-        int8_t *o = img + cc * (I8_ND * 1024) + i8_tile_off(j, kk);
+#pragma unroll 2
+    for (int it = 0; it < 8; it++) {
+        const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
+        unsigned dw[I8_ND] = {0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < I8_ND; i++) o[i * 1024] = d[i];
+        for (int x = 0; x < 4; x++) {
+            const int k = kq * 16 + k4 * 4 + x;
+            long long v = 0;
+            if (k < a.K && n < a.Ncols) {
+                const u64 w = src[(size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride];
+                v = (long long)((w & 0xFFFULL) | (((w >> 16) & 0xFFFULL) << 12) | ((w >> 32) << 24));       // packed-limb panel word (pack_limbs)
+            }
+            int8_t d[I8_ND]; i8_digits(v, d);
+#pragma unroll
+            for (int i = 0; i < I8_ND; i++) dw[i] |= (unsigned)(uint8_t)d[i] << (8 * x);
+        }
+#pragma unroll
+        for (int i = 0; i < I8_ND; i++) *reinterpret_cast<unsigned *>(img + cc * I8_PSTR + i * 256 + j * 16 + k4 * 4) = dw[i];
     }
     __syncthreads();
-    for (int c2 = 0; c2 < I8_PC; c2++) {
-        uint4 *dst = reinterpret_cast<uint4 *>(a.B + (((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * I8_ND) * 1024);
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(img + c2 * (I8_ND * 1024));
-        for (int i = tid; i < I8_ND * 64; i += 256) dst[i] = s4[i];
+    // piece (cc, digit): 256 bytes = 16 lanes x 16 bytes, at byte (kq % 4) * 256 of its tile
+    const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
+    for (int pc = tid >> 4; pc < I8_PP * I8_ND; pc += 16) {
+        const int c2 = pc / I8_ND, d = pc % I8_ND;
+        const unsigned *sp = reinterpret_cast<const unsigned *>(img + c2 * I8_PSTR + d * 256 + l16 * 16);
+        const uint4 w = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * I8_ND + d) * 1024) + g * 256 + l16 * 16) = w;
+    }
+}
+// ---- the same from digit planes (the plaintext NTT's output when the int8 MAC is on: five planes of N/2 bytes in a row's 64 KiB).  workgroup = (modulus m,
+// column tile jt, 16 k, 128 coefficients), one digit at a time: 256 (k, column) rows of 128 contiguous bytes in; a lane takes four consecutive k of FOUR consecutive
+// coefficients (a dword each) and a 4 x 4 byte transpose turns them into one dword of four k per coefficient.  Image [cc 128][j 16][k4 4] dwords, j and k4 XORed with
+// bits of the lane's coefficient group so that the 32 lanes of a row group hit 32 banks.
+constexpr int I8_PD = 128;
+__global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
+    const int H = SFG_N / 2, tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int cb = b % (H / I8_PD); b /= H / I8_PD;
+    const int kq = b % (a.nch * 4); b /= a.nch * 4;
+    const int jt = b % a.njt, m = b / a.njt;
+    const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
+    const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + (size_t)(a.l0 + m) * a.pt_l_stride) + c0 + cq * 4;
+    for (int d = 0; d < I8_ND; d++) {
+#pragma unroll 2
+        for (int it = 0; it < 8; it++) {
+            const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
+            unsigned w[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int k = kq * 16 + k4 * 4 + x;
+                w[x] = (k < a.K && n < a.Ncols) ? *reinterpret_cast<const unsigned *>(src + ((size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride) * 8 + (size_t)d * H) : 0u;
+            }
+            unsigned o[4]; bytes_tr4(w[0], w[1], w[2], w[3], o);
+#pragma unroll
+            for (int e = 0; e < 4; e++) img[(cq * 4 + e) * 64 + ((j ^ (cq & 7)) << 2) + (k4 ^ (cq >> 3))] = o[e];
+        }
+        __syncthreads();
+        for (int pc = tid >> 4; pc < I8_PD; pc += 16) {
+            const int q2 = pc >> 2;
+            const unsigned *sp = img + pc * 64 + ((l16 ^ (q2 & 7)) << 2);
+            const uint4 w = make_uint4(sp[0 ^ (q2 >> 3)], sp[1 ^ (q2 >> 3)], sp[2 ^ (q2 >> 3)], sp[3 ^ (q2 >> 3)]);
+            *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * I8_ND + d) * 1024) + g * 256 + l16 * 16) = w;
+        }
+        __syncthreads();
     }
 }
 // ---- the MAC.  grid = nl * N/2 workgroups of njt waves
@@ -164,7 +216,6 @@ __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *mod
 
 int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (ctx.hip)
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * I8_ND * 1024));
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_pt, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * I8_ND * 1024));
     return 0;
 }
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
@@ -177,21 +228,36 @@ int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, 
     a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
     a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = H; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
     a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
-    a.nch = (K + 63) / 64; a.njt = (Ncols + 15) / 16;
+    a.nch = (K + 63) / 64; a.njt = (Ncols + 15) / 16; a.pt_digits = st.pt_digits ? 1 : 0;
     const size_t nA = (size_t)nl * N * a.nch * 2 * I8_ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * I8_ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
-    SFG_TRY(sfg_scratch(ctx, "mi8.A", nA, (void **)&a.A));
+    // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column
+    const u64 sig0 = ctx->i8_gen, sig1 = ((u64)K << 40) ^ ((u64)R << 28) ^ ((u64)r0 << 20) ^ ((u64)l0 << 12) ^ ((u64)nl << 8) ^ (u64)plane0 ^ ((u64)rotf_k_stride << 44);
+    int slot = -1;
+    for (int i = 0; i < 2; i++) if (ctx->i8_src[i] == (const void *)rotf && ctx->i8_sig[i][0] == sig0 && ctx->i8_sig[i][1] == sig1) slot = i;
+    const bool repack = slot < 0;
+    if (repack) { slot = ctx->i8_next; ctx->i8_next ^= 1; }
+    SFG_TRY(sfg_scratch(ctx, slot ? "mi8.A1" : "mi8.A0", nA, (void **)&a.A));
+    if (repack) {
+        // (a regrown scratch buffer invalidates what the other slot's twin held only if it is the same buffer: the two slots have their own)
+        ctx->i8_src[slot] = (const void *)rotf; ctx->i8_sig[slot][0] = sig0; ctx->i8_sig[slot][1] = sig1;
+    }
     SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
-    { PhaseTimer t(ctx, "mac_i8_pack_rot");
+    const double tile = 1024.0;
+    if (repack) { PhaseTimer t(ctx, "mac_i8_pack_rot");
       hipLaunchKernelGGL(k_i8_pack_rot, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * I8_ND * 1024, ctx->stream, a);
-      SFG_HIP(ctx, hipGetLastError()); t.stop(1); }
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K * std::min(32, R - r0) * 8.0 + (double)a.nch * 2 * I8_ND * tile)); }
     { PhaseTimer t(ctx, "mac_i8_pack_pt");
-      hipLaunchKernelGGL(k_i8_pack_pt, dim3((unsigned)((size_t)nl * a.njt * a.nch * (H / I8_PC))), dim3(256), I8_PC * I8_ND * 1024, ctx->stream, a);
-      SFG_HIP(ctx, hipGetLastError()); t.stop(1); }
-    { PhaseTimer t(ctx, "mac_small");
+      if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD))), dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL(k_i8_pack_pt, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? 5.0 : 8.0) + (double)a.njt * a.nch * I8_ND * tile)); }
+    { PhaseTimer t(ctx, "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
       hipLaunchKernelGGL(k_mac_i8, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
+      t.stop(1, (double)nl * ((double)N * a.nch * 2 * I8_ND * tile + (double)H * a.njt * a.nch * I8_ND * tile + (double)H * 2 * a.njt * 2 * 256 * 8.0)); }
+    { PhaseTimer t(ctx, "mac_i8_untile");
       hipLaunchKernelGGL(k_i8_untile, dim3((unsigned)((size_t)nl * (H / 16) * 2 * a.njt * 2)), dim3(256), 0, ctx->stream, a, ctx->modc);
-      SFG_HIP(ctx, hipGetLastError()); t.stop(2); }
+      SFG_HIP(ctx, hipGetLastError());
+      t.stop(1, (double)nl * N * (double)Ncols * std::min(32, R - r0) * 8.0 * (accumulate ? 3.0 : 2.0)); }
     return 0;
 }

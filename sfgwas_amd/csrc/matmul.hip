@@ -322,13 +322,18 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             std::vector<int> po, ib; const int npl = mac_dma_planes(ctx, L, po, ib);
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
-                for (const char *nm : {"mm.pt", "mm.rotf"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
+                for (const char *nm : {"mm.pt", "mm.rotf", "mi8.A0", "mi8.A1", "mi8.B", "mi8.T"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
                 for (int cand : {24, 16}) {
                     const int G2 = std::min(cand, b1 - b0);
                     if (G2 <= G) break;
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
                     size_t need = (size_t)G2 * nplain * L * ((size_t)N / 2) * 8;
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
+                    if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
+                        int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
+                        const size_t nch = ((size_t)G2 * d + 63) / 64;
+                        need += (size_t)nsm * ((size_t)N * nch * 10240 * 2 + (size_t)(N / 2) * 6 * nch * 5120 + (size_t)(N / 2) * 2 * 6 * 2 * 256 * 8);
+                    }
                     if (need + (12ULL << 30) <= have) { G = G2; break; }
                 }
             }
@@ -358,6 +363,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // rotation cache of one group into half `buf` of mm.rotf (on whatever stream is current)
     auto build_group = [&](int bg, int buf) -> int {
         const int ng = std::min(G, b1 - bg);
+        ctx->i8_gen++;                                          // (the int8 MAC keeps a transposed copy per rot operand: this one changes now)
         double *dst = rotf + (size_t)buf * grp_slices * s * 2 * rowf;
         for (int g = 0; g < ng; g++) SFG_TRY(build_rot_row(ctx, A, s, nl_in, nl, lev, L, sh, bg + g, a_row, rotc, dma, dma ? dst + (size_t)g * d * s * 2 * rowf : nullptr));
         if (dma && (ng * d) % 4)          // the ragged last MAC chunk reads up to 3 k-slices past the group against zero plaintexts: keep them finite
@@ -437,7 +443,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 {
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask, pcc.mode ? &pcc : nullptr);
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask | (ctx->cfg.mac_i8 && packed_mask ? 0x80000000u : 0u),
+                                                         pcc.mode ? &pcc : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
                     t.stop(nruns);
@@ -449,7 +456,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0;   // pt[giant][g][baby]: k = g*91 + baby
+                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = dma && ctx->cfg.mac_i8 && packed_mask;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
@@ -535,6 +542,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
                                  int blk0, int blk1, uint64_t *out, const double *rotf_ext) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->phases.clear();
+    ctx->i8_gen++;                                              // a new product: whatever rot operand the int8 MAC had transposed is stale
     Shape sh = make_shape(g, flags);
     const int d = SFG_D, L = max_level, N = SFG_N;
     const size_t accw = (size_t)s * 2 * L * N;
@@ -662,6 +670,7 @@ extern "C" int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A, int 
 }
 extern "C" int sfg_rotcache_scatter_dev(sfg_ctx *ctx, const double *staged, int s, int max_level, int job0, int job1, int row0, int nrows, double *cache) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->i8_gen++;
     const int d = SFG_D;
     size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, max_level, rowf));
     if (s < 1 || nrows < 1 || job0 < row0 * s || job1 > (row0 + nrows) * s || job0 > job1) SFG_FAIL(ctx, "rotcache: job range outside the cache rows");
@@ -675,7 +684,9 @@ extern "C" int sfg_rotcache_scatter_dev(sfg_ctx *ctx, const double *staged, int 
     return 0;
 }
 // tabs (nullable): per block row of [b0, b1) the 91 active-baby flags (matmult.go:1326-1336; a superset is always right); null = all 91
+// (every writer of a caller-held rotation cache bumps ctx->i8_gen: the int8 MAC keeps a transposed copy of a rot operand per (pointer, generation))
 int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, int nbr, int b0, int b1, const std::vector<std::vector<uint8_t>> *tabs, double *cache) {
+    ctx->i8_gen++;
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     const int N = SFG_N, d = SFG_D, L = max_level;
     size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, L, rowf));

@@ -247,7 +247,8 @@ constexpr int H3_LDS_BYTES = H3_DOUBLES * 8;      // 34,816 B: four workgroups p
 // halves are independent size-n transforms whose twiddles sit hs * (m / 2) further in each stage's table (tw[m + i], i in [hs m/2, (hs+1) m/2)).
 // first(j) returns the stage-1 output r_j of this half, j < n; store(j, x) receives the lazy result of output index hs * n + j.
 struct NoFill {};
-template <class First, class Store, class Fill = NoFill>
+// WIDE: store(j0, v0, v1, v2, v3) receives four CONSECUTIVE outputs (a lane takes words 4 lane .. 4 lane + 3 of each 256-word run instead of every 64th)
+template <class First, class Store, class Fill = NoFill, bool WIDE = false>
 __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store, double *lds, const double *tw, const double2 *pack, double q, double qinv, int tid, Fill fill = Fill()) {
     double v[32];
     const int a_b = tid >> 4, c_b = tid & 15;                  // phase B identity
@@ -318,10 +319,17 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
             // output j = a*512 + (16 r + b')*16 + c: per `a` row 256 consecutive words, 64 lanes at a time
 #pragma unroll
             for (int ai = 0; ai < 4; ai++) {
+                if constexpr (WIDE) {
+                    const int x0 = 4 * lane;                             // x0 + e: b' = lane >> 2, c = 4 (lane & 3) + e
+                    const int base = ai * 256 + (lane >> 2);
+                    store((4 * wv + ai) * 512 + 256 * r + x0, img[sw(base + (4 * (lane & 3) + 0) * 16)], img[sw(base + (4 * (lane & 3) + 1) * 16)],
+                          img[sw(base + (4 * (lane & 3) + 2) * 16)], img[sw(base + (4 * (lane & 3) + 3) * 16)]);
+                } else {
 #pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    const int x = qd * 64 + lane;                        // b' = x >> 4, c = x & 15
-                    store((4 * wv + ai) * 512 + 256 * r + x, img[sw(ai * 256 + (x & 15) * 16 + (x >> 4))]);
+                    for (int qd = 0; qd < 4; qd++) {
+                        const int x = qd * 64 + lane;                        // b' = x >> 4, c = x & 15
+                        store((4 * wv + ai) * 512 + 256 * r + x, img[sw(ai * 256 + (x & 15) * 16 + (x >> 4))]);
+                    }
                 }
             }
         }
@@ -331,7 +339,7 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
 // image X -> X^g of cached row u (perm[t] = u | g << 16): coefficient i of the row becomes coefficient i g mod 2N of the image (>= N: minus coefficient - N), and a
 // row is stored as its first N/2 coefficients (p_{N-c} = -p_c, p_{N/2} = 0).  The rounding of the encoder commutes with this signed permutation, so the NTT input is
 // the very integer polynomial a fresh encode of the rotated diagonal would give.
-template <bool PERM>
+template <bool PERM, bool DIG>
 __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
                                                       const uint32_t *perm) {
     extern __shared__ double lds[];
@@ -391,12 +399,32 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
     if (SFG_NTT_DIAG == 1) { ntt_half3_body(0, first, [&](int j, double x) { if (x == 0.123) out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid); return; }
     if (SFG_NTT_DIAG == 2) { ntt_half3_body(0, first, [&](int j, double x) { out[j] = (u64)__double_as_longlong(x); }, lds, tw, pack, q, qinv, tid); return; }
 #endif
+    // int8 MAC (mac_i8.hip; bit 31 of the mask): the packed rows leave as five planes of signed base-256 digits instead of words - 5 of the row's 8 bytes per word.
+    // Balanced digits of v: the bytes of v + 0x8080808080 with their top bits flipped; the sum is read off the mantissa of v + 2^52 + 0x8080808080.
+    if constexpr (DIG) if ((pm.packed_mask >> m) & 1u) {
+        uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
+        auto dig = [&](double x, unsigned &lo, unsigned &hi) {
+            const u64 b = (u64)__double_as_longlong(canon_le(x, q, qinv) + (4503599627370496.0 + 551911719040.0));
+            lo = (unsigned)b ^ 0x80808080u; hi = (unsigned)(b >> 32) ^ 0x80u;
+        };
+        auto st8 = [&](int j0, double x0, double x1, double x2, double x3) {        // four consecutive coefficients: one dword per digit plane
+            unsigned l0, l1, l2, l3, h0, h1, h2, h3;
+            dig(x0, l0, h0); dig(x1, l1, h1); dig(x2, l2, h2); dig(x3, l3, h3);
+            unsigned o[4]; bytes_tr4(l0, l1, l2, l3, o);
+#pragma unroll
+            for (int d = 0; d < 4; d++) *reinterpret_cast<unsigned *>(o8 + d * n + j0) = o[d];
+            *reinterpret_cast<unsigned *>(o8 + 4 * n + j0) = (h0 & 255u) | ((h1 & 255u) << 8) | ((h2 & 255u) << 16) | (h3 << 24);
+        };
+        if constexpr (PERM) ntt_half3_body<decltype(first), decltype(st8), decltype(fill), true>(0, first, st8, lds, tw, pack, q, qinv, tid, fill);
+        else ntt_half3_body<decltype(first), decltype(st8), NoFill, true>(0, first, st8, lds, tw, pack, q, qinv, tid);
+        return;
+    }
     if constexpr (PERM) {
-        if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid, fill);
+        if (!DIG && ((pm.packed_mask >> m) & 1u)) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid, fill);
         else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid, fill);
     } else {
         (void)fill;
-        if ((pm.packed_mask >> m) & 1u) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
+        if (!DIG && ((pm.packed_mask >> m) & 1u)) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
         else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
     }
 }
@@ -436,8 +464,10 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
@@ -467,9 +497,12 @@ int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, in
 int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm) {
     if (!nplain) return 0;
     const dim3 grid((unsigned)((nplain + 7) / 8 * 8 * L));
-    if (perm) hipLaunchKernelGGL(k_ntt_half3<true>, grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
+    const bool dig = pm.packed_mask >> 31;                 // digit planes for the int8 MAC (mac_i8.hip): its own instances, the default kernels are untouched
+    if (perm && dig) hipLaunchKernelGGL((k_ntt_half3<true, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
+    else if (perm) hipLaunchKernelGGL((k_ntt_half3<true, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
+    else if (dig) hipLaunchKernelGGL((k_ntt_half3<false, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
     else if (ctx->cfg.ntt_half_full) hipLaunchKernelGGL(k_ntt_half, grid, dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
-    else hipLaunchKernelGGL(k_ntt_half3<false>, grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
+    else hipLaunchKernelGGL((k_ntt_half3<false, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }

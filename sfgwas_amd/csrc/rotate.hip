@@ -327,6 +327,7 @@ int launch_rotate_right_indexed(sfg_ctx *ctx, const u64 *in, int nin, u64 *out, 
 int launch_rotate_right_indexed_f64(sfg_ctx *ctx, const u64 *in, int nin, double *outf, int nct, int level, const int *nrot_host, const int *in_index, int L,
                                     const size_t *out_slot) {
     const int N = SFG_N, nl = level + 1;
+    ctx->i8_gen++;                  // fp64 rot operand rows are (re)written: the int8 MAC's transposed copy of whatever buffer this is goes stale
     if (level < 0 || level >= ctx->nq || L > nl) SFG_FAIL(ctx, "rotate: level out of range");
     const size_t ctw = (size_t)2 * nl * N;
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);

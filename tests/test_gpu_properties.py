@@ -146,25 +146,25 @@ np.save(sys.argv[1], h)
 def test_group_size_and_mac_kernel_invariance(tmp_path):
     """the same product in separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8, the register-staged MAC, and a small
     accumulator budget (one block column per pass -> the product-wide rotation cache is built once and reused), the round-1 LDS-DMA MAC in both
-    workgroup shapes, the plain plaintext panel, the full-image NTT kernels, the experimental int8 matrix-core MAC (SFG_MAC_IMPL=i8)"""
+    workgroup shapes, the plain plaintext panel, the full-image NTT kernels, the fp64 DPP-broadcast MAC for every modulus (SFG_MAC_IMPL=bc; the default runs the small moduli on the int8 matrix core)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"}),
                        ("budget", {"SFG_MM_ACC_BUDGET_MB": "300"}), ("budget_g1", {"SFG_MM_ACC_BUDGET_MB": "300", "SFG_MM_GROUP": "1"}),
                        ("dma", {"SFG_MAC_IMPL": "dma"}), ("dma_wc2", {"SFG_MAC_IMPL": "dma", "SFG_MAC_WC": "2"}), ("plain_pt", {"SFG_MAC_PT": "plain"}),
-                       ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"}), ("i8", {"SFG_MAC_IMPL": "i8"}), ("i8_g1", {"SFG_MAC_IMPL": "i8", "SFG_MM_GROUP": "1"})]:
+                       ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"}), ("bc", {"SFG_MAC_IMPL": "bc"}), ("bc_g1", {"SFG_MAC_IMPL": "bc", "SFG_MM_GROUP": "1"})]:
         f = str(tmp_path / (name + ".npy"))
         e = dict(os.environ); e.update(envv)
         r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1]), "block-row grouping changed the result"
-    assert np.array_equal(outs[0], outs[2]), "DPP-broadcast and register-staged MAC kernels disagree"
+    assert np.array_equal(outs[0], outs[2]), "default and register-staged MAC kernels disagree"
     assert np.array_equal(outs[0], outs[3]) and np.array_equal(outs[0], outs[4]), "column passes / shared rotation cache changed the result"
     assert np.array_equal(outs[0], outs[5]) and np.array_equal(outs[0], outs[6]), "DPP-broadcast and 8 x 3-tile LDS-DMA MAC kernels (4- / 8-wave workgroups) disagree"
     assert np.array_equal(outs[0], outs[7]), "packed-limb and plain plaintext panels disagree"
     assert np.array_equal(outs[0], outs[8]), "split and full-image NTT kernels disagree"
-    assert np.array_equal(outs[0], outs[9]) and np.array_equal(outs[0], outs[10]), "the experimental int8 matrix-core MAC (five signed base-256 digits, nine int32 sums) disagrees"
+    assert np.array_equal(outs[0], outs[9]) and np.array_equal(outs[0], outs[10]), "the int8 matrix-core MAC (default: five signed base-256 digits, nine int32 sums) and the fp64 DPP-broadcast MAC of round 2 (SFG_MAC_IMPL=bc) disagree"
     assert outs[0].any()
 
 
