@@ -328,7 +328,7 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
         while (l < L) {
             const bool big = is_big[l]; int e = l; while (e < L && is_big[e] == (int)big) e++;
             if (!big && !st.pt_packed) SFG_FAIL(ctx, "sfg_mac: the broadcast MAC needs packed-limb plaintext rows for the small moduli");
-            if (!big && ctx->cfg.mac_i8 && st.pt_half) {            // SFG_MAC_IMPL=i8 (experimental): the small moduli on the int8 matrix core, mac_i8.hip
+            if (!big && st.i8 && st.pt_half) {            // SFG_MAC_IMPL=i8 (experimental): the small moduli on the int8 matrix core, mac_i8.hip
                 SFG_TRY(launch_mac_i8_small(ctx, rotf, rows_per_k * rowf, rowf, plane_of[l], pt, out, K, R, r0, Ncols, l, e - l, accumulate, st));
                 l = e; continue;
             }

@@ -318,7 +318,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         G = ctx->cfg.mm_group;
         // 16 (24) block rows per launch halve (third) the accumulator read-modify-writes and the per-launch prologues (16: -1.7 % at 100k x 1M, identical bits) but
         // need a 43 (65) GB plaintext panel and, for the pipelined rotation caches, 2 x 34.5 (52) GB of operands: taken only when that fits beside what is resident
-        if (ctx->cfg.mm_group_auto && b1 - b0 > G) {
+        // (not for a single block column against a caller's rotation cache - the association scan: fewer launches save a few accumulator passes there, and the
+        //  larger panel competes with the 115 GB cache for HBM: measured 0.49 s instead of 0.31 s per batch)
+        if (ctx->cfg.mm_group_auto && b1 - b0 > G && (j1 - j0 >= 4 || !rotf_pre)) {
             std::vector<int> po, ib; const int npl = mac_dma_planes(ctx, L, po, ib);
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
@@ -342,6 +344,10 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     }
     u64 *a_row = nullptr, *rotc = nullptr, *pt = nullptr; int8_t *skew = nullptr; double *rotf = nullptr, *rotsum = nullptr; size_t rowf = 0;
     const unsigned packed_mask = dma ? mac_dma_packed_mask(ctx, L) : 0u;      // small-modulus plaintext rows in the packed-limb format
+    // The int8 MAC multiplies with a k-contiguous copy of a group's rot operand, transposed when the operand changes and kept for two operands.  That pays when
+    // the copy is reused: several block columns in this call, or so few groups that the copies survive from call to call (a caller's rotation cache multiplied one
+    // block column at a time).  The association scan - one block column per batch against a 62-block-row cache - takes the fp64 kernel.
+    const bool use_i8 = dma && ctx->cfg.mac_i8 && packed_mask && ((b1 - b0 + G - 1) / G <= 2 || j1 - j0 >= 4);
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
     const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
@@ -443,7 +449,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 {
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask | (ctx->cfg.mac_i8 && packed_mask ? 0x80000000u : 0u),
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask | (use_i8 ? 0x80000000u : 0u),
                                                          pcc.mode ? &pcc : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
@@ -456,7 +462,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = dma && ctx->cfg.mac_i8 && packed_mask;   // pt[giant][g][baby]: k = g*91 + baby
+                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
@@ -870,7 +876,7 @@ extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int
                 SFG_HIP(ctx, hipGetLastError());
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;
-                st.pt_k = plw; st.pt_n = (size_t)d * plw; st.pt_half = true; st.pt_packed = packed_mask != 0;     // panel[j][baby]
+                st.pt_k = plw; st.pt_n = (size_t)d * plw; st.pt_half = true; st.pt_packed = packed_mask != 0; st.i8 = ctx->cfg.mac_i8 && packed_mask;     // panel[j][baby]
                 st.out_n = (size_t)d * accw; st.out_r = (size_t)L * N;                                           // acc[j][giant][r], column n = j
                 PhaseTimer t(ctx, "mac");
                 int r2 = launch_mac_dma(ctx, rotf, (size_t)s * 2, panel, acc + (size_t)cur_giant * accw, d, 2 * s, jn, L, 1, st, rotsum);
