@@ -444,7 +444,7 @@ def main():
     res = {
         "metric": "pca_power_iter_ring_macs_per_s", "value": value, "unit": "ring-MAC/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 (exact integers in fp64 limbs)",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 ring words, exact integers: int8 digits on the matrix core for the 35-bit moduli, fp64 limbs elsewhere",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: one PCA power iteration local work = Q*X + Q'*X^T, {n_ind} x {m_snp} int8 genotypes, "
                                f"kp={KP}, PN14QP438-shaped ring (N=16384, L=5 of 6 moduli), on-the-fly diagonal encode",
