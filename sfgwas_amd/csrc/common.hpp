@@ -54,6 +54,7 @@ struct SfgConfig {
     bool mac_reg = false;          // SFG_MAC_IMPL=reg      register-staged MAC kernel (mac.hip)
     bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
     bool mac_i8 = true;            // SFG_MAC_IMPL=bc       the DPP-broadcast fp64 kernel for every modulus (round 2's MAC) instead of: small moduli on the int8 matrix core (mac_i8.hip), the 46-bit one on the DPP-broadcast kernel
+    bool mac_i8_nolds = true;      // SFG_MAC_I8_ROT=lds    int8 MAC: rot tiles of a coefficient pair staged through LDS (k_mac_i8_lds) instead of shared through the cache (measured at 100k x 1M: 3.31 s against 2.56 s per step - the barriers cost more than the re-fetches)
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
     bool mm_group_auto = true;     //                       (unset) 16 block rows per launch when the plaintext panel and the rotation operands of such a group fit the free HBM, else 8

@@ -186,6 +186,70 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
         }
     }
 }
+// ---- the same with the rot tiles of the pair staged through LDS (six column waves: the product's 91 columns).  Through the cache alone the six waves fetched
+// them 2.8 x (PMC); here the workgroup loads the 20 KiB of a chunk once - the next chunk's pieces travel in registers beside the current chunk's MFMAs - and every
+// wave reads its 20 operand tiles from the 2 x 20 KiB image.
+__global__ void __launch_bounds__(384, 1) k_mac_i8_lds(I8Args a, const ModConst *modc) {
+    __shared__ uint4 As[2][2 * 2 * I8_ND * 64];
+    const int N = SFG_N, H = N / 2, tid = threadIdx.x;
+    const int lane = tid & 63, jt = tid >> 6;
+    const int c = blockIdx.x % H, m = blockIdx.x / H;
+    const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
+    v4i acc[4][9];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s = 0; s < 9; s++) acc[t][s] = (v4i){0, 0, 0, 0};
+    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * I8_ND * 64 + lane;
+    const uint4 *A0 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + c) * a.nch) * 2 * I8_ND * 64;
+    const uint4 *A1 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + (N - 1 - c)) * a.nch) * 2 * I8_ND * 64;
+    constexpr int HALF = 2 * I8_ND * 64;               // uint4 per coefficient and chunk (10 KiB)
+    // piece i < 2 HALF of chunk ch: coefficient half i / HALF, offset i % HALF; thread tid takes pieces tid, tid + 384, ...
+    auto src = [&](int ch, int i) { return (i < HALF ? A0 : A1) + (size_t)ch * HALF + (i < HALF ? i : i - HALF); };
+    uint4 stage[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = tid + 384 * u; if (i < 2 * HALF) As[0][i] = *src(0, i); }
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < a.nch; ch++) {
+        const bool more = ch + 1 < a.nch;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = tid + 384 * u; if (i < 2 * HALF) stage[u] = *src(ch + 1, i); }
+        }
+        v4i b[I8_ND];
+#pragma unroll
+        for (int d = 0; d < I8_ND; d++) { const uint4 w = Bp[(size_t)(ch * I8_ND + d) * 64]; b[d] = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
+        const uint4 *Ac = As[ch & 1];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int x = 0; x < I8_ND; x++) {
+                const uint4 w = Ac[(t * I8_ND + x) * 64 + lane];
+                const v4i av = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+#pragma unroll
+                for (int d = 0; d < I8_ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[d], acc[t][x + d], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = tid + 384 * u; if (i < 2 * HALF) As[(ch + 1) & 1][i] = stage[u]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * a.njt + jt) * 2 + (t & 1)) * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            double r = (double)acc[t][8][e];
+#pragma unroll
+            for (int s = 7; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
+            if (r < 0) r += q;
+            o[e] = (u64)r;
+        }
+    }
+}
 // ---- tile-ordered results -> canonical accumulators.  workgroup = (m, 16 coefficient pairs, half, jt, rt): 256 (n, r) rows x 16 coefficients through LDS
 __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *modc) {
     __shared__ u64 img[16][257];
@@ -252,7 +316,8 @@ int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, 
       else hipLaunchKernelGGL(k_i8_pack_pt, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? 5.0 : 8.0) + (double)a.njt * a.nch * I8_ND * tile)); }
     { PhaseTimer t(ctx, "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
-      hipLaunchKernelGGL(k_mac_i8, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
+      if (a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
+      else hipLaunchKernelGGL(k_mac_i8, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
       t.stop(1, (double)nl * ((double)N * a.nch * 2 * I8_ND * tile + (double)H * a.njt * a.nch * I8_ND * tile + (double)H * 2 * a.njt * 2 * 256 * 8.0)); }
     { PhaseTimer t(ctx, "mac_i8_untile");
