@@ -22,9 +22,12 @@ int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 // mac.hip
-struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; };   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
+struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; bool i8_big = false; bool pt_digits_big = false; };   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                         int l0, int nl, int accumulate, const MacStrides &st);       // mac_i8.hip
+int launch_mac_i8_big(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
+                      int l0, int accumulate, const MacStrides &st);
+size_t mac_i8_stream_bytes(int K, int nl, int ND, int copies_of_rot);
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate);
 int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
 // encode.hip

@@ -18,13 +18,13 @@
 #include <vector>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int I8_ND = 5;                   // digits per operand word
+constexpr int I8_ND = 5;                   // digits per operand word of a 35-bit modulus (the 46-bit one: 6)
 constexpr int I8_PC = 8;                   // coefficients per packing workgroup (64-byte source runs)
 
-// five signed base-256 digits of an integer |v| < 2^39 (two's complement arithmetic shift)
-__device__ __forceinline__ void i8_digits(long long v, int8_t d[I8_ND]) {
+// ND signed base-256 digits of an integer |v| < 2^(8 ND - 1) (two's complement arithmetic shift)
+template <int ND> __device__ __forceinline__ void i8_digits(long long v, int8_t d[ND]) {
 #pragma unroll
-    for (int i = 0; i < I8_ND; i++) { const long long lo = ((v + 128) & 255) - 128; d[i] = (int8_t)lo; v = (v - lo) >> 8; }
+    for (int i = 0; i < ND; i++) { const long long lo = ((v + 128) & 255) - 128; d[i] = (int8_t)lo; v = (v - lo) >> 8; }
 }
 // byte offset of element (row-or-column i < 16, kk < 64) inside a 1 KiB operand tile: lane = i + 16 (kk / 16), byte kk % 16
 __device__ __forceinline__ int i8_tile_off(int i, int kk) { return ((i + 16 * (kk >> 4)) << 4) + (kk & 15); }
@@ -36,35 +36,41 @@ struct I8Args {
     int8_t *A, *B; u64 *T;
 };
 
-// ---- rot planes -> A.  workgroup = (modulus m, chunk ch, 8 coefficients): 64 k x 32 rows x 8 coefficients through an 80 KiB digit image
+// ---- rot planes -> A.  workgroup = (modulus m, chunk ch, 8 coefficients): 64 k x 32 rows x 8 coefficients through an 80 (96) KiB digit image.
+// ND = 6: the 46-bit modulus, whose fp64 plane holds the signed split {lo 23 bits, hi} per coefficient (k_rot_to_f64): v = hi 2^23 + lo
+template <int ND>
 __global__ void __launch_bounds__(256) k_i8_pack_rot(I8Args a) {
-    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 8][rt 2][a 5][1 KiB]
+    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 8][rt 2][a ND][1 KiB]
     const int N = SFG_N, tid = threadIdx.x;
     const int xb = blockIdx.x % (N / I8_PC), ch = (blockIdx.x / (N / I8_PC)) % a.nch, m = blockIdx.x / (N / I8_PC) / a.nch;
     const int x0 = xb * I8_PC, cc = tid & (I8_PC - 1);
-    const double *src = a.rotf + (size_t)(a.plane0 + m) * N + x0 + cc;
+    const double *src = ND == 6 ? a.rotf + (size_t)a.plane0 * N + 2 * (x0 + cc) : a.rotf + (size_t)(a.plane0 + m) * N + x0 + cc;
     for (int p = tid / I8_PC; p < 64 * 32; p += 256 / I8_PC) {
         const int kk = p >> 5, r = p & 31, k = ch * 64 + kk;
         long long v = 0;
-        if (k < a.K && a.r0 + r < a.R && r < 32) v = (long long)src[(size_t)k * a.rotf_k_stride + (size_t)(a.r0 + r) * a.rotf_r_stride];
-        int8_t d[I8_ND]; i8_digits(v, d);
-        int8_t *o = img + cc * (2 * I8_ND * 1024) + (r >> 4) * (I8_ND * 1024) + i8_tile_off(r & 15, kk);
+        if (k < a.K && a.r0 + r < a.R) {
+            const double *e = src + (size_t)k * a.rotf_k_stride + (size_t)(a.r0 + r) * a.rotf_r_stride;
+            v = ND == 6 ? (long long)e[1] * 8388608LL + (long long)e[0] : (long long)e[0];
+        }
+        int8_t d[ND]; i8_digits<ND>(v, d);
+        int8_t *o = img + cc * (2 * ND * 1024) + (r >> 4) * (ND * 1024) + i8_tile_off(r & 15, kk);
 #pragma unroll
-        for (int i = 0; i < I8_ND; i++) o[i * 1024] = d[i];
+        for (int i = 0; i < ND; i++) o[i * 1024] = d[i];
     }
     __syncthreads();
     for (int c2 = 0; c2 < I8_PC; c2++) {
-        uint4 *dst = reinterpret_cast<uint4 *>(a.A + ((((size_t)m * N + x0 + c2) * a.nch + ch) * 2 * I8_ND) * 1024);
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(img + c2 * (2 * I8_ND * 1024));
-        for (int i = tid; i < 2 * I8_ND * 64; i += 256) dst[i] = s4[i];
+        uint4 *dst = reinterpret_cast<uint4 *>(a.A + ((((size_t)m * N + x0 + c2) * a.nch + ch) * 2 * ND) * 1024);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(img + c2 * (2 * ND * 1024));
+        for (int i = tid; i < 2 * ND * 64; i += 256) dst[i] = s4[i];
     }
 }
 // ---- panel words -> B.  workgroup = (modulus m, column tile jt, 16 k, 32 coefficients): 256 (k, column) rows of 256 contiguous bytes in, 160 pieces of 256
 // contiguous bytes out (the 16-k quarter of a 1 KiB tile).  A thread takes four consecutive k of one (column, coefficient), so a digit of the four is one dword.
 constexpr int I8_PP = 32;                                   // coefficients per workgroup
-constexpr int I8_PSTR = I8_ND * 256 + 4;                    // bytes per coefficient in the image (+ 4: lanes = coefficients fall on distinct banks)
+template <int ND>
 __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char img[I8_PP * I8_PSTR];       // [cc 32][b 5][j 16][kk 16]
+    constexpr int PSTR = ND * 256 + 4;                      // bytes per coefficient in the image (+ 4: lanes = coefficients fall on distinct banks)
+    __shared__ __attribute__((aligned(16))) unsigned char img[I8_PP * PSTR];       // [cc 32][b ND][j 16][kk 16]
     const int H = SFG_N / 2, tid = threadIdx.x;
     int b = blockIdx.x;
     const int cb = b % (H / I8_PP); b /= H / I8_PP;
@@ -75,30 +81,32 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
 #pragma unroll 2
     for (int it = 0; it < 8; it++) {
         const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
-        unsigned dw[I8_ND] = {0, 0, 0, 0, 0};
+        unsigned dw[ND];
+#pragma unroll
+        for (int i = 0; i < ND; i++) dw[i] = 0;
 #pragma unroll
         for (int x = 0; x < 4; x++) {
             const int k = kq * 16 + k4 * 4 + x;
             long long v = 0;
             if (k < a.K && n < a.Ncols) {
                 const u64 w = src[(size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride];
-                v = (long long)((w & 0xFFFULL) | (((w >> 16) & 0xFFFULL) << 12) | ((w >> 32) << 24));       // packed-limb panel word (pack_limbs)
+                v = ND == 6 ? (long long)w : (long long)((w & 0xFFFULL) | (((w >> 16) & 0xFFFULL) << 12) | ((w >> 32) << 24));       // plain word / packed-limb panel word (pack_limbs)
             }
-            int8_t d[I8_ND]; i8_digits(v, d);
+            int8_t d[ND]; i8_digits<ND>(v, d);
 #pragma unroll
-            for (int i = 0; i < I8_ND; i++) dw[i] |= (unsigned)(uint8_t)d[i] << (8 * x);
+            for (int i = 0; i < ND; i++) dw[i] |= (unsigned)(uint8_t)d[i] << (8 * x);
         }
 #pragma unroll
-        for (int i = 0; i < I8_ND; i++) *reinterpret_cast<unsigned *>(img + cc * I8_PSTR + i * 256 + j * 16 + k4 * 4) = dw[i];
+        for (int i = 0; i < ND; i++) *reinterpret_cast<unsigned *>(img + cc * PSTR + i * 256 + j * 16 + k4 * 4) = dw[i];
     }
     __syncthreads();
     // piece (cc, digit): 256 bytes = 16 lanes x 16 bytes, at byte (kq % 4) * 256 of its tile
     const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
-    for (int pc = tid >> 4; pc < I8_PP * I8_ND; pc += 16) {
-        const int c2 = pc / I8_ND, d = pc % I8_ND;
-        const unsigned *sp = reinterpret_cast<const unsigned *>(img + c2 * I8_PSTR + d * 256 + l16 * 16);
+    for (int pc = tid >> 4; pc < I8_PP * ND; pc += 16) {
+        const int c2 = pc / ND, d = pc % ND;
+        const unsigned *sp = reinterpret_cast<const unsigned *>(img + c2 * PSTR + d * 256 + l16 * 16);
         const uint4 w = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * I8_ND + d) * 1024) + g * 256 + l16 * 16) = w;
+        *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g * 256 + l16 * 16) = w;
     }
 }
 // ---- the same from digit planes (the plaintext NTT's output when the int8 MAC is on: five planes of N/2 bytes in a row's 64 KiB).  workgroup = (modulus m,
@@ -106,6 +114,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
 // coefficients (a dword each) and a 4 x 4 byte transpose turns them into one dword of four k per coefficient.  Image [cc 128][j 16][k4 4] dwords, j and k4 XORed with
 // bits of the lane's coefficient group so that the 32 lanes of a row group hit 32 banks.
 constexpr int I8_PD = 128;
+template <int ND>
 __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
     __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
     const int H = SFG_N / 2, tid = threadIdx.x;
@@ -116,7 +125,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
     const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
     const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
     const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + (size_t)(a.l0 + m) * a.pt_l_stride) + c0 + cq * 4;
-    for (int d = 0; d < I8_ND; d++) {
+    for (int d = 0; d < ND; d++) {
 #pragma unroll 2
         for (int it = 0; it < 8; it++) {
             const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
@@ -135,39 +144,40 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
             const int q2 = pc >> 2;
             const unsigned *sp = img + pc * 64 + ((l16 ^ (q2 & 7)) << 2);
             const uint4 w = make_uint4(sp[0 ^ (q2 >> 3)], sp[1 ^ (q2 >> 3)], sp[2 ^ (q2 >> 3)], sp[3 ^ (q2 >> 3)]);
-            *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * I8_ND + d) * 1024) + g * 256 + l16 * 16) = w;
+            *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g * 256 + l16 * 16) = w;
         }
         __syncthreads();
     }
 }
 // ---- the MAC.  grid = nl * N/2 workgroups of njt waves
+template <int ND>
 __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *modc) {
     const int N = SFG_N, H = N / 2;
     const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6;
     const int c = blockIdx.x % H, m = blockIdx.x / H;
     const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
-    v4i acc[4][9];
+    v4i acc[4][2 * ND - 1];
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int s = 0; s < 9; s++) acc[t][s] = (v4i){0, 0, 0, 0};
-    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * I8_ND * 64 + lane;
-    const uint4 *A0 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + c) * a.nch) * 2 * I8_ND * 64 + lane;
-    const uint4 *A1 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + (N - 1 - c)) * a.nch) * 2 * I8_ND * 64 + lane;
+        for (int s = 0; s < 2 * ND - 1; s++) acc[t][s] = (v4i){0, 0, 0, 0};
+    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * ND * 64 + lane;
+    const uint4 *A0 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + c) * a.nch) * 2 * ND * 64 + lane;
+    const uint4 *A1 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + (N - 1 - c)) * a.nch) * 2 * ND * 64 + lane;
 #pragma unroll 1
     for (int ch = 0; ch < a.nch; ch++) {
-        v4i b[I8_ND];
+        v4i b[ND];
 #pragma unroll
-        for (int d = 0; d < I8_ND; d++) { const uint4 w = Bp[(size_t)(ch * I8_ND + d) * 64]; b[d] = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
+        for (int d = 0; d < ND; d++) { const uint4 w = Bp[(size_t)(ch * ND + d) * 64]; b[d] = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const uint4 *Ap = (t < 2 ? A0 : A1) + (size_t)((ch * 2 + (t & 1)) * I8_ND) * 64;
+            const uint4 *Ap = (t < 2 ? A0 : A1) + (size_t)((ch * 2 + (t & 1)) * ND) * 64;
 #pragma unroll
-            for (int x = 0; x < I8_ND; x++) {
+            for (int x = 0; x < ND; x++) {
                 const uint4 w = Ap[(size_t)x * 64];
                 const v4i av = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w};
 #pragma unroll
-                for (int d = 0; d < I8_ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[d], acc[t][x + d], 0, 0, 0);
+                for (int d = 0; d < ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[d], acc[t][x + d], 0, 0, 0);
             }
         }
         __syncthreads();                                 // the column waves of a pair stay within one chunk of each other: the rot tiles come from HBM once
@@ -178,9 +188,9 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
         u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * a.njt + jt) * 2 + (t & 1)) * 64 + lane) * 4;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            double r = (double)acc[t][8][e];
+            double r = (double)acc[t][2 * ND - 2][e];
 #pragma unroll
-            for (int s = 7; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
+            for (int s = 2 * ND - 3; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
             if (r < 0) r += q;
             o[e] = (u64)r;
         }
@@ -279,50 +289,69 @@ __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *mod
 }
 
 int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (ctx.hip)
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * I8_ND * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 5 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 6 * 1024));
     return 0;
 }
-int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
-                        int l0, int nl, int accumulate, const MacStrides &st) {
+// bytes of the two operand streams and the tile-ordered results of one launch (for the group-size choice in matmul.hip)
+size_t mac_i8_stream_bytes(int K, int nl, int ND, int copies_of_rot) {
+    const size_t N = SFG_N, H = N / 2, nch = ((size_t)K + 63) / 64;
+    return (size_t)nl * (N * nch * 2 * ND * 1024 * copies_of_rot + H * 6 * nch * ND * 1024 + H * 2 * 6 * 2 * 256 * 8);
+}
+template <int ND>
+static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
+                            int l0, int nl, int accumulate, const MacStrides &st) {
     const int N = SFG_N, H = N / 2;
-    if (!st.pt_half || !st.pt_packed) SFG_FAIL(ctx, "sfg_mac (i8): needs half-row packed-limb plaintext rows");
+    constexpr bool BIG = ND == 6;
+    if (!st.pt_half || (!BIG && !st.pt_packed)) SFG_FAIL(ctx, "sfg_mac (i8): needs half-row plaintext rows (packed-limb words or digit planes for the small moduli)");
+    if (BIG && nl != 1) SFG_FAIL(ctx, "sfg_mac (i8): one 46-bit modulus per launch");
     if (Ncols > 96) SFG_FAIL(ctx, "sfg_mac (i8): more than 96 columns per launch");
-    if (K >= 26000) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums");
+    if ((long long)K * ND >= 131072) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums (ND K 2^14 must stay below 2^31)");
     I8Args a;
     a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
     a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = H; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
     a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
     a.nch = (K + 63) / 64; a.njt = (Ncols + 15) / 16; a.pt_digits = st.pt_digits ? 1 : 0;
-    const size_t nA = (size_t)nl * N * a.nch * 2 * I8_ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * I8_ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
-    // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column
+    const size_t nA = (size_t)nl * N * a.nch * 2 * ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
+    // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column.
+    // Two copies per kind of modulus (the pipelined product alternates between two rot buffers).
     const u64 sig0 = ctx->i8_gen, sig1 = ((u64)K << 40) ^ ((u64)R << 28) ^ ((u64)r0 << 20) ^ ((u64)l0 << 12) ^ ((u64)nl << 8) ^ (u64)plane0 ^ ((u64)rotf_k_stride << 44);
+    const int base = BIG ? 2 : 0;
     int slot = -1;
-    for (int i = 0; i < 2; i++) if (ctx->i8_src[i] == (const void *)rotf && ctx->i8_sig[i][0] == sig0 && ctx->i8_sig[i][1] == sig1) slot = i;
+    for (int i = base; i < base + 2; i++) if (ctx->i8_src[i] == (const void *)rotf && ctx->i8_sig[i][0] == sig0 && ctx->i8_sig[i][1] == sig1) slot = i;
     const bool repack = slot < 0;
-    if (repack) { slot = ctx->i8_next; ctx->i8_next ^= 1; }
-    SFG_TRY(sfg_scratch(ctx, slot ? "mi8.A1" : "mi8.A0", nA, (void **)&a.A));
-    if (repack) {
-        // (a regrown scratch buffer invalidates what the other slot's twin held only if it is the same buffer: the two slots have their own)
-        ctx->i8_src[slot] = (const void *)rotf; ctx->i8_sig[slot][0] = sig0; ctx->i8_sig[slot][1] = sig1;
-    }
+    if (repack) { slot = base + ctx->i8_next[BIG ? 1 : 0]; ctx->i8_next[BIG ? 1 : 0] ^= 1; }
+    static const char *names[4] = {"mi8.A0", "mi8.A1", "mi8.Ab0", "mi8.Ab1"};
+    SFG_TRY(sfg_scratch(ctx, names[slot], nA, (void **)&a.A));
+    if (repack) { ctx->i8_src[slot] = (const void *)rotf; ctx->i8_sig[slot][0] = sig0; ctx->i8_sig[slot][1] = sig1; }
     SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
+    // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers, and growing one re-runs its transposition below)
+    if (!repack && ctx->pool[names[slot]].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
     const double tile = 1024.0;
     if (repack) { PhaseTimer t(ctx, "mac_i8_pack_rot");
-      hipLaunchKernelGGL(k_i8_pack_rot, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * I8_ND * 1024, ctx->stream, a);
-      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K * std::min(32, R - r0) * 8.0 + (double)a.nch * 2 * I8_ND * tile)); }
+      hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * ND * 1024, ctx->stream, a);
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K * std::min(32, R - r0) * (BIG ? 16.0 : 8.0) + (double)a.nch * 2 * ND * tile)); }
     { PhaseTimer t(ctx, "mac_i8_pack_pt");
-      if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD))), dim3(256), 0, ctx->stream, a);
-      else hipLaunchKernelGGL(k_i8_pack_pt, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
-      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? 5.0 : 8.0) + (double)a.njt * a.nch * I8_ND * tile)); }
-    { PhaseTimer t(ctx, "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
-      if (a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
-      else hipLaunchKernelGGL(k_mac_i8, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
+      if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD))), dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL(k_i8_pack_pt<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
+    { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
+      if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
+      else hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
-      t.stop(1, (double)nl * ((double)N * a.nch * 2 * I8_ND * tile + (double)H * a.njt * a.nch * I8_ND * tile + (double)H * 2 * a.njt * 2 * 256 * 8.0)); }
+      t.stop(1, (double)nl * ((double)N * a.nch * 2 * ND * tile + (double)H * a.njt * a.nch * ND * tile + (double)H * 2 * a.njt * 2 * 256 * 8.0)); }
     { PhaseTimer t(ctx, "mac_i8_untile");
       hipLaunchKernelGGL(k_i8_untile, dim3((unsigned)((size_t)nl * (H / 16) * 2 * a.njt * 2)), dim3(256), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
       t.stop(1, (double)nl * N * (double)Ncols * std::min(32, R - r0) * 8.0 * (accumulate ? 3.0 : 2.0)); }
     return 0;
+}
+int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
+                        int l0, int nl, int accumulate, const MacStrides &st) {
+    return launch_mac_i8_nd<5>(ctx, rotf, rotf_k_stride, rotf_r_stride, plane0, pt, out, K, R, r0, Ncols, l0, nl, accumulate, st);
+}
+int launch_mac_i8_big(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
+                      int l0, int accumulate, const MacStrides &st) {
+    return launch_mac_i8_nd<6>(ctx, rotf, rotf_k_stride, rotf_r_stride, plane0, pt, out, K, R, r0, Ncols, l0, 1, accumulate, st);
 }

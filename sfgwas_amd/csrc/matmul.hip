@@ -324,7 +324,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             std::vector<int> po, ib; const int npl = mac_dma_planes(ctx, L, po, ib);
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
-                for (const char *nm : {"mm.pt", "mm.rotf", "mi8.A0", "mi8.A1", "mi8.B", "mi8.T"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
+                for (const char *nm : {"mm.pt", "mm.rotf", "mi8.A0", "mi8.A1", "mi8.Ab0", "mi8.Ab1", "mi8.B", "mi8.T"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
                 for (int cand : {24, 16}) {
                     const int G2 = std::min(cand, b1 - b0);
                     if (G2 <= G) break;
@@ -333,8 +333,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
-                        const size_t nch = ((size_t)G2 * d + 63) / 64;
-                        need += (size_t)nsm * ((size_t)N * nch * 10240 * 2 + (size_t)(N / 2) * 6 * nch * 5120 + (size_t)(N / 2) * 2 * 6 * 2 * 256 * 8);
+                        need += mac_i8_stream_bytes(G2 * d, nsm, 5, 2);
+                        if (ctx->cfg.mac_i8_big && nsm < L) need += mac_i8_stream_bytes(G2 * d, 1, 6, 2) - mac_i8_stream_bytes(G2 * d, 1, 6, 0) * 0;
                     }
                     if (need + (12ULL << 30) <= have) { G = G2; break; }
                 }
@@ -348,6 +348,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // the copy is reused: several block columns in this call, or so few groups that the copies survive from call to call (a caller's rotation cache multiplied one
     // block column at a time).  The association scan - one block column per batch against a 62-block-row cache - takes the fp64 kernel.
     const bool use_i8 = dma && ctx->cfg.mac_i8 && packed_mask && ((b1 - b0 + G - 1) / G <= 2 || j1 - j0 >= 4);
+    const bool use_i8_big = use_i8 && ctx->cfg.mac_i8_big;                    // the 46-bit modulus too: six digit planes, its own pair of transposed rot copies
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
     const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
@@ -449,7 +450,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 {
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask | (use_i8 ? 0x80000000u : 0u),
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u),
                                                          pcc.mode ? &pcc : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
@@ -462,7 +463,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8;   // pt[giant][g][baby]: k = g*91 + baby
+                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
@@ -876,7 +877,7 @@ extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int
                 SFG_HIP(ctx, hipGetLastError());
                 MacStrides st;
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;
-                st.pt_k = plw; st.pt_n = (size_t)d * plw; st.pt_half = true; st.pt_packed = packed_mask != 0; st.i8 = ctx->cfg.mac_i8 && packed_mask;     // panel[j][baby]
+                st.pt_k = plw; st.pt_n = (size_t)d * plw; st.pt_half = true; st.pt_packed = packed_mask != 0; st.i8 = ctx->cfg.mac_i8 && packed_mask; st.i8_big = st.i8 && ctx->cfg.mac_i8_big;     // panel[j][baby]
                 st.out_n = (size_t)d * accw; st.out_r = (size_t)L * N;                                           // acc[j][giant][r], column n = j
                 PhaseTimer t(ctx, "mac");
                 int r2 = launch_mac_dma(ctx, rotf, (size_t)s * 2, panel, acc + (size_t)cur_giant * accw, d, 2 * s, jn, L, 1, st, rotsum);

@@ -401,6 +401,26 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
 #endif
     // int8 MAC (mac_i8.hip; bit 31 of the mask): the packed rows leave as five planes of signed base-256 digits instead of words - 5 of the row's 8 bytes per word.
     // Balanced digits of v: the bytes of v + 0x8080808080 with their top bits flipped; the sum is read off the mantissa of v + 2^52 + 0x8080808080.
+    if constexpr (DIG) if (!((pm.packed_mask >> m) & 1u) && ((pm.packed_mask >> 30) & 1u)) {        // the 46-bit row as SIX digit planes (48 KiB of its 64 KiB)
+        uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
+        auto dig6 = [&](double x, unsigned &lo, unsigned &hi) {
+            const u64 b = (u64)__double_as_longlong(canon(x, q, qinv) + (4503599627370496.0 + 141289400074368.0));       // + 2^52 + 0x808080808080
+            lo = (unsigned)b ^ 0x80808080u; hi = (unsigned)(b >> 32) ^ 0x8080u;
+        };
+        auto st6 = [&](int j0, double x0, double x1, double x2, double x3) {
+            unsigned l0, l1, l2, l3, h0, h1, h2, h3;
+            dig6(x0, l0, h0); dig6(x1, l1, h1); dig6(x2, l2, h2); dig6(x3, l3, h3);
+            unsigned o[4]; bytes_tr4(l0, l1, l2, l3, o);
+#pragma unroll
+            for (int d = 0; d < 4; d++) *reinterpret_cast<unsigned *>(o8 + d * n + j0) = o[d];
+            unsigned p[4]; bytes_tr4(h0, h1, h2, h3, p);
+            *reinterpret_cast<unsigned *>(o8 + 4 * n + j0) = p[0];
+            *reinterpret_cast<unsigned *>(o8 + 5 * n + j0) = p[1];
+        };
+        if constexpr (PERM) ntt_half3_body<decltype(first), decltype(st6), decltype(fill), true>(0, first, st6, lds, tw, pack, q, qinv, tid, fill);
+        else ntt_half3_body<decltype(first), decltype(st6), NoFill, true>(0, first, st6, lds, tw, pack, q, qinv, tid);
+        return;
+    }
     if constexpr (DIG) if ((pm.packed_mask >> m) & 1u) {
         uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
         auto dig = [&](double x, unsigned &lo, unsigned &hi) {
