@@ -325,7 +325,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
                 for (const char *nm : {"mm.pt", "mm.rotf", "mi8.A0", "mi8.A1", "mi8.Ab0", "mi8.Ab1", "mi8.B", "mi8.T"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
-                for (int cand : {24, 16}) {
+                for (int cand : {24, 16, 12}) {
                     const int G2 = std::min(cand, b1 - b0);
                     if (G2 <= G) break;
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
@@ -334,7 +334,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
                         need += mac_i8_stream_bytes(G2 * d, nsm, 5, 2);
-                        if (ctx->cfg.mac_i8_big && nsm < L) need += mac_i8_stream_bytes(G2 * d, 1, 6, 2) - mac_i8_stream_bytes(G2 * d, 1, 6, 0) * 0;
+                        if (ctx->cfg.mac_i8_big && nsm < L) need += mac_i8_stream_bytes(G2 * d, 1, 6, 2);
                     }
                     if (need + (12ULL << 30) <= have) { G = G2; break; }
                 }
