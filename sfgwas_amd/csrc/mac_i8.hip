@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
     for (int ch = 0; ch < a.nch; ch++) {
         v4i b[ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++) { const uint4 w = Bp[(size_t)(ch * ND + d) * 64]; b[d] = (v4i){(int)w.x, (int)w.y, (int)w.z, (int)w.w}; }
+        for (int d = 0; d < ND; d++) b[d] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(Bp + (size_t)(ch * ND + d) * 64));       // read once: streamed past the caches, which keep the rot tiles the six waves share
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const uint4 *Ap = (t < 2 ? A0 : A1) + (size_t)((ch * 2 + (t & 1)) * ND) * 64;
