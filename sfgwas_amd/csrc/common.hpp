@@ -108,7 +108,7 @@ struct sfg_ctx {
     SfgConfig cfg;
     // int8 MAC (mac_i8.hip): generation of the fp64 rot operands - bumped by whoever rewrites a rotation cache - and the two transposed copies keyed by it
     unsigned ntt_plain_seq = 0;      // sampling counter of the panel-NTT phase timer (encode.hip)
-    u64 i8_gen = 1; const void *i8_src[4] = {nullptr, nullptr, nullptr, nullptr}; u64 i8_sig[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; int i8_next[2] = {0, 0};   // [0..1] 35-bit moduli, [2..3] the 46-bit one
+    u64 i8_gen = 1; const void *i8_src[4] = {nullptr, nullptr, nullptr, nullptr}; u64 i8_sig[4][8] = {}; int i8_next[2] = {0, 0};   // [0..1] 35-bit moduli, [2..3] the 46-bit one
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t user_stream = nullptr;   // installed by sfg_ctx_set_stream (nullptr = own_stream is the main queue)
     hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC

@@ -1,20 +1,22 @@
-// The ring MAC of the small (< 2^36) moduli on the int8 matrix core (SFG_MAC_IMPL=i8; experimental, not the default).
-// Same contract as the small-modulus launches of launch_mac_bc: out[n][r][l][x] (+)= sum_k pt[k][n][l][x'] * rotf[k][r][plane l][x] mod q_l, x' = x or N-1-x.
+// The ring MAC on the int8 matrix core: the default for the 35-bit moduli (SFG_MAC_IMPL=bc restores the fp64 kernel), an option for the 46-bit one (SFG_MAC_I8_BIG=1).
+// Same contract as the launches of launch_mac_bc: out[n][r][l][x] (+)= sum_k pt[k][n][l][x'] * rotf[k][r][plane l][x] mod q_l, x' = x or N-1-x.
 //
-// Per coefficient x that is a 32 x 96 x K GEMM over exact integers.  Both operands are written as five signed base-256 digits (pt canonical < 2^36, rot centred
-// < 2^35 in magnitude: the top digit stays within +-9), the 25 digit products of a k-step go through v_mfma_i32_16x16x64_i8 into NINE int32 sums per output - one per
-// digit-weight a + b, each |sum| <= 5 K 2^14 < 2^31 for K < 26 000 - and the nine are recombined mod q by Horner in the epilogue.  Nothing is rounded anywhere.
+// Per coefficient x that is a 32 x 96 x K GEMM over exact integers.  Both operands are written as ND signed base-256 digits (ND = 5: pt canonical < 2^36, rot centred;
+// ND = 6 for the 46-bit modulus), the ND^2 digit products of a k-step go through v_mfma_i32_16x16x64_i8 into 2 ND - 1 int32 sums per output - one per digit-weight
+// a + b, each |sum| <= ND K 2^14 < 2^31 - and the sums are recombined mod q by Horner in the epilogue.  Nothing is rounded anywhere.
 //
 // The matrix instruction contracts over k, so a lane needs 16 consecutive k of ONE coefficient; the product's operands are coefficient-contiguous (a plaintext NTT
-// owns all coefficients of one k).  Hence two transposition kernels into MFMA register order (1 KiB = 64 lanes x 16 bytes per operand tile, chunk of 64 k and digit):
-//   k_i8_pack_rot  rotf planes  -> A [m][x < N][ch][rt 2][a 5][1 KiB]       once per rot operand (a group's rotation cache serves every block column)
-//   k_i8_pack_pt   panel words  -> B [m][c < N/2][jt][ch][b 5][1 KiB]       once per launch
-// and the MAC proper streams both from global memory without LDS: a wave owns one coefficient pair (c, N-1-c share the plaintext word: the pt tile is loaded once for
-// 64 rows) x 16 columns = 4 row tiles x 9 weights = 36 accumulator tiles; the <= 6 column waves of a pair form a workgroup and share the rot tiles through the cache.
-// Results leave in tile order (T [m][c][half][jt][rt][lane][4]) and k_i8_untile adds them into the canonical accumulators with coefficient-contiguous runs.
+// owns all coefficients of one k).  Hence transposition kernels into MFMA register order (1 KiB = 64 lanes x 16 bytes per operand tile, chunk of 64 k and digit):
+//   k_i8_pack_rot<ND>        rotf planes         -> A [m][x < N][ch][rt 2][a ND][1 KiB]    once per rot operand generation (a group's rotation cache serves every column)
+//   k_i8_pack_pt_digits<ND>  NTT digit planes    -> B [m][c < N/2][jt][ch][b ND][1 KiB]    once per launch (k_i8_pack_pt<ND>: the same from panel words, DiagCache products)
+// and the MAC proper (k_mac_i8<ND>) streams both from global memory without LDS: a wave owns one coefficient pair (c, N-1-c share the plaintext word: the pt tile is
+// loaded once for 64 rows) x 16 columns = 4 row tiles x (2 ND - 1) weights of accumulator tiles; the <= 6 column waves of a pair form a workgroup and share the rot
+// tiles through the cache (k_mac_i8_lds stages them through LDS instead: measured slower).  Results leave in tile order (T [m][c][half][jt][rt][lane][4]) and
+// k_i8_untile adds them into the canonical accumulators with coefficient-contiguous runs.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -315,15 +317,15 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     const size_t nA = (size_t)nl * N * a.nch * 2 * ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
     // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column.
     // Two copies per kind of modulus (the pipelined product alternates between two rot buffers).
-    const u64 sig0 = ctx->i8_gen, sig1 = ((u64)K << 40) ^ ((u64)R << 28) ^ ((u64)r0 << 20) ^ ((u64)l0 << 12) ^ ((u64)nl << 8) ^ (u64)plane0 ^ ((u64)rotf_k_stride << 44);
+    const u64 sig[8] = {ctx->i8_gen, (u64)K, (u64)R, (u64)r0, (u64)l0, (u64)nl, (u64)plane0, (u64)rotf_k_stride};
     const int base = BIG ? 2 : 0;
     int slot = -1;
-    for (int i = base; i < base + 2; i++) if (ctx->i8_src[i] == (const void *)rotf && ctx->i8_sig[i][0] == sig0 && ctx->i8_sig[i][1] == sig1) slot = i;
+    for (int i = base; i < base + 2; i++) if (ctx->i8_src[i] == (const void *)rotf && !memcmp(ctx->i8_sig[i], sig, sizeof sig)) slot = i;
     const bool repack = slot < 0;
     if (repack) { slot = base + ctx->i8_next[BIG ? 1 : 0]; ctx->i8_next[BIG ? 1 : 0] ^= 1; }
     static const char *names[4] = {"mi8.A0", "mi8.A1", "mi8.Ab0", "mi8.Ab1"};
     SFG_TRY(sfg_scratch(ctx, names[slot], nA, (void **)&a.A));
-    if (repack) { ctx->i8_src[slot] = (const void *)rotf; ctx->i8_sig[slot][0] = sig0; ctx->i8_sig[slot][1] = sig1; }
+    if (repack) { ctx->i8_src[slot] = (const void *)rotf; memcpy(ctx->i8_sig[slot], sig, sizeof sig); }
     SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
     // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers, and growing one re-runs its transposition below)

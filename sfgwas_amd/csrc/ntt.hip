@@ -277,11 +277,19 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
     }
     // ---- phase B: thread (a, c), 32 values of b; stages t = 256 .. 16
     const int ab = 16 * hs + a_b;
+#if defined(SFG_NTT_DIAG) && SFG_NTT_DIAG == 3          // timing only: no phase-B twiddle loads
+    ct_stage<32, 16>(v, q, qinv, [&](int g) { return (double)(ab + g + 3); });
+    ct_stage<32, 8>(v, q, qinv, [&](int g) { return (double)(ab * 2 + g + 5); });
+    ct_stage<32, 4>(v, q, qinv, [&](int g) { return (double)(ab * 4 + g + 7); });
+    ct_stage<32, 2>(v, q, qinv, [&](int g) { return (double)(ab * 8 + g + 9); });
+    ct_stage<32, 1>(v, q, qinv, [&](int g) { return (double)(ab * 16 + g + 11); });
+#else
     ct_stage<32, 16>(v, q, qinv, [&](int g) { return tw[32 + ab + g]; });
     ct_stage<32, 8>(v, q, qinv, [&](int g) { return tw[64 + ab * 2 + g]; });
     ct_stage<32, 4>(v, q, qinv, [&](int g) { return tw[128 + ab * 4 + g]; });
     ct_stage<32, 2>(v, q, qinv, [&](int g) { return tw[256 + ab * 8 + g]; });
     ct_stage<32, 1>(v, q, qinv, [&](int g) { return tw[512 + ab * 16 + g]; });
+#endif
     // ---- B->C, phase C and the output staging are WAVE-PRIVATE.  Thread (a_b, c_b) of phase B and the phase-C owner of group (a, b) with
     // a = tid >> 4 live in the same 16-lane quarter of a wave: the B->C exchange is a 16 x 16 transpose inside each quarter, and staging a wave's
     // results for coalesced stores needs only that wave's four `a` rows.  So each wave works in its own 8 KiB of the (dead) A->B image with
