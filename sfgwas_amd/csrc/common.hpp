@@ -54,6 +54,7 @@ struct SfgConfig {
     bool mac_reg = false;          // SFG_MAC_IMPL=reg      register-staged MAC kernel (mac.hip)
     bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
     bool mac_i8 = true;            // SFG_MAC_IMPL=bc       the DPP-broadcast fp64 kernel for every modulus (round 2's MAC) instead of: small moduli on the int8 matrix core (mac_i8.hip), the 46-bit one on the DPP-broadcast kernel
+    size_t i8_keep_reserve = 80ULL << 30;   // SFG_I8_KEEP_RESERVE_GB  HBM that must stay free beside the transposed copies of ALL groups of a caller's rotation cache (association scan) for the int8 MAC to take that call
     bool mac_i8_big = false;       // SFG_MAC_I8_BIG=1      the 46-bit modulus on the int8 matrix core too (six digits, 36 products, eleven sums) instead of the fp64 DPP-broadcast kernel: identical words, measured slower (13.06 s against 12.49 s per power iteration: its own transposition passes cost more than the kernel saves)
     bool mac_i8_nolds = true;      // SFG_MAC_I8_ROT=lds    int8 MAC: rot tiles of a coefficient pair staged through LDS (k_mac_i8_lds) instead of shared through the cache (measured at 100k x 1M: 3.31 s against 2.56 s per step - the barriers cost more than the re-fetches)
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
@@ -108,7 +109,11 @@ struct sfg_ctx {
     SfgConfig cfg;
     // int8 MAC (mac_i8.hip): generation of the fp64 rot operands - bumped by whoever rewrites a rotation cache - and the two transposed copies keyed by it
     unsigned ntt_plain_seq = 0;      // sampling counter of the panel-NTT phase timer (encode.hip)
-    u64 i8_gen = 1; const void *i8_src[4] = {nullptr, nullptr, nullptr, nullptr}; u64 i8_sig[4][8] = {}; int i8_next[2] = {0, 0};   // [0..1] 35-bit moduli, [2..3] the 46-bit one
+    // A copy is recycled when its generation is stale (a product's groups), kept while it is current (a caller's rotation cache multiplied batch after batch:
+    // one copy per group of the cache, as many as the free HBM takes).
+    struct I8Slot { const void *src = nullptr; u64 sig[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 last_use = 0; };
+    static constexpr int I8_SLOTS = 16;
+    u64 i8_gen = 1, i8_clock = 0; I8Slot i8_slot[2][I8_SLOTS];   // [0] 35-bit moduli, [1] the 46-bit one
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t user_stream = nullptr;   // installed by sfg_ctx_set_stream (nullptr = own_stream is the main queue)
     hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC

@@ -28,6 +28,7 @@ int mac_i8_set_attrs(sfg_ctx *ctx);
 static void read_config(SfgConfig &c) {
     auto env = [](const char *n) { return getenv(n); };
     if (const char *e = env("SFG_MAC_IMPL")) { c.mac_reg = !strcmp(e, "reg"); c.mac_bc = strcmp(e, "dma") != 0 && !c.mac_reg; c.mac_i8 = !strcmp(e, "i8"); }      // bc | dma | reg | i8
+    if (const char *e = env("SFG_I8_KEEP_RESERVE_GB")) c.i8_keep_reserve = (size_t)atoll(e) << 30;
     if (const char *e = env("SFG_MAC_I8_BIG")) c.mac_i8_big = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_ROT")) c.mac_i8_nolds = strcmp(e, "lds") != 0;
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;

@@ -318,18 +318,35 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column.
     // Two copies per kind of modulus (the pipelined product alternates between two rot buffers).
     const u64 sig[8] = {ctx->i8_gen, (u64)K, (u64)R, (u64)r0, (u64)l0, (u64)nl, (u64)plane0, (u64)rotf_k_stride};
-    const int base = BIG ? 2 : 0;
+    sfg_ctx::I8Slot *slots = ctx->i8_slot[BIG ? 1 : 0];
     int slot = -1;
-    for (int i = base; i < base + 2; i++) if (ctx->i8_src[i] == (const void *)rotf && !memcmp(ctx->i8_sig[i], sig, sizeof sig)) slot = i;
+    for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) if (slots[i].src == (const void *)rotf && !memcmp(slots[i].sig, sig, sizeof sig)) slot = i;
     const bool repack = slot < 0;
-    if (repack) { slot = base + ctx->i8_next[BIG ? 1 : 0]; ctx->i8_next[BIG ? 1 : 0] ^= 1; }
-    static const char *names[4] = {"mi8.A0", "mi8.A1", "mi8.Ab0", "mi8.Ab1"};
-    SFG_TRY(sfg_scratch(ctx, names[slot], nA, (void **)&a.A));
-    if (repack) { ctx->i8_src[slot] = (const void *)rotf; memcpy(ctx->i8_sig[slot], sig, sizeof sig); }
+    char nm[24];
+    if (repack) {
+        // victim: a copy of a stale generation (a product's earlier group), else an unused slot if the HBM takes another copy, else the least recently used one
+        int stale = -1, empty = -1, lru = 0;
+        for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) {
+            if (!slots[i].src) { if (empty < 0) empty = i; continue; }
+            if (slots[i].sig[0] != ctx->i8_gen && (stale < 0 || slots[i].last_use < slots[stale].last_use)) stale = i;
+            if (slots[i].last_use < slots[lru].last_use || !slots[lru].src) lru = i;
+        }
+        slot = stale;
+        if (slot < 0 && empty >= 0) {
+            int live = 0; for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) live += slots[i].src != nullptr;
+            size_t fr = 0, tot = 0;
+            if (live < 2 || (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= nA + (48ULL << 30))) slot = empty;
+        }
+        if (slot < 0) slot = lru;
+    }
+    snprintf(nm, sizeof nm, BIG ? "mi8.Ab%d" : "mi8.A%d", slot);
+    SFG_TRY(sfg_scratch(ctx, nm, nA, (void **)&a.A));
+    if (repack) { slots[slot].src = (const void *)rotf; memcpy(slots[slot].sig, sig, sizeof sig); }
+    slots[slot].last_use = ++ctx->i8_clock;
     SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
-    // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers, and growing one re-runs its transposition below)
-    if (!repack && ctx->pool[names[slot]].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
+    // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers)
+    if (!repack && ctx->pool[nm].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
     const double tile = 1024.0;
     if (repack) { PhaseTimer t(ctx, "mac_i8_pack_rot");
       hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * ND * 1024, ctx->stream, a);

@@ -324,7 +324,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             std::vector<int> po, ib; const int npl = mac_dma_planes(ctx, L, po, ib);
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
-                for (const char *nm : {"mm.pt", "mm.rotf", "mi8.A0", "mi8.A1", "mi8.Ab0", "mi8.Ab1", "mi8.B", "mi8.T"}) { auto it = ctx->pool.find(nm); if (it != ctx->pool.end()) have += it->second.second; }   // regrown in place
+                for (const auto &kv : ctx->pool) if (kv.first == "mm.pt" || kv.first == "mm.rotf" || kv.first.rfind("mi8.", 0) == 0) have += kv.second.second;   // regrown in place
                 for (int cand : {24, 16, 12}) {
                     const int G2 = std::min(cand, b1 - b0);
                     if (G2 <= G) break;
@@ -333,8 +333,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
-                        need += mac_i8_stream_bytes(G2 * d, nsm, 5, 2);
-                        if (ctx->cfg.mac_i8_big && nsm < L) need += mac_i8_stream_bytes(G2 * d, 1, 6, 2);
+                        need += mac_i8_stream_bytes(G2 * d, nsm, 5, 1);          // (one transposed rot copy: a group's copy is recycled for the next group, in stream order)
+                        if (ctx->cfg.mac_i8_big && nsm < L) need += mac_i8_stream_bytes(G2 * d, 1, 6, 1);
                     }
                     if (need + (12ULL << 30) <= have) { G = G2; break; }
                 }
@@ -347,7 +347,15 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // The int8 MAC multiplies with a k-contiguous copy of a group's rot operand, transposed when the operand changes and kept for two operands.  That pays when
     // the copy is reused: several block columns in this call, or so few groups that the copies survive from call to call (a caller's rotation cache multiplied one
     // block column at a time).  The association scan - one block column per batch against a 62-block-row cache - takes the fp64 kernel.
-    const bool use_i8 = dma && ctx->cfg.mac_i8 && packed_mask && ((b1 - b0 + G - 1) / G <= 2 || j1 - j0 >= 4);
+    bool keep_all = false;                                  // a caller's rotation cache of up to 16 groups whose transposed copies all fit: the association scan
+    if (dma && ctx->cfg.mac_i8 && packed_mask && rotf_pre && (b1 - b0 + G - 1) / G <= 16) {
+        int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
+        const size_t per = mac_i8_stream_bytes(G * d, nsm, 5, 1) - mac_i8_stream_bytes(G * d, nsm, 5, 0), ngr = (size_t)(b1 - b0 + G - 1) / G;
+        size_t fr = 0, tot = 0, held = 0;
+        for (const auto &kv : ctx->pool) if (kv.first.rfind("mi8.A", 0) == 0) held += kv.second.second;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) keep_all = fr + held >= ngr * per + mac_i8_stream_bytes(G * d, nsm, 5, 0) + ctx->cfg.i8_keep_reserve;     // (the panel, accumulators and key-switch scratch of the call are still to be allocated the first time)
+    }
+    const bool use_i8 = dma && ctx->cfg.mac_i8 && packed_mask && ((b1 - b0 + G - 1) / G <= 2 || j1 - j0 >= 4 || keep_all);
     const bool use_i8_big = use_i8 && ctx->cfg.mac_i8_big;                    // the 46-bit modulus too: six digit planes, its own pair of transposed rot copies
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
     const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
@@ -549,7 +557,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
                                  int blk0, int blk1, uint64_t *out, const double *rotf_ext) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->phases.clear();
-    ctx->i8_gen++;                                              // a new product: whatever rot operand the int8 MAC had transposed is stale
+    if (!rotf_ext) ctx->i8_gen++;                               // a product that builds its own rot operands: whatever the int8 MAC had transposed is stale
     Shape sh = make_shape(g, flags);
     const int d = SFG_D, L = max_level, N = SFG_N;
     const size_t accw = (size_t)s * 2 * L * N;
