@@ -325,7 +325,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
                 for (const auto &kv : ctx->pool) if (kv.first == "mm.pt" || kv.first == "mm.rotf" || kv.first.rfind("mi8.", 0) == 0) have += kv.second.second;   // regrown in place
-                for (int cand : {24, 16, 12}) {
+                for (int cand : {24, 20, 16, 14, 12, 10}) {
                     const int G2 = std::min(cand, b1 - b0);
                     if (G2 <= G) break;
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
