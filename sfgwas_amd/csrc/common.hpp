@@ -62,6 +62,9 @@ struct SfgConfig {
     bool mm_group_auto = true;     //                       (unset) 16 block rows per launch when the plaintext panel and the rotation operands of such a group fit the free HBM, else 8
     size_t acc_budget = 24ULL << 30;   // SFG_MM_ACC_BUDGET_MB
     bool no_overlap = false;       // SFG_MM_NO_OVERLAP     single queue
+    bool no_enc_overlap = true;    // SFG_MM_ENC_OVERLAP=1  the encode of MAC launch k + 1 on a third queue beside the transposition + MAC of launch k (two plaintext panels).  Built and measured at
+                                   // 100k x 1M: 12.24 s against 12.20 s - the kernels then share the machine in time, not in space: a MAC workgroup (6 waves x 240 VGPRs) leaves no SIMD
+                                   // with the 128 VGPRs a plaintext-NTT wave needs, so an encode workgroup cannot be resident beside it.  Off until the MAC leaves that room.
     bool ntt_fwd_full = false;     // SFG_NTT_FWD_IMPL=full   one 512-thread workgroup per row for the general forward NTT (instead of two half-row workgroups)
     bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
@@ -119,6 +122,8 @@ struct sfg_ctx {
     hipStream_t aux_stream = nullptr;    // second queue: key switching of the next group / previous column pass runs beside encode + MAC
     // pinned host ring for small stream-ordered uploads (pointer tables): no blocking copies on the launch path
     unsigned char *pin = nullptr; size_t pin_bytes = 0, pin_head = 0;
+    hipStream_t enc_stream = nullptr;    // third queue: the encode (skew, FFT, NTT: fp64-issue bound) of MAC launch k + 1 beside the HBM-bound transposition + int8 MAC of launch k
+    hipEvent_t ev_enc[4] = {nullptr, nullptr, nullptr, nullptr};    // [0,1]: panel buffer encoded; [2,3]: panel buffer consumed by its MAC
     hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // [0,1]: rotation cache of group parity ready; [2,3]: finalize of column pass parity done
     std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;     // ordering events (no timing), reused round-robin
     std::map<int, void *> ksw_cache;   // per-level key-switch constants (device), rotate.hip

@@ -35,6 +35,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
     if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
     c.no_overlap = env("SFG_MM_NO_OVERLAP") != nullptr;
+    if (const char *e = env("SFG_MM_ENC_OVERLAP")) c.no_enc_overlap = atoi(e) == 0;
     if (const char *e = env("SFG_NTT_HALF_IMPL")) c.ntt_half_full = !strcmp(e, "full");
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
     c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
@@ -60,7 +61,9 @@ static const char *ctx_exec_init(sfg_ctx *ctx) {
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) return "hipStreamCreate failed";
     }
+    if (hipStreamCreateWithFlags(&ctx->enc_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_enc[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     ctx->pin_bytes = 64u << 20;
     if (hipHostMalloc((void **)&ctx->pin, ctx->pin_bytes, hipHostMallocDefault) != hipSuccess) return "hipHostMalloc failed";
     if (hipMalloc(&ctx->tie_count_dev, 16) != hipSuccess || hipMemset(ctx->tie_count_dev, 0, 16) != hipSuccess) return "hipMalloc failed";
@@ -161,6 +164,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->enc_stream) (void)hipStreamSynchronize(ctx->enc_stream);
     if (ctx->user_stream) (void)hipStreamSynchronize(ctx->user_stream);
     sfg_phases_resolve(ctx);
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
@@ -168,6 +172,8 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     (void)hipFree(ctx->ws); (void)hipFree(ctx->tie_count_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->enc_stream) (void)hipStreamDestroy(ctx->enc_stream);
+    for (int i = 0; i < 4; i++) if (ctx->ev_enc[i]) (void)hipEventDestroy(ctx->ev_enc[i]);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; i++) if (ctx->ev_pipe[i]) (void)hipEventDestroy(ctx->ev_pipe[i]);
@@ -200,6 +206,7 @@ int sfg_sync_all(sfg_ctx *ctx) {
     if (ctx->user_stream && ctx->user_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->user_stream));
     if (ctx->own_stream && ctx->own_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
     if (ctx->aux_stream && ctx->aux_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+    if (ctx->enc_stream && ctx->enc_stream != ctx->stream) SFG_HIP(ctx, hipStreamSynchronize(ctx->enc_stream));
     return 0;
 }
 

@@ -329,7 +329,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     const int G2 = std::min(cand, b1 - b0);
                     if (G2 <= G) break;
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
-                    size_t need = (size_t)G2 * nplain * L * ((size_t)N / 2) * 8;
+                    const bool enc2 = !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G2 - 1) / G2) * (j1 - j0) >= 2;
+                    size_t need = (size_t)G2 * nplain * L * ((size_t)N / 2) * 8 * (enc2 ? 2 : 1);
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
@@ -361,7 +362,11 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", dma ? 8 : (size_t)d * s * ctw * 8, (void **)&rotc));     // u64 rotation cache: only the register-staged MAC reads one
-    SFG_TRY(sfg_scratch(ctx, "mm.pt", (size_t)G * nplain * L * prow * 8, (void **)&pt));
+    // Two plaintext panels when the encode of launch k + 1 runs on its own queue beside the transposition + MAC of launch k (fp64-issue bound beside HBM bound)
+    const bool enc_ov = dma && !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G - 1) / G) * (j1 - j0) >= 2;
+    const size_t panel_words = (size_t)G * nplain * L * prow;
+    SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov ? 2 : 1), (void **)&pt));
+    u64 *const pt_base = pt;
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
     int8_t *unpacked = nullptr;
     if (sh.g->packed) SFG_TRY(sfg_scratch(ctx, "mm.unpack", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&unpacked));
@@ -394,7 +399,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         { AuxScope aux(ctx); SFG_TRY(build_group(b0, 0)); }
         SFG_HIP(ctx, hipEventRecord(ctx->ev_pipe[0], ctx->aux_stream));
     }
-    int gi = 0;
+    int gi = 0, it = 0;
+    struct StreamRestore { sfg_ctx *c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore_main{ctx, main_stream};       // whatever path leaves the loop
+    if (enc_ov) SFG_TRY(sfg_stream_after(ctx, ctx->enc_stream, main_stream));      // the genotypes, the cache slots and whatever the caller enqueued before
     for (int bg = b0; bg < b1 && !rc; bg += G, gi++) {
         const int ng = std::min(G, b1 - bg);
         // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
@@ -413,8 +420,14 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             rc = build_group(bg, 0);
             if (rc) break;
         }
-        for (int bj = j0; bj < j1 && !rc; bj++) {
+        for (int bj = j0; bj < j1 && !rc; bj++, it++) {
             const int nc = sh.cols_of(bj);
+            const int pbuf = enc_ov ? (it & 1) : 0;
+            pt = pt_base + (size_t)pbuf * panel_words;
+            if (enc_ov) {                                  // encode on its queue: after the MAC that last read this panel buffer
+                if (it >= 2) SFG_HIP(ctx, hipStreamWaitEvent(ctx->enc_stream, ctx->ev_enc[2 + pbuf], 0));
+                ctx->stream = ctx->enc_stream;
+            }
             for (int g = 0; g < ng && !rc; g++) {
                 const int bi = bg + g, nr = sh.rows_of(bi);
                 // plaintext coefficient cache of the stored block (sfg_geno_set_plaintext_cache)
@@ -466,6 +479,10 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 }
                 if (rc) ptc_undo();
             }
+            if (enc_ov) {
+                ctx->stream = main_stream;
+                if (!rc) { SFG_HIP(ctx, hipEventRecord(ctx->ev_enc[pbuf], ctx->enc_stream)); SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_enc[pbuf], 0)); }
+            }
             if (rc) break;
             {
                 PhaseTimer t(ctx, "mac");
@@ -479,6 +496,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
                 t.stop(1);
             }
+            if (enc_ov && !rc) SFG_HIP(ctx, hipEventRecord(ctx->ev_enc[2 + pbuf], main_stream));
         }
         first_group = false;
     }
