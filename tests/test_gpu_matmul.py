@@ -83,3 +83,10 @@ def test_transposed_operand_two_block_rows(env):
 
 def test_level_drop(env):
     run_case(env, 25, 25, 1, 7, 5, 0, 4)
+
+
+@pytest.mark.parametrize("s,in_level,max_level", [(1, 5, 3), (3, 4, 2), (17, 5, 5), (13, 5, 4)])
+def test_fewer_moduli_and_row_counts(env, s, in_level, max_level):
+    """max_level < 5 (three / two / four of the product's moduli: the int8 MAC's modulus indexing, with and without the 46-bit row beside it) and row counts
+    that are neither 30 nor a multiple of 16 (s = 17: two row passes of 30 + 4; s = 13: the association scan's 26 rows; s = 3: one partly filled row tile)"""
+    run_case(env, 70, 50, s, in_level, max_level, 0, 40 + s)
