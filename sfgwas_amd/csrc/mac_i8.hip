@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
                 for (int d = 0; d < ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[d], acc[t][x + d], 0, 0, 0);
             }
         }
-        __syncthreads();                                 // the column waves of a pair stay within one chunk of each other: the rot tiles come from HBM once
+        // (no workgroup barrier: a barrier drains every wave's loads at every chunk and exposes the load latency 23 times per workgroup; left alone the six waves
+        //  drift by a few chunks and still find the pair's rot tiles in the L2)
     }
     // sum_s D_s 256^s mod q by Horner: |r| <= q/2 and |D| < 2^31, so r 256 + D is exact in fp64; then canonical
 #pragma unroll
