@@ -102,21 +102,53 @@ def cpu_model():
     return "unknown"
 
 
+def granted_cores():
+    """cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a 1-GPU lease of a 256-thread host is a fraction of it)"""
+    present = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = present
+    quota = None
+    try:                                                    # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    granted = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return granted, {"present": present, "affinity": aff, "cgroup_quota_cpus": quota, "granted": granted}
+
+
 def cpu_baseline(seconds, L, N, D):
     """the reference's MAC loop (matmult.go:247-289,380-399) restated in C, built -O3 -march=native ON this host, with the
-    reference's data layout (shared rotCache[i][baby], u128 accCache[i][giant]), all host threads; encode excluded"""
+    reference's data layout (shared rotCache[i][baby], u128 accCache[i][giant]); one thread per GRANTED core (affinity mask capped by the
+    cgroup quota), every buffer first-touched before the clock starts, >= 3 whole passes over the sample; encode excluded"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle_native.so"))
     lib.orc_bench_mac_ref_layout.restype = C.c_double
-    lib.orc_bench_mac_ref_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
-    threads = os.cpu_count() or 1
-    n_done, active = C.c_longlong(), C.c_int()
-    rate = lib.orc_bench_mac_ref_layout(KP, L, N, D, threads, float(seconds), C.byref(n_done), C.byref(active))
-    return {"value": rate, "unit": "ring-MAC/s", "cores": active.value, "kind": "port", "cpu": cpu_model(),
-            "build": "gcc -O3 -march=native -fopenmp (oracle/Makefile: native)",
+    lib.orc_bench_mac_ref_layout.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    threads, cores = granted_cores()
+    n_done, active, secs = C.c_longlong(), C.c_int(), C.c_double()
+    # calibration: one pass over 2 items per thread (not reported), then the sample sized so that PASSES whole passes take about `seconds`
+    passes, total_items = 3, KP * D
+    cal_items = min(total_items, 2 * threads)
+    cal = lib.orc_bench_mac_ref_layout(KP, L, N, D, threads, cal_items, 1, C.byref(n_done), C.byref(active), C.byref(secs))
+    macs_per_item = D * 2 * L * N
+    items = int(max(threads, min(total_items, cal * seconds / passes / macs_per_item)))
+    rate = lib.orc_bench_mac_ref_layout(KP, L, N, D, threads, items, passes, C.byref(n_done), C.byref(active), C.byref(secs))
+    return {"value": rate, "unit": "ring-MAC/s", "cores": active.value, "cores_granted_vs_present": cores, "kind": "port", "cpu": cpu_model(),
+            "build": "gcc -O3 -march=native -fopenmp (oracle/Makefile: native)", "per_core": rate / max(active.value, 1),
             "sample": f"reference MAC loop CPMultAccWithoutMRedV2 (u128 lazy accumulation, s={KP}, L={L}, N={N}) in the reference's layout: shared "
-                      f"rotCache[i][baby] ({KP * D} cts), accCache[i][giant] of one block column ({KP * D} work items = the reference's lock units), one "
-                      f"plaintext per diagonal; {active.value} of {threads} threads computed x {seconds:.0f} s = {n_done.value:.3e} MACs; cached-diagonal "
+                      f"rotCache[i][baby] ({KP * D} cts), {items} of the {total_items} accCache[i][giant] of one block column (the reference's lock units) as work items, "
+                      f"one plaintext per diagonal; {passes} whole passes = {n_done.value:.3e} MACs in {secs.value:.1f} s on {active.value} threads "
+                      f"(cores granted {cores['granted']} of {cores['present']} present); all buffers first-touched before the clock; cached-diagonal "
                       f"mode (encode excluded); CPU restatement, not the Go binary"}
 
 
@@ -173,7 +205,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("SFG_BENCH_CONFIG", "c4"))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (seconds of wall time)")
+    ap.add_argument("--cpu-seconds", type=float, default=18.0, help="bounded CPU-baseline sample (seconds of wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle parity gate")
     ap.add_argument("--no-digest", action="store_true", help="skip the SHA-256 digests of the outputs")
@@ -181,6 +213,19 @@ def main():
                     help="nccl = RCCL, one GPU per rank (the measured path); gloo = host-staged collectives, ranks may share one GPU (rehearsal)")
     ap.add_argument("--packed-geno", action="store_true", help="keep the genotype matrix 2-bit packed in HBM (sfg_geno_pack: 4x smaller, blocks expanded on the fly)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (one per GPU, torch.distributed.run) before
+    # anything in this process touches torch.cuda / HIP, relay rank 0's JSON line and exit with the launcher's code.  (No exec: a process that has
+    # initialised the GPU must not be replaced, and this parent never initialises it.)
+    if args.gpus > 1 and "RANK" not in os.environ and not os.environ.get("SFG_BENCH_SOLO"):
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
@@ -236,10 +281,11 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream))
 
     def chk(rc, what):
         ctx.check(rc, what)
+
+    chk(lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)), "set_stream")     # a refused handle would leave the collectives unordered against the MAC
 
     rots = P.rotations_for_matmul()
     arr = (C.c_int * len(rots))(*rots)
@@ -496,7 +542,9 @@ def main():
             NTT_FP64_INSTR = 2016                                               # fp64 vector instructions per thread of k_ntt_half3 (static count of the gfx950 ISA)
             ntt_instr_s = plains_per_launch * L * 256 * NTT_FP64_INSTR / (ntt_avg_ms * 1e-3) if n_ntt else 0.0
             ntt_blk = {"bound": "valu_fp64", "achieved": 2.0 * ntt_instr_s / 1e12, "peak": 2.0 * FP64_VALU_SPEC_FMA_S / 1e12, "unit": "TFLOP/s",
-                       "frac": ntt_instr_s / FP64_VALU_SPEC_FMA_S, "kernel": "k_ntt_half3<false, true>", "avg_launch_ms": ntt_avg_ms, "launches": n_ntt_all,
+                       "frac": ntt_instr_s / FP64_VALU_SPEC_FMA_S, "frac_kind": "fp64 ISSUE-SLOT fraction: every fp64 vector instruction (mul, rndne, fma, add) counts as one slot "
+                       "of 64 lanes; 'TFLOP/s' here is slots x 64 lanes x 2 (FMA-equivalent) so that it compares with the guide's fp64 vector peak - it is not a count of "
+                       "floating-point operations performed", "kernel": "k_ntt_half3<false, true>", "avg_launch_ms": ntt_avg_ms, "launches": n_ntt_all,
                        "launches_timed": n_ntt, "total_ms_in_timed_region": ntt_total_ms,
                        "what": "plaintext (panel) NTT: 2016 fp64 vector instructions per thread and (plaintext, modulus) row (13 stages x 16 butterflies x 8 + the degenerate first "
                                "stage + canonicalisation), one issue slot = 64 lanes counted as 2 flop (FMA-equivalent; the mix is mul, rndne, fma, add) against the fp64 vector peak "

@@ -1068,55 +1068,72 @@ double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long lon
 
 /* cpu_baseline with the REFERENCE's data layout (matmult.go:1065-1068,1121-1129,1154-1168): one shared rotCache[i][baby]
  * (s*d ciphertexts), lazily reduced u128 accumulators accCache[i][giant] for ONE output block column (m_ct = 1), one plaintext per
- * diagonal.  The work items are the reference's lock units accCache[i][giant] (s*d = 1365 of them: every stated thread computes; the reference
+ * diagonal.  The work items are the reference's lock units accCache[i][giant] (the first `items` of the s*d = 1365; the reference
  * locks accCacheMux[i][giant] instead of owning it, and ownership costs no lock traffic, so this flatters the CPU slightly).  Encode is excluded
- * (cached-diagonal mode, MatMult4StreamCompute): the plaintext words are random.  Returns u128 MACs per second over all threads;
- * *threads_active = threads that executed at least one MAC. */
-double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double seconds, long long *macs_done, int *threads_active) {
+ * (cached-diagonal mode, MatMult4StreamCompute): the plaintext words are random.
+ * Measurement hygiene (round 4): every buffer is allocated AND written by the thread team before the clock starts (first touch outside the timed
+ * region), the timed region is `passes` WHOLE passes over the items (no stop flag inside a pass), and the caller states the thread count - the cores
+ * its cgroup / affinity mask actually grants, not the cores the machine has.
+ * Returns u128 MACs per second over all threads; *threads_active = threads that executed at least one item; *seconds_out = the timed region. */
+double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, int items, int passes, long long *macs_done, int *threads_active,
+                                double *seconds_out) {
     size_t ctw = (size_t)2 * (L + 1) * N, accw = (size_t)2 * L * N * 2;
+    if (items < 1 || items > s * d) items = s * d;
+    if (passes < 1) passes = 1;
     u64 **rot = malloc(sizeof(u64 *) * (size_t)s * d), **acc = malloc(sizeof(u64 *) * (size_t)s * d);
-    for (size_t k = 0; k < (size_t)s * d; k++) { rot[k] = malloc(ctw * 8); acc[k] = NULL; }
+    for (size_t k = 0; k < (size_t)s * d; k++) { rot[k] = NULL; acc[k] = NULL; }
 #pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int k = 0; k < s * d; k++) {
         u64 st = 0x9876 + 131 * (u64)k;
+        rot[k] = malloc(ctw * 8);
         for (size_t x = 0; x < ctw; x++) rot[k][x] = orc_splitmix64(&st) >> 18;
-        acc[k] = calloc(accw, 8);
     }
-    long long total = 0; int stop = 0, active = 0;
-    double t_begin = omp_get_wtime(), t_end;
-#pragma omp parallel num_threads(nthreads) reduction(+ : total, active)
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int item = 0; item < items; item++) {                          /* pre-touch: every accumulator page is mapped before the clock starts */
+        const int giant = item / s, i = item % s;
+        u64 *a = malloc(accw * 8);
+        memset(a, 0, accw * 8);
+        acc[(size_t)i * d + giant] = a;
+    }
+    long long total = 0; int active = 0;
+    u64 **pts = malloc(sizeof(u64 *) * (size_t)nthreads);
+#pragma omp parallel num_threads(nthreads)
     {
         u64 *pt = malloc((size_t)(L + 1) * N * 8);
         u64 st = 0x1234 + 77 * (u64)omp_get_thread_num();
         for (size_t x = 0; x < (size_t)(L + 1) * N; x++) pt[x] = orc_splitmix64(&st) >> 18;
+        pts[omp_get_thread_num()] = pt;
+    }
+    double t_begin = omp_get_wtime(), t_end;
+#pragma omp parallel num_threads(nthreads) reduction(+ : total, active)
+    {
+        const u64 *pt = pts[omp_get_thread_num()];
         long long mine = 0;
-        while (!stop) {
+        for (int pass = 0; pass < passes; pass++) {
 #pragma omp for schedule(dynamic) nowait
-            for (int item = 0; item < s * d; item++) {                  /* item = accCache[i][giant] */
+            for (int item = 0; item < items; item++) {                  /* item = accCache[i][giant] */
                 const int giant = item / s, i = item % s;
                 u64 *a = acc[(size_t)i * d + giant];
-                for (int baby = 0; baby < d && !stop; baby++) {         /* CPMultAccWithoutMRedV2(rotCache[i][baby], plainVec, accCache[i][giant]) */
+                for (int baby = 0; baby < d; baby++) {                  /* CPMultAccWithoutMRedV2(rotCache[i][baby], plainVec, accCache[i][giant]) */
                     const u64 *rc = rot[(size_t)i * d + baby];
                     for (int l = 0; l < L; l++) {
                         orc_mul_coeffs_and_add128(rc + (size_t)l * N, pt + (size_t)l * N, a + ((size_t)l * N) * 2, N);
                         orc_mul_coeffs_and_add128(rc + (size_t)(L + 1 + l) * N, pt + (size_t)l * N, a + ((size_t)(L + l) * N) * 2, N);
                     }
                     mine += (long long)2 * L * N;
-                    if (omp_get_wtime() - t_begin >= seconds) {
-#pragma omp atomic write
-                        stop = 1;
-                    }
                 }
             }
         }
         total += mine; active += mine > 0;
-        free(pt);
     }
     t_end = omp_get_wtime();
+    for (int t = 0; t < nthreads; t++) free(pts[t]);
+    free(pts);
     for (size_t k = 0; k < (size_t)s * d; k++) { free(rot[k]); free(acc[k]); }
     free(rot); free(acc);
     if (macs_done) *macs_done = total;
     if (threads_active) *threads_active = active;
+    if (seconds_out) *seconds_out = t_end - t_begin;
     return (double)total / (t_end - t_begin);
 }
 

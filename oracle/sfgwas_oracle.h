@@ -149,7 +149,8 @@ double orc_bench_mac(int s, int L, int N, int nthreads, double seconds, long lon
 
 /* the same MAC loop on the reference's data layout: shared rotCache[i][baby], u128 accCache[i][giant] of one block column,
  * workers taking whole diagonals (matmult.go:1065-1068,1121-1168) */
-double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, double seconds, long long *macs_done, int *threads_active);
+double orc_bench_mac_ref_layout(int s, int L, int N, int d, int nthreads, int items, int passes, long long *macs_done, int *threads_active,
+                                double *seconds_out);
 
 /* ---- DiagCache file format (gwas/filestream.go:19-282) ---- */
 /* payload byte order for coefficients: big-endian u64 (lattigo ring.WriteCoeffsTo, unverified — see header) */

@@ -57,6 +57,7 @@ struct SfgConfig {
     size_t i8_keep_reserve = 80ULL << 30;   // SFG_I8_KEEP_RESERVE_GB  HBM that must stay free beside the transposed copies of ALL groups of a caller's rotation cache (association scan) for the int8 MAC to take that call
     bool mac_i8_big = false;       // SFG_MAC_I8_BIG=1      the 46-bit modulus on the int8 matrix core too (six digits, 36 products, eleven sums) instead of the fp64 DPP-broadcast kernel: identical words, measured slower (13.06 s against 12.49 s per power iteration: its own transposition passes cost more than the kernel saves)
     bool mac_i8_nolds = true;      // SFG_MAC_I8_ROT=lds    int8 MAC: rot tiles of a coefficient pair staged through LDS (k_mac_i8_lds) instead of shared through the cache (measured at 100k x 1M: 3.31 s against 2.56 s per step - the barriers cost more than the re-fetches)
+    bool mac_i8_wg1 = false;       // SFG_MAC_I8_WG=1       int8 MAC diagnostic: one column wave per workgroup (no cache shared between the column waves of a coefficient pair); for the PMC re-fetch measurement
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
     bool mm_group_auto = true;     //                       (unset) 16 block rows per launch when the plaintext panel and the rotation operands of such a group fit the free HBM, else 8

@@ -155,8 +155,12 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
 template <int ND>
 __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *modc) {
     const int N = SFG_N, H = N / 2;
-    const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6;
-    const int c = blockIdx.x % H, m = blockIdx.x / H;
+    const int lane = threadIdx.x & 63;
+    // wave -> (modulus, coefficient pair, column tile).  Default: the njt column waves of a pair are one workgroup (blockDim = 64 njt); the diagnostic launch
+    // SFG_MAC_I8_WG=1 gives every wave its own workgroup (consecutive workgroups go to different XCDs: no cache shared between the column waves of a pair)
+    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int jt = gw % a.njt, pr = gw / a.njt;
+    const int c = pr % H, m = pr / H;
     const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
     v4i acc[4][2 * ND - 1];
 #pragma unroll
@@ -358,6 +362,7 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
     { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
       if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
+      else if (ctx->cfg.mac_i8_wg1) hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H * a.njt)), dim3(64), 0, ctx->stream, a, ctx->modc);
       else hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
       t.stop(1, (double)nl * ((double)N * a.nch * 2 * ND * tile + (double)H * a.njt * a.nch * ND * tile + (double)H * 2 * a.njt * 2 * 256 * 8.0)); }

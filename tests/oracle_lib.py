@@ -110,7 +110,7 @@ def lib():
         L.orc_bench_mac.restype = C.c_double
         L.orc_bench_mac.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong)]
         L.orc_bench_mac_ref_layout.restype = C.c_double
-        L.orc_bench_mac_ref_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+        L.orc_bench_mac_ref_layout.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_splitmix64.argtypes = [C.POINTER(C.c_uint64)]
         L.orc_diagcache_create.restype = C.c_void_p

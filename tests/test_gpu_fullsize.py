@@ -311,3 +311,119 @@ def test_c5_batch_500000x8192_square_s13_and_s1(env):
     for d in (A13, out13, d7, out1, outsq, acc, fin, gd):
         d.free()
     env.ctx.geno_free(g)
+
+
+# --------------------------------------------------------------------------- configs[3]: 100 000 x 1 000 000 on one GPU
+# Digests of bench.py's c4 outputs (seed 0x5F6A genotypes, 0xC1F3 / 0xD2A7_0000 ciphertexts, 0xBEEF keys): identical in BENCH_r02.json (fp64 MAC,
+# 8 block rows per launch), BENCH_r03.json (int8 matrix-core MAC, memory-chosen groups) and every profiles/r0*_bench_c4_* line.
+C4_OUT1_SHA256 = "cab05b5a8326ff9dc51f0e139c2261d47dc2a8830541a134273bffbc6f3888e6"
+C4_OUT2_SHA256 = "ce9b0e28cb6318dafb77b27fbdff1d4491f3fcb3e70548d5bfac723753d7ee62"
+
+
+def _ct_digest(h):
+    """bench.py's digest: SHA-256 over the per-ciphertext SHA-256s in [i][j] order"""
+    return hashlib.sha256(b"".join(hashlib.sha256(h[i, j].tobytes()).digest() for i in range(h.shape[0]) for j in range(h.shape[1]))).hexdigest()
+
+
+def test_c4_100000x1000000_kp15_pinned_digests_and_oracle_at_the_c4_launch_shapes():
+    """configs[3] (the configuration BASELINE.json's metric is quoted on) at full size, as bench.py runs it: 123 x 13 blocks, kp = 15, the default
+    schedule (memory-chosen MAC groups beside 100 GB of int8 genotypes, several accumulator passes).
+      (a) both products' digests equal the values pinned since round 2;
+      (b) Q*X (matmult.go:1043-1236 via pca.go:344): block columns 61 (interior) and 122 (ragged: 576 SNPs) x rows {0, 14} of the FULL run vs the
+          oracle over all 13 block rows (row independence: the oracle runs s = 2);
+      (c) Q'*X^T (pca.go:352): the device accumulators of the 14-block-row range [109, 123) (one MAC launch of K = 1274, ragged last SNP block) x the
+          ragged output block column 12, rows {0, 14}, vs orc_matmult_accumulate; the device accumulators of ALL 123 block rows for those two rows,
+          aligned by orc_matmult_finalize, must equal rows {0, 14} of the full run's output (every block column)."""
+    from sfgwas_amd import capi
+    from sfgwas_amd.params import rotations_for_matmul
+    import time
+    t_start = time.perf_counter()
+    n_ind, m_snp, kp = 100_000, 1_000_000, 15
+    nbr_x, mct_x = 13, 123
+    lib = capi.lib()
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rots = rotations_for_matmul()
+    arr = (C.c_int * len(rots))(*rots)
+    ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, arr, len(rots), 0xBEEF), "fill rotkeys")
+    for k in rots:
+        g_el = ring.galois(k)
+        keys.add(g_el, ctx.export_rotkey(g_el))
+
+    class E:                                    # what oracle_product / oracle_accumulate / oracle_finalize read
+        pass
+    e = E()
+    e.ring, e.keys = ring, keys
+    try:
+        geno = capi.DevArray(ctx, (n_ind, m_snp), np.int8)
+        ctx.check(lib.sfg_fill_geno_window_dev(ctx.h, geno.p, n_ind, m_snp, m_snp, 0, m_snp, 0x5F6A), "fill_geno")
+        g = C.c_void_p()
+        ctx.check(lib.sfg_geno_from_device(ctx.h, geno.p, n_ind, m_snp, m_snp, C.byref(g)), "geno_from_device")
+        A1 = ctx.fill_uniform_cts(kp * nbr_x, LEVEL, 0xC1F3)                        # [kp][13]
+        A2 = capi.DevArray(ctx, (kp, mct_x, 2, LEVEL + 1, N))                       # [kp][123]: ciphertext (i, b) has seed base + i*123 + b
+        ctw = 2 * (LEVEL + 1) * N
+        for i in range(kp):
+            ctx.check(lib.sfg_fill_uniform_ct_dev(ctx.h, C.c_void_p(A2.p.value + i * mct_x * ctw * 8), mct_x, LEVEL, 0xD2A7_0000 + i * mct_x), "fill A2")
+        out1 = ctx.matmul_resident(A1, kp, LEVEL, L, g)                             # Q*X    [kp][123]
+        out2 = ctx.matmul_resident(A2, kp, LEVEL, L, g, flags=capi.SFG_TRANSPOSE)   # Q'*X^T [kp][13]
+        h2 = out2.host().reshape(kp, nbr_x, 2, L, N)
+        assert _ct_digest(h2) == C4_OUT2_SHA256, "Q'*X^T digest moved"
+        rows = [0, 14]
+        h1_rows = {}
+        d1 = hashlib.sha256()
+        for i in range(kp):                                                          # 2.4 GB: one row of A at a time
+            hi = out1.host_slice((i,)).reshape(mct_x, 2, L, N)
+            d1.update(b"".join(hashlib.sha256(hi[j].tobytes()).digest() for j in range(mct_x)))
+            if i in rows:
+                h1_rows[i] = hi[[61, 122]].copy()
+        assert d1.hexdigest() == C4_OUT1_SHA256, "Q*X digest moved"
+        out1.free(); out2.free()
+        t_products = time.perf_counter()
+
+        def window(c0, ncol, r0=0, r1=n_ind):
+            """host copy of X[r0:r1, c0:c0+ncol], regenerated on the device as the window of the same global matrix"""
+            w = capi.DevArray(ctx, (n_ind, ncol), np.int8)
+            ctx.check(lib.sfg_fill_geno_window_dev(ctx.h, w.p, n_ind, ncol, ncol, c0, m_snp, 0x5F6A), "window")
+            out = np.empty((r1 - r0, ncol), dtype=np.int8)
+            ctx.check(lib.sfg_memcpy_d2h(ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(w.p.value + r0 * ncol), out.nbytes), "d2h")
+            w.free()
+            return out
+
+        # (b) Q*X, two block columns x two rows of A over all 13 block rows
+        A1h = A1.host().reshape(kp, nbr_x, 2, LEVEL + 1, N)
+        A1sel = np.ascontiguousarray(A1h[rows])
+        for jj, j in enumerate((61, 122)):
+            ncol = min(SLOTS, m_snp - j * SLOTS)
+            sub = window(j * SLOTS, ncol)
+            # spot check that the window IS the resident matrix there
+            probe = np.empty(ncol, dtype=np.int8)
+            ctx.check(lib.sfg_memcpy_d2h(ctx.h, probe.ctypes.data_as(C.c_void_p), C.c_void_p(geno.p.value + 77_777 * m_snp + j * SLOTS), ncol), "d2h")
+            assert np.array_equal(probe, sub[77_777])
+            want, _, _ = ol.matmult4stream(ring, keys, SCALE, A1sel, LEVEL, L, sub, enc_prec=1)
+            for r, i in enumerate(rows):
+                assert np.array_equal(h1_rows[i][jj], want[r, 0]), f"Q*X row {i} block column {j}"
+        t_qx = time.perf_counter()
+
+        # (c) Q'*X^T: accumulators of block rows [109, 123) x output block column 12 (the last 1696 individuals)
+        A2sel = np.ascontiguousarray(np.stack([A2.host_slice((i,)) for i in rows]))   # [2][123][2][6][N]
+        dsel = capi.DevArray.from_host(ctx, A2sel)
+        b0, b1, jo = 109, 123, 12
+        sub_t = np.ascontiguousarray(window(b0 * SLOTS, m_snp - b0 * SLOTS, jo * SLOTS, n_ind).T)     # X^T block rows 109..122 x individuals 98304..
+        acc_sel = ctx.matmul_accumulate(dsel, 2, LEVEL, L, g, capi.SFG_TRANSPOSE, b0, b1, jo, jo + 1)
+        want_acc, _ = oracle_accumulate(e, np.ascontiguousarray(A2sel[:, b0:b1]), sub_t, 0, b1 - b0)
+        assert np.array_equal(acc_sel.host(), want_acc), "Q'*X^T accumulators, block rows [109,123), block column 12"
+        acc_sel.free()
+        t_acc = time.perf_counter()
+        acc = ctx.matmul_accumulate(dsel, 2, LEVEL, L, g, capi.SFG_TRANSPOSE, 0, mct_x, 0, nbr_x)
+        fin = oracle_finalize(e, acc.host(), 2, nbr_x, 0, D)
+        for r, i in enumerate(rows):
+            assert np.array_equal(fin[r], h2[i]), f"Q'*X^T row {i}: oracle alignment of the device accumulators vs the full run"
+        acc.free(); dsel.free()
+        print(f"\nc4 test: products + digests {t_products - t_start:.0f} s, Q*X oracle {t_qx - t_products:.0f} s, accumulate oracle {t_acc - t_qx:.0f} s, "
+              f"finalize oracle {time.perf_counter() - t_acc:.0f} s")
+        A1.free(); A2.free()
+        lib.sfg_geno_free(ctx.h, g)
+        geno.free()
+    finally:
+        ctx.close()
