@@ -46,6 +46,10 @@ int sfg_ctx_fork(sfg_ctx *parent, sfg_ctx **out);
 void sfg_ctx_destroy(sfg_ctx *ctx);
 const char *sfg_last_error(const sfg_ctx *ctx);     /* ctx may be NULL: error of a failed sfg_ctx_create */
 int sfg_ctx_synchronize(sfg_ctx *ctx);
+/* returns every scratch buffer the context has grown (plaintext panels, rotation operands, digit streams, accumulators) to the device, after its queues
+ * have drained; the next call re-grows what it needs.  For callers that change to a very different product shape beside a large resident matrix.
+ * (No reference counterpart: Go's garbage collector plays this role for the accCache / rotCache slices of matmult.go:1065-1129.) */
+int sfg_ctx_release_scratch(sfg_ctx *ctx);
 /* sfg_ctx_synchronize waits for every queue of the context (main, own, auxiliary key-switch queue).  It - like sfg_memcpy_d2h and the host-pointer product
  * entry points - FAILS while an encoder coefficient within 2^-50 of a rounding tie is outstanding (see sfg_ctx_encoder_near_ties): results whose
  * bit-exactness with the reference's 256-bit encoder cannot be proven do not leave the device silently. */

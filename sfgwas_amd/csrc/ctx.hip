@@ -279,6 +279,18 @@ int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out) {
     *out = e.first;
     return 0;
 }
+// Returns every scratch buffer of the context to the device (after all of its queues have drained).  The pools grow to the largest shape a context has
+// multiplied and are kept for the next call of that shape; a caller that moves to a very different shape beside a large resident matrix (kp = 15 products,
+// then s = 2 products whose memory-chosen groups are larger) calls this in between instead of running out of HBM.
+extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(sfg_sync_all(ctx));
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
+    ctx->pool.clear();
+    for (int b = 0; b < 2; b++) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) ctx->i8_slot[b][i] = sfg_ctx::I8Slot();      // the kept transposed rot copies lived in the pool
+    ctx->i8_gen++;
+    return 0;
+}
 extern "C" int sfg_ctx_clear_phases(sfg_ctx *ctx) { sfg_phases_resolve(ctx); ctx->phases.clear(); return 0; }
 extern "C" double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase) {
     sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));

@@ -36,15 +36,18 @@ size_t pgen_header_bytes(const uint8_t *f12) {
     return p;
 }
 // f: at least the header bytes (`bytes` of them are readable); file_bytes: the size of the whole file, against which the record table is validated
-int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, size_t file_bytes, PgenIndex &ix) {
+static int pgen_index_unchecked(sfg_ctx *ctx, const uint8_t *f, size_t bytes, size_t file_bytes, PgenIndex &ix) {
     if (!f || bytes < 12 || f[0] != 0x6C || f[1] != 0x1B) SFG_FAIL(ctx, "pgen: not a PLINK 2 .pgen (bad magic)");
+    if (bytes > file_bytes) bytes = file_bytes;
     auto u32 = [&](size_t p) { return (uint32_t)f[p] | (uint32_t)f[p + 1] << 8 | (uint32_t)f[p + 2] << 16 | (uint32_t)f[p + 3] << 24; };
     ix.nv = u32(3); ix.ns = u32(7);
     if (!ix.nv || !ix.ns) SFG_FAIL(ctx, "pgen: empty file (%u variants, %u samples)", ix.nv, ix.ns);
-    ix.off.resize(ix.nv); ix.len.resize(ix.nv); ix.vrt.resize(ix.nv);
+    if (ix.ns > 0x7FFFFFFFu) SFG_FAIL(ctx, "pgen: sample count %u out of range", ix.ns);
+    // a hostile / corrupt header must not size anything: the variant count is believed only as far as the file is long enough to hold that many entries
     if (f[2] == 0x02) {
         const uint64_t bps = ((uint64_t)ix.ns + 3) / 4;
-        if (file_bytes < 12 + (uint64_t)ix.nv * bps) SFG_FAIL(ctx, "pgen: truncated fixed-width file");
+        if ((file_bytes - 12) / bps < ix.nv) SFG_FAIL(ctx, "pgen: truncated fixed-width file");
+        ix.off.resize(ix.nv); ix.len.resize(ix.nv); ix.vrt.resize(ix.nv);
         for (uint32_t v = 0; v < ix.nv; v++) { ix.off[v] = 12 + (uint64_t)v * bps; ix.len[v] = (uint32_t)bps; ix.vrt[v] = 0; }
         return 0;
     }
@@ -53,12 +56,16 @@ int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, size_t file_bytes, 
     if (wmode > 7) SFG_FAIL(ctx, "pgen: header control byte 0x%02x not supported", ctrl);
     const unsigned vbits = wmode < 4 ? 4 : 8, lb = (wmode & 3) + 1;
     const uint32_t nblk = (ix.nv + 65535) / 65536;
+    const size_t header_end = pgen_header_bytes(f);                       // 12 + block offsets + per-block tables: >= 1.5 bytes per variant
+    if (!header_end || header_end > file_bytes) SFG_FAIL(ctx, "pgen: the header tables of %u variants do not fit the file (%zu bytes)", ix.nv, file_bytes);
+    if (header_end > bytes) SFG_FAIL(ctx, "pgen: truncated header");
+    ix.off.resize(ix.nv); ix.len.resize(ix.nv); ix.vrt.resize(ix.nv);
     size_t p = 12 + (size_t)8 * nblk;
-    if (p > bytes) SFG_FAIL(ctx, "pgen: truncated header");
-    uint64_t cur = 0;
+    uint64_t cur = header_end;                                            // records follow the header, block after block, in file order
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t v0 = b * 65536u, cnt = std::min<uint32_t>(65536u, ix.nv - v0);
         uint64_t bo = 0; for (int k = 0; k < 8; k++) bo |= (uint64_t)f[12 + 8 * (size_t)b + k] << (8 * k);
+        if (bo < header_end || bo < cur || bo > file_bytes) SFG_FAIL(ctx, "pgen: block %u starts at byte %llu, outside [%llu, %zu] (header end / previous block end, file size)", b, (unsigned long long)bo, (unsigned long long)cur, file_bytes);
         cur = bo;
         const size_t vt_bytes = vbits == 4 ? (cnt + 1) / 2 : cnt;
         if (p + vt_bytes + (size_t)cnt * lb + (size_t)cnt * ac_bytes > bytes) SFG_FAIL(ctx, "pgen: truncated header");
@@ -66,13 +73,20 @@ int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, size_t file_bytes, 
         p += vt_bytes;
         for (uint32_t k = 0; k < cnt; k++) {
             uint32_t x = 0; for (unsigned j = 0; j < lb; j++) x |= (uint32_t)f[p + (size_t)k * lb + j] << (8 * j);
-            ix.len[v0 + k] = x; ix.off[v0 + k] = cur; cur += x;
-            if (cur > file_bytes) SFG_FAIL(ctx, "pgen: record %u runs past the end of the file", v0 + k);
+            ix.len[v0 + k] = x; ix.off[v0 + k] = cur;
+            if (x > file_bytes - cur) SFG_FAIL(ctx, "pgen: record %u runs past the end of the file", v0 + k);      // cur <= file_bytes: no wrap
+            cur += x;
         }
         p += (size_t)cnt * lb + (size_t)cnt * ac_bytes;
         if (nonref == 3) p += (cnt + 7) / 8;
     }
     return 0;
+}
+// f: at least the header bytes (`bytes` of them are readable); file_bytes: the size of the whole file, against which the record table is validated.
+// Nothing thrown by the containers (std::bad_alloc, std::length_error) crosses the extern "C" boundary of the callers.
+int pgen_index(sfg_ctx *ctx, const uint8_t *f, size_t bytes, size_t file_bytes, PgenIndex &ix) {
+    try { return pgen_index_unchecked(ctx, f, bytes, file_bytes, ix); }
+    catch (const std::exception &e) { SFG_FAIL(ctx, "pgen: cannot index the file (%s)", e.what()); }
 }
 
 enum { PGEN_ERR_FORMAT = 1, PGEN_ERR_MULTIALLELIC = 2, PGEN_ERR_TYPE = 4 };
@@ -208,6 +222,8 @@ int pgen_window(sfg_ctx *ctx, const PgenIndex &ix, size_t file_bytes, size_t v0,
     if (w.f1 > file_bytes || w.f0 > w.f1) SFG_FAIL(ctx, "pgen: record table inconsistent with the file size");
     w.off.resize(w.nr); w.ldb.assign(w.nr, 0xFFFFFFFFu); uint32_t last = 0;
     for (size_t r = 0; r < w.nr; r++) {
+        const uint64_t o = ix.off[start + r], l = ix.len[start + r];
+        if (o < w.f0 || o > w.f1 || l > w.f1 - o) SFG_FAIL(ctx, "pgen: record %zu lies outside its window's byte range", start + r);     // every record, not only the first and last
         w.off[r] = ix.off[start + r] - w.f0;
         if ((ix.vrt[start + r] & 6) == 2) w.ldb[r] = last; else last = (uint32_t)r;
     }

@@ -379,6 +379,7 @@ def test_c4_100000x1000000_kp15_pinned_digests_and_oracle_at_the_c4_launch_shape
                 h1_rows[i] = hi[[61, 122]].copy()
         assert d1.hexdigest() == C4_OUT1_SHA256, "Q*X digest moved"
         out1.free(); out2.free()
+        ctx.check(lib.sfg_ctx_release_scratch(ctx.h), "release_scratch")           # the kp = 15 pools; the s = 2 samples below choose their own (larger) groups
         t_products = time.perf_counter()
 
         def window(c0, ncol, r0=0, r1=n_ind):
