@@ -110,7 +110,11 @@ int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, in
 int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset);
 /* the coefficients within 2^-50 of a tie seen since the last reset (the condition that makes the synchronising entry points fail) */
 int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *count);
-/* test hook for the failure path above: marks n coefficients as too close to a tie */
+/* With a plaintext coefficient cache on (sfg_geno_set_plaintext_cache) a cached row was audited when it was FILLED: "count == 0" then proves the plaintexts
+ * of the calls since the cache was enabled.  When the 2^-50 condition is reported (a failing synchronising call) or reset, every cache the context owns
+ * forgets its rows, so the recovery never keeps serving a row that was filled while the condition was outstanding. */
+/* test hook for the failure path above: marks n coefficients as too close to a tie.  Refused unless the process set SFG_ENABLE_TEST_HOOKS=1 before
+ * sfg_ctx_create (a production caller cannot wedge a context with it by accident). */
 int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n);
 /* crypto.EncodeFloatVector (crypto.go:398-420; behind Mask / MaskTrunc / MaskWithScaling, basics.go:110-172, and
  * CPMult operands): nvec real slot vectors [nvec][slots] (host) -> NTT-domain plaintexts pt_dev[nvec][level+1][N]
@@ -290,8 +294,11 @@ int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc_dev, int s, 
  *     staged[job - job0][baby][poly][rowf],
  * the ranks all-gather the staging buffers and scatter them into the cache layout.  All 91 baby steps are rotated (rotations the reference's
  * active-baby table would skip meet zero plaintexts only), so every baby rotation key must be loaded (crypto.go:252-263 generates them all).
- * A cache must be (re)written through these entry points only: the MAC keeps a transposed copy of the operand it last multiplied with, keyed by the cache
- * pointer and a generation count that sfg_rotcache_scatter_dev / sfg_rotcache_build_rows_dev advance. */
+ * The MAC keeps a transposed copy of the operand it last multiplied with, keyed by the cache pointer, its shape and strides, and a PER-CONTEXT generation
+ * count that sfg_rotcache_scatter_dev / sfg_rotcache_build_rows_dev advance on the context they run on.  A cache buffer written by any other route - a
+ * collective straight into the layout, a device copy of a saved cache, a build on ANOTHER (forked) context - must be announced to the multiplying context
+ * with sfg_rotcache_invalidate before its next *_rc_dev product, or that product may read the stale copy. */
+int sfg_rotcache_invalidate(sfg_ctx *ctx);
 int sfg_rotcache_layout(sfg_ctx *ctx, int s, int max_level, size_t *job_doubles, size_t *tail_doubles);
 int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, int nbr, int job0, int job1, double *staged_dev);
 /* staged jobs [job0, job1) -> cache rows [row0, row0 + nrows); also zeroes the tail */

@@ -1,0 +1,409 @@
+//go:build hip
+
+// Package hip is the cgo binding of libsfgwas_hip.so (include/sfgwas_hip.h) for hhcho/sfgwas.
+//
+// Where it goes: copy this directory to github.com/hhcho/sfgwas/hip and the sibling files to gwas/, crypto/ and mpc/
+// (each carries the build tag `hip`; the files they replace get `//go:build !hip`, see INTEGRATION.md §0).
+//
+// NOT COMPILED IN THE sfgwas-hip REPOSITORY: its image has no Go toolchain and the lattigo fork / mpc-core modules are not
+// vendored in the reference tree.  The lattigo API used here is the one the reference itself uses (ckks.Ciphertext.Value()[k].Coeffs[l],
+// ckks.NewCiphertext, ckks.RotationKeySet.Keys, ckks.SwitchingKey.Value, ring.NewRing / PsiMont / MredParams / InvMForm); a maintainer
+// should expect to fix small spelling differences against the fork on the first build.
+//
+// This package imports lattigo only (never sfgwas/crypto, gwas or mpc), so all three can import it without a cycle.
+package hip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../third_party/sfgwas-hip/include
+#cgo LDFLAGS: -L${SRCDIR}/../third_party/sfgwas-hip/sfgwas_amd/lib -lsfgwas_hip -Wl,-rpath,${SRCDIR}/../third_party/sfgwas-hip/sfgwas_amd/lib
+#include <stdlib.h>
+#include "sfgwas_hip.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"sync"
+	"unsafe"
+
+	"github.com/ldsec/lattigo/v2/ckks"
+	"github.com/ldsec/lattigo/v2/ring"
+)
+
+// Ctx is one caller's handle on the library: tables and keys are shared between forks, queues and scratch are per handle.
+// The reference runs MatMult4Stream from several goroutines at once (gwas/assoc.go:360-408): each takes its own Fork().
+type Ctx struct {
+	p      *C.sfg_ctx
+	Params *ckks.Parameters
+	N      int // ring degree
+	NQ, NP int // moduli of Q and of P
+}
+
+// Default is the context the drop-in function bodies use; Init sets it (gwas/gwas.go:212, after CollectiveInit).
+var Default *Ctx
+
+// check converts a non-zero return code into a panic: the reference panics / log.Fatals on this path
+// (gwas/matmult.go:361, gwas/filestream.go:60,334, crypto/basics.go:817), it never returns errors.
+func (h *Ctx) check(rc C.int, what string) {
+	if rc != 0 {
+		panic(fmt.Sprintf("sfgwas-hip: %s: %s", what, C.GoString(C.sfg_last_error(h.p))))
+	}
+}
+
+// Init creates the device context from the CKKS parameters and uploads every switching key the party holds.
+//   rotKs: cryptoParams.RotKs (crypto/crypto.go:50, filled at :208), rlk: cryptoParams.Rlk (:49).
+func Init(params *ckks.Parameters, rotKs *ckks.RotationKeySet, rlk *ckks.RelinearizationKey, device int) *Ctx {
+	qi, pi := params.Qi(), params.Pi()
+	moduli := append(append([]uint64{}, qi...), pi...)
+	ringQP, err := ring.NewRing(params.N(), moduli)
+	if err != nil {
+		panic(err)
+	}
+	// lattigo's own primitive 2N-th roots, out of Montgomery form: the NTT output order then is lattigo's, whichever root its
+	// parameter generation picked (include/sfgwas_hip.h: sfg_ctx_create, `psi`)
+	psi := make([]uint64, len(moduli))
+	for i := range moduli {
+		psi[i] = ring.InvMForm(ringQP.PsiMont[i], moduli[i], ringQP.MredParams[i])
+	}
+	var c *C.sfg_ctx
+	if C.sfg_ctx_create(&c, C.int(device), C.int(params.LogN()), C.int(len(qi)), C.int(len(pi)),
+		(*C.uint64_t)(unsafe.Pointer(&moduli[0])), (*C.uint64_t)(unsafe.Pointer(&psi[0])), C.double(params.Scale())) != 0 {
+		panic("sfgwas-hip: sfg_ctx_create: " + C.GoString(C.sfg_last_error(nil)))
+	}
+	h := &Ctx{p: c, Params: params, N: params.N(), NQ: len(qi), NP: len(pi)}
+	if rotKs != nil {
+		for galEl, swk := range rotKs.Keys {
+			flat := FlattenSwitchingKey(swk, h.NQ+h.NP, h.N)
+			h.check(C.sfg_ctx_load_rotkey(c, C.uint64_t(galEl), (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "load_rotkey")
+		}
+	}
+	if rlk != nil && len(rlk.Keys) > 0 {
+		flat := FlattenSwitchingKey(rlk.Keys[0], h.NQ+h.NP, h.N)
+		h.check(C.sfg_ctx_load_relinkey(c, (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "load_relinkey")
+	}
+	Default = h
+	return h
+}
+
+// Fork returns a handle for another goroutine: same keys and tables, own queues (sfg_ctx_fork).
+func (h *Ctx) Fork() *Ctx {
+	var c *C.sfg_ctx
+	h.check(C.sfg_ctx_fork(h.p, &c), "fork")
+	f := *h
+	f.p = c
+	return &f
+}
+
+// Close destroys the handle (a fork: its queues and scratch; the root: everything).
+func (h *Ctx) Close() { C.sfg_ctx_destroy(h.p); h.p = nil }
+
+// Raw exposes the C handle to the sibling files of this binding.
+func (h *Ctx) Raw() unsafe.Pointer { return unsafe.Pointer(h.p) }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Flat layouts.  cgo may read Go memory only for the duration of a call and only if it holds no Go pointers, so the
+// [][]uint64 of lattigo polynomials are copied into one []uint64 per call (SURVEY.md §8b "Ownership").
+
+// FlattenSwitchingKey: swk.Value[i][k].Coeffs[m][:] -> [beta][2][nq+np][N] (lattigo keeps these rows in NTT + Montgomery form).
+func FlattenSwitchingKey(swk *ckks.SwitchingKey, nmod, n int) []uint64 {
+	beta := len(swk.Value)
+	flat := make([]uint64, beta*2*nmod*n)
+	for i := 0; i < beta; i++ {
+		for k := 0; k < 2; k++ {
+			for m := 0; m < nmod; m++ {
+				copy(flat[((i*2+k)*nmod+m)*n:], swk.Value[i][k].Coeffs[m][:n])
+			}
+		}
+	}
+	return flat
+}
+
+// CtWords is the number of uint64 words of a degree-1 ciphertext at `level`.
+func (h *Ctx) CtWords(level int) int { return 2 * (level + 1) * h.N }
+
+// FlattenCt writes ct.Value()[k].Coeffs[l] for l <= level into dst ([2][level+1][N]); the ciphertext must be at a level >= `level`
+// (rows above `level` are dropped: lattigo's DropLevel keeps the first rows).
+func (h *Ctx) FlattenCt(ct *ckks.Ciphertext, level int, dst []uint64) {
+	nl := level + 1
+	for k := 0; k < 2; k++ {
+		for l := 0; l < nl; l++ {
+			copy(dst[(k*nl+l)*h.N:], ct.Value()[k].Coeffs[l][:h.N])
+		}
+	}
+}
+
+// FlattenVec: a CipherVector ([]*ckks.Ciphertext) at one level, with length-1 broadcasting to n entries.
+func (h *Ctx) FlattenVec(v []*ckks.Ciphertext, n, level int) []uint64 {
+	w := h.CtWords(level)
+	flat := make([]uint64, n*w)
+	for i := 0; i < n; i++ {
+		src := v[0]
+		if len(v) > 1 {
+			src = v[i]
+		}
+		h.FlattenCt(src, level, flat[i*w:(i+1)*w])
+	}
+	return flat
+}
+
+// FlattenCipherMatrix: A[i][b] -> [s][nbr][2][level+1][N].
+func (h *Ctx) FlattenCipherMatrix(A [][]*ckks.Ciphertext, level int) []uint64 {
+	s, nbr, w := len(A), len(A[0]), h.CtWords(level)
+	flat := make([]uint64, s*nbr*w)
+	for i := 0; i < s; i++ {
+		for b := 0; b < nbr; b++ {
+			h.FlattenCt(A[i][b], level, flat[(i*nbr+b)*w:(i*nbr+b+1)*w])
+		}
+	}
+	return flat
+}
+
+// CtFromFlat builds a fresh ckks.Ciphertext (the callers mutate results in place, e.g. eval.Sub(out, .., out) at gwas/matmult.go:56,
+// so results must be new objects) from [2][level+1][N] words.
+func (h *Ctx) CtFromFlat(src []uint64, level int, scale float64) *ckks.Ciphertext {
+	ct := ckks.NewCiphertext(h.Params, 1, level, scale)
+	nl := level + 1
+	for k := 0; k < 2; k++ {
+		for l := 0; l < nl; l++ {
+			copy(ct.Value()[k].Coeffs[l], src[(k*nl+l)*h.N:(k*nl+l+1)*h.N])
+		}
+	}
+	return ct
+}
+
+// VecFromFlat: n ciphertexts from consecutive flat blocks.
+func (h *Ctx) VecFromFlat(src []uint64, n, level int, scale float64) []*ckks.Ciphertext {
+	w := h.CtWords(level)
+	out := make([]*ckks.Ciphertext, n)
+	for i := range out {
+		out[i] = h.CtFromFlat(src[i*w:(i+1)*w], level, scale)
+	}
+	return out
+}
+
+// AddFlatInto: out[i][j] += ciphertext(flat[i][j]) with lattigo's own Add.  MatMult4Stream / ...Compute start from crypto.CZeroMat - a FRESH
+// ENCRYPTION of zero (gwas/matmult.go:1174,1225,1443; crypto/basics.go:367-384) - and add the deterministic sum onto it; the shim
+// keeps that, so outputs carry the same fresh randomness the reference's do.
+func (h *Ctx) AddFlatInto(eval ckks.Evaluator, out [][]*ckks.Ciphertext, flat []uint64, level int, scale float64) {
+	w := h.CtWords(level)
+	for i := range out {
+		for j := range out[i] {
+			k := i*len(out[i]) + j
+			ct := h.CtFromFlat(flat[k*w:(k+1)*w], level, scale)
+			out[i][j].SetScale(scale) // CZeroMat encrypts at the default scale; the sum carries A.scale * Params.Scale (matmult.go:1045)
+			if out[i][j].Level() > level {
+				eval.DropLevel(out[i][j], out[i][j].Level()-level)
+			}
+			eval.Add(out[i][j], ct, out[i][j])
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Device buffers (uint64 words unless stated).
+
+type DevBuf struct {
+	h     *Ctx
+	p     unsafe.Pointer
+	Bytes int
+}
+
+func (h *Ctx) Alloc(bytes int) *DevBuf {
+	var p unsafe.Pointer
+	h.check(C.sfg_malloc(h.p, &p, C.size_t(bytes)), "malloc")
+	return &DevBuf{h, p, bytes}
+}
+func (b *DevBuf) Free()               { b.h.check(C.sfg_free(b.h.p, b.p), "free"); b.p = nil }
+func (b *DevBuf) Ptr() unsafe.Pointer { return b.p }
+func (b *DevBuf) U64() *C.uint64_t    { return (*C.uint64_t)(b.p) }
+
+// Upload copies host words to a new device buffer.
+func (h *Ctx) Upload(words []uint64) *DevBuf {
+	b := h.Alloc(8 * len(words))
+	h.check(C.sfg_memcpy_h2d(h.p, b.p, unsafe.Pointer(&words[0]), C.size_t(8*len(words))), "h2d")
+	return b
+}
+
+// Download copies a device buffer back (synchronises the handle's queue; fails while an unprovable encoder rounding is outstanding).
+func (b *DevBuf) Download() []uint64 {
+	out := make([]uint64, b.Bytes/8)
+	b.h.check(C.sfg_memcpy_d2h(b.h.p, unsafe.Pointer(&out[0]), b.p, C.size_t(b.Bytes)), "d2h")
+	return out
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Resident genotype matrices, keyed by the reference's cache-file prefix (gwas/pca.go:112-113 passes one prefix for X and one
+// for X^T: ONE resident int8 copy serves both, the second prefix is registered with SFG_TRANSPOSE).
+
+type Geno struct {
+	g     *C.sfg_geno
+	Flags uint
+	NRow  int
+	NCol  int
+}
+
+var (
+	genoMu      sync.Mutex
+	genoByKey   = map[string]*Geno{}
+	genoByShape = map[[2]int]*C.sfg_geno{} // (nrow, ncol) of the stored orientation -> handle, to find X when X^T is registered
+)
+
+const (
+	FlagSquare    = uint(C.SFG_SQUARE)
+	FlagTranspose = uint(C.SFG_TRANSPOSE)
+)
+
+// RegisterGeno uploads (or re-uses) the matrix behind a cache prefix.  rows is the row-major int8 matrix as GenoFileStream
+// delivers it (filters applied, missing = -1 kept: the device zeroes negatives before sums and products, matmult.go:1292-1300).
+// If a matrix of the transposed shape is already resident it is reused with SFG_TRANSPOSE instead of uploading a second copy.
+func (h *Ctx) RegisterGeno(prefix string, rows []int8, nrow, ncol int) *Geno {
+	genoMu.Lock()
+	defer genoMu.Unlock()
+	if g, ok := genoByKey[prefix]; ok {
+		return g
+	}
+	if g, ok := genoByShape[[2]int{ncol, nrow}]; ok {
+		e := &Geno{g, FlagTranspose, nrow, ncol}
+		genoByKey[prefix] = e
+		return e
+	}
+	var g *C.sfg_geno
+	h.check(C.sfg_geno_upload(h.p, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &g), "geno_upload")
+	genoByShape[[2]int{nrow, ncol}] = g
+	e := &Geno{g, 0, nrow, ncol}
+	genoByKey[prefix] = e
+	return e
+}
+
+// LookupGeno returns the resident matrix of a prefix, or nil (then MatMult4StreamCompute falls back to the DiagCache files on disk).
+func LookupGeno(prefix string) *Geno {
+	genoMu.Lock()
+	defer genoMu.Unlock()
+	return genoByKey[prefix]
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The calls the sibling files make.
+
+// MatmulStream = MatMult4Stream on host buffers (include/sfgwas_hip.h: sfg_matmul_stream).
+func (h *Ctx) MatmulStream(aFlat []uint64, s, inLevel, maxLevel int, geno []int8, nrow, ncol int, square bool, sum, sqsum []float64) []uint64 {
+	mct := (ncol-1)/(h.N/2) + 1
+	out := make([]uint64, s*mct*2*maxLevel*h.N)
+	flags := C.uint(0)
+	if square {
+		flags |= C.SFG_SQUARE
+	}
+	var ps, pq *C.double
+	if sum != nil {
+		ps, pq = (*C.double)(unsafe.Pointer(&sum[0])), (*C.double)(unsafe.Pointer(&sqsum[0]))
+	}
+	h.check(C.sfg_matmul_stream(h.p, (*C.uint64_t)(unsafe.Pointer(&aFlat[0])), C.int(s), C.int(inLevel), C.int(maxLevel),
+		(*C.int8_t)(unsafe.Pointer(&geno[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), flags,
+		(*C.uint64_t)(unsafe.Pointer(&out[0])), ps, pq), "matmul_stream")
+	return out
+}
+
+// MatmulResident = MatMult4StreamCompute on a resident matrix; returns [s][m_ct][2][maxLevel][N] words.
+func (h *Ctx) MatmulResident(aFlat []uint64, s, inLevel, maxLevel int, g *Geno) []uint64 {
+	lcol := g.NCol
+	dA := h.Upload(aFlat)
+	defer dA.Free()
+	mct := (lcol-1)/(h.N/2) + 1
+	dOut := h.Alloc(8 * s * mct * 2 * maxLevel * h.N)
+	defer dOut.Free()
+	h.check(C.sfg_matmul_resident_dev(h.p, dA.U64(), C.int(s), C.int(inLevel), C.int(maxLevel), g.g, C.uint(g.Flags), dOut.U64()), "matmul_resident")
+	return dOut.Download()
+}
+
+// MatmulFromCache = MatMult4StreamCompute on DiagCache files a CPU party wrote (gwas/filestream.go:19-282).
+func (h *Ctx) MatmulFromCache(aFlat []uint64, s, inLevel, maxLevel int, prefix string, nbr int) []uint64 {
+	cp := C.CString(prefix)
+	defer C.free(unsafe.Pointer(cp))
+	var hdr [6]C.uint64_t
+	h.check(C.sfg_diagcache_header(h.p, cp, 0, &hdr[0]), "diagcache_header")
+	mct := int(hdr[0])
+	dA := h.Upload(aFlat)
+	defer dA.Free()
+	dOut := h.Alloc(8 * s * mct * 2 * maxLevel * h.N)
+	defer dOut.Free()
+	h.check(C.sfg_matmul_from_cache(h.p, dA.U64(), C.int(s), C.int(inLevel), C.int(maxLevel), cp, C.int(nbr), dOut.U64()), "matmul_from_cache")
+	return dOut.Download()
+}
+
+// RotateRight: a batch of ciphertexts at one level, ct j rotated right by nrot[j] (crypto/basics.go:201-224 semantics).
+func (h *Ctx) RotateRight(flat []uint64, nct, level int, nrot []int) []uint64 {
+	dIn := h.Upload(flat)
+	defer dIn.Free()
+	dOut := h.Alloc(8 * len(flat))
+	defer dOut.Free()
+	cn := make([]C.int, nct)
+	for i := range cn {
+		cn[i] = C.int(nrot[i])
+	}
+	h.check(C.sfg_rotate_right_dev(h.p, dIn.U64(), dOut.U64(), C.int(nct), C.int(level), &cn[0]), "rotate_right")
+	return dOut.Download()
+}
+
+// Binary element-wise ops on equal-level batches: "add", "sub", "mulrelin".
+func (h *Ctx) Binary(op string, a, b []uint64, nct, level int) []uint64 {
+	dA, dB := h.Upload(a), h.Upload(b)
+	defer dA.Free()
+	defer dB.Free()
+	dOut := h.Alloc(8 * nct * h.CtWords(level))
+	defer dOut.Free()
+	switch op {
+	case "add":
+		h.check(C.sfg_ct_add_dev(h.p, dA.U64(), dB.U64(), dOut.U64(), C.int(nct), C.int(level)), op)
+	case "sub":
+		h.check(C.sfg_ct_sub_dev(h.p, dA.U64(), dB.U64(), dOut.U64(), C.int(nct), C.int(level)), op)
+	case "mulrelin":
+		h.check(C.sfg_ct_mulrelin_dev(h.p, dA.U64(), dB.U64(), dOut.U64(), C.int(nct), C.int(level)), op)
+	default:
+		panic("sfgwas-hip: unknown op " + op)
+	}
+	return dOut.Download()
+}
+
+// Rescale divides a batch at `level` by q_level (lattigo DivRoundByLastModulus); output at level-1.
+func (h *Ctx) Rescale(in []uint64, nct, level int) []uint64 {
+	dIn := h.Upload(in)
+	defer dIn.Free()
+	dOut := h.Alloc(8 * nct * h.CtWords(level-1))
+	defer dOut.Free()
+	h.check(C.sfg_ct_rescale_dev(h.p, dIn.U64(), dOut.U64(), C.int(nct), C.int(level)), "rescale")
+	return dOut.Download()
+}
+
+// InnerSumAll: sum of nct ciphertexts, then the 13 rotate-and-add steps (crypto/basics.go:278-292); one ciphertext out.
+func (h *Ctx) InnerSumAll(in []uint64, nct, level int) []uint64 {
+	dIn := h.Upload(in)
+	defer dIn.Free()
+	dOut := h.Alloc(8 * h.CtWords(level))
+	defer dOut.Free()
+	h.check(C.sfg_ct_innersum_dev(h.p, dIn.U64(), C.int(nct), C.int(level), dOut.U64()), "innersum")
+	return dOut.Download()
+}
+
+// BeaverElem / BeaverMatmul: local Beaver products over a prime field of `limbs` 64-bit little-endian limbs (mpc/beavermult.go:94-147).
+func (h *Ctx) BeaverElem(pid, limbs int, modulus, ar, am, br, bm []uint64, n int) []uint64 {
+	out := make([]uint64, n*limbs)
+	p := func(s []uint64) *C.uint64_t {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+	}
+	h.check(C.sfg_beaver_elem(h.p, C.int(pid), C.int(limbs), p(modulus), p(ar), p(am), p(br), p(bm), p(out), C.size_t(n)), "beaver_elem")
+	return out
+}
+func (h *Ctx) BeaverMatmul(pid, limbs int, modulus, ar, am, br, bm []uint64, m, k, n int) []uint64 {
+	out := make([]uint64, m*n*limbs)
+	p := func(s []uint64) *C.uint64_t {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+	}
+	h.check(C.sfg_beaver_matmul(h.p, C.int(pid), C.int(limbs), p(modulus), p(ar), p(am), p(br), p(bm), p(out), C.int(m), C.int(k), C.int(n)), "beaver_matmul")
+	return out
+}

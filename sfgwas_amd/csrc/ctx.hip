@@ -30,8 +30,10 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_IMPL")) { c.mac_reg = !strcmp(e, "reg"); c.mac_bc = strcmp(e, "dma") != 0 && !c.mac_reg; c.mac_i8 = !strcmp(e, "i8"); }      // bc | dma | reg | i8
     if (const char *e = env("SFG_I8_KEEP_RESERVE_GB")) c.i8_keep_reserve = (size_t)atoll(e) << 30;
     if (const char *e = env("SFG_MAC_I8_BIG")) c.mac_i8_big = atoi(e) != 0;
-    if (const char *e = env("SFG_MAC_I8_ROT")) c.mac_i8_nolds = strcmp(e, "lds") != 0;
+    if (const char *e = env("SFG_MAC_I8_ROT")) { c.mac_i8_nolds = strcmp(e, "lds") != 0; c.mac_i8_ring = !strcmp(e, "ring"); }      // ring (default) | cache | lds
+    if (env("SFG_MAC_I8_WG")) c.mac_i8_ring = false;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
+    if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
     if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
@@ -49,7 +51,7 @@ static void read_config(SfgConfig &c) {
 // copy the shared scalars / table pointers into the context (read-only mirrors: the launch code reads ctx->q, ctx->modc, ...)
 static void ctx_bind_shared(sfg_ctx *ctx, SfgShared *sh) {
     ctx->sh = sh; ctx->device = sh->device; ctx->logN = sh->logN; ctx->N = sh->N; ctx->nq = sh->nq; ctx->np = sh->np; ctx->nmod = sh->nmod;
-    ctx->beta = sh->beta; ctx->scale = sh->scale; ctx->cfg = sh->cfg;
+    ctx->beta = sh->beta; ctx->scale = sh->scale; ctx->cfg = sh->cfg; ctx->test_hooks = sh->cfg.test_hooks;
     memcpy(ctx->q, sh->q, sizeof sh->q); memcpy(ctx->psi, sh->psi, sizeof sh->psi); memcpy(ctx->modc_host, sh->modc_host, sizeof sh->modc_host);
     ctx->tw_fwd = sh->tw_fwd; ctx->tw_inv = sh->tw_inv; ctx->pack_fwd = sh->pack_fwd; ctx->pack_inv = sh->pack_inv; ctx->modc = sh->modc;
 }
@@ -291,6 +293,10 @@ extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx) {
     ctx->i8_gen++;
     return 0;
 }
+// The int8 MAC keeps a transposed copy of a rotation-cache operand, keyed by its address, shape and a per-context generation counter that every library
+// writer of rotation rows advances.  A caller that writes a cache buffer by any other route (an RCCL all-gather straight into the layout, a device copy of a
+// saved cache, another context's build) tells the multiplying context so with this call before the next *_rc_dev product.
+extern "C" int sfg_rotcache_invalidate(sfg_ctx *ctx) { ctx->i8_gen++; return 0; }
 extern "C" int sfg_ctx_clear_phases(sfg_ctx *ctx) { sfg_phases_resolve(ctx); ctx->phases.clear(); return 0; }
 extern "C" double sfg_last_phase_ms(const sfg_ctx *ctx, const char *phase) {
     sfg_phases_resolve(const_cast<sfg_ctx *>(ctx));

@@ -621,8 +621,13 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
 extern "C" int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     SFG_TRY(sfg_sync_all(ctx));
-    SFG_HIP(ctx, hipMemcpy(count, ctx->tie_count_dev, 8, hipMemcpyDeviceToHost));
-    if (reset) SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 16));
+    unsigned long long c[2] = {0, 0};
+    SFG_HIP(ctx, hipMemcpy(c, ctx->tie_count_dev, 16, hipMemcpyDeviceToHost));
+    *count = c[0];
+    if (reset) {
+        if (c[1]) sfg_ptc_invalidate_all(ctx);       // rows cached while an unprovable rounding was outstanding are not served after the reset
+        SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 16));
+    }
     return 0;
 }
 
@@ -631,6 +636,7 @@ extern "C" int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count
 int sfg_encoder_check(sfg_ctx *ctx) {
     unsigned long long c[2] = {0, 0};
     SFG_HIP(ctx, hipMemcpy(c, ctx->tie_count_dev, 16, hipMemcpyDeviceToHost));
+    if (c[1]) sfg_ptc_invalidate_all(ctx);
     if (c[1]) SFG_FAIL(ctx, "encoder: %llu coefficient(s) within 2^-50 of a rounding tie - the double-double encoder cannot prove them rounded as the reference's 256-bit "
                             "EncoderBig rounds; re-derive the products of this context since the last reset with a big-float encoder (sfg_ctx_encoder_near_ties resets)", c[1]);
     return 0;
@@ -643,6 +649,7 @@ extern "C" int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *coun
     return 0;
 }
 extern "C" int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n) {      // test hook: pretend n such coefficients were seen
+    if (!ctx->test_hooks) SFG_FAIL(ctx, "sfg_ctx_encoder_inject_unsafe_for_test: test hook, enabled only in a process that set SFG_ENABLE_TEST_HOOKS=1 before creating the context");
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long c[2] = {0, n};
     SFG_HIP(ctx, hipMemcpy((unsigned long long *)ctx->tie_count_dev + 1, c + 1, 8, hipMemcpyHostToDevice));

@@ -267,6 +267,95 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_lds(I8Args a, const ModConst 
         }
     }
 }
+// ---- the MAC with both operand streams prefetched through an LDS ring by the DMA engine (round 4; the default for full 91-column launches).
+// Counters (profiles/r04_pmc_mac_i8.json) show that k_mac_i8 fetches exactly its operand bytes (31.88 GB per launch against 31.88 GB algorithmic: the six column
+// waves of a pair do share the rot tiles, in the L1) - and yet runs at 55 % of the achievable HBM rate: a wave requests a chunk's 25 KiB, waits for all of it,
+// then issues 100 MFMAs with nothing in flight; the round time is memory time PLUS matrix time.  Here a workgroup's chunk (20 KiB of rot tiles, loaded ONCE,
+// + 6 x 5 KiB of plaintext tiles) travels global -> LDS by global_load_lds_dwordx4 two chunks ahead of its use (three 50 KiB slots, counted vmcnt, one raw
+// s_barrier per chunk), needs no VGPRs on the way, and the MFMA operands come from LDS by ds_read_b128 issued three tiles ahead (counted lgkmcnt, by hand:
+// left to the compiler, every LDS read after a DMA instruction is preceded by s_waitcnt vmcnt(0)).  Identical arithmetic, identical words.
+constexpr int I8R_DEPTH = 3;
+__device__ __forceinline__ void i8_dma16(const void *gsrc, void *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+template <int ND>
+__global__ void __launch_bounds__(384, 1) k_mac_i8_ring(I8Args a, const ModConst *modc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    constexpr int NA = 4 * ND, NB = 6 * ND, SLOT = (NA + NB) * 1024, AR = (NA + 5) / 6, NJ = ND + AR;      // tiles per slot; DMA instructions per wave and chunk
+    static_assert(NJ < 32 && SLOT * I8R_DEPTH <= 160 * 1024 && SLOT < 65536, "ring budget");
+    const int N = SFG_N, H = N / 2;
+    const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6;                  // six column waves (launched for njt == 6 only)
+    const int c = blockIdx.x % H, m = blockIdx.x / H, nch = a.nch;
+    v4i acc[4][2 * ND - 1];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s = 0; s < 2 * ND - 1; s++) acc[t][s] = (v4i){0, 0, 0, 0};
+    const unsigned char *gB = reinterpret_cast<const unsigned char *>(a.B) + ((((size_t)m * H + c) * 6 + jt) * nch) * ND * 1024 + lane * 16;
+    const unsigned char *gA0 = reinterpret_cast<const unsigned char *>(a.A) + (((size_t)m * N + c) * nch) * 2 * ND * 1024 + lane * 16;
+    const unsigned char *gA1 = reinterpret_cast<const unsigned char *>(a.A) + (((size_t)m * N + (N - 1 - c)) * nch) * 2 * ND * 1024 + lane * 16;
+    // the rot tiles of a chunk, tile j = (half, rt, digit) = t * ND + x for the MFMA loop below: wave jt fetches j = jt, jt + 6, ... (the last round wraps around
+    // and fetches a tile another wave fetches too: same bytes to the same place, so that every wave issues the same number of DMA instructions)
+    auto issue = [&](int ch, int slot) {
+        unsigned char *sl = ring + slot * SLOT;
+#pragma unroll
+        for (int d = 0; d < ND; d++) i8_dma16(gB + ((size_t)ch * ND + d) * 1024, sl + (NA + jt * ND + d) * 1024);
+#pragma unroll
+        for (int r = 0; r < AR; r++) {
+            int j = r * 6 + jt; if (j >= NA) j -= NA;
+            const int half = j / (2 * ND), rem = j - half * 2 * ND;
+            i8_dma16((half ? gA1 : gA0) + ((size_t)ch * 2 * ND + rem) * 1024, sl + j * 1024);
+        }
+    };
+#pragma unroll
+    for (int ch = 0; ch < I8R_DEPTH - 1; ch++) if (ch < nch) issue(ch, ch);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring + (unsigned)lane * 16u;
+    int slot = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ch++) {
+        // chunk ch has landed once every wave's own pieces have (the chunk issued after it may still be in flight) and the workgroup has met; the meeting also
+        // says that everybody has finished reading chunk ch - 1, whose slot is refilled next
+        if (ch + I8R_DEPTH - 2 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * (I8R_DEPTH - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ch + I8R_DEPTH - 1 < nch) issue(ch + I8R_DEPTH - 1, slot == 0 ? I8R_DEPTH - 1 : slot - 1);
+        const unsigned ab = lds0 + (unsigned)(slot * SLOT), bb = ab + (unsigned)((NA + jt * ND) * 1024);
+        v4i b[ND], ar[5];
+#pragma unroll
+        for (int d = 0; d < ND; d++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[d]) : "v"(bb), "n"(d * 1024) : "memory");
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[i]) : "v"(ab), "n"(i * 1024) : "memory");
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            // rot tile i is in: the LDS unit answers in order, and at most min(2, NA - 1 - i) reads were issued after it
+            if (i == 0) {
+                if constexpr (ND == 5) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4])::"memory");
+                else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[ND - 1])::"memory");
+            } else if (i < NA - 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[i % 5])::"memory");
+            else if (i == NA - 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ar[i % 5])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[i % 5])::"memory");
+            // tile i + 3 goes into the registers of tile i - 2 (tile i is named as an operand so that its MFMAs stay BEHIND this request: three tiles in flight)
+            if (i + 3 < NA) asm volatile("ds_read_b128 %0, %2 offset:%3" : "=&v"(ar[(i + 3) % 5]), "+v"(ar[i % 5]) : "v"(ab), "n"((i + 3) * 1024) : "memory");
+            const int t = i / ND, x = i - t * ND;
+#pragma unroll
+            for (int d = 0; d < ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ar[i % 5], b[d], acc[t][x + d], 0, 0, 0);
+        }
+        slot = slot + 1 == I8R_DEPTH ? 0 : slot + 1;
+    }
+    const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * 6 + jt) * 2 + (t & 1)) * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            double r = (double)acc[t][2 * ND - 2][e];
+#pragma unroll
+            for (int s = 2 * ND - 3; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
+            if (r < 0) r += q;
+            o[e] = (u64)r;
+        }
+    }
+}
 // ---- tile-ordered results -> canonical accumulators.  workgroup = (m, 16 coefficient pairs, half, jt, rt): 256 (n, r) rows x 16 coefficients through LDS
 __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *modc) {
     __shared__ u64 img[16][257];
@@ -298,6 +387,7 @@ __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *mod
 int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (ctx.hip)
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 5 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 6 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8R_DEPTH * 10 * 5 * 1024));
     return 0;
 }
 // bytes of the two operand streams and the tile-ordered results of one launch (for the group-size choice in matmul.hip)
@@ -322,7 +412,7 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     const size_t nA = (size_t)nl * N * a.nch * 2 * ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
     // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column.
     // Two copies per kind of modulus (the pipelined product alternates between two rot buffers).
-    const u64 sig[8] = {ctx->i8_gen, (u64)K, (u64)R, (u64)r0, (u64)l0, (u64)nl, (u64)plane0, (u64)rotf_k_stride};
+    const u64 sig[8] = {ctx->i8_gen, (u64)K, (u64)R, (u64)r0, (u64)l0 << 8 | (u64)nl, (u64)plane0, (u64)rotf_k_stride, (u64)rotf_r_stride};
     sfg_ctx::I8Slot *slots = ctx->i8_slot[BIG ? 1 : 0];
     int slot = -1;
     for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) if (slots[i].src == (const void *)rotf && !memcmp(slots[i].sig, sig, sizeof sig)) slot = i;
@@ -361,7 +451,8 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       else hipLaunchKernelGGL(k_i8_pack_pt<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
     { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
-      if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
+      if (!BIG && a.njt == 6 && ctx->cfg.mac_i8_ring) hipLaunchKernelGGL(k_mac_i8_ring<5>, dim3((unsigned)(nl * H)), dim3(384), I8R_DEPTH * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+      else if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
       else if (ctx->cfg.mac_i8_wg1) hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H * a.njt)), dim3(64), 0, ctx->stream, a, ctx->modc);
       else hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());

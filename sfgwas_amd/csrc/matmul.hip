@@ -172,16 +172,24 @@ extern "C" int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *dev, size_t nrow
     *out = g; return 0;
 }
 static void ptc_drop(sfg_ctx *ctx, const sfg_geno *g) {
+    sfg_ctx *own = g->ptc_owner ? (sfg_ctx *)g->ptc_owner : ctx;
+    own->ptc_genos.erase(g);
     if (g->ptc.empty() && !g->ptc_perm) return;
-    (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(own->device); (void)sfg_sync_all(own);          // every queue of the owner (fills and hits may still be running on its encode queue)
+    if (own != ctx) (void)sfg_sync_all(ctx);
     g->ptc.clear(); g->ptc_used = 0;
     if (g->ptc_arena) { (void)hipFree(g->ptc_arena); g->ptc_arena = nullptr; }
     if (g->ptc_perm) { (void)hipFree(g->ptc_perm); g->ptc_perm = nullptr; }
 }
+// An unprovable encoder rounding (2^-50 counter) was reported or reset: rows cached while it was outstanding cannot be told from the others, and the recovery
+// ("re-derive, then reset") must not keep serving them - every cache this context owns forgets its rows (the arenas stay; later products refill them).
+void sfg_ptc_invalidate_all(sfg_ctx *ctx) {
+    for (const sfg_geno *g : ctx->ptc_genos) { g->ptc.clear(); g->ptc_used = 0; }
+}
 extern "C" void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g) {
     if (!g) return;
     ptc_drop(ctx, g);
-    if (g->owned) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); (void)hipFree((void *)g->dev); }
+    if (g->owned) { (void)hipSetDevice(ctx->device); (void)sfg_sync_all(ctx); (void)hipFree((void *)g->dev); }
     delete g;
 }
 // Plaintext coefficient cache of a resident matrix: up to max_bytes of HBM (512 MB per 8192 x 8192 block and SFG_SQUARE flavour), filled by the products that
@@ -218,7 +226,7 @@ extern "C" int sfg_geno_set_plaintext_cache(sfg_ctx *ctx, const sfg_geno *g, siz
         if (hipMalloc(&a, want) != hipSuccess) { (void)hipGetLastError(); SFG_FAIL(ctx, "sfg_geno_set_plaintext_cache: cannot allocate %zu bytes", want); }
         g->ptc_arena = (double *)a; g->ptc_budget = want;
     }
-    g->ptc_owner = ctx;
+    g->ptc_owner = ctx; ctx->ptc_genos.insert(g);
     return 0;
 }
 // blocks cached / bytes held / hits and fills since the cache was enabled

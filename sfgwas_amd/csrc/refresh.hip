@@ -244,8 +244,12 @@ extern "C" int sfg_refresh_gen_shares_dev(sfg_ctx *ctx, const uint64_t *ct, int 
 extern "C" int sfg_refresh_gen_shares_scaled_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, double ct_scale, double target_scale, const uint64_t *crs,
                                                  const uint64_t *mask, int W, const int32_t *e0, const int32_t *e1, uint64_t *h0, uint64_t *h1) {
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "refresh: level %d out of range", level);
+    if (ct_scale == target_scale) return refresh_gen_shares(ctx, ct, nct, level, crs, mask, W, e0, e1, h0, h1, nullptr);     // ratio 1: the unscaled kernels (Quo(mask * x, x) = mask)
     ScaleRatio sr; SFG_TRY(scale_ratio(ctx, level, ct_scale, target_scale, sr));
     if (W > BG) SFG_FAIL(ctx, "refresh: mask limb count %d exceeds %d in the target-scale form", W, BG);
+    // the kernel multiplies the W-limb mask magnitude by the 53-bit mantissa of the target scale and shifts it left by (target exponent - ciphertext exponent)
+    // inside 64 BG bits: a mask wider than Q (the bound scale_ratio checks) must fit as well, or the product would wrap silently
+    if (64 * W + 54 + (sr.sh > 0 ? sr.sh : 0) > 64 * BG) SFG_FAIL(ctx, "refresh: a %d-limb mask times the target scale (shift %d) does not fit %d bits", W, sr.sh, 64 * BG);
     return refresh_gen_shares(ctx, ct, nct, level, crs, mask, W, e0, e1, h0, h1, &sr);
 }
 static int refresh_gen_shares(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, const uint64_t *crs, const uint64_t *mask, int W,
@@ -335,6 +339,7 @@ extern "C" int sfg_refresh_finish_dev(sfg_ctx *ctx, const uint64_t *ct, int nct,
 extern "C" int sfg_refresh_finish_scaled_dev(sfg_ctx *ctx, const uint64_t *ct, int nct, int level, double ct_scale, double target_scale, const uint64_t *h0agg,
                                              const uint64_t *h1agg, const uint64_t *crs, uint64_t *out) {
     if (level < 0 || level >= ctx->nq) SFG_FAIL(ctx, "refresh: level %d out of range", level);
+    if (ct_scale == target_scale) return refresh_finish(ctx, ct, nct, level, h0agg, h1agg, crs, out, nullptr);
     ScaleRatio sr; SFG_TRY(scale_ratio(ctx, level, ct_scale, target_scale, sr));
     return refresh_finish(ctx, ct, nct, level, h0agg, h1agg, crs, out, &sr);
 }

@@ -102,3 +102,41 @@ def test_another_context_cannot_take_the_cache(env):
     assert b"another context" in lib.sfg_last_error(other.h)
     other.close()
     ctx.geno_free(g)
+
+
+def test_unprovable_rounding_drops_the_cached_rows(env):
+    """rows cached while the 2^-50 near-tie condition is outstanding must not be served after the documented recovery (reset): the failing
+    synchronising call and the reset both make the owning context's caches forget their rows; later products refill and agree"""
+    ctx, lib, geno, prod, stats, ref = env
+    from sfgwas_amd import capi
+    g = ctx.geno_upload(geno)
+    ctx.check(lib.sfg_geno_set_plaintext_cache(ctx.h, g, 8 << 30), "enable")
+    ctx.encoder_near_ties(reset=True)
+    assert np.array_equal(prod(g, 0), ref[0])
+    assert stats(g)[0] == 4
+    ctx.check(lib.sfg_ctx_encoder_inject_unsafe_for_test(ctx.h, 1), "inject")
+    with pytest.raises(capi.SfgError, match="rounding tie"):
+        ctx.sync()
+    assert stats(g)[:2] == (0, 0)                                     # forgotten at the report ...
+    ctx.check(lib.sfg_ctx_encoder_inject_unsafe_for_test(ctx.h, 1), "inject")
+    ctx.encoder_near_ties(reset=True)                                 # ... and at the reset
+    assert stats(g)[:2] == (0, 0)
+    assert np.array_equal(prod(g, T), ref[T])                         # refills (4 blocks, from the transposed orientation this time)
+    assert stats(g)[0] == 4 and stats(g)[3] == 8
+    assert np.array_equal(prod(g, 0), ref[0])
+    ctx.geno_free(g)
+
+
+def test_failure_path_hook_is_refused_without_the_test_switch(env):
+    import os
+    from sfgwas_amd import capi
+    saved = os.environ.pop("SFG_ENABLE_TEST_HOOKS", None)
+    try:
+        other = capi.Context(ol.Q_PN14, ol.P_PN14)
+    finally:
+        if saved is not None:
+            os.environ["SFG_ENABLE_TEST_HOOKS"] = saved
+    assert capi.lib().sfg_ctx_encoder_inject_unsafe_for_test(other.h, 1) != 0
+    assert b"SFG_ENABLE_TEST_HOOKS" in capi.lib().sfg_last_error(other.h)
+    other.sync()
+    other.close()
