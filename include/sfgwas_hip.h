@@ -234,6 +234,13 @@ int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_l
  * MatMult4StreamPreprocess writes them (increasing shift, matmult.go:1001-1035): the records of one giant step then form ONE MAC launch; any
  * other order still gives the right sums, at one upload + launch per change of giant step. */
 int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A_dev, int s, int in_level, int max_level, const char *cache_prefix, int nbr, uint64_t *out_dev);
+/* MatMult4StreamPreprocess with its on-disk result (gwas/matmult.go:914-1041): writes <prefix>_<bi>.bin for every block row of the (optionally transposed)
+ * resident matrix in the reference's DiagCacheStream format (filestream.go:144-231: 6 x u64 LE header, 2 d table bytes, per active shift u64 LE length,
+ * u32 LE shift, per block column u8 isEmpty + (max_level + 1) x N words, NTT + Montgomery form, big-endian) from diagonals encoded ON THE DEVICE - for
+ * interoperability with CPU-only parties and for sfg_matmul_from_cache.  Existing files are kept, as the reference keeps them (:928-931); records are in
+ * increasing shift (the reference's worker pool delivers them in nearly that order; every reader takes them in any order).  96 bytes per genotype:
+ * a 10 000 x 100 000 matrix makes 96 GB - the resident int8 matrix is the default for a reason.  *files_written (optional): files created by this call. */
+int sfg_diagcache_write(sfg_ctx *ctx, const sfg_geno *g, unsigned flags, int max_level, const char *cache_prefix, int *files_written);
 /* header of <prefix>_<block_row>.bin: {vectorLen (= block columns), level, scale (f64 bits), n, numModuli, rowSize} */
 int sfg_diagcache_header(sfg_ctx *ctx, const char *cache_prefix, int block_row, uint64_t hdr[6]);
 /* host-pointer form, one call = MatMult4Stream(cps, A, gfs, maxLevel, computeSquaredSum, square, nproc) */

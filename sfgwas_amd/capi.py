@@ -94,6 +94,7 @@ def _sig(L):
         "sfg_matmul_resident_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, vp]),
         "sfg_matmul_from_cache": (i, [vp, vp, i, i, i, C.c_char_p, i, vp]),
         "sfg_diagcache_header": (i, [vp, C.c_char_p, i, u64p]),
+        "sfg_diagcache_write": (i, [vp, vp, C.c_uint, i, C.c_char_p, C.POINTER(C.c_int)]),
         "sfg_matmul_stream": (i, [vp, u64p, i, i, i, vp, sz, sz, sz, C.c_uint, u64p, C.POINTER(d), C.POINTER(d)]),
         "sfg_matmul_resident_range_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, vp]),
         "sfg_matmul_accumulate_dev": (i, [vp, vp, i, i, i, vp, C.c_uint, i, i, i, i, i, vp]),

@@ -830,6 +830,109 @@ __global__ void __launch_bounds__(256) k_cache_to_panel(const u64 *raw, const ui
     dst[x] = packed ? pack_limbs(v) : v;
 }
 
+// ---- MatMult4StreamPreprocess with its reference-format output (matmult.go:914-1041 -> filestream.go:144-231): the DiagCache files of a resident matrix,
+// written from DEVICE-encoded diagonals, so that a CPU-only party (or sfg_matmul_from_cache) can multiply from them.
+// canonical NTT words pt[nshift][LV][N] -> payload words of ring.WriteCoeffsTo: MForm (x 2^64 mod q, matmult.go:401-440) then big-endian
+__global__ void __launch_bounds__(256) k_cache_payload(const u64 *pt, u64 *out, int LV, const u64 *r64, const ModConst *modc) {
+    const int N = SFG_N; const size_t row = blockIdx.x / (N / 256); const int l = (int)(row % LV);
+    const size_t x = row * N + (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    out[x] = __builtin_bswap64(d_mulmod_u64(pt[x], r64[l], modc[l].qi));
+}
+extern "C" int sfg_diagcache_write(sfg_ctx *ctx, const sfg_geno *g, unsigned flags, int max_level, const char *prefix, int *files_written) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (files_written) *files_written = 0;
+    if (!g || !prefix) SFG_FAIL(ctx, "sfg_diagcache_write: null argument");
+    if (flags & ~SFG_TRANSPOSE) SFG_FAIL(ctx, "sfg_diagcache_write: only SFG_TRANSPOSE is meaningful here (MatMult4StreamPreprocess neither squares nor sums)");
+    const int LV = max_level + 1;                    // EncodeDiagWithEncoder makes level-maxLevel plaintexts: maxLevel + 1 moduli rows are written, maxLevel are multiplied
+    if (max_level < 1 || LV > ctx->nq) SFG_FAIL(ctx, "sfg_diagcache_write: max_level out of range");
+    if (g->packed) {
+        sfg_geno *u = nullptr; SFG_TRY(sfg_geno_unpack(ctx, g, &u));
+        const int rc = sfg_diagcache_write(ctx, u, flags, max_level, prefix, files_written); sfg_geno_free(ctx, u); return rc;
+    }
+    const Shape sh = make_shape(g, flags);
+    const int N = SFG_N, d = SFG_D, slots = SFG_SLOTS;
+    const size_t ptw = (size_t)LV * N;                                   // words per plaintext
+    const size_t row_size = 4 + (1 + ptw * 8) * (size_t)sh.m_ct;         // filestream.go:166 rowSize
+    // 2^64 mod q_l per modulus (ring.MForm's constant)
+    u64 r64_h[SFG_MAXMOD];
+    for (int l = 0; l < LV; l++) { const unsigned __int128 t = ((unsigned __int128)1 << 64) % ctx->q[l]; r64_h[l] = (u64)t; }
+    u64 *r64_d = nullptr; int8_t *skew = nullptr; u64 *half = nullptr, *full = nullptr, *pay_d = nullptr; unsigned char *pay_h = nullptr;
+    const int BATCH = 64;                                                // shifts per device batch: 64 x LV x N x 8 = 50 MB of payload per block column
+    SFG_TRY(sfg_scratch(ctx, "dcw.r64", SFG_MAXMOD * 8, (void **)&r64_d));
+    SFG_TRY(sfg_scratch(ctx, "enc.skew", (size_t)slots * slots, (void **)&skew));
+    SFG_TRY(sfg_scratch(ctx, "enc.half", (size_t)BATCH * LV * (N / 2) * 8, (void **)&half));
+    SFG_TRY(sfg_scratch(ctx, "dcw.full", (size_t)BATCH * ptw * 8, (void **)&full));
+    SFG_TRY(sfg_scratch(ctx, "dcw.pay", (size_t)BATCH * ptw * 8, (void **)&pay_d));
+    SFG_HIP(ctx, hipMemcpyAsync(r64_d, r64_h, SFG_MAXMOD * 8, hipMemcpyHostToDevice, ctx->stream));
+    SFG_HIP(ctx, hipHostMalloc((void **)&pay_h, (size_t)BATCH * ptw * 8, hipHostMallocDefault));
+    int rc = 0, written = 0;
+    for (int bi = 0; bi < sh.nbr && !rc; bi++) {
+        const std::string fn = std::string(prefix) + "_" + std::to_string(bi) + ".bin";
+        if (FILE *t = fopen(fn.c_str(), "rb")) { fclose(t); continue; }             // NewDiagCacheStream(..., isWrite): an existing file is kept (filestream.go:48-54, matmult.go:928-931)
+        const int nr = sh.rows_of(bi);
+        // active shifts and the baby / giant tables of the header (matmult.go:962-972): union over the block columns
+        std::vector<uint8_t> baby_t(d, 0), giant_t(d, 0), shift_t(slots, 0);
+        std::vector<std::vector<uint8_t>> has(sh.m_ct, std::vector<uint8_t>(slots, 0));
+        for (int shift = 0; shift < slots; shift++) {
+            bool any = false;
+            for (int bj = 0; bj < sh.m_ct; bj++) { has[bj][shift] = diag_bool(nr, sh.cols_of(bj), slots, -shift) ? 1 : 0; any = any || has[bj][shift]; }
+            if (any) { baby_t[shift % d] = 1; giant_t[shift / d] = 1; shift_t[shift] = 1; }
+        }
+        const std::string tmp = fn + ".part";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) { ctx->err = "sfg_diagcache_write: cannot create " + tmp; rc = 1; break; }
+        {   // header: 6 x u64 LE {vectorLen, level, scale bits, n, numModuli, rowSize}, then d baby flags, d giant flags (filestream.go:154-187)
+            uint64_t sb; const double sc = ctx->scale; memcpy(&sb, &sc, 8);
+            const uint64_t hdr[6] = {(uint64_t)sh.m_ct, (uint64_t)max_level, sb, (uint64_t)N, (uint64_t)LV, (uint64_t)row_size};
+            unsigned char hb[48]; for (int k = 0; k < 6; k++) for (int i = 0; i < 8; i++) hb[8 * k + i] = (unsigned char)(hdr[k] >> (8 * i));
+            if (fwrite(hb, 1, 48, f) != 48 || fwrite(baby_t.data(), 1, d, f) != (size_t)d || fwrite(giant_t.data(), 1, d, f) != (size_t)d) rc = 1;
+        }
+        // one file position per record: records are laid out in increasing shift (the order of the reference's job feeder, matmult.go:989-999), a record's
+        // plaintext j sits at a known offset, so the block columns can be encoded one after the other (one skew per block) and written in place
+        std::vector<long long> rec_pos(slots, -1); long long pos = 48 + 2 * d;
+        for (int shift = 0; shift < slots && !rc; shift++) if (shift_t[shift]) {
+            size_t len = 4; for (int bj = 0; bj < sh.m_ct; bj++) len += 1 + (has[bj][shift] ? ptw * 8 : 0);
+            unsigned char head[12]; for (int i = 0; i < 8; i++) head[i] = (unsigned char)((uint64_t)len >> (8 * i));
+            for (int i = 0; i < 4; i++) head[8 + i] = (unsigned char)((uint32_t)shift >> (8 * i));
+            if (fseeko(f, pos, SEEK_SET) || fwrite(head, 1, 12, f) != 12) { rc = 1; break; }
+            rec_pos[shift] = pos + 12; pos += 8 + (long long)len;
+        }
+        for (int bj = 0; bj < sh.m_ct && !rc; bj++) {
+            const int nc = sh.cols_of(bj);
+            rc = launch_skew(ctx, sh.block(bi, bj), sh.ld, nr, nc, sh.transposed ? 1 : 0, 0, skew);
+            for (int s0 = 0; s0 < slots && !rc; s0 += BATCH) {
+                int lo = -1, hi = -1;
+                for (int sft = s0; sft < std::min(slots, s0 + BATCH); sft++) if (has[bj][sft]) { if (lo < 0) lo = sft; hi = sft + 1; }
+                if (lo >= 0) {
+                    const int nb = hi - lo;
+                    rc = launch_encode_rows(ctx, skew, lo, nb, LV, half, true);
+                    if (!rc) rc = launch_expand_half(ctx, half, full, (size_t)nb * LV);
+                    if (!rc) {
+                        hipLaunchKernelGGL(k_cache_payload, dim3((unsigned)((size_t)nb * LV * (N / 256))), dim3(256), 0, ctx->stream, full, pay_d, LV, r64_d, ctx->modc);
+                        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(pay_h, pay_d, (size_t)nb * ptw * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                            hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "sfg_diagcache_write: device work failed"; rc = 1; }
+                    }
+                }
+                for (int sft = s0; sft < std::min(slots, s0 + BATCH) && !rc; sft++) if (shift_t[sft]) {
+                    // plaintext bj of record sft: isEmpty byte, then the payload
+                    long long off = rec_pos[sft]; for (int k = 0; k < bj; k++) off += 1 + (has[k][sft] ? (long long)ptw * 8 : 0);
+                    const unsigned char flag = has[bj][sft] ? 0 : 1;
+                    if (fseeko(f, off, SEEK_SET) || fwrite(&flag, 1, 1, f) != 1) { rc = 1; break; }
+                    if (has[bj][sft] && fwrite(pay_h + (size_t)(sft - lo) * ptw * 8, 1, ptw * 8, f) != ptw * 8) { rc = 1; break; }
+                }
+            }
+        }
+        if (fclose(f)) rc = 1;
+        if (!rc && rename(tmp.c_str(), fn.c_str())) rc = 1;
+        if (rc) { remove(tmp.c_str()); if (ctx->err.empty()) ctx->err = "sfg_diagcache_write: I/O error on " + fn; break; }
+        written++;
+    }
+    (void)hipHostFree(pay_h);
+    if (files_written) *files_written = written;
+    if (!rc) rc = sfg_encoder_check(ctx);
+    return rc;
+}
+
 extern "C" int sfg_diagcache_header(sfg_ctx *ctx, const char *prefix, int block_row, uint64_t hdr[6]) {
     FILE *f = nullptr; DiagCacheHdr h;
     SFG_TRY(dc_open(ctx, std::string(prefix) + "_" + std::to_string(block_row) + ".bin", &f, h));

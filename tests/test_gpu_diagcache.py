@@ -126,3 +126,30 @@ def test_two_block_rows_two_block_columns_sparse_diagonals(env, tmp_path):
     os.remove(prefix + "_1.bin")
     with pytest.raises(capi.SfgError):
         from_cache(ctx, capi, A, prefix, nbr, m_ct, s)
+
+
+def test_gpu_written_cache_equals_the_oracle_writer_byte_for_byte_and_is_consumed(env, tmp_path):
+    """sfg_diagcache_write (MatMult4StreamPreprocess, matmult.go:914-1041): the file the GPU writes from device-encoded diagonals (MForm, big-endian
+    payload, filestream.go:144-231 layout) equals the oracle writer's bytes, and sfg_matmul_from_cache multiplies from it; the transposed view of
+    the one resident copy gives the file of X^T; an existing file is kept."""
+    ctx, ring, keys, capi = env
+    lib = capi.lib()
+    rnd = np.random.default_rng(43)
+    geno = rnd.integers(-1, 3, (45, 33)).astype(np.int8)
+    g = ctx.geno_upload(geno)
+    for flags, logical, tag in ((0, geno, "x"), (capi.SFG_TRANSPOSE, np.ascontiguousarray(geno.T), "xt")):
+        ref_prefix, gpu_prefix = str(tmp_path / f"ref_{tag}"), str(tmp_path / f"gpu_{tag}")
+        nbr, m_ct = write_cache(ring, logical, ref_prefix)
+        nfiles = C.c_int()
+        ctx.check(lib.sfg_diagcache_write(ctx.h, g, flags, LEVEL, gpu_prefix.encode(), C.byref(nfiles)), "diagcache_write")
+        assert nfiles.value == nbr == 1
+        a, b = open(ref_prefix + "_0.bin", "rb").read(), open(gpu_prefix + "_0.bin", "rb").read()
+        assert len(a) == len(b) and a == b, "GPU-written DiagCache differs from the oracle writer's bytes"
+        s = 2
+        A = np.stack([np.stack([ring.fill_uniform(LEVEL, 90 + i)]) for i in range(s)])
+        got = from_cache(ctx, capi, A, gpu_prefix, nbr, m_ct, s)
+        want, _, _ = ol.matmult4stream(ring, keys, SCALE, A, LEVEL, L, logical, enc_prec=1)
+        assert np.array_equal(got, want)
+        ctx.check(lib.sfg_diagcache_write(ctx.h, g, flags, LEVEL, gpu_prefix.encode(), C.byref(nfiles)), "diagcache_write again")
+        assert nfiles.value == 0                                          # "skips existing files" (matmult.go:928-931)
+    ctx.geno_free(g)
