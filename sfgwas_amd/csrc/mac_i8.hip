@@ -274,11 +274,11 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_lds(I8Args a, const ModConst 
 // + 6 x 5 KiB of plaintext tiles) travels global -> LDS by global_load_lds_dwordx4 two chunks ahead of its use (three 50 KiB slots, counted vmcnt, one raw
 // s_barrier per chunk), needs no VGPRs on the way, and the MFMA operands come from LDS by ds_read_b128 issued three tiles ahead (counted lgkmcnt, by hand:
 // left to the compiler, every LDS read after a DMA instruction is preceded by s_waitcnt vmcnt(0)).  Identical arithmetic, identical words.
-constexpr int I8R_DEPTH = 3;
 __device__ __forceinline__ void i8_dma16(const void *gsrc, void *lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
-template <int ND>
+// DEPTH slots of 10 ND KiB: three for the 35-bit moduli (150 KiB), two for the 46-bit one (120 KiB: its 144 MFMAs per chunk cover one chunk of lookahead)
+template <int ND, int I8R_DEPTH>
 __global__ void __launch_bounds__(384, 1) k_mac_i8_ring(I8Args a, const ModConst *modc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     constexpr int NA = 4 * ND, NB = 6 * ND, SLOT = (NA + NB) * 1024, AR = (NA + 5) / 6, NJ = ND + AR;      // tiles per slot; DMA instructions per wave and chunk
@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *mod
 int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (ctx.hip)
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 5 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 6 * 1024));
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8R_DEPTH * 10 * 5 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 10 * 6 * 1024));
     return 0;
 }
 // bytes of the two operand streams and the tile-ordered results of one launch (for the group-size choice in matmul.hip)
@@ -451,7 +452,10 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       else hipLaunchKernelGGL(k_i8_pack_pt<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
     { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
-      if (!BIG && a.njt == 6 && ctx->cfg.mac_i8_ring) hipLaunchKernelGGL(k_mac_i8_ring<5>, dim3((unsigned)(nl * H)), dim3(384), I8R_DEPTH * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+      if (a.njt == 6 && ctx->cfg.mac_i8_ring) {
+          if (BIG) hipLaunchKernelGGL((k_mac_i8_ring<6, 2>), dim3((unsigned)(nl * H)), dim3(384), 2 * 10 * 6 * 1024, ctx->stream, a, ctx->modc);
+          else hipLaunchKernelGGL((k_mac_i8_ring<5, 3>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+      }
       else if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
       else if (ctx->cfg.mac_i8_wg1) hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H * a.njt)), dim3(64), 0, ctx->stream, a, ctx->modc);
       else hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
