@@ -56,10 +56,11 @@ struct SfgConfig {
     bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
     bool mac_i8 = true;            // SFG_MAC_IMPL=bc       the DPP-broadcast fp64 kernel for every modulus (round 2's MAC) instead of: small moduli on the int8 matrix core (mac_i8.hip), the 46-bit one on the DPP-broadcast kernel
     size_t i8_keep_reserve = 80ULL << 30;   // SFG_I8_KEEP_RESERVE_GB  HBM that must stay free beside the transposed copies of ALL groups of a caller's rotation cache (association scan) for the int8 MAC to take that call
-    bool mac_i8_big = false;       // SFG_MAC_I8_BIG=1      the 46-bit modulus on the int8 matrix core too (six digits, 36 products, eleven sums) instead of the fp64 DPP-broadcast kernel: identical words, measured slower (13.06 s against 12.49 s per power iteration: its own transposition passes cost more than the kernel saves)
+    bool mac_i8_big = true;        // SFG_MAC_I8_BIG=1      the 46-bit modulus on the int8 matrix core too (six digits, 36 products, eleven sums) instead of the fp64 DPP-broadcast kernel: identical words, measured slower (13.06 s against 12.49 s per power iteration: its own transposition passes cost more than the kernel saves)
     bool mac_i8_nolds = true;      // SFG_MAC_I8_ROT=lds    int8 MAC: rot tiles of a coefficient pair staged through LDS (k_mac_i8_lds) instead of shared through the cache (measured at 100k x 1M: 3.31 s against 2.56 s per step - the barriers cost more than the re-fetches)
     bool test_hooks = false;       // SFG_ENABLE_TEST_HOOKS=1   sfg_ctx_encoder_inject_unsafe_for_test may be called (tests of the failure path only)
     bool mac_i8_ring = true;       // SFG_MAC_I8_ROT=cache    int8 MAC without the LDS prefetch ring (k_mac_i8: operands straight from global memory, rot tiles shared through the L1)
+    bool stage_pack = true;        // SFG_MAC_I8_STAGE=0    int8 MAC: plaintext digit planes through the full panel and a transposition pass per MAC launch instead of the streamed transposition (StagePack)
     bool mac_i8_wg1 = false;       // SFG_MAC_I8_WG=1       int8 MAC diagnostic: one column wave per workgroup (no cache shared between the column waves of a coefficient pair); for the PMC re-fetch measurement
     int mac_wc = 1;                // SFG_MAC_WC            column waves per small-modulus MAC workgroup
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
@@ -137,6 +138,7 @@ struct sfg_ctx {
     std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
     std::string err;
     std::map<std::string, PhaseStat> phases;
+    int sp_shape = -1;                      // block rows per group the streamed tile buffers (mi8.Bs / mi8.Bb) were last cleared for
     std::set<const sfg_geno *> ptc_genos;   // matrices whose plaintext coefficient cache this context owns (dropped when an unprovable encoder rounding is reported / reset)
     bool test_hooks = false;                // SFG_ENABLE_TEST_HOOKS=1 at context creation: the failure-path test hook may be used
     void *tie_count_dev = nullptr;          // two counters: encoder coefficients within 2^-40 of a rounding tie (audit) and within 2^-50 (sticky failure, sfg_encoder_check)

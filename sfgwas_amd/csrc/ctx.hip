@@ -32,6 +32,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_I8_BIG")) c.mac_i8_big = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_ROT")) { c.mac_i8_nolds = strcmp(e, "lds") != 0; c.mac_i8_ring = !strcmp(e, "ring"); }      // ring (default) | cache | lds
     if (env("SFG_MAC_I8_WG")) c.mac_i8_ring = false;
+    if (const char *e = env("SFG_MAC_I8_STAGE")) c.stage_pack = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
     if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
@@ -290,7 +291,7 @@ extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx) {
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
     ctx->pool.clear();
     for (int b = 0; b < 2; b++) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) ctx->i8_slot[b][i] = sfg_ctx::I8Slot();      // the kept transposed rot copies lived in the pool
-    ctx->i8_gen++;
+    ctx->i8_gen++; ctx->sp_shape = -1;
     return 0;
 }
 // The int8 MAC keeps a transposed copy of a rotation-cache operand, keyed by its address, shape and a per-context generation counter that every library

@@ -522,10 +522,11 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
 // half_rows + G > 0: `pt` is the base of a grouped panel and rows are scattered by PanelMap (half rows only)
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask, const PcCache *pcache) {
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask, const PcCache *pcache, StagePack *sp) {
     EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
-    const int BATCH = ctx->cfg.enc_batch;                 // plaintexts per FFT / NTT launch pair (SFG_ENC_BATCH)
+    if (sp && (shift0 % SFG_D || !half_rows || !(packed_mask >> 31))) SFG_FAIL(ctx, "encode: internal: the streamed transposition takes whole giant steps of digit-plane rows");
+    const int BATCH = sp ? SFG_STAGE_BATCH : ctx->cfg.enc_batch;                 // plaintexts per FFT / NTT launch pair (SFG_ENC_BATCH)
     const int cmode = pcache && pcache->slot && half_rows && G > 0 ? pcache->mode : 0;
     double *pc = nullptr;
     if (!cmode) SFG_TRY(enc_pc_scratch(ctx, (size_t)(nshift < BATCH ? nshift : BATCH), &pc));
@@ -542,7 +543,18 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         const bool sampled = half_rows && G > 0 && (ctx->ntt_plain_seq++ & 15) == 0;
         PhaseTimer tn(ctx, "ntt_plain", sampled);
         if (half_rows && G > 0) { PhaseStat &all = ctx->phases["ntt_plain_all"]; all.launches += 1; }
-        if (cmode == 3) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm)); }
+        if (sp) {
+            // the staging buffer is free once the previous batch has been transposed (that ran beside this batch's FFT)
+            if (sp->pending) SFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, sp->ev_pack, 0));
+            PanelMap pm{0, 0, shift0 + s0, packed_mask};
+            SFG_TRY(launch_ntt_plain_half(ctx, cmode == 3 ? pcache->slot : pc, sp->stage, nb, L, pm, cmode == 3 ? pcache->perm : nullptr));
+            SFG_HIP(ctx, hipEventRecord(sp->ev_ntt, ctx->stream));
+            SFG_HIP(ctx, hipStreamWaitEvent(sp->q, sp->ev_ntt, 0));
+            SFG_TRY(launch_i8_pack_stage(ctx, *sp, shift0 + s0, nb, L));
+            SFG_HIP(ctx, hipEventRecord(sp->ev_pack, sp->q));
+            sp->pending = true;
+        }
+        else if (cmode == 3) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm)); }
         else if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
         else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));

@@ -22,12 +22,14 @@ int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 // mac.hip
-struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; bool i8_big = false; bool pt_digits_big = false; };   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
+struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; bool i8_big = false; bool pt_digits_big = false;
+                    const int8_t *B_small = nullptr, *B_big = nullptr; int kb = 0; };   // B_*: the int8 MAC's plaintext tiles are already in place (streamed transposition, StagePack): no panel, k' = g * kb + baby   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                         int l0, int nl, int accumulate, const MacStrides &st);       // mac_i8.hip
 int launch_mac_i8_big(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                       int l0, int accumulate, const MacStrides &st);
 size_t mac_i8_stream_bytes(int K, int nl, int ND, int copies_of_rot);
+size_t mac_i8_tile_bytes(int Kp, int nl, int ND);      // plaintext tile buffer of nl moduli with ND digits, K' contraction steps (mac_i8.hip)
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate);
 int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st);
 // encode.hip
@@ -35,7 +37,21 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 // pcache (nullable): the block's slot of the plaintext coefficient cache, [8192 shifts][N/2] doubles.  mode 1: the FFT writes its rows there (and the NTT reads them);
 // 2: the rows are there already (no FFT; D unused); 3: they are there in the block's other orientation (no FFT; NTT through the permutation table)
 struct PcCache { double *slot = nullptr; int mode = 0; const uint32_t *perm = nullptr; };
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0, unsigned packed_mask = 0, const PcCache *pcache = nullptr);
+// Streamed transposition (round 4): the plaintext NTT of a batch writes its digit planes DENSE into one small staging buffer (reused by every batch, so it lives in
+// the Infinity Cache and never reaches HBM) and k_i8_pack_stage moves the batch into the int8 MAC's k-contiguous tiles on a second queue, beside the (fp64-issue
+// bound) FFT of the next batch.  The 21 - 43 GB plaintext panel and its read + write pass per MAC launch disappear.
+struct StagePack {
+    u64 *stage = nullptr;                  // [batch][L][N/2 words]
+    int8_t *Bs = nullptr, *Bb = nullptr;   // tiles of the small moduli [m][c][jt][ch][5][1 KiB] / of the 46-bit modulus [c][jt][ch][6][1 KiB]
+    int g = 0, kb = 92, njt = 6, nch = 0;  // block row inside the MAC group: k' = g * kb + baby
+    int l_big = -1, l_small0 = 0, n_small = 0;
+    hipStream_t q = nullptr; hipEvent_t ev_ntt = nullptr, ev_pack = nullptr; bool pending = false;
+    unsigned seq = 0;
+};
+constexpr int SFG_STAGE_BATCH = 11 * SFG_D;       // whole giant steps per batch: 1001 plaintexts (5005 NTT workgroups)
+int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, int L);      // mac_i8.hip
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0, unsigned packed_mask = 0, const PcCache *pcache = nullptr,
+                       StagePack *sp = nullptr);
 // genoio.hip: dense int8 copy [nr][ld_out] of the stored sub-block (r0.., c0..) of a 2-bit packed matrix (c0 a multiple of 4)
 int launch_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, size_t r0, size_t c0, size_t nr, size_t nc, int8_t *out, size_t ld_out);
 // rotate.hip

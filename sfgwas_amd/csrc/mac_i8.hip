@@ -35,6 +35,7 @@ struct I8Args {
     const double *rotf; const u64 *pt; u64 *out;
     size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
     int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt, pt_digits;
+    int kb;                                // 0: k is the row of the rot operand; else k' = g * kb + baby with baby < 91 real (streamed plaintext tiles: block rows start on a dword)
     int8_t *A, *B; u64 *T;
 };
 
@@ -50,8 +51,10 @@ __global__ void __launch_bounds__(256) k_i8_pack_rot(I8Args a) {
     for (int p = tid / I8_PC; p < 64 * 32; p += 256 / I8_PC) {
         const int kk = p >> 5, r = p & 31, k = ch * 64 + kk;
         long long v = 0;
-        if (k < a.K && a.r0 + r < a.R) {
-            const double *e = src + (size_t)k * a.rotf_k_stride + (size_t)(a.r0 + r) * a.rotf_r_stride;
+        int ks = k; bool kv = k < a.K;
+        if (a.kb) { const int gg = k / a.kb, baby = k - gg * a.kb; kv = kv && baby < SFG_D; ks = gg * SFG_D + baby; }
+        if (kv && a.r0 + r < a.R) {
+            const double *e = src + (size_t)ks * a.rotf_k_stride + (size_t)(a.r0 + r) * a.rotf_r_stride;
             v = ND == 6 ? (long long)e[1] * 8388608LL + (long long)e[0] : (long long)e[0];
         }
         int8_t d[ND]; i8_digits<ND>(v, d);
@@ -148,6 +151,57 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
             const uint4 w = make_uint4(sp[0 ^ (q2 >> 3)], sp[1 ^ (q2 >> 3)], sp[2 ^ (q2 >> 3)], sp[3 ^ (q2 >> 3)]);
             *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g * 256 + l16 * 16) = w;
         }
+        __syncthreads();
+    }
+}
+// ---- the same from the DENSE digit planes of one encode batch (StagePack, kernels.hpp): plaintext p of the batch is shift shift0 + p = giant n, baby b of block
+// row g; its byte goes to column n, k' = g * kb + b.  A workgroup = (modulus, column tile jt, 16 k', 128 coefficients) as above, restricted to what this batch
+// owns: columns [n_lo, n_hi) x the dwords of block row g (kb is a multiple of 4, so a 16-byte run splits between block rows on dword boundaries).  Owned positions
+// without a plaintext - the pad baby 91, shifts past 8191 - are written as zeros; what no batch owns (columns 91..95, k' past the last block row) is zeroed when the
+// tile buffer is (re)shaped.  Reads come from the staging buffer the NTT has just written (Infinity Cache), writes are 16-byte pieces of 1 KiB tiles.
+struct I8StageArgs { const u64 *stage; int8_t *B; int L, l0, nl, shift0, nshift, n_lo, n_hi, g, kb, njt, nch, jt0, njt_b, kq0, nkq; };
+template <int ND>
+__global__ void __launch_bounds__(256) k_i8_pack_stage(I8StageArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
+    const int H = SFG_N / 2, tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int cb = b % (H / I8_PD); b /= H / I8_PD;
+    const int kq = a.kq0 + b % a.nkq; b /= a.nkq;
+    const int jt = a.jt0 + b % a.njt_b, m = b / a.njt_b;
+    const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
+    const int ch = kq >> 2, g16 = kq & 3, l16 = tid & 15;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.stage) + (size_t)(a.l0 + m) * H * 8 + c0 + cq * 4;
+    const size_t pstride = (size_t)a.L * H * 8;                       // bytes per plaintext of the staging buffer
+    // ownership of this workgroup's stores: lane l16 = column n, dword k4 of a 16-byte piece = k' in [kq*16 + 4 k4, + 4)
+    const int n_st = jt * 16 + l16; const bool lane_owned = n_st >= a.n_lo && n_st < a.n_hi;
+    unsigned own = 0;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++) { const int k0 = kq * 16 + k4 * 4; if (k0 >= a.g * a.kb && k0 < (a.g + 1) * a.kb) own |= 1u << k4; }
+    for (int d = 0; d < ND; d++) {
+#pragma unroll 2
+        for (int it = 0; it < 8; it++) {
+            const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
+            unsigned w[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int k = kq * 16 + k4 * 4 + x, baby = k - a.g * a.kb, p = n * SFG_D + baby - a.shift0;
+                const bool ok = baby >= 0 && baby < SFG_D && n >= a.n_lo && n < a.n_hi && p >= 0 && p < a.nshift;
+                w[x] = ok ? *reinterpret_cast<const unsigned *>(src + (size_t)p * pstride + (size_t)d * H) : 0u;
+            }
+            unsigned o[4]; bytes_tr4(w[0], w[1], w[2], w[3], o);
+#pragma unroll
+            for (int e = 0; e < 4; e++) img[(cq * 4 + e) * 64 + ((j ^ (cq & 7)) << 2) + (k4 ^ (cq >> 3))] = o[e];
+        }
+        __syncthreads();
+        if (lane_owned && own)
+            for (int pc = tid >> 4; pc < I8_PD; pc += 16) {
+                const int q2 = pc >> 2;
+                const unsigned *sp = img + pc * 64 + ((l16 ^ (q2 & 7)) << 2);
+                const uint4 w = make_uint4(sp[0 ^ (q2 >> 3)], sp[1 ^ (q2 >> 3)], sp[2 ^ (q2 >> 3)], sp[3 ^ (q2 >> 3)]);
+                unsigned *dst = reinterpret_cast<unsigned *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g16 * 256 + l16 * 16);
+                if (own == 15u) *reinterpret_cast<uint4 *>(dst) = w;
+                else { if (own & 1u) dst[0] = w.x; if (own & 2u) dst[1] = w.y; if (own & 4u) dst[2] = w.z; if (own & 8u) dst[3] = w.w; }
+            }
         __syncthreads();
     }
 }
@@ -396,6 +450,35 @@ size_t mac_i8_stream_bytes(int K, int nl, int ND, int copies_of_rot) {
     const size_t N = SFG_N, H = N / 2, nch = ((size_t)K + 63) / 64;
     return (size_t)nl * (N * nch * 2 * ND * 1024 * copies_of_rot + H * 6 * nch * ND * 1024 + H * 2 * 6 * 2 * 256 * 8);
 }
+int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, int L) {
+    const int H = SFG_N / 2, d = SFG_D;
+    if (shift_lo % d) SFG_FAIL(ctx, "i8 stage pack: internal: a batch starts inside a giant step");
+    I8StageArgs a;
+    a.stage = sp.stage; a.L = L; a.shift0 = shift_lo; a.nshift = nshift; a.g = sp.g; a.kb = sp.kb; a.njt = sp.njt; a.nch = sp.nch;
+    a.n_lo = shift_lo / d; a.n_hi = (shift_lo + nshift + d - 1) / d;
+    if (shift_lo + nshift >= SFG_SLOTS) a.n_hi = d;                  // the last batch owns all of giant 90 (its shifts past 8191 are zero plaintexts)
+    a.jt0 = a.n_lo / 16; a.njt_b = (a.n_hi - 1) / 16 - a.jt0 + 1;
+    a.kq0 = (sp.g * sp.kb) / 16; a.nkq = ((sp.g + 1) * sp.kb - 1) / 16 - a.kq0 + 1;
+    hipStream_t saved = ctx->stream; ctx->stream = sp.q;
+    const bool sampled = (sp.seq++ & 7) == 0;
+    {
+        PhaseTimer t(ctx, "mac_i8_pack_pt", sampled);
+        if (sp.n_small) {
+            a.B = sp.Bs; a.l0 = sp.l_small0; a.nl = sp.n_small;
+            hipLaunchKernelGGL(k_i8_pack_stage<5>, dim3((unsigned)((size_t)a.nl * a.njt_b * a.nkq * (H / I8_PD))), dim3(256), 0, sp.q, a);
+        }
+        if (sp.l_big >= 0) {
+            a.B = sp.Bb; a.l0 = sp.l_big; a.nl = 1;
+            hipLaunchKernelGGL(k_i8_pack_stage<6>, dim3((unsigned)((size_t)a.njt_b * a.nkq * (H / I8_PD))), dim3(256), 0, sp.q, a);
+        }
+        if (sampled) t.stop(8, 8.0 * nshift * H * (5.0 * sp.n_small + (sp.l_big >= 0 ? 6.0 : 0.0)) * 2.0);       // (one launch pair in eight is timed: counted for eight)
+    }
+    ctx->stream = saved;
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// bytes of the tile buffer of `nl` moduli with ND digits for K' contraction steps
+size_t mac_i8_tile_bytes(int Kp, int nl, int ND) { return (size_t)nl * (SFG_N / 2) * 6 * (((size_t)Kp + 63) / 64) * ND * 1024; }
 template <int ND>
 static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                             int l0, int nl, int accumulate, const MacStrides &st) {
@@ -405,7 +488,11 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (BIG && nl != 1) SFG_FAIL(ctx, "sfg_mac (i8): one 46-bit modulus per launch");
     if (Ncols > 96) SFG_FAIL(ctx, "sfg_mac (i8): more than 96 columns per launch");
     if ((long long)K * ND >= 131072) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums (ND K 2^14 must stay below 2^31)");
-    I8Args a;
+    const int8_t *B_pre = BIG ? st.B_big : st.B_small;              // streamed transposition: the plaintext tiles are in place, k' = g * kb + baby
+    if (B_pre && (K % SFG_D || !st.kb || Ncols != SFG_D)) SFG_FAIL(ctx, "sfg_mac (i8): internal: prepacked tiles need whole block rows and 91 columns");
+    const int K_rot = K;                                            // rows of the rot operand
+    if (B_pre) K = K / SFG_D * st.kb;
+    I8Args a; a.kb = B_pre ? st.kb : 0;
     a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
     a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = H; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
     a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
@@ -413,7 +500,7 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     const size_t nA = (size_t)nl * N * a.nch * 2 * ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
     // the transposed rot operand is kept while its source (pointer, generation, shape) is unchanged: a group's rotation cache serves every block column.
     // Two copies per kind of modulus (the pipelined product alternates between two rot buffers).
-    const u64 sig[8] = {ctx->i8_gen, (u64)K, (u64)R, (u64)r0, (u64)l0 << 8 | (u64)nl, (u64)plane0, (u64)rotf_k_stride, (u64)rotf_r_stride};
+    const u64 sig[8] = {ctx->i8_gen, (u64)K | (u64)a.kb << 32, (u64)R, (u64)r0, (u64)l0 << 8 | (u64)nl, (u64)plane0, (u64)rotf_k_stride, (u64)rotf_r_stride};
     sfg_ctx::I8Slot *slots = ctx->i8_slot[BIG ? 1 : 0];
     int slot = -1;
     for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) if (slots[i].src == (const void *)rotf && !memcmp(slots[i].sig, sig, sizeof sig)) slot = i;
@@ -439,15 +526,16 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     SFG_TRY(sfg_scratch(ctx, nm, nA, (void **)&a.A));
     if (repack) { slots[slot].src = (const void *)rotf; memcpy(slots[slot].sig, sig, sizeof sig); }
     slots[slot].last_use = ++ctx->i8_clock;
-    SFG_TRY(sfg_scratch(ctx, "mi8.B", nB, (void **)&a.B));
+    if (B_pre) a.B = const_cast<int8_t *>(B_pre);
+    else SFG_TRY(sfg_scratch(ctx, BIG ? "mi8.Bb" : "mi8.Bs", nB, (void **)&a.B));        // (the buffers of the streamed tiles: a launch uses them one way or the other)
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
     // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers)
     if (!repack && ctx->pool[nm].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
     const double tile = 1024.0;
     if (repack) { PhaseTimer t(ctx, "mac_i8_pack_rot");
       hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * ND * 1024, ctx->stream, a);
-      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K * std::min(32, R - r0) * (BIG ? 16.0 : 8.0) + (double)a.nch * 2 * ND * tile)); }
-    { PhaseTimer t(ctx, "mac_i8_pack_pt");
+      SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K_rot * std::min(32, R - r0) * (BIG ? 16.0 : 8.0) + (double)a.nch * 2 * ND * tile)); }
+    if (!B_pre) { PhaseTimer t(ctx, "mac_i8_pack_pt");
       if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD))), dim3(256), 0, ctx->stream, a);
       else hipLaunchKernelGGL(k_i8_pack_pt<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }

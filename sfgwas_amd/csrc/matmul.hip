@@ -338,7 +338,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     if (G2 <= G) break;
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
                     const bool enc2 = !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G2 - 1) / G2) * (j1 - j0) >= 2;
-                    size_t need = (size_t)G2 * nplain * L * ((size_t)N / 2) * 8 * (enc2 ? 2 : 1);
+                    const bool streamable2 = ctx->cfg.mac_i8 && ctx->cfg.mac_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc2;      // then the panel holds 4 block rows
+                    size_t need = (size_t)(streamable2 ? std::min(G2, 4) : G2) * nplain * L * ((size_t)N / 2) * 8 * (enc2 ? 2 : 1);
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
@@ -372,7 +373,10 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", dma ? 8 : (size_t)d * s * ctw * 8, (void **)&rotc));     // u64 rotation cache: only the register-staged MAC reads one
     // Two plaintext panels when the encode of launch k + 1 runs on its own queue beside the transposition + MAC of launch k (fp64-issue bound beside HBM bound)
     const bool enc_ov = dma && !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G - 1) / G) * (j1 - j0) >= 2;
-    const size_t panel_words = (size_t)G * nplain * L * prow;
+    // where every modulus multiplies on the int8 matrix core from streamed tiles, the panel serves only the rare launches that cannot stream: Gp block rows of it
+    const bool streamable = use_i8 && use_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc_ov;
+    const int Gp = streamable ? std::min(G, 4) : G;
+    const size_t panel_words = (size_t)Gp * nplain * L * prow;
     SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov ? 2 : 1), (void **)&pt));
     u64 *const pt_base = pt;
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
@@ -430,13 +434,47 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         }
         for (int bj = j0; bj < j1 && !rc; bj++, it++) {
             const int nc = sh.cols_of(bj);
+            // Streamed transposition (StagePack, kernels.hpp): when every block of this launch has all 8192 diagonals and every modulus multiplies on the int8
+            // matrix core, the NTT's digit planes go batch by batch through a cache-resident staging buffer into the MAC's tiles - no panel, no transposition pass
+            bool stream = streamable;
+            for (int g = 0; g < ng && stream; g++) stream = sh.rows_of(bg + g) + nc > SFG_SLOTS;
+            StagePack sp;
+            if (stream) {
+                std::vector<int> po, ib; (void)mac_dma_planes(ctx, L, po, ib);
+                int nbig = 0; sp.l_big = -1; sp.l_small0 = -1; sp.n_small = 0;
+                for (int l = 0; l < L; l++) { if (ib[l]) { nbig++; sp.l_big = l; } else { if (sp.l_small0 < 0) sp.l_small0 = l; sp.n_small++; } }
+                bool contiguous = nbig <= 1;
+                for (int l = 0; l < L && contiguous; l++) if (!ib[l] && (l < sp.l_small0 || l >= sp.l_small0 + sp.n_small)) contiguous = false;
+                if (!contiguous || !sp.n_small) stream = false;
+            }
+            if (stream) {
+                sp.kb = 92; sp.njt = 6; sp.nch = (ng * sp.kb + 63) / 64; sp.q = ctx->enc_stream; sp.ev_ntt = ctx->ev_enc[0]; sp.ev_pack = ctx->ev_enc[1];
+                const size_t nBs = mac_i8_tile_bytes(ng * sp.kb, sp.n_small, 5), nBb = sp.l_big >= 0 ? mac_i8_tile_bytes(ng * sp.kb, 1, 6) : 0;
+                const size_t had_s = ctx->pool.count("mi8.Bs") ? ctx->pool["mi8.Bs"].second : 0, had_b = ctx->pool.count("mi8.Bb") ? ctx->pool["mi8.Bb"].second : 0;
+                rc = sfg_scratch(ctx, "mi8.Bs", nBs, (void **)&sp.Bs); if (rc) break;
+                if (nBb) { rc = sfg_scratch(ctx, "mi8.Bb", nBb, (void **)&sp.Bb); if (rc) break; }
+                rc = sfg_scratch(ctx, "mi8.stage", (size_t)SFG_STAGE_BATCH * L * (N / 2) * 8, (void **)&sp.stage); if (rc) break;
+                // what no batch owns (columns 91..95, k' past the group's last block row) must read as zero: cleared when the buffers are new or the group shape changes
+                if (had_s < nBs || had_b < nBb || ctx->sp_shape != ng) {
+                    SFG_HIP(ctx, hipMemsetAsync(sp.Bs, 0, nBs, ctx->stream));
+                    if (nBb) SFG_HIP(ctx, hipMemsetAsync(sp.Bb, 0, nBb, ctx->stream));
+                    ctx->sp_shape = ng;
+                }
+                // the transposition queue starts behind everything this queue has done (the previous MAC launch read the tiles, the memsets above)
+                rc = sfg_stream_after(ctx, sp.q, ctx->stream); if (rc) break;
+            }
             const int pbuf = enc_ov ? (it & 1) : 0;
             pt = pt_base + (size_t)pbuf * panel_words;
             if (enc_ov) {                                  // encode on its queue: after the MAC that last read this panel buffer
                 if (it >= 2) SFG_HIP(ctx, hipStreamWaitEvent(ctx->enc_stream, ctx->ev_enc[2 + pbuf], 0));
                 ctx->stream = ctx->enc_stream;
             }
-            for (int g = 0; g < ng && !rc; g++) {
+          // A launch that cannot stream (a block with fewer than 8192 diagonals: the corner of a ragged matrix) goes through the plaintext panel.  Where streaming
+          // is the rule the panel holds only Gp block rows, and such a launch is multiplied in sub-launches of Gp rows that accumulate onto each other.
+          const int step = stream ? ng : std::min(ng, Gp);
+          for (int sub0 = 0; sub0 < ng && !rc; sub0 += step) {
+            const int gs = std::min(step, ng - sub0);
+            for (int g = sub0; g < sub0 + gs && !rc; g++) {
                 const int bi = bg + g, nr = sh.rows_of(bi);
                 // plaintext coefficient cache of the stored block (sfg_geno_set_plaintext_cache)
                 PcCache pcc; uint64_t ptc_key = 0; bool ptc_new = false;
@@ -470,17 +508,19 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 else { runs[0][0] = 0; runs[0][1] = nr; runs[1][0] = SFG_SLOTS - nc + 1; runs[1][1] = SFG_SLOTS; nruns = runs[1][0] < runs[1][1] ? 2 : 1; }
                 const bool full = nruns == 1 && runs[0][1] - runs[0][0] == SFG_SLOTS;
                 // zero what the encoder will not write: plaintext slot of (giant, g, baby) is ((giant*ng + g)*91 + baby)
-                if (full) {        // only the 89 slots past shift 8191 (giant 90, baby 2..90)
-                    rc = launch_pt_zero(ctx, pt + (((size_t)(d - 1) * ng + g) * d + (SFG_SLOTS - (d - 1) * d)) * plw, 0, (nplain - SFG_SLOTS) * plw, 1, L, prow, packed_mask);
+                if (stream) {      // (the tiles' unowned positions are zero already, owned ones without a plaintext are written as zeros)
+                } else if (full) {        // only the 89 slots past shift 8191 (giant 90, baby 2..90)
+                    rc = launch_pt_zero(ctx, pt + (((size_t)(d - 1) * gs + (g - sub0)) * d + (SFG_SLOTS - (d - 1) * d)) * plw, 0, (nplain - SFG_SLOTS) * plw, 1, L, prow, packed_mask);
                 } else {           // ragged block: all 91 x 91 slots of this block row
-                    rc = launch_pt_zero(ctx, pt + (size_t)g * d * plw, (size_t)ng * d * plw, (size_t)d * plw, d, L, prow, packed_mask);
+                    rc = launch_pt_zero(ctx, pt + (size_t)(g - sub0) * d * plw, (size_t)gs * d * plw, (size_t)d * plw, d, L, prow, packed_mask);
                 }
                 if (rc) { ptc_undo(); break; }
                 {
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, ng, g, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u),
-                                                         pcc.mode ? &pcc : nullptr);
+                        if (stream) sp.g = g;
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, gs, g - sub0, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u),
+                                                         pcc.mode ? &pcc : nullptr, stream ? &sp : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
                     t.stop(nruns);
@@ -492,18 +532,22 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 if (!rc) { SFG_HIP(ctx, hipEventRecord(ctx->ev_enc[pbuf], ctx->enc_stream)); SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_enc[pbuf], 0)); }
             }
             if (rc) break;
+            if (!stream && streamable) ctx->sp_shape = -1;       // (this launch transposes through the tile buffers the streamed launches keep partly cleared)
+            if (stream && sp.pending) SFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, sp.ev_pack, 0));       // the last batch is in the tiles
             {
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
+                if (stream) { st.B_small = sp.Bs; st.B_big = sp.Bb; st.kb = sp.kb; }
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = plw; st.pt_n = (size_t)ng * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
+                st.pt_k = plw; st.pt_n = (size_t)gs * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
-                const int acc_flag = (accumulate || !first_group) ? 1 : 0;      // the first group of a fresh call overwrites
+                const int acc_flag = (accumulate || !first_group || sub0 > 0) ? 1 : 0;      // the first (sub-)launch of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
-                if (dma) rc = launch_mac_dma(ctx, rotf_grp, (size_t)s * 2, pt, accj, ng * d, 2 * s, d, L, acc_flag, st, rotsum_grp);
+                if (dma) rc = launch_mac_dma(ctx, rotf_grp + (size_t)sub0 * d * s * 2 * rowf, (size_t)s * 2, pt, accj, gs * d, 2 * s, d, L, acc_flag, st, rotsum_grp);
                 else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
                 t.stop(1);
             }
+          }
             if (enc_ov && !rc) SFG_HIP(ctx, hipEventRecord(ctx->ev_enc[2 + pbuf], main_stream));
         }
         first_group = false;
