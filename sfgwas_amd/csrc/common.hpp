@@ -135,6 +135,8 @@ struct sfg_ctx {
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
     std::map<std::string, std::pair<void *, size_t>> pool;   // named grow-only device scratch (sfg_scratch), freed with the context
+    std::map<std::string, unsigned long long> pool_epoch;    // the top-level call (ApiScope) that last asked for the buffer: when the device is full, buffers no call in progress uses are given back
+    unsigned long long api_epoch = 0; int api_depth = 0;
     std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
     std::string err;
     std::map<std::string, PhaseStat> phases;
@@ -173,6 +175,12 @@ static inline uint32_t h_brev(uint32_t x, int bits) { uint32_t r = 0; for (int i
 
 // stream-ordered upload of a small host table: staged in the pinned ring, copied with hipMemcpyAsync on ctx->stream
 int sfg_upload_small(sfg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+// A top-level product call in progress (nested entry points share the outermost scope): sfg_scratch may evict buffers that were last requested by EARLIER calls
+struct ApiScope {
+    sfg_ctx *c;
+    explicit ApiScope(sfg_ctx *c_) : c(c_) { if (c->api_depth++ == 0) c->api_epoch++; }
+    ~ApiScope() { c->api_depth--; }
+};
 // run the enclosed launches on the auxiliary stream (everything launches on ctx->stream)
 struct AuxScope {
     sfg_ctx *c; hipStream_t saved;

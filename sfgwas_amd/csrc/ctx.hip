@@ -272,11 +272,32 @@ void sfg_phases_resolve(sfg_ctx *ctx) {
 }
 int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out) {
     auto &e = ctx->pool[name];
+    ctx->pool_epoch[name] = ctx->api_epoch;
     if (e.second < bytes) {
         SFG_TRY(sfg_sync_all(ctx));
         if (e.first) SFG_HIP(ctx, hipFree(e.first));
         e.first = nullptr; e.second = 0;
-        SFG_HIP(ctx, hipMalloc(&e.first, bytes));
+        hipError_t err = hipMalloc(&e.first, bytes);
+        if (err != hipSuccess && ctx->api_depth > 0) {
+            // The pools grow to the largest shape each buffer has served and are kept for the next call of that shape.  When the device is full, give back what
+            // only EARLIER top-level calls asked for (nothing of the call in progress: every buffer it uses was requested under its epoch) and try once more.
+            (void)hipGetLastError();
+            bool freed_rot_copy = false;
+            for (auto it = ctx->pool.begin(); it != ctx->pool.end();) {
+                if (it->first != name && it->second.first && ctx->pool_epoch[it->first] < ctx->api_epoch) {
+                    if (it->first.rfind("mi8.A", 0) == 0) freed_rot_copy = true;
+                    (void)hipFree(it->second.first); ctx->pool_epoch.erase(it->first); it = ctx->pool.erase(it);
+                } else ++it;
+            }
+            if (freed_rot_copy) { for (int b = 0; b < 2; b++) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) ctx->i8_slot[b][i] = sfg_ctx::I8Slot(); ctx->i8_gen++; }
+            ctx->sp_shape = -1;
+            auto &e2 = ctx->pool[name];
+            err = hipMalloc(&e2.first, bytes);
+            if (err != hipSuccess) { e2.first = nullptr; e2.second = 0; SFG_FAIL(ctx, "out of device memory: %zu bytes for scratch buffer '%s' (after returning the buffers of earlier calls)", bytes, name); }
+            e2.second = bytes; *out = e2.first;
+            return 0;
+        }
+        if (err != hipSuccess) { e.first = nullptr; SFG_FAIL(ctx, "out of device memory: %zu bytes for scratch buffer '%s' (sfg_ctx_release_scratch returns the grown pools)", bytes, name); }
         e.second = bytes;
     }
     *out = e.first;
@@ -289,7 +310,7 @@ extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     SFG_TRY(sfg_sync_all(ctx));
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
-    ctx->pool.clear();
+    ctx->pool.clear(); ctx->pool_epoch.clear();
     for (int b = 0; b < 2; b++) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) ctx->i8_slot[b][i] = sfg_ctx::I8Slot();      // the kept transposed rot copies lived in the pool
     ctx->i8_gen++; ctx->sp_shape = -1;
     return 0;

@@ -604,11 +604,13 @@ static void giant_table(const Shape &sh, std::vector<uint8_t> &giant_t) {
 
 extern "C" int sfg_matmul_accumulate_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
                                          int b0, int b1, int j0, int j1, int accumulate, uint64_t *acc) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     Shape sh = make_shape(g, flags);
     return matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, j0, j1, accumulate, (u64 *)acc);
 }
 extern "C" int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc, int s, int max_level, int ncolb, int g0, int g1, int accumulate, uint64_t *out) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     return matmul_finalize(ctx, (const u64 *)acc, s, max_level, ncolb, ncolb, 0, g0, g1, nullptr, accumulate, (u64 *)out);
 }
@@ -617,6 +619,7 @@ extern "C" int sfg_matmul_finalize_dev(sfg_ctx *ctx, const uint64_t *acc, int s,
 // giant_base + g (what a reduce-scatter over giant steps leaves on each rank); slots whose giant step is >= 91 are ignored
 extern "C" int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc, int s, int max_level, int ncolb, int acc_giants, int giant_base,
                                              int g0, int g1, int accumulate, uint64_t *out) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (acc_giants < 1) SFG_FAIL(ctx, "finalize: acc_giants must be positive");
     return matmul_finalize(ctx, (const u64 *)acc, s, max_level, ncolb, ncolb, 0, g0, g1, nullptr, accumulate, (u64 *)out, acc_giants, giant_base);
@@ -700,6 +703,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
 }
 extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
                                              int blk0, int blk1, uint64_t *out) {
+    ApiScope api_scope(ctx);
     return matmul_resident_range(ctx, A, s, in_level, max_level, g, flags, blk0, blk1, out, nullptr);
 }
 
@@ -724,6 +728,7 @@ extern "C" int sfg_rotcache_layout(sfg_ctx *ctx, int s, int max_level, size_t *j
     return 0;
 }
 extern "C" int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int job0, int job1, double *staged) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     const int N = SFG_N, d = SFG_D, L = max_level;
     size_t rowf = 0; SFG_TRY(rotcache_rowf(ctx, L, rowf));
@@ -754,6 +759,7 @@ extern "C" int sfg_rotcache_build_jobs_dev(sfg_ctx *ctx, const uint64_t *A, int 
     return 0;
 }
 extern "C" int sfg_rotcache_scatter_dev(sfg_ctx *ctx, const double *staged, int s, int max_level, int job0, int job1, int row0, int nrows, double *cache) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->i8_gen++;
     const int d = SFG_D;
@@ -789,6 +795,7 @@ int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int
     return 0;
 }
 extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int b0, int b1, double *cache) {
+    ApiScope api_scope(ctx);
     return rotcache_build_rows_tab(ctx, (const u64 *)A, s, in_level, max_level, nbr, b0, b1, nullptr, cache);
 }
 // GetDiagBool (matmult.go:627-631) for other translation units
@@ -796,11 +803,13 @@ int sfg_diag_bool(int r, int c, int dim, int index) { return diag_bool(r, c, dim
 // the products on a prebuilt cache that covers exactly the operand block rows the call contracts over ([0, nbr) for X, [blk0, blk1) / [b0, b1) for X^T)
 extern "C" int sfg_matmul_resident_range_rc_dev(sfg_ctx *ctx, const double *cache, int s, int max_level, const sfg_geno *g, unsigned flags,
                                                 int blk0, int blk1, uint64_t *out) {
+    ApiScope api_scope(ctx);
     if (!cache) SFG_FAIL(ctx, "matmul: null rotation cache");
     return matmul_resident_range(ctx, nullptr, s, max_level, max_level, g, flags, blk0, blk1, out, cache);
 }
 extern "C" int sfg_matmul_accumulate_rc_dev(sfg_ctx *ctx, const double *cache, int s, int max_level, const sfg_geno *g, unsigned flags,
                                             int b0, int b1, int j0, int j1, int accumulate, uint64_t *acc) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (!cache) SFG_FAIL(ctx, "matmul: null rotation cache");
     if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
@@ -809,6 +818,7 @@ extern "C" int sfg_matmul_accumulate_rc_dev(sfg_ctx *ctx, const double *cache, i
 }
 
 extern "C" int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, uint64_t *out) {
+    ApiScope api_scope(ctx);
     const size_t nb = (g->ncol + SFG_SLOTS - 1) / SFG_SLOTS;    // SNP blocks = block columns of the stored matrix
     return sfg_matmul_resident_range_dev(ctx, A, s, in_level, max_level, g, flags, 0, (int)nb, out);
 }
@@ -817,6 +827,7 @@ extern "C" int sfg_matmul_resident_dev(sfg_ctx *ctx, const uint64_t *A, int s, i
 extern "C" int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level, int max_level,
                                  const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, unsigned flags,
                                  uint64_t *out_host, double *sum_host, double *sqsum_host) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     sfg_geno *g = nullptr;
     SFG_TRY(sfg_geno_upload(ctx, geno_host, nrow, ncol, ld, &g));
@@ -883,6 +894,7 @@ __global__ void __launch_bounds__(256) k_cache_payload(const u64 *pt, u64 *out, 
     out[x] = __builtin_bswap64(d_mulmod_u64(pt[x], r64[l], modc[l].qi));
 }
 extern "C" int sfg_diagcache_write(sfg_ctx *ctx, const sfg_geno *g, unsigned flags, int max_level, const char *prefix, int *files_written) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (files_written) *files_written = 0;
     if (!g || !prefix) SFG_FAIL(ctx, "sfg_diagcache_write: null argument");
@@ -987,6 +999,7 @@ extern "C" int sfg_diagcache_header(sfg_ctx *ctx, const char *prefix, int block_
 }
 
 extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const char *prefix, int nbr, uint64_t *out) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->phases.clear();
     if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul_from_cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");

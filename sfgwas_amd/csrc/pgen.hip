@@ -341,6 +341,7 @@ extern "C" int sfg_pgen_geno_counts(sfg_ctx *ctx, const uint8_t *pgen_host, size
 extern "C" int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pgen_bytes, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
                               const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                               uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (!batch_snps) SFG_FAIL(ctx, "assoc_pgen: bad batch size");
     if (flags & SFG_TRANSPOSE) SFG_FAIL(ctx, "assoc_pgen: batches are multiplied as X (samples x SNPs)");

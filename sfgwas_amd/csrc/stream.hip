@@ -242,6 +242,7 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
 extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
                                     size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                                     uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    ApiScope api_scope(ctx);
     return assoc_stream_common(ctx, FMT_BED, bed_path, num_sample, num_snp, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
                                sum_host, sqsum_host);
 }
@@ -250,6 +251,7 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
 extern "C" int sfg_assoc_stream_pgen(sfg_ctx *ctx, const char *pgen_path, const uint8_t *row_filter, const uint8_t *col_filter,
                                      size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                                      uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    ApiScope api_scope(ctx);
     return assoc_stream_common(ctx, FMT_PGEN, pgen_path, 0, 0, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
                                sum_host, sqsum_host);
 }
