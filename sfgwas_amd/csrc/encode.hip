@@ -544,15 +544,15 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         PhaseTimer tn(ctx, "ntt_plain", sampled);
         if (half_rows && G > 0) { PhaseStat &all = ctx->phases["ntt_plain_all"]; all.launches += 1; }
         if (sp) {
-            // a staging buffer is free once the batch before the previous one has been transposed (that ran beside the previous batch's FFT and NTT)
-            if (sp->pending[sp->buf]) SFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, sp->ev_pack[sp->buf], 0));
+            // the staging buffer is free once the previous batch has been transposed (that ran beside this batch's FFT)
+            if (sp->pending) SFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, sp->ev_pack, 0));
             PanelMap pm{0, 0, shift0 + s0, packed_mask};
-            SFG_TRY(launch_ntt_plain_half(ctx, cmode == 3 ? pcache->slot : pc, sp->stage + (size_t)sp->buf * SFG_STAGE_BATCH * L * (SFG_N / 2), nb, L, pm, cmode == 3 ? pcache->perm : nullptr));
+            SFG_TRY(launch_ntt_plain_half(ctx, cmode == 3 ? pcache->slot : pc, sp->stage, nb, L, pm, cmode == 3 ? pcache->perm : nullptr));
             SFG_HIP(ctx, hipEventRecord(sp->ev_ntt, ctx->stream));
             SFG_HIP(ctx, hipStreamWaitEvent(sp->q, sp->ev_ntt, 0));
             SFG_TRY(launch_i8_pack_stage(ctx, *sp, shift0 + s0, nb, L));
-            SFG_HIP(ctx, hipEventRecord(sp->ev_pack[sp->buf], sp->q));
-            sp->pending[sp->buf] = true; sp->buf ^= 1;
+            SFG_HIP(ctx, hipEventRecord(sp->ev_pack, sp->q));
+            sp->pending = true;
         }
         else if (cmode == 3) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm)); }
         else if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }

@@ -41,12 +41,11 @@ struct PcCache { double *slot = nullptr; int mode = 0; const uint32_t *perm = nu
 // the Infinity Cache and never reaches HBM) and k_i8_pack_stage moves the batch into the int8 MAC's k-contiguous tiles on a second queue, beside the (fp64-issue
 // bound) FFT of the next batch.  The 21 - 43 GB plaintext panel and its read + write pass per MAC launch disappear.
 struct StagePack {
-    u64 *stage = nullptr;                  // two buffers of [batch][L][N/2 words]: batch b is transposed beside the FFT and NTT of batch b + 1
-    int buf = 0;                           // the buffer the current batch uses
+    u64 *stage = nullptr;                  // [batch][L][N/2 words]
     int8_t *Bs = nullptr, *Bb = nullptr;   // tiles of the small moduli [m][c][jt][ch][5][1 KiB] / of the 46-bit modulus [c][jt][ch][6][1 KiB]
     int g = 0, kb = 92, njt = 6, nch = 0;  // block row inside the MAC group: k' = g * kb + baby
     int l_big = -1, l_small0 = 0, n_small = 0;
-    hipStream_t q = nullptr; hipEvent_t ev_ntt = nullptr, ev_pack[2] = {nullptr, nullptr}; bool pending[2] = {false, false};
+    hipStream_t q = nullptr; hipEvent_t ev_ntt = nullptr, ev_pack = nullptr; bool pending = false;
     unsigned seq = 0;
 };
 constexpr int SFG_STAGE_BATCH = 11 * SFG_D;       // whole giant steps per batch: 1001 plaintexts (5005 NTT workgroups)

@@ -9,10 +9,6 @@
 // owns all coefficients of one k).  Hence transposition kernels into MFMA register order (1 KiB = 64 lanes x 16 bytes per operand tile, chunk of 64 k and digit):
 //   k_i8_pack_rot<ND>        rotf planes         -> A [m][x < N][ch][rt 2][a ND][1 KiB]    once per rot operand generation (a group's rotation cache serves every column)
 //   k_i8_pack_pt_digits<ND>  NTT digit planes    -> B [m][c < N/2][jt][ch][b ND][1 KiB]    once per launch (k_i8_pack_pt<ND>: the same from panel words, DiagCache products)
-//   k_i8_pack_stage<ND>      one encode batch    -> B, batch by batch beside the encode (the default since round 4: StagePack, kernels.hpp)
-// A plaintext tile is stored COLUMN-major - byte (column i, kk) at i * 64 + kk, a column's 64 k contiguous - so that a producer that owns some columns of a tile (an
-// encode batch holds 11 giant steps = columns) writes whole 64-byte runs; a wave reads the tile in register order through per-lane addresses (lane i + 16 (kk / 16)
-// takes the 16 bytes at i * 64 + 16 (kk / 16): the same 1 KiB per load instruction).  Rot tiles are stored in register order.
 // and the MAC proper (k_mac_i8<ND>) streams both from global memory without LDS: a wave owns one coefficient pair (c, N-1-c share the plaintext word: the pt tile is
 // loaded once for 64 rows) x 16 columns = 4 row tiles x (2 ND - 1) weights of accumulator tiles; the <= 6 column waves of a pair form a workgroup and share the rot
 // tiles through the cache (k_mac_i8_lds stages them through LDS instead: measured slower).  Results leave in tile order (T [m][c][half][jt][rt][lane][4]) and
@@ -115,7 +111,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
         const int c2 = pc / ND, d = pc % ND;
         const unsigned *sp = reinterpret_cast<const unsigned *>(img + c2 * PSTR + d * 256 + l16 * 16);
         const uint4 w = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + l16 * 64 + g * 16) = w;
+        *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + c2) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g * 256 + l16 * 16) = w;
     }
 }
 // ---- the same from digit planes (the plaintext NTT's output when the int8 MAC is on: five planes of N/2 bytes in a row's 64 KiB).  workgroup = (modulus m,
@@ -153,58 +149,56 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
             const int q2 = pc >> 2;
             const unsigned *sp = img + pc * 64 + ((l16 ^ (q2 & 7)) << 2);
             const uint4 w = make_uint4(sp[0 ^ (q2 >> 3)], sp[1 ^ (q2 >> 3)], sp[2 ^ (q2 >> 3)], sp[3 ^ (q2 >> 3)]);
-            *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + l16 * 64 + g * 16) = w;
+            *reinterpret_cast<uint4 *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g * 256 + l16 * 16) = w;
         }
         __syncthreads();
     }
 }
 // ---- the same from the DENSE digit planes of one encode batch (StagePack, kernels.hpp): plaintext p of the batch is shift shift0 + p = giant n, baby b of block
-// row g; its byte goes to column n, k' = g * kb + b.  A workgroup = (modulus, chunk of 64 k', four columns, 128 coefficients), restricted to what this batch owns:
-// columns [n_lo, n_hi) x the dwords of block row g (kb is a multiple of 4, so a column's 64-byte run splits between block rows on dword boundaries).  Owned
-// positions without a plaintext - the pad baby 91, shifts past 8191 - are written as zeros; what no batch owns (columns 91..95, k' past the last block row) is zeroed
-// when the tile buffer is (re)shaped.  Reads come from the staging buffer the NTT has just written, writes are 64-byte column runs, 256 bytes per four columns.
-struct I8StageArgs { const u64 *stage; int8_t *B; int L, l0, nl, shift0, nshift, n_lo, n_hi, g, kb, njt, nch, nq0, nnq, ch0, nchb; };
+// row g; its byte goes to column n, k' = g * kb + b.  A workgroup = (modulus, column tile jt, 16 k', 128 coefficients) as above, restricted to what this batch
+// owns: columns [n_lo, n_hi) x the dwords of block row g (kb is a multiple of 4, so a 16-byte run splits between block rows on dword boundaries).  Owned positions
+// without a plaintext - the pad baby 91, shifts past 8191 - are written as zeros; what no batch owns (columns 91..95, k' past the last block row) is zeroed when the
+// tile buffer is (re)shaped.  Reads come from the staging buffer the NTT has just written (Infinity Cache), writes are 16-byte pieces of 1 KiB tiles.
+struct I8StageArgs { const u64 *stage; int8_t *B; int L, l0, nl, shift0, nshift, n_lo, n_hi, g, kb, njt, nch, jt0, njt_b, kq0, nkq; };
 template <int ND>
 __global__ void __launch_bounds__(256) k_i8_pack_stage(I8StageArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];                   // [cc 128][nl 4][k4 16] dwords, (nl, k4) XORed with bits of the coefficient group
+    __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
     const int H = SFG_N / 2, tid = threadIdx.x;
     int b = blockIdx.x;
     const int cb = b % (H / I8_PD); b /= H / I8_PD;
-    const int nq = a.nq0 + b % a.nnq; b /= a.nnq;                       // column quad: columns 4 nq .. 4 nq + 3
-    const int ch = a.ch0 + b % a.nchb, m = b / a.nchb;
+    const int kq = a.kq0 + b % a.nkq; b /= a.nkq;
+    const int jt = a.jt0 + b % a.njt_b, m = b / a.njt_b;
     const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
+    const int ch = kq >> 2, g16 = kq & 3, l16 = tid & 15;
     const unsigned char *src = reinterpret_cast<const unsigned char *>(a.stage) + (size_t)(a.l0 + m) * H * 8 + c0 + cq * 4;
     const size_t pstride = (size_t)a.L * H * 8;                       // bytes per plaintext of the staging buffer
-    // store side: thread (pc = tid >> 4 (+ 16 per round), column nl_s = (tid & 15) >> 2, 16-byte piece q16 = tid & 3 of the column's 64 bytes)
-    const int nl_s = (tid & 15) >> 2, q16 = tid & 3, n_st = nq * 4 + nl_s;
-    const bool col_owned = n_st >= a.n_lo && n_st < a.n_hi;
+    // ownership of this workgroup's stores: lane l16 = column n, dword k4 of a 16-byte piece = k' in [kq*16 + 4 k4, + 4)
+    const int n_st = jt * 16 + l16; const bool lane_owned = n_st >= a.n_lo && n_st < a.n_hi;
     unsigned own = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) { const int k0 = ch * 64 + q16 * 16 + e * 4; if (k0 >= a.g * a.kb && k0 < (a.g + 1) * a.kb) own |= 1u << e; }
-    const int jt = n_st >> 4, i_st = n_st & 15;
+    for (int k4 = 0; k4 < 4; k4++) { const int k0 = kq * 16 + k4 * 4; if (k0 >= a.g * a.kb && k0 < (a.g + 1) * a.kb) own |= 1u << k4; }
     for (int d = 0; d < ND; d++) {
 #pragma unroll 2
         for (int it = 0; it < 8; it++) {
-            const int item = it * 8 + slot, nl = item >> 4, k4 = item & 15, n = nq * 4 + nl;
+            const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
             unsigned w[4];
 #pragma unroll
             for (int x = 0; x < 4; x++) {
-                const int k = ch * 64 + k4 * 4 + x, baby = k - a.g * a.kb, p = n * SFG_D + baby - a.shift0;
+                const int k = kq * 16 + k4 * 4 + x, baby = k - a.g * a.kb, p = n * SFG_D + baby - a.shift0;
                 const bool ok = baby >= 0 && baby < SFG_D && n >= a.n_lo && n < a.n_hi && p >= 0 && p < a.nshift;
                 w[x] = ok ? *reinterpret_cast<const unsigned *>(src + (size_t)p * pstride + (size_t)d * H) : 0u;
             }
             unsigned o[4]; bytes_tr4(w[0], w[1], w[2], w[3], o);
 #pragma unroll
-            for (int e = 0; e < 4; e++) img[(cq * 4 + e) * 64 + ((item ^ (cq << 1)) & 63)] = o[e];          // lanes = coefficient groups: 2 cq mod 64 spreads them over the banks (x 4 dwords of e)
+            for (int e = 0; e < 4; e++) img[(cq * 4 + e) * 64 + ((j ^ (cq & 7)) << 2) + (k4 ^ (cq >> 3))] = o[e];
         }
         __syncthreads();
-        if (col_owned && own)
+        if (lane_owned && own)
             for (int pc = tid >> 4; pc < I8_PD; pc += 16) {
-                const int q2 = pc >> 2;                                     // the coefficient group that wrote row pc
-                const unsigned *row = img + pc * 64;
-                const int it0 = nl_s * 16 + q16 * 4;
-                const uint4 w = make_uint4(row[((it0 + 0) ^ (q2 << 1)) & 63], row[((it0 + 1) ^ (q2 << 1)) & 63], row[((it0 + 2) ^ (q2 << 1)) & 63], row[((it0 + 3) ^ (q2 << 1)) & 63]);
-                unsigned *dst = reinterpret_cast<unsigned *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + i_st * 64 + q16 * 16);
+                const int q2 = pc >> 2;
+                const unsigned *sp = img + pc * 64 + ((l16 ^ (q2 & 7)) << 2);
+                const uint4 w = make_uint4(sp[0 ^ (q2 >> 3)], sp[1 ^ (q2 >> 3)], sp[2 ^ (q2 >> 3)], sp[3 ^ (q2 >> 3)]);
+                unsigned *dst = reinterpret_cast<unsigned *>(a.B + ((((((size_t)m * H + c0 + pc) * a.njt + jt) * a.nch + ch) * ND + d) * 1024) + g16 * 256 + l16 * 16);
                 if (own == 15u) *reinterpret_cast<uint4 *>(dst) = w;
                 else { if (own & 1u) dst[0] = w.x; if (own & 2u) dst[1] = w.y; if (own & 4u) dst[2] = w.z; if (own & 8u) dst[3] = w.w; }
             }
@@ -227,7 +221,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int s = 0; s < 2 * ND - 1; s++) acc[t][s] = (v4i){0, 0, 0, 0};
-    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * ND * 64 + ((lane & 15) * 4 + (lane >> 4));      // column-major tile
+    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * ND * 64 + lane;
     const uint4 *A0 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + c) * a.nch) * 2 * ND * 64 + lane;
     const uint4 *A1 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + (N - 1 - c)) * a.nch) * 2 * ND * 64 + lane;
 #pragma unroll 1
@@ -277,7 +271,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_lds(I8Args a, const ModConst 
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int s = 0; s < 9; s++) acc[t][s] = (v4i){0, 0, 0, 0};
-    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * I8_ND * 64 + ((lane & 15) * 4 + (lane >> 4));
+    const uint4 *Bp = reinterpret_cast<const uint4 *>(a.B) + ((((size_t)m * H + c) * a.njt + jt) * a.nch) * I8_ND * 64 + lane;
     const uint4 *A0 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + c) * a.nch) * 2 * I8_ND * 64;
     const uint4 *A1 = reinterpret_cast<const uint4 *>(a.A) + (((size_t)m * N + (N - 1 - c)) * a.nch) * 2 * I8_ND * 64;
     constexpr int HALF = 2 * I8_ND * 64;               // uint4 per coefficient and chunk (10 KiB)
@@ -351,7 +345,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_ring(I8Args a, const ModConst
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int s = 0; s < 2 * ND - 1; s++) acc[t][s] = (v4i){0, 0, 0, 0};
-    const unsigned char *gB = reinterpret_cast<const unsigned char *>(a.B) + ((((size_t)m * H + c) * 6 + jt) * nch) * ND * 1024 + ((lane & 15) * 4 + (lane >> 4)) * 16;      // column-major tile -> register order
+    const unsigned char *gB = reinterpret_cast<const unsigned char *>(a.B) + ((((size_t)m * H + c) * 6 + jt) * nch) * ND * 1024 + lane * 16;
     const unsigned char *gA0 = reinterpret_cast<const unsigned char *>(a.A) + (((size_t)m * N + c) * nch) * 2 * ND * 1024 + lane * 16;
     const unsigned char *gA1 = reinterpret_cast<const unsigned char *>(a.A) + (((size_t)m * N + (N - 1 - c)) * nch) * 2 * ND * 1024 + lane * 16;
     // the rot tiles of a chunk, tile j = (half, rt, digit) = t * ND + x for the MFMA loop below: wave jt fetches j = jt, jt + 6, ... (the last round wraps around
@@ -460,22 +454,22 @@ int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, 
     const int H = SFG_N / 2, d = SFG_D;
     if (shift_lo % d) SFG_FAIL(ctx, "i8 stage pack: internal: a batch starts inside a giant step");
     I8StageArgs a;
-    a.stage = sp.stage + (size_t)sp.buf * SFG_STAGE_BATCH * L * H; a.L = L; a.shift0 = shift_lo; a.nshift = nshift; a.g = sp.g; a.kb = sp.kb; a.njt = sp.njt; a.nch = sp.nch;
+    a.stage = sp.stage; a.L = L; a.shift0 = shift_lo; a.nshift = nshift; a.g = sp.g; a.kb = sp.kb; a.njt = sp.njt; a.nch = sp.nch;
     a.n_lo = shift_lo / d; a.n_hi = (shift_lo + nshift + d - 1) / d;
     if (shift_lo + nshift >= SFG_SLOTS) a.n_hi = d;                  // the last batch owns all of giant 90 (its shifts past 8191 are zero plaintexts)
-    a.nq0 = a.n_lo / 4; a.nnq = (a.n_hi - 1) / 4 - a.nq0 + 1;
-    a.ch0 = (sp.g * sp.kb) / 64; a.nchb = ((sp.g + 1) * sp.kb - 1) / 64 - a.ch0 + 1;
+    a.jt0 = a.n_lo / 16; a.njt_b = (a.n_hi - 1) / 16 - a.jt0 + 1;
+    a.kq0 = (sp.g * sp.kb) / 16; a.nkq = ((sp.g + 1) * sp.kb - 1) / 16 - a.kq0 + 1;
     hipStream_t saved = ctx->stream; ctx->stream = sp.q;
     const bool sampled = (sp.seq++ & 7) == 0;
     {
         PhaseTimer t(ctx, "mac_i8_pack_pt", sampled);
         if (sp.n_small) {
             a.B = sp.Bs; a.l0 = sp.l_small0; a.nl = sp.n_small;
-            hipLaunchKernelGGL(k_i8_pack_stage<5>, dim3((unsigned)((size_t)a.nl * a.nchb * a.nnq * (H / I8_PD))), dim3(256), 0, sp.q, a);
+            hipLaunchKernelGGL(k_i8_pack_stage<5>, dim3((unsigned)((size_t)a.nl * a.njt_b * a.nkq * (H / I8_PD))), dim3(256), 0, sp.q, a);
         }
         if (sp.l_big >= 0) {
             a.B = sp.Bb; a.l0 = sp.l_big; a.nl = 1;
-            hipLaunchKernelGGL(k_i8_pack_stage<6>, dim3((unsigned)((size_t)a.nchb * a.nnq * (H / I8_PD))), dim3(256), 0, sp.q, a);
+            hipLaunchKernelGGL(k_i8_pack_stage<6>, dim3((unsigned)((size_t)a.njt_b * a.nkq * (H / I8_PD))), dim3(256), 0, sp.q, a);
         }
         if (sampled) t.stop(8, 8.0 * nshift * H * (5.0 * sp.n_small + (sp.l_big >= 0 ? 6.0 : 0.0)) * 2.0);       // (one launch pair in eight is timed: counted for eight)
     }

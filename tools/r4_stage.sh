@@ -1,6 +1,6 @@
 # round 4: streamed transposition (StagePack) - parity, then same-box A/B at c4 against the panel + transposition pass
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04stage
-timeout -k 10 900 python -m pytest tests/test_gpu_matmul.py tests/test_gpu_properties.py tests/test_gpu_mac.py -x -q -m gpu > gpurun_out/r04stage/tests.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_gpu_matmul.py tests/test_gpu_properties.py tests/test_gpu_ptcache.py tests/test_gpu_fullsize.py -x -q -m gpu -k "not c4_100000" > gpurun_out/r04stage/tests.log 2>&1; rc=$?
 tail -5 gpurun_out/r04stage/tests.log
 [ $rc = 0 ] || exit $rc
 for v in 1 0; do
