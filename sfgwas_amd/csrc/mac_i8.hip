@@ -527,7 +527,7 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (repack) { slots[slot].src = (const void *)rotf; memcpy(slots[slot].sig, sig, sizeof sig); }
     slots[slot].last_use = ++ctx->i8_clock;
     if (B_pre) a.B = const_cast<int8_t *>(B_pre);
-    else SFG_TRY(sfg_scratch(ctx, BIG ? "mi8.Bb" : "mi8.Bs", nB, (void **)&a.B));        // (the buffers of the streamed tiles: a launch uses them one way or the other)
+    else SFG_TRY(sfg_scratch(ctx, !ctx->cfg.stage_pack ? "mi8.B" : BIG ? "mi8.Bb" : "mi8.Bs", nB, (void **)&a.B));        // (with the streamed transposition on: the buffers of the streamed tiles, a launch uses them one way or the other)
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
     // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers)
     if (!repack && ctx->pool[nm].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
