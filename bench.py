@@ -490,7 +490,7 @@ def main():
     res = {
         "metric": "pca_power_iter_ring_macs_per_s", "value": value, "unit": "ring-MAC/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 ring words, exact integers: int8 digits on the matrix core for the 35-bit moduli, fp64 limbs elsewhere",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 ring words, exact integers: int8 digits on the matrix core for the MAC of all five moduli, fp64-held integers in the encode and key-switch kernels",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: one PCA power iteration local work = Q*X + Q'*X^T, {n_ind} x {m_snp} int8 genotypes, "
                                f"kp={KP}, PN14QP438-shaped ring (N=16384, L=5 of 6 moduli), on-the-fly diagonal encode",
@@ -553,11 +553,21 @@ def main():
                                "frac": (by_ntt / max(ms_ntt, 1e-9)) / 1e6 / HBM_PEAK_GBS}}
             mac_gbps = by_small / (ms_small * 1e-3) / 1e9
             padded_macs_s = 2 * nbr_x * mct_x * D * D * 2 * KP * (L - 1) * N * args.steps / world / (ms_small * 1e-3)
-            mac_blk = {"bound": "hbm", "achieved": mac_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mac_gbps / HBM_PEAK_GBS, "kernel": "k_mac_i8",
+            refetch, refetch_src = None, None
+            try:        # exact fabric-side read bytes of this kernel (TCC_EA0_RDREQ_{32B,64B,128B}) against its operand tiles: profiles/r04_pmc_mac_i8.json
+                pm4 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mac_i8.json")))
+                refetch = pm4["default"]["k_mac_i8"]["read_bytes_per_launch"] / pm4["_algorithmic_read_bytes_K1183"]["total"]
+                refetch_src = "profiles/r04_pmc_mac_i8.json (static: counter passes at c2, K = 1183; the cache-shared kernel the ring kernel replaced fetched the same tiles)"
+            except Exception:
+                pass
+            mac_blk = {"bound": "hbm", "achieved": mac_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mac_gbps / HBM_PEAK_GBS, "kernel": "k_mac_i8_ring<5, 3>",
+                       "frac_of_achievable_6300": mac_gbps / 6300.0, "read_bytes_over_operand_bytes": refetch, "read_bytes_source": refetch_src,
                        "avg_launch_ms": ms_small / n_small, "launches": n_small, "total_ms_in_timed_region": ms_small, "alg_bytes_per_launch": by_small / n_small,
                        "padded_ring_macs_per_s_in_kernel": padded_macs_s, "int8_macs_per_s_in_kernel": 25.0 * padded_macs_s * (32 * 96) / (30 * 91),
                        "what": "ring MAC of the four 35-bit moduli on v_mfma_i32_16x16x64_i8: operands as five signed base-256 digits, 25 digit products per ring-MAC into nine "
-                               "int32 sums, Horner mod q in the epilogue (exact); bytes = both k-contiguous digit streams read once + tile-ordered results written",
+                               "int32 sums, Horner mod q in the epilogue (exact); both k-contiguous digit streams prefetched global -> LDS by the DMA engine two chunks ahead "
+                               "(three 50 KiB slots), read once; bytes = the two streams + tile-ordered results written.  The 46-bit modulus runs the same kernel with six digits "
+                               "(k_mac_i8_ring<6, 2>, phase mac_big)",
                        "helpers_ms_per_step": {k: phase_tot[k][0] / args.steps for k in ("mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile") if k in phase_tot}}
             dom, other = (ntt_blk, mac_blk) if ntt_total_ms >= ms_small else (mac_blk, ntt_blk)
             alg_step = 2 * n_ind * m_snp + (KP * nbr_x + KP * mct_x) * ctw * 8 + (KP * mct_x + KP * nbr_x) * outw * 8
