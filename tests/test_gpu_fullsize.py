@@ -325,7 +325,7 @@ def _ct_digest(h):
     return hashlib.sha256(b"".join(hashlib.sha256(h[i, j].tobytes()).digest() for i in range(h.shape[0]) for j in range(h.shape[1]))).hexdigest()
 
 
-def test_c4_100000x1000000_kp15_pinned_digests_and_oracle_at_the_c4_launch_shapes():
+def test_c4_100000x1000000_kp15_pinned_digests_and_oracle_at_the_c4_launch_shapes(env):
     """configs[3] (the configuration BASELINE.json's metric is quoted on) at full size, as bench.py runs it: 123 x 13 blocks, kp = 15, the default
     schedule (memory-chosen MAC groups beside 100 GB of int8 genotypes, several accumulator passes).
       (a) both products' digests equal the values pinned since round 2;
@@ -341,6 +341,7 @@ def test_c4_100000x1000000_kp15_pinned_digests_and_oracle_at_the_c4_launch_shape
     n_ind, m_snp, kp = 100_000, 1_000_000, 15
     nbr_x, mct_x = 13, 123
     lib = capi.lib()
+    env.ctx.check(lib.sfg_ctx_release_scratch(env.ctx.h), "release_scratch")      # the module's context keeps the pools of the c2 / c5 tests: this test needs the whole device
     ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
     ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
     keys = ol.RotKeys(ring)
