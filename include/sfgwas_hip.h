@@ -108,7 +108,12 @@ int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, int nvec, in
  * 10^15) is NOT tolerated: every synchronising entry point fails until the counters are reset, and the affected products must be re-derived with a
  * big-float encoder on the host. */
 int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset);
-/* the coefficients within 2^-50 of a tie seen since the last reset (the condition that makes the synchronising entry points fail) */
+/* Round 4: a genotype-diagonal coefficient inside the 2^-50 band is RE-DERIVED on the device before it can fail anything: p_j = (Delta/n) sum_t v_t cos(2 pi 5^t j / 2N)
+ * is summed exactly - small integers times 100-bit fixed-point cosines, integer accumulation - so only the cosine table's error (< 2^-68 of a unit) is left, and a sum
+ * farther than 2^-62 from the tie proves its rounding and replaces the double-double value (sfg_ctx_encoder_resolved counts them).  What stays unproven - closer than
+ * 2^-62 (about once per 10^18 coefficients), more than eight such coefficients in one plaintext, real-valued slot rows (sfg_encode_vectors_dev) - fails as described. */
+int sfg_ctx_encoder_resolved(sfg_ctx *ctx, unsigned long long *count);
+/* the coefficients within 2^-50 of a tie seen since the last reset that could NOT be proven (the condition that makes the synchronising entry points fail) */
 int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *count);
 /* With a plaintext coefficient cache on (sfg_geno_set_plaintext_cache) a cached row was audited when it was FILLED: "count == 0" then proves the plaintexts
  * of the calls since the cache was enabled.  When the 2^-50 condition is reported (a failing synchronising call) or reset, every cache the context owns

@@ -35,6 +35,7 @@ def _sig(L):
         "sfg_rotcache_invalidate": (i, [vp]),
         "sfg_ctx_use_own_stream": (i, [vp]),
         "sfg_ctx_encoder_inject_unsafe_for_test": (i, [vp, C.c_ulonglong]),
+        "sfg_ctx_encoder_resolved": (i, [vp, C.POINTER(C.c_ulonglong)]),
         "sfg_ctx_encoder_unprovable": (i, [vp, C.POINTER(C.c_ulonglong)]),
         "sfg_ctx_load_rotkey": (i, [vp, u64, u64p, i]),
         "sfg_ctx_load_secret_key": (i, [vp, u64p, i]),

@@ -58,6 +58,7 @@ struct SfgConfig {
     size_t i8_keep_reserve = 80ULL << 30;   // SFG_I8_KEEP_RESERVE_GB  HBM that must stay free beside the transposed copies of ALL groups of a caller's rotation cache (association scan) for the int8 MAC to take that call
     bool mac_i8_big = true;        // SFG_MAC_I8_BIG=1      the 46-bit modulus on the int8 matrix core too (six digits, 36 products, eleven sums) instead of the fp64 DPP-broadcast kernel: identical words, measured slower (13.06 s against 12.49 s per power iteration: its own transposition passes cost more than the kernel saves)
     bool mac_i8_nolds = true;      // SFG_MAC_I8_ROT=lds    int8 MAC: rot tiles of a coefficient pair staged through LDS (k_mac_i8_lds) instead of shared through the cache (measured at 100k x 1M: 3.31 s against 2.56 s per step - the barriers cost more than the re-fetches)
+    double tie_band = 0x1p-50;     // distance from a rounding tie inside which the encoder's double-double value does not prove the rounding (SFG_TEST_TIE_BAND_LOG2 widens it under the test switch)
     bool test_hooks = false;       // SFG_ENABLE_TEST_HOOKS=1   sfg_ctx_encoder_inject_unsafe_for_test may be called (tests of the failure path only)
     bool mac_i8_ring = true;       // SFG_MAC_I8_ROT=cache    int8 MAC without the LDS prefetch ring (k_mac_i8: operands straight from global memory, rot tiles shared through the L1)
     bool stage_pack = false;       // SFG_MAC_I8_STAGE=1    int8 MAC: streamed transposition (StagePack, kernels.hpp) instead of the full plaintext panel and a transposition pass per MAC launch.  Built, bit-exact, and measured SLOWER at 100k x 1M (14.2 s against 12.5 s per step on one box: the small per-batch transposition launches run at 1.5 TB/s and slow the encode kernels they share the chip with)
@@ -143,7 +144,7 @@ struct sfg_ctx {
     int sp_shape = -1;                      // block rows per group the streamed tile buffers (mi8.Bs / mi8.Bb) were last cleared for
     std::set<const sfg_geno *> ptc_genos;   // matrices whose plaintext coefficient cache this context owns (dropped when an unprovable encoder rounding is reported / reset)
     bool test_hooks = false;                // SFG_ENABLE_TEST_HOOKS=1 at context creation: the failure-path test hook may be used
-    void *tie_count_dev = nullptr;          // two counters: encoder coefficients within 2^-40 of a rounding tie (audit) and within 2^-50 (sticky failure, sfg_encoder_check)
+    void *tie_count_dev = nullptr;          // counters (+ a third: coefficients inside the band whose rounding the exact re-derivation proved): encoder coefficients within 2^-40 of a rounding tie (audit) and within 2^-50 (sticky failure, sfg_encoder_check)
     hipStream_t main_stream() const { return user_stream ? user_stream : own_stream; }
     std::map<u64, RotKey> &rotkeys() { return sh->rotkeys; }
     const std::map<u64, RotKey> &rotkeys() const { return sh->rotkeys; }

@@ -35,6 +35,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_I8_STAGE")) c.stage_pack = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
     if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
+    if (const char *e = env("SFG_TEST_TIE_BAND_LOG2")) { if (c.test_hooks) c.tie_band = ldexp(1.0, atoi(e)); }       // test hook: a wider band sends ordinary coefficients through the exact re-derivation
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
     if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
@@ -70,7 +71,7 @@ static const char *ctx_exec_init(sfg_ctx *ctx) {
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_enc[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     ctx->pin_bytes = 64u << 20;
     if (hipHostMalloc((void **)&ctx->pin, ctx->pin_bytes, hipHostMallocDefault) != hipSuccess) return "hipHostMalloc failed";
-    if (hipMalloc(&ctx->tie_count_dev, 16) != hipSuccess || hipMemset(ctx->tie_count_dev, 0, 16) != hipSuccess) return "hipMalloc failed";
+    if (hipMalloc(&ctx->tie_count_dev, 32) != hipSuccess || hipMemset(ctx->tie_count_dev, 0, 32) != hipSuccess) return "hipMalloc failed";
     return nullptr;
 }
 

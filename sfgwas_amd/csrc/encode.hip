@@ -62,6 +62,8 @@ constexpr int ENC_TB_SIZE = ENC_TB_RZ2 + ENC_TB_RLEN;
 struct EncTables {                // immutable, shared by a context and its forks
     double4 *tb = nullptr;        // twiddles {re.hi, re.lo, im.hi, im.lo} of zeta^-k = exp(-2 pi i k / 32768), laid out in the order the kernel's lanes read them (ENC_TB_*)
     uint16_t *tinv = nullptr;     // [n] slot index t with (5^t - 1)/4 mod n == m
+    double2 *costab = nullptr;    // [8193] cos(2 pi k / 32768) as {hi, lo}: the exact re-derivation of a coefficient next to a rounding tie (k_fft_encode)
+    int sexp = -1;                // log2(Delta / n) when that is a power of two (every preset), else -1: no re-derivation
 };
 // per-context scratch (sfg_scratch pool): "enc.skew" diag-major copy of one block [n][n] int8;
 // "enc.pc" half-coefficient rows [batch][n]: the rounded integers, held as doubles (|p| < 2^53)
@@ -123,6 +125,14 @@ int sfg_encoder_init(sfg_ctx *ctx) {
     std::vector<uint16_t> tinv(n);
     u64 g = 1;
     for (int t = 0; t < n; t++) { tinv[((g - 1) / 4) % n] = (uint16_t)t; g = (g * 5) % M; }
+    {   // quarter-wave cosine table for the near-tie re-derivation: cos(2 pi k / 32768) = Re zeta^-k
+        std::vector<double2> ct(ENC_TW / 2 + 1);
+        for (int k = 0; k <= ENC_TW / 2; k++) ct[k] = make_double2(z[k].re.hi, z[k].re.lo);
+        SFG_HIP(ctx, hipMalloc(&et->costab, ct.size() * sizeof(double2)));
+        SFG_HIP(ctx, hipMemcpy(et->costab, ct.data(), ct.size() * sizeof(double2), hipMemcpyHostToDevice));
+        int e = 0; const double son = std::frexp(ctx->sh->scale / (double)n, &e);
+        et->sexp = (son == 0.5 && e - 1 >= 0 && e - 1 <= 40) ? e - 1 : -1;
+    }
     SFG_HIP(ctx, hipMalloc(&et->tb, tb.size() * sizeof(double4)));
     SFG_HIP(ctx, hipMalloc(&et->tinv, n * sizeof(uint16_t)));
     SFG_HIP(ctx, hipMemcpy(et->tb, tb.data(), tb.size() * sizeof(double4), hipMemcpyHostToDevice));
@@ -132,7 +142,7 @@ int sfg_encoder_init(sfg_ctx *ctx) {
 void sfg_encoder_destroy(SfgShared *sh) {
     EncTables *et = (EncTables *)sh->enc_tables;
     if (!et) return;
-    (void)hipFree(et->tb); (void)hipFree(et->tinv);
+    (void)hipFree(et->tb); (void)hipFree(et->tinv); (void)hipFree(et->costab);
     delete et; sh->enc_tables = nullptr;
 }
 
@@ -362,11 +372,12 @@ __device__ __forceinline__ void dif_radix8(dd (&xr)[8], dd (&xi)[8], const doubl
 // coefficients): while it is non-zero every synchronising entry point FAILS (sfg_encoder_check) - the contract is bit-exactness, and such a
 // coefficient has to be re-derived by a big-float encoder on the host before the product may be used.
 template <bool EXACT_TIES>
-__device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie) {                // integer-valued double
+__device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie, double band, bool &inside) {                // integer-valued double
     double nn = __builtin_rint(x.hi);
     double diff = (x.hi - nn) + x.lo;                                                         // |diff| <= 1/2 + |x.lo|
     const double tie_dist = __builtin_fabs(__builtin_fabs(diff) - 0.5);
-    near_tie += (tie_dist < 0x1p-40 ? 1u : 0u) + (tie_dist < 0x1p-50 ? 0x10000u : 0u);      // low half: audit band; high half: band inside which the call FAILS
+    inside = tie_dist < band;                                                                 // band (2^-50): the double-double value does not prove the rounding - re-derived exactly below, or the call FAILS
+    near_tie += (tie_dist < 0x1p-40 ? 1u : 0u);                                               // audit band
     if (!EXACT_TIES) return nn + __builtin_rint(diff);      // = the rule below whenever |diff| != 1/2; an exact tie (impossible for integer slot values at Delta/n = 2^k) is counted above
     const bool up = (diff > 0.5) | ((diff == 0.5) & (nn >= 0)), dn = (diff < -0.5) | ((diff == -0.5) & (nn <= 0));      // (no short-circuit: selects, not branches)
     return nn + (up ? 1.0 : 0.0) - (dn ? 1.0 : 0.0);
@@ -380,8 +391,12 @@ constexpr size_t ENC_LDS_BYTES = (size_t)2 * ENC_H * 8;        // 65,536 B: two 
 // at most 8 high + 8 low complex parts across a round.  16 waves per CU.
 template <bool F64IN>
 __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *tb, const uint16_t *tinv,
-                                                      double *pc_out, unsigned long long *tie_count) {
+                                                      double *pc_out, unsigned long long *tie_count, const double2 *costab, int sexp, double band) {
     unsigned near_tie = 0;
+    constexpr int TIE_MAX = 8;                                      // coefficients of one plaintext that can be re-derived (the band holds ~10^-15 of them)
+    __shared__ int tie_n, tie_j[TIE_MAX];
+    __shared__ unsigned long long tie_sum[TIE_MAX][3];
+    if (threadIdx.x == 0) tie_n = 0;
     extern __shared__ double lds[];
     double *RE = lds, *IM = lds + ENC_H;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
@@ -463,6 +478,9 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         const int c = tid + 512 * i, pa = padj_fin(c), pb = padj_fin((h - c) & (h - 1));
         Ar[i].lo = RE[pa]; Ai[i].lo = IM[pa]; Br[i].lo = RE[pb]; Bi[i].lo = -IM[pb];
     }
+    // a coefficient inside the band: listed for the exact re-derivation below (the list is a few words of static LDS; the images are not touched)
+    unsigned unproven = 0;
+    auto note = [&](int j) { const int k = atomicAdd(&tie_n, 1); if (k < TIE_MAX) tie_j[k] = j; else unproven++; };
     // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c / 2 = zeta^-4c / 2, zc = (Delta/n) zeta^-c, zh = (Delta/n) zeta^-(h-c)
     auto recomb = [&](int c, dd Ar, dd Ai, dd Br, dd Bi) {
         // (genotype rows: A and B are sums on the fixed grid, so the recombination adds are exact two-flop grid adds as well)
@@ -484,8 +502,11 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             dd Wr = radd(Xr, Yr), Wi = radd(Xi, Yi);
             dd zr = dd_make(zc.x, zc.y), zi = dd_make(zc.z, zc.w);
             dd wr = dd_dot2_raw(Wr, zr, Wi, zi, -1.0), wi = dd_dot2_raw(Wr, zi, Wi, zr, 1.0);       // (rounded next: no renormalisation needed)
-            pc[c] = dd_round_away<F64IN>(wr, near_tie);
-            if (c > 0) pc[n - c] = -dd_round_away<F64IN>(wi, near_tie);
+            bool in0, in1 = false;
+            pc[c] = dd_round_away<F64IN>(wr, near_tie, band, in0);
+            if (c > 0) pc[n - c] = -dd_round_away<F64IN>(wi, near_tie, band, in1);
+            if (in0) note(c);
+            if (in1) note(n - c);
         }
         // W_{h-c}  (c = 0 gives W_h)
         if (c < h / 2) {
@@ -494,14 +515,64 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
             dd Wr = rsub(Xr, Yr), Wi = dd_neg(rsub(Xi, Yi));
             dd zr = dd_make(zh.x, zh.y), zi = dd_make(zh.z, zh.w);
             dd wr = dd_dot2_raw(Wr, zr, Wi, zi, -1.0), wi = dd_dot2_raw(Wr, zi, Wi, zr, 1.0);       // (rounded next: no renormalisation needed)
-            pc[cc] = dd_round_away<F64IN>(wr, near_tie);
-            if (cc < h) pc[n - cc] = -dd_round_away<F64IN>(wi, near_tie);
+            bool in0, in1 = false;
+            pc[cc] = dd_round_away<F64IN>(wr, near_tie, band, in0);
+            if (cc < h) pc[n - cc] = -dd_round_away<F64IN>(wi, near_tie, band, in1);
+            if (in0) note(cc);
+            if (in1) note(n - cc);
         }
     };
 #pragma unroll
     for (int i = 0; i < 4; i++) recomb(tid + 512 * i, Ar[i], Ai[i], Br[i], Bi[i]);
     if (tid == 0) recomb(h / 2, Ar[4], Ai[4], Br[4], Bi[4]);
-    if (near_tie) { atomicAdd(tie_count, (unsigned long long)(near_tie & 0xFFFFu)); if (near_tie >> 16) atomicAdd(tie_count + 1, (unsigned long long)(near_tie >> 16)); }
+    // ---- exact re-derivation of the listed coefficients (genotype rows, Delta / n a power of two).  p_j = (Delta / n) sum_t v_t cos(2 pi 5^t j / 2N): with
+    // 5^t = 4 m + 1 over the FFT's input order m, every term is a small integer times a table cosine; the cosines enter as 100-bit fixed point (three signed limbs
+    // of 40 bits from the {hi, lo} pair, exact), the 8192 products are summed as integers (no rounding at all), and the only error left is the table's: below
+    // 2^-68 of a unit after the scaling.  A sum farther than 2^-62 from the tie therefore PROVES its rounding, and that value replaces the double-double one;
+    // anything closer (or an overfull list, or real-valued slot rows) stays unproven and makes the synchronising entry points fail, as before.
+    __syncthreads();
+    const int ntie = tie_n < TIE_MAX ? tie_n : TIE_MAX;
+    if (ntie > 0) {
+        unsigned resolved = 0;
+        if (!F64IN && sexp >= 0) {
+            for (int e = tid; e < ntie * 3; e += 512) tie_sum[e / 3][e % 3] = 0ULL;
+            __syncthreads();
+            for (int e = 0; e < ntie; e++) {
+                const unsigned j = (unsigned)tie_j[e];
+                long long sa = 0, sb = 0, sc = 0;
+                for (int i = 0; i < 16; i++) {
+                    const int m = tid + 512 * i;
+                    int t = (int)tinv[m] - nrot; t += t < 0 ? n : 0;
+                    const int v = (int)row[t];                                  // (the skewed block: missing calls are zero already)
+                    if (!v) continue;
+                    unsigned k = ((4u * (unsigned)m + 1u) * j) & 32767u;        // angle 2 pi k / 32768
+                    if (k > 16384u) k = 32768u - k;                             // cos is even
+                    const bool neg = k > 8192u; if (neg) k = 16384u - k;        // cos(pi - x) = -cos x
+                    const double2 cv = costab[k];
+                    const double x = cv.x * 0x1p20, a = __builtin_rint(x), r1 = x - a;
+                    const double y = r1 * 0x1p40, bq = __builtin_rint(y), r2 = y - bq;
+                    const double cq = __builtin_rint(r2 * 0x1p40 + cv.y * 0x1p100);
+                    const long long sv = neg ? -(long long)v : (long long)v;
+                    sa += sv * (long long)a; sb += sv * (long long)bq; sc += sv * (long long)cq;
+                }
+                atomicAdd(&tie_sum[e][0], (unsigned long long)sa); atomicAdd(&tie_sum[e][1], (unsigned long long)sb); atomicAdd(&tie_sum[e][2], (unsigned long long)sc);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int e = 0; e < ntie; e++) {
+                    const __int128 T = ((__int128)(long long)tie_sum[e][0] << 80) + ((__int128)(long long)tie_sum[e][1] << 40) + (__int128)(long long)tie_sum[e][2];     // p_j 2^(100 - sexp)
+                    const int sh = 100 - sexp;
+                    const __int128 q = T >> sh, rem = T - (q << sh), half = (__int128)1 << (sh - 1);      // floor; 0 <= rem < 2^sh
+                    const __int128 dist = rem > half ? rem - half : half - rem;
+                    if (dist > ((__int128)1 << (sh - 62))) { pc[tie_j[e]] = (double)((long long)q + (rem > half ? 1 : 0)); resolved++; }
+                    else unproven++;
+                }
+            }
+        } else if (tid == 0) unproven += (unsigned)ntie;
+        if (resolved) atomicAdd(tie_count + 2, (unsigned long long)resolved);
+    }
+    if (near_tie) atomicAdd(tie_count, (unsigned long long)near_tie);
+    if (unproven) atomicAdd(tie_count + 1, (unsigned long long)unproven);
 }
 
 static int enc_pc_scratch(sfg_ctx *ctx, size_t nplain, double **pc) {
@@ -535,7 +606,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         if (cmode == 1) pc = pcache->slot + (size_t)(shift0 + s0) * SFG_SLOTS;          // the coefficient rows of these shifts live in the cache slot
         if (cmode <= 1) {
             PhaseTimer t(ctx, "encode", false);
-            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->tb, et->tinv, pc, (unsigned long long *)ctx->tie_count_dev);
+            hipLaunchKernelGGL(k_fft_encode<false>, dim3(nb), dim3(512), lds_bytes, ctx->stream, (const void *)D, shift0 + s0, et->tb, et->tinv, pc, (unsigned long long *)ctx->tie_count_dev, et->costab, et->sexp, ctx->cfg.tie_band);
             SFG_HIP(ctx, hipGetLastError());
         }
         if (cmode == 2) pc = pcache->slot + (size_t)(shift0 + s0) * SFG_SLOTS;
@@ -595,7 +666,7 @@ extern "C" int sfg_encode_coeffs_host(sfg_ctx *ctx, const double *values_host, i
     int rc = 0;
     if (hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
     if (!rc) {
-        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, dpc, (unsigned long long *)ctx->tie_count_dev);
+        hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, dpc, (unsigned long long *)ctx->tie_count_dev, et->costab, -1, ctx->cfg.tie_band);
         if (hipGetLastError() != hipSuccess) rc = 1;
     }
     if (!rc && hipMemcpyAsync(pc.data(), dpc, (size_t)nvec * n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
@@ -622,7 +693,7 @@ extern "C" int sfg_encode_vectors_dev(sfg_ctx *ctx, const double *values_host, i
     SFG_TRY(sfg_scratch(ctx, "enc.vectors", (size_t)nvec * n * 16, &p));
     double *dv = (double *)p; double *dpc = dv + (size_t)nvec * n;
     SFG_HIP(ctx, hipMemcpyAsync(dv, values_host, (size_t)nvec * n * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, dpc, (unsigned long long *)ctx->tie_count_dev);
+    hipLaunchKernelGGL(k_fft_encode<true>, dim3(nvec), dim3(512), lds_bytes, ctx->stream, (const void *)dv, 0, et->tb, et->tinv, dpc, (unsigned long long *)ctx->tie_count_dev, et->costab, -1, ctx->cfg.tie_band);
     SFG_HIP(ctx, hipGetLastError());
     SFG_TRY(launch_ntt_plain(ctx, dpc, (u64 *)pt_dev, (size_t)nvec, level + 1));
     SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // values_host may be reused by the caller
@@ -638,7 +709,7 @@ extern "C" int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count
     *count = c[0];
     if (reset) {
         if (c[1]) sfg_ptc_invalidate_all(ctx);       // rows cached while an unprovable rounding was outstanding are not served after the reset
-        SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 16));
+        SFG_HIP(ctx, hipMemset(ctx->tie_count_dev, 0, 32));
     }
     return 0;
 }
@@ -651,6 +722,13 @@ int sfg_encoder_check(sfg_ctx *ctx) {
     if (c[1]) sfg_ptc_invalidate_all(ctx);
     if (c[1]) SFG_FAIL(ctx, "encoder: %llu coefficient(s) within 2^-50 of a rounding tie - the double-double encoder cannot prove them rounded as the reference's 256-bit "
                             "EncoderBig rounds; re-derive the products of this context since the last reset with a big-float encoder (sfg_ctx_encoder_near_ties resets)", c[1]);
+    return 0;
+}
+// coefficients inside the 2^-50 band whose rounding was PROVEN by the exact re-derivation in k_fft_encode (and taken from it) since the last reset
+extern "C" int sfg_ctx_encoder_resolved(sfg_ctx *ctx, unsigned long long *count) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    SFG_TRY(sfg_sync_all(ctx));
+    SFG_HIP(ctx, hipMemcpy(count, (unsigned long long *)ctx->tie_count_dev + 2, 8, hipMemcpyDeviceToHost));
     return 0;
 }
 // the sticky 2^-50 counter behind sfg_encoder_check (not reset)
