@@ -106,3 +106,17 @@ def test_pipelined_and_sharded_sequences_over_rccl_at_world_size_1(plain):
     assert got["config"]["collectives"] == "RCCL" and got["config"]["rotation_cache_QX"].startswith("sharded")
     assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
     same(plain("c2"), got, "c2, forced RCCL collectives, sharded cache, pipelined reduce-scatter")
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu(plain):
+    """`python bench.py --gpus 2` with no launcher around it (no RANK in the environment) starts its two ranks itself - child processes under
+    torch.distributed.run, before the parent touches the GPU - and relays rank 0's line.  Same digests as the single process."""
+    e = dict(os.environ)
+    e.update(SHARED_GPU_ENV)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--config", "c2", "--gpus", "2", "--backend", "gloo"] + COMMON, cwd=ROOT, env=e, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["collectives"].startswith("gloo")
+    same(line, plain("c2"), "self-launched 2 ranks")
