@@ -32,6 +32,8 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_I8_BIG")) c.mac_i8_big = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_ROT")) { c.mac_i8_nolds = strcmp(e, "lds") != 0; c.mac_i8_ring = !strcmp(e, "ring"); }      // ring (default) | cache | lds
     if (env("SFG_MAC_I8_WG")) c.mac_i8_ring = false;
+    if (const char *e = env("SFG_MAC_I8_DIAG")) c.mac_i8_diag = atoi(e);
+    if (const char *e = env("SFG_MAC_I8_WAVES")) c.mac_i8_waves = atoi(e) == 6 ? 6 : 12;
     if (const char *e = env("SFG_MAC_I8_STAGE")) c.stage_pack = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
     if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;

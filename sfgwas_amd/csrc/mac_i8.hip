@@ -332,33 +332,45 @@ __device__ __forceinline__ void i8_dma16(const void *gsrc, void *lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 // DEPTH slots of 10 ND KiB: three for the 35-bit moduli (150 KiB), two for the 46-bit one (120 KiB: its 144 MFMAs per chunk cover one chunk of lookahead)
-template <int ND, int I8R_DEPTH>
-__global__ void __launch_bounds__(384, 1) k_mac_i8_ring(I8Args a, const ModConst *modc) {
+// DIAG (timing diagnostics only, results invalid; SFG_MAC_I8_DIAG): 1 = one MFMA per rot tile instead of ND (the matrix pipe nearly idle), 2 = no DMA after the prologue
+// (the memory system idle): which side of the ring sets the chunk time
+// HALVES = 2: twelve waves, a wave = one COEFFICIENT (c or N-1-c) x 16 columns: 2 row tiles x (2 ND - 1) sums, three waves on every SIMD instead of 2-2-1-1.  The
+// timing diagnostics showed the matrix side of the six-wave form (3.85 ms of a 5.02 ms launch with the memory system idle; 4.29 ms with the matrix pipe idle) set by
+// the two doubly occupied SIMDs; with LDS-staged operands the second wave of a pair costs no extra fetch.
+template <int ND, int I8R_DEPTH, int DIAG = 0, int HALVES = 1>
+__global__ void __launch_bounds__(384 * HALVES, 1) k_mac_i8_ring(I8Args a, const ModConst *modc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
-    constexpr int NA = 4 * ND, NB = 6 * ND, SLOT = (NA + NB) * 1024, AR = (NA + 5) / 6, NJ = ND + AR;      // tiles per slot; DMA instructions per wave and chunk
-    static_assert(NJ < 32 && SLOT * I8R_DEPTH <= 160 * 1024 && SLOT < 65536, "ring budget");
+    constexpr int NA = 4 * ND, NB = 6 * ND, SLOT = (NA + NB) * 1024;                  // tiles per slot
+    constexpr int NT = 4 / HALVES, NAW = NT * ND;                                       // row tiles / rot tiles of one wave
+    // DMA instructions per wave and chunk.  Six waves: own plaintext tiles + every sixth rot tile.  Twelve: the waves of coefficient c fetch the plaintext tiles of
+    // their column, the waves of N-1-c the rot tiles (every sixth; the last round wraps around onto tiles already fetched - same bytes to the same place)
+    constexpr int AR = (NA + 5) / 6, NJ0 = HALVES == 1 ? ND + AR : ND, NJ1 = HALVES == 1 ? ND + AR : AR;
+    static_assert(NJ0 < 32 && NJ1 < 32 && SLOT * I8R_DEPTH <= 160 * 1024 && SLOT < 65536, "ring budget");
     const int N = SFG_N, H = N / 2;
-    const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6;                  // six column waves (launched for njt == 6 only)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), jt = wv % 6, hf = wv / 6;      // (scalar: wave-uniform branches below) column tile; (HALVES = 2) coefficient of the pair
     const int c = blockIdx.x % H, m = blockIdx.x / H, nch = a.nch;
-    v4i acc[4][2 * ND - 1];
+    v4i acc[NT][2 * ND - 1];
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int s = 0; s < 2 * ND - 1; s++) acc[t][s] = (v4i){0, 0, 0, 0};
     const unsigned char *gB = reinterpret_cast<const unsigned char *>(a.B) + ((((size_t)m * H + c) * 6 + jt) * nch) * ND * 1024 + lane * 16;
     const unsigned char *gA0 = reinterpret_cast<const unsigned char *>(a.A) + (((size_t)m * N + c) * nch) * 2 * ND * 1024 + lane * 16;
     const unsigned char *gA1 = reinterpret_cast<const unsigned char *>(a.A) + (((size_t)m * N + (N - 1 - c)) * nch) * 2 * ND * 1024 + lane * 16;
-    // the rot tiles of a chunk, tile j = (half, rt, digit) = t * ND + x for the MFMA loop below: wave jt fetches j = jt, jt + 6, ... (the last round wraps around
-    // and fetches a tile another wave fetches too: same bytes to the same place, so that every wave issues the same number of DMA instructions)
+    // the rot tiles of a chunk: tile j = (coefficient, row tile, digit) = t * ND + x of the MFMA loop below
     auto issue = [&](int ch, int slot) {
         unsigned char *sl = ring + slot * SLOT;
+        if (HALVES == 1 || hf == 0) {
 #pragma unroll
-        for (int d = 0; d < ND; d++) i8_dma16(gB + ((size_t)ch * ND + d) * 1024, sl + (NA + jt * ND + d) * 1024);
+            for (int d = 0; d < ND; d++) i8_dma16(gB + ((size_t)ch * ND + d) * 1024, sl + (NA + jt * ND + d) * 1024);
+        }
+        if (HALVES == 1 || hf == 1) {
 #pragma unroll
-        for (int r = 0; r < AR; r++) {
-            int j = r * 6 + jt; if (j >= NA) j -= NA;
-            const int half = j / (2 * ND), rem = j - half * 2 * ND;
-            i8_dma16((half ? gA1 : gA0) + ((size_t)ch * 2 * ND + rem) * 1024, sl + j * 1024);
+            for (int r = 0; r < AR; r++) {
+                int j = r * 6 + jt; if (j >= NA) j -= NA;
+                const int half = j / (2 * ND), rem = j - half * 2 * ND;
+                i8_dma16((half ? gA1 : gA0) + ((size_t)ch * 2 * ND + rem) * 1024, sl + j * 1024);
+            }
         }
     };
 #pragma unroll
@@ -369,37 +381,39 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_ring(I8Args a, const ModConst
     for (int ch = 0; ch < nch; ch++) {
         // chunk ch has landed once every wave's own pieces have (the chunk issued after it may still be in flight) and the workgroup has met; the meeting also
         // says that everybody has finished reading chunk ch - 1, whose slot is refilled next
-        if (ch + I8R_DEPTH - 2 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * (I8R_DEPTH - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DIAG == 2 || ch + I8R_DEPTH - 2 >= nch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (HALVES == 1 || hf == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ0 * (I8R_DEPTH - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ1 * (I8R_DEPTH - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (ch + I8R_DEPTH - 1 < nch) issue(ch + I8R_DEPTH - 1, slot == 0 ? I8R_DEPTH - 1 : slot - 1);
-        const unsigned ab = lds0 + (unsigned)(slot * SLOT), bb = ab + (unsigned)((NA + jt * ND) * 1024);
+        if (DIAG != 2 && ch + I8R_DEPTH - 1 < nch) issue(ch + I8R_DEPTH - 1, slot == 0 ? I8R_DEPTH - 1 : slot - 1);
+        const unsigned ab = lds0 + (unsigned)(slot * SLOT) + (unsigned)(hf * NAW * 1024), bb = lds0 + (unsigned)(slot * SLOT) + (unsigned)((NA + jt * ND) * 1024);
         v4i b[ND], ar[5];
 #pragma unroll
         for (int d = 0; d < ND; d++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[d]) : "v"(bb), "n"(d * 1024) : "memory");
 #pragma unroll
         for (int i = 0; i < 3; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[i]) : "v"(ab), "n"(i * 1024) : "memory");
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            // rot tile i is in: the LDS unit answers in order, and at most min(2, NA - 1 - i) reads were issued after it
+        for (int i = 0; i < NAW; i++) {
+            // rot tile i is in: the LDS unit answers in order, and at most min(2, NAW - 1 - i) reads were issued after it
             if (i == 0) {
                 if constexpr (ND == 5) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4])::"memory");
                 else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[ND - 1])::"memory");
-            } else if (i < NA - 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[i % 5])::"memory");
-            else if (i == NA - 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ar[i % 5])::"memory");
+            } else if (i < NAW - 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[i % 5])::"memory");
+            else if (i == NAW - 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ar[i % 5])::"memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[i % 5])::"memory");
             // tile i + 3 goes into the registers of tile i - 2 (tile i is named as an operand so that its MFMAs stay BEHIND this request: three tiles in flight)
-            if (i + 3 < NA) asm volatile("ds_read_b128 %0, %2 offset:%3" : "=&v"(ar[(i + 3) % 5]), "+v"(ar[i % 5]) : "v"(ab), "n"((i + 3) * 1024) : "memory");
+            if (i + 3 < NAW) asm volatile("ds_read_b128 %0, %2 offset:%3" : "=&v"(ar[(i + 3) % 5]), "+v"(ar[i % 5]) : "v"(ab), "n"((i + 3) * 1024) : "memory");
             const int t = i / ND, x = i - t * ND;
 #pragma unroll
-            for (int d = 0; d < ND; d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ar[i % 5], b[d], acc[t][x + d], 0, 0, 0);
+            for (int d = 0; d < (DIAG == 1 ? 1 : ND); d++) acc[t][x + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ar[i % 5], b[d], acc[t][x + d], 0, 0, 0);
         }
         slot = slot + 1 == I8R_DEPTH ? 0 : slot + 1;
     }
     const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * 6 + jt) * 2 + (t & 1)) * 64 + lane) * 4;
+    for (int t = 0; t < NT; t++) {
+        const int tg = hf * NT + t;                                                     // tile of the pair: (coefficient, row tile)
+        u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (tg >> 1)) * 6 + jt) * 2 + (tg & 1)) * 64 + lane) * 4;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             double r = (double)acc[t][2 * ND - 2][e];
@@ -443,6 +457,10 @@ int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (c
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 6 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 10 * 6 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<6, 2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 10 * 6 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
     return 0;
 }
 // bytes of the two operand streams and the tile-ordered results of one launch (for the group-size choice in matmul.hip)
@@ -541,7 +559,11 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
     { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
       if (a.njt == 6 && ctx->cfg.mac_i8_ring) {
-          if (BIG) hipLaunchKernelGGL((k_mac_i8_ring<6, 2>), dim3((unsigned)(nl * H)), dim3(384), 2 * 10 * 6 * 1024, ctx->stream, a, ctx->modc);
+          if (BIG && ctx->cfg.mac_i8_waves == 12) hipLaunchKernelGGL((k_mac_i8_ring<6, 2, 0, 2>), dim3((unsigned)(nl * H)), dim3(768), 2 * 10 * 6 * 1024, ctx->stream, a, ctx->modc);
+          else if (BIG) hipLaunchKernelGGL((k_mac_i8_ring<6, 2>), dim3((unsigned)(nl * H)), dim3(384), 2 * 10 * 6 * 1024, ctx->stream, a, ctx->modc);
+          else if (ctx->cfg.mac_i8_waves == 12 && !ctx->cfg.mac_i8_diag) hipLaunchKernelGGL((k_mac_i8_ring<5, 3, 0, 2>), dim3((unsigned)(nl * H)), dim3(768), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+          else if (ctx->cfg.mac_i8_diag == 1) hipLaunchKernelGGL((k_mac_i8_ring<5, 3, 1>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+          else if (ctx->cfg.mac_i8_diag == 2) hipLaunchKernelGGL((k_mac_i8_ring<5, 3, 2>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
           else hipLaunchKernelGGL((k_mac_i8_ring<5, 3>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
       }
       else if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);

@@ -152,8 +152,8 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     for name, envv in [("g1", {"SFG_MM_GROUP": "1"}), ("g8", {"SFG_MM_GROUP": "8"}), ("reg", {"SFG_MAC_IMPL": "reg"}),
                        ("budget", {"SFG_MM_ACC_BUDGET_MB": "300"}), ("budget_g1", {"SFG_MM_ACC_BUDGET_MB": "300", "SFG_MM_GROUP": "1"}),
                        ("dma", {"SFG_MAC_IMPL": "dma"}), ("dma_wc2", {"SFG_MAC_IMPL": "dma", "SFG_MAC_WC": "2"}), ("plain_pt", {"SFG_MAC_PT": "plain"}),
-                       ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"}), ("bc", {"SFG_MAC_IMPL": "bc"}), ("bc_g1", {"SFG_MAC_IMPL": "bc", "SFG_MM_GROUP": "1"}), ("i8_lds", {"SFG_MAC_I8_ROT": "lds"}), ("i8_big", {"SFG_MAC_I8_BIG": "1"}),
-                       ("i8_cache", {"SFG_MAC_I8_ROT": "cache"}), ("i8_wg1", {"SFG_MAC_I8_WG": "1"})]:
+                       ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"}), ("bc", {"SFG_MAC_IMPL": "bc"}), ("bc_g1", {"SFG_MAC_IMPL": "bc", "SFG_MM_GROUP": "1"}), ("i8_lds", {"SFG_MAC_I8_ROT": "lds"}), ("i8_big", {"SFG_MAC_I8_BIG": "0"}),
+                       ("i8_cache", {"SFG_MAC_I8_ROT": "cache"}), ("i8_wg1", {"SFG_MAC_I8_WG": "1"}), ("i8_w6", {"SFG_MAC_I8_WAVES": "6"}), ("i8_w6_big0", {"SFG_MAC_I8_WAVES": "6", "SFG_MAC_I8_BIG": "0"})]:
         f = str(tmp_path / (name + ".npy"))
         e = dict(os.environ); e.update(envv)
         r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
@@ -167,8 +167,9 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     assert np.array_equal(outs[0], outs[8]), "split and full-image NTT kernels disagree"
     assert np.array_equal(outs[0], outs[9]) and np.array_equal(outs[0], outs[10]), "the int8 matrix-core MAC (default: five signed base-256 digits, nine int32 sums) and the fp64 DPP-broadcast MAC of round 2 (SFG_MAC_IMPL=bc) disagree"
     assert np.array_equal(outs[0], outs[11]), "int8 MAC with LDS-staged rot tiles disagrees"
-    assert np.array_equal(outs[0], outs[12]), "the 46-bit modulus on the int8 matrix core (six digits) disagrees with the fp64 kernel"
+    assert np.array_equal(outs[0], outs[12]), "the 46-bit modulus on the int8 matrix core (six digits, the default) disagrees with the fp64 kernel (SFG_MAC_I8_BIG=0)"
     assert np.array_equal(outs[0], outs[13]) and np.array_equal(outs[0], outs[14]), "int8 MAC from the LDS prefetch ring (default) and straight from global memory (SFG_MAC_I8_ROT=cache, SFG_MAC_I8_WG=1) disagree"
+    assert np.array_equal(outs[0], outs[15]) and np.array_equal(outs[0], outs[16]), "twelve-wave (default) and six-wave ring MAC disagree"
     assert outs[0].any()
 
 
