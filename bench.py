@@ -142,6 +142,7 @@ def cpu_baseline(seconds, L, N, D):
     cal = lib.orc_bench_mac_ref_layout(KP, L, N, D, threads, cal_items, 1, C.byref(n_done), C.byref(active), C.byref(secs))
     macs_per_item = D * 2 * L * N
     items = int(max(threads, min(total_items, cal * seconds / passes / macs_per_item)))
+    passes = int(max(passes, min(64, round(cal * seconds / (items * macs_per_item)))))      # a fast host finishes three passes over ALL items early: more whole passes, same sample
     rate = lib.orc_bench_mac_ref_layout(KP, L, N, D, threads, items, passes, C.byref(n_done), C.byref(active), C.byref(secs))
     return {"value": rate, "unit": "ring-MAC/s", "cores": active.value, "cores_granted_vs_present": cores, "kind": "port", "cpu": cpu_model(),
             "build": "gcc -O3 -march=native -fopenmp (oracle/Makefile: native)", "per_core": rate / max(active.value, 1),
