@@ -111,7 +111,8 @@ int sfg_ctx_encoder_near_ties(sfg_ctx *ctx, unsigned long long *count, int reset
 /* Round 4: a genotype-diagonal coefficient inside the 2^-50 band is RE-DERIVED on the device before it can fail anything: p_j = (Delta/n) sum_t v_t cos(2 pi 5^t j / 2N)
  * is summed exactly - small integers times 100-bit fixed-point cosines, integer accumulation - so only the cosine table's error (< 2^-68 of a unit) is left, and a sum
  * farther than 2^-62 from the tie proves its rounding and replaces the double-double value (sfg_ctx_encoder_resolved counts them).  What stays unproven - closer than
- * 2^-62 (about once per 10^18 coefficients), more than eight such coefficients in one plaintext, real-valued slot rows (sfg_encode_vectors_dev) - fails as described. */
+ * 2^-62 (about once per 10^18 coefficients), a second such coefficient among the 16 - 20 one lane rounds, real-valued slot rows (sfg_encode_vectors_dev) - fails as
+ * described.  Cost: 1.4 % of the encode FFT (the re-derivation is a non-inlined serial loop at the kernel's end; same-box A/B in profiles/r04_fft_resolver_ab.txt). */
 int sfg_ctx_encoder_resolved(sfg_ctx *ctx, unsigned long long *count);
 /* the coefficients within 2^-50 of a tie seen since the last reset that could NOT be proven (the condition that makes the synchronising entry points fail) */
 int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *count);

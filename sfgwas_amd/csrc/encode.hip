@@ -383,6 +383,37 @@ __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie, double
     return nn + (up ? 1.0 : 0.0) - (dn ? 1.0 : 0.0);
 }
 
+// Exact re-derivation of ONE coefficient of a genotype-row plaintext (Delta / n = 2^sexp).  p_j = (Delta / n) sum_t v_t cos(2 pi 5^t j / 2N): with 5^t = 4 m + 1
+// over the FFT's input order m every term is a small integer times a table cosine; the cosines enter as 100-bit fixed point (three signed limbs of 40 bits from the
+// {hi, lo} pair, exact), the 8192 products are summed as integers (no rounding at all), and the only error left is the table's: below 2^-68 of a unit after the
+// scaling.  A sum farther than 2^-62 from the tie PROVES its rounding.  Called by the one lane that met a coefficient inside the band (about once per 10^15
+// coefficients): a serial loop, deliberately not inlined so that it costs the encoder's hot path one predicate and no registers.
+__device__ __noinline__ bool enc_tie_resolve(const int8_t *row, const uint16_t *tinv, int nrot, const double2 *costab, int sexp, int j, double *out) {
+    const int n = SFG_SLOTS;
+    long long sa = 0, sb = 0, sc = 0;
+    for (int m = 0; m < n; m++) {
+        int t = (int)tinv[m] - nrot; t += t < 0 ? n : 0;
+        const int v = (int)row[t];                                      // (the skewed block: missing calls are zero already)
+        if (!v) continue;
+        unsigned k = ((4u * (unsigned)m + 1u) * (unsigned)j) & 32767u;  // angle 2 pi k / 32768
+        if (k > 16384u) k = 32768u - k;                                 // cos is even
+        const bool neg = k > 8192u; if (neg) k = 16384u - k;            // cos(pi - x) = -cos x
+        const double2 cv = costab[k];
+        const double x = cv.x * 0x1p20, a = __builtin_rint(x), r1 = x - a;
+        const double y = r1 * 0x1p40, bq = __builtin_rint(y), r2 = y - bq;
+        const double cq = __builtin_rint(r2 * 0x1p40 + cv.y * 0x1p100);
+        const long long sv = neg ? -(long long)v : (long long)v;
+        sa += sv * (long long)a; sb += sv * (long long)bq; sc += sv * (long long)cq;
+    }
+    const __int128 T = ((__int128)sa << 80) + ((__int128)sb << 40) + (__int128)sc;      // p_j 2^(100 - sexp)
+    const int sh = 100 - sexp;
+    const __int128 q = T >> sh, rem = T - (q << sh), half = (__int128)1 << (sh - 1);      // floor; 0 <= rem < 2^sh
+    const __int128 dist = rem > half ? rem - half : half - rem;
+    if (dist <= ((__int128)1 << (sh - 62))) return false;
+    *out = (double)((long long)q + (rem > half ? 1 : 0));
+    return true;
+}
+
 // rows: diag-major int8 rows of length n; plaintext p encodes row (shift0 + p) right-rotated by d*((shift0+p)/d).
 // F64IN: rows are n doubles (arbitrary real slot vectors, no rotation) — the Mask / EncodeFloatVector use.
 constexpr size_t ENC_LDS_BYTES = (size_t)2 * ENC_H * 8;        // 65,536 B: two workgroups per CU
@@ -393,10 +424,6 @@ template <bool F64IN>
 __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift0, const double4 *tb, const uint16_t *tinv,
                                                       double *pc_out, unsigned long long *tie_count, const double2 *costab, int sexp, double band) {
     unsigned near_tie = 0;
-    constexpr int TIE_MAX = 8;                                      // coefficients of one plaintext that can be re-derived (the band holds ~10^-15 of them)
-    __shared__ int tie_n, tie_j[TIE_MAX];
-    __shared__ unsigned long long tie_sum[TIE_MAX][3];
-    if (threadIdx.x == 0) tie_n = 0;
     extern __shared__ double lds[];
     double *RE = lds, *IM = lds + ENC_H;
     const int n = SFG_SLOTS, h = ENC_H, tid = threadIdx.x;
@@ -478,9 +505,10 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
         const int c = tid + 512 * i, pa = padj_fin(c), pb = padj_fin((h - c) & (h - 1));
         Ar[i].lo = RE[pa]; Ai[i].lo = IM[pa]; Br[i].lo = RE[pb]; Bi[i].lo = -IM[pb];
     }
-    // a coefficient inside the band: listed for the exact re-derivation below (the list is a few words of static LDS; the images are not touched)
-    unsigned unproven = 0;
-    auto note = [&](int j) { const int k = atomicAdd(&tie_n, 1); if (k < TIE_MAX) tie_j[k] = j; else unproven++; };
+    // a coefficient inside the band is remembered (one per lane: the band holds ~10^-15 of them) and re-derived exactly at the very end of the kernel, where nothing
+    // else is live: the hot path pays two selects
+    int tie_j = -1; unsigned tie_n = 0;
+    auto note = [&](int j) { tie_j = j; tie_n++; };
     // one pair (c, h - c): A = Z_c, B = conj Z_{h-c};  wo = omega^-c / 2 = zeta^-4c / 2, zc = (Delta/n) zeta^-c, zh = (Delta/n) zeta^-(h-c)
     auto recomb = [&](int c, dd Ar, dd Ai, dd Br, dd Bi) {
         // (genotype rows: A and B are sums on the fixed grid, so the recombination adds are exact two-flop grid adds as well)
@@ -525,54 +553,17 @@ __global__ void __launch_bounds__(512, 4) k_fft_encode(const void *Dv, int shift
 #pragma unroll
     for (int i = 0; i < 4; i++) recomb(tid + 512 * i, Ar[i], Ai[i], Br[i], Bi[i]);
     if (tid == 0) recomb(h / 2, Ar[4], Ai[4], Br[4], Bi[4]);
-    // ---- exact re-derivation of the listed coefficients (genotype rows, Delta / n a power of two).  p_j = (Delta / n) sum_t v_t cos(2 pi 5^t j / 2N): with
-    // 5^t = 4 m + 1 over the FFT's input order m, every term is a small integer times a table cosine; the cosines enter as 100-bit fixed point (three signed limbs
-    // of 40 bits from the {hi, lo} pair, exact), the 8192 products are summed as integers (no rounding at all), and the only error left is the table's: below
-    // 2^-68 of a unit after the scaling.  A sum farther than 2^-62 from the tie therefore PROVES its rounding, and that value replaces the double-double one;
-    // anything closer (or an overfull list, or real-valued slot rows) stays unproven and makes the synchronising entry points fail, as before.
-    __syncthreads();
-    const int ntie = tie_n < TIE_MAX ? tie_n : TIE_MAX;
-    if (ntie > 0) {
-        unsigned resolved = 0;
-        if (!F64IN && sexp >= 0) {
-            for (int e = tid; e < ntie * 3; e += 512) tie_sum[e / 3][e % 3] = 0ULL;
-            __syncthreads();
-            for (int e = 0; e < ntie; e++) {
-                const unsigned j = (unsigned)tie_j[e];
-                long long sa = 0, sb = 0, sc = 0;
-                for (int i = 0; i < 16; i++) {
-                    const int m = tid + 512 * i;
-                    int t = (int)tinv[m] - nrot; t += t < 0 ? n : 0;
-                    const int v = (int)row[t];                                  // (the skewed block: missing calls are zero already)
-                    if (!v) continue;
-                    unsigned k = ((4u * (unsigned)m + 1u) * j) & 32767u;        // angle 2 pi k / 32768
-                    if (k > 16384u) k = 32768u - k;                             // cos is even
-                    const bool neg = k > 8192u; if (neg) k = 16384u - k;        // cos(pi - x) = -cos x
-                    const double2 cv = costab[k];
-                    const double x = cv.x * 0x1p20, a = __builtin_rint(x), r1 = x - a;
-                    const double y = r1 * 0x1p40, bq = __builtin_rint(y), r2 = y - bq;
-                    const double cq = __builtin_rint(r2 * 0x1p40 + cv.y * 0x1p100);
-                    const long long sv = neg ? -(long long)v : (long long)v;
-                    sa += sv * (long long)a; sb += sv * (long long)bq; sc += sv * (long long)cq;
-                }
-                atomicAdd(&tie_sum[e][0], (unsigned long long)sa); atomicAdd(&tie_sum[e][1], (unsigned long long)sb); atomicAdd(&tie_sum[e][2], (unsigned long long)sc);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int e = 0; e < ntie; e++) {
-                    const __int128 T = ((__int128)(long long)tie_sum[e][0] << 80) + ((__int128)(long long)tie_sum[e][1] << 40) + (__int128)(long long)tie_sum[e][2];     // p_j 2^(100 - sexp)
-                    const int sh = 100 - sexp;
-                    const __int128 q = T >> sh, rem = T - (q << sh), half = (__int128)1 << (sh - 1);      // floor; 0 <= rem < 2^sh
-                    const __int128 dist = rem > half ? rem - half : half - rem;
-                    if (dist > ((__int128)1 << (sh - 62))) { pc[tie_j[e]] = (double)((long long)q + (rem > half ? 1 : 0)); resolved++; }
-                    else unproven++;
-                }
-            }
-        } else if (tid == 0) unproven += (unsigned)ntie;
-        if (resolved) atomicAdd(tie_count + 2, (unsigned long long)resolved);
+    if (tie_n) {       // re-derived exactly by this lane (enc_tie_resolve), or counted as unproven (a second one in the same lane, real-valued slot rows, Delta / n not a
+        unsigned unproven = tie_n - 1, resolved = 0;      // power of two, the A/B build -DSFG_ENC_NO_RESOLVE) - which makes the synchronising entry points fail
+        double v;
+#ifndef SFG_ENC_NO_RESOLVE
+        if (!F64IN && sexp >= 0 && enc_tie_resolve(row, tinv, nrot, costab, sexp, tie_j, &v)) { pc[tie_j] = v; resolved = 1; } else
+#endif
+            unproven++;
+        if (resolved) atomicAdd(tie_count + 2, 1ULL);
+        if (unproven) atomicAdd(tie_count + 1, (unsigned long long)unproven);
     }
     if (near_tie) atomicAdd(tie_count, (unsigned long long)near_tie);
-    if (unproven) atomicAdd(tie_count + 1, (unsigned long long)unproven);
 }
 
 static int enc_pc_scratch(sfg_ctx *ctx, size_t nplain, double **pc) {
