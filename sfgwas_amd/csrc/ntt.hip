@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(512) k_ntt_fwd(const void *in_, u64 *out_, Mod
     const size_t row = blockIdx.x;
     const int m = pat.m[row % pat.period];
     const size_t grp = row / rm.rpg, gi = row % rm.rpg;
+    if (m == -2) return;                                 // row marked "nobody reads it": neither transformed nor copied
     if (m < 0) {                                         // row marked "leave untouched": copied through when the transform runs out of place
         const u64 *src = (const u64 *)in_ + grp * rm.gstride_in + gi * N; u64 *dst = out_ + grp * rm.gstride_out + gi * N;
         if (IN_MODE == 0 && src != dst) for (int a = 0; a < 32; a++) dst[a * 512 + tid] = src[a * 512 + tid];
@@ -468,6 +469,7 @@ __global__ void __launch_bounds__(256, 4) k_ntt_fwd_split(const u64 *in_, u64 *o
     const size_t grp = row / rm.rpg, gi = row % rm.rpg;
     const u64 *in = in_ + grp * rm.gstride_in + gi * N;
     u64 *out = out_ + grp * rm.gstride_out + gi * N + (size_t)hs * n;
+    if (m == -2) return;                                 // row marked "nobody reads it"
     if (m < 0) {                                         // row marked "leave untouched": out of place that means "copy through"
         for (int k = 0; k < 32; k++) out[k * 256 + tid] = in[(size_t)hs * n + k * 256 + tid];
         return;

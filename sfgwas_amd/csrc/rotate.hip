@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(256) k_ksw_extend(const u64 *c2, const u64 *ct
     const int N = SFG_N, x = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y; const size_t b = blockIdx.z;
     const ExtConst &e = kc.dig[i];
     const u64 *c2b = c2 + b * (size_t)kc.nl * N;
-    const u64 *cxb = ct_in + b * (size_t)2 * kc.nl * N + (size_t)kc.nl * N;
     u64 *eb = ext + (b * kc.beta + i) * (size_t)kc.nt * N;
     double xs[KSW_MAXA], y[KSW_MAXA], v = 0.0;
 #pragma unroll
@@ -133,15 +132,16 @@ __global__ void __launch_bounds__(256) k_ksw_extend(const u64 *c2, const u64 *ct
     for (int t = 0; t < kc.nt; t++) {
         const int tg = kc.tmod[t];
         u64 outv;
-        if (kc.digit_of[t] == i) outv = cxb[(size_t)t * N + x];                       // in-digit: original NTT row
+        if (kc.digit_of[t] == i) continue;                                            // in-digit: the original NTT row, which k_ksw_inner reads where it lies
         else if (e.a == 1) outv = f64_to_u64(canon(xs[0], modc[tg].q, modc[tg].qinv)); // single-prime digit: raw copy mod q_t
         else outv = f64_to_u64(ext_target(e, tg, modc[tg].q, modc[tg].qinv, y, v));
         eb[(size_t)t * N + x] = outv;
     }
 }
 
-// grid (N/512, nt, B). acc: [B][2][nt][N]; inidx[b] = which decomposed input feeds output b.  Two coefficients per thread: 16-byte loads and stores
-__global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *const *keys, const int *inidx, u64 *acc, const KswConst *kcp, const ModConst *modc, int nmod) {
+// grid (N/512, nt, B). acc: [B][2][nt][N]; inidx[b] = which decomposed input feeds output b.  Two coefficients per thread: 16-byte loads and stores.
+// The row of digit i at a target inside digit i is the input's own NTT row (polynomial 1 of ct_in): read there, never copied (round 4: 15 of ~250 row transfers per switch less)
+__global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *ct_in, const u64 *const *keys, const int *inidx, u64 *acc, const KswConst *kcp, const ModConst *modc, int nmod) {
     const KswConst &kc = *kcp;
     const int N = SFG_N, x = 2 * (blockIdx.x * 256 + threadIdx.x), t = blockIdx.y; const size_t b = blockIdx.z;
     const int tg = kc.tmod[t];
@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(256) k_ksw_inner(const u64 *ext, const u64 *co
     const size_t bi = (size_t)inidx[b];
     double a0x = 0.0, a0y = 0.0, a1x = 0.0, a1y = 0.0;
     for (int i = 0; i < kc.beta; i++) {
-        const ulonglong2 ev = *reinterpret_cast<const ulonglong2 *>(ext + ((bi * kc.beta + i) * (size_t)kc.nt + t) * N + x);
+        const ulonglong2 ev = kc.digit_of[t] == i ? *reinterpret_cast<const ulonglong2 *>(ct_in + (bi * 2 * (size_t)kc.nl + kc.nl + t) * N + x)
+                                                  : *reinterpret_cast<const ulonglong2 *>(ext + ((bi * kc.beta + i) * (size_t)kc.nt + t) * N + x);
         const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)i * 2 + 0) * nmod + tg) * N + x);
         const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(key + (((size_t)i * 2 + 1) * nmod + tg) * N + x);
         const double ex = u64_to_f64(ev.x), ey = u64_to_f64(ev.y);
@@ -251,7 +252,7 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
     int *inidx_all = (int *)(out_all + nr);
     ModPattern pq; pq.period = nl; for (int m = 0; m < nl; m++) pq.m[m] = (int8_t)m;
     ModPattern pext; pext.period = kc.beta * kc.nt;
-    for (int i = 0; i < kc.beta; i++) for (int t = 0; t < kc.nt; t++) pext.m[i * kc.nt + t] = kc.digit_of[t] == i ? (int8_t)-1 : (int8_t)kc.tmod[t];
+    for (int i = 0; i < kc.beta; i++) for (int t = 0; t < kc.nt; t++) pext.m[i * kc.nt + t] = kc.digit_of[t] == i ? (int8_t)-2 : (int8_t)kc.tmod[t];      // in-digit rows: nobody reads them
     ModPattern pp; pp.period = kc.np; for (int p = 0; p < kc.np; p++) pp.m[p] = (int8_t)(ctx->nq + p);
     for (int i0 = 0; i0 < nin; i0 += in_grp) {
         const int ni = nin - i0 < in_grp ? nin - i0 : in_grp;
@@ -280,7 +281,7 @@ static int launch_keyswitch_jobs(sfg_ctx *ctx, const u64 *in, int nin, int level
             const int nb = (int)(jobs.size() - c0 < (size_t)chunk ? jobs.size() - c0 : (size_t)chunk);
             const u64 **keys_d = keys_all + c0; const uint16_t **idx_d = idx_all + c0; u64 **out_d = out_all + c0; int *inidx_d = inidx_all + c0;
             // 3. inner product with the key
-            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 512, kc.nt, nb), dim3(256), 0, ctx->stream, extT, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
+            hipLaunchKernelGGL(k_ksw_inner, dim3(N / 512, kc.nt, nb), dim3(256), 0, ctx->stream, extT, bin, keys_d, inidx_d, acc, kcd, ctx->modc, ctx->nmod);
             SFG_HIP(ctx, hipGetLastError());
             // 4. ModDown: INTT special rows in place, extend to Q, NTT
             RowMap rm4; rm4.rpg = kc.np; rm4.gstride_in = (size_t)kc.nt * N; rm4.gstride_out = (size_t)kc.nt * N;
