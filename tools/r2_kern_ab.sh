@@ -12,7 +12,7 @@ rows = {r['Name'].split('(')[0][:28]: r for r in csv.DictReader(open(glob.glob("
 line = [l for l in open("gpurun_out/$TAG/$name.log") if l.startswith('{')]
 dig = json.loads(line[-1])['digests']['out1_sha256'][:12] if line else '?'
 out = "%-28s" % "$name"
-for k in ("void k_fft_encode<false>", "k_ntt_half3", "void k_mac_bc<false, 30>", "k_ntt_fwd_split", "k_ntt_inv", "k_ksw_finish", "k_ksw_inner", "k_ksw_extend", "k_moddown_extend", "k_skew", "void k_skew<false>", "void k_skew<true>"):
+for k in ("void k_fft_encode<false>", "void k_ntt_half3<false, true", "k_ntt_half3", "void k_mac_bc<false, 30>", "k_ntt_fwd_split", "k_ntt_inv", "k_ksw_finish", "k_ksw_inner", "k_ksw_extend", "k_moddown_extend", "k_skew", "void k_skew<false>", "void k_skew<true>"):
     r = rows.get(k[:28]); out += ("  %s %8.1f us" % (k.split()[-1][:14], float(r['AverageNs']) / 1e3) if r else "")
 print(out, dig)
 PY
