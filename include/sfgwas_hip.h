@@ -50,6 +50,10 @@ int sfg_ctx_synchronize(sfg_ctx *ctx);
  * have drained; the next call re-grows what it needs.  For callers that change to a very different product shape beside a large resident matrix.
  * (No reference counterpart: Go's garbage collector plays this role for the accCache / rotCache slices of matmult.go:1065-1129.) */
 int sfg_ctx_release_scratch(sfg_ctx *ctx);
+/* bytes the context currently keeps in scratch buffers whose name starts with `prefix` ("" = all of them; "assoc.rot8" / "assoc.rotf" = an association scan's
+ * rotation cache as int8 tiles / fp64 rows, "mm." = the product's panels, operands and accumulators, "mi8." = the int8 MAC's streams).  Introspection for tests
+ * and memory planning; sfg_malloc returns these buffers to the device by itself when a caller's allocation would otherwise fail between library calls. */
+int sfg_ctx_scratch_bytes(const sfg_ctx *ctx, const char *prefix, size_t *bytes);
 /* sfg_ctx_synchronize waits for every queue of the context (main, own, auxiliary key-switch queue).  It - like sfg_memcpy_d2h and the host-pointer product
  * entry points - FAILS while an encoder coefficient within 2^-50 of a rounding tie is outstanding (see sfg_ctx_encoder_near_ties): results whose
  * bit-exactness with the reference's 256-bit encoder cannot be proven do not leave the device silently. */

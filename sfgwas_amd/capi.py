@@ -32,6 +32,7 @@ def _sig(L):
         "sfg_ctx_synchronize": (i, [vp]),
         "sfg_ctx_set_stream": (i, [vp, vp]),
         "sfg_ctx_release_scratch": (i, [vp]),
+        "sfg_ctx_scratch_bytes": (i, [vp, C.c_char_p, C.POINTER(C.c_size_t)]),
         "sfg_rotcache_invalidate": (i, [vp]),
         "sfg_ctx_use_own_stream": (i, [vp]),
         "sfg_ctx_encoder_inject_unsafe_for_test": (i, [vp, C.c_ulonglong]),

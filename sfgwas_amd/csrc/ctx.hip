@@ -47,6 +47,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
     c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
     if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
+    if (const char *e = env("SFG_ASSOC_I8")) c.assoc_i8 = atoi(e) != 0;
     if (const char *e = env("SFG_ASSOC_ROTCACHE_MB")) c.assoc_cache_budget = (size_t)atoll(e) << 20;
     if (const char *e = env("SFG_KSW_BUDGET_MB")) { c.ksw_budget = (size_t)atoll(e) << 20; if (c.ksw_budget < (16ULL << 20)) c.ksw_budget = 16ULL << 20; }
     if (const char *e = env("SFG_ENC_BATCH")) { c.enc_batch = atoi(e); if (c.enc_batch < 64) c.enc_batch = 64; if (c.enc_batch > 8192) c.enc_batch = 8192; }
@@ -253,7 +254,20 @@ int sfg_ws_reserve(sfg_ctx *ctx, size_t bytes) {
     return 0;
 }
 
-extern "C" int sfg_malloc(sfg_ctx *ctx, void **p, size_t bytes) { SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMalloc(p, bytes)); return 0; }
+extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx);
+// (a caller's buffer comes before the context's kept scratch - panels, accumulators, an association scan's rotation cache: when the device is full and no
+//  library call is in progress, the pools are returned and the allocation tried once more)
+extern "C" int sfg_malloc(sfg_ctx *ctx, void **p, size_t bytes) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t err = hipMalloc(p, bytes);
+    if (err == hipErrorOutOfMemory && ctx->api_depth == 0 && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        SFG_TRY(sfg_ctx_release_scratch(ctx));
+        err = hipMalloc(p, bytes);
+    }
+    SFG_HIP(ctx, err);
+    return 0;
+}
 extern "C" int sfg_free(sfg_ctx *ctx, void *p) { SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); SFG_HIP(ctx, hipFree(p)); return 0; }
 extern "C" int sfg_memcpy_h2d(sfg_ctx *ctx, void *d, const void *s, size_t n) {
     SFG_HIP(ctx, hipSetDevice(ctx->device)); SFG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return 0;
@@ -316,6 +330,12 @@ extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx) {
     ctx->pool.clear(); ctx->pool_epoch.clear();
     for (int b = 0; b < 2; b++) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) ctx->i8_slot[b][i] = sfg_ctx::I8Slot();      // the kept transposed rot copies lived in the pool
     ctx->i8_gen++; ctx->sp_shape = -1;
+    return 0;
+}
+extern "C" int sfg_ctx_scratch_bytes(const sfg_ctx *ctx, const char *prefix, size_t *bytes) {
+    size_t n = 0; const std::string pre = prefix ? prefix : "";
+    for (const auto &kv : ctx->pool) if (kv.second.first && kv.first.rfind(pre, 0) == 0) n += kv.second.second;
+    if (bytes) *bytes = n;
     return 0;
 }
 // The int8 MAC keeps a transposed copy of a rotation-cache operand, keyed by its address, shape and a per-context generation counter that every library

@@ -23,7 +23,8 @@ int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, cons
 int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
 // mac.hip
 struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; bool i8_big = false; bool pt_digits_big = false;
-                    const int8_t *B_small = nullptr, *B_big = nullptr; int kb = 0; };   // B_*: the int8 MAC's plaintext tiles are already in place (streamed transposition, StagePack): no panel, k' = g * kb + baby   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
+                    const int8_t *B_small = nullptr, *B_big = nullptr; int kb = 0;
+                    const int8_t *A_small = nullptr, *A_big = nullptr; };   // A_*: the transposed rot tiles of this launch are given (I8RotPre): no copy to look up or make   // B_*: the int8 MAC's plaintext tiles are already in place (streamed transposition, StagePack): no panel, k' = g * kb + baby   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                         int l0, int nl, int accumulate, const MacStrides &st);       // mac_i8.hip
 int launch_mac_i8_big(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
@@ -79,3 +80,17 @@ int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int
 int sfg_diag_bool(int r, int c, int dim, int index);
 // stream.hip: the call-wide rotation cache of an association scan (nullptr in *out = not applicable; caller hipFree()s)
 int assoc_build_rotcache(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, double **out);
+// A caller's baby-step rotation cache held ONLY as the int8 MAC's transposed rot tiles (round 4): one pair of buffers (35-bit moduli / 46-bit modulus) per MAC group of
+// G block rows.  The association scan multiplies one block column per batch against the cache of all its block rows: the fp64 operand form (1.86 GB per block row at
+// s = 13, 115 GB at 500 000 samples) is then only the source of the tiles - built group by group in a scratch buffer and dropped - and the scan's MAC runs on the matrix core.
+struct I8RotPre { int G = 0, nbr = 0, s = 0, L = 0; std::vector<int8_t *> As, Ab; };
+int i8_rotpre_build(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, int nbr, const std::vector<std::vector<uint8_t>> *tabs, size_t budget_bytes, const char *prefix, I8RotPre &pre);   // pre.G == 0 afterwards: not taken (fp64 path)
+void i8_rotpre_free(I8RotPre &pre);
+int matmul_resident_range_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int blk0, int blk1, uint64_t *out);
+int launch_i8_pack_rot_to(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, int K, int R, int l0, int nl, bool big, int8_t *A_out);      // mac_i8.hip
+size_t mac_i8_rot_tile_bytes(int K, int nl, int ND);
+// the rotation cache of an association scan in whichever form the context multiplies with
+struct AssocRot { double *f64 = nullptr; I8RotPre pre; };
+int assoc_build_rot(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, AssocRot &out);
+void assoc_free_rot(AssocRot &r);
+int assoc_product(sfg_ctx *ctx, const AssocRot &r, const uint64_t *A_dev, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, int nct, uint64_t *out);

@@ -339,6 +339,7 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
                 for (int t = l; t < e; t++) SFG_TRY(launch_mac_i8_big(ctx, rotf, rows_per_k * rowf, rowf, plane_of[t], pt, out, K, R, r0, Ncols, t, accumulate, sb));
                 l = e; continue;
             }
+            if (!rotf) SFG_FAIL(ctx, "sfg_mac: internal: a rot operand given as int8 tiles only reached the fp64 kernel");
             BcArgs a; a.rotf = rotf; a.pt = pt; a.out = out; a.zeros = (const u64 *)ctx->zeros_dev();
             a.rotf_k_stride = rows_per_k * rowf; a.rotf_r_stride = rowf;
             a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = st.pt_half ? N / 2 : N; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;

@@ -362,6 +362,7 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
         return launch_mac_bc(ctx, rotf, rows_per_k, pt, out, K, R, Ncols, L, accumulate, st, rotsum);
     const int N = SFG_N;
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
+    if (!rotf) SFG_FAIL(ctx, "sfg_mac: internal: a rot operand given as int8 tiles only reached the fp64 kernel");
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) return 1;
     const size_t rowf = (size_t)nplanes * N;

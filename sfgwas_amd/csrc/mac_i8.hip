@@ -130,19 +130,28 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
     const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
     const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
     const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + (size_t)(a.l0 + m) * a.pt_l_stride) + c0 + cq * 4;
+    constexpr int NI = 8;                                   // items whose loads are issued together (4 dwords each; 2, 4, 8 measured: 8 = the plain loop's time, round 4)
     for (int d = 0; d < ND; d++) {
-#pragma unroll 2
-        for (int it = 0; it < 8; it++) {
-            const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
-            unsigned w[4];
+        for (int it0 = 0; it0 < 8; it0 += NI) {
+            unsigned w[NI][4];
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int k = kq * 16 + k4 * 4 + x;
-                w[x] = (k < a.K && n < a.Ncols) ? *reinterpret_cast<const unsigned *>(src + ((size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride) * 8 + (size_t)d * H) : 0u;
+            for (int u = 0; u < NI; u++) {
+                const int item = (it0 + u) * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const int k = kq * 16 + k4 * 4 + x;
+                    const bool ok = k < a.K && n < a.Ncols;
+                    const unsigned v = *reinterpret_cast<const unsigned *>(src + (ok ? ((size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride) * 8 : (size_t)0) + (size_t)d * H);
+                    w[u][x] = ok ? v : 0u;
+                }
             }
-            unsigned o[4]; bytes_tr4(w[0], w[1], w[2], w[3], o);
 #pragma unroll
-            for (int e = 0; e < 4; e++) img[(cq * 4 + e) * 64 + ((j ^ (cq & 7)) << 2) + (k4 ^ (cq >> 3))] = o[e];
+            for (int u = 0; u < NI; u++) {
+                const int item = (it0 + u) * 8 + slot, j = item >> 2, k4 = item & 3;
+                unsigned o[4]; bytes_tr4(w[u][0], w[u][1], w[u][2], w[u][3], o);
+#pragma unroll
+                for (int e = 0; e < 4; e++) img[(cq * 4 + e) * 64 + ((j ^ (cq & 7)) << 2) + (k4 ^ (cq >> 3))] = o[e];
+            }
         }
         __syncthreads();
         for (int pc = tid >> 4; pc < I8_PD; pc += 16) {
@@ -508,6 +517,8 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if ((long long)K * ND >= 131072) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums (ND K 2^14 must stay below 2^31)");
     const int8_t *B_pre = BIG ? st.B_big : st.B_small;              // streamed transposition: the plaintext tiles are in place, k' = g * kb + baby
     if (B_pre && (K % SFG_D || !st.kb || Ncols != SFG_D)) SFG_FAIL(ctx, "sfg_mac (i8): internal: prepacked tiles need whole block rows and 91 columns");
+    const int8_t *A_pre = BIG ? st.A_big : st.A_small;             // the transposed rot tiles of exactly this launch, made by launch_i8_pack_rot_to (I8RotPre)
+    if (A_pre && (B_pre || r0 != 0 || R > 32)) SFG_FAIL(ctx, "sfg_mac (i8): internal: given rot tiles cover one block of <= 32 rows, with the plaintext panel");
     const int K_rot = K;                                            // rows of the rot operand
     if (B_pre) K = K / SFG_D * st.kb;
     I8Args a; a.kb = B_pre ? st.kb : 0;
@@ -521,8 +532,8 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     const u64 sig[8] = {ctx->i8_gen, (u64)K | (u64)a.kb << 32, (u64)R, (u64)r0, (u64)l0 << 8 | (u64)nl, (u64)plane0, (u64)rotf_k_stride, (u64)rotf_r_stride};
     sfg_ctx::I8Slot *slots = ctx->i8_slot[BIG ? 1 : 0];
     int slot = -1;
-    for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) if (slots[i].src == (const void *)rotf && !memcmp(slots[i].sig, sig, sizeof sig)) slot = i;
-    const bool repack = slot < 0;
+    if (!A_pre) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) if (slots[i].src == (const void *)rotf && !memcmp(slots[i].sig, sig, sizeof sig)) slot = i;
+    const bool repack = slot < 0 && !A_pre;
     char nm[24];
     if (repack) {
         // victim: a copy of a stale generation (a product's earlier group), else an unused slot if the HBM takes another copy, else the least recently used one
@@ -540,15 +551,18 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
         }
         if (slot < 0) slot = lru;
     }
-    snprintf(nm, sizeof nm, BIG ? "mi8.Ab%d" : "mi8.A%d", slot);
-    SFG_TRY(sfg_scratch(ctx, nm, nA, (void **)&a.A));
-    if (repack) { slots[slot].src = (const void *)rotf; memcpy(slots[slot].sig, sig, sizeof sig); }
-    slots[slot].last_use = ++ctx->i8_clock;
+    if (A_pre) a.A = const_cast<int8_t *>(A_pre);
+    else {
+        snprintf(nm, sizeof nm, BIG ? "mi8.Ab%d" : "mi8.A%d", slot);
+        SFG_TRY(sfg_scratch(ctx, nm, nA, (void **)&a.A));
+        if (repack) { slots[slot].src = (const void *)rotf; memcpy(slots[slot].sig, sig, sizeof sig); }
+        slots[slot].last_use = ++ctx->i8_clock;
+    }
     if (B_pre) a.B = const_cast<int8_t *>(B_pre);
     else SFG_TRY(sfg_scratch(ctx, !ctx->cfg.stage_pack ? "mi8.B" : BIG ? "mi8.Bb" : "mi8.Bs", nB, (void **)&a.B));        // (with the streamed transposition on: the buffers of the streamed tiles, a launch uses them one way or the other)
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
     // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers)
-    if (!repack && ctx->pool[nm].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
+    if (!A_pre && !repack && ctx->pool[nm].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
     const double tile = 1024.0;
     if (repack) { PhaseTimer t(ctx, "mac_i8_pack_rot");
       hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * ND * 1024, ctx->stream, a);
@@ -575,6 +589,21 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       hipLaunchKernelGGL(k_i8_untile, dim3((unsigned)((size_t)nl * (H / 16) * 2 * a.njt * 2)), dim3(256), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
       t.stop(1, (double)nl * N * (double)Ncols * std::min(32, R - r0) * 8.0 * (accumulate ? 3.0 : 2.0)); }
+    return 0;
+}
+// the transposed rot tiles of one MAC group into a caller's buffer (mac_i8_rot_tile_bytes(K, nl, ND) bytes): rows [0, R) of every k-slice, R <= 32
+size_t mac_i8_rot_tile_bytes(int K, int nl, int ND) { return (size_t)nl * SFG_N * (((size_t)K + 63) / 64) * 2 * ND * 1024; }
+int launch_i8_pack_rot_to(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, int K, int R, int l0, int nl, bool big, int8_t *A_out) {
+    if (R > 32 || (big && nl != 1)) SFG_FAIL(ctx, "i8 rot tiles: internal: at most 32 rows, one 46-bit modulus per buffer");
+    I8Args a; memset(&a, 0, sizeof a);
+    a.rotf = rotf; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride; a.K = K; a.R = R; a.r0 = 0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
+    a.nch = (K + 63) / 64; a.kb = 0; a.A = A_out;
+    const int N = SFG_N;
+    PhaseTimer t(ctx, "mac_i8_pack_rot");
+    if (big) hipLaunchKernelGGL(k_i8_pack_rot<6>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * 6 * 1024, ctx->stream, a);
+    else hipLaunchKernelGGL(k_i8_pack_rot<5>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * 5 * 1024, ctx->stream, a);
+    SFG_HIP(ctx, hipGetLastError());
+    t.stop(1);
     return 0;
 }
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,

@@ -307,8 +307,12 @@ static int build_rot_row_tab(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int n
 // acc_dev: [(j - j0)][giant < d][i < s][2][L][N] canonical residues (zero-initialised here unless accumulate != 0)
 // for operand block rows [b0, b1) and block columns [j0, j1).
 static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, const Shape &sh, unsigned flags,
-                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc, const double *rotf_pre = nullptr, const double *rotsum_pre = nullptr) {
+                             int b0, int b1, int j0, int j1, int accumulate, u64 *acc, const double *rotf_pre = nullptr, const double *rotsum_pre = nullptr,
+                             const I8RotPre *pre8 = nullptr) {
     const int N = SFG_N, d = SFG_D, L = max_level;
+    if (pre8 && (rotf_pre || !mac_use_dma(ctx) || b0 != 0 || b1 != pre8->nbr || sh.nbr != pre8->nbr || s != pre8->s || L != pre8->L))
+        SFG_FAIL(ctx, "matmul: internal: the int8 rot tiles were built for another product (block rows %d, s = %d, level %d)", pre8->nbr, pre8->s, pre8->L);
+    const bool rot_ext = rotf_pre || pre8;                  // the caller holds the rotations of every block row
     const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "matmul: max_level out of range");
     if (nl < L) SFG_FAIL(ctx, "matmul: input level %d has fewer than max_level = %d moduli", in_level, max_level);
@@ -328,7 +332,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         // need a 43 (65) GB plaintext panel and, for the pipelined rotation caches, 2 x 34.5 (52) GB of operands: taken only when that fits beside what is resident
         // (not for a single block column against a caller's rotation cache - the association scan: fewer launches save a few accumulator passes there, and the
         //  larger panel competes with the 115 GB cache for HBM: measured 0.49 s instead of 0.31 s per batch)
-        if (ctx->cfg.mm_group_auto && b1 - b0 > G && (j1 - j0 >= 4 || !rotf_pre)) {
+        if (pre8) G = pre8->G;
+        else if (ctx->cfg.mm_group_auto && b1 - b0 > G && (j1 - j0 >= 4 || !rotf_pre)) {
             std::vector<int> po, ib; const int npl = mac_dma_planes(ctx, L, po, ib);
             size_t have = 0, total = 0;
             if (npl > 0 && hipMemGetInfo(&have, &total) == hipSuccess) {
@@ -365,16 +370,16 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         for (const auto &kv : ctx->pool) if (kv.first.rfind("mi8.A", 0) == 0) held += kv.second.second;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) keep_all = fr + held >= ngr * per + mac_i8_stream_bytes(G * d, nsm, 5, 0) + ctx->cfg.i8_keep_reserve;     // (the panel, accumulators and key-switch scratch of the call are still to be allocated the first time)
     }
-    const bool use_i8 = dma && ctx->cfg.mac_i8 && packed_mask && ((b1 - b0 + G - 1) / G <= 2 || j1 - j0 >= 4 || keep_all);
-    const bool use_i8_big = use_i8 && ctx->cfg.mac_i8_big;                    // the 46-bit modulus too: six digit planes, its own pair of transposed rot copies
+    const bool use_i8 = pre8 || (dma && ctx->cfg.mac_i8 && packed_mask && ((b1 - b0 + G - 1) / G <= 2 || j1 - j0 >= 4 || keep_all));
+    const bool use_i8_big = pre8 || (use_i8 && ctx->cfg.mac_i8_big);                    // the 46-bit modulus too: six digit planes, its own pair of transposed rot copies
     const size_t grp_slices = (size_t)G * d + 3;            // k-slices of one group's fp64 rotation cache (+ 3: see launch_mac_dma)
-    const bool pipelined = dma && !rotf_pre && b1 - b0 > G && !ctx->cfg.no_overlap;
+    const bool pipelined = dma && !rot_ext && b1 - b0 > G && !ctx->cfg.no_overlap;
     SFG_TRY(sfg_scratch(ctx, "mm.a_row", (size_t)s * ctw * 8, (void **)&a_row));
     SFG_TRY(sfg_scratch(ctx, "mm.rotc", dma ? 8 : (size_t)d * s * ctw * 8, (void **)&rotc));     // u64 rotation cache: only the register-staged MAC reads one
     // Two plaintext panels when the encode of launch k + 1 runs on its own queue beside the transposition + MAC of launch k (fp64-issue bound beside HBM bound)
     const bool enc_ov = dma && !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G - 1) / G) * (j1 - j0) >= 2;
     // where every modulus multiplies on the int8 matrix core from streamed tiles, the panel serves only the rare launches that cannot stream: Gp block rows of it
-    const bool streamable = use_i8 && use_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc_ov;
+    const bool streamable = use_i8 && use_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc_ov && !pre8;
     const int Gp = streamable ? std::min(G, 4) : G;
     const size_t panel_words = (size_t)Gp * nplain * L * prow;
     SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov ? 2 : 1), (void **)&pt));
@@ -386,8 +391,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         rowf = (size_t)nplanes * N;
-        if (!rotf_pre) SFG_TRY(sfg_scratch(ctx, "mm.rotf", grp_slices * s * 2 * rowf * 8 * (pipelined ? 2 : 1), (void **)&rotf));
-        if (!rotf_pre && packed_mask) SFG_TRY(sfg_scratch(ctx, "mm.rotsum", (size_t)2 * s * 2 * rowf * 8, (void **)&rotsum));     // one per ring half
+        if (!rot_ext) SFG_TRY(sfg_scratch(ctx, "mm.rotf", grp_slices * s * 2 * rowf * 8 * (pipelined ? 2 : 1), (void **)&rotf));
+        if (!rot_ext && packed_mask) SFG_TRY(sfg_scratch(ctx, "mm.rotsum", (size_t)2 * s * 2 * rowf * 8, (void **)&rotsum));     // one per ring half
     }
     const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
@@ -419,6 +424,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
         const double *rotf_grp = rotf, *rotsum_grp = rotsum;
         if (rotf_pre) { rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf; rotsum_grp = rotsum_pre ? rotsum_pre + (size_t)gi * s * 2 * rowf : nullptr; }
+        else if (pre8) { rotf_grp = nullptr; rotsum_grp = nullptr; }            // group gi multiplies from pre8->As[gi] / Ab[gi]
         else if (pipelined) {
             if (bg + G < b1) {                                                   // next group: its half was last read by group gi-1
                 SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));
@@ -538,12 +544,13 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 PhaseTimer t(ctx, "mac");
                 MacStrides st;
                 if (stream) { st.B_small = sp.Bs; st.B_big = sp.Bb; st.kb = sp.kb; }
+                if (pre8) { st.A_small = pre8->As[gi]; st.A_big = pre8->Ab[gi]; }
                 st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
                 st.pt_k = plw; st.pt_n = (size_t)gs * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
                 st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
                 const int acc_flag = (accumulate || !first_group || sub0 > 0) ? 1 : 0;      // the first (sub-)launch of a fresh call overwrites
                 u64 *accj = acc + (size_t)(bj - j0) * d * accw;
-                if (dma) rc = launch_mac_dma(ctx, rotf_grp + (size_t)sub0 * d * s * 2 * rowf, (size_t)s * 2, pt, accj, gs * d, 2 * s, d, L, acc_flag, st, rotsum_grp);
+                if (dma) rc = launch_mac_dma(ctx, pre8 ? nullptr : rotf_grp + (size_t)sub0 * d * s * 2 * rowf, (size_t)s * 2, pt, accj, gs * d, 2 * s, d, L, acc_flag, st, rotsum_grp);
                 else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
                 t.stop(1);
             }
@@ -627,10 +634,10 @@ extern "C" int sfg_matmul_finalize_slots_dev(sfg_ctx *ctx, const uint64_t *acc, 
 
 // SNP-block range [blk0, blk1) over the block columns of the STORED matrix: output columns for X, contraction rows for X^T
 static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags,
-                                 int blk0, int blk1, uint64_t *out, const double *rotf_ext) {
+                                 int blk0, int blk1, uint64_t *out, const double *rotf_ext, const I8RotPre *pre8 = nullptr) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->phases.clear();
-    if (!rotf_ext) ctx->i8_gen++;                               // a product that builds its own rot operands: whatever the int8 MAC had transposed is stale
+    if (!rotf_ext && !pre8) ctx->i8_gen++;                               // a product that builds its own rot operands: whatever the int8 MAC had transposed is stale
     Shape sh = make_shape(g, flags);
     const int d = SFG_D, L = max_level, N = SFG_N;
     const size_t accw = (size_t)s * 2 * L * N;
@@ -646,7 +653,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
     // ciphertext).  When the whole cache fits (48 GiB; Q*X at 100k x 1M: 13 block rows = 28 GB) it is built once here.
     const double *rotf_all = rotf_ext, *rotsum_all = nullptr;
     if (rotf_ext && !mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
-    if (!rotf_ext && mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
+    if (!rotf_ext && !pre8 && mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
         const size_t rowf = (size_t)nplanes * N, per_row = (size_t)d * s * 2 * rowf;       // doubles per block row
@@ -674,7 +681,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
     }
     // With the product-wide cache the accumulate passes do no key switching, so the giant-step alignment of pass k runs on the
     // auxiliary stream beside the encode + MAC of pass k+1 (two accumulator buffers of half the budget each).
-    const bool overlap = rotf_all && !ctx->cfg.no_overlap;
+    const bool overlap = (rotf_all || pre8) && !ctx->cfg.no_overlap;
     if (overlap) { jg = (jg + 1) / 2; }
     hipStream_t main_stream = ctx->stream;
     int k = 0;
@@ -686,7 +693,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
             acc += (size_t)(k & 1) * jg * d * accw;
             if (k >= 2) SFG_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pipe[2 + (k & 1)], 0));    // pass k-2 has been aligned out of this buffer
         }
-        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc, rotf_all, rotsum_all);
+        int rc = matmul_accumulate(ctx, (const u64 *)A, s, in_level, max_level, sh, flags, b0, b1, ja, jb, 0, acc, rotf_all, rotsum_all, pre8);
         if (rc) return rc;
         if (overlap) {
             SFG_TRY(sfg_stream_after(ctx, ctx->aux_stream, main_stream));
@@ -797,6 +804,58 @@ int rotcache_build_rows_tab(sfg_ctx *ctx, const u64 *A, int s, int in_level, int
 extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int s, int in_level, int max_level, int nbr, int b0, int b1, double *cache) {
     ApiScope api_scope(ctx);
     return rotcache_build_rows_tab(ctx, (const u64 *)A, s, in_level, max_level, nbr, b0, b1, nullptr, cache);
+}
+// ---- the same cache held only as the int8 MAC's rot tiles (I8RotPre, kernels.hpp).  Built group by group: the fp64 operand rows of G block rows go through the
+// product's own mm.rotf scratch, k_i8_pack_rot turns them into the group's tile buffers.  pre.G stays 0 (and nothing is held) when the context does not multiply
+// every modulus on the int8 matrix core, the rows do not fit one row tile pair (2 s > 32) or the tiles do not fit the budget / the device.
+// (the tile buffers are scratch entries "<prefix>.s<gi>" / "<prefix>.b<gi>" of the context: a scan's next call finds them in place - hipMalloc / hipFree of ~100 GB cost
+//  0.2 to 3.3 s per call, measured - and they go back to the device like every kept buffer: under memory pressure from a later call, or sfg_ctx_release_scratch)
+void i8_rotpre_free(I8RotPre &pre) { pre = I8RotPre(); }
+int i8_rotpre_build(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, int nbr, const std::vector<std::vector<uint8_t>> *tabs, size_t budget_bytes, const char *prefix, I8RotPre &pre) {
+    pre = I8RotPre();
+    const int d = SFG_D, L = max_level;
+    const auto &c = ctx->cfg;
+    if (!c.assoc_i8 || !mac_use_dma(ctx) || !c.mac_bc || c.mac_plain_pt || !c.mac_i8 || !c.mac_i8_big || 2 * s > 32 || L < 1 || L > ctx->nq || nbr < 1) return 0;
+    if (!mac_dma_packed_mask(ctx, L)) return 0;
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) { ctx->err.clear(); return 0; }
+    // launch_mac_bc multiplies run by run of like moduli: one run of 35-bit moduli and at most one 46-bit modulus have one tile buffer each
+    int l_big = -1, l_s0 = -1, n_s = 0, runs = 0;
+    for (int l = 0; l < L; l++) {
+        if (is_big[l]) { if (l_big >= 0) return 0; l_big = l; }
+        else { if (l_s0 < 0) l_s0 = l; n_s++; if (l == 0 || is_big[l - 1]) runs++; }
+    }
+    if (runs != 1) return 0;
+    const size_t rowf = (size_t)nplanes * SFG_N;
+    const int G = std::min(c.mm_group, nbr), ngrp = (nbr + G - 1) / G;
+    if ((long long)G * d * 6 >= 131072) return 0;
+    size_t total = 0;
+    for (int gi = 0; gi < ngrp; gi++) { const int ng = std::min(G, nbr - gi * G); total += mac_i8_rot_tile_bytes(ng * d, n_s, 5) + (l_big >= 0 ? mac_i8_rot_tile_bytes(ng * d, 1, 6) : 0); }
+    if (total > budget_bytes) return 0;
+    double *tmp = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)G * d + 3) * s * 2 * rowf * 8, (void **)&tmp));
+    pre.As.assign(ngrp, nullptr); pre.Ab.assign(ngrp, nullptr);
+    for (int gi = 0; gi < ngrp; gi++) {
+        const int bg = gi * G, ng = std::min(G, nbr - bg);
+        char nm[48];
+        snprintf(nm, sizeof nm, "%s.s%d", prefix, gi);
+        int arc = sfg_scratch(ctx, nm, mac_i8_rot_tile_bytes(ng * d, n_s, 5), (void **)&pre.As[gi]);
+        if (!arc && l_big >= 0) { snprintf(nm, sizeof nm, "%s.b%d", prefix, gi); arc = sfg_scratch(ctx, nm, mac_i8_rot_tile_bytes(ng * d, 1, 6), (void **)&pre.Ab[gi]); }
+        if (arc) { ctx->err.clear(); i8_rotpre_free(pre); return 0; }              // no room even without the buffers of earlier calls: the caller falls back
+        std::vector<std::vector<uint8_t>> sub;
+        if (tabs) sub.assign(tabs->begin() + bg, tabs->begin() + bg + ng);
+        int rc = rotcache_build_rows_tab(ctx, A, s, in_level, max_level, nbr, bg, bg + ng, tabs ? &sub : nullptr, tmp);
+        if (!rc) rc = launch_i8_pack_rot_to(ctx, tmp, (size_t)s * 2 * rowf, rowf, plane_of[l_s0], ng * d, 2 * s, l_s0, n_s, false, pre.As[gi]);
+        if (!rc && l_big >= 0) rc = launch_i8_pack_rot_to(ctx, tmp, (size_t)s * 2 * rowf, rowf, plane_of[l_big], ng * d, 2 * s, l_big, 1, true, pre.Ab[gi]);
+        if (rc) { i8_rotpre_free(pre); return rc; }
+    }
+    pre.G = G; pre.nbr = nbr; pre.s = s; pre.L = L;
+    return 0;
+}
+int matmul_resident_range_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int blk0, int blk1, uint64_t *out) {
+    ApiScope api_scope(ctx);
+    if (!pre.G) SFG_FAIL(ctx, "matmul: no int8 rot tiles");
+    return matmul_resident_range(ctx, nullptr, s, max_level, max_level, g, flags, blk0, blk1, out, nullptr, &pre);
 }
 // GetDiagBool (matmult.go:627-631) for other translation units
 int sfg_diag_bool(int r, int c, int dim, int index) { return diag_bool(r, c, dim, index); }

@@ -362,8 +362,8 @@ extern "C" int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pge
     if (total_ct > out_ct_capacity) SFG_FAIL(ctx, "assoc_pgen: output needs %zu ciphertexts per row, capacity %zu", total_ct, out_ct_capacity);
     std::vector<size_t> widths;
     for (const B &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
-    double *rotbuf = nullptr; u64 *tmp = nullptr;
-    SFG_TRY(assoc_build_rotcache(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, &rotbuf));
+    AssocRot rot; u64 *tmp = nullptr;
+    SFG_TRY(assoc_build_rot(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, rot));
     int rc = 0;
     if (hipMalloc(&tmp, (size_t)s * ((max_kept + slots - 1) / slots) * ctw * 8) != hipSuccess) { ctx->err = "assoc_pgen: out of device memory"; rc = 1; }
     size_t out_shift = 0;
@@ -373,8 +373,7 @@ extern "C" int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pge
         rc = sfg_geno_from_pgen(ctx, pgen_host, pgen_bytes, b.v0, b.v1, row_filter, col_filter ? col_filter + b.v0 : nullptr, &g);
         if (rc) break;
         const size_t nct = (b.kept + slots - 1) / slots;
-        rc = rotbuf ? sfg_matmul_resident_range_rc_dev(ctx, rotbuf, s, max_level, g, flags, 0, (int)nct, (uint64_t *)tmp)
-                    : sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, g, flags, (uint64_t *)tmp);
+        rc = assoc_product(ctx, rot, A_dev, s, in_level, max_level, g, flags, (int)nct, (uint64_t *)tmp);
         for (int i = 0; i < s && !rc; i++)
             if (hipMemcpyAsync(out_dev + ((size_t)i * out_ct_capacity + out_shift) * ctw, tmp + (size_t)i * nct * ctw, nct * ctw * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { ctx->err = "assoc_pgen: copy failed"; rc = 1; }
         if (!rc && (sum_host || sqsum_host)) {
@@ -386,6 +385,6 @@ extern "C" int sfg_assoc_pgen(sfg_ctx *ctx, const uint8_t *pgen_host, size_t pge
         out_shift += nct;
     }
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp); (void)hipFree(rotbuf);
+    (void)hipFree(tmp); assoc_free_rot(rot);
     return rc;
 }

@@ -16,6 +16,7 @@
 // same bits; 1.86 GB per block row at s = 13: 115 GB for 500 000 samples) and every batch multiplies against it (SFG_ASSOC_ROTCACHE_MB=0 restores the
 // per-batch rebuild; a cache that exceeds the budget falls back to it).
 #include "common.hpp"
+#include <chrono>
 #include "kernels.hpp"
 #include "pgen.hpp"
 #include <algorithm>
@@ -68,9 +69,21 @@ struct Reader {                                        // fills pinned slot k & 
 };
 }  // namespace
 
+static void assoc_baby_tabs(size_t nr, const std::vector<size_t> &widths, std::vector<std::vector<uint8_t>> &tabs) {
+    const size_t slots = SFG_SLOTS;
+    const int nbr = (int)((nr + slots - 1) / slots);
+    tabs.assign(nbr, std::vector<uint8_t>(SFG_D, 0));
+    for (int bi = 0; bi < nbr; bi++) {
+        const int rows = (int)(std::min((size_t)(bi + 1) * slots, nr) - (size_t)bi * slots);
+        for (int shift = 0; shift < SFG_SLOTS; shift++) {
+            if (tabs[bi][shift % SFG_D]) continue;
+            for (size_t w : widths) if (sfg_diag_bool(rows, (int)w, SFG_SLOTS, -shift)) { tabs[bi][shift % SFG_D] = 1; break; }
+        }
+    }
+}
 // The baby-step rotation cache of the ciphertext matrix every batch of an association scan multiplies (see the header comment): *out = nullptr when the
 // cache is switched off, does not fit the budget or the device (the caller then lets every product build its own rotations).  widths: the distinct
-// block-column widths of the batches, for the active-baby tables (matmult.go:1326-1336).  The caller hipFree()s *out.
+// block-column widths of the batches, for the active-baby tables (matmult.go:1326-1336).  *out is the context's scratch entry "assoc.rotf" (kept for the next call).
 int assoc_build_rotcache(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, double **out) {
     *out = nullptr;
     const size_t slots = SFG_SLOTS;
@@ -80,18 +93,27 @@ int assoc_build_rotcache(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, in
     const size_t words = (size_t)nbr * s * jobw + tailw;
     if (words * 8 > ctx->cfg.assoc_cache_budget) return 0;
     double *buf = nullptr;
-    if (hipMalloc(&buf, words * 8) != hipSuccess) { (void)hipGetLastError(); return 0; }      // no room: per-batch rotations
-    std::vector<std::vector<uint8_t>> tabs(nbr, std::vector<uint8_t>(SFG_D, 0));
-    for (int bi = 0; bi < nbr; bi++) {
-        const int rows = (int)(std::min((size_t)(bi + 1) * slots, nr) - (size_t)bi * slots);
-        for (int shift = 0; shift < SFG_SLOTS; shift++) {
-            if (tabs[bi][shift % SFG_D]) continue;
-            for (size_t w : widths) if (sfg_diag_bool(rows, (int)w, SFG_SLOTS, -shift)) { tabs[bi][shift % SFG_D] = 1; break; }
-        }
-    }
-    const int rc = rotcache_build_rows_tab(ctx, A_dev, s, in_level, max_level, nbr, 0, nbr, &tabs, buf);
-    if (rc) { (void)hipFree(buf); return rc; }
+    if (sfg_scratch(ctx, "assoc.rotf", words * 8, (void **)&buf)) { ctx->err.clear(); return 0; }      // no room even without the buffers of earlier calls: per-batch rotations
+    std::vector<std::vector<uint8_t>> tabs; assoc_baby_tabs(nr, widths, tabs);
+    SFG_TRY(rotcache_build_rows_tab(ctx, A_dev, s, in_level, max_level, nbr, 0, nbr, &tabs, buf));
     *out = buf; return 0;
+}
+// The cache in the form the context multiplies with: the int8 MAC's rot tiles where every modulus runs on the matrix core (round 4: the scan's MAC leaves the
+// fp64 kernel, the cache shrinks from 1.86 to 1.3 GB per block row at s = 13), else the fp64 operand rows, else nothing (every product rotates for itself).
+int assoc_build_rot(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, AssocRot &out) {
+    out = AssocRot();
+    if (ctx->cfg.assoc_cache_budget && ctx->cfg.assoc_i8) {
+        std::vector<std::vector<uint8_t>> tabs; assoc_baby_tabs(nr, widths, tabs);
+        SFG_TRY(i8_rotpre_build(ctx, A_dev, s, in_level, max_level, (int)tabs.size(), &tabs, ctx->cfg.assoc_cache_budget, "assoc.rot8", out.pre));
+        if (out.pre.G) return 0;
+    }
+    return assoc_build_rotcache(ctx, A_dev, s, in_level, max_level, nr, widths, &out.f64);
+}
+void assoc_free_rot(AssocRot &r) { i8_rotpre_free(r.pre); r = AssocRot(); }        // (the buffers are the context's scratch: see i8_rotpre_free)
+int assoc_product(sfg_ctx *ctx, const AssocRot &r, const uint64_t *A_dev, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, int nct, uint64_t *out) {
+    if (r.pre.G) return matmul_resident_range_i8pre(ctx, r.pre, s, max_level, g, flags, 0, nct, out);
+    if (r.f64) return sfg_matmul_resident_range_rc_dev(ctx, r.f64, s, max_level, g, flags, 0, nct, out);
+    return sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, g, flags, out);
 }
 
 // out_dev: [s][out_ct_capacity][2][max_level][N]; *out_ct = sum over batches of ceil(kept / slots) (the width ConcatCipherMatrix would give).
@@ -155,14 +177,14 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
     int rc = 0;
     int32_t *rmap = nullptr, *cmap[2] = {nullptr, nullptr}; uint8_t *hb[2] = {nullptr, nullptr}, *db[2] = {nullptr, nullptr}, *rows[2] = {nullptr, nullptr}, *desc[2] = {nullptr, nullptr};
     int8_t *gb[2] = {nullptr, nullptr}; int *herr = nullptr;
-    double *rotbuf = nullptr;
+    AssocRot rot;
     u64 *tmp = nullptr; hipStream_t copy = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     const size_t ctw = 2 * L * N, max_ct = (max_kept + slots - 1) / slots;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(ctx->stream); if (copy) (void)hipStreamSynchronize(copy);
         for (int i = 0; i < 2; i++) { (void)hipHostFree(hb[i]); (void)hipFree(db[i]); (void)hipFree(gb[i]); (void)hipFree(cmap[i]); (void)hipFree(rows[i]); (void)hipFree(desc[i]);
             if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_free[i]) (void)hipEventDestroy(ev_free[i]); }
-        (void)hipFree(rmap); (void)hipFree(tmp); (void)hipFree(rotbuf); (void)hipHostFree(herr); if (copy) (void)hipStreamDestroy(copy); close(fd);
+        (void)hipFree(rmap); (void)hipFree(tmp); assoc_free_rot(rot); (void)hipHostFree(herr); if (copy) (void)hipStreamDestroy(copy); close(fd);
     };
 #define ST_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; snprintf(_b, sizeof _b, "%s: %s failed: %s", who, #call, hipGetErrorString(_e)); ctx->err = _b; rc = 1; } } while (0)
     ST_HIP(hipMalloc(&rmap, num_sample * sizeof(int32_t)));
@@ -181,14 +203,16 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
     }
     if (rc) { cleanup(); return rc; }
+    const bool trace = getenv("SFG_ASSOC_TRACE") != nullptr;       // (debug: wall times of the cache build and of every batch's product, each synchronised)
     // ---- the baby-step rotation cache of `mat`, once for all batches of the call
-    const double *rotcache = nullptr;
     {
         std::vector<size_t> widths;
         for (const Batch &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
-        rc = assoc_build_rotcache(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, &rotbuf);
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = assoc_build_rot(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, rot);
         if (rc) { cleanup(); return rc; }
-        rotcache = rotbuf;
+        if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[assoc] rotation cache (%s): %.1f ms\n", rot.pre.G ? "int8 tiles" : rot.f64 ? "fp64 rows" : "none",
+                                                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
     }
     Reader rd; rd.fd = fd; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
     std::thread reader([&rd] { rd.run(); });
@@ -221,8 +245,10 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
         ST_HIP(hipStreamWaitEvent(ctx->stream, ev_ready[sl], 0));
         sfg_geno g; g.dev = gb[sl]; g.nrow = nr; g.ncol = b.kept; g.ld = b.kept; g.owned = false;
         const size_t nct = (b.kept + slots - 1) / slots;
-        if (!rc) rc = rotcache ? sfg_matmul_resident_range_rc_dev(ctx, rotcache, s, max_level, &g, flags, 0, (int)nct, (uint64_t *)tmp)
-                               : sfg_matmul_resident_dev(ctx, A_dev, s, in_level, max_level, &g, flags, (uint64_t *)tmp);
+        const auto tb = std::chrono::steady_clock::now();
+        if (!rc) rc = assoc_product(ctx, rot, A_dev, s, in_level, max_level, &g, flags, (int)nct, (uint64_t *)tmp);
+        if (trace) { const double t_enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count(); (void)hipStreamSynchronize(ctx->stream);
+                     fprintf(stderr, "[assoc] batch %zu: enqueued in %.1f ms, done after %.1f ms\n", k, t_enq, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count()); }
         for (int i = 0; i < s && !rc; i++)
             ST_HIP(hipMemcpyAsync(out_dev + ((size_t)i * out_ct_capacity + out_shift) * ctw, tmp + (size_t)i * nct * ctw, nct * ctw * 8, hipMemcpyDeviceToDevice, ctx->stream));
         if (!rc && (sum_host || sqsum_host)) {

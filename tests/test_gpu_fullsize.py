@@ -313,6 +313,43 @@ def test_c5_batch_500000x8192_square_s13_and_s1(env):
     env.ctx.geno_free(g)
 
 
+def test_c5_streamed_bed_batches_on_the_int8_rot_tiles_equal_the_resident_products(env, tmp_path):
+    """configs[4] as sfg_assoc_stream_bed runs it (assoc.go:371-416): 500 000 individuals, s = 13, two batches (2048 and 952 kept SNPs) streamed from a .bed.
+    The call keeps the baby-step rotation cache of all 62 block rows as the int8 MAC's rot tiles (round 4: 8 MAC groups of 8, 8, ..., 6 block rows, the last
+    block row ragged) and multiplies every batch from them; each batch must equal, word for word, MatMult4Stream of the same ciphertexts with the decoded batch
+    resident - the product path the test above holds against the oracle (its own rotations, transposed per launch)."""
+    capi = env.capi
+    n_ind, nsnp, batch, s = 500_000, 3000, 2048, 13
+    bps = n_ind // 4
+    rnd = np.random.default_rng(0xBED5)
+    raw = rnd.integers(0, 256, (nsnp, bps), dtype=np.uint8)
+    path = str(tmp_path / "c5.bed")
+    with open(path, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01])); f.write(raw.tobytes())
+    nbr = (n_ind - 1) // SLOTS + 1
+    env.ctx.check(capi.lib().sfg_ctx_release_scratch(env.ctx.h), "release_scratch")
+    A = env.ctx.fill_uniform_cts(s * nbr, LEVEL, 0xA550C)
+    out = capi.DevArray(env.ctx, (s, 2, 2, L, N))
+    got = C.c_size_t()
+    env.ctx.check(capi.lib().sfg_assoc_stream_bed(env.ctx.h, path.encode(), n_ind, nsnp, None, None, batch, A.p, s, LEVEL, L, 0, out.p, 2, C.byref(got), None, None), "assoc_stream_bed")
+    assert got.value == 2
+    kept = C.c_size_t()
+    env.ctx.check(capi.lib().sfg_ctx_scratch_bytes(env.ctx.h, b"assoc.rot8", C.byref(kept)), "scratch_bytes")
+    assert kept.value > 60 << 30, "the scan did not keep its rotation cache as int8 tiles"
+    h = out.host()
+    lut = np.array([2, -1, 1, 0], dtype=np.int8)                                  # 2-bit code -> dosage (scripts/plinkBedToBinary.py:18-27)
+    for b, (a0, a1) in enumerate([(0, batch), (batch, nsnp)]):
+        geno = np.empty((n_ind, a1 - a0), dtype=np.int8)
+        for k in range(4):
+            geno[k::4] = lut[(raw[a0:a1] >> (2 * k)) & 3].T
+        g = env.ctx.geno_upload(geno)
+        want = env.ctx.matmul_resident(A, s, LEVEL, L, g)
+        assert np.array_equal(h[:, b:b + 1], want.host()), f"batch {b}: streamed product on the int8 rot tiles differs from the resident product"
+        want.free(); env.ctx.geno_free(g)
+    A.free(); out.free()
+    env.ctx.check(capi.lib().sfg_ctx_release_scratch(env.ctx.h), "release_scratch")
+
+
 # --------------------------------------------------------------------------- configs[3]: 100 000 x 1 000 000 on one GPU
 # Digests of bench.py's c4 outputs (seed 0x5F6A genotypes, 0xC1F3 / 0xD2A7_0000 ciphertexts, 0xBEEF keys): identical in BENCH_r02.json (fp64 MAC,
 # 8 block rows per launch), BENCH_r03.json (int8 matrix-core MAC, memory-chosen groups) and every profiles/r0*_bench_c4_* line.
