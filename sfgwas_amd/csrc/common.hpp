@@ -139,6 +139,7 @@ struct sfg_ctx {
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
     std::map<std::string, std::pair<void *, size_t>> pool;   // named grow-only device scratch (sfg_scratch), freed with the context
+    std::map<std::string, std::pair<void *, size_t>> host_pool;   // named grow-only PINNED host scratch (sfg_host_scratch): the streamed scan's two file slots; freed with the context and by sfg_ctx_release_scratch
     std::map<std::string, unsigned long long> pool_epoch;    // the top-level call (ApiScope) that last asked for the buffer: when the device is full, buffers no call in progress uses are given back
     unsigned long long api_epoch = 0; int api_depth = 0;
     std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
@@ -195,6 +196,7 @@ struct AuxScope {
 int sfg_stream_after(sfg_ctx *ctx, hipStream_t waiter, hipStream_t signaller);
 // named grow-only scratch buffers owned by the context (avoids hipMalloc/hipFree of multi-GB buffers per call)
 int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out);
+int sfg_host_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out);     // pinned host memory, same keeping rules
 // reads back all pending phase events (one stream sync); called by the phase query functions and at API exits
 void sfg_phases_resolve(sfg_ctx *ctx);
 

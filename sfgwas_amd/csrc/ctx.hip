@@ -176,6 +176,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     if (ctx->user_stream) (void)hipStreamSynchronize(ctx->user_stream);
     sfg_phases_resolve(ctx);
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
+    for (auto &kv : ctx->host_pool) (void)hipHostFree(kv.second.first);
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
     (void)hipFree(ctx->ws); (void)hipFree(ctx->tie_count_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -328,8 +329,23 @@ extern "C" int sfg_ctx_release_scratch(sfg_ctx *ctx) {
     SFG_TRY(sfg_sync_all(ctx));
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);
     ctx->pool.clear(); ctx->pool_epoch.clear();
+    for (auto &kv : ctx->host_pool) (void)hipHostFree(kv.second.first);
+    ctx->host_pool.clear();
     for (int b = 0; b < 2; b++) for (int i = 0; i < sfg_ctx::I8_SLOTS; i++) ctx->i8_slot[b][i] = sfg_ctx::I8Slot();      // the kept transposed rot copies lived in the pool
     ctx->i8_gen++; ctx->sp_shape = -1;
+    return 0;
+}
+// pinned host scratch: a streamed scan reads its file through two slots of one batch each (1 GB at 500 000 samples x 8192 SNPs); pinning them costs ~0.2 s per
+// GB and call, so they are kept like the device pools
+int sfg_host_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out) {
+    auto &e = ctx->host_pool[name];
+    if (e.second < bytes) {
+        if (e.first) { SFG_TRY(sfg_sync_all(ctx)); SFG_HIP(ctx, hipHostFree(e.first)); }
+        e.first = nullptr; e.second = 0;
+        SFG_HIP(ctx, hipHostMalloc(&e.first, bytes, hipHostMallocDefault));
+        e.second = bytes;
+    }
+    *out = e.first;
     return 0;
 }
 extern "C" int sfg_ctx_scratch_bytes(const sfg_ctx *ctx, const char *prefix, size_t *bytes) {

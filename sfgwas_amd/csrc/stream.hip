@@ -180,42 +180,46 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
     AssocRot rot;
     u64 *tmp = nullptr; hipStream_t copy = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     const size_t ctw = 2 * L * N, max_ct = (max_kept + slots - 1) / slots;
+    // every buffer of the call is scratch of the context (device pool / pinned host pool): the next call of the scan - gWY makes four per block - finds them in place
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(ctx->stream); if (copy) (void)hipStreamSynchronize(copy);
-        for (int i = 0; i < 2; i++) { (void)hipHostFree(hb[i]); (void)hipFree(db[i]); (void)hipFree(gb[i]); (void)hipFree(cmap[i]); (void)hipFree(rows[i]); (void)hipFree(desc[i]);
-            if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_free[i]) (void)hipEventDestroy(ev_free[i]); }
-        (void)hipFree(rmap); (void)hipFree(tmp); assoc_free_rot(rot); (void)hipHostFree(herr); if (copy) (void)hipStreamDestroy(copy); close(fd);
+        for (int i = 0; i < 2; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_free[i]) (void)hipEventDestroy(ev_free[i]); }
+        assoc_free_rot(rot); if (copy) (void)hipStreamDestroy(copy); close(fd);
     };
 #define ST_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; snprintf(_b, sizeof _b, "%s: %s failed: %s", who, #call, hipGetErrorString(_e)); ctx->err = _b; rc = 1; } } while (0)
-    ST_HIP(hipMalloc(&rmap, num_sample * sizeof(int32_t)));
+    const auto t_call = std::chrono::steady_clock::now();
+    rc = sfg_scratch(ctx, "assoc.rmap", num_sample * sizeof(int32_t), (void **)&rmap);
     if (!rc) ST_HIP(hipMemcpy(rmap, rmap_h.data(), num_sample * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (!rc) ST_HIP(hipMalloc(&tmp, (size_t)s * max_ct * ctw * 8));
+    if (!rc) rc = sfg_scratch(ctx, "assoc.tmp", (size_t)s * max_ct * ctw * 8, (void **)&tmp);
     if (!rc) ST_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-    if (!rc && fmt == FMT_PGEN) ST_HIP(hipHostMalloc((void **)&herr, 2 * sizeof(int), hipHostMallocDefault));
+    if (!rc && fmt == FMT_PGEN) rc = sfg_host_scratch(ctx, "assoc.herr", 2 * sizeof(int), (void **)&herr);
     for (int i = 0; i < 2 && !rc; i++) {
-        ST_HIP(hipHostMalloc((void **)&hb[i], max_bytes + 8192, hipHostMallocDefault));       // + the alignment slack of O_DIRECT ranges
-        if (!rc) ST_HIP(hipMalloc(&db[i], max_bytes + 16));
-        if (!rc) ST_HIP(hipMalloc(&gb[i], nr * max_kept));
-        if (!rc) ST_HIP(hipMalloc(&cmap[i], max_nsnp * sizeof(int32_t)));
-        if (!rc && fmt == FMT_PGEN) { ST_HIP(hipMalloc(&rows[i], max_rows * pitch)); if (!rc) ST_HIP(hipMalloc(&desc[i], pgen_desc_bytes(max_rows))); }
+        const std::string sx = std::to_string(i);
+        rc = sfg_host_scratch(ctx, ("assoc.hb" + sx).c_str(), max_bytes + 8192, (void **)&hb[i]);       // + the alignment slack of O_DIRECT ranges
+        if (!rc) rc = sfg_scratch(ctx, ("assoc.db" + sx).c_str(), max_bytes + 16, (void **)&db[i]);
+        if (!rc) rc = sfg_scratch(ctx, ("assoc.gb" + sx).c_str(), nr * max_kept, (void **)&gb[i]);
+        if (!rc) rc = sfg_scratch(ctx, ("assoc.cmap" + sx).c_str(), max_nsnp * sizeof(int32_t), (void **)&cmap[i]);
+        if (!rc && fmt == FMT_PGEN) { rc = sfg_scratch(ctx, ("assoc.rows" + sx).c_str(), max_rows * pitch, (void **)&rows[i]); if (!rc) rc = sfg_scratch(ctx, ("assoc.desc" + sx).c_str(), pgen_desc_bytes(max_rows), (void **)&desc[i]); }
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
     }
     if (rc) { cleanup(); return rc; }
     const bool trace = getenv("SFG_ASSOC_TRACE") != nullptr;       // (debug: wall times of the cache build and of every batch's product, each synchronised)
+    if (trace) fprintf(stderr, "[assoc] buffers: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+    // the reader fills the first two slots while the rotation cache is built
+    Reader rd; rd.fd = fd; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
+    std::thread reader([&rd] { rd.run(); });
     // ---- the baby-step rotation cache of `mat`, once for all batches of the call
     {
         std::vector<size_t> widths;
         for (const Batch &b : bt) for (size_t c0 = 0; c0 < b.kept; c0 += slots) { const size_t w = std::min(slots, b.kept - c0); if (std::find(widths.begin(), widths.end(), w) == widths.end()) widths.push_back(w); }
         const auto t0 = std::chrono::steady_clock::now();
         rc = assoc_build_rot(ctx, (const u64 *)A_dev, s, in_level, max_level, nr, widths, rot);
-        if (rc) { cleanup(); return rc; }
+        if (rc) { rd.release(bt.size() + 2); reader.join(); cleanup(); return rc; }
         if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[assoc] rotation cache (%s): %.1f ms\n", rot.pre.G ? "int8 tiles" : rot.f64 ? "fp64 rows" : "none",
                                                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
     }
-    Reader rd; rd.fd = fd; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;
-    std::thread reader([&rd] { rd.run(); });
     std::vector<int32_t> cmap_h(max_nsnp);
     size_t out_shift = 0;
     for (size_t k = 0; k < bt.size() && !rc; k++) {
@@ -262,7 +266,10 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
 #undef ST_HIP
     if (rc) rd.release(bt.size() + 2);                             // let the reader run out
     reader.join();
+    const auto t_end = std::chrono::steady_clock::now();
     cleanup();
+    if (trace) fprintf(stderr, "[assoc] call: %.1f ms until the last batch is enqueued, %.1f ms with the queues drained\n", std::chrono::duration<double, std::milli>(t_end - t_call).count(),
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
     return rc;
 }
 extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04_stream_trace
-for v in 1 0; do
-SFG_ASSOC_TRACE=1 SFG_ASSOC_I8=$v timeout -k 10 500 python3 tools/bench_stream.py --snps ${SNPS:-65536} --dir $GRAFT_REPO_ROOT > gpurun_out/r04_stream_trace/stream_$v.txt 2> gpurun_out/r04_stream_trace/trace_$v.txt; rc=$?
-echo "assoc_i8=$v rc=$rc"; grep -c batch gpurun_out/r04_stream_trace/trace_$v.txt; sed -n 1,60p gpurun_out/r04_stream_trace/trace_$v.txt
-done
+timeout -k 10 500 python -m pytest tests/test_gpu_stream.py tests/test_gpu_pgen.py -x -q -m gpu > gpurun_out/r04_stream_trace/tests.log 2>&1; rc=$?; tail -3 gpurun_out/r04_stream_trace/tests.log; [ $rc = 0 ] || exit $rc
+SFG_ASSOC_TRACE=1 timeout -k 10 500 python3 tools/bench_stream.py --snps ${SNPS:-65536} --dir $GRAFT_REPO_ROOT > gpurun_out/r04_stream_trace/stream_1.txt 2> gpurun_out/r04_stream_trace/trace_1.txt; rc=$?
+echo "traced rc=$rc"; grep -v "batch [1-9]" gpurun_out/r04_stream_trace/trace_1.txt | sed -n 1,40p
+timeout -k 10 500 python3 tools/bench_stream.py --snps ${SNPS:-65536} --dir $GRAFT_REPO_ROOT > gpurun_out/r04_stream_trace/stream_u.txt 2>&1; rc=$?
+echo "untraced rc=$rc"; tail -1 gpurun_out/r04_stream_trace/stream_u.txt | cut -c1-700
 rm -f sfg_stream_bench.bed sfg_stream_bench.bed.half
