@@ -827,21 +827,51 @@ int i8_rotpre_build(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_lev
     }
     if (runs != 1) return 0;
     const size_t rowf = (size_t)nplanes * SFG_N;
-    const int G = std::min(c.mm_group, nbr), ngrp = (nbr + G - 1) / G;
-    if ((long long)G * d * 6 >= 131072) return 0;
-    size_t total = 0;
-    for (int gi = 0; gi < ngrp; gi++) { const int ng = std::min(G, nbr - gi * G); total += mac_i8_rot_tile_bytes(ng * d, n_s, 5) + (l_big >= 0 ? mac_i8_rot_tile_bytes(ng * d, 1, 6) : 0); }
-    if (total > budget_bytes) return 0;
+    auto tiles_of = [&](int Gc) { size_t t = 0; for (int b = 0; b < nbr; b += Gc) { const int ng = std::min(Gc, nbr - b); t += mac_i8_rot_tile_bytes(ng * d, n_s, 5) + (l_big >= 0 ? mac_i8_rot_tile_bytes(ng * d, 1, 6) : 0); } return t; };
+    int G = std::min(c.mm_group, nbr);
+    // 16 (12) block rows per MAC group where the HBM takes the larger plaintext panel (two of them: the encode of a launch runs beside the previous launch's
+    // MAC) and plaintext tiles: half the launches, half the accumulator read-modify-writes (0.256 against 0.272 s per batch at 500 000 samples, 8 batches)
+    if (c.mm_group_auto && nbr > G) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            size_t have = fr;
+            for (const auto &kv : ctx->pool) if (kv.first.rfind(prefix, 0) == 0 || kv.first == "mm.pt" || kv.first == "mm.rotf" || kv.first.rfind("mi8.", 0) == 0) have += kv.second.second;
+            for (int cand : {16, 12}) {
+                const int G2 = std::min(cand, nbr);
+                if (G2 <= G) break;
+                const size_t panel = (size_t)G2 * d * d * L * (SFG_N / 2) * 8 * 2, rotf = ((size_t)G2 * d + 3) * s * 2 * rowf * 8;
+                const size_t need = tiles_of(G2) + panel + rotf + mac_i8_stream_bytes(G2 * d, n_s, 5, 0) + (l_big >= 0 ? mac_i8_stream_bytes(G2 * d, 1, 6, 0) : 0) + (24ULL << 30);
+                if (need <= have && tiles_of(G2) <= budget_bytes) { G = G2; break; }
+            }
+        }
+    }
+    if ((long long)G * d * 6 >= 131072 || tiles_of(G) > budget_bytes) return 0;
+    // every buffer first (the fp64 rows of one group in the product's own mm.rotf, the tile buffers of all groups); where the larger groups do not fit after
+    // all - another context on the device - the default group size is tried before the caller is told to fall back
     double *tmp = nullptr;
-    SFG_TRY(sfg_scratch(ctx, "mm.rotf", ((size_t)G * d + 3) * s * 2 * rowf * 8, (void **)&tmp));
-    pre.As.assign(ngrp, nullptr); pre.Ab.assign(ngrp, nullptr);
+    auto alloc_all = [&](int Gc) -> bool {
+        const int ngc = (nbr + Gc - 1) / Gc;
+        pre.As.assign(ngc, nullptr); pre.Ab.assign(ngc, nullptr);
+        int arc = sfg_scratch(ctx, "mm.rotf", ((size_t)Gc * d + 3) * s * 2 * rowf * 8, (void **)&tmp);
+        for (int gi = 0; gi < ngc && !arc; gi++) {
+            const int ng = std::min(Gc, nbr - gi * Gc);
+            char nm[48];
+            snprintf(nm, sizeof nm, "%s.s%d", prefix, gi);
+            arc = sfg_scratch(ctx, nm, mac_i8_rot_tile_bytes(ng * d, n_s, 5), (void **)&pre.As[gi]);
+            if (!arc && l_big >= 0) { snprintf(nm, sizeof nm, "%s.b%d", prefix, gi); arc = sfg_scratch(ctx, nm, mac_i8_rot_tile_bytes(ng * d, 1, 6), (void **)&pre.Ab[gi]); }
+        }
+        if (arc) { ctx->err.clear(); i8_rotpre_free(pre); }
+        return !arc;
+    };
+    if (!alloc_all(G)) {
+        const int G0 = std::min(c.mm_group, nbr);
+        if (G0 == G) return 0;
+        G = G0;
+        if (!alloc_all(G)) return 0;
+    }
+    const int ngrp = (nbr + G - 1) / G;
     for (int gi = 0; gi < ngrp; gi++) {
         const int bg = gi * G, ng = std::min(G, nbr - bg);
-        char nm[48];
-        snprintf(nm, sizeof nm, "%s.s%d", prefix, gi);
-        int arc = sfg_scratch(ctx, nm, mac_i8_rot_tile_bytes(ng * d, n_s, 5), (void **)&pre.As[gi]);
-        if (!arc && l_big >= 0) { snprintf(nm, sizeof nm, "%s.b%d", prefix, gi); arc = sfg_scratch(ctx, nm, mac_i8_rot_tile_bytes(ng * d, 1, 6), (void **)&pre.Ab[gi]); }
-        if (arc) { ctx->err.clear(); i8_rotpre_free(pre); return 0; }              // no room even without the buffers of earlier calls: the caller falls back
         std::vector<std::vector<uint8_t>> sub;
         if (tabs) sub.assign(tabs->begin() + bg, tabs->begin() + bg + ng);
         int rc = rotcache_build_rows_tab(ctx, A, s, in_level, max_level, nbr, bg, bg + ng, tabs ? &sub : nullptr, tmp);
