@@ -347,7 +347,15 @@ def test_c5_streamed_bed_batches_on_the_int8_rot_tiles_equal_the_resident_produc
         assert np.array_equal(h[:, b:b + 1], want.host()), f"batch {b}: streamed product on the int8 rot tiles differs from the resident product"
         want.free(); env.ctx.geno_free(g)
     A.free(); out.free()
-    env.ctx.check(capi.lib().sfg_ctx_release_scratch(env.ctx.h), "release_scratch")
+    # the scan's cache, panels and staging stay in the context's pools (> 120 GB here) for its next call; a caller's own allocation that no longer fits beside
+    # them gets them back (sfg_malloc retries once after sfg_ctx_release_scratch) instead of failing
+    env.ctx.check(capi.lib().sfg_ctx_scratch_bytes(env.ctx.h, b"", C.byref(kept)), "scratch_bytes")
+    assert kept.value > 120 << 30
+    big = C.c_void_p()
+    env.ctx.check(capi.lib().sfg_malloc(env.ctx.h, C.byref(big), C.c_size_t(200 << 30)), "a 200 GB buffer beside the kept pools")
+    env.ctx.check(capi.lib().sfg_ctx_scratch_bytes(env.ctx.h, b"", C.byref(kept)), "scratch_bytes")
+    assert kept.value == 0
+    env.ctx.check(capi.lib().sfg_free(env.ctx.h, big), "free")
 
 
 # --------------------------------------------------------------------------- configs[3]: 100 000 x 1 000 000 on one GPU
