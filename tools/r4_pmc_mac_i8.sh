@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT; TAG=${1:-r04pmc}; CFG=${2:-c2}; mkdir -p $R/gpurun_out/$TAG;
 ( while sleep 45; do echo "tick $(date +%T)"; done ) & TICK=$!
 export SFG_MM_NO_OVERLAP=1 SFG_UPLOAD_BLOCKING=1
 rc=0
-for v in default wg1 lds; do
+for v in ${VARIANTS:-default wg1 lds}; do
   case $v in default) unset SFG_MAC_I8_WG SFG_MAC_I8_ROT;; wg1) export SFG_MAC_I8_WG=1; unset SFG_MAC_I8_ROT;; lds) unset SFG_MAC_I8_WG; export SFG_MAC_I8_ROT=lds;; esac
   for p in "P1 TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum" "P2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"; do
     set -- $p; pn=$1; shift
