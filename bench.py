@@ -555,10 +555,10 @@ def main():
             mac_gbps = by_small / (ms_small * 1e-3) / 1e9
             padded_macs_s = 2 * nbr_x * mct_x * D * D * 2 * KP * (L - 1) * N * args.steps / world / (ms_small * 1e-3)
             refetch, refetch_src = None, None
-            try:        # exact fabric-side read bytes of this kernel (TCC_EA0_RDREQ_{32B,64B,128B}) against its operand tiles: profiles/r04_pmc_mac_i8.json
-                pm4 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mac_i8.json")))
+            try:        # exact fabric-side read bytes of this kernel (TCC_EA0_RDREQ_{32B,64B,128B}) against its operand tiles: profiles/r04_pmc_mac_i8_ring.json
+                pm4 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mac_i8_ring.json")))
                 refetch = pm4["default"]["k_mac_i8"]["read_bytes_per_launch"] / pm4["_algorithmic_read_bytes_K1183"]["total"]
-                refetch_src = "profiles/r04_pmc_mac_i8.json (static: counter passes at c2, K = 1183; the cache-shared kernel the ring kernel replaced fetched the same tiles)"
+                refetch_src = "profiles/r04_pmc_mac_i8_ring.json (static: counter passes of k_mac_i8_ring<5, 3, 0, 2> at c2, K = 1183)"
             except Exception:
                 pass
             mac_blk = {"bound": "hbm", "achieved": mac_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mac_gbps / HBM_PEAK_GBS, "kernel": "k_mac_i8_ring<5, 3>",
