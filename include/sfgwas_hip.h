@@ -267,7 +267,7 @@ int sfg_matmul_stream(sfg_ctx *ctx, const uint64_t *A_host, int s, int in_level,
  * [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).  flags: SFG_SQUARE, SFG_STREAM_DIRECT.
  * The baby-step rotation cache of `A` (rotCache[i][baby], matmult.go:1373-1377 - a function of A alone, rebuilt by the reference in every MatMult4Stream
  * call) is built ONCE per call and shared by all batches when it fits (SFG_ASSOC_ROTCACHE_MB, 0 = per batch): as the int8 MAC's rot tiles where every
- * modulus multiplies on the matrix core (1.3 GB per block row for s <= 16), else as fp64 operand rows (1.86 GB per block row at s = 13; SFG_ASSOC_I8=0).
+ * modulus multiplies on the matrix core (1.3 GB per block row for s <= 15), else as fp64 operand rows (1.86 GB per block row at s = 13; SFG_ASSOC_I8=0).
  * The cache and the call's staging buffers (two pinned file slots of one batch each, the decoded batches) stay in the context's scratch pools for the next
  * call of the scan (sfg_ctx_scratch_bytes(ctx, "assoc.", ..); sfg_ctx_release_scratch returns them).
  * A Go shim that keeps calling per batch gets the same saving from sfg_rotcache_build_rows_dev + sfg_matmul_resident_range_rc_dev. */

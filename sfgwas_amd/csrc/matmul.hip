@@ -807,7 +807,7 @@ extern "C" int sfg_rotcache_build_rows_dev(sfg_ctx *ctx, const uint64_t *A, int 
 }
 // ---- the same cache held only as the int8 MAC's rot tiles (I8RotPre, kernels.hpp).  Built group by group: the fp64 operand rows of G block rows go through the
 // product's own mm.rotf scratch, k_i8_pack_rot turns them into the group's tile buffers.  pre.G stays 0 (and nothing is held) when the context does not multiply
-// every modulus on the int8 matrix core, the rows do not fit one row tile pair (2 s > 32) or the tiles do not fit the budget / the device.
+// every modulus on the int8 matrix core, the rows do not fit one MAC launch (2 s > 30: launch_mac_bc walks the rows 30 at a time) or the tiles do not fit the budget / the device.
 // (the tile buffers are scratch entries "<prefix>.s<gi>" / "<prefix>.b<gi>" of the context: a scan's next call finds them in place - hipMalloc / hipFree of ~100 GB cost
 //  0.2 to 3.3 s per call, measured - and they go back to the device like every kept buffer: under memory pressure from a later call, or sfg_ctx_release_scratch)
 void i8_rotpre_free(I8RotPre &pre) { pre = I8RotPre(); }
@@ -815,7 +815,7 @@ int i8_rotpre_build(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_lev
     pre = I8RotPre();
     const int d = SFG_D, L = max_level;
     const auto &c = ctx->cfg;
-    if (!c.assoc_i8 || !mac_use_dma(ctx) || !c.mac_bc || c.mac_plain_pt || !c.mac_i8 || !c.mac_i8_big || 2 * s > 32 || L < 1 || L > ctx->nq || nbr < 1) return 0;
+    if (!c.assoc_i8 || !mac_use_dma(ctx) || !c.mac_bc || c.mac_plain_pt || !c.mac_i8 || !c.mac_i8_big || 2 * s > 30 || L < 1 || L > ctx->nq || nbr < 1) return 0;
     if (!mac_dma_packed_mask(ctx, L)) return 0;
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) { ctx->err.clear(); return 0; }

@@ -86,6 +86,44 @@ def test_stream_bed_batches_match_oracle(tmp_path, square):
     dA.free(); dout.free(); ctx.close()
 
 
+@pytest.mark.parametrize("s,level,maxl,form", [(16, 5, 5, "assoc.rotf"), (3, 5, 3, "assoc.rot8"), (15, 4, 4, "assoc.rot8")])
+def test_stream_bed_cache_forms_at_their_limits(tmp_path, s, level, maxl, form):
+    """The call-wide rotation cache is kept as int8 rot tiles while the 2 s ciphertext rows of a k-slice fit the MAC's two row tiles in one launch (s <= 15) and as fp64 operand
+    rows beyond (s = 16); a product below the top level (max_level 3 and 4: the 46-bit modulus and two or three 35-bit ones) takes the tiles of those moduli only.
+    Two batches each, every word against the oracle."""
+    from sfgwas_amd import capi
+    ns, nv, batch = 120, 150, 80
+    rnd = np.random.default_rng(1000 + s)
+    geno = rnd.choice(np.array([2, -1, 1, 0], dtype=np.int8), size=(ns, nv), p=[0.2, 0.05, 0.35, 0.4])
+    path = str(tmp_path / "lim.bed")
+    write_bed(path, geno)
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    slots, d = ring.slots, 91
+    shifts = set(range(ns)) | set(range(slots - batch + 1, slots))
+    rots = sorted({sh % d for sh in shifts if sh % d} | {(sh // d) * d for sh in shifts if sh // d})
+    for k in rots:
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 700 + k)
+        keys.add(g, key); ctx.load_rotkey(g, key)
+    A = np.stack([np.stack([ring.fill_uniform(level, 300 + i)]) for i in range(s)])
+    dA = capi.DevArray.from_host(ctx, A)
+    dout = capi.DevArray(ctx, (s, 2, 2, maxl, ring.N))
+    got_ct = C.c_size_t()
+    ctx.check(capi.lib().sfg_assoc_stream_bed(ctx.h, path.encode(), ns, nv, None, None, batch, dA.p, s, level, maxl, 0, dout.p, 2, C.byref(got_ct), None, None), "assoc_stream_bed")
+    assert got_ct.value == 2
+    for name in (b"assoc.rot8", b"assoc.rotf"):
+        n = C.c_size_t()
+        ctx.check(capi.lib().sfg_ctx_scratch_bytes(ctx.h, name, C.byref(n)), "scratch_bytes")
+        assert (n.value > 0) == (name.decode() == form), (name, n.value)
+    out = dout.host()
+    for b, (a0, a1) in enumerate([(0, batch), (batch, nv)]):
+        want, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, maxl, np.ascontiguousarray(geno[:, a0:a1]), enc_prec=1)
+        assert np.array_equal(out[:, b:b + 1], want), f"batch {b}"
+    dA.free(); dout.free(); ctx.close()
+
+
 def _ctx_with_env(capi, **env):
     """the library reads its switches once, in sfg_ctx_create"""
     import os
