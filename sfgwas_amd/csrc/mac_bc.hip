@@ -331,12 +331,12 @@ int launch_mac_bc(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u64
             // (the int8 kernels take <= 96 columns and K 2^14 ND < 2^31 per launch; anything else - a DiagCache product over more than 96 block columns - stays here)
             const bool i8_fits = Ncols <= 96 && (long long)K * 6 < 131072;
             if (!big && st.i8 && st.pt_half && (i8_fits || st.pt_digits)) {            // the 35-bit moduli on the int8 matrix core (mac_i8.hip)
-                SFG_TRY(launch_mac_i8_small(ctx, rotf, rows_per_k * rowf, rowf, plane_of[l], pt, out, K, R, r0, Ncols, l, e - l, accumulate, st));
+                SFG_TRY(launch_mac_i8_small(ctx, rotf, rows_per_k * rowf, rowf, plane_of[l], pt, out, K, r0 + rows, r0, Ncols, l, e - l, accumulate, st));      // (row bound r0 + rows: this pass's rows only - the kernel would take 32 from r0)
                 l = e; continue;
             }
             if (big && st.i8_big && st.pt_half && (i8_fits || st.pt_digits_big)) {         // the 46-bit modulus likewise, six digits (one modulus per launch)
                 MacStrides sb = st; sb.pt_digits = st.pt_digits_big;
-                for (int t = l; t < e; t++) SFG_TRY(launch_mac_i8_big(ctx, rotf, rows_per_k * rowf, rowf, plane_of[t], pt, out, K, R, r0, Ncols, t, accumulate, sb));
+                for (int t = l; t < e; t++) SFG_TRY(launch_mac_i8_big(ctx, rotf, rows_per_k * rowf, rowf, plane_of[t], pt, out, K, r0 + rows, r0, Ncols, t, accumulate, sb));
                 l = e; continue;
             }
             if (!rotf) SFG_FAIL(ctx, "sfg_mac: internal: a rot operand given as int8 tiles only reached the fp64 kernel");

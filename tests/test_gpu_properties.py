@@ -173,6 +173,40 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
     assert outs[0].any()
 
 
+def test_more_than_thirty_rows_per_k_slice_across_groups():
+    """s = 17 ciphertexts (34 rows of every k-slice: MAC passes of 30 + 4 rows) over three block rows in two MAC groups (SFG_MM_GROUP=2: the second group
+    accumulates).  The int8 kernels take up to 32 rows from a pass's first row, so a pass must stop at its own last row - rows 30, 31 were added twice before
+    round 4.  Row independence: rows [0, 8) and [8, 17) multiplied on their own (16 and 18 rows: single passes) give the same words."""
+    from sfgwas_amd import capi
+    import ctypes as C
+    import oracle_lib as ol
+    saved = os.environ.get("SFG_MM_GROUP"); os.environ["SFG_MM_GROUP"] = "2"
+    try:
+        ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    finally:
+        if saved is None:
+            os.environ.pop("SFG_MM_GROUP", None)
+        else:
+            os.environ["SFG_MM_GROUP"] = saved
+    lib = capi.lib()
+    D, N, L, LEVEL, SLOTS = 91, 16384, 5, 5, 8192
+    rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < SLOTS]
+    ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(rots))(*rots), len(rots), 0xBEEF), "keys")
+    nrow, ncol, s = 2 * SLOTS + 500, 70, 17
+    nbr = 3
+    gd, gh = ctx.fill_geno(nrow, ncol, 0x77)
+    A = ctx.fill_uniform_cts(s * nbr, LEVEL, 0x1234)
+    full = ctx.matmul_resident(A, s, LEVEL, L, gh).host()
+    assert full.shape == (s, 1, 2, L, N) and full.any()
+    Ah = A.host().reshape(s, nbr, 2, LEVEL + 1, N)
+    for r0, r1 in ((0, 8), (8, 17)):
+        sub = capi.DevArray.from_host(ctx, np.ascontiguousarray(Ah[r0:r1]))
+        part = ctx.matmul_resident(sub, r1 - r0, LEVEL, L, gh)
+        assert np.array_equal(part.host(), full[r0:r1]), f"rows [{r0}, {r1}) of the 34-row product differ from the product of those rows alone"
+        sub.free(); part.free()
+    A.free(); gd.free(); ctx.geno_free(gh); ctx.close()
+
+
 _CHILD_LARGE = r"""
 import sys, ctypes as C, hashlib, numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
