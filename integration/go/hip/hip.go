@@ -315,6 +315,41 @@ func (h *Ctx) MatmulResident(aFlat []uint64, s, inLevel, maxLevel int, g *Geno) 
 	return dOut.Download()
 }
 
+// AssocStreamPgen = the per-batch loop of GenoBlockMult's pgen branch (gwas/assoc.go:371-416) for one chromosome file, in one call: per batch of batchSnps kept
+// variants FilterMatrixFilePgen + NewGenoFileStream + MatMult4Stream(cps, mat, X, 5, false, square, nproc), the batches' outputs in ConcatCipherMatrix order.
+// sampleKeep: one byte per sample of the file (the --keep list of SampleKeepFile), snpFilt: one byte per variant of the file.  The baby-step rotations of `mat`
+// are made once for all batches and kept on the device as the int8 MAC's rot tiles (include/sfgwas_hip.h: sfg_assoc_stream_pgen).  Returns [s][nct][2][maxLevel][N]
+// words with nct = sum over batches of ceil(kept / slots).
+func (h *Ctx) AssocStreamPgen(pgenPath string, sampleKeep, snpFilt []byte, batchSnps int, aFlat []uint64, s, inLevel, maxLevel int, square bool, capacity int) ([]uint64, int) {
+	cp := C.CString(pgenPath)
+	defer C.free(unsafe.Pointer(cp))
+	dA := h.Upload(aFlat)
+	defer dA.Free()
+	dOut := h.Alloc(8 * s * capacity * 2 * maxLevel * h.N)
+	defer dOut.Free()
+	flags := C.uint(0)
+	if square {
+		flags |= C.SFG_SQUARE
+	}
+	var pr, pc *C.uint8_t
+	if sampleKeep != nil {
+		pr = (*C.uint8_t)(unsafe.Pointer(&sampleKeep[0]))
+	}
+	if snpFilt != nil {
+		pc = (*C.uint8_t)(unsafe.Pointer(&snpFilt[0]))
+	}
+	var nct C.size_t
+	h.check(C.sfg_assoc_stream_pgen(h.p, cp, pr, pc, C.size_t(batchSnps), dA.U64(), C.int(s), C.int(inLevel), C.int(maxLevel), flags,
+		dOut.U64(), C.size_t(capacity), &nct, nil, nil), "assoc_stream_pgen") // computeSquaredSum = false on this branch (assoc.go:395)
+	all := dOut.Download() // [s][capacity][2][maxLevel][N]: keep the first nct ciphertexts of every row
+	ctw := 2 * maxLevel * h.N
+	out := make([]uint64, s*int(nct)*ctw)
+	for i := 0; i < s; i++ {
+		copy(out[i*int(nct)*ctw:(i+1)*int(nct)*ctw], all[i*capacity*ctw:(i*capacity+int(nct))*ctw])
+	}
+	return out, int(nct)
+}
+
 // MatmulFromCache = MatMult4StreamCompute on DiagCache files a CPU party wrote (gwas/filestream.go:19-282).
 func (h *Ctx) MatmulFromCache(aFlat []uint64, s, inLevel, maxLevel int, prefix string, nbr int) []uint64 {
 	cp := C.CString(prefix)
