@@ -41,3 +41,48 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "sfgwas_oracle" not in txt, f"{f} references the oracle"
+
+
+def test_go_shim_calls_only_declared_entry_points_with_the_declared_number_of_arguments():
+    """integration/go/ cannot be compiled here (no Go toolchain): at least every C.sfg_* call in it must name a function include/sfgwas_hip.h declares and pass as
+    many arguments as the declaration has, and every C.SFG_* constant must be one of the header's."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sfgwas_hip.h")).read(), flags=re.S)
+    nargs = {}
+    for m in re.finditer(r"\b(sfg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        params = m.group(2).strip()
+        nargs[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    consts = set(re.findall(r"\b(SFG_[A-Z0-9_]+)\b", hdr))
+
+    def call_args(txt, start):                       # number of top-level arguments of the call whose '(' is at `start`
+        depth, n, i, seen = 0, 0, start, False
+        while i < len(txt):
+            c = txt[i]
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+                if depth == 0:
+                    return n + (1 if seen else 0)
+            elif c == "," and depth == 1:
+                n += 1
+            elif depth >= 1 and not c.isspace():
+                seen = True
+            i += 1
+        raise AssertionError("unbalanced call")
+
+    calls = 0
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "integration", "go")):
+        for f in files:
+            if not f.endswith(".go"):
+                continue
+            txt = open(os.path.join(dirpath, f)).read()
+            code = re.sub(r"//[^\n]*", "", txt)
+            for m in re.finditer(r"\bC\.(sfg_[a-z0-9_]+)\s*\(", code):
+                name = m.group(1)
+                assert name in nargs, f"{f}: C.{name} is not declared in include/sfgwas_hip.h"
+                got = call_args(code, m.end() - 1)
+                assert got == nargs[name], f"{f}: C.{name} called with {got} arguments, declared with {nargs[name]}"
+                calls += 1
+            for c in re.findall(r"\bC\.(SFG_[A-Z0-9_]+)\b", code):
+                assert c in consts, f"{f}: C.{c} is not a constant of the header"
+    assert calls >= 20
