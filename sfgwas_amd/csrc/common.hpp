@@ -69,7 +69,7 @@ struct SfgConfig {
     int mm_group = 8;              // SFG_MM_GROUP          block rows per MAC launch
     bool mm_group_auto = true;     //                       (unset) 16 block rows per launch when the plaintext panel and the rotation operands of such a group fit the free HBM, else 8
     size_t acc_budget = 24ULL << 30;   // SFG_MM_ACC_BUDGET_MB
-    bool no_overlap = false;       // SFG_MM_NO_OVERLAP     single queue
+    bool no_overlap = true;        // SFG_MM_OVERLAP=1      two queues: the key switching of the next block-row group / the giant-step alignment of the last column pass beside the encode + MAC.  Off since round 4 (single queue: 10.87 s against 10.91 s per step at 100k x 1M, 3.39 against 3.41 s at 50k x 500k - the fp64-issue-bound kernels only slow each other down beside the HBM-bound ones); SFG_MM_NO_OVERLAP=1 is still accepted
     bool no_enc_overlap = true;    // SFG_MM_ENC_OVERLAP=1  the encode of MAC launch k + 1 on a third queue beside the transposition + MAC of launch k (two plaintext panels).  Built and measured at
                                    // 100k x 1M: 12.24 s against 12.20 s - the kernels then share the machine in time, not in space: a MAC workgroup (6 waves x 240 VGPRs) leaves no SIMD
                                    // with the 128 VGPRs a plaintext-NTT wave needs, so an encode workgroup cannot be resident beside it.  Off until the MAC leaves that room.

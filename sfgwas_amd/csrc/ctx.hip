@@ -41,7 +41,8 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
     if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
-    c.no_overlap = env("SFG_MM_NO_OVERLAP") != nullptr;
+    if (const char *e = env("SFG_MM_OVERLAP")) c.no_overlap = atoi(e) == 0;
+    if (env("SFG_MM_NO_OVERLAP")) c.no_overlap = true;
     if (const char *e = env("SFG_MM_ENC_OVERLAP")) c.no_enc_overlap = atoi(e) == 0;
     if (const char *e = env("SFG_NTT_HALF_IMPL")) c.ntt_half_full = !strcmp(e, "full");
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");

@@ -109,7 +109,7 @@ def test_multi_group_two_pass_overlap_vs_oracle():
     accumulator budget of one block column per pass (two column passes, alignment of pass k beside accumulate of pass k+1)"""
     s, nrow, ncol = 2, 2 * SLOTS + 100, SLOTS + 50
     accw_mb = D * s * 2 * L * N * 8 / 2 ** 20                       # one block column of accumulators
-    e = Env(SFG_MM_GROUP=2, SFG_MM_ACC_BUDGET_MB=int(2 * accw_mb) + 1)
+    e = Env(SFG_MM_GROUP=2, SFG_MM_ACC_BUDGET_MB=int(2 * accw_mb) + 1, SFG_MM_OVERLAP=1)        # (the two-queue schedule is opt-in since round 4)
     try:
         rnd = np.random.default_rng(202)
         geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)

@@ -236,12 +236,12 @@ open(sys.argv[1], 'w').write(h.hexdigest())
 def test_schedule_invariance_at_kp15_multi_pass_size(tmp_path):
     """Both products of a power iteration at kp = 15 on a 50 000 x 131 077 matrix (7 ragged block rows x 17 block
     columns: several block-row groups, two column passes at the default accumulator budget, the shared rotation cache
-    and the two-queue overlap all engage).  The digest of every output word must not depend on the schedule: default vs single queue + groups of 3 +
+    engage).  The digest of every output word must not depend on the schedule: default (one queue) vs the two-queue overlap (SFG_MM_OVERLAP=1) + groups of 3 +
     a 3-column accumulator budget + the register-staged MAC kernel for the third run."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
     for name, envv in [("default", {}),
-                       ("serial", {"SFG_MM_NO_OVERLAP": "1", "SFG_MM_GROUP": "3", "SFG_MM_ACC_BUDGET_MB": "6000", "SFG_UPLOAD_BLOCKING": "1"}),
+                       ("two_queues", {"SFG_MM_OVERLAP": "1", "SFG_MM_GROUP": "3", "SFG_MM_ACC_BUDGET_MB": "6000", "SFG_UPLOAD_BLOCKING": "1"}),
                        ("full_ntt", {"SFG_NTT_HALF_IMPL": "full", "SFG_NTT_FWD_IMPL": "full", "SFG_MM_GROUP": "5", "SFG_MAC_IMPL": "dma"})]:
         f = str(tmp_path / (name + ".txt"))
         e = dict(os.environ); e.update(envv)

@@ -1,14 +1,14 @@
-# final profiles of round 4: the default bench command under rocprofv3 --kernel-trace --stats (two queues), the same on one queue, and the bench line
+# final profiles of round 4: the default bench command under rocprofv3 --kernel-trace --stats (one queue, the default), the same with the two-queue overlap, and the bench line
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04final; mkdir -p $O
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o p -- python3 $R/bench.py > $O/bench_default.log 2>&1 || { tail -5 $O/bench_default.log; exit 1; }
-SFG_MM_NO_OVERLAP=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o p -- python3 $R/bench.py --no-cpu-baseline --no-check --no-digest > $O/bench_single.log 2>&1 || { tail -5 $O/bench_single.log; exit 1; }
+SFG_MM_OVERLAP=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_overlap -o p -- python3 $R/bench.py --no-cpu-baseline --no-check --no-digest > $O/bench_overlap.log 2>&1 || { tail -5 $O/bench_overlap.log; exit 1; }
 cd $R
 find $O -name "*kernel_trace.csv" -delete
 grep '^{' $O/bench_default.log | tail -1 > $O/benchline.json
 python3 - <<P
 import csv,glob,json
-for tag in ("default","single"):
+for tag in ("default","overlap"):
     f=glob.glob("gpurun_out/r04final/prof_%s/**/*kernel_stats.csv"%tag, recursive=True)[0]
     print("==", tag)
     for r in list(csv.DictReader(open(f)))[:12]:

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04ovl2
 for cfg in c4 c3; do for v in 0 1 0 1; do
-  if [ $v = 1 ]; then export SFG_MM_NO_OVERLAP=1; else unset SFG_MM_NO_OVERLAP; fi
+  if [ $v = 1 ]; then unset SFG_MM_OVERLAP; else export SFG_MM_OVERLAP=1; fi      # v = 1: one queue (the default since round 4), v = 0: the two-queue overlap
   timeout -k 10 400 python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-digest > gpurun_out/r04ovl2/b_${cfg}_$v.json 2> gpurun_out/r04ovl2/b.err || { tail -5 gpurun_out/r04ovl2/b.err; exit 1; }
   python - <<P
 import json
