@@ -94,6 +94,17 @@ int sfg_intt_rows(sfg_ctx *ctx, uint64_t *rows_dev, int nrows, const int *mod_id
 int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot_dev, const uint64_t *pt_dev, uint64_t *out_dev,
                 int K, int R, int Ncols, int L, int accumulate);
 
+/* Test hook (refused unless SFG_ENABLE_TEST_HOOKS=1 was set before sfg_ctx_create): the SAME sum through the kernels a product multiplies with by default -
+ * the int8 matrix-core MAC of mac_i8.hip (five signed base-256 digits for moduli < 2^36, six for moduli < 2^47; transposition kernels, ring / cache kernel by
+ * column count, Horner recombination, untile), reached exactly as sfg_matmul_* reaches it.  Those kernels serve the mirror-symmetric plaintexts a real slot
+ * vector encodes to (P[N-1-x] = P[x]) from half rows: pt_half_dev is [K][Ncols][L][N/2] canonical words, the result is
+ *    out[n][r][l][x] (+)= sum_k rot[k][r][l][x] * pt_half[k][n][l][min(x, N-1-x)]   mod q_l.
+ * pt_form 0: the plaintext rows are first written as the digit planes the product's plaintext NTT emits (k_i8_pack_pt_digits); 1: as panel words - packed
+ * limbs / plain words - the DiagCache product's form (k_i8_pack_pt).  Ncols <= 96, K < 21846.  Replaces nothing in the reference: it exists so that
+ * matmult.go:247-324's arithmetic can be checked against the default kernels directly (tests/test_gpu_mac.py). */
+int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot_dev, const uint64_t *pt_half_dev, uint64_t *out_dev,
+                   int K, int R, int Ncols, int L, int accumulate, int pt_form);
+
 /* ---- A6/A7: diagonal extraction + CKKS encode (matmult.go:636-731, EncodeNTT) ----
  * Encodes the generalized diagonals `shift` in [shift0, shift0+nshift) of one <= slots x slots int8 block
  * (block rows r, cols c, row stride ld; transposed != 0 reads the block transposed), each right-rotated by

@@ -23,6 +23,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"sync"
 	"unsafe"
 
@@ -242,10 +243,17 @@ type Geno struct {
 	NCol  int
 }
 
+// residentGeno is one uploaded matrix: its handle, stored shape and an order-independent content fingerprint.
+type residentGeno struct {
+	g          *C.sfg_geno
+	nrow, ncol int
+	print      uint64
+}
+
 var (
-	genoMu      sync.Mutex
-	genoByKey   = map[string]*Geno{}
-	genoByShape = map[[2]int]*C.sfg_geno{} // (nrow, ncol) of the stored orientation -> handle, to find X when X^T is registered
+	genoMu    sync.Mutex
+	genoByKey = map[string]*Geno{}
+	resident  []residentGeno // uploaded matrices, to find X when X^T is registered
 )
 
 const (
@@ -253,23 +261,77 @@ const (
 	FlagTranspose = uint(C.SFG_TRANSPOSE)
 )
 
+// genoFingerprint is sum over (i, j) of mix(i, j, M[i][j]) mod 2^64 over the STORED orientation of a matrix: a sum, so that it can be
+// evaluated in any traversal order - in particular over the rows of a candidate transpose (transposed = true swaps the roles of the
+// two indices).  Two different matrices of the same shape collide with probability ~2^-64.  One pass, split over the CPUs.
+func genoFingerprint(rows []int8, nrow, ncol int, transposed bool) uint64 {
+	mix := func(i, j uint64, v int8) uint64 {
+		z := (i*0x9E3779B97F4A7C15 ^ j*0xC2B2AE3D27D4EB4F) + uint64(uint8(v))*0x165667B19E3779F9
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EB
+		return z ^ (z >> 31)
+	}
+	nw := runtime.NumCPU()
+	if nw > nrow {
+		nw = nrow
+	}
+	part := make([]uint64, nw)
+	var wg sync.WaitGroup
+	for w := 0; w < nw; w++ {
+		wg.Add(1)
+		go func(w int) {
+			defer wg.Done()
+			var acc uint64
+			for r := w * nrow / nw; r < (w+1)*nrow/nw; r++ {
+				row := rows[r*ncol : (r+1)*ncol]
+				for c, v := range row {
+					if transposed {
+						acc += mix(uint64(c), uint64(r), v)
+					} else {
+						acc += mix(uint64(r), uint64(c), v)
+					}
+				}
+			}
+			part[w] = acc
+		}(w)
+	}
+	wg.Wait()
+	var sum uint64
+	for _, a := range part {
+		sum += a
+	}
+	return sum
+}
+
 // RegisterGeno uploads (or re-uses) the matrix behind a cache prefix.  rows is the row-major int8 matrix as GenoFileStream
 // delivers it (filters applied, missing = -1 kept: the device zeroes negatives before sums and products, matmult.go:1292-1300).
-// If a matrix of the transposed shape is already resident it is reused with SFG_TRANSPOSE instead of uploading a second copy.
+// If the TRANSPOSE of this matrix is already resident - same shape swapped AND the same content (fingerprint of `rows` read as a
+// transpose = fingerprint of the stored matrix; shape alone would also match an unrelated second n x n matrix) - it is reused
+// with SFG_TRANSPOSE instead of uploading a second copy (pca.go:112-113 registers X, then X^T).
 func (h *Ctx) RegisterGeno(prefix string, rows []int8, nrow, ncol int) *Geno {
 	genoMu.Lock()
 	defer genoMu.Unlock()
 	if g, ok := genoByKey[prefix]; ok {
 		return g
 	}
-	if g, ok := genoByShape[[2]int{ncol, nrow}]; ok {
-		e := &Geno{g, FlagTranspose, nrow, ncol}
-		genoByKey[prefix] = e
-		return e
+	var asTranspose uint64
+	haveT := false
+	for _, r := range resident {
+		if r.nrow != ncol || r.ncol != nrow {
+			continue
+		}
+		if !haveT {
+			asTranspose, haveT = genoFingerprint(rows, nrow, ncol, true), true
+		}
+		if r.print == asTranspose {
+			e := &Geno{r.g, FlagTranspose, nrow, ncol}
+			genoByKey[prefix] = e
+			return e
+		}
 	}
 	var g *C.sfg_geno
 	h.check(C.sfg_geno_upload(h.p, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &g), "geno_upload")
-	genoByShape[[2]int{nrow, ncol}] = g
+	resident = append(resident, residentGeno{g, nrow, ncol, genoFingerprint(rows, nrow, ncol, false)})
 	e := &Geno{g, 0, nrow, ncol}
 	genoByKey[prefix] = e
 	return e

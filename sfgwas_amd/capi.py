@@ -64,6 +64,7 @@ def _sig(L):
         "sfg_ntt_rows": (i, [vp, vp, i, C.POINTER(i)]),
         "sfg_intt_rows": (i, [vp, vp, i, C.POINTER(i)]),
         "sfg_mac_dev": (i, [vp, vp, vp, vp, i, i, i, i, i]),
+        "sfg_mac_i8_dev": (i, [vp, vp, vp, vp, i, i, i, i, i, i]),
         "sfg_encode_diags_dev": (i, [vp, vp, sz, i, i, i, i, i, i, vp]),
         "sfg_encode_coeffs_host": (i, [vp, C.POINTER(d), i, C.POINTER(C.c_int64)]),
         "sfg_encode_vectors_dev": (i, [vp, C.POINTER(d), i, i, vp]),
@@ -312,6 +313,42 @@ def _ctx_mac(self, rot, pt, L, out_init=None):
 
 
 Context.mac = _ctx_mac
+
+
+def _ctx_mac_i8(self, rot, pt_half, L, K=None, out_init=None, pt_form=0):
+    """sfg_mac_i8_dev (test hook): the default int8 matrix-core MAC.  rot [P][R][L][N], pt_half [P][Ncols][L][N/2]; with K > P the P k-slices are
+    repeated cyclically ON THE DEVICE (k-slice k = slice k mod P) so that long contractions cost one small upload.  Returns out [Ncols][R][L][N]."""
+    rot = np.ascontiguousarray(rot, dtype=np.uint64)
+    pt_half = np.ascontiguousarray(pt_half, dtype=np.uint64)
+    P, R = rot.shape[0], rot.shape[1]
+    Ncols = pt_half.shape[1]
+    K = P if K is None else K
+    assert rot.shape[2] == L and pt_half.shape[2] == L and pt_half.shape[0] == P and pt_half.shape[3] == self.N // 2 and K >= P
+    bufs = []
+    for arr in (rot, pt_half):
+        sl = arr.nbytes // P                                    # bytes per k-slice
+        d = self.malloc(sl * K)
+        self.check(lib().sfg_memcpy_h2d(self.h, d, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+        filled = P
+        while filled < K:
+            n = min(filled, K - filled)
+            self.check(lib().sfg_memcpy_d2d(self.h, C.c_void_p(d.value + filled * sl), d, n * sl), "d2d")
+            filled += n
+        bufs.append(d)
+    if out_init is not None:
+        d_out = self.to_device(np.ascontiguousarray(out_init, dtype=np.uint64))
+    else:
+        d_out = self.malloc(Ncols * R * L * self.N * 8)
+    try:
+        self.check(lib().sfg_mac_i8_dev(self.h, bufs[0], bufs[1], d_out, K, R, Ncols, L, int(out_init is not None), pt_form), "sfg_mac_i8_dev")
+        out = self.to_host(d_out, (Ncols, R, L, self.N), np.uint64)
+    finally:
+        for p_ in bufs + [d_out]:
+            self.free(p_)
+    return out
+
+
+Context.mac_i8 = _ctx_mac_i8
 
 
 def _ctx_encode_diags(self, block, shift0, nshift, L, transposed=False):

@@ -160,6 +160,7 @@ struct sfg_ctx {
 int sfg_sync_all(sfg_ctx *ctx);
 // after a sync: non-zero while an encoder coefficient too close to a rounding tie is outstanding (encode.hip)
 int sfg_encoder_check(sfg_ctx *ctx);
+void sfg_ptc_detach_all(sfg_ctx *ctx);         // matmul.hip: release every plaintext coefficient cache this context owns and clear the owner of its matrices (context destruction)
 void sfg_ptc_invalidate_all(sfg_ctx *ctx);     // matmul.hip: forget every cached coefficient row of the matrices this context owns a cache of (arenas kept)
 
 extern thread_local std::string g_create_error;

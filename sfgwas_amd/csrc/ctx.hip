@@ -32,11 +32,11 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_I8_BIG")) c.mac_i8_big = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_ROT")) { c.mac_i8_nolds = strcmp(e, "lds") != 0; c.mac_i8_ring = !strcmp(e, "ring"); }      // ring (default) | cache | lds
     if (env("SFG_MAC_I8_WG")) c.mac_i8_ring = false;
-    if (const char *e = env("SFG_MAC_I8_DIAG")) c.mac_i8_diag = atoi(e);
+    if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
+    if (const char *e = env("SFG_MAC_I8_DIAG")) { if (c.test_hooks) c.mac_i8_diag = atoi(e); }       // timing diagnostics with INVALID results: honoured under the test switch only
     if (const char *e = env("SFG_MAC_I8_WAVES")) c.mac_i8_waves = atoi(e) == 6 ? 6 : 12;
     if (const char *e = env("SFG_MAC_I8_STAGE")) c.stage_pack = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
-    if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
     if (const char *e = env("SFG_TEST_TIE_BAND_LOG2")) { if (c.test_hooks) c.tie_band = ldexp(1.0, atoi(e)); }       // test hook: a wider band sends ordinary coefficients through the exact re-derivation
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
@@ -176,6 +176,7 @@ extern "C" void sfg_ctx_destroy(sfg_ctx *ctx) {
     if (ctx->enc_stream) (void)hipStreamSynchronize(ctx->enc_stream);
     if (ctx->user_stream) (void)hipStreamSynchronize(ctx->user_stream);
     sfg_phases_resolve(ctx);
+    sfg_ptc_detach_all(ctx);           // matrices whose plaintext cache this context owns must not keep a pointer to it (their handles outlive a fork)
     for (auto &kv : ctx->ksw_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->host_pool) (void)hipHostFree(kv.second.first);
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.first);

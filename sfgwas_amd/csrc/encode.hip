@@ -390,7 +390,7 @@ __device__ __forceinline__ double dd_round_away(dd x, unsigned &near_tie, double
 // coefficients): a serial loop, deliberately not inlined so that it costs the encoder's hot path one predicate and no registers.
 __device__ __noinline__ bool enc_tie_resolve(const int8_t *row, const uint16_t *tinv, int nrot, const double2 *costab, int sexp, int j, double *out) {
     const int n = SFG_SLOTS;
-    long long sa = 0, sb = 0, sc = 0;
+    __int128 sa = 0, sb = 0, sc = 0;                                    // (the matrix API takes any int8: |v| 128 x |limb| 2^41 x 8192 terms passes 2^63; the loop is cold)
     for (int m = 0; m < n; m++) {
         int t = (int)tinv[m] - nrot; t += t < 0 ? n : 0;
         const int v = (int)row[t];                                      // (the skewed block: missing calls are zero already)
@@ -403,9 +403,9 @@ __device__ __noinline__ bool enc_tie_resolve(const int8_t *row, const uint16_t *
         const double y = r1 * 0x1p40, bq = __builtin_rint(y), r2 = y - bq;
         const double cq = __builtin_rint(r2 * 0x1p40 + cv.y * 0x1p100);
         const long long sv = neg ? -(long long)v : (long long)v;
-        sa += sv * (long long)a; sb += sv * (long long)bq; sc += sv * (long long)cq;
+        sa += (__int128)(sv * (long long)a); sb += (__int128)(sv * (long long)bq); sc += (__int128)(sv * (long long)cq);     // each product < 2^7 2^41: exact in 64 bits
     }
-    const __int128 T = ((__int128)sa << 80) + ((__int128)sb << 40) + (__int128)sc;      // p_j 2^(100 - sexp)
+    const __int128 T = (sa << 80) + (sb << 40) + sc;      // p_j 2^(100 - sexp)
     const int sh = 100 - sexp;
     const __int128 q = T >> sh, rem = T - (q << sh), half = (__int128)1 << (sh - 1);      // floor; 0 <= rem < 2^sh
     const __int128 dist = rem > half ? rem - half : half - rem;

@@ -31,6 +31,26 @@ template <int ND> __device__ __forceinline__ void i8_digits(long long v, int8_t 
 // byte offset of element (row-or-column i < 16, kk < 64) inside a 1 KiB operand tile: lane = i + 16 (kk / 16), byte kk % 16
 __device__ __forceinline__ int i8_tile_off(int i, int kk) { return ((i + 16 * (kk >> 4)) << 4) + (kk & 15); }
 
+// sum_s D_s 256^s mod q by Horner on exact integers held in fp64: |r| <= q/2 and |D| < 2^31.  One step x = r 256 + D, r' = x - q rint(x / q) is exact while
+// 128 q + 2^31 < 2^53 (x itself AND the product q rint(x / q) <= 128 q), i.e. for q <= 2^46 - 2^24: PN14QP438's q0 = 0x200000440001 < 2^46 and every 35-bit prime.
+// A modulus in (2^46 - 2^24, 2^47) - accepted by sfg_ctx_create - takes the step as two multiplications by 16 with a reduction in between (8 q + 2^31 < 2^51).
+// `wide` is uniform over the launch's modulus (a scalar branch).
+constexpr double I8_WIDE_Q = 0x1p46 - 0x1p24;
+template <int NS> __device__ __forceinline__ double i8_horner(const v4i (&a)[NS], int e, double q, double qinv, bool wide) {
+    double r = (double)a[NS - 1][e];
+    if (!wide) {
+#pragma unroll
+        for (int s = NS - 2; s >= 0; s--) { const double x = r * 256.0 + (double)a[s][e]; r = x - q * __builtin_rint(x * qinv); }
+    } else {
+#pragma unroll
+        for (int s = NS - 2; s >= 0; s--) {
+            const double x1 = r * 16.0, r1 = x1 - q * __builtin_rint(x1 * qinv);
+            const double x = r1 * 16.0 + (double)a[s][e]; r = x - q * __builtin_rint(x * qinv);
+        }
+    }
+    return r < 0 ? r + q : r;
+}
+
 struct I8Args {
     const double *rotf; const u64 *pt; u64 *out;
     size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
@@ -252,18 +272,13 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
         // (no workgroup barrier: a barrier drains every wave's loads at every chunk and exposes the load latency 23 times per workgroup; left alone the six waves
         //  drift by a few chunks and still find the pair's rot tiles in the L2)
     }
-    // sum_s D_s 256^s mod q by Horner: |r| <= q/2 and |D| < 2^31, so r 256 + D is exact in fp64; then canonical
+    // sum_s D_s 256^s mod q by Horner (i8_horner), canonical
+    const bool wide = q > I8_WIDE_Q;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * a.njt + jt) * 2 + (t & 1)) * 64 + lane) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            double r = (double)acc[t][2 * ND - 2][e];
-#pragma unroll
-            for (int s = 2 * ND - 3; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
-            if (r < 0) r += q;
-            o[e] = (u64)r;
-        }
+        for (int e = 0; e < 4; e++) o[e] = (u64)i8_horner(acc[t], e, q, qinv, wide);
     }
 }
 // ---- the same with the rot tiles of the pair staged through LDS (six column waves: the product's 91 columns).  Through the cache alone the six waves fetched
@@ -321,13 +336,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_lds(I8Args a, const ModConst 
     for (int t = 0; t < 4; t++) {
         u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (t >> 1)) * a.njt + jt) * 2 + (t & 1)) * 64 + lane) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            double r = (double)acc[t][8][e];
-#pragma unroll
-            for (int s = 7; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
-            if (r < 0) r += q;
-            o[e] = (u64)r;
-        }
+        for (int e = 0; e < 4; e++) o[e] = (u64)i8_horner(acc[t], e, q, qinv, false);       // (five digits: q < 2^39)
     }
 }
 // ---- the MAC with both operand streams prefetched through an LDS ring by the DMA engine (round 4; the default for full 91-column launches).
@@ -419,18 +428,13 @@ __global__ void __launch_bounds__(384 * HALVES, 1) k_mac_i8_ring(I8Args a, const
         slot = slot + 1 == I8R_DEPTH ? 0 : slot + 1;
     }
     const double q = modc[a.l0 + m].q, qinv = modc[a.l0 + m].qinv;
+    const bool wide = ND == 6 && q > I8_WIDE_Q;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int tg = hf * NT + t;                                                     // tile of the pair: (coefficient, row tile)
         u64 *o = a.T + ((((((size_t)m * H + c) * 2 + (tg >> 1)) * 6 + jt) * 2 + (tg & 1)) * 64 + lane) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            double r = (double)acc[t][2 * ND - 2][e];
-#pragma unroll
-            for (int s = 2 * ND - 3; s >= 0; s--) { const double x = r * 256.0 + (double)acc[t][s][e]; r = x - q * __builtin_rint(x * qinv); }
-            if (r < 0) r += q;
-            o[e] = (u64)r;
-        }
+        for (int e = 0; e < 4; e++) o[e] = (u64)i8_horner(acc[t], e, q, qinv, wide);
     }
 }
 // ---- tile-ordered results -> canonical accumulators.  workgroup = (m, 16 coefficient pairs, half, jt, rt): 256 (n, r) rows x 16 coefficients through LDS
@@ -515,6 +519,11 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (BIG && nl != 1) SFG_FAIL(ctx, "sfg_mac (i8): one 46-bit modulus per launch");
     if (Ncols > 96) SFG_FAIL(ctx, "sfg_mac (i8): more than 96 columns per launch");
     if ((long long)K * ND >= 131072) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums (ND K 2^14 must stay below 2^31)");
+    // digit range: ND signed base-256 digits hold |v| < 2^(8 ND - 1) - the canonical plaintext word (< q) and the centred rot word (<= q / 2); the Horner recombination
+    // (i8_horner) is exact below 2^47 (two x 16 steps above 2^46 - 2^24), and the five-digit kernels use its one-step form only (128 q < 2^53 with room to spare)
+    for (int t = l0; t < l0 + nl; t++) {
+        if (ctx->q[t] >= (BIG ? (1ULL << 47) : (1ULL << 39))) SFG_FAIL(ctx, "sfg_mac (i8): modulus %d = %llu does not fit %d signed base-256 digits / the exact fp64 recombination", t, (unsigned long long)ctx->q[t], ND);
+    }
     const int8_t *B_pre = BIG ? st.B_big : st.B_small;              // streamed transposition: the plaintext tiles are in place, k' = g * kb + baby
     if (B_pre && (K % SFG_D || !st.kb || Ncols != SFG_D)) SFG_FAIL(ctx, "sfg_mac (i8): internal: prepacked tiles need whole block rows and 91 columns");
     const int8_t *A_pre = BIG ? st.A_big : st.A_small;             // the transposed rot tiles of exactly this launch, made by launch_i8_pack_rot_to (I8RotPre)
@@ -613,4 +622,55 @@ int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, 
 int launch_mac_i8_big(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                       int l0, int accumulate, const MacStrides &st) {
     return launch_mac_i8_nd<6>(ctx, rotf, rotf_k_stride, rotf_r_stride, plane0, pt, out, K, R, r0, Ncols, l0, 1, accumulate, st);
+}
+
+// ---- test hook: the product's default MAC on caller-given operands (tests/test_gpu_mac.py; refused without SFG_ENABLE_TEST_HOOKS=1)
+// half rows of canonical words -> the digit-plane rows the plaintext NTT writes (k_ntt_half3<., true>): plane d of row (k, n, l) holds byte c = digit d of word c
+__global__ void __launch_bounds__(256) k_i8_words_to_planes(const u64 *in, u64 *out, int L, unsigned big_mask) {
+    const int H = SFG_N / 2;
+    const size_t row = blockIdx.x; const int l = (int)(row % (size_t)L);
+    const u64 *src = in + row * H; int8_t *dst = reinterpret_cast<int8_t *>(out + row * H);
+    const bool big = (big_mask >> l) & 1u;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const long long v = (long long)src[c];
+        if (big) { int8_t d[6]; i8_digits<6>(v, d);
+#pragma unroll
+            for (int i = 0; i < 6; i++) dst[(size_t)i * H + c] = d[i]; }
+        else { int8_t d[5]; i8_digits<5>(v, d);
+#pragma unroll
+            for (int i = 0; i < 5; i++) dst[(size_t)i * H + c] = d[i]; }
+    }
+}
+extern "C" int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt_half, uint64_t *out, int K, int R, int Ncols, int L, int accumulate, int pt_form) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->test_hooks) SFG_FAIL(ctx, "sfg_mac_i8_dev is a test hook: set SFG_ENABLE_TEST_HOOKS=1 before sfg_ctx_create");
+    if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac_i8: L out of range");
+    if (K < 1 || R < 1 || Ncols < 1) SFG_FAIL(ctx, "sfg_mac_i8: K, R and Ncols must be positive (got %d, %d, %d)", K, R, Ncols);
+    if (Ncols > 96 || (long long)K * 6 >= 131072) SFG_FAIL(ctx, "sfg_mac_i8: at most 96 columns and K < 21846 per launch");
+    if (pt_form != 0 && pt_form != 1) SFG_FAIL(ctx, "sfg_mac_i8: pt_form is 0 (digit planes) or 1 (panel words)");
+    const int N = SFG_N, H = N / 2;
+    std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
+    if (nplanes < 0) return 1;
+    unsigned big_mask = 0, small_mask = 0; for (int l = 0; l < L; l++) (is_big[l] ? big_mask : small_mask) |= 1u << l;
+    const size_t rrows = (size_t)K * R, prows = (size_t)K * Ncols * L;
+    double *rotf = nullptr; u64 *ptp = nullptr;
+    int rc = 0;
+    if (hipMalloc(&rotf, rrows * (size_t)nplanes * N * 8) != hipSuccess || hipMalloc(&ptp, prows * H * 8) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(rotf); SFG_FAIL(ctx, "sfg_mac_i8: out of device memory"); }
+    rc = launch_rot_to_f64(ctx, (const u64 *)rot, rrows, L, L, rotf);                   // centred fp64 planes, {lo 23 bits, hi} pairs for a big modulus: the product's rot operand
+    if (!rc) {
+        if (pt_form == 0) { hipLaunchKernelGGL(k_i8_words_to_planes, dim3((unsigned)prows), dim3(256), 0, ctx->stream, (const u64 *)pt_half, ptp, L, big_mask); if (hipGetLastError() != hipSuccess) { rc = 1; ctx->err = "sfg_mac_i8: plane kernel launch failed"; } }
+        else rc = launch_pack_pt(ctx, (const u64 *)pt_half, ptp, prows, (size_t)H, L, small_mask);       // packed-limb words for the small moduli, plain words for a big one (the DiagCache product's panel)
+    }
+    if (!rc) {
+        MacStrides st;
+        st.rot_k = (size_t)R * L * N; st.rot_r = (size_t)L * N;
+        st.pt_k = (size_t)Ncols * L * H; st.pt_n = (size_t)L * H;
+        st.out_n = (size_t)R * L * N; st.out_r = (size_t)L * N;
+        st.pt_half = true; st.pt_packed = true; st.i8 = st.i8_big = true; st.pt_digits = st.pt_digits_big = pt_form == 0;
+        PhaseTimer t(ctx, "mac");
+        rc = launch_mac_bc(ctx, rotf, (size_t)R, ptp, (u64 *)out, K, R, Ncols, L, accumulate, st, nullptr);
+        t.stop(1);
+    }
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rotf); (void)hipFree(ptp);
+    return rc;
 }

@@ -186,6 +186,17 @@ static void ptc_drop(sfg_ctx *ctx, const sfg_geno *g) {
 void sfg_ptc_invalidate_all(sfg_ctx *ctx) {
     for (const sfg_geno *g : ctx->ptc_genos) { g->ptc.clear(); g->ptc_used = 0; }
 }
+// The owning context goes away (sfg_ctx_destroy, after its queues have drained): every cache it owns is released and its matrices are detached, so that a later
+// sfg_geno_free / sfg_geno_set_plaintext_cache on another context finds no dangling owner.  The matrices themselves stay valid (cache off).
+void sfg_ptc_detach_all(sfg_ctx *ctx) {
+    for (const sfg_geno *g : ctx->ptc_genos) {
+        g->ptc.clear(); g->ptc_used = 0; g->ptc_budget = 0;
+        if (g->ptc_arena) { (void)hipFree(g->ptc_arena); g->ptc_arena = nullptr; }
+        if (g->ptc_perm) { (void)hipFree(g->ptc_perm); g->ptc_perm = nullptr; }
+        g->ptc_owner = nullptr;
+    }
+    ctx->ptc_genos.clear();
+}
 extern "C" void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g) {
     if (!g) return;
     ptc_drop(ctx, g);

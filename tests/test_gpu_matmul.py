@@ -90,3 +90,24 @@ def test_fewer_moduli_and_row_counts(env, s, in_level, max_level):
     """max_level < 5 (three / two / four of the product's moduli: the int8 MAC's modulus indexing, with and without the 46-bit row beside it) and row counts
     that are neither 30 nor a multiple of 16 (s = 17: two row passes of 30 + 4; s = 13: the association scan's 26 rows; s = 3: one partly filled row tile)"""
     run_case(env, 70, 50, s, in_level, max_level, 0, 40 + s)
+
+
+@pytest.fixture(scope="module")
+def env47():
+    """the same ring with q0 replaced by a 47-bit prime - the widest modulus sfg_ctx_create accepts (the int8 MAC then recombines in two x 16 Horner steps)"""
+    from sfgwas_amd import capi
+    q47 = ol.small_primes(14, 47, 1)[0]
+    assert (1 << 47) - (1 << 24) < q47 < (1 << 47)
+    moduli = [q47] + list(ol.Q_PN14[1:])
+    ctx = capi.Context(moduli, ol.P_PN14)
+    ring = ol.Ring(14, moduli, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    yield ctx, ring, keys
+    ctx.close()
+
+
+@pytest.mark.parametrize("nrow,ncol,s,flags", [(70, 50, 3, 0), (40, SLOTS + 30, 2, 2)])
+def test_whole_product_with_a_47_bit_q0(env47, nrow, ncol, s, flags):
+    """every kernel of a product - key switch, encode FFT + NTT with six digit planes, k_mac_i8_ring<6, 2, 0, 2> + epilogue, untile, giant
+    alignment - on a modulus in [2^46, 2^47), every output word vs the oracle (matmult.go:1238-1505)."""
+    run_case(env47, nrow, ncol, s, 5, 5, flags, 470 + s)

@@ -140,3 +140,24 @@ def test_failure_path_hook_is_refused_without_the_test_switch(env):
     assert b"SFG_ENABLE_TEST_HOOKS" in capi.lib().sfg_last_error(other.h)
     other.sync()
     other.close()
+
+
+def test_destroying_the_owner_detaches_its_matrices(env):
+    """a fork that owns a matrix's cache is destroyed BEFORE the matrix is freed on another context - the handle must not keep a pointer to the
+    dead context (sfg_ctx_destroy releases the caches it owns and clears the owner); the matrix keeps multiplying, cache off, and can be cached again elsewhere."""
+    ctx, lib, geno, prod, stats, ref = env
+    g = ctx.geno_upload(geno)
+    fork = ctx.fork()
+    fork.check(lib.sfg_geno_set_plaintext_cache(fork.h, g, 8 << 30), "enable on the fork")
+    Af = fork.fill_uniform_cts(S * 2, LEVEL, 0xA1)
+    out = fork.matmul_resident(Af, S, LEVEL, L, g, 0)
+    assert np.array_equal(out.host(), ref[0])
+    assert stats(g)[0] == 4
+    out.free(); Af.free()
+    fork.close()                                                      # the owner goes first
+    assert stats(g)[:2] == (0, 0)
+    assert np.array_equal(prod(g, T), ref[T])                         # no cache: encoded afresh on the surviving context
+    ctx.check(lib.sfg_geno_set_plaintext_cache(ctx.h, g, 8 << 30), "the parent may take the cache now")
+    assert np.array_equal(prod(g, 0), ref[0])
+    assert stats(g)[0] == 4
+    ctx.geno_free(g)                                                  # (used to dereference the destroyed fork)

@@ -59,3 +59,39 @@ def test_digit_sums_fit_int32_and_horner_recovers_the_ring_mac(q, nd, K):
             r += qf
         want = sum(int(p) * int(t) for p, t in zip(pt, rot)) % q
         assert int(r) % q == want
+
+
+def test_horner_needs_two_steps_of_16_above_2_46():
+    """The one-step recombination x = r 256 + D is exact only while 128 q + 2^31 < 2^53 (q <= 2^46 - 2^24).  For a 47-bit prime - accepted by sfg_ctx_create - the
+    kernels split the step (i8_horner, mac_i8.hip): replayed here in numpy float64 (no FMA, as the library is built with -ffp-contract=off) on random digit sums:
+    the two-step form equals integer arithmetic everywhere, the one-step form does not (that was round 4's latent wrong-answer path)."""
+    q = (1 << 47) - 229375                       # 0x7ffffffc8001, prime, == 1 mod 2^15
+    assert q % (1 << 15) == 1 and q > (1 << 46)
+    nd, n = 6, 20000
+    rnd = np.random.default_rng(46)
+    D = rnd.integers(-(2 ** 31) + 1, 2 ** 31, (2 * nd - 1, n))
+    want = np.array([sum(int(D[s, i]) << (8 * s) for s in range(2 * nd - 1)) % q for i in range(n)], dtype=object)
+    qf, qinv = np.float64(q), np.float64(1.0) / np.float64(q)
+
+    def horner(two_step):
+        r = D[-1].astype(np.float64)
+        for s in range(2 * nd - 3, -1, -1):
+            if two_step:
+                x1 = r * 16.0
+                assert (np.abs(x1) < 2.0 ** 53).all()
+                r1 = x1 - qf * np.rint(x1 * qinv)
+                x = r1 * 16.0 + D[s].astype(np.float64)
+            else:
+                x = r * 256.0 + D[s].astype(np.float64)
+            r = x - qf * np.rint(x * qinv)
+        r = np.where(r < 0, r + qf, r)
+        return np.array([int(v) for v in r], dtype=object)
+
+    assert (horner(True) == want).all()
+    assert (horner(False) != want).sum() > n // 2          # the defect the split removes
+    # and the PN14QP438 prime stays on the one-step form, exactly
+    q0 = Q46
+    want0 = np.array([sum(int(D[s, i]) << (8 * s) for s in range(2 * nd - 1)) % q0 for i in range(n)], dtype=object)
+    qf, qinv = np.float64(q0), np.float64(1.0) / np.float64(q0)
+    assert q0 <= (1 << 46) - (1 << 24)
+    assert (horner(False) == want0).all()
