@@ -18,6 +18,7 @@ constexpr int SFG_N = 1 << SFG_LOGN;      // ring degree (PN14QP438, gwas.go:169
 constexpr int SFG_SLOTS = SFG_N / 2;
 constexpr int SFG_D = 91;                 // ceil(sqrt(8192)), matmult.go:1047
 constexpr int SFG_MAXMOD = 16;
+constexpr unsigned long long SFG_I8_BIG_QMAX = 0x7F7F7F7F7F80ULL;   // largest modulus whose canonical words (<= q - 1) fit six signed base-256 digits (mac_i8.hip, the NTT's six digit planes)
 
 // per-modulus constants, device copy
 struct ModConst {
@@ -56,7 +57,7 @@ struct SfgConfig {
     bool mac_bc = true;            // SFG_MAC_IMPL=dma      the 8 x 3-tile LDS-DMA kernel (mac_dma.hip) instead of the DPP-broadcast kernel (mac_bc.hip)
     bool mac_i8 = true;            // SFG_MAC_IMPL=bc       the DPP-broadcast fp64 kernel for every modulus (round 2's MAC) instead of: small moduli on the int8 matrix core (mac_i8.hip), the 46-bit one on the DPP-broadcast kernel
     size_t i8_keep_reserve = 80ULL << 30;   // SFG_I8_KEEP_RESERVE_GB  HBM that must stay free beside the transposed copies of ALL groups of a caller's rotation cache (association scan) for the int8 MAC to take that call
-    bool mac_i8_big = true;        // SFG_MAC_I8_BIG=1      the 46-bit modulus on the int8 matrix core too (six digits, 36 products, eleven sums) instead of the fp64 DPP-broadcast kernel: identical words, measured slower (13.06 s against 12.49 s per power iteration: its own transposition passes cost more than the kernel saves)
+    bool mac_i8_big = true;        // SFG_MAC_I8_BIG=0      the 46-bit modulus on the fp64 DPP-broadcast kernel k_mac_bc<true> (round 3's default) instead of the int8 matrix core (six digits, 36 products, eleven sums; round 4, same box: 11.14 s against 11.85 s per power iteration - mac_big 0.53 s + 0.5 s of transposition against 1.83 s).  Forced off for a ciphertext modulus above SFG_I8_BIG_QMAX
     bool mac_i8_nolds = true;      // SFG_MAC_I8_ROT=lds    int8 MAC: rot tiles of a coefficient pair staged through LDS (k_mac_i8_lds) instead of shared through the cache (measured at 100k x 1M: 3.31 s against 2.56 s per step - the barriers cost more than the re-fetches)
     double tie_band = 0x1p-50;     // distance from a rounding tie inside which the encoder's double-double value does not prove the rounding (SFG_TEST_TIE_BAND_LOG2 widens it under the test switch)
     bool test_hooks = false;       // SFG_ENABLE_TEST_HOOKS=1   sfg_ctx_encoder_inject_unsafe_for_test may be called (tests of the failure path only)

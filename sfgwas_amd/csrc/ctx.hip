@@ -100,6 +100,9 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
         u64 q = moduli[m];
         if (q >= (1ULL << 47) || (q - 1) % (2ULL * N)) return fail("modulus must be < 2^47 (exact fp64 arithmetic: 14 lazy NTT stages stay below 2^51) and == 1 mod 2N");
         sh->q[m] = q;
+        // six signed base-256 digits hold a canonical plaintext word up to 0x7F7F7F7F7F7F: a ciphertext modulus beyond that (the top 0.8 % of the 47-bit range) keeps its MAC
+        // on the fp64 kernel k_mac_bc<true>, whatever SFG_MAC_I8_BIG says
+        if (m < nq && q > SFG_I8_BIG_QMAX) sh->cfg.mac_i8_big = false;
         sh->psi[m] = psi ? psi[m] : derive_psi(q, logN);
         if (h_powmod(sh->psi[m], N, q) != q - 1) return fail("psi is not a primitive 2N-th root of unity");
         u64 psi_inv = h_invmod(sh->psi[m], q), p = 1, pi = 1;

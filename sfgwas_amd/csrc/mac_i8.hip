@@ -519,10 +519,10 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (BIG && nl != 1) SFG_FAIL(ctx, "sfg_mac (i8): one 46-bit modulus per launch");
     if (Ncols > 96) SFG_FAIL(ctx, "sfg_mac (i8): more than 96 columns per launch");
     if ((long long)K * ND >= 131072) SFG_FAIL(ctx, "sfg_mac (i8): K too large for the int32 digit sums (ND K 2^14 must stay below 2^31)");
-    // digit range: ND signed base-256 digits hold |v| < 2^(8 ND - 1) - the canonical plaintext word (< q) and the centred rot word (<= q / 2); the Horner recombination
-    // (i8_horner) is exact below 2^47 (two x 16 steps above 2^46 - 2^24), and the five-digit kernels use its one-step form only (128 q < 2^53 with room to spare)
+    // digit range: ND signed base-256 digits hold -0x80..80 <= v <= 0x7F..7F - the canonical plaintext word (< q) and the centred rot word (|v| <= q / 2); the Horner
+    // recombination (i8_horner) is exact below 2^47 (two x 16 steps above 2^46 - 2^24), and the five-digit kernels use its one-step form only (128 q < 2^53 with room to spare)
     for (int t = l0; t < l0 + nl; t++) {
-        if (ctx->q[t] >= (BIG ? (1ULL << 47) : (1ULL << 39))) SFG_FAIL(ctx, "sfg_mac (i8): modulus %d = %llu does not fit %d signed base-256 digits / the exact fp64 recombination", t, (unsigned long long)ctx->q[t], ND);
+        if (ctx->q[t] > (BIG ? SFG_I8_BIG_QMAX : (1ULL << 38))) SFG_FAIL(ctx, "sfg_mac (i8): modulus %d = %llu does not fit %d signed base-256 digits / the exact fp64 recombination", t, (unsigned long long)ctx->q[t], ND);
     }
     const int8_t *B_pre = BIG ? st.B_big : st.B_small;              // streamed transposition: the plaintext tiles are in place, k' = g * kb + baby
     if (B_pre && (K % SFG_D || !st.kb || Ncols != SFG_D)) SFG_FAIL(ctx, "sfg_mac (i8): internal: prepacked tiles need whole block rows and 91 columns");
@@ -652,6 +652,7 @@ extern "C" int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t 
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) return 1;
     unsigned big_mask = 0, small_mask = 0; for (int l = 0; l < L; l++) (is_big[l] ? big_mask : small_mask) |= 1u << l;
+    if (big_mask && !ctx->cfg.mac_i8_big) SFG_FAIL(ctx, "sfg_mac_i8: a modulus above 2^36 is on the fp64 kernel in this context (SFG_MAC_I8_BIG=0, or it exceeds six signed digits: q > 0x7F7F7F7F7F80)");
     const size_t rrows = (size_t)K * R, prows = (size_t)K * Ncols * L;
     double *rotf = nullptr; u64 *ptp = nullptr;
     int rc = 0;

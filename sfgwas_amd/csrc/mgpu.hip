@@ -1,0 +1,459 @@
+// mgpu.hip — SURVEY §8e as a PRODUCT entry point: one party's local products on the G GPUs of a node, behind the C-ABI (sfg_mgpu_*, include/sfgwas_hip.h).
+//
+// The reference runs ONE OS process per party (run_example.sh:1-12) and calls MatMult4StreamCompute twice per power iteration (gwas/pca.go:344,352) and
+// MatMult4Stream once per SNP batch of the association scan (gwas/assoc.go:360-408).  A Go party process therefore needs all of a node's GPUs from ONE process:
+// sfg_mgpu_create makes one context per device and one RCCL communicator set (ncclCommInitAll); every product call runs one host thread per device.  The same
+// engine serves one-process-per-GPU launchers (bench.py under torch.distributed.run): sfg_mgpu_create_rank joins a world with a 128-byte id carried by the caller.
+//
+// Partitioning (the arithmetic of sfgwas_amd/sharding.py restated in C): the genotype matrix X (n_ind x m_snp) is split by blocks of 8192 SNP columns.
+//   Q  * X    (kp x n_ind)(n_ind x m_snp): rank r owns output block columns [blk0, blk1).  No data-path collective: every rank key-switches the baby-step rotation
+//             cache of all inputs itself (72 ms at 100k x 1M; an all-gather of a sharded build would move 25 GB into every rank).
+//   Q' * X^T  (kp x m_snp)(m_snp x n_ind): contraction over the rank's SNP blocks.  Key switching is not bit-linear, so the partial sums are combined BEFORE the
+//             giant-step rotations: per output block column j, the canonical uint64 accumulators [giant][i][2][L][N] (padded to world * ceil(91 / world) giant slots)
+//             are reduce-scattered over the giant axis on a second queue while column j + 1 is being multiplied (two column buffers); then every rank reduces mod q,
+//             aligns ITS giant steps (sfg_matmul_finalize_slots_dev), and the aligned partial outputs are all-reduced and reduced once more.
+//             Sums of `world` canonical residues stay below world * 2^47: no overflow in uint64.
+//
+// Transports: "rccl" (ncclReduceScatter / ncclAllReduce on uint64 over xGMI; the library resolves librccl at run time with dlopen so that single-GPU users need
+// no RCCL and a process that already holds a copy - PyTorch's - shares it) and "direct" (single process only: a rank sums its slice straight out of its peers'
+// buffers with a kernel - peer access over xGMI, or plain loads when several ranks share one device, which RCCL refuses: that is how world sizes 2 and 3 are
+// tested on a one-GPU box; host-side rendezvous, no overlap).  Integer sums: both give identical words.
+#include "common.hpp"
+#include <rccl/rccl.h>          // types and prototypes only; the functions are resolved at run time (Rccl below)
+#include <dlfcn.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct Rccl {
+    void *so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string load() {
+        if (so) return "";
+        const char *names[] = {getenv("SFG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { if (!n || !*n) continue; so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
+        if (!so) return std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?") + " - set SFG_RCCL_LIB, or use SFG_MGPU_TRANSPORT=direct in a single process";
+#define SFG_RCCL_SYM(f) f = (decltype(f))dlsym(so, "nccl" #f); if (!f) return std::string("RCCL symbol missing: nccl" #f)
+        SFG_RCCL_SYM(GetUniqueId); SFG_RCCL_SYM(CommInitAll); SFG_RCCL_SYM(CommInitRank); SFG_RCCL_SYM(CommDestroy); SFG_RCCL_SYM(ReduceScatter); SFG_RCCL_SYM(AllReduce);
+        SFG_RCCL_SYM(GetErrorString);
+#undef SFG_RCCL_SYM
+        return "";
+    }
+};
+Rccl g_rccl; std::mutex g_rccl_mu;          // (function pointers of a shared object: the one process-wide datum of the library, written once under the lock)
+
+struct MgRank {
+    sfg_ctx *ctx = nullptr;
+    int rank = 0, device = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t coll = nullptr;             // the collectives' queue (RCCL kernels beside the MAC of the next column)
+    hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_rs[2] = {nullptr, nullptr}, ev_c = nullptr;
+    std::string err;
+};
+
+// host-side meeting point of the rank threads of the direct transport
+struct Rendezvous {
+    std::mutex m; std::condition_variable cv; int n = 1, count = 0; unsigned long gen = 0; std::atomic<bool> failed{false};
+    const void *ptr[64];
+    bool barrier() {       // false: a peer has failed (nobody will arrive)
+        std::unique_lock<std::mutex> lk(m);
+        if (failed.load()) return false;
+        const unsigned long g = gen;
+        if (++count == n) { count = 0; gen++; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return gen != g || failed.load(); });
+        return gen != g;
+    }
+    void fail() { std::unique_lock<std::mutex> lk(m); failed.store(true); cv.notify_all(); }
+};
+
+// out[x] = sum_p src[p][x] over n peers' slices (uint64, wraps never: world * 2^47)
+struct PeerPtrs { const u64 *p[64]; };
+__global__ void __launch_bounds__(256) k_sum_peers(u64 *out, PeerPtrs src, int n, size_t count) {
+    for (size_t x = (size_t)blockIdx.x * 256 + threadIdx.x; x < count; x += (size_t)gridDim.x * 256) {
+        u64 s = 0;
+        for (int p = 0; p < n; p++) s += src.p[p][x];
+        out[x] = s;
+    }
+}
+
+}  // namespace
+
+struct sfg_mgpu {
+    int world = 1;
+    bool single_process = true, direct = false, force_coll = false;
+    size_t cache_budget = 72ULL << 30;      // SFG_MGPU_CACHE_GB: a rank's own Q'X^T rotation cache up to this size -> per-column pipelined reduce-scatter
+    std::vector<MgRank> r;                  // local ranks
+    Rendezvous rv;
+    std::string err;
+};
+struct sfg_mgeno {
+    size_t nrow = 0, ncol = 0;              // of the GLOBAL matrix
+    std::vector<sfg_geno *> shard;          // per local rank: its SNP-block window [col0, col1) as a resident matrix (nullptr: the rank owns no block)
+    std::vector<void *> owned;              // per local rank: device buffer behind a non-owning handle (nullptr: the handle owns its memory)
+    std::vector<size_t> blk0, blk1;
+};
+
+thread_local std::string g_mgpu_create_error;
+#define MG_FAIL(mg, ...) do { char _b[640]; snprintf(_b, sizeof _b, __VA_ARGS__); (mg)->err = _b; return 1; } while (0)
+#define R_FAIL(R, ...) do { char _b[640]; snprintf(_b, sizeof _b, __VA_ARGS__); (R).err = _b; return 1; } while (0)
+#define R_HIP(R, call) do { hipError_t _e = (call); if (_e != hipSuccess) R_FAIL(R, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define R_CTX(R, call) do { if ((call)) { (R).err = std::string(#call).substr(0, std::string(#call).find('(')) + ": " + (R).ctx->err; return 1; } } while (0)
+#define R_NCCL(R, call) do { ncclResult_t _e = (call); if (_e != ncclSuccess) R_FAIL(R, "%s failed: %s", #call, g_rccl.GetErrorString(_e)); } while (0)
+
+// one host thread per local rank (the library's rule: one thread drives a context at a time); first failure wins
+template <class F> static int run_ranks(sfg_mgpu *mg, F &&fn) {
+    const int n = (int)mg->r.size();
+    std::vector<int> rc((size_t)n, 0);
+    for (auto &R : mg->r) R.err.clear();
+    mg->rv.failed.store(false);
+    auto body = [&](int i) { rc[(size_t)i] = fn(mg->r[(size_t)i], i); if (rc[(size_t)i]) mg->rv.fail(); };
+    if (n == 1) body(0);
+    else { std::vector<std::thread> th; for (int i = 0; i < n; i++) th.emplace_back(body, i); for (auto &t : th) t.join(); }
+    for (int i = 0; i < n; i++) if (rc[(size_t)i] && !mg->r[(size_t)i].err.empty() && mg->r[(size_t)i].err != "a peer rank failed") {
+        mg->err = "rank " + std::to_string(mg->r[(size_t)i].rank) + " (device " + std::to_string(mg->r[(size_t)i].device) + "): " + mg->r[(size_t)i].err; return 1; }
+    for (int i = 0; i < n; i++) if (rc[(size_t)i]) { mg->err = "rank " + std::to_string(mg->r[(size_t)i].rank) + ": " + (mg->r[(size_t)i].err.empty() ? mg->r[(size_t)i].ctx->err : mg->r[(size_t)i].err); return 1; }
+    return 0;
+}
+
+extern "C" int sfg_mgpu_shard(int world, size_t ncol, int rank, size_t *blk0, size_t *blk1, size_t *col0, size_t *col1) {
+    if (world < 1 || rank < 0 || rank >= world || !ncol) return 1;
+    const size_t nblk = (ncol + SFG_SLOTS - 1) / SFG_SLOTS, b0 = nblk * (size_t)rank / (size_t)world, b1 = nblk * ((size_t)rank + 1) / (size_t)world;
+    if (blk0) *blk0 = b0; if (blk1) *blk1 = b1;
+    if (col0) *col0 = b0 * SFG_SLOTS; if (col1) *col1 = std::min(b1 * (size_t)SFG_SLOTS, ncol);
+    return 0;
+}
+
+static void mgpu_read_env(sfg_mgpu *mg) {
+    if (const char *e = getenv("SFG_MGPU_TRANSPORT")) mg->direct = !strcmp(e, "direct");
+    if (const char *e = getenv("SFG_MGPU_FORCE_COLLECTIVES")) mg->force_coll = atoi(e) != 0;
+    if (const char *e = getenv("SFG_MGPU_CACHE_GB")) mg->cache_budget = (size_t)(atof(e) * (double)(1ULL << 30));
+}
+static const char *rank_exec_init(MgRank &R) {
+    if (hipSetDevice(R.device) != hipSuccess) return "hipSetDevice failed";
+    if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&R.ev_acc[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&R.ev_rs[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    if (hipEventCreateWithFlags(&R.ev_c, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    return nullptr;
+}
+
+extern "C" void sfg_mgpu_destroy(sfg_mgpu *mg) {
+    if (!mg) return;
+    for (auto &R : mg->r) {
+        (void)hipSetDevice(R.device);
+        if (R.ctx) (void)sfg_sync_all(R.ctx);
+        if (R.coll) (void)hipStreamSynchronize(R.coll);
+    }
+    for (auto &R : mg->r) if (R.comm) { (void)hipSetDevice(R.device); (void)g_rccl.CommDestroy(R.comm); }
+    for (auto &R : mg->r) {
+        (void)hipSetDevice(R.device);
+        if (R.coll) (void)hipStreamDestroy(R.coll);
+        for (int i = 0; i < 2; i++) { if (R.ev_acc[i]) (void)hipEventDestroy(R.ev_acc[i]); if (R.ev_rs[i]) (void)hipEventDestroy(R.ev_rs[i]); }
+        if (R.ev_c) (void)hipEventDestroy(R.ev_c);
+        if (R.ctx) sfg_ctx_destroy(R.ctx);
+    }
+    delete mg;
+}
+
+extern "C" int sfg_mgpu_unique_id(uint8_t *id128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    { std::lock_guard<std::mutex> lk(g_rccl_mu); const std::string e = g_rccl.load(); if (!e.empty()) { g_mgpu_create_error = e; return 1; } }
+    ncclUniqueId id; const ncclResult_t rc = g_rccl.GetUniqueId(&id);
+    if (rc != ncclSuccess) { g_mgpu_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(rc); return 1; }
+    memcpy(id128, &id, 128); return 0;
+}
+
+static int mgpu_create_common(sfg_mgpu **out, const int *devices, int n, int rank0, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
+                              const uint64_t *psi, double scale) {
+    *out = nullptr;
+    if (n < 1 || n > 64 || world < n || world > 64 * 1024) { g_mgpu_create_error = "sfg_mgpu_create: bad device / rank counts"; return 1; }
+    sfg_mgpu *mg = new sfg_mgpu();
+    mg->world = world; mg->single_process = id128 == nullptr; mg->rv.n = n;
+    mgpu_read_env(mg);
+    auto fail = [&](const std::string &m) { g_mgpu_create_error = m; sfg_mgpu_destroy(mg); return 1; };
+    bool dup = false;
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) dup = dup || devices[i] == devices[j];
+    if (dup) mg->direct = true;                      // several ranks on one device (RCCL refuses that): the in-process transport
+    if (mg->direct && !mg->single_process) return fail("sfg_mgpu_create_rank: the direct transport exists inside one process only (unset SFG_MGPU_TRANSPORT)");
+    mg->r.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        MgRank &R = mg->r[(size_t)i]; R.rank = rank0 + i; R.device = devices[i];
+        if (sfg_ctx_create(&R.ctx, devices[i], logN, nq, np, moduli, psi, scale)) return fail(std::string("sfg_mgpu_create: device ") + std::to_string(devices[i]) + ": " + sfg_last_error(nullptr));
+        if (const char *e = rank_exec_init(R)) return fail(e);
+    }
+    const bool need_comm = world > 1 || mg->force_coll;
+    if (need_comm && !mg->direct) {
+        { std::lock_guard<std::mutex> lk(g_rccl_mu); const std::string e = g_rccl.load(); if (!e.empty()) return fail(e); }
+        if (mg->single_process) {
+            std::vector<ncclComm_t> comms((size_t)n);
+            const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), n, devices);
+            if (rc != ncclSuccess) return fail(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc));
+            for (int i = 0; i < n; i++) mg->r[(size_t)i].comm = comms[(size_t)i];
+        } else {
+            ncclUniqueId id; memcpy(&id, id128, 128);
+            if (hipSetDevice(devices[0]) != hipSuccess) return fail("hipSetDevice failed");
+            const ncclResult_t rc = g_rccl.CommInitRank(&mg->r[0].comm, world, id, rank0);
+            if (rc != ncclSuccess) return fail(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc));
+        }
+    }
+    if (mg->direct) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) if (devices[i] != devices[j]) {
+        int can = 0; (void)hipDeviceCanAccessPeer(&can, devices[i], devices[j]);
+        if (!can) return fail("sfg_mgpu_create: direct transport: devices " + std::to_string(devices[i]) + " and " + std::to_string(devices[j]) + " cannot access each other's memory");
+        (void)hipSetDevice(devices[i]);
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
+    *out = mg;
+    return 0;
+}
+extern "C" int sfg_mgpu_create(sfg_mgpu **out, const int *devices, int n, int logN, int nq, int np, const uint64_t *moduli, const uint64_t *psi, double scale) {
+    if (!devices) { g_mgpu_create_error = "sfg_mgpu_create: null device list"; *out = nullptr; return 1; }
+    return mgpu_create_common(out, devices, n, 0, n, nullptr, logN, nq, np, moduli, psi, scale);
+}
+extern "C" int sfg_mgpu_create_rank(sfg_mgpu **out, int device, int rank, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
+                                    const uint64_t *psi, double scale) {
+    if (!id128 || rank < 0 || rank >= world) { g_mgpu_create_error = "sfg_mgpu_create_rank: bad rank / missing id"; *out = nullptr; return 1; }
+    return mgpu_create_common(out, &device, 1, rank, world, id128, logN, nq, np, moduli, psi, scale);
+}
+extern "C" const char *sfg_mgpu_last_error(const sfg_mgpu *mg) { return mg ? mg->err.c_str() : g_mgpu_create_error.c_str(); }
+extern "C" int sfg_mgpu_world(const sfg_mgpu *mg) { return mg->world; }
+extern "C" int sfg_mgpu_nlocal(const sfg_mgpu *mg) { return (int)mg->r.size(); }
+extern "C" int sfg_mgpu_rank(const sfg_mgpu *mg, int local) { return local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].rank : -1; }
+extern "C" sfg_ctx *sfg_mgpu_ctx(sfg_mgpu *mg, int local) { return local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].ctx : nullptr; }
+extern "C" const char *sfg_mgpu_transport(const sfg_mgpu *mg) { return mg->world == 1 && !mg->force_coll ? "none" : mg->direct ? "direct" : "rccl"; }
+
+extern "C" int sfg_mgpu_load_rotkey(sfg_mgpu *mg, uint64_t galois_el, const uint64_t *key_host, int montgomery_form) {
+    return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_ctx_load_rotkey(R.ctx, galois_el, key_host, montgomery_form)); return 0; });
+}
+extern "C" int sfg_mgpu_load_relinkey(sfg_mgpu *mg, const uint64_t *key_host, int montgomery_form) {
+    return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_ctx_load_relinkey(R.ctx, key_host, montgomery_form)); return 0; });
+}
+extern "C" int sfg_mgpu_fill_rotkeys_synthetic(sfg_mgpu *mg, const int *rot_left, int nrot, uint64_t seed) {
+    return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_fill_rotkeys_synthetic(R.ctx, rot_left, nrot, seed)); return 0; });
+}
+extern "C" int sfg_mgpu_synchronize(sfg_mgpu *mg) {
+    return run_ranks(mg, [&](MgRank &R, int) { R_HIP(R, hipSetDevice(R.device)); R_HIP(R, hipStreamSynchronize(R.coll)); R_CTX(R, sfg_ctx_synchronize(R.ctx)); return 0; });
+}
+
+// ---------------------------------------------------------------- the sharded genotype matrix
+static sfg_mgeno *mgeno_new(sfg_mgpu *mg, size_t nrow, size_t ncol) {
+    sfg_mgeno *g = new sfg_mgeno(); g->nrow = nrow; g->ncol = ncol;
+    const size_t n = mg->r.size(); g->shard.assign(n, nullptr); g->owned.assign(n, nullptr); g->blk0.assign(n, 0); g->blk1.assign(n, 0);
+    return g;
+}
+extern "C" void sfg_mgpu_geno_free(sfg_mgpu *mg, sfg_mgeno *g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->shard.size() && i < mg->r.size(); i++) {
+        if (g->shard[i]) sfg_geno_free(mg->r[i].ctx, g->shard[i]);
+        if (g->owned[i]) (void)sfg_free(mg->r[i].ctx, g->owned[i]);
+    }
+    delete g;
+}
+// geno_host: the party's WHOLE matrix, row-major int8 with row stride ld (what GenoFileStream delivers); every local rank uploads its own column window
+extern "C" int sfg_mgpu_geno_upload(sfg_mgpu *mg, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_mgeno **out) {
+    *out = nullptr;
+    if (!geno_host || !nrow || !ncol || ld < ncol) MG_FAIL(mg, "sfg_mgpu_geno_upload: bad dimensions");
+    sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
+    const int rc = run_ranks(mg, [&](MgRank &R, int i) {
+        size_t c0, c1; (void)sfg_mgpu_shard(mg->world, ncol, R.rank, &g->blk0[(size_t)i], &g->blk1[(size_t)i], &c0, &c1);
+        if (c1 > c0) R_CTX(R, sfg_geno_upload(R.ctx, geno_host + c0, nrow, c1 - c0, ld, &g->shard[(size_t)i]));
+        return 0;
+    });
+    if (rc) { sfg_mgpu_geno_free(mg, g); return 1; }
+    *out = g; return 0;
+}
+// per-rank handles the caller made on the ranks' own contexts (sfg_geno_from_bed / _from_pgen / _from_device of the rank's window); ownership passes to the result.
+// shards[i] == NULL for a local rank whose window is empty.
+extern "C" int sfg_mgpu_geno_adopt(sfg_mgpu *mg, size_t nrow, size_t ncol, sfg_geno *const *shards, sfg_mgeno **out) {
+    *out = nullptr;
+    sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
+    for (size_t i = 0; i < mg->r.size(); i++) {
+        size_t c0, c1; (void)sfg_mgpu_shard(mg->world, ncol, mg->r[i].rank, &g->blk0[i], &g->blk1[i], &c0, &c1);
+        if ((c1 > c0) != (shards[i] != nullptr) || (shards[i] && (shards[i]->nrow != nrow || shards[i]->ncol != c1 - c0))) {
+            delete g; MG_FAIL(mg, "sfg_mgpu_geno_adopt: shard %zu is not the %zu x %zu window [%zu, %zu) of rank %d", i, nrow, c1 - c0, c0, c1, mg->r[i].rank); }
+    }
+    for (size_t i = 0; i < mg->r.size(); i++) g->shard[i] = shards[i];
+    *out = g; return 0;
+}
+// bench.py / tests: every rank generates exactly the window of the SAME global synthetic matrix it owns (sfg_fill_geno_window_dev), so any world size multiplies
+// the same matrix.  packed != 0: 2-bit residency (sfg_geno_pack)
+extern "C" int sfg_mgpu_geno_synthetic(sfg_mgpu *mg, size_t nrow, size_t ncol, uint64_t seed, int packed, sfg_mgeno **out) {
+    *out = nullptr;
+    if (!nrow || !ncol) MG_FAIL(mg, "sfg_mgpu_geno_synthetic: bad dimensions");
+    sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
+    const int rc = run_ranks(mg, [&](MgRank &R, int i) {
+        size_t c0, c1; (void)sfg_mgpu_shard(mg->world, ncol, R.rank, &g->blk0[(size_t)i], &g->blk1[(size_t)i], &c0, &c1);
+        if (c1 <= c0) return 0;
+        const size_t w = c1 - c0; void *buf = nullptr;
+        R_CTX(R, sfg_malloc(R.ctx, &buf, nrow * w));
+        g->owned[(size_t)i] = buf;
+        R_CTX(R, sfg_fill_geno_window_dev(R.ctx, (int8_t *)buf, nrow, w, w, c0, ncol, seed));
+        R_CTX(R, sfg_geno_from_device(R.ctx, (const int8_t *)buf, nrow, w, w, &g->shard[(size_t)i]));
+        if (packed) {
+            sfg_geno *p = nullptr;
+            R_CTX(R, sfg_geno_pack(R.ctx, g->shard[(size_t)i], &p));
+            sfg_geno_free(R.ctx, g->shard[(size_t)i]); g->shard[(size_t)i] = p;
+            R_CTX(R, sfg_free(R.ctx, buf)); g->owned[(size_t)i] = nullptr;
+        }
+        return 0;
+    });
+    if (rc) { sfg_mgpu_geno_free(mg, g); return 1; }
+    *out = g; return 0;
+}
+extern "C" const sfg_geno *sfg_mgpu_geno_shard(const sfg_mgeno *g, int local) { return local >= 0 && (size_t)local < g->shard.size() ? g->shard[(size_t)local] : nullptr; }
+extern "C" int sfg_mgpu_geno_dims(const sfg_mgeno *g, size_t *nrow, size_t *ncol) { if (nrow) *nrow = g->nrow; if (ncol) *ncol = g->ncol; return 0; }
+extern "C" int sfg_mgpu_geno_blocks(const sfg_mgeno *g, int local, size_t *blk0, size_t *blk1) {
+    if (local < 0 || (size_t)local >= g->shard.size()) return 1;
+    if (blk0) *blk0 = g->blk0[(size_t)local]; if (blk1) *blk1 = g->blk1[(size_t)local]; return 0;
+}
+extern "C" int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *g, size_t max_bytes_per_rank) {
+    return run_ranks(mg, [&](MgRank &R, int i) { if (g->shard[(size_t)i]) R_CTX(R, sfg_geno_set_plaintext_cache(R.ctx, g->shard[(size_t)i], max_bytes_per_rank)); return 0; });
+}
+
+// ---------------------------------------------------------------- collectives (enqueued on `st` of the calling rank, in order with it)
+static int coll_reduce_scatter(sfg_mgpu *mg, MgRank &R, const u64 *send, u64 *recv, size_t recv_count, hipStream_t st) {
+    if (!mg->direct) { R_NCCL(R, g_rccl.ReduceScatter(send, recv, recv_count, ncclUint64, ncclSum, R.comm, st)); return 0; }
+    const int n = mg->world;
+    R_HIP(R, hipStreamSynchronize(st));                               // this rank's contribution is complete
+    mg->rv.ptr[R.rank] = send;
+    if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");
+    PeerPtrs pp; for (int p = 0; p < n; p++) pp.p[p] = (const u64 *)mg->rv.ptr[p] + (size_t)R.rank * recv_count;
+    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>((recv_count + 255) / 256, 4096)), dim3(256), 0, st, recv, pp, n, recv_count);
+    R_HIP(R, hipGetLastError());
+    R_HIP(R, hipStreamSynchronize(st));
+    if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");          // everybody has read: the send buffers may be overwritten
+    return 0;
+}
+static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, u64 *buf, size_t count, hipStream_t st) {
+    if (!mg->direct) { R_NCCL(R, g_rccl.AllReduce(buf, buf, count, ncclUint64, ncclSum, R.comm, st)); return 0; }
+    const int n = mg->world;
+    // in place: sum into a private copy first (a peer may still be reading this rank's buffer), swap after the second meeting
+    u64 *tmp = nullptr;
+    R_CTX(R, sfg_scratch(R.ctx, "mg.ar", count * 8, (void **)&tmp));
+    R_HIP(R, hipStreamSynchronize(st));
+    mg->rv.ptr[R.rank] = buf;
+    if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");
+    PeerPtrs pp; for (int p = 0; p < n; p++) pp.p[p] = (const u64 *)mg->rv.ptr[p];
+    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>((count + 255) / 256, 4096)), dim3(256), 0, st, tmp, pp, n, count);
+    R_HIP(R, hipGetLastError());
+    R_HIP(R, hipStreamSynchronize(st));
+    if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");
+    R_HIP(R, hipMemcpyAsync(buf, tmp, count * 8, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// ---------------------------------------------------------------- the products
+// Q' * X^T of one rank: see the header of this file
+static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const u64 *A, int s, int in_level, int L, const sfg_mgeno *g, unsigned flags, u64 *out) {
+    sfg_ctx *ctx = R.ctx;
+    R_HIP(R, hipSetDevice(R.device));
+    const int world = mg->world, d = SFG_D, N = SFG_N;
+    const sfg_geno *shard = g->shard[(size_t)li];
+    const int nloc = (int)(g->blk1[(size_t)li] - g->blk0[(size_t)li]), nbr_x = (int)((g->nrow + SFG_SLOTS - 1) / SFG_SLOTS);
+    const unsigned fl = (flags & SFG_SQUARE) | SFG_TRANSPOSE;
+    const size_t outw = (size_t)2 * L * N, accw = (size_t)s * outw;
+    const int gpr = (d + world - 1) / world, g_lo = R.rank * gpr;
+    const size_t col = (size_t)d * accw, colp = (size_t)world * gpr * accw, mine = (size_t)gpr * accw;
+    if (world == 1 && !mg->force_coll) { R_CTX(R, sfg_matmul_resident_dev(ctx, A, s, in_level, L, shard, fl, out)); return 0; }
+    if (in_level < L) R_FAIL(R, "sfg_mgpu_matmul: input level %d below max_level %d", in_level, L);
+    size_t jobw = 0, tailw = 0;
+    R_CTX(R, sfg_rotcache_layout(ctx, s, L, &jobw, &tailw));
+    const size_t cache_w = (size_t)nloc * s * jobw + tailw;
+    const bool pipe = cache_w * 8 <= mg->cache_budget;
+    u64 *acc_mine = nullptr, *acc2 = nullptr; double *cache = nullptr;
+    R_CTX(R, sfg_scratch(ctx, "mg.mine", (size_t)nbr_x * mine * 8, (void **)&acc_mine));
+    hipStream_t cs = ctx->stream;
+    // (the collectives' queue must not start before earlier work of the compute queue that still reads these buffers: previous call's finalize)
+    R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
+    if (pipe) {
+        const bool fresh = ctx->pool.find("mg.acc2") == ctx->pool.end() || ctx->pool["mg.acc2"].second < 2 * colp * 8;
+        R_CTX(R, sfg_scratch(ctx, "mg.acc2", 2 * colp * 8, (void **)&acc2));
+        if (fresh || !nloc) R_HIP(R, hipMemsetAsync(acc2, 0, 2 * colp * 8, cs));       // the padded giant slots (>= 91) are never written by a product: zero once
+        if (nloc) {
+            R_CTX(R, sfg_scratch(ctx, "mg.cache", cache_w * 8, (void **)&cache));
+            R_CTX(R, sfg_rotcache_build_rows_dev(ctx, A, s, in_level, L, nloc, 0, nloc, cache));
+        }
+        for (int j = 0; j < nbr_x; j++) {              // column j is multiplied while column j - 1 is reduce-scattered
+            u64 *buf = acc2 + (size_t)(j & 1) * colp;
+            if (j >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[j & 1], 0));            // the reduce-scatter of column j - 2 has read this buffer
+            if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
+            R_HIP(R, hipEventRecord(R.ev_acc[j & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[j & 1], 0));
+            if (coll_reduce_scatter(mg, R, buf, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
+            R_HIP(R, hipEventRecord(R.ev_rs[j & 1], R.coll));
+        }
+    } else {                                           // the rank's own cache would not fit: the library's grouped rotation cache, reduce-scatters after the product
+        const size_t acc_w = ((size_t)nbr_x * d + ((size_t)world * gpr - d)) * accw;
+        R_CTX(R, sfg_scratch(ctx, "mg.acc2", acc_w * 8, (void **)&acc2));
+        R_HIP(R, hipMemsetAsync(acc2, 0, acc_w * 8, cs));
+        if (nloc) R_CTX(R, sfg_matmul_accumulate_dev(ctx, A, s, in_level, L, shard, fl, 0, nloc, 0, nbr_x, 0, acc2));
+        R_HIP(R, hipEventRecord(R.ev_acc[0], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[0], 0));
+        for (int j = 0; j < nbr_x; j++)                 // the window of the last giants runs into the next block column: those slots are ignored by the finalize
+            if (coll_reduce_scatter(mg, R, acc2 + (size_t)j * col, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
+    }
+    R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
+    R_CTX(R, sfg_reduce_rows_dev(ctx, acc_mine, (size_t)nbr_x * gpr * s * 2, L));
+    R_CTX(R, sfg_matmul_finalize_slots_dev(ctx, acc_mine, s, L, nbr_x, gpr, g_lo, 0, gpr, 0, out));
+    R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
+    if (coll_all_reduce(mg, R, out, (size_t)s * nbr_x * outw, R.coll)) return 1;     // aligned partial outputs of the ranks' giant shards
+    R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
+    R_CTX(R, sfg_reduce_rows_dev(ctx, out, (size_t)s * nbr_x * 2, L));
+    return 0;
+}
+
+// device-pointer form.  A_dev[i] / out_dev[i] belong to local rank i (device sfg_mgpu_ctx(mg, i)):
+//   flags without SFG_TRANSPOSE (Q * X):   A_dev[i] = the whole [s][ceil(nrow / 8192)] input grid (replicated); out_dev[i] = [s][blk1 - blk0] of the rank's block columns
+//   SFG_TRANSPOSE (Q' * X^T):              A_dev[i] = [s][blk1 - blk0] inputs of the rank's SNP blocks;          out_dev[i] = the whole [s][ceil(nrow / 8192)] result, on EVERY rank
+// Stream-ordered on each rank's context queue; sfg_mgpu_synchronize waits.
+extern "C" int sfg_mgpu_matmul_dev(sfg_mgpu *mg, const uint64_t *const *A_dev, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags,
+                                   uint64_t *const *out_dev) {
+    if (!g || g->shard.size() != mg->r.size()) MG_FAIL(mg, "sfg_mgpu_matmul: the matrix belongs to another engine");
+    if (s < 1 || max_level < 1) MG_FAIL(mg, "sfg_mgpu_matmul: bad s / max_level");
+    return run_ranks(mg, [&](MgRank &R, int i) {
+        R_HIP(R, hipSetDevice(R.device));
+        if (flags & SFG_TRANSPOSE) return rank_contract(mg, R, i, (const u64 *)A_dev[i], s, in_level, max_level, g, flags, (u64 *)out_dev[i]);
+        if (g->shard[(size_t)i]) R_CTX(R, sfg_matmul_resident_dev(R.ctx, A_dev[i], s, in_level, max_level, g->shard[(size_t)i], flags & SFG_SQUARE, out_dev[i]));
+        return 0;
+    });
+}
+
+// host-pointer form = MatMult4StreamCompute on the sharded resident matrix (what the Go shim calls):
+//   Q * X   : A_host [s][nbr][2][in_level+1][N] -> out_host [s][m_ct][2][max_level][N] (every block column, gathered from the local ranks; in a multi-process world
+//             a process fills the block columns of ITS ranks and leaves the others untouched)
+//   Q' * X^T: A_host [s][m_ct][...] (all SNP blocks; each rank takes its own) -> out_host [s][nbr][2][max_level][N], complete in every process
+extern "C" int sfg_mgpu_matmul(sfg_mgpu *mg, const uint64_t *A_host, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags, uint64_t *out_host) {
+    if (!g || g->shard.size() != mg->r.size()) MG_FAIL(mg, "sfg_mgpu_matmul: the matrix belongs to another engine");
+    const size_t N = SFG_N, ctw = 2 * (size_t)(in_level + 1) * N, outw = 2 * (size_t)max_level * N;
+    const size_t nbr_x = (g->nrow + SFG_SLOTS - 1) / SFG_SLOTS, mct = (g->ncol + SFG_SLOTS - 1) / SFG_SLOTS;
+    const bool tr = flags & SFG_TRANSPOSE;
+    const size_t n = mg->r.size();
+    std::vector<uint64_t *> A(n, nullptr), O(n, nullptr);
+    int rc = run_ranks(mg, [&](MgRank &R, int i) {
+        const size_t nloc = g->blk1[(size_t)i] - g->blk0[(size_t)i], na = tr ? nloc : nbr_x, no = tr ? nbr_x : nloc;
+        R_CTX(R, sfg_scratch(R.ctx, "mg.Ain", std::max<size_t>(na, 1) * s * ctw * 8, (void **)&A[(size_t)i]));
+        R_CTX(R, sfg_scratch(R.ctx, "mg.Oout", std::max<size_t>(no, 1) * s * outw * 8, (void **)&O[(size_t)i]));
+        if (!tr) { if (na) R_CTX(R, sfg_memcpy_h2d(R.ctx, A[(size_t)i], A_host, (size_t)s * nbr_x * ctw * 8)); }
+        else for (int r = 0; r < s && nloc; r++)      // row r of the input grid: the rank's block range
+            R_CTX(R, sfg_memcpy_h2d(R.ctx, A[(size_t)i] + (size_t)r * nloc * ctw, A_host + ((size_t)r * mct + g->blk0[(size_t)i]) * ctw, nloc * ctw * 8));
+        return 0;
+    });
+    if (rc) return rc;
+    std::vector<const uint64_t *> Ac(A.begin(), A.end());
+    rc = sfg_mgpu_matmul_dev(mg, Ac.data(), s, in_level, max_level, g, flags, O.data());
+    if (rc) return rc;
+    return run_ranks(mg, [&](MgRank &R, int i) {
+        const size_t nloc = g->blk1[(size_t)i] - g->blk0[(size_t)i];
+        if (tr) { if (i == 0) R_CTX(R, sfg_memcpy_d2h(R.ctx, out_host, O[(size_t)i], (size_t)s * nbr_x * outw * 8)); else R_CTX(R, sfg_ctx_synchronize(R.ctx)); }
+        else for (int r = 0; r < s && nloc; r++)
+            R_CTX(R, sfg_memcpy_d2h(R.ctx, out_host + ((size_t)r * mct + g->blk0[(size_t)i]) * outw, O[(size_t)i] + (size_t)r * nloc * outw, nloc * outw * 8));
+        return 0;
+    });
+}

@@ -25,14 +25,27 @@ def env():
 
 @pytest.fixture(scope="module")
 def env47():
-    """q0 a 47-bit prime (the widest modulus sfg_ctx_create accepts): six digits and the two-step Horner recombination"""
+    """q0 a 47-bit prime, the widest one whose words fit six signed digits: the two-step Horner recombination"""
     from sfgwas_amd import capi
-    q47 = ol.small_primes(14, 47, 1)[0]
-    assert (1 << 47) - (1 << 24) < q47 < (1 << 47)
+    q47 = widest_six_digit_prime()
     moduli = [q47] + list(ol.Q_PN14[1:3])
     ctx = capi.Context(moduli, ol.P_PN14)
     yield ctx, moduli
     ctx.close()
+
+
+I8_BIG_QMAX = 0x7F7F7F7F7F80          # common.hpp SFG_I8_BIG_QMAX: canonical words up to q - 1 must fit six signed digits (<= 0x7F7F7F7F7F7F)
+
+
+def widest_six_digit_prime():
+    """the largest NTT-friendly prime (== 1 mod 2N) the int8 MAC takes: in (2^46 - 2^24, I8_BIG_QMAX], so the Horner recombination runs its two-step form"""
+    from sympy import isprime
+    M = 2 << 14
+    x = I8_BIG_QMAX - (I8_BIG_QMAX - 1) % M
+    while not isprime(x):
+        x -= M
+    assert (1 << 46) < x <= I8_BIG_QMAX and x % M == 1
+    return x
 
 
 def sdigits(v, nd):
@@ -170,7 +183,7 @@ def test_default_mac_accumulates_onto_out(env):
 
 @pytest.mark.parametrize("K,P,R,Ncols,form", [(1456, 5, 30, 91, 0), (300, 7, 30, 33, 0), (182, 5, 12, 91, 1)])
 def test_default_mac_with_a_47_bit_modulus(env47, K, P, R, Ncols, form):
-    """q0 in (2^47 - 2^24, 2^47): one Horner step r 256 + D passes 2^53 there (128 q), the kernels take it as two x 16 steps (i8_horner, mac_i8.hip).
+    """q0 in (2^46, 0x7F7F7F7F7F80]: one Horner step r 256 + D passes 2^53 there (128 q), the kernels take it as two x 16 steps (i8_horner, mac_i8.hip).
     Round 4's epilogue gave 18 468 wrong words of 20 000 on such a prime."""
     ctx, moduli = env47
     L, N = 2, ctx.N

@@ -92,22 +92,26 @@ def test_fewer_moduli_and_row_counts(env, s, in_level, max_level):
     run_case(env, 70, 50, s, in_level, max_level, 0, 40 + s)
 
 
-@pytest.fixture(scope="module")
-def env47():
-    """the same ring with q0 replaced by a 47-bit prime - the widest modulus sfg_ctx_create accepts (the int8 MAC then recombines in two x 16 Horner steps)"""
+def _ctx_with_q0(q0):
     from sfgwas_amd import capi
-    q47 = ol.small_primes(14, 47, 1)[0]
-    assert (1 << 47) - (1 << 24) < q47 < (1 << 47)
-    moduli = [q47] + list(ol.Q_PN14[1:])
+    moduli = [q0] + list(ol.Q_PN14[1:])
     ctx = capi.Context(moduli, ol.P_PN14)
     ring = ol.Ring(14, moduli, ol.P_PN14)
-    keys = ol.RotKeys(ring)
-    yield ctx, ring, keys
-    ctx.close()
+    return ctx, ring, ol.RotKeys(ring)
 
 
+@pytest.mark.parametrize("which", ["widest six-digit prime (int8 MAC, two-step Horner)", "first prime below 2^47 (fp64 MAC)"])
 @pytest.mark.parametrize("nrow,ncol,s,flags", [(70, 50, 3, 0), (40, SLOTS + 30, 2, 2)])
-def test_whole_product_with_a_47_bit_q0(env47, nrow, ncol, s, flags):
-    """every kernel of a product - key switch, encode FFT + NTT with six digit planes, k_mac_i8_ring<6, 2, 0, 2> + epilogue, untile, giant
-    alignment - on a modulus in [2^46, 2^47), every output word vs the oracle (matmult.go:1238-1505)."""
-    run_case(env47, nrow, ncol, s, 5, 5, flags, 470 + s)
+def test_whole_product_with_a_47_bit_q0(which, nrow, ncol, s, flags):
+    """every kernel of a product - key switch, encode FFT + NTT, MAC + epilogue, untile, giant alignment - on a modulus in
+    [2^46, 2^47), every output word vs the oracle (matmult.go:1238-1505).  Up to 0x7F7F7F7F7F80 the 46/47-bit modulus multiplies on the int8 matrix core
+    (six digit planes, k_mac_i8_ring<6, 2, 0, 2>, two-step Horner); above, a canonical word no longer fits six signed digits and the context keeps
+    that modulus on the fp64 kernel k_mac_bc<true>."""
+    from test_gpu_mac_i8 import widest_six_digit_prime, I8_BIG_QMAX
+    q0 = widest_six_digit_prime() if which.startswith("widest") else ol.small_primes(14, 47, 1)[0]
+    assert (q0 <= I8_BIG_QMAX) == which.startswith("widest") and (1 << 46) < q0 < (1 << 47)
+    env_q = _ctx_with_q0(q0)
+    try:
+        run_case(env_q, nrow, ncol, s, 5, 5, flags, 470 + s)
+    finally:
+        env_q[0].close()
