@@ -345,6 +345,64 @@ int sfg_matmul_accumulate_rc_dev(sfg_ctx *ctx, const double *cache_dev, int s, i
 /* after an integer all-reduce(sum) of partial outputs across ranks: canonical reduction mod q_l of [rows][L][N] */
 int sfg_reduce_rows_dev(sfg_ctx *ctx, uint64_t *rows_dev, size_t nrows_of_L, int L);
 
+/* ---- one party's products on the G GPUs of a node (mgpu.hip) ----
+ * The reference runs one OS process per party (run_example.sh:1-12) and calls MatMult4StreamCompute twice per power iteration (gwas/pca.go:344,352) and
+ * MatMult4Stream once per SNP batch (gwas/assoc.go:360-408).  sfg_mgpu_create gives such a process all of a node's GPUs: one context per device, one host thread per
+ * device inside every call, RCCL (resolved with dlopen at the first use) for the one exchange step of Q' * X^T.  Launchers that start one process per GPU
+ * (bench.py under torch.distributed.run) join the same engine with sfg_mgpu_create_rank and a 128-byte id made by sfg_mgpu_unique_id on rank 0 and carried to
+ * the other ranks by the caller's own channel (the Go network layer, a TCP store).
+ * Partitioning: X (n_ind x m_snp) by blocks of 8192 SNP columns, rank r owns blocks [nblk r / world, nblk (r + 1) / world) (sfg_mgpu_shard).
+ *   Q * X     every rank multiplies its own output block columns; no data-path collective.
+ *   Q' * X^T  contraction over the rank's blocks; per output block column the canonical uint64 accumulators are REDUCE-SCATTERED over the giant-step axis
+ *             (padded to world * ceil(91 / world) slots) on a second queue while the next column is multiplied; every rank reduces mod q and aligns its own giant
+ *             steps (key switching is not bit-linear: partial sums must be combined BEFORE the rotations of matmult.go:1474-1494), the aligned partial
+ *             outputs are ALL-REDUCED and reduced mod q.  Identical words for every world size (tests/test_gpu_mgpu.py, bench.py's digests).
+ * SFG_MGPU_TRANSPORT=direct (single process only; forced when `devices` repeats a device, which RCCL refuses): a rank sums its slice straight from its peers'
+ * buffers with a kernel (peer access); SFG_MGPU_FORCE_COLLECTIVES=1 runs the exchange even at world size 1; SFG_MGPU_CACHE_GB (72) bounds a rank's own
+ * rotation cache for the pipelined form.  A failing rank fails the call (sfg_mgpu_last_error names it). */
+typedef struct sfg_mgpu sfg_mgpu;
+typedef struct sfg_mgeno sfg_mgeno;
+#define SFG_MGPU_ID_BYTES 128
+int sfg_mgpu_unique_id(uint8_t *id128);
+/* context arguments as sfg_ctx_create; devices[n]: HIP device indices, world size = n, local rank i = rank i */
+int sfg_mgpu_create(sfg_mgpu **out, const int *devices, int n, int logN, int nq, int np, const uint64_t *moduli, const uint64_t *psi, double scale);
+int sfg_mgpu_create_rank(sfg_mgpu **out, int device, int rank, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
+                         const uint64_t *psi, double scale);
+void sfg_mgpu_destroy(sfg_mgpu *mg);
+const char *sfg_mgpu_last_error(const sfg_mgpu *mg);      /* mg may be NULL: error of a failed create */
+int sfg_mgpu_world(const sfg_mgpu *mg);
+int sfg_mgpu_nlocal(const sfg_mgpu *mg);                  /* ranks driven by this process (n, or 1) */
+int sfg_mgpu_rank(const sfg_mgpu *mg, int local);
+sfg_ctx *sfg_mgpu_ctx(sfg_mgpu *mg, int local);           /* the context of a local rank: device buffers (sfg_malloc), evaluator ops, phase timers */
+const char *sfg_mgpu_transport(const sfg_mgpu *mg);       /* "none" (world 1), "rccl", "direct" */
+int sfg_mgpu_synchronize(sfg_mgpu *mg);
+/* key material to every local device: cryptoParams.RotKs / Rlk as sfg_ctx_load_rotkey / _relinkey */
+int sfg_mgpu_load_rotkey(sfg_mgpu *mg, uint64_t galois_el, const uint64_t *key_host, int montgomery_form);
+int sfg_mgpu_load_relinkey(sfg_mgpu *mg, const uint64_t *key_host, int montgomery_form);
+int sfg_mgpu_fill_rotkeys_synthetic(sfg_mgpu *mg, const int *rot_left, int nrot, uint64_t seed);
+/* SNP-block shard of `rank`: block columns [*blk0, *blk1), columns [*col0, *col1) (any pointer may be NULL) */
+int sfg_mgpu_shard(int world, size_t ncol, int rank, size_t *blk0, size_t *blk1, size_t *col0, size_t *col1);
+/* MatMult4StreamPreprocess on G GPUs (matmult.go:914-1041): the party's whole row-major int8 matrix (row stride ld); every local rank keeps its column window
+ * resident.  _adopt: per-rank windows the caller made on the ranks' contexts (sfg_geno_from_bed / _from_pgen / _from_device; NULL for an empty window), ownership
+ * passes.  _synthetic: the window of ONE global synthetic matrix (sfg_fill_geno_window_dev), optionally 2-bit packed - bench.py and the tests. */
+int sfg_mgpu_geno_upload(sfg_mgpu *mg, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_mgeno **out);
+int sfg_mgpu_geno_adopt(sfg_mgpu *mg, size_t nrow, size_t ncol, sfg_geno *const *shards, sfg_mgeno **out);
+int sfg_mgpu_geno_synthetic(sfg_mgpu *mg, size_t nrow, size_t ncol, uint64_t seed, int packed, sfg_mgeno **out);
+void sfg_mgpu_geno_free(sfg_mgpu *mg, sfg_mgeno *g);
+const sfg_geno *sfg_mgpu_geno_shard(const sfg_mgeno *g, int local);
+int sfg_mgpu_geno_dims(const sfg_mgeno *g, size_t *nrow, size_t *ncol);
+int sfg_mgpu_geno_blocks(const sfg_mgeno *g, int local, size_t *blk0, size_t *blk1);
+int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *g, size_t max_bytes_per_rank);
+/* MatMult4StreamCompute (matmult.go:1043-1236) on the sharded matrix.  Device-pointer form, A_dev[i] / out_dev[i] on local rank i's device:
+ *   flags = 0 or SFG_SQUARE  (Q * X):    A_dev[i] = the whole input grid [s][ceil(nrow / 8192)] (replicated);  out_dev[i] = [s][blk1 - blk0], the rank's block columns
+ *   | SFG_TRANSPOSE          (Q' * X^T): A_dev[i] = [s][blk1 - blk0], the inputs of the rank's SNP blocks;    out_dev[i] = the whole [s][ceil(nrow / 8192)], on every rank
+ * ciphertext layouts as sfg_matmul_resident_dev; stream-ordered on each rank's queue (sfg_mgpu_synchronize waits).
+ * Host-pointer form (the Go shim's): Q * X takes A_host [s][nbr] and fills out_host [s][m_ct] (in a multi-process world: the block columns of this process's
+ * ranks only); Q' * X^T takes A_host [s][m_ct] (all SNP blocks, each rank uploads its own) and fills out_host [s][nbr] completely in every process. */
+int sfg_mgpu_matmul_dev(sfg_mgpu *mg, const uint64_t *const *A_dev, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags,
+                        uint64_t *const *out_dev);
+int sfg_mgpu_matmul(sfg_mgpu *mg, const uint64_t *A_host, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags, uint64_t *out_host);
+
 /* ---- f-1: collective bootstrap, LOCAL work (mpc/mhe.go:222-348: CollectiveBootstrap / CollectiveBootstrapMat) ----
  * Per ciphertext the reference calls lattigo's dckks.RefreshProtocol: GenShares (mhe.go:251,315), aggregates the shares over the network
  * (AggregateRefreshShare*, stays in Go), then Decrypt / Recode / Recrypt (mhe.go:256-258,329-331).  PARITY UNPINNED: restated from the published

@@ -120,6 +120,31 @@ def _sig(L):
         "sfg_fill_geno_dev": (i, [vp, vp, sz, sz, u64]),
         "sfg_fill_geno_window_dev": (i, [vp, vp, sz, sz, sz, sz, sz, u64]),
         "sfg_fill_rotkeys_synthetic": (i, [vp, C.POINTER(i), i, u64]),
+        "sfg_mgpu_unique_id": (i, [vp]),
+        "sfg_mgpu_create": (i, [C.POINTER(vp), C.POINTER(i), i, i, i, i, u64p, u64p, d]),
+        "sfg_mgpu_create_rank": (i, [C.POINTER(vp), i, i, i, vp, i, i, i, u64p, u64p, d]),
+        "sfg_mgpu_destroy": (None, [vp]),
+        "sfg_mgpu_last_error": (C.c_char_p, [vp]),
+        "sfg_mgpu_world": (i, [vp]),
+        "sfg_mgpu_nlocal": (i, [vp]),
+        "sfg_mgpu_rank": (i, [vp, i]),
+        "sfg_mgpu_ctx": (vp, [vp, i]),
+        "sfg_mgpu_transport": (C.c_char_p, [vp]),
+        "sfg_mgpu_synchronize": (i, [vp]),
+        "sfg_mgpu_load_rotkey": (i, [vp, u64, u64p, i]),
+        "sfg_mgpu_load_relinkey": (i, [vp, u64p, i]),
+        "sfg_mgpu_fill_rotkeys_synthetic": (i, [vp, C.POINTER(i), i, u64]),
+        "sfg_mgpu_shard": (i, [i, sz, i, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_mgpu_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
+        "sfg_mgpu_geno_adopt": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "sfg_mgpu_geno_synthetic": (i, [vp, sz, sz, u64, i, C.POINTER(vp)]),
+        "sfg_mgpu_geno_free": (None, [vp, vp]),
+        "sfg_mgpu_geno_shard": (vp, [vp, i]),
+        "sfg_mgpu_geno_dims": (i, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_mgpu_geno_blocks": (i, [vp, i, C.POINTER(sz), C.POINTER(sz)]),
+        "sfg_mgpu_geno_set_plaintext_cache": (i, [vp, vp, sz]),
+        "sfg_mgpu_matmul_dev": (i, [vp, C.POINTER(vp), i, i, i, vp, C.c_uint, C.POINTER(vp)]),
+        "sfg_mgpu_matmul": (i, [vp, u64p, i, i, i, vp, C.c_uint, u64p]),
         "sfg_ctx_clear_phases": (i, [vp]),
         "sfg_last_phase_ms": (d, [vp, C.c_char_p]),
         "sfg_last_phase_launches": (i, [vp, C.c_char_p]),
@@ -622,3 +647,101 @@ Context.fill_geno = _ctx_fill_geno
 Context.matmul_resident = _ctx_matmul_resident
 Context.matmul_accumulate = _ctx_matmul_accumulate
 Context.matmul_finalize = _ctx_matmul_finalize
+
+
+# ---- the multi-GPU engine (sfg_mgpu_*, mgpu.hip); plumbing for the tests and bench.py
+class MultiGpu:
+    """sfg_mgpu wrapper.  devices = [0, 1, ...] makes a single-process engine (one rank per entry; a repeated device selects the in-process `direct` transport);
+    rank / world / uid join a multi-process world (one rank per process)."""
+
+    def __init__(self, q, p, devices=None, scale=2.0 ** 34, logN=14, rank=None, world=None, uid=None, device=0):
+        L = lib()
+        self.q, self.p = list(q), list(p)
+        self.nq, self.np_ = len(q), len(p)
+        self.N, self.slots = 1 << logN, (1 << logN) // 2
+        mods = np.array(self.q + self.p, dtype=np.uint64)
+        h = C.c_void_p()
+        if uid is None:
+            devs = (C.c_int * len(devices))(*devices)
+            rc = L.sfg_mgpu_create(C.byref(h), devs, len(devices), logN, self.nq, self.np_, p64(mods), None, float(scale))
+        else:
+            buf = (C.c_uint8 * 128).from_buffer_copy(bytes(uid))
+            rc = L.sfg_mgpu_create_rank(C.byref(h), device, rank, world, buf, logN, self.nq, self.np_, p64(mods), None, float(scale))
+        if rc:
+            raise SfgError("sfg_mgpu_create: " + L.sfg_mgpu_last_error(None).decode())
+        self.h = h
+        self.world, self.nlocal = L.sfg_mgpu_world(h), L.sfg_mgpu_nlocal(h)
+        self.transport = L.sfg_mgpu_transport(h).decode()
+        self.ctx = []
+        for i in range(self.nlocal):                        # borrowed contexts (owned by the engine): for device buffers and phase timers
+            c = Context.__new__(Context)
+            c.__dict__.update(q=self.q, p=self.p, nq=self.nq, np_=self.np_, N=self.N, slots=self.slots, beta=(self.nq + self.np_ - 1) // self.np_)
+            c.h = C.c_void_p(L.sfg_mgpu_ctx(h, i))
+            c.close = lambda: None
+            self.ctx.append(c)
+        self.ranks = [L.sfg_mgpu_rank(h, i) for i in range(self.nlocal)]
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        if lib().sfg_mgpu_unique_id(buf):
+            raise SfgError("sfg_mgpu_unique_id: " + lib().sfg_mgpu_last_error(None).decode())
+        return bytes(buf)
+
+    def check(self, rc, what):
+        if rc:
+            raise SfgError(f"{what}: {lib().sfg_mgpu_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.ctx:
+                c.h = None
+            lib().sfg_mgpu_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self.check(lib().sfg_mgpu_synchronize(self.h), "sfg_mgpu_synchronize")
+
+    def fill_rotkeys_synthetic(self, rots_left, seed):
+        arr = (C.c_int * len(rots_left))(*rots_left)
+        self.check(lib().sfg_mgpu_fill_rotkeys_synthetic(self.h, arr, len(rots_left), seed), "sfg_mgpu_fill_rotkeys_synthetic")
+
+    def load_rotkey(self, galois, key, montgomery=False):
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        self.check(lib().sfg_mgpu_load_rotkey(self.h, int(galois), p64(key), int(montgomery)), "sfg_mgpu_load_rotkey")
+
+    def geno_upload(self, geno):
+        geno = np.ascontiguousarray(geno, dtype=np.int8)
+        g = C.c_void_p()
+        self.check(lib().sfg_mgpu_geno_upload(self.h, geno.ctypes.data_as(C.c_void_p), geno.shape[0], geno.shape[1], geno.shape[1], C.byref(g)), "sfg_mgpu_geno_upload")
+        return g
+
+    def geno_synthetic(self, nrow, ncol, seed, packed=False):
+        g = C.c_void_p()
+        self.check(lib().sfg_mgpu_geno_synthetic(self.h, nrow, ncol, seed, int(packed), C.byref(g)), "sfg_mgpu_geno_synthetic")
+        return g
+
+    def geno_free(self, g):
+        lib().sfg_mgpu_geno_free(self.h, g)
+
+    def geno_blocks(self, g, local):
+        b0, b1 = C.c_size_t(), C.c_size_t()
+        lib().sfg_mgpu_geno_blocks(g, local, C.byref(b0), C.byref(b1))
+        return b0.value, b1.value
+
+    def matmul_dev(self, A, s, in_level, max_level, g, flags, out):
+        """A / out: lists of DevArray, one per local rank"""
+        n = self.nlocal
+        pa = (C.c_void_p * n)(*[a.p for a in A])
+        po = (C.c_void_p * n)(*[o.p for o in out])
+        self.check(lib().sfg_mgpu_matmul_dev(self.h, pa, s, in_level, max_level, g, flags, po), "sfg_mgpu_matmul_dev")
+
+    def matmul(self, A_host, s, in_level, max_level, g, flags=0):
+        """host form: A_host [s][nbr or m_ct][2][in_level+1][N] -> out [s][m_ct or nbr][2][max_level][N]"""
+        A_host = np.ascontiguousarray(A_host, dtype=np.uint64)
+        nr, nc = C.c_size_t(), C.c_size_t()
+        lib().sfg_mgpu_geno_dims(g, C.byref(nr), C.byref(nc))
+        ncols = ((nr.value if flags & SFG_TRANSPOSE else nc.value) - 1) // self.slots + 1
+        out = np.zeros((s, ncols, 2, max_level, self.N), dtype=np.uint64)
+        self.check(lib().sfg_mgpu_matmul(self.h, p64(A_host), s, in_level, max_level, g, flags, p64(out)), "sfg_mgpu_matmul")
+        return out

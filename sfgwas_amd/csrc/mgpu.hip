@@ -320,30 +320,30 @@ extern "C" int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *
 }
 
 // ---------------------------------------------------------------- collectives (enqueued on `st` of the calling rank, in order with it)
-static int coll_reduce_scatter(sfg_mgpu *mg, MgRank &R, const u64 *send, u64 *recv, size_t recv_count, hipStream_t st) {
+static int coll_reduce_scatter(sfg_mgpu *mg, MgRank &R, const uint64_t *send, uint64_t *recv, size_t recv_count, hipStream_t st) {
     if (!mg->direct) { R_NCCL(R, g_rccl.ReduceScatter(send, recv, recv_count, ncclUint64, ncclSum, R.comm, st)); return 0; }
     const int n = mg->world;
     R_HIP(R, hipStreamSynchronize(st));                               // this rank's contribution is complete
     mg->rv.ptr[R.rank] = send;
     if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");
     PeerPtrs pp; for (int p = 0; p < n; p++) pp.p[p] = (const u64 *)mg->rv.ptr[p] + (size_t)R.rank * recv_count;
-    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>((recv_count + 255) / 256, 4096)), dim3(256), 0, st, recv, pp, n, recv_count);
+    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>((recv_count + 255) / 256, 4096)), dim3(256), 0, st, (u64 *)recv, pp, n, recv_count);
     R_HIP(R, hipGetLastError());
     R_HIP(R, hipStreamSynchronize(st));
     if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");          // everybody has read: the send buffers may be overwritten
     return 0;
 }
-static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, u64 *buf, size_t count, hipStream_t st) {
+static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, uint64_t *buf, size_t count, hipStream_t st) {
     if (!mg->direct) { R_NCCL(R, g_rccl.AllReduce(buf, buf, count, ncclUint64, ncclSum, R.comm, st)); return 0; }
     const int n = mg->world;
     // in place: sum into a private copy first (a peer may still be reading this rank's buffer), swap after the second meeting
-    u64 *tmp = nullptr;
+    uint64_t *tmp = nullptr;
     R_CTX(R, sfg_scratch(R.ctx, "mg.ar", count * 8, (void **)&tmp));
     R_HIP(R, hipStreamSynchronize(st));
     mg->rv.ptr[R.rank] = buf;
     if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");
     PeerPtrs pp; for (int p = 0; p < n; p++) pp.p[p] = (const u64 *)mg->rv.ptr[p];
-    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>((count + 255) / 256, 4096)), dim3(256), 0, st, tmp, pp, n, count);
+    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>((count + 255) / 256, 4096)), dim3(256), 0, st, (u64 *)tmp, pp, n, count);
     R_HIP(R, hipGetLastError());
     R_HIP(R, hipStreamSynchronize(st));
     if (!mg->rv.barrier()) R_FAIL(R, "a peer rank failed");
@@ -353,7 +353,7 @@ static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, u64 *buf, size_t count, hipS
 
 // ---------------------------------------------------------------- the products
 // Q' * X^T of one rank: see the header of this file
-static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const u64 *A, int s, int in_level, int L, const sfg_mgeno *g, unsigned flags, u64 *out) {
+static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int s, int in_level, int L, const sfg_mgeno *g, unsigned flags, uint64_t *out) {
     sfg_ctx *ctx = R.ctx;
     R_HIP(R, hipSetDevice(R.device));
     const int world = mg->world, d = SFG_D, N = SFG_N;
@@ -369,7 +369,7 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const u64 *A, int s, i
     R_CTX(R, sfg_rotcache_layout(ctx, s, L, &jobw, &tailw));
     const size_t cache_w = (size_t)nloc * s * jobw + tailw;
     const bool pipe = cache_w * 8 <= mg->cache_budget;
-    u64 *acc_mine = nullptr, *acc2 = nullptr; double *cache = nullptr;
+    uint64_t *acc_mine = nullptr, *acc2 = nullptr; double *cache = nullptr;
     R_CTX(R, sfg_scratch(ctx, "mg.mine", (size_t)nbr_x * mine * 8, (void **)&acc_mine));
     hipStream_t cs = ctx->stream;
     // (the collectives' queue must not start before earlier work of the compute queue that still reads these buffers: previous call's finalize)
@@ -383,7 +383,7 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const u64 *A, int s, i
             R_CTX(R, sfg_rotcache_build_rows_dev(ctx, A, s, in_level, L, nloc, 0, nloc, cache));
         }
         for (int j = 0; j < nbr_x; j++) {              // column j is multiplied while column j - 1 is reduce-scattered
-            u64 *buf = acc2 + (size_t)(j & 1) * colp;
+            uint64_t *buf = acc2 + (size_t)(j & 1) * colp;
             if (j >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[j & 1], 0));            // the reduce-scatter of column j - 2 has read this buffer
             if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
             R_HIP(R, hipEventRecord(R.ev_acc[j & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[j & 1], 0));
@@ -419,7 +419,7 @@ extern "C" int sfg_mgpu_matmul_dev(sfg_mgpu *mg, const uint64_t *const *A_dev, i
     if (s < 1 || max_level < 1) MG_FAIL(mg, "sfg_mgpu_matmul: bad s / max_level");
     return run_ranks(mg, [&](MgRank &R, int i) {
         R_HIP(R, hipSetDevice(R.device));
-        if (flags & SFG_TRANSPOSE) return rank_contract(mg, R, i, (const u64 *)A_dev[i], s, in_level, max_level, g, flags, (u64 *)out_dev[i]);
+        if (flags & SFG_TRANSPOSE) return rank_contract(mg, R, i, A_dev[i], s, in_level, max_level, g, flags, out_dev[i]);
         if (g->shard[(size_t)i]) R_CTX(R, sfg_matmul_resident_dev(R.ctx, A_dev[i], s, in_level, max_level, g->shard[(size_t)i], flags & SFG_SQUARE, out_dev[i]));
         return 0;
     });

@@ -1,0 +1,178 @@
+"""SURVEY §8e as a product entry point: the multi-GPU engine sfg_mgpu_* (sfgwas_amd/csrc/mgpu.hip) gives the words of the single-GPU products
+(MatMult4StreamCompute, gwas/matmult.go:1043-1236, both orientations of gwas/pca.go:344,352) for every world size and transport a one-GPU box can run:
+  * one process, world 1, the exchange forced over RCCL (ncclCommInitAll + ncclReduceScatter / ncclAllReduce at one rank);
+  * one process, world 2 and 3 with every rank on device 0 - RCCL refuses a repeated device, so the engine takes its in-process `direct` transport
+    (a rank sums its slice out of its peers' buffers): the SAME sequence (SNP-block shards, per-column reduce-scatter over padded giant slots, reduce,
+    finalize of the owned giants, all-reduce, reduce), including a rank that owns no SNP block and the unpipelined form;
+  * the multi-process entry (sfg_mgpu_create_rank + a 128-byte id) at world 1.
+The single-GPU products themselves are checked against the oracle elsewhere (tests/test_gpu_matmul.py, test_gpu_fullsize.py)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SLOTS, D, L, LEVEL, S = 8192, 91, 5, 5, 2
+NROW, NCOL = 2 * SLOTS + 300, 2 * SLOTS + 77         # 3 output block columns of Q'X^T (the j >= 2 buffer hand-over), 3 SNP blocks
+T, SQ = 2, 1
+ROTS = list(range(1, D)) + [g * D for g in range(1, D) if g * D < SLOTS]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    """the single-GPU products of one context on the whole matrix"""
+    from sfgwas_amd import capi
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    lib = capi.lib()
+    ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(ROTS))(*ROTS), len(ROTS), 0xBEEF), "keys")
+    rng = np.random.default_rng(85)
+    geno = rng.integers(0, 3, (NROW, NCOL), dtype=np.int8)
+    geno[rng.random((NROW, NCOL)) < 0.01] = -1
+    small = np.ascontiguousarray(geno[:100, :SLOTS + 5])          # 2 SNP blocks: with 3 ranks, rank 0 owns none
+    nbr, mct = 3, 3
+    A = {0: ctx.fill_uniform_cts(S * nbr, LEVEL, 0xB1), T: ctx.fill_uniform_cts(S * mct, LEVEL, 0xB2)}
+    As = {0: ctx.fill_uniform_cts(S * 1, LEVEL, 0xB3), T: ctx.fill_uniform_cts(S * 2, LEVEL, 0xB4)}
+    Ah = {f: a.host().reshape(S, -1, 2, LEVEL + 1, ctx.N) for f, a in A.items()}
+    Ash = {f: a.host().reshape(S, -1, 2, LEVEL + 1, ctx.N) for f, a in As.items()}
+    g = ctx.geno_upload(geno)
+    gs = ctx.geno_upload(small)
+    want, wants = {}, {}
+    for f in (0, T, SQ, T | SQ):
+        o = ctx.matmul_resident(A[f & T], S, LEVEL, L, g, f); want[f] = o.host().copy(); o.free()
+    for f in (0, T):
+        o = ctx.matmul_resident(As[f & T], S, LEVEL, L, gs, f); wants[f] = o.host().copy(); o.free()
+    ctx.geno_free(g); ctx.geno_free(gs)
+    for a in list(A.values()) + list(As.values()):
+        a.free()
+    ctx.close()
+    return geno, small, Ah, Ash, want, wants
+
+
+def make_engine(monkeypatch, devices, env=None, **kw):
+    from sfgwas_amd import capi
+    for k in ("SFG_MGPU_TRANSPORT", "SFG_MGPU_FORCE_COLLECTIVES", "SFG_MGPU_CACHE_GB"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    mg = capi.MultiGpu(ol.Q_PN14, ol.P_PN14, devices=devices, **kw)
+    mg.fill_rotkeys_synthetic(ROTS, 0xBEEF)
+    return mg
+
+
+def check_products(mg, geno, Ah, want, flag_sets):
+    g = mg.geno_upload(geno)
+    try:
+        for f in flag_sets:
+            got = mg.matmul(Ah[f & T], S, LEVEL, L, g, f)
+            assert got.shape == want[f].shape
+            assert np.array_equal(got, want[f]), f"flags {f}: {np.count_nonzero(got != want[f])} words differ"
+    finally:
+        mg.geno_free(g)
+
+
+def test_world_1_exchange_over_rccl(ref, monkeypatch):
+    geno, small, Ah, Ash, want, wants = ref
+    mg = make_engine(monkeypatch, [0], {"SFG_MGPU_FORCE_COLLECTIVES": "1"})
+    try:
+        assert (mg.world, mg.nlocal, mg.transport) == (1, 1, "rccl")
+        check_products(mg, geno, Ah, want, (0, T, T | SQ))
+    finally:
+        mg.close()
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_direct_transport_on_one_device(ref, monkeypatch, n):
+    geno, small, Ah, Ash, want, wants = ref
+    mg = make_engine(monkeypatch, [0] * n)
+    try:
+        assert (mg.world, mg.nlocal, mg.transport) == (n, n, "direct")
+        check_products(mg, geno, Ah, want, (0, T) if n == 3 else (0, T, SQ, T | SQ))
+        if n == 3:                                      # 2 SNP blocks on 3 ranks: rank 0 contributes zeros to every exchange and multiplies nothing in Q X
+            check_products(mg, small, Ash, wants, (0, T))
+    finally:
+        mg.close()
+
+
+def test_unpipelined_form_and_device_pointer_entry(ref, monkeypatch):
+    """SFG_MGPU_CACHE_GB=0: a rank's own rotation cache 'does not fit' -> the library's grouped cache, reduce-scatters after the product (windows that run into
+    the next block column).  Driven through sfg_mgpu_matmul_dev with per-rank device buffers, as bench.py drives it."""
+    from sfgwas_amd import capi
+    geno, small, Ah, Ash, want, wants = ref
+    mg = make_engine(monkeypatch, [0, 0], {"SFG_MGPU_CACHE_GB": "0"})
+    g = mg.geno_upload(geno)
+    try:
+        N = mg.N
+        A, out = [], []
+        for i in range(mg.nlocal):
+            b0, b1 = mg.geno_blocks(g, i)
+            A.append(capi.DevArray.from_host(mg.ctx[i], np.ascontiguousarray(Ah[T][:, b0:b1])))
+            out.append(capi.DevArray(mg.ctx[i], (S, 3, 2, L, N)))
+        mg.matmul_dev(A, S, LEVEL, L, g, T, out)
+        mg.sync()
+        for i in range(mg.nlocal):                      # the complete result on EVERY rank
+            assert np.array_equal(out[i].host(), want[T]), i
+        for a in A + out:
+            a.free()
+        A, out = [], []
+        for i in range(mg.nlocal):
+            b0, b1 = mg.geno_blocks(g, i)
+            A.append(capi.DevArray.from_host(mg.ctx[i], Ah[0]))
+            out.append(capi.DevArray(mg.ctx[i], (S, b1 - b0, 2, L, N)))
+        mg.matmul_dev(A, S, LEVEL, L, g, 0, out)
+        mg.sync()
+        for i in range(mg.nlocal):
+            b0, b1 = mg.geno_blocks(g, i)
+            assert np.array_equal(out[i].host(), want[0][:, b0:b1]), i
+        for a in A + out:
+            a.free()
+    finally:
+        mg.geno_free(g)
+        mg.close()
+
+
+def test_multi_process_entry_at_world_1(ref, monkeypatch):
+    """sfg_mgpu_unique_id + sfg_mgpu_create_rank: how bench.py's ranks (one process per GPU) join; here one rank, the exchange forced over RCCL"""
+    from sfgwas_amd import capi
+    geno, small, Ah, Ash, want, wants = ref
+    for k in ("SFG_MGPU_TRANSPORT", "SFG_MGPU_CACHE_GB"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SFG_MGPU_FORCE_COLLECTIVES", "1")
+    uid = capi.MultiGpu.unique_id()
+    assert len(uid) == 128
+    mg = capi.MultiGpu(ol.Q_PN14, ol.P_PN14, rank=0, world=1, uid=uid, device=0)
+    mg.fill_rotkeys_synthetic(ROTS, 0xBEEF)
+    try:
+        assert (mg.world, mg.nlocal, mg.transport) == (1, 1, "rccl")
+        check_products(mg, small, Ash, wants, (0, T))
+    finally:
+        mg.close()
+
+
+def test_shard_arithmetic_matches_sharding_py():
+    from sfgwas_amd import capi
+    from sfgwas_amd.sharding import snp_block_range
+    lib = capi.lib()
+    for m_snp in (1, 8192, 8193, 100_000, 1_000_000):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                v = [C.c_size_t() for _ in range(4)]
+                assert lib.sfg_mgpu_shard(world, m_snp, r, *[C.byref(x) for x in v]) == 0
+                assert tuple(x.value for x in v) == snp_block_range(m_snp, r, world)
+
+
+def test_errors_are_reported_not_hung(ref, monkeypatch):
+    from sfgwas_amd import capi
+    geno, small, Ah, Ash, want, wants = ref
+    with pytest.raises(capi.SfgError, match="bad device"):
+        capi.MultiGpu(ol.Q_PN14, ol.P_PN14, devices=[0, 99])
+    mg = make_engine(monkeypatch, [0, 0])
+    g = mg.geno_upload(small)
+    try:
+        with pytest.raises(capi.SfgError, match="level"):          # every rank fails before the first meeting
+            mg.matmul(Ash[T][:, :, :, :3], S, 2, L, g, T)
+        got = mg.matmul(Ash[0], S, LEVEL, L, g, 0)                  # the engine is still usable
+        assert np.array_equal(got, wants[0])
+    finally:
+        mg.geno_free(g)
+        mg.close()
