@@ -200,6 +200,259 @@ class Coll:
         t.copy_(h)
 
 
+def roofline_blocks(phase_tot, args, dims, world, dt, value):
+    """the `roofline` object of the JSON line for the default (int8 MAC) build, from rank 0's phase totals (HIP events on the library's queue)"""
+    n_ind, m_snp, nbr_x, mct_x, N, L, D, SLOTS, LEVEL = dims
+    ctw, outw = 2 * (LEVEL + 1) * N, 2 * L * N
+    ms_small, n_small, by_small = phase_tot.get("mac_small", [0.0, 0, 0.0])
+    ms_ntt, n_ntt, by_ntt = phase_tot.get("ntt_plain", [0.0, 0, 0.0])
+    n_ntt_all = phase_tot.get("ntt_plain_all", [0.0, 0, 0.0])[1]
+    ntt_avg_ms = ms_ntt / max(n_ntt, 1)
+    ntt_total_ms = ntt_avg_ms * n_ntt_all
+    bytes_per_plain = (N // 2) * (8 + 5 * (L - 1) + 8)                   # coefficient row in, five digit planes per small modulus + one word row out
+    plains_per_launch = (by_ntt / max(n_ntt, 1)) / bytes_per_plain
+    NTT_FP64_INSTR = 2016                                               # fp64 vector instructions per thread of k_ntt_half3 (static count of the gfx950 ISA, DESIGN.md §8)
+    ntt_instr_s = plains_per_launch * L * 256 * NTT_FP64_INSTR / (ntt_avg_ms * 1e-3) if n_ntt else 0.0
+    ntt_blk = {"bound": "valu_fp64", "achieved": 2.0 * ntt_instr_s / 1e12, "peak": 2.0 * FP64_VALU_SPEC_FMA_S / 1e12, "unit": "TFLOP/s",
+               "frac": ntt_instr_s / FP64_VALU_SPEC_FMA_S, "frac_kind": "fp64 ISSUE-SLOT fraction: every fp64 vector instruction (mul, rndne, fma, add) counts as one slot "
+               "of 64 lanes; 'TFLOP/s' here is slots x 64 lanes x 2 (FMA-equivalent) so that it compares with the guide's fp64 vector peak - it is not a count of "
+               "floating-point operations performed", "kernel": "k_ntt_half3<false, true>", "avg_launch_ms": ntt_avg_ms, "launches": n_ntt_all,
+               "launches_timed": n_ntt, "total_ms_in_timed_region": ntt_total_ms,
+               "what": "plaintext (panel) NTT: 2016 fp64 vector instructions per thread and (plaintext, modulus) row (13 stages x 16 butterflies x 8 + the degenerate first "
+                       "stage + canonicalisation), one issue slot = 64 lanes counted as 2 flop (FMA-equivalent; the mix is mul, rndne, fma, add) against the fp64 vector peak "
+                       "256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz",
+               "hbm": {"alg_bytes_per_launch": by_ntt / max(n_ntt, 1), "achieved_GBps": (by_ntt / max(ms_ntt, 1e-9)) / 1e6, "peak_GBps": HBM_PEAK_GBS,
+                       "frac": (by_ntt / max(ms_ntt, 1e-9)) / 1e6 / HBM_PEAK_GBS}}
+    mac_gbps = by_small / (ms_small * 1e-3) / 1e9
+    padded_macs_s = 2 * nbr_x * mct_x * D * D * 2 * KP * (L - 1) * N * args.steps / world / (ms_small * 1e-3)
+    refetch, refetch_src = None, None
+    try:        # exact fabric-side read bytes of this kernel (TCC_EA0_RDREQ_{32B,64B,128B}) against its operand tiles: profiles/r04_pmc_mac_i8_ring.json
+        pm4 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mac_i8_ring.json")))
+        refetch = pm4["default"]["k_mac_i8"]["read_bytes_per_launch"] / pm4["_algorithmic_read_bytes_K1183"]["total"]
+        refetch_src = "profiles/r04_pmc_mac_i8_ring.json (static: counter passes of k_mac_i8_ring<5, 3, 0, 2> at c2, K = 1183)"
+    except Exception:
+        pass
+    mac_blk = {"bound": "hbm", "achieved": mac_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mac_gbps / HBM_PEAK_GBS, "kernel": "k_mac_i8_ring<5, 3>",
+               "frac_of_achievable_6300": mac_gbps / 6300.0, "read_bytes_over_operand_bytes": refetch, "read_bytes_source": refetch_src,
+               "avg_launch_ms": ms_small / n_small, "launches": n_small, "total_ms_in_timed_region": ms_small, "alg_bytes_per_launch": by_small / n_small,
+               "padded_ring_macs_per_s_in_kernel": padded_macs_s, "int8_macs_per_s_in_kernel": 25.0 * padded_macs_s * (32 * 96) / (30 * 91),
+               "what": "ring MAC of the four 35-bit moduli on v_mfma_i32_16x16x64_i8: operands as five signed base-256 digits, 25 digit products per ring-MAC into nine "
+                       "int32 sums, Horner mod q in the epilogue (exact); both k-contiguous digit streams prefetched global -> LDS by the DMA engine two chunks ahead "
+                       "(three 50 KiB slots), read once; bytes = the two streams + tile-ordered results written.  The 46-bit modulus runs the same kernel with six digits "
+                       "(k_mac_i8_ring<6, 2>, phase mac_big)",
+               "helpers_ms_per_step": {k: phase_tot[k][0] / args.steps for k in ("mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile") if k in phase_tot}}
+    dom, other = (ntt_blk, mac_blk) if ntt_total_ms >= ms_small else (mac_blk, ntt_blk)
+    alg_step = 2 * n_ind * m_snp + (KP * nbr_x + KP * mct_x) * ctw * 8 + (KP * mct_x + KP * nbr_x) * outw * 8
+    hbm_alg = alg_step * args.steps / dt / 1e9
+    traffic, traffic_src = None, "no counter pass of this kernel in profiles/"
+    try:
+        for name in ("r05_pmc_ntt.json", "r03_pmc_traffic_per_launch_i8.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            pm = json.load(open(path))
+            ks = [k for k in pm if dom["kernel"].split("<")[0] in k and not k.startswith("_")]
+            if ks:
+                best = max(ks, key=lambda k: pm[k]["launches"])
+                traffic = pm[best]["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/{name} (static: separate rocprofv3 --pmc passes at config {pm.get('_config')}; "
+                               "this kernel's launch shape - 1024 plaintexts x 5 moduli - is the same at every config)")
+                break
+    except Exception:
+        pass
+    return dict(dom, traffic=traffic, traffic_source=traffic_src, second_kernel=other,
+                hbm_algorithmic={"bytes_per_step": alg_step, "achieved_GBps": hbm_alg, "frac": hbm_alg / HBM_PEAK_GBS,
+                                 "what": "SURVEY §8(d): int8 genotypes once per product + ciphertexts in/out, divided by the WHOLE step time"})
+
+
+PHASES = ("rotate", "skew", "encode", "mac", "mac_small", "mac_big", "ntt_plain", "ntt_plain_all", "mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile")
+
+
+def main_lib_engine(args):
+    """N > 1 with the multi-GPU sequence INSIDE the library (sfg_mgpu_*, sfgwas_amd/csrc/mgpu.hip): this script only makes the synthetic inputs, calls the two
+    products per step, keeps the clock and hashes the outputs.  One process per GPU (the driver's launch: each rank joins with sfg_mgpu_create_rank and a 128-byte
+    id passed through torch.distributed's TCP store) or --single-process (sfg_mgpu_create: one host thread per device, the Go party's form)."""
+    single = args.single_process or (args.gpus == 1 and "RANK" not in os.environ)
+    if not single and "RANK" not in os.environ:           # no launcher around us: start the N ranks as children (never exec after touching the GPU)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+        sys.exit(subprocess.call(cmd, env=env))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sfgwas_amd import capi
+    from sfgwas_amd import params as P
+
+    SLOTS, D, N, L, LEVEL = P.SLOTS, P.D, P.N, P.MAX_LEVEL, P.MAX_LEVEL
+    world = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if single:
+        rank, local_rank = 0, 0
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
+        if len(devices) != world:
+            raise SystemExit(f"--devices names {len(devices)} ranks, --gpus {world}")
+        mg = capi.MultiGpu(P.Q_PN14, P.P_PN14, devices=devices)
+    else:
+        rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+        if int(os.environ["WORLD_SIZE"]) != world:
+            raise SystemExit(f"--gpus {world} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)          # host-side only: the id, barriers, the clock's max, the digest gather.  The data path's
+        box = [capi.MultiGpu.unique_id() if rank == 0 else None]              # collectives are the library's own RCCL calls.
+        dist.broadcast_object_list(box, src=0)
+        devices = [local_rank]
+        mg = capi.MultiGpu(P.Q_PN14, P.P_PN14, rank=rank, world=world, uid=box[0], device=local_rank)
+    lib = capi.lib()
+    nloc = mg.nlocal
+    shared_device = len(set(devices)) < len(devices)
+    mg.fill_rotkeys_synthetic(P.rotations_for_matmul(), 0xBEEF)
+    n_ind, m_snp = CONFIGS[args.config]
+    nbr_x, mct_x = ceil_div(n_ind, SLOTS), ceil_div(m_snp, SLOTS)
+    gate = None
+    if rank == 0 and not args.no_check:
+        gate = parity_gate(mg.ctx[0], capi, P)
+    g = mg.geno_synthetic(n_ind, m_snp, 0x5F6A, packed=args.packed_geno)
+    blocks = [mg.geno_blocks(g, i) for i in range(nloc)]
+    A1, A2, out1, out2 = [], [], [], []
+    for i, c in enumerate(mg.ctx):
+        b0, b1 = blocks[i]
+        a1 = capi.DevArray(c, (KP, nbr_x, 2, LEVEL + 1, N))                 # Q : kp x n_ind (replicated)
+        c.check(lib.sfg_fill_uniform_ct_dev(c.h, a1.p, KP * nbr_x, LEVEL, 0xC1F3), "fill A1")
+        a2 = capi.DevArray(c, (KP, max(b1 - b0, 1), 2, LEVEL + 1, N))       # Q': kp x m_snp, this rank's SNP blocks; ciphertext (i, global block b) has seed base + i*mct_x + b
+        for r in range(KP):
+            if b1 > b0:
+                c.check(lib.sfg_fill_uniform_ct_dev(c.h, C.c_void_p(a2.p.value + r * (b1 - b0) * 2 * (LEVEL + 1) * N * 8), b1 - b0, LEVEL, 0xD2A7_0000 + r * mct_x + b0), "fill A2")
+        A1.append(a1); A2.append(a2)
+        out1.append(capi.DevArray(c, (KP, max(b1 - b0, 1), 2, L, N)))
+        out2.append(capi.DevArray(c, (KP, nbr_x, 2, L, N)))
+    mg.sync()
+    ctx0 = mg.ctx[0]
+    phase_tot = {}
+
+    def add_phases():
+        for ph in PHASES:
+            ms = ctx0.phase_ms(ph)
+            if ms >= 0:
+                n = lib.sfg_last_phase_launches(ctx0.h, ph.encode())
+                a = phase_tot.setdefault(ph, [0.0, 0, 0.0])
+                a[0] += ms
+                a[1] += n
+                a[2] += max(lib.sfg_last_phase_bytes(ctx0.h, ph.encode()), 0.0)
+
+    def step():
+        lib.sfg_ctx_clear_phases(ctx0.h)
+        mg.matmul_dev(A1, KP, LEVEL, L, g, 0, out1)                         # Q * X   : the ranks' own output block columns
+        mg.matmul_dev(A2, KP, LEVEL, L, g, capi.SFG_TRANSPOSE, out2)        # Q' * X^T: contraction over the ranks' SNP blocks + the exchange
+        add_phases()                                                        # (resolves rank 0's timing events: one host wait per step, after both products are enqueued)
+
+    def barrier():
+        mg.sync()
+        if not single:
+            dist.barrier()
+        for dv in set(devices):
+            torch.cuda.synchronize(dv)
+
+    pt_cache = {}
+
+    def enable_pt_cache():
+        want = os.environ.get("SFG_BENCH_PT_CACHE_GB", "auto")
+        if want == "0" or (want == "auto" and shared_device):
+            return
+        barrier()
+        budget = min(torch.cuda.mem_get_info(dv)[0] for dv in set(devices)) - (16 << 30)
+        if want != "auto":
+            budget = min(budget, int(float(want) * (1 << 30)))
+        if budget >= (1 << 29):
+            mg.check(lib.sfg_mgpu_geno_set_plaintext_cache(mg.h, g, C.c_size_t(budget)), "plaintext cache")
+            pt_cache["budget"] = budget
+
+    for w in range(args.warmup):
+        step()
+        if w == 0:
+            enable_pt_cache()
+    phase_tot.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if not single:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    near_ties = ctx0.encoder_near_ties()
+    unprovable = C.c_ulonglong()
+    ctx0.check(lib.sfg_ctx_encoder_unprovable(ctx0.h, C.byref(unprovable)), "encoder_unprovable")
+    if "budget" in pt_cache:
+        v = [C.c_size_t() for _ in range(4)]
+        ctx0.check(lib.sfg_geno_plaintext_cache_stats(ctx0.h, C.c_void_p(lib.sfg_mgpu_geno_shard(g, 0)), *[C.byref(x) for x in v]), "plaintext cache stats")
+        pt_cache.update(blocks=v[0].value, bytes=v[1].value, hits=v[2].value, fills=v[3].value)
+    digests = None
+    if not args.no_digest:
+        def ct_hashes(h):                                   # [KP][ncols][...] -> bytes [KP][ncols][32]
+            return np.frombuffer(b"".join(hashlib.sha256(h[i, j].tobytes()).digest() for i in range(h.shape[0]) for j in range(h.shape[1])),
+                                 dtype=np.uint8).reshape(h.shape[0], h.shape[1], 32)
+        parts = [(blocks[i][0], ct_hashes(out1[i].host())) for i in range(nloc) if blocks[i][1] > blocks[i][0]]
+        if not single:
+            allp = [None] * world
+            dist.all_gather_object(allp, parts)
+            parts = [p for sub in allp for p in sub]
+        parts.sort(key=lambda p: p[0])
+        if rank == 0:
+            o2 = ct_hashes(out2[0].host())
+            for i in range(1, nloc):                        # every rank holds the complete Q'X^T: they must agree
+                if not np.array_equal(ct_hashes(out2[i].host()), o2):
+                    raise SystemExit(f"rank {mg.ranks[i]} holds a different Q'*X^T than rank 0")
+            digests = {"out1_sha256": hashlib.sha256(np.concatenate([p[1] for p in parts], axis=1).tobytes()).hexdigest(),
+                       "out2_sha256": hashlib.sha256(o2.tobytes()).hexdigest(),
+                       "of": "SHA-256 over the per-ciphertext SHA-256s in [i][j] order: Q*X (kp x m_ct) and Q'*X^T (kp x nbr); equal for every world size"}
+    macs_per_step = 2 * n_ind * m_snp * KP * 2 * L * (N // SLOTS)
+    value = macs_per_step * args.steps / dt
+    if rank == 0:
+        res = {
+            "metric": "pca_power_iter_ring_macs_per_s", "value": value, "unit": "ring-MAC/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 ring words, exact integers: int8 digits on the matrix core for the MAC of all five moduli, fp64-held integers in the encode and key-switch kernels",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: one PCA power iteration local work = Q*X + Q'*X^T, {n_ind} x {m_snp} int8 genotypes, "
+                                   f"kp={KP}, PN14QP438-shaped ring (N=16384, L=5 of 6 moduli), on-the-fly diagonal encode",
+                       "parallelism": f"snp-block x{world}", "power_iter_wall_s": dt / args.steps,
+                       "genotype_residency": "2-bit packed (sfg_geno_pack)" if args.packed_geno else "int8",
+                       "engine": "libsfgwas_hip sfg_mgpu_* (mgpu.hip): " + ("one process, one host thread per device" if single else "one process per GPU, joined by sfg_mgpu_create_rank"),
+                       "collectives": {"rccl": "RCCL (called by the library; librccl resolved with dlopen)",
+                                       "direct": "in-process direct transport (ranks share a device: a rehearsal; timing not meaningful)"}.get(mg.transport, mg.transport),
+                       "plaintext_cache": (f"{pt_cache['blocks']} blocks of rank 0 ({pt_cache['bytes'] / 2**30:.1f} GiB; {pt_cache.get('hits', 0)} block encodes served from it, "
+                                           f"{pt_cache.get('fills', 0)} filled)" if "budget" in pt_cache else "off"),
+                       "rotation_cache_QX": "replicated",
+                       "QtXt_reduce_scatter": "per output block column, on the collectives' queue beside the next column's product"},
+        }
+        if gate is not None:
+            res["parity_gate"] = gate
+        if digests is not None:
+            res["digests"] = digests
+        res["encoder_near_ties"] = {"count": near_ties, "within_2^-50": unprovable.value, "what": "rank 0; see the N = 1 line"}
+        if phase_tot.get("mac_small", [0, 0, 0])[1] and "mac_i8_pack_pt" in phase_tot:
+            res["roofline"] = roofline_blocks(phase_tot, args, (n_ind, m_snp, nbr_x, mct_x, N, L, D, SLOTS, LEVEL), world, dt, value)
+            res["roofline"]["of"] = "rank 0's launches (HIP events on its queue)"
+        res["phases_ms_per_step"] = {k: v[0] / args.steps for k, v in phase_tot.items()}
+        print(json.dumps(res), flush=True)
+    for a in A1 + A2 + out1 + out2:
+        a.free()
+    mg.geno_free(g)
+    mg.close()
+    if not single:
+        dist.destroy_process_group()
+    if gate is not None and gate["status"] != "ok":
+        raise SystemExit("parity gate FAILED: the HIP path differs from the oracle")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,7 +466,19 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("SFG_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="nccl = RCCL, one GPU per rank (the measured path); gloo = host-staged collectives, ranks may share one GPU (rehearsal)")
     ap.add_argument("--packed-geno", action="store_true", help="keep the genotype matrix 2-bit packed in HBM (sfg_geno_pack: 4x smaller, blocks expanded on the fly)")
+    ap.add_argument("--engine", default=os.environ.get("SFG_BENCH_ENGINE", "lib"), choices=("lib", "torch"),
+                    help="N > 1 only.  lib (default): the multi-GPU sequence runs INSIDE libsfgwas_hip (sfg_mgpu_*: SNP-block shards, per-column reduce-scatter over RCCL "
+                         "on a second queue, finalize of the owned giants, all-reduce); torch: the same sequence issued from this script through torch.distributed (the A/B baseline)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="engine lib: ONE process drives all N GPUs (sfg_mgpu_create + ncclCommInitAll, one host thread per device) - the form a Go party process uses - "
+                         "instead of one process per GPU")
+    ap.add_argument("--devices", default=None, help="--single-process: comma-separated device indices of the N ranks (a repeated device selects the in-process "
+                                                    "'direct' transport: a rehearsal of N > 1 on one GPU; timings then mean nothing)")
     args = ap.parse_args()
+    # SFG_MGPU_FORCE_COLLECTIVES=1 runs the library's exchange even with one rank (over RCCL): `--gpus 1` then takes the engine too
+    if ((args.gpus > 1 or os.environ.get("SFG_MGPU_FORCE_COLLECTIVES") == "1") and args.engine == "lib" and args.backend == "nccl"
+            and not os.environ.get("SFG_BENCH_SOLO") and os.environ.get("SFG_BENCH_FORCE_COLLECTIVES") != "1"):
+        return main_lib_engine(args)
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (one per GPU, torch.distributed.run) before
     # anything in this process touches torch.cuda / HIP, relay rank 0's JSON line and exit with the launcher's code.  (No exec: a process that has
@@ -347,7 +612,7 @@ def main():
     phase_tot = {}
 
     def add_phases():
-        for ph in ("rotate", "skew", "encode", "mac", "mac_small", "mac_big", "ntt_plain", "ntt_plain_all", "mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile"):
+        for ph in PHASES:
             ms = ctx.phase_ms(ph)
             if ms >= 0:
                 n = lib.sfg_last_phase_launches(ctx.h, ph.encode())
@@ -534,61 +799,7 @@ def main():
             # default build: the small-modulus MAC runs on the int8 matrix core (mac_i8.hip) and is HBM bound; the kernel with the largest total time in the
             # timed region is then the panel NTT (fp64 vector issue bound).  Both are measured live (HIP events on the library's stream; the NTT on every 16th
             # of its ~50 000 launches per step, all launches counted) and the larger total is reported as `roofline`, the other one inside it.
-            ms_ntt, n_ntt, by_ntt = phase_tot.get("ntt_plain", [0.0, 0, 0.0])
-            n_ntt_all = phase_tot.get("ntt_plain_all", [0.0, 0, 0.0])[1]
-            ntt_avg_ms = ms_ntt / max(n_ntt, 1)
-            ntt_total_ms = ntt_avg_ms * n_ntt_all
-            bytes_per_plain = (N // 2) * (8 + 5 * (L - 1) + 8)                   # coefficient row in, five digit planes per small modulus + one word row out
-            plains_per_launch = (by_ntt / max(n_ntt, 1)) / bytes_per_plain
-            NTT_FP64_INSTR = 2016                                               # fp64 vector instructions per thread of k_ntt_half3 (static count of the gfx950 ISA)
-            ntt_instr_s = plains_per_launch * L * 256 * NTT_FP64_INSTR / (ntt_avg_ms * 1e-3) if n_ntt else 0.0
-            ntt_blk = {"bound": "valu_fp64", "achieved": 2.0 * ntt_instr_s / 1e12, "peak": 2.0 * FP64_VALU_SPEC_FMA_S / 1e12, "unit": "TFLOP/s",
-                       "frac": ntt_instr_s / FP64_VALU_SPEC_FMA_S, "frac_kind": "fp64 ISSUE-SLOT fraction: every fp64 vector instruction (mul, rndne, fma, add) counts as one slot "
-                       "of 64 lanes; 'TFLOP/s' here is slots x 64 lanes x 2 (FMA-equivalent) so that it compares with the guide's fp64 vector peak - it is not a count of "
-                       "floating-point operations performed", "kernel": "k_ntt_half3<false, true>", "avg_launch_ms": ntt_avg_ms, "launches": n_ntt_all,
-                       "launches_timed": n_ntt, "total_ms_in_timed_region": ntt_total_ms,
-                       "what": "plaintext (panel) NTT: 2016 fp64 vector instructions per thread and (plaintext, modulus) row (13 stages x 16 butterflies x 8 + the degenerate first "
-                               "stage + canonicalisation), one issue slot = 64 lanes counted as 2 flop (FMA-equivalent; the mix is mul, rndne, fma, add) against the fp64 vector peak "
-                               "256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz",
-                       "hbm": {"alg_bytes_per_launch": by_ntt / max(n_ntt, 1), "achieved_GBps": (by_ntt / max(ms_ntt, 1e-9)) / 1e6, "peak_GBps": HBM_PEAK_GBS,
-                               "frac": (by_ntt / max(ms_ntt, 1e-9)) / 1e6 / HBM_PEAK_GBS}}
-            mac_gbps = by_small / (ms_small * 1e-3) / 1e9
-            padded_macs_s = 2 * nbr_x * mct_x * D * D * 2 * KP * (L - 1) * N * args.steps / world / (ms_small * 1e-3)
-            refetch, refetch_src = None, None
-            try:        # exact fabric-side read bytes of this kernel (TCC_EA0_RDREQ_{32B,64B,128B}) against its operand tiles: profiles/r04_pmc_mac_i8_ring.json
-                pm4 = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mac_i8_ring.json")))
-                refetch = pm4["default"]["k_mac_i8"]["read_bytes_per_launch"] / pm4["_algorithmic_read_bytes_K1183"]["total"]
-                refetch_src = "profiles/r04_pmc_mac_i8_ring.json (static: counter passes of k_mac_i8_ring<5, 3, 0, 2> at c2, K = 1183)"
-            except Exception:
-                pass
-            mac_blk = {"bound": "hbm", "achieved": mac_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mac_gbps / HBM_PEAK_GBS, "kernel": "k_mac_i8_ring<5, 3>",
-                       "frac_of_achievable_6300": mac_gbps / 6300.0, "read_bytes_over_operand_bytes": refetch, "read_bytes_source": refetch_src,
-                       "avg_launch_ms": ms_small / n_small, "launches": n_small, "total_ms_in_timed_region": ms_small, "alg_bytes_per_launch": by_small / n_small,
-                       "padded_ring_macs_per_s_in_kernel": padded_macs_s, "int8_macs_per_s_in_kernel": 25.0 * padded_macs_s * (32 * 96) / (30 * 91),
-                       "what": "ring MAC of the four 35-bit moduli on v_mfma_i32_16x16x64_i8: operands as five signed base-256 digits, 25 digit products per ring-MAC into nine "
-                               "int32 sums, Horner mod q in the epilogue (exact); both k-contiguous digit streams prefetched global -> LDS by the DMA engine two chunks ahead "
-                               "(three 50 KiB slots), read once; bytes = the two streams + tile-ordered results written.  The 46-bit modulus runs the same kernel with six digits "
-                               "(k_mac_i8_ring<6, 2>, phase mac_big)",
-                       "helpers_ms_per_step": {k: phase_tot[k][0] / args.steps for k in ("mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile") if k in phase_tot}}
-            dom, other = (ntt_blk, mac_blk) if ntt_total_ms >= ms_small else (mac_blk, ntt_blk)
-            alg_step = 2 * n_ind * m_snp + (KP * nbr_x + KP * mct_x) * ctw * 8 + (KP * mct_x + KP * nbr_x) * outw * 8
-            hbm_alg = alg_step * args.steps / dt / 1e9
-            traffic, traffic_src = None, "no counter pass of this kernel in profiles/"
-            try:
-                path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_per_launch_i8.json")
-                if os.path.exists(path):
-                    pm = json.load(open(path))
-                    ks = [k for k in pm if dom["kernel"].split("<")[0] in k and not k.startswith("_")]
-                    if ks:
-                        best = max(ks, key=lambda k: pm[k]["launches"])
-                        traffic = pm[best]["hbm_bytes_per_launch"]
-                        traffic_src = (f"profiles/r03_pmc_traffic_per_launch_i8.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at config {pm.get('_config')}; "
-                                       "this kernel's launch shape - 1024 plaintexts x 5 moduli - is the same at every config)")
-            except Exception:
-                pass
-            res["roofline"] = dict(dom, traffic=traffic, traffic_source=traffic_src, second_kernel=other,
-                                   hbm_algorithmic={"bytes_per_step": alg_step, "achieved_GBps": hbm_alg, "frac": hbm_alg / HBM_PEAK_GBS,
-                                                    "what": "SURVEY §8(d): int8 genotypes once per product + ciphertexts in/out, divided by the WHOLE step time"})
+            res["roofline"] = roofline_blocks(phase_tot, args, (n_ind, m_snp, nbr_x, mct_x, N, L, D, SLOTS, LEVEL), world, dt, value)
         elif n_small:
             nl_small = L - 1
             avg_ms = ms_small / n_small

@@ -1,8 +1,13 @@
-"""bench.py's N > 1 path EXECUTED with world size > 1 on the one GPU a box has: `--backend gloo` stages the collectives through
+"""bench.py's N > 1 paths EXECUTED with world size > 1 on the one GPU a box has.
+
+(1) --engine torch (the A/B baseline since round 5: the sequence issued from bench.py through torch.distributed): `--backend gloo` stages the collectives through
 host memory, so several ranks can share a device (RCCL refuses that).  Everything but the transport is the code the driver's
 8-GPU run executes: per-rank SNP-block windows of one global matrix, per-rank ciphertext slices and seeds, the sharded
 rotation-cache build + all-gather + scatter, the per-column reduce-scatter windows over the padded giant axis, finalize of the
 owned giant slots, the all-reduce of the aligned partial outputs (pca.go:344,352).
+
+(2) --engine lib (the default for N > 1 since round 5): the sequence runs INSIDE libsfgwas_hip (sfg_mgpu_*, mgpu.hip) - as one process driving N ranks (the Go
+party's form; ranks on one device use the library's in-process direct transport) and under the driver's one-process-per-GPU launcher (RCCL, world 1 here).
 
 The bar: the SHA-256 digests of both products printed by every world size equal the single-process line's - every output
 word of Q*X and Q'*X^T is the same whatever the sharding."""
@@ -55,16 +60,6 @@ def same(a, b, what):
     assert a["digests"]["out2_sha256"] == b["digests"]["out2_sha256"], f"{what}: Q'*X^T differs from the single-process product"
 
 
-def test_c2_two_ranks_share_the_gpu_with_a_sharded_rotation_cache_and_reproduce_the_single_process_digests(plain):
-    """10 000 x 100 000 (13 SNP blocks -> 6 + 7; the last rank holds the ragged block).  Q*X's rotation cache built in shards (15 of the 30
-    (block row, input) jobs per rank), all-gathered and scattered into the MAC layout; Q'*X^T one output block column at a time beside the previous
-    column's reduce-scatter"""
-    got = bench_line("c2", 2, "gloo", dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="sharded"))
-    assert got["n_gpus"] == 2 and got["config"]["rotation_cache_QX"].startswith("sharded")
-    assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
-    same(plain("c2"), got, "c2, 2 ranks, sharded cache")
-
-
 def test_c2_three_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain):
     """4 + 4 + 5 SNP blocks; 31 giant slots per rank (93 > 91: the last rank owns 29); the default multi-GPU configuration"""
     got = bench_line("c2", 3, "gloo", SHARED_GPU_ENV)
@@ -82,30 +77,12 @@ def test_c2_three_ranks_sharded_cache_and_unpipelined_reduce_scatter(plain):
     same(plain("c2"), got, "c2, 3 ranks, sharded cache, unpipelined")
 
 
-def test_c3_two_ranks_share_the_gpu_and_reproduce_the_single_process_digests(plain):
-    """50 000 x 500 000 (62 SNP blocks, 7 block rows of individuals): several MAC groups per rank, 7 reduce-scatter windows of which the last runs
-    past its block column, 46 giant slots per rank of which the last rank owns 45; sharded rotation cache with a SHORT last shard (105 jobs = 53 + 52:
-    the all-gather is padded)"""
-    got = bench_line("c3", 2, "gloo", dict(SHARED_GPU_ENV, SFG_BENCH_ROTCACHE="sharded"))
-    assert got["n_gpus"] == 2 and got["config"]["rotation_cache_QX"].startswith("sharded")
-    same(plain("c3"), got, "c3, 2 ranks")
-
-
 def test_collectives_path_at_world_size_1_over_rccl_matches_the_plain_path(plain):
     """the same sequence over RCCL (backend nccl) with one rank: stream ordering between the library's kernels and the collectives
     (bench.py once handed torch's default stream, handle 0 = "the context's own stream", to the library and the collectives read the accumulators early)"""
-    got = bench_line("c3", 1, "nccl", None, force_coll=True)
+    got = bench_line("c2", 1, "nccl", None, force_coll=True)
     assert got["config"]["collectives"] == "RCCL"
-    same(plain("c3"), got, "c3, forced collectives at world size 1")
-
-
-def test_pipelined_and_sharded_sequences_over_rccl_at_world_size_1(plain):
-    """the round-3 additions over the real transport: all_gather_into_tensor of the sharded rotation cache and the ASYNC per-column reduce-scatters
-    (RCCL's own stream, work.wait() before a column buffer is reused) with one rank, 10 000 x 100 000"""
-    got = bench_line("c2", 1, "nccl", {"SFG_BENCH_ROTCACHE": "sharded"}, force_coll=True)
-    assert got["config"]["collectives"] == "RCCL" and got["config"]["rotation_cache_QX"].startswith("sharded")
-    assert got["config"]["QtXt_reduce_scatter"].startswith("per output block column")
-    same(plain("c2"), got, "c2, forced RCCL collectives, sharded cache, pipelined reduce-scatter")
+    same(plain("c2"), got, "c2, forced collectives at world size 1")
 
 
 def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu(plain):
@@ -120,3 +97,51 @@ def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu(plain):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collectives"].startswith("gloo")
     same(line, plain("c2"), "self-launched 2 ranks")
+
+
+# ---- the same bar for the multi-GPU sequence INSIDE the library (bench.py --engine lib, the default for N > 1: sfg_mgpu_*, sfgwas_amd/csrc/mgpu.hip)
+LIB_SHARED_ENV = {"SFG_MM_GROUP": "4", "SFG_MM_ACC_BUDGET_MB": "4096", "SFG_MGPU_CACHE_GB": "24"}
+
+
+def lib_line(config, world, extra=(), env=None, launcher=False):
+    e = dict(os.environ)
+    e.update(env or {})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    args = ["bench.py", "--config", config, "--gpus", str(world)] + COMMON + list(extra)
+    if launcher:
+        _port[0] += 1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_port[0])] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_library_engine_one_process_two_ranks_on_one_device_reproduces_the_single_gpu_digests(plain):
+    """the Go party's form: ONE process, sfg_mgpu_create(devices = [0, 0]) - a repeated device, so the in-process direct transport carries the reduce-scatters and
+    the all-reduce; 10 000 x 100 000 = 13 SNP blocks -> 6 + 7"""
+    got = lib_line("c2", 2, ["--single-process", "--devices", "0,0"], LIB_SHARED_ENV)
+    assert got["n_gpus"] == 2 and got["config"]["engine"].startswith("libsfgwas_hip sfg_mgpu") and got["config"]["collectives"].startswith("in-process direct")
+    same(plain("c2"), got, "c2, library engine, 2 ranks in one process")
+
+
+def test_library_engine_three_ranks_c3_and_unpipelined_c2(plain):
+    """50 000 x 500 000 on three ranks (62 SNP blocks -> 20 + 21 + 21, 7 output block columns: the two column buffers change hands five times; 31 giant slots per
+    rank, 93 > 91) and the unpipelined form at 10 000 x 100 000"""
+    got = lib_line("c3", 3, ["--single-process", "--devices", "0,0,0"], LIB_SHARED_ENV)
+    same(plain("c3"), got, "c3, library engine, 3 ranks in one process")
+    got = lib_line("c2", 3, ["--single-process", "--devices", "0,0,0"], dict(LIB_SHARED_ENV, SFG_MGPU_CACHE_GB="0"))
+    same(plain("c2"), got, "c2, library engine, 3 ranks, reduce-scatters after the product")
+
+
+def test_library_engine_over_rccl_at_world_1_in_both_process_models(plain):
+    """the library's own RCCL calls (ncclReduceScatter on the collectives' queue beside the next column's product, ncclAllReduce) with one rank: as one process
+    (ncclCommInitAll) and under the launcher the driver uses (one process per GPU: sfg_mgpu_unique_id on rank 0 -> TCP store -> sfg_mgpu_create_rank)"""
+    got = lib_line("c2", 1, [], {"SFG_MGPU_FORCE_COLLECTIVES": "1"})
+    assert got["config"]["collectives"].startswith("RCCL (called by the library")
+    same(plain("c2"), got, "c2, library engine, RCCL at world 1, one process")
+    got = lib_line("c2", 1, [], {"SFG_MGPU_FORCE_COLLECTIVES": "1"}, launcher=True)
+    assert got["config"]["engine"].endswith("sfg_mgpu_create_rank") and got["config"]["collectives"].startswith("RCCL")
+    same(plain("c2"), got, "c2, library engine, RCCL at world 1, launcher")
