@@ -402,6 +402,17 @@ int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *g, size_t m
 int sfg_mgpu_matmul_dev(sfg_mgpu *mg, const uint64_t *const *A_dev, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags,
                         uint64_t *const *out_dev);
 int sfg_mgpu_matmul(sfg_mgpu *mg, const uint64_t *A_host, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags, uint64_t *out_host);
+/* GenoBlockMult's batch loop (gwas/assoc.go:340-420) on G GPUs: the reference hands the SNP batches of a chromosome file to assoc_num_blocks_parallel workers
+ * (:360-408); here batch k goes to rank k % world.  Every rank streams its batches from the file (sfg_assoc_stream_bed / _pgen: reader thread, pinned slots, decode on
+ * the device), multiplies them against its own call-wide rotation cache of `mat` and its output ciphertexts land at their positions of
+ * out_host [s][out_ct_capacity][2][max_level][N] (a multi-process world: the positions of this process's ranks only).  A_host: mat, [s][ceil(kept samples / 8192)]
+ * ciphertexts at in_level.  sum_host / sqsum_host, flags, *out_ct as in the single-GPU calls.  No collective. */
+int sfg_mgpu_assoc_stream_bed(sfg_mgpu *mg, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                              size_t batch_snps, const uint64_t *A_host, int s, int in_level, int max_level, unsigned flags,
+                              uint64_t *out_host, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
+int sfg_mgpu_assoc_stream_pgen(sfg_mgpu *mg, const char *pgen_path, const uint8_t *row_filter, const uint8_t *col_filter, size_t kept_samples,
+                               size_t batch_snps, const uint64_t *A_host, int s, int in_level, int max_level, unsigned flags,
+                               uint64_t *out_host, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host);
 
 /* ---- f-1: collective bootstrap, LOCAL work (mpc/mhe.go:222-348: CollectiveBootstrap / CollectiveBootstrapMat) ----
  * Per ciphertext the reference calls lattigo's dckks.RefreshProtocol: GenShares (mhe.go:251,315), aggregates the shares over the network

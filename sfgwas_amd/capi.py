@@ -145,6 +145,8 @@ def _sig(L):
         "sfg_mgpu_geno_set_plaintext_cache": (i, [vp, vp, sz]),
         "sfg_mgpu_matmul_dev": (i, [vp, C.POINTER(vp), i, i, i, vp, C.c_uint, C.POINTER(vp)]),
         "sfg_mgpu_matmul": (i, [vp, u64p, i, i, i, vp, C.c_uint, u64p]),
+        "sfg_mgpu_assoc_stream_bed": (i, [vp, C.c_char_p, sz, sz, vp, vp, sz, u64p, i, i, i, C.c_uint, u64p, sz, C.POINTER(sz), vp, vp]),
+        "sfg_mgpu_assoc_stream_pgen": (i, [vp, C.c_char_p, vp, vp, sz, sz, u64p, i, i, i, C.c_uint, u64p, sz, C.POINTER(sz), vp, vp]),
         "sfg_ctx_clear_phases": (i, [vp]),
         "sfg_last_phase_ms": (d, [vp, C.c_char_p]),
         "sfg_last_phase_launches": (i, [vp, C.c_char_p]),

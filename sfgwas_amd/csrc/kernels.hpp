@@ -94,3 +94,9 @@ struct AssocRot { double *f64 = nullptr; I8RotPre pre; };
 int assoc_build_rot(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, size_t nr, const std::vector<size_t> &widths, AssocRot &out);
 void assoc_free_rot(AssocRot &r);
 int assoc_product(sfg_ctx *ctx, const AssocRot &r, const uint64_t *A_dev, int s, int in_level, int max_level, const sfg_geno *g, unsigned flags, int nct, uint64_t *out);
+
+// stream.hip: the streamed association scan restricted to the batches k % nparts == part (fmt 0 = .bed, 1 = .pgen); see its definition
+int assoc_stream_part(sfg_ctx *ctx, int fmt, const char *path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                      size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                      uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host,
+                      int part, int nparts, std::vector<std::pair<size_t, size_t>> *ranges);

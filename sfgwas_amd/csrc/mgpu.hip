@@ -19,6 +19,7 @@
 // buffers with a kernel - peer access over xGMI, or plain loads when several ranks share one device, which RCCL refuses: that is how world sizes 2 and 3 are
 // tested on a one-GPU box; host-side rendezvous, no overlap).  Integer sums: both give identical words.
 #include "common.hpp"
+#include "kernels.hpp"
 #include <rccl/rccl.h>          // types and prototypes only; the functions are resolved at run time (Rccl below)
 #include <dlfcn.h>
 #include <atomic>
@@ -148,12 +149,14 @@ static const char *rank_exec_init(MgRank &R) {
 extern "C" void sfg_mgpu_destroy(sfg_mgpu *mg) {
     if (!mg) return;
     for (auto &R : mg->r) {
+        if (!R.ctx) continue;                          // (a rank whose context was never made - a bad device index - owns nothing, and its device must not be touched)
         (void)hipSetDevice(R.device);
-        if (R.ctx) (void)sfg_sync_all(R.ctx);
+        (void)sfg_sync_all(R.ctx);
         if (R.coll) (void)hipStreamSynchronize(R.coll);
     }
     for (auto &R : mg->r) if (R.comm) { (void)hipSetDevice(R.device); (void)g_rccl.CommDestroy(R.comm); }
     for (auto &R : mg->r) {
+        if (!R.ctx) continue;
         (void)hipSetDevice(R.device);
         if (R.coll) (void)hipStreamDestroy(R.coll);
         for (int i = 0; i < 2; i++) { if (R.ev_acc[i]) (void)hipEventDestroy(R.ev_acc[i]); if (R.ev_rs[i]) (void)hipEventDestroy(R.ev_rs[i]); }
@@ -456,4 +459,49 @@ extern "C" int sfg_mgpu_matmul(sfg_mgpu *mg, const uint64_t *A_host, int s, int 
             R_CTX(R, sfg_memcpy_d2h(R.ctx, out_host + ((size_t)r * mct + g->blk0[(size_t)i]) * outw, O[(size_t)i] + (size_t)r * nloc * outw, nloc * outw * 8));
         return 0;
     });
+}
+
+// ---------------------------------------------------------------- the association scan on G GPUs
+// GenoBlockMult (gwas/assoc.go:340-420) hands the SNP batches of a chromosome file to assoc_num_blocks_parallel workers (:360-408); here the workers are the
+// ranks: batch k goes to rank k % world, every rank streams ITS batches from the file (its own reader thread and pinned slots), multiplies them against its own
+// copy of the call-wide rotation cache of `mat` (built once per rank: the rotations are a function of mat alone) and the outputs are copied to their
+// positions of out_host [s][out_ct_capacity][2][max_level][N].  No collective: batches are independent.  In a multi-process world a process fills the
+// positions of its ranks' batches and leaves the others untouched; *out_ct is the total in every process.
+static int mgpu_assoc(sfg_mgpu *mg, int fmt, const char *path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
+                      const uint64_t *A_host, size_t nbr, int s, int in_level, int max_level, unsigned flags, uint64_t *out_host, size_t out_ct_capacity, size_t *out_ct,
+                      double *sum_host, double *sqsum_host) {
+    if (s < 1 || !nbr || !out_host || !A_host) MG_FAIL(mg, "sfg_mgpu_assoc: bad arguments");
+    const size_t N = SFG_N, ctw_in = 2 * (size_t)(in_level + 1) * N, ctw = 2 * (size_t)max_level * N;
+    std::vector<size_t> totals(mg->r.size(), 0);
+    const int rc = run_ranks(mg, [&](MgRank &R, int i) {
+        uint64_t *A = nullptr, *out = nullptr;
+        R_CTX(R, sfg_scratch(R.ctx, "mg.Ain", (size_t)s * nbr * ctw_in * 8, (void **)&A));
+        R_CTX(R, sfg_scratch(R.ctx, "mg.assoc_out", (size_t)s * out_ct_capacity * ctw * 8, (void **)&out));
+        R_CTX(R, sfg_memcpy_h2d(R.ctx, A, A_host, (size_t)s * nbr * ctw_in * 8));
+        std::vector<std::pair<size_t, size_t>> ranges;
+        ApiScope api_scope(R.ctx);
+        R_CTX(R, assoc_stream_part(R.ctx, fmt, path, num_sample, num_snp, row_filter, col_filter, batch_snps, A, s, in_level, max_level, flags, out, out_ct_capacity, &totals[(size_t)i],
+                                   sum_host, sqsum_host, R.rank, mg->world, &ranges));       // (sums: every rank writes the slices of its own batches - disjoint)
+        for (const auto &rg : ranges) for (int r = 0; r < s; r++)
+            R_CTX(R, sfg_memcpy_d2h(R.ctx, out_host + ((size_t)r * out_ct_capacity + rg.first) * ctw, out + ((size_t)r * out_ct_capacity + rg.first) * ctw, rg.second * ctw * 8));
+        return 0;
+    });
+    if (rc) return rc;
+    if (out_ct) *out_ct = totals[0];
+    return 0;
+}
+extern "C" int sfg_mgpu_assoc_stream_bed(sfg_mgpu *mg, const char *bed_path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                                         size_t batch_snps, const uint64_t *A_host, int s, int in_level, int max_level, unsigned flags,
+                                         uint64_t *out_host, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    size_t nr = 0; for (size_t i = 0; i < num_sample; i++) nr += (!row_filter || row_filter[i]) ? 1 : 0;
+    return mgpu_assoc(mg, 0, bed_path, num_sample, num_snp, row_filter, col_filter, batch_snps, A_host, (nr + SFG_SLOTS - 1) / SFG_SLOTS, s, in_level, max_level, flags,
+                      out_host, out_ct_capacity, out_ct, sum_host, sqsum_host);
+}
+// kept_samples: the number of samples the row filter keeps (the file's sample count when row_filter is NULL) - it sizes `A_host` ([s][ceil(kept_samples / 8192)])
+extern "C" int sfg_mgpu_assoc_stream_pgen(sfg_mgpu *mg, const char *pgen_path, const uint8_t *row_filter, const uint8_t *col_filter, size_t kept_samples,
+                                          size_t batch_snps, const uint64_t *A_host, int s, int in_level, int max_level, unsigned flags,
+                                          uint64_t *out_host, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+    if (!kept_samples) MG_FAIL(mg, "sfg_mgpu_assoc_stream_pgen: kept_samples must be given (it sizes the input ciphertext grid)");
+    return mgpu_assoc(mg, 1, pgen_path, 0, 0, row_filter, col_filter, batch_snps, A_host, (kept_samples + SFG_SLOTS - 1) / SFG_SLOTS, s, in_level, max_level, flags,
+                      out_host, out_ct_capacity, out_ct, sum_host, sqsum_host);
 }

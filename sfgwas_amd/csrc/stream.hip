@@ -120,10 +120,14 @@ int assoc_product(sfg_ctx *ctx, const AssocRot &r, const uint64_t *A_dev, int s,
 // sum_host / sqsum_host: optional [*out_ct * slots] column sums in the reference's padded layout (dosageSum[outShift + c], assoc.go:404-405).
 // One engine for both on-disk formats: a batch is a contiguous byte range of the file (.bed: nsnp * bps bytes; .pgen: the variant records of the batch, preceded by
 // the LD base its first records may need), read ahead by the reader thread, copied as it is, decoded on the copy queue into the batch's int8 matrix.
+// part / nparts (multi-GPU scans, mgpu.hip): this call multiplies the batches k with k % nparts == part - the reference's dispatcher hands batches to
+// assoc_num_blocks_parallel workers the same way (assoc.go:360-408) - and leaves the output ciphertexts and sums of the other batches untouched; `ranges`
+// (optional) receives (first output ciphertext, count) of every batch it multiplied.
 enum { FMT_BED = 0, FMT_PGEN = 1 };
-static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
-                               size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
-                               uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
+int assoc_stream_part(sfg_ctx *ctx, int fmt, const char *path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter,
+                      size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
+                      uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host,
+                      int part, int nparts, std::vector<std::pair<size_t, size_t>> *ranges) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     const char *who = fmt == FMT_BED ? "assoc_stream_bed" : "assoc_stream_pgen";
     if (!batch_snps) SFG_FAIL(ctx, "%s: bad dimensions", who);
@@ -155,8 +159,20 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
         fd = open(path, O_RDONLY | O_DIRECT);
         if (fd < 0) SFG_FAIL(ctx, "%s: the file system of %s does not support O_DIRECT", who, path);
     }
-    std::vector<Batch> bt = make_batches(col_filter, num_snp, batch_snps);
-    size_t total_ct = 0, max_bytes = 0, max_rows = 0, max_nsnp = 0, max_kept = 0;
+    std::vector<Batch> bt_all = make_batches(col_filter, num_snp, batch_snps), bt;
+    std::vector<size_t> shift_of;                       // first output ciphertext of each of THIS part's batches (positions count every batch of the file)
+    if (nparts < 1 || part < 0 || part >= nparts) { close(fd); SFG_FAIL(ctx, "%s: bad part", who); }
+    {
+        size_t sh = 0;
+        for (size_t k = 0; k < bt_all.size(); k++) {
+            if ((int)(k % (size_t)nparts) == part) { bt.push_back(bt_all[k]); shift_of.push_back(sh); }
+            sh += (bt_all[k].kept + SFG_SLOTS - 1) / SFG_SLOTS;
+        }
+        if (out_ct) *out_ct = sh;
+        if (sh > out_ct_capacity) { close(fd); SFG_FAIL(ctx, "%s: output needs %zu ciphertexts per row, capacity %zu", who, sh, out_ct_capacity); }
+    }
+    if (ranges) ranges->clear();
+    size_t max_bytes = 0, max_rows = 0, max_nsnp = 0, max_kept = 0;
     if (fmt == FMT_PGEN) win.resize(bt.size());
     for (size_t k = 0; k < bt.size(); k++) {
         Batch &b = bt[k];
@@ -165,11 +181,9 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
             if (pgen_window(ctx, ix, (size_t)stt.st_size, b.snp0, b.snp0 + b.nsnp, win[k])) { close(fd); return 1; }
             b.off = (off_t)win[k].f0; b.bytes = (size_t)(win[k].f1 - win[k].f0); max_rows = std::max(max_rows, win[k].nr);
         }
-        total_ct += (b.kept + slots - 1) / slots; max_bytes = std::max(max_bytes, b.bytes); max_nsnp = std::max(max_nsnp, b.nsnp); max_kept = std::max(max_kept, b.kept);
+        max_bytes = std::max(max_bytes, b.bytes); max_nsnp = std::max(max_nsnp, b.nsnp); max_kept = std::max(max_kept, b.kept);
     }
-    if (out_ct) *out_ct = total_ct;
     if (bt.empty()) { close(fd); return 0; }
-    if (total_ct > out_ct_capacity) { close(fd); SFG_FAIL(ctx, "%s: output needs %zu ciphertexts per row, capacity %zu", who, total_ct, out_ct_capacity); }
     // row map once; column maps per batch
     std::vector<int32_t> rmap_h(num_sample); size_t nr = 0;
     for (size_t i = 0; i < num_sample; i++) rmap_h[i] = (!row_filter || row_filter[i]) ? (int32_t)nr++ : -1;
@@ -221,9 +235,9 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
                                                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
     }
     std::vector<int32_t> cmap_h(max_nsnp);
-    size_t out_shift = 0;
     for (size_t k = 0; k < bt.size() && !rc; k++) {
         const Batch &b = bt[k]; const int sl = (int)(k & 1);
+        const size_t out_shift = shift_of[k];
         if (!rd.wait_filled(k)) { ctx->err = std::string(who) + ": " + rd.err; rc = 1; break; }
         size_t kc = 0;
         for (size_t j = 0; j < b.nsnp; j++) cmap_h[j] = (!col_filter || col_filter[b.snp0 + j]) ? (int32_t)kc++ : -1;
@@ -261,7 +275,7 @@ static int assoc_stream_common(sfg_ctx *ctx, int fmt, const char *path, size_t n
             rc = sfg_geno_colsums(ctx, &g, sum_host ? sum_host + out_shift * slots : nullptr, sqsum_host ? sqsum_host + out_shift * slots : nullptr);
         }
         if (!rc) ST_HIP(hipEventRecord(ev_free[sl], ctx->stream));
-        out_shift += nct;
+        if (ranges) ranges->push_back({out_shift, nct});
     }
 #undef ST_HIP
     if (rc) rd.release(bt.size() + 2);                             // let the reader run out
@@ -276,8 +290,8 @@ extern "C" int sfg_assoc_stream_bed(sfg_ctx *ctx, const char *bed_path, size_t n
                                     size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                                     uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
     ApiScope api_scope(ctx);
-    return assoc_stream_common(ctx, FMT_BED, bed_path, num_sample, num_snp, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
-                               sum_host, sqsum_host);
+    return assoc_stream_part(ctx, FMT_BED, bed_path, num_sample, num_snp, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
+                             sum_host, sqsum_host, 0, 1, nullptr);
 }
 // the same scan straight from a PLINK 2 .pgen on disk (the reference's input at config 5: 10 M SNPs per party do not fit host memory as one image); sample and
 // variant counts come from the file's header
@@ -285,6 +299,6 @@ extern "C" int sfg_assoc_stream_pgen(sfg_ctx *ctx, const char *pgen_path, const 
                                      size_t batch_snps, const uint64_t *A_dev, int s, int in_level, int max_level, unsigned flags,
                                      uint64_t *out_dev, size_t out_ct_capacity, size_t *out_ct, double *sum_host, double *sqsum_host) {
     ApiScope api_scope(ctx);
-    return assoc_stream_common(ctx, FMT_PGEN, pgen_path, 0, 0, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
-                               sum_host, sqsum_host);
+    return assoc_stream_part(ctx, FMT_PGEN, pgen_path, 0, 0, row_filter, col_filter, batch_snps, A_dev, s, in_level, max_level, flags, out_dev, out_ct_capacity, out_ct,
+                             sum_host, sqsum_host, 0, 1, nullptr);
 }

@@ -176,3 +176,64 @@ def test_errors_are_reported_not_hung(ref, monkeypatch):
     finally:
         mg.geno_free(g)
         mg.close()
+
+
+def test_association_scan_batches_round_robin_over_ranks(tmp_path, monkeypatch):
+    """sfg_mgpu_assoc_stream_bed / _pgen: batch k of GenoBlockMult's loop (gwas/assoc.go:360-408) goes to rank k % world; outputs and padded column sums land where the
+    single-GPU scan (tests/test_gpu_stream.py: oracle-checked) puts them.  7 batches over 2 and 3 ranks, row + column filters, SFG_SQUARE; then a .pgen."""
+    from sfgwas_amd import capi
+    from test_gpu_stream import write_bed
+    import pgen_writer
+    lib = capi.lib()
+    ns, nv, batch, s, level, maxl = 130, 700, 100, 3, 5, 5
+    rnd = np.random.default_rng(23)
+    geno = rnd.choice(np.array([2, -1, 1, 0], dtype=np.int8), size=(ns, nv), p=[0.2, 0.05, 0.35, 0.4])
+    rowf = (rnd.random(ns) < 0.9).astype(np.uint8); colf = (rnd.random(nv) < 0.9).astype(np.uint8)
+    path = str(tmp_path / "chr.bed")
+    write_bed(path, geno)
+    N, slots = 16384, 8192
+    ctx = capi.Context(ol.Q_PN14, ol.P_PN14)
+    ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(ROTS))(*ROTS), len(ROTS), 0xBEEF), "keys")
+    dA = ctx.fill_uniform_cts(s, level, 0xA55)
+    A = dA.host().copy()
+    cap = 9
+    want = {}
+    for flags in (0, SQ):
+        dout = capi.DevArray(ctx, (s, cap, 2, maxl, N))
+        ctx.check(lib.sfg_memcpy_h2d(ctx.h, dout.p, np.zeros(s * cap * 2 * maxl * N, dtype=np.uint64).ctypes.data_as(C.c_void_p), s * cap * 2 * maxl * N * 8), "zero")
+        sums = np.full(cap * slots, -7.0); sq = np.full(cap * slots, -7.0); n_ct = C.c_size_t()
+        ctx.check(lib.sfg_assoc_stream_bed(ctx.h, path.encode(), ns, nv, rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch, dA.p, s, level, maxl, flags,
+                                           dout.p, cap, C.byref(n_ct), sums.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p)), "assoc_stream_bed")
+        assert n_ct.value == 7
+        want[flags] = (dout.host().copy(), sums, sq)
+        dout.free()
+    # a .pgen of the same shape through the independent writer (tests/pgen_writer.py)
+    codes, vrt = pgen_writer.synthetic(nv, ns, 5)                                          # every record type, LD runs that cross batch boundaries
+    ppath = str(tmp_path / "chr.pgen")
+    open(ppath, "wb").write(pgen_writer.write_pgen(codes, vrt, wmode=5).tobytes())
+    dout = capi.DevArray(ctx, (s, cap, 2, maxl, N))
+    ctx.check(lib.sfg_memcpy_h2d(ctx.h, dout.p, np.zeros(s * cap * 2 * maxl * N, dtype=np.uint64).ctypes.data_as(C.c_void_p), s * cap * 2 * maxl * N * 8), "zero")
+    n_ct = C.c_size_t()
+    ctx.check(lib.sfg_assoc_stream_pgen(ctx.h, ppath.encode(), rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch, dA.p, s, level, maxl, 0,
+                                        dout.p, cap, C.byref(n_ct), None, None), "assoc_stream_pgen")
+    want_pgen = dout.host().copy()
+    dout.free(); dA.free(); ctx.close()
+    kept = int(rowf.sum())
+    for n in (2, 3):
+        mg = make_engine(monkeypatch, [0] * n)
+        try:
+            for flags in (0, SQ):
+                out = np.zeros((s, cap, 2, maxl, N), dtype=np.uint64)
+                sums = np.full(cap * slots, -7.0); sq = np.full(cap * slots, -7.0); n_ct = C.c_size_t()
+                mg.check(lib.sfg_mgpu_assoc_stream_bed(mg.h, path.encode(), ns, nv, rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), batch,
+                                                       capi.p64(A), s, level, maxl, flags, capi.p64(out), cap, C.byref(n_ct),
+                                                       sums.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p)), "mgpu_assoc_stream_bed")
+                assert n_ct.value == 7
+                assert np.array_equal(out, want[flags][0]), (n, flags)
+                assert np.array_equal(sums, want[flags][1]) and np.array_equal(sq, want[flags][2]), (n, flags)
+            out = np.zeros((s, cap, 2, maxl, N), dtype=np.uint64)
+            mg.check(lib.sfg_mgpu_assoc_stream_pgen(mg.h, ppath.encode(), rowf.ctypes.data_as(C.c_void_p), colf.ctypes.data_as(C.c_void_p), kept, batch,
+                                                    capi.p64(A), s, level, maxl, 0, capi.p64(out), cap, C.byref(n_ct), None, None), "mgpu_assoc_stream_pgen")
+            assert np.array_equal(out, want_pgen), n
+        finally:
+            mg.close()
