@@ -4,15 +4,13 @@
 // SURVEY.md §8).  The untagged originals move behind `//go:build !hip`.  Each function keeps the reference's signature and
 // scale / level bookkeeping; only the ring arithmetic runs on the device.  NOT COMPILED in the sfgwas-hip repository.
 //
-// These bodies round-trip through host memory per call, which is the minimal drop-in.  The resident form (ciphertexts stay
-// on the device between CMult -> product -> InnerProd -> Sub) is what sfgwas_amd/host/gwas.hpp implements in C++ and what a
-// maintainer would grow this file into (INTEGRATION.md §4b').
+// These bodies round-trip through host memory per call, which is the minimal drop-in.  The resident form (ciphertexts stay on the device between
+// CMult -> product -> InnerProd) is hip.DevVec + gwas/matmult_hip.go's QXLazyNormStream; the C++ mirror sfgwas_amd/host/gwas.hpp carries it through Sub / MaskTrunc too.
 package crypto
 
 import (
 	"github.com/hhcho/sfgwas/hip"
 	"github.com/ldsec/lattigo/v2/ckks"
-	"go.dedis.ch/onet/v3/log"
 )
 
 func minLevel(v CipherVector) int {
@@ -56,23 +54,100 @@ func RotateRight(cryptoParams *CryptoParams, ct *ckks.Ciphertext, nrot int) *ckk
 	return h.CtFromFlat(out, level, ct.Scale())
 }
 
-// CMult - crypto/basics.go:386-427: element-wise MulRelinNew + Rescale(Params.Scale()) with length-1 broadcasting.
+// pick returns v[i] with length-1 broadcasting (crypto/basics.go:386-427 treats a one-element operand as a scalar).
+func pick(v CipherVector, i int) *ckks.Ciphertext {
+	if len(v) == 1 {
+		return v[0]
+	}
+	return v[i]
+}
+
+// opGroup: the entries of an element-wise vector op that share operand level and scales - ONE batched device call each.  The reference loops
+// eval.MulRelinNew / Rescale / AddNew per ciphertext (crypto/basics.go:386-470, 568-590): every result keeps its OWN level (min of its two operands) and scale;
+// dropping a whole vector to its minimum level would change the words of the higher entries (qrfact.go's Householder vectors carry their pivot ciphertext one
+// level below the others).
+type opGroup struct {
+	level  int
+	sx, sy float64
+}
+
+func groupPairs(n int, lx, ly func(int) int, sx, sy func(int) float64) ([]opGroup, map[opGroup][]int) {
+	idx := map[opGroup][]int{}
+	var order []opGroup
+	for i := 0; i < n; i++ {
+		l := lx(i)
+		if ly(i) < l {
+			l = ly(i)
+		}
+		k := opGroup{l, sx(i), sy(i)}
+		if _, ok := idx[k]; !ok {
+			order = append(order, k)
+		}
+		idx[k] = append(idx[k], i)
+	}
+	return order, idx
+}
+
+func flattenPicked(h *hip.Ctx, v CipherVector, ids []int, level int) []uint64 {
+	w := h.CtWords(level)
+	flat := make([]uint64, len(ids)*w)
+	for j, i := range ids {
+		h.FlattenCt(pick(v, i), level, flat[j*w:(j+1)*w])
+	}
+	return flat
+}
+
+// CMult - crypto/basics.go:386-427: element-wise MulRelinNew + Rescale(Params.Scale()) with length-1 broadcasting, per ciphertext level and scale.
 func CMult(cryptoParams *CryptoParams, X CipherVector, Y CipherVector) CipherVector {
 	h := hip.Default
 	n := Max(len(X), len(Y))
-	level := minLevel(X)
-	if l := minLevel(Y); l < level {
-		level = l
+	res := make(CipherVector, n)
+	order, idx := groupPairs(n, func(i int) int { return pick(X, i).Level() }, func(i int) int { return pick(Y, i).Level() },
+		func(i int) float64 { return pick(X, i).Scale() }, func(i int) float64 { return pick(Y, i).Scale() })
+	for _, k := range order {
+		ids := idx[k]
+		prod := h.Binary("mulrelin", flattenPicked(h, X, ids, k.level), flattenPicked(h, Y, ids, k.level), len(ids), k.level)
+		prod, level, scale := rescaleLoop(h, prod, len(ids), k.level, k.sx*k.sy, cryptoParams.Params.Scale())
+		for j, ct := range h.VecFromFlat(prod, len(ids), level, scale) {
+			res[ids[j]] = ct
+		}
 	}
-	fx, fy := h.FlattenVec(X, n, level), h.FlattenVec(Y, n, level)
-	prod := h.Binary("mulrelin", fx, fy, n, level)
-	scale := X[0].Scale() * Y[0].Scale()
-	prod, level, scale = rescaleLoop(h, prod, n, level, scale, cryptoParams.Params.Scale())
-	return CipherVector(h.VecFromFlat(prod, n, level, scale))
+	return res
 }
 
-// CAdd / CSub - crypto/basics.go:568-590 (equal scales and levels, as at every call site on the hot path; lattigo's scale
-// matching for unequal scales is implemented in gwas.hpp's CAddSubDev and is PARITY UNPINNED - keep the CPU path for those).
+// CPMult - crypto/basics.go:429-470: the same with NTT-domain plaintexts (eval.MulRelinNew(ct, plaintext) multiplies both polynomials by the plaintext).
+func CPMult(cryptoParams *CryptoParams, X CipherVector, Y PlainVector) CipherVector {
+	h := hip.Default
+	n := Max(len(X), len(Y))
+	res := make(CipherVector, n)
+	py := func(i int) *ckks.Plaintext {
+		if len(Y) == 1 {
+			return Y[0]
+		}
+		return Y[i]
+	}
+	order, idx := groupPairs(n, func(i int) int { return pick(X, i).Level() }, func(i int) int { return py(i).Level() },
+		func(i int) float64 { return pick(X, i).Scale() }, func(i int) float64 { return py(i).Scale() })
+	for _, k := range order {
+		ids := idx[k]
+		nl := k.level + 1
+		pts := make([]uint64, len(ids)*nl*h.N)
+		for j, i := range ids {
+			for l := 0; l < nl; l++ {
+				copy(pts[(j*nl+l)*h.N:], py(i).Value()[0].Coeffs[l][:h.N])
+			}
+		}
+		prod := h.MulPlain(flattenPicked(h, X, ids, k.level), pts, len(ids), len(ids), k.level)
+		prod, level, scale := rescaleLoop(h, prod, len(ids), k.level, k.sx*k.sy, cryptoParams.Params.Scale())
+		for j, ct := range h.VecFromFlat(prod, len(ids), level, scale) {
+			res[ids[j]] = ct
+		}
+	}
+	return res
+}
+
+// CAdd / CSub - crypto/basics.go:568-590: eval.AddNew / SubNew per ciphertext - result level = min of the pair.  Pairs at EQUAL scales only (every call site on
+// the PCA path); lattigo's scale matching for unequal scales is restated in gwas.hpp's CellVec ops and is PARITY UNPINNED - such pairs stay on the CPU evaluator.
 func CAdd(cryptoParams *CryptoParams, X CipherVector, Y CipherVector) CipherVector {
 	return addSub(cryptoParams, X, Y, "add")
 }
@@ -82,17 +157,30 @@ func CSub(cryptoParams *CryptoParams, X CipherVector, Y CipherVector) CipherVect
 func addSub(cryptoParams *CryptoParams, X, Y CipherVector, op string) CipherVector {
 	h := hip.Default
 	n := len(X)
-	for i := range X {
-		if X[i].Scale() != Y[i].Scale() {
-			log.Fatal("sfgwas-hip: CAdd/CSub with unequal scales: use the CPU build for this call site")
+	res := make(CipherVector, n)
+	order, idx := groupPairs(n, func(i int) int { return X[i].Level() }, func(i int) int { return Y[i].Level() },
+		func(i int) float64 { return X[i].Scale() }, func(i int) float64 { return Y[i].Scale() })
+	for _, k := range order {
+		ids := idx[k]
+		if k.sx != k.sy { // lattigo rescales one operand by the integer scale ratio first: left to lattigo itself
+			cryptoParams.WithEvaluator(func(eval ckks.Evaluator) error {
+				for _, i := range ids {
+					if op == "add" {
+						res[i] = eval.AddNew(X[i], Y[i])
+					} else {
+						res[i] = eval.SubNew(X[i], Y[i])
+					}
+				}
+				return nil
+			})
+			continue
+		}
+		out := h.Binary(op, flattenPicked(h, X, ids, k.level), flattenPicked(h, Y, ids, k.level), len(ids), k.level)
+		for j, ct := range h.VecFromFlat(out, len(ids), k.level, k.sx) {
+			res[ids[j]] = ct
 		}
 	}
-	level := minLevel(X)
-	if l := minLevel(Y); l < level {
-		level = l
-	}
-	out := h.Binary(op, h.FlattenVec(X, n, level), h.FlattenVec(Y, n, level), n, level)
-	return CipherVector(h.VecFromFlat(out, n, level, X[0].Scale()))
+	return res
 }
 
 // InnerSumAll - crypto/basics.go:278-292: sum of the vector's ciphertexts, then 13 rotate-by-2^k-and-add steps.

@@ -9,6 +9,7 @@ package gwas
 import (
 	"github.com/hhcho/sfgwas/crypto"
 	"github.com/hhcho/sfgwas/hip"
+	"github.com/hhcho/sfgwas/mpc"
 	"github.com/ldsec/lattigo/v2/ckks"
 )
 
@@ -96,4 +97,71 @@ func MatMult4StreamCompute(cps *crypto.CryptoParams, A crypto.CipherMatrix, maxL
 	flat := h.MatmulFromCache(aFlat, s, inLevel, maxLevel, cacheFilePrefix, nbr)
 	mct := len(flat) / (s * 2 * maxLevel * cps.Params.N())
 	return finish(cps, h, flat, s, mct, maxLevel, outScale)
+}
+
+// QXLazyNormStream - gwas/matmult.go:27-77 (move the original behind `//go:build !hip` with the three products): Q * S * (X - m 1^T) as (Q S) X - ((Q S) m) 1^T.
+// Q S is made ON the device (crypto.CMult, basics.go:386-427) and stays there for its two consumers - the product and the inner products with XMean - instead of
+// being downloaded by CMult, uploaded by MatMult4StreamCompute and uploaded again by every InnerProd.  The network step (BootstrapMatAll) and the final Sub /
+// MaskTrunc (lattigo's own scale matching) are the reference's lines, unchanged.
+func QXLazyNormStream(cps *crypto.CryptoParams, mpcObj *mpc.MPC, Q crypto.CipherMatrix, Xcachefile string, XMean, XStdInv crypto.CipherVector, numInd int) (out crypto.CipherMatrix) {
+	if mpcObj.GetPid() == 0 {
+		return
+	}
+	h := hip.Default
+	slots := cps.GetSlots()
+	g := hip.LookupGeno(Xcachefile)
+	if g == nil { // DiagCache files of a CPU run: the host-pointer path
+		QS := make(crypto.CipherMatrix, len(Q))
+		for i := range Q {
+			QS[i] = crypto.CMult(cps, Q[i], XStdInv)
+		}
+		return qxLazyNormTail(cps, mpcObj, MatMult4StreamCompute(cps, QS, 5, Xcachefile), func(i int) *ckks.Ciphertext { return crypto.InnerProd(cps, QS[i], XMean) }, slots, numInd)
+	}
+	dS, dM := h.UploadVec([]*ckks.Ciphertext(XStdInv)), h.UploadVec([]*ckks.Ciphertext(XMean))
+	defer dS.Free()
+	defer dM.Free()
+	QS := make([]*hip.DevVec, len(Q))
+	for i := range Q { // QS[i] = crypto.CMult(cps, Q[i], XStdInv)
+		dq := h.UploadVec([]*ckks.Ciphertext(Q[i]))
+		QS[i] = h.CMultDev(dq, dS, cps.Params.Scale())
+		dq.Free()
+	}
+	defer func() {
+		for _, v := range QS {
+			v.Free()
+		}
+	}()
+	flat := h.MatmulResidentRows(QS, 5, g) // out = MatMult4StreamCompute(cps, QS, 5, Xcachefile)
+	mct := (g.NCol-1)/slots + 1
+	prod := finish(cps, h, flat, len(Q), mct, 5, QS[0].Scale*cps.Params.Scale())
+	return qxLazyNormTail(cps, mpcObj, prod, func(i int) *ckks.Ciphertext { // crypto.InnerProd(cps, QS[i], XMean) = InnerSumAll(CMult(QS[i], XMean)), basics.go:274-292
+		p := h.CMultDev(QS[i], dM, cps.Params.Scale())
+		t := h.InnerSumAllDev(p)
+		ct := h.DownloadVec(t)[0]
+		p.Free()
+		t.Free()
+		return ct
+	}, slots, numInd)
+}
+
+// qxLazyNormTail: gwas/matmult.go:44-72 as written there - bootstrap, (Q S) m per row, Sub, MaskTrunc of the ragged tail.
+func qxLazyNormTail(cps *crypto.CryptoParams, mpcObj *mpc.MPC, out crypto.CipherMatrix, innerProd func(int) *ckks.Ciphertext, slots, numInd int) crypto.CipherMatrix {
+	out = mpcObj.Network.BootstrapMatAll(cps, out)
+	for i := range out {
+		QSm := innerProd(i)
+		cps.WithEvaluator(func(eval ckks.Evaluator) error {
+			for j := range out[i] {
+				eval.Sub(out[i][j], QSm, out[i][j])
+			}
+			return nil
+		})
+		for j := range out[i] {
+			N := slots
+			if j == len(out[i])-1 {
+				N = ((numInd - 1) % slots) + 1
+			}
+			out[i][j] = crypto.MaskTrunc(cps, out[i][j], N)
+		}
+	}
+	return out
 }

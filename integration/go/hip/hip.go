@@ -35,6 +35,7 @@ import (
 // The reference runs MatMult4Stream from several goroutines at once (gwas/assoc.go:360-408): each takes its own Fork().
 type Ctx struct {
 	p      *C.sfg_ctx
+	mg     *C.sfg_mgpu // non-nil when Init was given several devices: the products and the association scan run on all of them (include/sfgwas_hip.h, "SURVEY 8e")
 	Params *ckks.Parameters
 	N      int // ring degree
 	NQ, NP int // moduli of Q and of P
@@ -51,9 +52,15 @@ func (h *Ctx) check(rc C.int, what string) {
 	}
 }
 
-// Init creates the device context from the CKKS parameters and uploads every switching key the party holds.
+// Init creates the device context(s) from the CKKS parameters and uploads every switching key the party holds.
 //   rotKs: cryptoParams.RotKs (crypto/crypto.go:50, filled at :208), rlk: cryptoParams.Rlk (:49).
-func Init(params *ckks.Parameters, rotKs *ckks.RotationKeySet, rlk *ckks.RelinearizationKey, device int) *Ctx {
+//   devices: the HIP devices of this party's node.  One device: a plain context.  Several: the multi-GPU engine (sfg_mgpu_create: one context per device,
+//   RCCL inside the library) - the genotype matrix registered by MatMult4StreamPreprocess is sharded by SNP block over them, MatMult4StreamCompute and the
+//   association scan run on all of them, and everything else (evaluator ops, per-call MatMult4Stream forks) runs on devices[0]'s context.
+func Init(params *ckks.Parameters, rotKs *ckks.RotationKeySet, rlk *ckks.RelinearizationKey, devices []int) *Ctx {
+	if len(devices) == 0 {
+		devices = []int{0}
+	}
 	qi, pi := params.Qi(), params.Pi()
 	moduli := append(append([]uint64{}, qi...), pi...)
 	ringQP, err := ring.NewRing(params.N(), moduli)
@@ -66,24 +73,54 @@ func Init(params *ckks.Parameters, rotKs *ckks.RotationKeySet, rlk *ckks.Relinea
 	for i := range moduli {
 		psi[i] = ring.InvMForm(ringQP.PsiMont[i], moduli[i], ringQP.MredParams[i])
 	}
-	var c *C.sfg_ctx
-	if C.sfg_ctx_create(&c, C.int(device), C.int(params.LogN()), C.int(len(qi)), C.int(len(pi)),
-		(*C.uint64_t)(unsafe.Pointer(&moduli[0])), (*C.uint64_t)(unsafe.Pointer(&psi[0])), C.double(params.Scale())) != 0 {
-		panic("sfgwas-hip: sfg_ctx_create: " + C.GoString(C.sfg_last_error(nil)))
+	h := &Ctx{Params: params, N: params.N(), NQ: len(qi), NP: len(pi)}
+	if len(devices) == 1 {
+		var c *C.sfg_ctx
+		if C.sfg_ctx_create(&c, C.int(devices[0]), C.int(params.LogN()), C.int(len(qi)), C.int(len(pi)),
+			(*C.uint64_t)(unsafe.Pointer(&moduli[0])), (*C.uint64_t)(unsafe.Pointer(&psi[0])), C.double(params.Scale())) != 0 {
+			panic("sfgwas-hip: sfg_ctx_create: " + C.GoString(C.sfg_last_error(nil)))
+		}
+		h.p = c
+	} else {
+		devs := make([]C.int, len(devices))
+		for i, d := range devices {
+			devs[i] = C.int(d)
+		}
+		var m *C.sfg_mgpu
+		if C.sfg_mgpu_create(&m, &devs[0], C.int(len(devs)), C.int(params.LogN()), C.int(len(qi)), C.int(len(pi)),
+			(*C.uint64_t)(unsafe.Pointer(&moduli[0])), (*C.uint64_t)(unsafe.Pointer(&psi[0])), C.double(params.Scale())) != 0 {
+			panic("sfgwas-hip: sfg_mgpu_create: " + C.GoString(C.sfg_mgpu_last_error(nil)))
+		}
+		h.mg = m
+		h.p = C.sfg_mgpu_ctx(m, 0)
 	}
-	h := &Ctx{p: c, Params: params, N: params.N(), NQ: len(qi), NP: len(pi)}
 	if rotKs != nil {
 		for galEl, swk := range rotKs.Keys {
 			flat := FlattenSwitchingKey(swk, h.NQ+h.NP, h.N)
-			h.check(C.sfg_ctx_load_rotkey(c, C.uint64_t(galEl), (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "load_rotkey")
+			if h.mg != nil {
+				h.mcheck(C.sfg_mgpu_load_rotkey(h.mg, C.uint64_t(galEl), (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "mgpu_load_rotkey")
+			} else {
+				h.check(C.sfg_ctx_load_rotkey(h.p, C.uint64_t(galEl), (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "load_rotkey")
+			}
 		}
 	}
 	if rlk != nil && len(rlk.Keys) > 0 {
 		flat := FlattenSwitchingKey(rlk.Keys[0], h.NQ+h.NP, h.N)
-		h.check(C.sfg_ctx_load_relinkey(c, (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "load_relinkey")
+		if h.mg != nil {
+			h.mcheck(C.sfg_mgpu_load_relinkey(h.mg, (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "mgpu_load_relinkey")
+		} else {
+			h.check(C.sfg_ctx_load_relinkey(h.p, (*C.uint64_t)(unsafe.Pointer(&flat[0])), 1), "load_relinkey")
+		}
 	}
 	Default = h
 	return h
+}
+
+// mcheck is check for the multi-GPU engine's calls (the failing rank is named in the message).
+func (h *Ctx) mcheck(rc C.int, what string) {
+	if rc != 0 {
+		panic(fmt.Sprintf("sfgwas-hip: %s: %s", what, C.GoString(C.sfg_mgpu_last_error(h.mg))))
+	}
 }
 
 // Fork returns a handle for another goroutine: same keys and tables, own queues (sfg_ctx_fork).
@@ -92,11 +129,20 @@ func (h *Ctx) Fork() *Ctx {
 	h.check(C.sfg_ctx_fork(h.p, &c), "fork")
 	f := *h
 	f.p = c
+	f.mg = nil // a fork is one caller on devices[0]; the multi-GPU calls belong to the root handle
 	return &f
 }
 
-// Close destroys the handle (a fork: its queues and scratch; the root: everything).
-func (h *Ctx) Close() { C.sfg_ctx_destroy(h.p); h.p = nil }
+// Close destroys the handle (a fork: its queues and scratch; the root: everything, on every device).
+func (h *Ctx) Close() {
+	if h.mg != nil {
+		C.sfg_mgpu_destroy(h.mg) // owns the per-device contexts, h.p among them
+		h.mg, h.p = nil, nil
+		return
+	}
+	C.sfg_ctx_destroy(h.p)
+	h.p = nil
+}
 
 // Raw exposes the C handle to the sibling files of this binding.
 func (h *Ctx) Raw() unsafe.Pointer { return unsafe.Pointer(h.p) }
@@ -237,7 +283,8 @@ func (b *DevBuf) Download() []uint64 {
 // for X^T: ONE resident int8 copy serves both, the second prefix is registered with SFG_TRANSPOSE).
 
 type Geno struct {
-	g     *C.sfg_geno
+	g     *C.sfg_geno  // single device
+	mg    *C.sfg_mgeno // multi-GPU engine: the matrix sharded by SNP block (exactly one of g / mg is set)
 	Flags uint
 	NRow  int
 	NCol  int
@@ -246,6 +293,7 @@ type Geno struct {
 // residentGeno is one uploaded matrix: its handle, stored shape and an order-independent content fingerprint.
 type residentGeno struct {
 	g          *C.sfg_geno
+	mg         *C.sfg_mgeno
 	nrow, ncol int
 	print      uint64
 }
@@ -324,15 +372,22 @@ func (h *Ctx) RegisterGeno(prefix string, rows []int8, nrow, ncol int) *Geno {
 			asTranspose, haveT = genoFingerprint(rows, nrow, ncol, true), true
 		}
 		if r.print == asTranspose {
-			e := &Geno{r.g, FlagTranspose, nrow, ncol}
+			e := &Geno{r.g, r.mg, FlagTranspose, nrow, ncol}
 			genoByKey[prefix] = e
 			return e
 		}
 	}
 	var g *C.sfg_geno
-	h.check(C.sfg_geno_upload(h.p, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &g), "geno_upload")
-	resident = append(resident, residentGeno{g, nrow, ncol, genoFingerprint(rows, nrow, ncol, false)})
-	e := &Geno{g, 0, nrow, ncol}
+	var m *C.sfg_mgeno
+	if h.mg != nil {
+		// the STORED orientation is the one whose columns are sharded over the GPUs: pca.go:112-113 registers X (individuals x SNPs) first, so SNP blocks
+		// are the shards, Q * X is output-sharded and Q' * X^T contraction-sharded, as SURVEY 8e lays out
+		h.mcheck(C.sfg_mgpu_geno_upload(h.mg, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &m), "mgpu_geno_upload")
+	} else {
+		h.check(C.sfg_geno_upload(h.p, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &g), "geno_upload")
+	}
+	resident = append(resident, residentGeno{g, m, nrow, ncol, genoFingerprint(rows, nrow, ncol, false)})
+	e := &Geno{g, m, 0, nrow, ncol}
 	genoByKey[prefix] = e
 	return e
 }
@@ -368,6 +423,13 @@ func (h *Ctx) MatmulStream(aFlat []uint64, s, inLevel, maxLevel int, geno []int8
 // MatmulResident = MatMult4StreamCompute on a resident matrix; returns [s][m_ct][2][maxLevel][N] words.
 func (h *Ctx) MatmulResident(aFlat []uint64, s, inLevel, maxLevel int, g *Geno) []uint64 {
 	lcol := g.NCol
+	if g.mg != nil { // every GPU of the node: sfg_mgpu_matmul shards, exchanges (Q' * X^T) and gathers
+		mctM := (lcol-1)/(h.N/2) + 1
+		out := make([]uint64, s*mctM*2*maxLevel*h.N)
+		Default.mcheck(C.sfg_mgpu_matmul(Default.mg, (*C.uint64_t)(unsafe.Pointer(&aFlat[0])), C.int(s), C.int(inLevel), C.int(maxLevel), g.mg, C.uint(g.Flags),
+			(*C.uint64_t)(unsafe.Pointer(&out[0]))), "mgpu_matmul")
+		return out
+	}
 	dA := h.Upload(aFlat)
 	defer dA.Free()
 	mct := (lcol-1)/(h.N/2) + 1
@@ -385,10 +447,6 @@ func (h *Ctx) MatmulResident(aFlat []uint64, s, inLevel, maxLevel int, g *Geno) 
 func (h *Ctx) AssocStreamPgen(pgenPath string, sampleKeep, snpFilt []byte, batchSnps int, aFlat []uint64, s, inLevel, maxLevel int, square bool, capacity int) ([]uint64, int) {
 	cp := C.CString(pgenPath)
 	defer C.free(unsafe.Pointer(cp))
-	dA := h.Upload(aFlat)
-	defer dA.Free()
-	dOut := h.Alloc(8 * s * capacity * 2 * maxLevel * h.N)
-	defer dOut.Free()
 	flags := C.uint(0)
 	if square {
 		flags |= C.SFG_SQUARE
@@ -401,15 +459,29 @@ func (h *Ctx) AssocStreamPgen(pgenPath string, sampleKeep, snpFilt []byte, batch
 		pc = (*C.uint8_t)(unsafe.Pointer(&snpFilt[0]))
 	}
 	var nct C.size_t
+	ctw := 2 * maxLevel * h.N
+	compact := func(all []uint64) []uint64 { // [s][capacity][ctw] -> [s][nct][ctw]
+		out := make([]uint64, s*int(nct)*ctw)
+		for i := 0; i < s; i++ {
+			copy(out[i*int(nct)*ctw:(i+1)*int(nct)*ctw], all[i*capacity*ctw:(i*capacity+int(nct))*ctw])
+		}
+		return out
+	}
+	if h.mg != nil { // batch k on GPU k % G (assoc.go:360-408 hands the batches to assoc_num_blocks_parallel workers the same way)
+		nbr := len(aFlat) / (s * 2 * (inLevel + 1) * h.N)
+		kept := nbr * (h.N / 2) // A's grid covers the kept samples; the library takes ceil(kept / slots) block rows from this
+		all := make([]uint64, s*capacity*ctw)
+		h.mcheck(C.sfg_mgpu_assoc_stream_pgen(h.mg, cp, pr, pc, C.size_t(kept), C.size_t(batchSnps), (*C.uint64_t)(unsafe.Pointer(&aFlat[0])), C.int(s), C.int(inLevel),
+			C.int(maxLevel), flags, (*C.uint64_t)(unsafe.Pointer(&all[0])), C.size_t(capacity), &nct, nil, nil), "mgpu_assoc_stream_pgen")
+		return compact(all), int(nct)
+	}
+	dA := h.Upload(aFlat)
+	defer dA.Free()
+	dOut := h.Alloc(8 * s * capacity * 2 * maxLevel * h.N)
+	defer dOut.Free()
 	h.check(C.sfg_assoc_stream_pgen(h.p, cp, pr, pc, C.size_t(batchSnps), dA.U64(), C.int(s), C.int(inLevel), C.int(maxLevel), flags,
 		dOut.U64(), C.size_t(capacity), &nct, nil, nil), "assoc_stream_pgen") // computeSquaredSum = false on this branch (assoc.go:395)
-	all := dOut.Download() // [s][capacity][2][maxLevel][N]: keep the first nct ciphertexts of every row
-	ctw := 2 * maxLevel * h.N
-	out := make([]uint64, s*int(nct)*ctw)
-	for i := 0; i < s; i++ {
-		copy(out[i*int(nct)*ctw:(i+1)*int(nct)*ctw], all[i*capacity*ctw:(i*capacity+int(nct))*ctw])
-	}
-	return out, int(nct)
+	return compact(dOut.Download()), int(nct) // [s][capacity][2][maxLevel][N]: the first nct ciphertexts of every row
 }
 
 // MatmulFromCache = MatMult4StreamCompute on DiagCache files a CPU party wrote (gwas/filestream.go:19-282).
@@ -478,6 +550,153 @@ func (h *Ctx) InnerSumAll(in []uint64, nct, level int) []uint64 {
 	dOut := h.Alloc(8 * h.CtWords(level))
 	defer dOut.Free()
 	h.check(C.sfg_ct_innersum_dev(h.p, dIn.U64(), C.int(nct), C.int(level), dOut.U64()), "innersum")
+	return dOut.Download()
+}
+
+// MulPlain: ciphertext j times NTT-domain plaintext j (eval.MulRelinNew(plaintext, ct) behind crypto.CPMult / Mask, crypto/basics.go:110-172,429-470); one plaintext
+// for all when npt == 1.  Level unchanged, the caller multiplies the scales.
+func (h *Ctx) MulPlain(cts, pts []uint64, nct, npt, level int) []uint64 {
+	dC, dP := h.Upload(cts), h.Upload(pts)
+	defer dC.Free()
+	defer dP.Free()
+	dOut := h.Alloc(8 * nct * h.CtWords(level))
+	defer dOut.Free()
+	stride := 0
+	if npt > 1 {
+		stride = (level + 1) * h.N
+	}
+	h.check(C.sfg_ct_mul_plain_dev(h.p, dC.U64(), dP.U64(), C.size_t(stride), dOut.U64(), C.int(nct), C.int(level)), "mul_plain")
+	return dOut.Download()
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Resident ciphertext vectors: the operands of CMult -> MatMult4StreamCompute -> InnerProd (gwas/matmult.go:27-77) stay in HBM between the calls instead of
+// crossing PCIe four times.  A DevVec holds Len ciphertexts of ONE level and scale, [Len][2][Level+1][N].
+
+type DevVec struct {
+	Buf   *DevBuf
+	Len   int
+	Level int
+	Scale float64
+}
+
+func (d *DevVec) Free() { d.Buf.Free() }
+
+// UploadVec: the vector's ciphertexts at their common (minimum) level; their scales must agree (they do for every CipherVector the hot path builds:
+// fresh encryptions and bootstrap outputs).
+func (h *Ctx) UploadVec(v []*ckks.Ciphertext) *DevVec {
+	level, scale := v[0].Level(), v[0].Scale()
+	for _, c := range v {
+		if c.Level() < level {
+			level = c.Level()
+		}
+		if c.Scale() != scale {
+			panic("sfgwas-hip: UploadVec: ciphertexts of one vector at different scales")
+		}
+	}
+	return &DevVec{h.Upload(h.FlattenVec(v, len(v), level)), len(v), level, scale}
+}
+
+// DownloadVec: fresh ckks.Ciphertexts.
+func (h *Ctx) DownloadVec(d *DevVec) []*ckks.Ciphertext {
+	return h.VecFromFlat(d.Buf.Download(), d.Len, d.Level, d.Scale)
+}
+
+// dropTo returns a view of d at `level` (a new buffer when rows have to go: DropLevel keeps the first level + 1 rows of either polynomial).
+func (h *Ctx) dropTo(d *DevVec, level int) (*DevVec, bool) {
+	if d.Level == level {
+		return d, false
+	}
+	out := h.Alloc(8 * d.Len * h.CtWords(level))
+	h.check(C.sfg_ct_drop_level_dev(h.p, d.Buf.U64(), out.U64(), C.int(d.Len), C.int(d.Level), C.int(level)), "drop_level")
+	return &DevVec{out, d.Len, level, d.Scale}, true
+}
+
+// CMultDev = crypto.CMult (crypto/basics.go:386-427) on resident operands: MulRelinNew + Rescale(minScale) per ciphertext, b broadcast when b.Len == 1.
+// Every entry of a DevVec shares level and scale, so the whole vector is one (level, scale) group.
+func (h *Ctx) CMultDev(a, b *DevVec, minScale float64) *DevVec {
+	level := a.Level
+	if b.Level < level {
+		level = b.Level
+	}
+	n := a.Len
+	if b.Len > n {
+		n = b.Len
+	}
+	x, fx := h.dropTo(a, level)
+	y, fy := h.dropTo(b, level)
+	w := h.CtWords(level)
+	rep := func(v *DevVec) *DevBuf { // length-1 broadcasting: n copies on the device
+		if v.Len == n {
+			return v.Buf
+		}
+		r := h.Alloc(8 * n * w)
+		for i := 0; i < n; i++ {
+			h.check(C.sfg_memcpy_d2d(h.p, unsafe.Pointer(uintptr(r.p)+uintptr(8*i*w)), v.Buf.p, C.size_t(8*w)), "d2d")
+		}
+		return r
+	}
+	bx, by := rep(x), rep(y)
+	out := h.Alloc(8 * n * w)
+	h.check(C.sfg_ct_mulrelin_dev(h.p, bx.U64(), by.U64(), out.U64(), C.int(n), C.int(level)), "mulrelin")
+	if bx != x.Buf {
+		bx.Free()
+	}
+	if by != y.Buf {
+		by.Free()
+	}
+	if fx {
+		x.Free()
+	}
+	if fy {
+		y.Free()
+	}
+	scale := a.Scale * b.Scale
+	qi := h.Params.Qi()
+	for level > 0 && scale/float64(qi[level]) >= minScale/2 { // ckks.Evaluator.Rescale's loop (threshold scale)
+		nxt := h.Alloc(8 * n * h.CtWords(level-1))
+		h.check(C.sfg_ct_rescale_dev(h.p, out.U64(), nxt.U64(), C.int(n), C.int(level)), "rescale")
+		out.Free()
+		out = nxt
+		scale /= float64(qi[level])
+		level--
+	}
+	return &DevVec{out, n, level, scale}
+}
+
+// InnerSumAllDev = crypto.InnerSumAll (crypto/basics.go:278-292) on a resident vector: one ciphertext, the total in every slot.
+func (h *Ctx) InnerSumAllDev(a *DevVec) *DevVec {
+	out := h.Alloc(8 * h.CtWords(a.Level))
+	h.check(C.sfg_ct_innersum_dev(h.p, a.Buf.U64(), C.int(a.Len), C.int(a.Level), out.U64()), "innersum")
+	return &DevVec{out, 1, a.Level, a.Scale}
+}
+
+// MatmulResidentRows = MatMult4StreamCompute with the rows of A resident (each a DevVec of nbr ciphertexts at one common level): on a single device the input grid is
+// assembled by device copies; with the multi-GPU engine the rows are downloaded once and the engine shards them.  Returns [s][m_ct][2][maxLevel][N] words.
+func (h *Ctx) MatmulResidentRows(rows []*DevVec, maxLevel int, g *Geno) []uint64 {
+	s, nbr, level := len(rows), rows[0].Len, rows[0].Level
+	for _, r := range rows {
+		if r.Len != nbr || r.Level != level {
+			panic("sfgwas-hip: MatmulResidentRows: rows of different shape")
+		}
+	}
+	w := h.CtWords(level)
+	if g.mg != nil {
+		flat := make([]uint64, s*nbr*w)
+		for i, r := range rows {
+			copy(flat[i*nbr*w:], r.Buf.Download())
+		}
+		return h.MatmulResident(flat, s, level, maxLevel, g)
+	}
+	grid := h.Alloc(8 * s * nbr * w)
+	defer grid.Free()
+	for i, r := range rows {
+		h.check(C.sfg_memcpy_d2d(h.p, unsafe.Pointer(uintptr(grid.p)+uintptr(8*i*nbr*w)), r.Buf.p, C.size_t(8*nbr*w)), "d2d")
+	}
+	mct := (g.NCol-1)/(h.N/2) + 1
+	dOut := h.Alloc(8 * s * mct * 2 * maxLevel * h.N)
+	defer dOut.Free()
+	h.check(C.sfg_matmul_resident_dev(h.p, grid.U64(), C.int(s), C.int(level), C.int(maxLevel), g.g, C.uint(g.Flags), dOut.U64()), "matmul_resident")
 	return dOut.Download()
 }
 

@@ -86,3 +86,76 @@ def test_go_shim_calls_only_declared_entry_points_with_the_declared_number_of_ar
             for c in re.findall(r"\bC\.(SFG_[A-Z0-9_]+)\b", code):
                 assert c in consts, f"{f}: C.{c} is not a constant of the header"
     assert calls >= 20
+
+
+def test_go_shim_files_call_only_methods_the_hip_package_defines_with_matching_arity():
+    """the four shim files (gwas/, crypto/, mpc/) reach the library through package hip: every `hip.X(...)` function and every `h.X(...)` / `hip.Default.X(...)`
+    method they call must be defined in integration/go/hip/hip.go with that many parameters (no Go toolchain here to tell us otherwise)"""
+    src = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "integration", "go", "hip", "hip.go")).read())
+
+    def count_params(sig):
+        sig = sig.strip()
+        if not sig:
+            return 0
+        n, depth, groups = 0, 0, []
+        cur = ""
+        for c in sig:
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+            if c == "," and depth == 0:
+                groups.append(cur); cur = ""
+            else:
+                cur += c
+        groups.append(cur)
+        # Go lets names share a type ("s, inLevel, maxLevel int"): every comma-separated item is one parameter either way
+        return len(groups)
+
+    funcs, methods = {}, {}
+    for m in re.finditer(r"^func\s+(\(\s*\w+\s+\*?(\w+)\s*\)\s*)?(\w+)\s*\(", src, flags=re.M):
+        start = m.end()
+        depth, i = 1, start
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        n = count_params(src[start:i - 1])
+        (methods if m.group(1) else funcs)[m.group(3)] = n
+    assert "Init" in funcs and funcs["Init"] == 4 and "MatmulResident" in methods and "CMultDev" in methods
+
+    def call_args(txt, start):
+        depth, n, i, seen = 0, 0, start, False
+        while i < len(txt):
+            c = txt[i]
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+                if depth == 0:
+                    return n + (1 if seen else 0)
+            elif c == "," and depth == 1:
+                n += 1
+            elif depth >= 1 and not c.isspace():
+                seen = True
+            i += 1
+        raise AssertionError("unbalanced call")
+
+    checked = 0
+    for sub in ("gwas", "crypto", "mpc"):
+        d = os.path.join(ROOT, "integration", "go", sub)
+        for f in os.listdir(d):
+            if not f.endswith(".go"):
+                continue
+            code = re.sub(r"//[^\n]*", "", open(os.path.join(d, f)).read())
+            for m in re.finditer(r"\bhip\.(?:Default\.)?([A-Z]\w*)\s*\(", code):
+                name = m.group(1)
+                table = methods if "Default." in m.group(0) else funcs
+                assert name in table, f"{f}: hip.{name} is not defined in hip/hip.go"
+                assert call_args(code, m.end() - 1) == table[name], f"{f}: hip.{name} called with {call_args(code, m.end() - 1)} arguments, defined with {table[name]}"
+                checked += 1
+            for m in re.finditer(r"\bh\.([A-Z]\w*)\s*\(", code):      # h := hip.Default / a fork
+                name = m.group(1)
+                assert name in methods, f"{f}: method {name} is not defined on hip.Ctx"
+                assert call_args(code, m.end() - 1) == methods[name], f"{f}: h.{name} called with {call_args(code, m.end() - 1)} arguments, defined with {methods[name]}"
+                checked += 1
+    assert checked >= 25
