@@ -551,7 +551,8 @@ def main():
     def chk(rc, what):
         ctx.check(rc, what)
 
-    chk(lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)), "set_stream")     # a refused handle would leave the collectives unordered against the MAC
+    if use_dist or os.environ.get("SFG_BENCH_OWN_STREAM") != "1":     # (SFG_BENCH_OWN_STREAM=1, one rank: the library keeps its own queues - the CU-partitioning experiments mask THOSE)
+        chk(lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)), "set_stream")     # a refused handle would leave the collectives unordered against the MAC
 
     rots = P.rotations_for_matmul()
     arr = (C.c_int * len(rots))(*rots)

@@ -80,6 +80,9 @@ struct SfgConfig {
     size_t ksw_budget = 4ULL << 30; // SFG_KSW_BUDGET_MB      key-switch scratch per input group / job chunk: more jobs per chunk = more reuse of a key (64 MB: +45 %, 1.5 GB: +2 %, 12 GB: -2 %)
     int enc_batch = 1024;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 64 MB of coefficient rows stay cache resident between the two (measured 256..8192: 1024 is best, 2048 +2.5 %, 512 +4 %)
     bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)
+    // CU partitioning experiments (round 5): restrict a queue of the context to a set of compute units, "lo-hi[,lo-hi...]" over the bits of hipExtStreamCreateWithCUMask
+    // (bit i = CU i of the device's enumeration).  Empty = all CUs (the default).  A stream installed by sfg_ctx_set_stream is the caller's and keeps its own mask.
+    std::string cu_main, cu_enc, cu_aux;   // SFG_CU_MAIN / SFG_CU_ENC / SFG_CU_AUX
     bool assoc_i8 = true;                   // SFG_ASSOC_I8=0           association scan: keep the rotation cache as fp64 operand rows (round 3) instead of the int8 MAC's rot tiles
     size_t assoc_cache_budget = 160ULL << 30;   // SFG_ASSOC_ROTCACHE_MB   largest baby-step rotation cache sfg_assoc_stream_bed keeps across the batches of a call (0: rebuild per batch, the A/B switch)
 };

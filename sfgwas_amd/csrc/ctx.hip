@@ -48,6 +48,9 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
     c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
     if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
+    if (const char *e = env("SFG_CU_MAIN")) c.cu_main = e;
+    if (const char *e = env("SFG_CU_ENC")) c.cu_enc = e;
+    if (const char *e = env("SFG_CU_AUX")) c.cu_aux = e;
     if (const char *e = env("SFG_ASSOC_I8")) c.assoc_i8 = atoi(e) != 0;
     if (const char *e = env("SFG_ASSOC_ROTCACHE_MB")) c.assoc_cache_budget = (size_t)atoll(e) << 20;
     if (const char *e = env("SFG_KSW_BUDGET_MB")) { c.ksw_budget = (size_t)atoll(e) << 20; if (c.ksw_budget < (16ULL << 20)) c.ksw_budget = 16ULL << 20; }
@@ -61,16 +64,37 @@ static void ctx_bind_shared(sfg_ctx *ctx, SfgShared *sh) {
     memcpy(ctx->q, sh->q, sizeof sh->q); memcpy(ctx->psi, sh->psi, sizeof sh->psi); memcpy(ctx->modc_host, sh->modc_host, sizeof sh->modc_host);
     ctx->tw_fwd = sh->tw_fwd; ctx->tw_inv = sh->tw_inv; ctx->pack_fwd = sh->pack_fwd; ctx->pack_inv = sh->pack_inv; ctx->modc = sh->modc;
 }
+// a queue restricted to the compute units named by `spec` ("lo-hi[,lo-hi...]", bits of hipExtStreamCreateWithCUMask); empty spec: nullptr (caller creates a plain queue)
+static hipStream_t stream_with_cu_mask(const std::string &spec) {
+    if (spec.empty()) return nullptr;
+    uint32_t mask[16] = {0};                                   // up to 512 CUs
+    const char *p = spec.c_str();
+    while (*p) {
+        char *e = nullptr; long lo = strtol(p, &e, 10), hi = lo + 1;
+        if (e == p) return nullptr;
+        if (*e == '-') { p = e + 1; hi = strtol(p, &e, 10); if (e == p) return nullptr; }
+        for (long i = lo; i < hi && i < 512; i++) if (i >= 0) mask[i >> 5] |= 1u << (i & 31);
+        p = *e == ',' ? e + 1 : e;
+        if (*e && *e != ',') return nullptr;
+    }
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, 16, mask) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return st;
+}
 // per-caller execution state: two queues, ordering events, the pinned staging ring
 static const char *ctx_exec_init(sfg_ctx *ctx) {
     if (hipSetDevice(ctx->device) != hipSuccess) return "hipSetDevice failed";
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+    const SfgConfig &c = ctx->sh->cfg;
+    if (!c.cu_main.empty() && !(ctx->own_stream = stream_with_cu_mask(c.cu_main))) return "SFG_CU_MAIN: bad CU list or hipExtStreamCreateWithCUMask failed";
+    if (!ctx->own_stream && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
     ctx->stream = ctx->own_stream;
-    {   // the auxiliary queue yields to the main one: its element-wise key-switch kernels fill gaps, they must not displace MAC workgroups
+    if (!c.cu_aux.empty() && !(ctx->aux_stream = stream_with_cu_mask(c.cu_aux))) return "SFG_CU_AUX: bad CU list or hipExtStreamCreateWithCUMask failed";
+    if (!ctx->aux_stream) {   // the auxiliary queue yields to the main one: its element-wise key-switch kernels fill gaps, they must not displace MAC workgroups
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) return "hipStreamCreate failed";
     }
-    if (hipStreamCreateWithFlags(&ctx->enc_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+    if (!c.cu_enc.empty() && !(ctx->enc_stream = stream_with_cu_mask(c.cu_enc))) return "SFG_CU_ENC: bad CU list or hipExtStreamCreateWithCUMask failed";
+    if (!ctx->enc_stream && hipStreamCreateWithFlags(&ctx->enc_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_enc[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     ctx->pin_bytes = 64u << 20;
