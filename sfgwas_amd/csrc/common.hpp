@@ -76,7 +76,6 @@ struct SfgConfig {
                                    // with the 128 VGPRs a plaintext-NTT wave needs, so an encode workgroup cannot be resident beside it.  Off until the MAC leaves that room.
     bool ntt_fwd_full = false;     // SFG_NTT_FWD_IMPL=full   one 512-thread workgroup per row for the general forward NTT (instead of two half-row workgroups)
     bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
-    bool ntt_persist = false;      // SFG_NTT_PERSIST=1       plaintext NTT with one workgroup per plaintext walking its moduli (k_ntt_half3_p) instead of one per (plaintext, modulus)
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
     size_t ksw_budget = 4ULL << 30; // SFG_KSW_BUDGET_MB      key-switch scratch per input group / job chunk: more jobs per chunk = more reuse of a key (64 MB: +45 %, 1.5 GB: +2 %, 12 GB: -2 %)
     int enc_batch = 1024;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 64 MB of coefficient rows stay cache resident between the two (measured 256..8192: 1024 is best, 2048 +2.5 %, 512 +4 %)

@@ -46,7 +46,6 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MM_ENC_OVERLAP")) c.no_enc_overlap = atoi(e) == 0;
     if (const char *e = env("SFG_NTT_HALF_IMPL")) c.ntt_half_full = !strcmp(e, "full");
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
-    if (const char *e = env("SFG_NTT_PERSIST")) c.ntt_persist = atoi(e) != 0;
     c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
     if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
     if (const char *e = env("SFG_CU_MAIN")) c.cu_main = e;

@@ -348,10 +348,13 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
 // image X -> X^g of cached row u (perm[t] = u | g << 16): coefficient i of the row becomes coefficient i g mod 2N of the image (>= N: minus coefficient - N), and a
 // row is stored as its first N/2 coefficients (p_{N-c} = -p_c, p_{N/2} = 0).  The rounding of the encoder commutes with this signed permutation, so the NTT input is
 // the very integer polynomial a fresh encode of the rotated diagonal would give.
-template <bool PERM, bool DIG, int FORM = 0>      // FORM (DIG only): 0 = the row's store form follows the mask at run time; 5 / 6 = it is known to be five / six digit planes
-__device__ __forceinline__ void ntt_half3_row(double *lds, size_t row, int m, const double *pc_all, u64 *out_, int L, PanelMap pm, const double *tw_all, const double2 *pack_all,
-                                              const ModConst *modc, const uint32_t *perm, int tid) {
-    const int N = SFG_N, n = N / 2;
+template <bool PERM, bool DIG>
+__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
+                                                      const uint32_t *perm) {
+    extern __shared__ double lds[];
+    const int N = SFG_N, n = N / 2, tid = threadIdx.x;
+    size_t row; int m;
+    if (!plain_block(nplain, L, row, m)) return;
     const double *tw = tw_all + (size_t)m * N;
     const double2 *pack = pack_all + (size_t)m * (N / 2);
     const double q = modc[m].q, qinv = modc[m].qinv;
@@ -407,7 +410,7 @@ __device__ __forceinline__ void ntt_half3_row(double *lds, size_t row, int m, co
 #endif
     // int8 MAC (mac_i8.hip; bit 31 of the mask): the packed rows leave as five planes of signed base-256 digits instead of words - 5 of the row's 8 bytes per word.
     // Balanced digits of v: the bytes of v + 0x8080808080 with their top bits flipped; the sum is read off the mantissa of v + 2^52 + 0x8080808080.
-    if constexpr (DIG && FORM != 5) if (FORM == 6 || (!((pm.packed_mask >> m) & 1u) && ((pm.packed_mask >> 30) & 1u))) {        // the 46-bit row as SIX digit planes (48 KiB of its 64 KiB)
+    if constexpr (DIG) if (!((pm.packed_mask >> m) & 1u) && ((pm.packed_mask >> 30) & 1u)) {        // the 46-bit row as SIX digit planes (48 KiB of its 64 KiB)
         uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
         auto dig6 = [&](double x, unsigned &lo, unsigned &hi) {
             const u64 b = (u64)__double_as_longlong(canon(x, q, qinv) + (4503599627370496.0 + 141289400074368.0));       // + 2^52 + 0x808080808080
@@ -427,7 +430,7 @@ __device__ __forceinline__ void ntt_half3_row(double *lds, size_t row, int m, co
         else ntt_half3_body<decltype(first), decltype(st6), NoFill, true>(0, first, st6, lds, tw, pack, q, qinv, tid);
         return;
     }
-    if constexpr (DIG && FORM != 6) if (FORM == 5 || ((pm.packed_mask >> m) & 1u)) {
+    if constexpr (DIG) if ((pm.packed_mask >> m) & 1u) {
         uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
         auto dig = [&](double x, unsigned &lo, unsigned &hi) {
             const u64 b = (u64)__double_as_longlong(canon_le(x, q, qinv) + (4503599627370496.0 + 551911719040.0));
@@ -452,43 +455,6 @@ __device__ __forceinline__ void ntt_half3_row(double *lds, size_t row, int m, co
         (void)fill;
         if (!DIG && ((pm.packed_mask >> m) & 1u)) ntt_half3_body(0, first, [&](int j, double x) { out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
         else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
-    }
-}
-template <bool PERM, bool DIG>
-__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
-                                                      const uint32_t *perm) {
-    extern __shared__ double lds[];
-    size_t row; int m;
-    if (!plain_block(nplain, L, row, m)) return;
-    ntt_half3_row<PERM, DIG>(lds, row, m, pc_all, out_, L, pm, tw_all, pack_all, modc, perm, (int)threadIdx.x);
-}
-// A/B (SFG_NTT_PERSIST=1, round 5): ONE workgroup per plaintext walks its L moduli - a launch of 1024 plaintexts is then exactly one resident round (256 CUs x 4
-// workgroups), no workgroup turnover inside the launch, and the coefficient row is re-read by the workgroup that read it last.
-template <bool PERM, bool DIG>
-__global__ void __launch_bounds__(256, 4) k_ntt_half3_p(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
-                                                        const uint32_t *perm) {
-    extern __shared__ double lds[];
-    const size_t plain = blockIdx.x;
-    if (plain >= nplain) return;
-    // one loop per store form (each holds ONE inlined transform body: with both in one loop the register allocation spills ~200 VGPRs); rows in any other form
-    // (plain words: a modulus outside the mask) take the run-time form
-    bool first_row = true;
-#pragma unroll 1
-    for (int pass = 0; pass < 3; pass++) {
-#pragma unroll 1
-        for (int m = 0; m < L; m++) {
-            const bool small = (pm.packed_mask >> m) & 1u, big = !small && ((pm.packed_mask >> 30) & 1u);
-            const int form = small ? 0 : big ? 1 : 2;
-            if (form != pass) continue;
-            if (!first_row) __syncthreads();                      // the wave-private regions of the previous row lie inside the next row's A->B image
-            first_row = false;
-            const size_t row = plain * (size_t)L + m;
-            int tid = (int)threadIdx.x;
-            asm volatile("" : "+v"(tid));                          // (nothing derived from the lane's id may be hoisted out of the loops: the 64 row addresses alone would spill)
-            if (pass == 0) ntt_half3_row<PERM, DIG, 5>(lds, row, m, pc_all, out_, L, pm, tw_all, pack_all, modc, perm, tid);
-            else if (pass == 1) ntt_half3_row<PERM, DIG, 6>(lds, row, m, pc_all, out_, L, pm, tw_all, pack_all, modc, perm, tid);
-            else ntt_half3_row<PERM, false, 0>(lds, row, m, pc_all, out_, L, pm, tw_all, pack_all, modc, perm, tid);
-        }
     }
 }
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
@@ -532,7 +498,6 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
@@ -565,7 +530,6 @@ int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t 
     const bool dig = pm.packed_mask >> 31;                 // digit planes for the int8 MAC (mac_i8.hip): its own instances, the default kernels are untouched
     if (perm && dig) hipLaunchKernelGGL((k_ntt_half3<true, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (perm) hipLaunchKernelGGL((k_ntt_half3<true, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
-    else if (dig && ctx->cfg.ntt_persist) hipLaunchKernelGGL((k_ntt_half3_p<false, true>), dim3((unsigned)nplain), dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
     else if (dig) hipLaunchKernelGGL((k_ntt_half3<false, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
     else if (ctx->cfg.ntt_half_full) hipLaunchKernelGGL(k_ntt_half, grid, dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
     else hipLaunchKernelGGL((k_ntt_half3<false, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
