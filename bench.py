@@ -307,7 +307,19 @@ def main_lib_engine(args):
         box = [capi.MultiGpu.unique_id() if rank == 0 else None]              # collectives are the library's own RCCL calls.
         dist.broadcast_object_list(box, src=0)
         devices = [local_rank]
-        mg = capi.MultiGpu(P.Q_PN14, P.P_PN14, rank=rank, world=world, uid=box[0], device=local_rank)
+        try:
+            mg = capi.MultiGpu(P.Q_PN14, P.P_PN14, rank=rank, world=world, uid=box[0], device=local_rank)
+            ok = 1
+        except capi.SfgError as e:
+            print(f"[bench] rank {rank}: sfg_mgpu_create_rank failed ({e}); falling back to --engine torch", file=sys.stderr, flush=True)
+            mg, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                        # every rank takes the same path
+        if int(flag.item()) == 0:
+            if mg is not None:
+                mg.close()
+            dist.destroy_process_group()
+            return "fallback"
     lib = capi.lib()
     nloc = mg.nlocal
     shared_device = len(set(devices)) < len(devices)
@@ -478,7 +490,14 @@ def main():
     # SFG_MGPU_FORCE_COLLECTIVES=1 runs the library's exchange even with one rank (over RCCL): `--gpus 1` then takes the engine too
     if ((args.gpus > 1 or os.environ.get("SFG_MGPU_FORCE_COLLECTIVES") == "1") and args.engine == "lib" and args.backend == "nccl"
             and not os.environ.get("SFG_BENCH_SOLO") and os.environ.get("SFG_BENCH_FORCE_COLLECTIVES") != "1"):
-        return main_lib_engine(args)
+        rc = main_lib_engine(args)
+        if rc != "fallback":
+            return rc
+        args.engine = "torch"             # the library's engine could not be created on this node (every rank saw the same failure): the torch-issued sequence
+    return main_torch(args)
+
+
+def main_torch(args):
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (one per GPU, torch.distributed.run) before
     # anything in this process touches torch.cuda / HIP, relay rank 0's JSON line and exit with the launcher's code.  (No exec: a process that has
@@ -763,6 +782,7 @@ def main():
                                f"kp={KP}, PN14QP438-shaped ring (N=16384, L=5 of 6 moduli), on-the-fly diagonal encode",
                    "parallelism": f"snp-block x{world}", "power_iter_wall_s": dt / args.steps,
                    "genotype_residency": "2-bit packed (sfg_geno_pack)" if args.packed_geno else "int8",
+                   "engine": ("bench.py through torch.distributed (--engine torch: the A/B of the library's sfg_mgpu_* engine)" if use_dist else "single context"),
                    "collectives": (("RCCL" if args.backend == "nccl" else "gloo, host-staged (rehearsal: ranks may share a GPU; timing not meaningful)") if use_dist else "none"),
                    "plaintext_cache": (f"{pt_cache['blocks']} of {nblk_loc * nbr_x} blocks of this rank ({pt_cache['bytes'] / 2**30:.1f} GiB of HBM left after the first warm-up step; "
                                        f"{pt_cache.get('hits', 0)} block encodes served from it, {pt_cache.get('fills', 0)} filled)" if "budget" in pt_cache else "off"),

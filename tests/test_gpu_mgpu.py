@@ -237,3 +237,42 @@ def test_association_scan_batches_round_robin_over_ranks(tmp_path, monkeypatch):
             assert np.array_equal(out, want_pgen), n
         finally:
             mg.close()
+
+
+def test_adopted_shards_packed_residency_and_the_plaintext_cache(ref, monkeypatch):
+    """the other ways a sharded matrix comes to be: per-rank windows made by the caller on the ranks' own contexts (sfg_mgpu_geno_adopt; a wrong window is refused),
+    2-bit packed shards (sfg_geno_pack per rank), and the per-rank plaintext coefficient cache (filled by Q X, hit through the automorphism permutation by Q' X^T)"""
+    from sfgwas_amd import capi
+    geno, small, Ah, Ash, want, wants = ref
+    lib = capi.lib()
+    mg = make_engine(monkeypatch, [0, 0])
+    try:
+        shards, packed = [], []
+        for i in range(mg.nlocal):
+            v = [C.c_size_t() for _ in range(4)]
+            assert lib.sfg_mgpu_shard(mg.world, NCOL, mg.ranks[i], *[C.byref(x) for x in v]) == 0
+            c0, c1 = v[2].value, v[3].value
+            g_i = mg.ctx[i].geno_upload(np.ascontiguousarray(np.where(geno[:, c0:c1] < 0, -1, geno[:, c0:c1])))
+            p_i = C.c_void_p()
+            mg.ctx[i].check(lib.sfg_geno_pack(mg.ctx[i].h, g_i, C.byref(p_i)), "geno_pack")
+            mg.ctx[i].geno_free(g_i)
+            packed.append(p_i)
+        arr = (C.c_void_p * mg.nlocal)(*packed)
+        g = C.c_void_p()
+        bad = (C.c_void_p * mg.nlocal)(packed[1], packed[0])
+        assert lib.sfg_mgpu_geno_adopt(mg.h, NROW, NCOL, bad, C.byref(g)) != 0 and b"window" in lib.sfg_mgpu_last_error(mg.h)
+        mg.check(lib.sfg_mgpu_geno_adopt(mg.h, NROW, NCOL, arr, C.byref(g)), "adopt")
+        mg.check(lib.sfg_mgpu_geno_set_plaintext_cache(mg.h, g, C.c_size_t(4 << 30)), "plaintext cache")
+        for f in (0, T, 0):
+            got = mg.matmul(Ah[f & T], S, LEVEL, L, g, f)
+            assert np.array_equal(got, want[f]), f
+        hits = 0
+        for i in range(mg.nlocal):
+            v = [C.c_size_t() for _ in range(4)]
+            mg.ctx[i].check(lib.sfg_geno_plaintext_cache_stats(mg.ctx[i].h, C.c_void_p(lib.sfg_mgpu_geno_shard(g, i)), *[C.byref(x) for x in v]), "stats")
+            assert v[0].value > 0
+            hits += v[2].value
+        assert hits > 0
+        mg.geno_free(g)                                    # owns the adopted handles
+    finally:
+        mg.close()
