@@ -63,6 +63,8 @@ struct SfgConfig {
     bool test_hooks = false;       // SFG_ENABLE_TEST_HOOKS=1   sfg_ctx_encoder_inject_unsafe_for_test may be called (tests of the failure path only)
     bool mac_i8_ring = true;       // SFG_MAC_I8_ROT=cache    int8 MAC without the LDS prefetch ring (k_mac_i8: operands straight from global memory, rot tiles shared through the L1)
     bool stage_pack = false;       // SFG_MAC_I8_STAGE=1    int8 MAC: streamed transposition (StagePack, kernels.hpp) instead of the full plaintext panel and a transposition pass per MAC launch.  Built, bit-exact, and measured SLOWER at 100k x 1M (14.2 s against 12.5 s per step on one box: the small per-batch transposition launches run at 1.5 TB/s and slow the encode kernels they share the chip with)
+    int stage_giants = 11;         // SFG_STAGE_GIANTS=n     giant steps per batch of the streamed transposition (16: a batch completes whole 16-column tiles)
+    bool stage_same_queue = false; // SFG_STAGE_SAMEQ=1      the batch transposition on the product's own queue (behind its NTT) instead of the encode queue
     int mac_i8_waves = 12;         // SFG_MAC_I8_WAVES=6     k_mac_i8_ring with six waves per coefficient pair (a wave = both coefficients x 16 columns) instead of twelve (one coefficient each)
     int mac_i8_diag = 0;           // SFG_MAC_I8_DIAG=1 / 2   timing diagnostics of k_mac_i8_ring, results INVALID: 1 = one MFMA per rot tile, 2 = no DMA after the prologue
     bool mac_i8_wg1 = false;       // SFG_MAC_I8_WG=1       int8 MAC diagnostic: one column wave per workgroup (no cache shared between the column waves of a coefficient pair); for the PMC re-fetch measurement

@@ -36,6 +36,8 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_MAC_I8_DIAG")) { if (c.test_hooks) c.mac_i8_diag = atoi(e); }       // timing diagnostics with INVALID results: honoured under the test switch only
     if (const char *e = env("SFG_MAC_I8_WAVES")) c.mac_i8_waves = atoi(e) == 6 ? 6 : 12;
     if (const char *e = env("SFG_MAC_I8_STAGE")) c.stage_pack = atoi(e) != 0;
+    if (const char *e = env("SFG_STAGE_GIANTS")) { c.stage_giants = atoi(e); if (c.stage_giants < 1) c.stage_giants = 1; if (c.stage_giants > 91) c.stage_giants = 91; }
+    if (const char *e = env("SFG_STAGE_SAMEQ")) c.stage_same_queue = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
     if (const char *e = env("SFG_TEST_TIE_BAND_LOG2")) { if (c.test_hooks) c.tie_band = ldexp(1.0, atoi(e)); }       // test hook: a wider band sends ordinary coefficients through the exact re-derivation
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;

@@ -588,7 +588,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
     EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
     if (sp && (shift0 % SFG_D || !half_rows || !(packed_mask >> 31))) SFG_FAIL(ctx, "encode: internal: the streamed transposition takes whole giant steps of digit-plane rows");
-    const int BATCH = sp ? SFG_STAGE_BATCH : ctx->cfg.enc_batch;                 // plaintexts per FFT / NTT launch pair (SFG_ENC_BATCH)
+    const int BATCH = sp ? ctx->cfg.stage_giants * SFG_D : ctx->cfg.enc_batch;                 // plaintexts per FFT / NTT launch pair (SFG_ENC_BATCH)
     const int cmode = pcache && pcache->slot && half_rows && G > 0 ? pcache->mode : 0;
     double *pc = nullptr;
     if (!cmode) SFG_TRY(enc_pc_scratch(ctx, (size_t)(nshift < BATCH ? nshift : BATCH), &pc));

@@ -49,7 +49,7 @@ struct StagePack {
     hipStream_t q = nullptr; hipEvent_t ev_ntt = nullptr, ev_pack = nullptr; bool pending = false;
     unsigned seq = 0;
 };
-constexpr int SFG_STAGE_BATCH = 11 * SFG_D;       // whole giant steps per batch: 1001 plaintexts (5005 NTT workgroups)
+// plaintexts per batch of the streamed transposition: cfg.stage_giants whole giant steps (default 11: 1001 plaintexts, 5005 NTT workgroups; SFG_STAGE_GIANTS)
 int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, int L);      // mac_i8.hip
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0, unsigned packed_mask = 0, const PcCache *pcache = nullptr,
                        StagePack *sp = nullptr);

@@ -465,12 +465,12 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 if (!contiguous || !sp.n_small) stream = false;
             }
             if (stream) {
-                sp.kb = 92; sp.njt = 6; sp.nch = (ng * sp.kb + 63) / 64; sp.q = ctx->enc_stream; sp.ev_ntt = ctx->ev_enc[0]; sp.ev_pack = ctx->ev_enc[1];
+                sp.kb = 92; sp.njt = 6; sp.nch = (ng * sp.kb + 63) / 64; sp.q = ctx->cfg.stage_same_queue ? ctx->stream : ctx->enc_stream; sp.ev_ntt = ctx->ev_enc[0]; sp.ev_pack = ctx->ev_enc[1];
                 const size_t nBs = mac_i8_tile_bytes(ng * sp.kb, sp.n_small, 5), nBb = sp.l_big >= 0 ? mac_i8_tile_bytes(ng * sp.kb, 1, 6) : 0;
                 const size_t had_s = ctx->pool.count("mi8.Bs") ? ctx->pool["mi8.Bs"].second : 0, had_b = ctx->pool.count("mi8.Bb") ? ctx->pool["mi8.Bb"].second : 0;
                 rc = sfg_scratch(ctx, "mi8.Bs", nBs, (void **)&sp.Bs); if (rc) break;
                 if (nBb) { rc = sfg_scratch(ctx, "mi8.Bb", nBb, (void **)&sp.Bb); if (rc) break; }
-                rc = sfg_scratch(ctx, "mi8.stage", (size_t)SFG_STAGE_BATCH * L * (N / 2) * 8, (void **)&sp.stage); if (rc) break;
+                rc = sfg_scratch(ctx, "mi8.stage", (size_t)ctx->cfg.stage_giants * SFG_D * L * (N / 2) * 8, (void **)&sp.stage); if (rc) break;
                 // what no batch owns (columns 91..95, k' past the group's last block row) must read as zero: cleared when the buffers are new or the group shape changes
                 if (had_s < nBs || had_b < nBb || ctx->sp_shape != ng) {
                     SFG_HIP(ctx, hipMemsetAsync(sp.Bs, 0, nBs, ctx->stream));
