@@ -41,11 +41,12 @@ using CipherMatrix = std::vector<CipherVector>;
 
 // HBM-resident genotype matrices keyed by the reference's cacheFilePrefix (see gwas::MatMult4StreamPreprocess); owned by the
 // CryptoParams that created them and shared with its forks - no process-global table
-struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; bool owner = false; };
+struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; bool owner = false; sfg_mgeno *mg = nullptr; };   // mg: sharded by SNP block over the GPUs of a multi-GPU CryptoParams
 struct ResidentTable { std::mutex mu; std::map<std::string, ResidentGeno> tab; };
 
 struct CryptoParams {             // crypto.go:32-60 (the parts the hot path touches)
     sfg_ctx *ctx = nullptr;
+    sfg_mgpu *mg = nullptr;          // set by NewCryptoParamsMulti: the party's node (one context per device, owned by the engine); ctx is then device 0's context
     int logN = 14, nq = 0, np = 0;
     double scale = 0;
     std::vector<uint64_t> qi;                                        // ciphertext moduli q_0..q_{nq-1} (Params.Qi())
@@ -54,8 +55,9 @@ struct CryptoParams {             // crypto.go:32-60 (the parts the hot path tou
     int GetSlots() const { return N() / 2; }                         // crypto.go:282-284
     ~CryptoParams() {
         if (!ctx) return;
-        if (resident.use_count() == 1) for (auto &kv : resident->tab) if (kv.second.owner) sfg_geno_free(ctx, kv.second.g);
-        sfg_ctx_destroy(ctx);
+        if (resident.use_count() == 1) for (auto &kv : resident->tab) if (kv.second.owner) { if (kv.second.mg) sfg_mgpu_geno_free(mg, kv.second.mg); else sfg_geno_free(ctx, kv.second.g); }
+        if (mg) sfg_mgpu_destroy(mg);          // destroys the per-device contexts, ctx among them
+        else sfg_ctx_destroy(ctx);
     }
     void check(int rc, const char *what) const {
         if (rc) throw std::runtime_error(std::string(what) + ": " + sfg_last_error(ctx));
@@ -81,8 +83,22 @@ inline std::unique_ptr<CryptoParams> NewCryptoParams(int device, int logN, const
     cps->logN = logN; cps->nq = (int)qi.size(); cps->np = (int)pi.size(); cps->scale = scale; cps->qi = qi;
     return cps;
 }
+// The same for a party that owns several GPUs of its node (the reference is one OS process per party, run_example.sh:1-12): the library's multi-GPU
+// engine (sfg_mgpu_create).  MatMult4StreamPreprocess then shards the matrix by SNP block, MatMult4StreamCompute runs on every device; everything else (evaluator
+// ops, MatMult4Stream forks) runs on devices[0]'s context.
+inline std::unique_ptr<CryptoParams> NewCryptoParamsMulti(const std::vector<int> &devices, int logN, const std::vector<uint64_t> &qi, const std::vector<uint64_t> &pi,
+                                                          const uint64_t *psi, double scale) {
+    auto cps = std::make_unique<CryptoParams>();
+    std::vector<uint64_t> mod(qi); mod.insert(mod.end(), pi.begin(), pi.end());
+    if (sfg_mgpu_create(&cps->mg, devices.data(), (int)devices.size(), logN, (int)qi.size(), (int)pi.size(), mod.data(), psi, scale))
+        throw std::runtime_error(std::string("sfg_mgpu_create: ") + sfg_mgpu_last_error(nullptr));
+    cps->ctx = sfg_mgpu_ctx(cps->mg, 0);
+    cps->logN = logN; cps->nq = (int)qi.size(); cps->np = (int)pi.size(); cps->scale = scale; cps->qi = qi;
+    return cps;
+}
 // cryptoParams.RotKs (crypto.go:50): one switching key per Galois element, [beta][2][nq+np][N]
 inline void LoadRotationKey(CryptoParams *cps, uint64_t galoisEl, const std::vector<uint64_t> &key, bool montgomeryForm) {
+    if (cps->mg) { if (sfg_mgpu_load_rotkey(cps->mg, galoisEl, key.data(), montgomeryForm ? 1 : 0)) throw std::runtime_error(std::string("LoadRotationKey: ") + sfg_mgpu_last_error(cps->mg)); return; }
     cps->check(sfg_ctx_load_rotkey(cps->ctx, galoisEl, key.data(), montgomeryForm ? 1 : 0), "LoadRotationKey");
 }
 
@@ -883,9 +899,12 @@ inline void MatMult4StreamPreprocess(crypto::CryptoParams *cps, GenoFileStream *
     std::lock_guard<std::mutex> lk(cps->resident->mu);
     auto &tab = cps->resident->tab;
     if (tab.count(cacheFilePrefix)) return;                          // "Found cache file" (filestream.go:52-54): skip
-    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE, false}; return; }
+    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE, false, it->second.mg}; return; }
     uint64_t nrow, ncol; std::vector<int8_t> geno = readAllRows(gfs, nrow, ncol);
-    crypto::ResidentGeno r; cps->check(sfg_geno_upload(cps->ctx, geno.data(), nrow, ncol, ncol, &r.g), "MatMult4StreamPreprocess");
+    crypto::ResidentGeno r;
+    if (cps->mg) {               // the STORED orientation's columns (pca.go:112: X, individuals x SNPs) are the shards
+        if (sfg_mgpu_geno_upload(cps->mg, geno.data(), nrow, ncol, ncol, &r.mg)) throw std::runtime_error(std::string("MatMult4StreamPreprocess: ") + sfg_mgpu_last_error(cps->mg));
+    } else cps->check(sfg_geno_upload(cps->ctx, geno.data(), nrow, ncol, ncol, &r.g), "MatMult4StreamPreprocess");
     r.owner = true;
     tab[cacheFilePrefix] = r;
 }
@@ -896,6 +915,12 @@ inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, con
         std::lock_guard<std::mutex> lk(cps->resident->mu);
         auto it = cps->resident->tab.find(cacheFilePrefix);
         if (it != cps->resident->tab.end()) rg = it->second;
+    }
+    if (rg.mg) {                 // every GPU of the node: shards, the exchange of Q' X^T and the gather happen inside the library (mgpu.hip)
+        const int s = (int)A.size(), inLevel = A[0][0].Level();
+        std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());
+        if (sfg_mgpu_matmul(cps->mg, a.data(), s, inLevel, maxLevel, rg.mg, rg.flags, o.data())) throw std::runtime_error(std::string("MatMult4StreamCompute: ") + sfg_mgpu_last_error(cps->mg));
+        return unflatten(o, s, m_ct, maxLevel - 1, A[0][0].Scale() * cps->scale, cps->N());
     }
     if (!rg.g) {
         // not resident: an on-disk DiagCache written by the reference (or by a CPU-only party) under this prefix is consumed as is
@@ -929,6 +954,7 @@ inline crypto::DevCipherMatrix MatMult4StreamComputeDev(crypto::CryptoParams *cp
     crypto::ResidentGeno rg;
     { std::lock_guard<std::mutex> lk(cps->resident->mu); auto it = cps->resident->tab.find(cacheFilePrefix);
       if (it == cps->resident->tab.end()) throw std::runtime_error("MatMult4StreamCompute: no resident matrix for prefix " + cacheFilePrefix); rg = it->second; }
+    if (rg.mg) throw std::runtime_error("MatMult4StreamComputeDev: the matrix is sharded over several GPUs - use MatMult4StreamCompute (host ciphertexts in, host ciphertexts out)");
     crypto::DevCipherMatrix out = crypto::NewDevCipherMatrix(cps, A.rows, (size_t)m_ct, maxLevel - 1, A.scale * cps->scale);
     cps->check(sfg_matmul_resident_dev(cps->ctx, A.buf->u(), (int)A.rows, A.level, maxLevel, rg.g, rg.flags, out.buf->u()), "MatMult4StreamCompute");
     return out;

@@ -1013,3 +1013,41 @@ def test_sigmoid_approximation_change_of_variable_and_evaluate_cheby(tmp_path, d
         cheb = np.polynomial.chebyshev.chebval((2 * xs[k] - A - B) / (B - A), coeffs)
         assert np.max(np.abs(dec - cheb)) < 2e-4, f"decrypted values are off the interpolant by {np.max(np.abs(dec - cheb))}"
         assert np.max(np.abs(dec - ref)) < (2e-2 if degree < 20 else 2e-3), f"decrypted values are off the sigmoid by {np.max(np.abs(dec - ref))}"
+
+
+@pytest.mark.gpu
+def test_host_mirror_on_a_multi_gpu_party_matches_the_oracle(tmp_path):
+    """crypto::NewCryptoParamsMulti({0, 0, 0}) - three ranks of the library's multi-GPU engine on one device (in-process direct transport) - behind the unchanged
+    call sites of pca.go:112-113,344,352: Preprocess(X), Preprocess(X^T as the transposed view), Compute(Q X), Compute(Q' X^T) on a ragged 1 x 3 block matrix, every
+    word against the oracle (gwas/matmult.go:1043-1236)."""
+    from sfgwas_amd import capi
+    capi.lib()
+    exe = build("host_mgpu_test")
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rnd = np.random.default_rng(41)
+    slots, d = 8192, 91
+    nrow, ncol, s, level, L = 70, 2 * slots + 40, 2, 5, 5
+    geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+    geno.tofile(tmp_path / "geno.bin")
+    steps = set(range(1, d)) | {g * d for g in range(1, d) if g * d < slots} | {slots - 1}       # every baby and giant step (the engine's rank-local rotation cache rotates all 91 babies)
+    blob = [np.array([len(steps)], dtype=np.uint64)]
+    for k in sorted(steps):
+        g = ring.galois(k)
+        key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 300 + k)
+        keys.add(g, key)
+        blob += [np.array([g], dtype=np.uint64), key.reshape(-1)]
+    np.concatenate(blob).tofile(tmp_path / "keys.bin")
+    np.array([len(ol.Q_PN14), len(ol.P_PN14)] + ol.Q_PN14 + ol.P_PN14, dtype=np.uint64).tofile(tmp_path / "moduli.bin")
+    A = np.stack([np.stack([ring.fill_uniform(level, 50 + i)]) for i in range(s)])                            # Q : s x 1 block row
+    AT = np.stack([np.stack([ring.fill_uniform(level, 70 + 3 * i + b) for b in range(3)]) for i in range(s)])     # Q': s x 3 SNP blocks
+    A.tofile(tmp_path / "A.bin"); AT.tofile(tmp_path / "AT.bin")
+    (tmp_path / "case.txt").write_text(f"{nrow} {ncol} {s} {level} {L} 0\n")
+    out = subprocess.run([exe, str(tmp_path), "0,0,0"], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK direct world 3" in out.stdout, (out.stdout, out.stderr)
+    want, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, L, geno)
+    assert np.array_equal(np.fromfile(tmp_path / "out_x.bin", dtype=np.uint64).reshape(want.shape), want)
+    want_t, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, AT, level, L, np.ascontiguousarray(geno.T))
+    assert np.array_equal(np.fromfile(tmp_path / "out_xt.bin", dtype=np.uint64).reshape(want_t.shape), want_t)
+    rot = np.fromfile(tmp_path / "rot.bin", dtype=np.uint64).reshape(A[0, 0].shape)
+    assert np.array_equal(rot, ol.rotate_right(ring, keys, level, A[0, 0], 1))
