@@ -272,7 +272,10 @@ def main_lib_engine(args):
     """N > 1 with the multi-GPU sequence INSIDE the library (sfg_mgpu_*, sfgwas_amd/csrc/mgpu.hip): this script only makes the synthetic inputs, calls the two
     products per step, keeps the clock and hashes the outputs.  One process per GPU (the driver's launch: each rank joins with sfg_mgpu_create_rank and a 128-byte
     id passed through torch.distributed's TCP store) or --single-process (sfg_mgpu_create: one host thread per device, the Go party's form)."""
-    single = args.single_process or (args.gpus == 1 and "RANK" not in os.environ)
+    solo = os.environ.get("SFG_MGPU_SOLO")            # r/w: TIMING ONLY - this process runs rank r of a w-rank world on one GPU, the exchanges stood in by local copies
+    single = args.single_process or (args.gpus == 1 and "RANK" not in os.environ) or bool(solo)
+    if solo:
+        args.no_check = args.no_digest = True
     if not single and "RANK" not in os.environ:           # no launcher around us: start the N ranks as children (never exec after touching the GPU)
         import socket
         with socket.socket() as so:
@@ -345,6 +348,15 @@ def main_lib_engine(args):
         out2.append(capi.DevArray(c, (KP, nbr_x, 2, L, N)))
     mg.sync()
     ctx0 = mg.ctx[0]
+    # Every rank's library queue is an explicit torch stream, as in the N = 1 path and the torch engine: the configuration every single-GPU number of this repository
+    # was measured in.  (Measured in round 5, profiles/r05_mgpu_queue_count.txt: with the product on the context's OWN queue and one more HIP stream alive in the process
+    # every kernel ran 7 - 100 % slower; SFG_BENCH_OWN_STREAM=1 keeps the library's own queues.)
+    _streams = []
+    if os.environ.get("SFG_BENCH_OWN_STREAM") != "1":
+        for i, c in enumerate(mg.ctx):
+            st = torch.cuda.Stream(device=torch.device("cuda", devices[i]))
+            c.check(lib.sfg_ctx_set_stream(c.h, C.c_void_p(st.cuda_stream)), "set_stream")
+            _streams.append(st)
     phase_tot = {}
 
     def add_phases():
@@ -427,6 +439,15 @@ def main_lib_engine(args):
                        "of": "SHA-256 over the per-ciphertext SHA-256s in [i][j] order: Q*X (kp x m_ct) and Q'*X^T (kp x nbr); equal for every world size"}
     macs_per_step = 2 * n_ind * m_snp * KP * 2 * L * (N // SLOTS)
     value = macs_per_step * args.steps / dt
+    if solo:
+        print(json.dumps({"solo_rank_timing_only": f"rank {mg.ranks[0]} of {mg.world} (library engine, SFG_MGPU_SOLO)", "config": args.config, "ms_per_step": 1e3 * dt / args.steps,
+                          "kernel_phases_ms_per_step": {k: v[0] / args.steps for k, v in phase_tot.items()}, "plaintext_cache": pt_cache,
+                          "note": "exchanges replaced by local copies: the outputs are not a product"}), flush=True)
+        for a in A1 + A2 + out1 + out2:
+            a.free()
+        mg.geno_free(g)
+        mg.close()
+        return
     if rank == 0:
         res = {
             "metric": "pca_power_iter_ring_macs_per_s", "value": value, "unit": "ring-MAC/s",
@@ -488,7 +509,7 @@ def main():
                                                     "'direct' transport: a rehearsal of N > 1 on one GPU; timings then mean nothing)")
     args = ap.parse_args()
     # SFG_MGPU_FORCE_COLLECTIVES=1 runs the library's exchange even with one rank (over RCCL): `--gpus 1` then takes the engine too
-    if ((args.gpus > 1 or os.environ.get("SFG_MGPU_FORCE_COLLECTIVES") == "1") and args.engine == "lib" and args.backend == "nccl"
+    if ((args.gpus > 1 or os.environ.get("SFG_MGPU_FORCE_COLLECTIVES") == "1" or os.environ.get("SFG_MGPU_SOLO")) and args.engine == "lib" and args.backend == "nccl"
             and not os.environ.get("SFG_BENCH_SOLO") and os.environ.get("SFG_BENCH_FORCE_COLLECTIVES") != "1"):
         rc = main_lib_engine(args)
         if rc != "fallback":
@@ -570,7 +591,7 @@ def main_torch(args):
     def chk(rc, what):
         ctx.check(rc, what)
 
-    if use_dist or os.environ.get("SFG_BENCH_OWN_STREAM") != "1":     # (SFG_BENCH_OWN_STREAM=1, one rank: the library keeps its own queues - the CU-partitioning experiments mask THOSE)
+    if (use_dist and not solo) or os.environ.get("SFG_BENCH_OWN_STREAM") != "1":     # (SFG_BENCH_OWN_STREAM=1, one rank: the library keeps its own queues - the CU-partitioning experiments mask THOSE)
         chk(lib.sfg_ctx_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)), "set_stream")     # a refused handle would leave the collectives unordered against the MAC
 
     rots = P.rotations_for_matmul()

@@ -898,6 +898,15 @@ int matmul_resident_range_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int ma
     if (!pre.G) SFG_FAIL(ctx, "matmul: no int8 rot tiles");
     return matmul_resident_range(ctx, nullptr, s, max_level, max_level, g, flags, blk0, blk1, out, nullptr, &pre);
 }
+// accumulate phase of a product (sfg_matmul_accumulate_rc_dev) against int8 rot tiles that cover ALL operand block rows of the (possibly transposed) matrix: the
+// multi-GPU engine's Q' X^T multiplies one output block column per call against the tiles of the rank's own block rows (mgpu.hip)
+int matmul_accumulate_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int j0, int j1, int accumulate, uint64_t *acc) {
+    ApiScope api_scope(ctx);
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!pre.G) SFG_FAIL(ctx, "matmul: no int8 rot tiles");
+    Shape sh = make_shape(g, flags);
+    return matmul_accumulate(ctx, nullptr, s, max_level, max_level, sh, flags, 0, pre.nbr, j0, j1, accumulate, (u64 *)acc, nullptr, nullptr, &pre);
+}
 // GetDiagBool (matmult.go:627-631) for other translation units
 int sfg_diag_bool(int r, int c, int dim, int index) { return diag_bool(r, c, dim, index); }
 // the products on a prebuilt cache that covers exactly the operand block rows the call contracts over ([0, nbr) for X, [blk0, blk1) / [b0, b1) for X^T)

@@ -57,6 +57,7 @@ struct MgRank {
     int rank = 0, device = 0;
     ncclComm_t comm = nullptr;
     hipStream_t coll = nullptr;             // the collectives' queue (RCCL kernels beside the MAC of the next column)
+    bool own_coll = false;                  // coll was created by the engine (else it is the context's encode queue)
     hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_rs[2] = {nullptr, nullptr}, ev_c = nullptr;
     std::string err;
 };
@@ -91,6 +92,8 @@ __global__ void __launch_bounds__(256) k_sum_peers(u64 *out, PeerPtrs src, int n
 struct sfg_mgpu {
     int world = 1;
     bool single_process = true, direct = false, force_coll = false;
+    bool solo = false;                      // SFG_MGPU_SOLO=r/w: TIMING ONLY - this process computes the share of rank r of a w-rank world on one GPU, every exchange replaced by a
+                                            // local copy of the rank's own slice (the outputs are not a product): per-rank phase times of world sizes a one-GPU box cannot run
     size_t cache_budget = 72ULL << 30;      // SFG_MGPU_CACHE_GB: a rank's own Q'X^T rotation cache up to this size -> per-column pipelined reduce-scatter
     std::vector<MgRank> r;                  // local ranks
     Rendezvous rv;
@@ -140,7 +143,11 @@ static void mgpu_read_env(sfg_mgpu *mg) {
 }
 static const char *rank_exec_init(MgRank &R) {
     if (hipSetDevice(R.device) != hipSuccess) return "hipSetDevice failed";
-    if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+    // The collectives' queue is the context's encode queue (idle unless SFG_MM_ENC_OVERLAP=1 - then the engine makes its own).  Not a fourth queue by default: measured
+    // (tools/r5_order.sh, profiles/r05_mgpu_queue_count.txt), with one more HIP stream alive in the process every kernel of the product's own queue ran 7 - 100 % slower
+    // (a rank's step 1.63 s against 1.43 s) - with GPU_MAX_HW_QUEUES=2, or with the product on a stream the caller made, the effect vanishes.
+    if (R.ctx->cfg.no_enc_overlap || R.ctx->cfg.no_overlap) { R.coll = R.ctx->enc_stream; R.own_coll = false; }
+    else { if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed"; R.own_coll = true; }
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&R.ev_acc[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&R.ev_rs[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     if (hipEventCreateWithFlags(&R.ev_c, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     return nullptr;
@@ -158,7 +165,7 @@ extern "C" void sfg_mgpu_destroy(sfg_mgpu *mg) {
     for (auto &R : mg->r) {
         if (!R.ctx) continue;
         (void)hipSetDevice(R.device);
-        if (R.coll) (void)hipStreamDestroy(R.coll);
+        if (R.coll && R.own_coll) (void)hipStreamDestroy(R.coll);
         for (int i = 0; i < 2; i++) { if (R.ev_acc[i]) (void)hipEventDestroy(R.ev_acc[i]); if (R.ev_rs[i]) (void)hipEventDestroy(R.ev_rs[i]); }
         if (R.ev_c) (void)hipEventDestroy(R.ev_c);
         if (R.ctx) sfg_ctx_destroy(R.ctx);
@@ -182,6 +189,11 @@ static int mgpu_create_common(sfg_mgpu **out, const int *devices, int n, int ran
     mg->world = world; mg->single_process = id128 == nullptr; mg->rv.n = n;
     mgpu_read_env(mg);
     auto fail = [&](const std::string &m) { g_mgpu_create_error = m; sfg_mgpu_destroy(mg); return 1; };
+    if (const char *e = getenv("SFG_MGPU_SOLO")) {
+        int r = 0, w = 0;
+        if (sscanf(e, "%d/%d", &r, &w) != 2 || w < 1 || r < 0 || r >= w || n != 1 || id128) return fail("SFG_MGPU_SOLO=r/w needs one local device and a single process");
+        mg->solo = true; mg->world = world = w; rank0 = r;
+    }
     bool dup = false;
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) dup = dup || devices[i] == devices[j];
     if (dup) mg->direct = true;                      // several ranks on one device (RCCL refuses that): the in-process transport
@@ -192,7 +204,7 @@ static int mgpu_create_common(sfg_mgpu **out, const int *devices, int n, int ran
         if (sfg_ctx_create(&R.ctx, devices[i], logN, nq, np, moduli, psi, scale)) return fail(std::string("sfg_mgpu_create: device ") + std::to_string(devices[i]) + ": " + sfg_last_error(nullptr));
         if (const char *e = rank_exec_init(R)) return fail(e);
     }
-    const bool need_comm = world > 1 || mg->force_coll;
+    const bool need_comm = (world > 1 || mg->force_coll) && !mg->solo;
     if (need_comm && !mg->direct) {
         { std::lock_guard<std::mutex> lk(g_rccl_mu); const std::string e = g_rccl.load(); if (!e.empty()) return fail(e); }
         if (mg->single_process) {
@@ -232,7 +244,7 @@ extern "C" int sfg_mgpu_world(const sfg_mgpu *mg) { return mg->world; }
 extern "C" int sfg_mgpu_nlocal(const sfg_mgpu *mg) { return (int)mg->r.size(); }
 extern "C" int sfg_mgpu_rank(const sfg_mgpu *mg, int local) { return local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].rank : -1; }
 extern "C" sfg_ctx *sfg_mgpu_ctx(sfg_mgpu *mg, int local) { return local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].ctx : nullptr; }
-extern "C" const char *sfg_mgpu_transport(const sfg_mgpu *mg) { return mg->world == 1 && !mg->force_coll ? "none" : mg->direct ? "direct" : "rccl"; }
+extern "C" const char *sfg_mgpu_transport(const sfg_mgpu *mg) { return mg->solo ? "solo" : mg->world == 1 && !mg->force_coll ? "none" : mg->direct ? "direct" : "rccl"; }
 
 extern "C" int sfg_mgpu_load_rotkey(sfg_mgpu *mg, uint64_t galois_el, const uint64_t *key_host, int montgomery_form) {
     return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_ctx_load_rotkey(R.ctx, galois_el, key_host, montgomery_form)); return 0; });
@@ -324,6 +336,7 @@ extern "C" int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *
 
 // ---------------------------------------------------------------- collectives (enqueued on `st` of the calling rank, in order with it)
 static int coll_reduce_scatter(sfg_mgpu *mg, MgRank &R, const uint64_t *send, uint64_t *recv, size_t recv_count, hipStream_t st) {
+    if (mg->solo) { R_HIP(R, hipMemcpyAsync(recv, send + (size_t)R.rank * recv_count, recv_count * 8, hipMemcpyDeviceToDevice, st)); return 0; }
     if (!mg->direct) { R_NCCL(R, g_rccl.ReduceScatter(send, recv, recv_count, ncclUint64, ncclSum, R.comm, st)); return 0; }
     const int n = mg->world;
     R_HIP(R, hipStreamSynchronize(st));                               // this rank's contribution is complete
@@ -337,6 +350,7 @@ static int coll_reduce_scatter(sfg_mgpu *mg, MgRank &R, const uint64_t *send, ui
     return 0;
 }
 static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, uint64_t *buf, size_t count, hipStream_t st) {
+    if (mg->solo) return 0;
     if (!mg->direct) { R_NCCL(R, g_rccl.AllReduce(buf, buf, count, ncclUint64, ncclSum, R.comm, st)); return 0; }
     const int n = mg->world;
     // in place: sum into a private copy first (a peer may still be reading this rank's buffer), swap after the second meeting
@@ -359,6 +373,7 @@ static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, uint64_t *buf, size_t count,
 static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int s, int in_level, int L, const sfg_mgeno *g, unsigned flags, uint64_t *out) {
     sfg_ctx *ctx = R.ctx;
     R_HIP(R, hipSetDevice(R.device));
+    ApiScope api_scope(ctx);                             // one top-level call for the scratch pools' bookkeeping
     const int world = mg->world, d = SFG_D, N = SFG_N;
     const sfg_geno *shard = g->shard[(size_t)li];
     const int nloc = (int)(g->blk1[(size_t)li] - g->blk0[(size_t)li]), nbr_x = (int)((g->nrow + SFG_SLOTS - 1) / SFG_SLOTS);
@@ -371,7 +386,12 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
     size_t jobw = 0, tailw = 0;
     R_CTX(R, sfg_rotcache_layout(ctx, s, L, &jobw, &tailw));
     const size_t cache_w = (size_t)nloc * s * jobw + tailw;
-    const bool pipe = cache_w * 8 <= mg->cache_budget;
+    // The rank's own baby-step rotations, once per product, for the per-column pipeline: as the int8 MAC's rot TILES where the context multiplies on the matrix core
+    // (1.3 GB per block row at s = 15; every column then multiplies there whatever the number of MAC groups - with fp64 rows a rank of more than two groups, i.e. a world
+    // of 4 or fewer at 100k x 1M, fell back to the fp64 kernel: 1.04 s of a 3.28 s rank step), else as fp64 operand rows (2.15 GB per block row) while they fit
+    I8RotPre pre8;
+    if (nloc) R_CTX(R, i8_rotpre_build(ctx, (const u64 *)A, s, in_level, L, nloc, nullptr, mg->cache_budget, "mg.rot8", pre8));
+    const bool pipe = !nloc || pre8.G || cache_w * 8 <= mg->cache_budget;
     uint64_t *acc_mine = nullptr, *acc2 = nullptr; double *cache = nullptr;
     R_CTX(R, sfg_scratch(ctx, "mg.mine", (size_t)nbr_x * mine * 8, (void **)&acc_mine));
     hipStream_t cs = ctx->stream;
@@ -381,14 +401,15 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
         const bool fresh = ctx->pool.find("mg.acc2") == ctx->pool.end() || ctx->pool["mg.acc2"].second < 2 * colp * 8;
         R_CTX(R, sfg_scratch(ctx, "mg.acc2", 2 * colp * 8, (void **)&acc2));
         if (fresh || !nloc) R_HIP(R, hipMemsetAsync(acc2, 0, 2 * colp * 8, cs));       // the padded giant slots (>= 91) are never written by a product: zero once
-        if (nloc) {
+        if (nloc && !pre8.G) {
             R_CTX(R, sfg_scratch(ctx, "mg.cache", cache_w * 8, (void **)&cache));
             R_CTX(R, sfg_rotcache_build_rows_dev(ctx, A, s, in_level, L, nloc, 0, nloc, cache));
         }
         for (int j = 0; j < nbr_x; j++) {              // column j is multiplied while column j - 1 is reduce-scattered
             uint64_t *buf = acc2 + (size_t)(j & 1) * colp;
             if (j >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[j & 1], 0));            // the reduce-scatter of column j - 2 has read this buffer
-            if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
+            if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, j, j + 1, 0, buf));
+            else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
             R_HIP(R, hipEventRecord(R.ev_acc[j & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[j & 1], 0));
             if (coll_reduce_scatter(mg, R, buf, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
             R_HIP(R, hipEventRecord(R.ev_rs[j & 1], R.coll));
@@ -402,6 +423,7 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
         for (int j = 0; j < nbr_x; j++)                 // the window of the last giants runs into the next block column: those slots are ignored by the finalize
             if (coll_reduce_scatter(mg, R, acc2 + (size_t)j * col, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
     }
+    i8_rotpre_free(pre8);                               // (the tile buffers stay in the context's pool for the next product)
     R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
     R_CTX(R, sfg_reduce_rows_dev(ctx, acc_mine, (size_t)nbr_x * gpr * s * 2, L));
     R_CTX(R, sfg_matmul_finalize_slots_dev(ctx, acc_mine, s, L, nbr_x, gpr, g_lo, 0, gpr, 0, out));
