@@ -58,6 +58,7 @@ struct MgRank {
     ncclComm_t comm = nullptr;
     hipStream_t coll = nullptr;             // the collectives' queue (RCCL kernels beside the MAC of the next column)
     bool own_coll = false;                  // coll was created by the engine (else it is the context's encode queue)
+    hipStream_t spare = nullptr;            // SFG_MGPU_COLL_QUEUE=spare (diagnostics)
     hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_rs[2] = {nullptr, nullptr}, ev_c = nullptr;
     std::string err;
 };
@@ -144,10 +145,15 @@ static void mgpu_read_env(sfg_mgpu *mg) {
 static const char *rank_exec_init(MgRank &R) {
     if (hipSetDevice(R.device) != hipSuccess) return "hipSetDevice failed";
     // The collectives' queue is the context's encode queue (idle unless SFG_MM_ENC_OVERLAP=1 - then the engine makes its own).  Not a fourth queue by default: measured
-    // (tools/r5_order.sh, profiles/r05_mgpu_queue_count.txt), with one more HIP stream alive in the process every kernel of the product's own queue ran 7 - 100 % slower
-    // (a rank's step 1.63 s against 1.43 s) - with GPU_MAX_HW_QUEUES=2, or with the product on a stream the caller made, the effect vanishes.
-    if (R.ctx->cfg.no_enc_overlap || R.ctx->cfg.no_overlap) { R.coll = R.ctx->enc_stream; R.own_coll = false; }
-    else { if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed"; R.own_coll = true; }
+    // (tools/r5_order.sh, tools/r5_collq.sh, profiles/r05_mgpu_queue_count.txt), with a fourth library stream IN USE and the product on the context's own queue every
+    // kernel of the step starts 15 - 30 us later (a rank's step 1.65 s against 1.46 s); a stream that only exists costs nothing, and with GPU_MAX_HW_QUEUES <= 3, or with
+    // the product on a stream the caller made, the effect vanishes - it depends on which hardware queues the runtime hands the streams.
+    const char *cq = getenv("SFG_MGPU_COLL_QUEUE");       // diagnostics (tools/r5_collq.sh): "own" = a queue of the engine's whatever the schedule, "spare" = made but not used
+    const bool own = cq && !strcmp(cq, "own"), spare = cq && !strcmp(cq, "spare");
+    if (!own && (spare || R.ctx->cfg.no_enc_overlap || R.ctx->cfg.no_overlap)) {
+        if (spare && hipStreamCreateWithFlags(&R.spare, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+        R.coll = R.ctx->enc_stream; R.own_coll = false;
+    } else { if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed"; R.own_coll = true; }
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&R.ev_acc[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&R.ev_rs[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     if (hipEventCreateWithFlags(&R.ev_c, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     return nullptr;
@@ -166,6 +172,7 @@ extern "C" void sfg_mgpu_destroy(sfg_mgpu *mg) {
         if (!R.ctx) continue;
         (void)hipSetDevice(R.device);
         if (R.coll && R.own_coll) (void)hipStreamDestroy(R.coll);
+        if (R.spare) (void)hipStreamDestroy(R.spare);
         for (int i = 0; i < 2; i++) { if (R.ev_acc[i]) (void)hipEventDestroy(R.ev_acc[i]); if (R.ev_rs[i]) (void)hipEventDestroy(R.ev_rs[i]); }
         if (R.ev_c) (void)hipEventDestroy(R.ev_c);
         if (R.ctx) sfg_ctx_destroy(R.ctx);
