@@ -349,8 +349,8 @@ def main_lib_engine(args):
     mg.sync()
     ctx0 = mg.ctx[0]
     # Every rank's library queue is an explicit torch stream, as in the N = 1 path and the torch engine: the configuration every single-GPU number of this repository
-    # was measured in.  (Measured in round 5, profiles/r05_mgpu_queue_count.txt: with the product on the context's OWN queue and one more HIP stream alive in the process
-    # every kernel ran 7 - 100 % slower; SFG_BENCH_OWN_STREAM=1 keeps the library's own queues.)
+    # was measured in.  (Measured in round 5, profiles/r05_mgpu_queue_count.txt: with the product on the context's OWN queue and a fourth library stream in use
+    # every kernel started 15 - 30 us later; SFG_BENCH_OWN_STREAM=1 keeps the library's own queues.)
     _streams = []
     if os.environ.get("SFG_BENCH_OWN_STREAM") != "1":
         for i, c in enumerate(mg.ctx):
