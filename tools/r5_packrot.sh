@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_i8_pack_rot: XCD-aware numbering of the workgroups that share a 128-byte source line (SFG_PACK_ROT_SPAN); 50k x 500k, ms per step and the phase's own time
+# (the switch SFG_PACK_ROT_SPAN existed only for this measurement and was removed with the variant: DESIGN.md section 8, Round 5)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05packrot; mkdir -p $O
 run() { local name=$1; shift
   env "$@" python3 bench.py --gpus 1 --config ${CFG:-c3} --steps 3 --warmup 2 --no-cpu-baseline --no-check > $O/$name.log 2>&1
