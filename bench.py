@@ -256,7 +256,7 @@ def roofline_blocks(phase_tot, args, dims, world, dt, value):
                 best = max(ks, key=lambda k: pm[k]["launches"])
                 traffic = pm[best]["hbm_bytes_per_launch"]
                 traffic_src = (f"profiles/{name} (static: separate rocprofv3 --pmc passes at config {pm.get('_config')}; "
-                               "this kernel's launch shape - 1024 plaintexts x 5 moduli - is the same at every config)")
+                               "this kernel's launch shape - 2048 plaintexts x 5 moduli - is the same at every config)")
                 break
     except Exception:
         pass

@@ -80,7 +80,7 @@ struct SfgConfig {
     bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
     size_t ksw_budget = 4ULL << 30; // SFG_KSW_BUDGET_MB      key-switch scratch per input group / job chunk: more jobs per chunk = more reuse of a key (64 MB: +45 %, 1.5 GB: +2 %, 12 GB: -2 %)
-    int enc_batch = 1024;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 64 MB of coefficient rows stay cache resident between the two (measured 256..8192: 1024 is best, 2048 +2.5 %, 512 +4 %)
+    int enc_batch = 2048;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 128 MB of coefficient rows stay cache resident between the two now that the NTT's digit planes leave by streaming stores (round 5: 2048 -3 % of a 50k x 500k step against 1024, 3072 the same, 4096 worse; with plain stores 1024 was best)
     bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)
     // CU partitioning experiments (round 5): restrict a queue of the context to a set of compute units, "lo-hi[,lo-hi...]" over the bits of hipExtStreamCreateWithCUMask
     // (bit i = CU i of the device's enumeration).  Empty = all CUs (the default).  A stream installed by sfg_ctx_set_stream is the caller's and keeps its own mask.

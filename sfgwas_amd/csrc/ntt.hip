@@ -348,6 +348,9 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
 // image X -> X^g of cached row u (perm[t] = u | g << 16): coefficient i of the row becomes coefficient i g mod 2N of the image (>= N: minus coefficient - N), and a
 // row is stored as its first N/2 coefficients (p_{N-c} = -p_c, p_{N/2} = 0).  The rounding of the encoder commutes with this signed permutation, so the NTT input is
 // the very integer polynomial a fresh encode of the rotated diagonal would give.
+// The digit planes are written once and read much later (by the transposition pass, after the whole panel): streaming stores keep them out of the way of the coefficient
+// rows the encode FFT has just left in the cache for this kernel - with them a launch pair takes 2048 plaintexts instead of 1024 (profiles/r05_ntt_streaming_stores.txt)
+#define NT_ST(p, v) __builtin_nontemporal_store((unsigned)(v), (p))
 template <bool PERM, bool DIG>
 __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
                                                       const uint32_t *perm) {
@@ -421,10 +424,10 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
             dig6(x0, l0, h0); dig6(x1, l1, h1); dig6(x2, l2, h2); dig6(x3, l3, h3);
             unsigned o[4]; bytes_tr4(l0, l1, l2, l3, o);
 #pragma unroll
-            for (int d = 0; d < 4; d++) *reinterpret_cast<unsigned *>(o8 + d * n + j0) = o[d];
+            for (int d = 0; d < 4; d++) NT_ST(reinterpret_cast<unsigned *>(o8 + d * n + j0), o[d]);
             unsigned p[4]; bytes_tr4(h0, h1, h2, h3, p);
-            *reinterpret_cast<unsigned *>(o8 + 4 * n + j0) = p[0];
-            *reinterpret_cast<unsigned *>(o8 + 5 * n + j0) = p[1];
+            NT_ST(reinterpret_cast<unsigned *>(o8 + 4 * n + j0), p[0]);
+            NT_ST(reinterpret_cast<unsigned *>(o8 + 5 * n + j0), p[1]);
         };
         if constexpr (PERM) ntt_half3_body<decltype(first), decltype(st6), decltype(fill), true>(0, first, st6, lds, tw, pack, q, qinv, tid, fill);
         else ntt_half3_body<decltype(first), decltype(st6), NoFill, true>(0, first, st6, lds, tw, pack, q, qinv, tid);
@@ -441,8 +444,8 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
             dig(x0, l0, h0); dig(x1, l1, h1); dig(x2, l2, h2); dig(x3, l3, h3);
             unsigned o[4]; bytes_tr4(l0, l1, l2, l3, o);
 #pragma unroll
-            for (int d = 0; d < 4; d++) *reinterpret_cast<unsigned *>(o8 + d * n + j0) = o[d];
-            *reinterpret_cast<unsigned *>(o8 + 4 * n + j0) = (h0 & 255u) | ((h1 & 255u) << 8) | ((h2 & 255u) << 16) | (h3 << 24);
+            for (int d = 0; d < 4; d++) NT_ST(reinterpret_cast<unsigned *>(o8 + d * n + j0), o[d]);
+            NT_ST(reinterpret_cast<unsigned *>(o8 + 4 * n + j0), (h0 & 255u) | ((h1 & 255u) << 8) | ((h2 & 255u) << 16) | (h3 << 24));
         };
         if constexpr (PERM) ntt_half3_body<decltype(first), decltype(st8), decltype(fill), true>(0, first, st8, lds, tw, pack, q, qinv, tid, fill);
         else ntt_half3_body<decltype(first), decltype(st8), NoFill, true>(0, first, st8, lds, tw, pack, q, qinv, tid);

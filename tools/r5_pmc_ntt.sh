@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: exact fabric-side traffic of the dominant kernel k_ntt_half3<false, true> at its product launch shape (1024 plaintexts x 5 moduli:
+# Round 5: exact fabric-side traffic of the dominant kernel k_ntt_half3<false, true> at its product launch shape (2048 plaintexts x 5 moduli since the streaming stores; 1024 before:
 # the same at every config; run at c2) - read AND write requests in separate counter passes - plus two SQ passes (issue / wait breakdown).
 #   R  TCC_EA0_RDREQ_{32B,64B,128B}_sum TCC_EA0_RDREQ_sum      read bytes  = 32 n32 + 64 n64 + 128 n128   (exact: no FETCH_SIZE "x 2" correction)
 #   W  TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum                 write bytes = 64 n64 + 32 (n - n64)
