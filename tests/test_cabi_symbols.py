@@ -159,3 +159,27 @@ def test_go_shim_files_call_only_methods_the_hip_package_defines_with_matching_a
                 assert call_args(code, m.end() - 1) == methods[name], f"{f}: h.{name} called with {call_args(code, m.end() - 1)} arguments, defined with {methods[name]}"
                 checked += 1
     assert checked >= 25
+
+
+def test_library_shard_arithmetic_matches_sharding_py():
+    """sfg_mgpu_shard is host arithmetic (no device): the SNP-block windows the multi-GPU engine gives its ranks are those of sfgwas_amd/sharding.py"""
+    from sfgwas_amd import capi
+    from sfgwas_amd.sharding import snp_block_range
+    lib = capi.lib()
+    for m_snp in (1, 8192, 8193, 100_000, 1_000_000):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                v = [C.c_size_t() for _ in range(4)]
+                assert lib.sfg_mgpu_shard(world, m_snp, r, *[C.byref(x) for x in v]) == 0
+                assert tuple(x.value for x in v) == snp_block_range(m_snp, r, world)
+    assert lib.sfg_mgpu_shard(2, 100, 2, None, None, None, None) != 0 and lib.sfg_mgpu_shard(0, 100, 0, None, None, None, None) != 0
+
+
+def test_multi_gpu_engine_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sfgwas_amd import capi
+    import oracle_lib as ol
+    with pytest.raises(capi.SfgError, match="no HIP device|hip|device"):
+        capi.MultiGpu(ol.Q_PN14, ol.P_PN14, devices=[0, 0])

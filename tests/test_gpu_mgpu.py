@@ -152,18 +152,6 @@ def test_multi_process_entry_at_world_1(ref, monkeypatch):
         mg.close()
 
 
-def test_shard_arithmetic_matches_sharding_py():
-    from sfgwas_amd import capi
-    from sfgwas_amd.sharding import snp_block_range
-    lib = capi.lib()
-    for m_snp in (1, 8192, 8193, 100_000, 1_000_000):
-        for world in (1, 2, 3, 8):
-            for r in range(world):
-                v = [C.c_size_t() for _ in range(4)]
-                assert lib.sfg_mgpu_shard(world, m_snp, r, *[C.byref(x) for x in v]) == 0
-                assert tuple(x.value for x in v) == snp_block_range(m_snp, r, world)
-
-
 def test_errors_are_reported_not_hung(ref, monkeypatch):
     from sfgwas_amd import capi
     geno, small, Ah, Ash, want, wants = ref
