@@ -195,6 +195,18 @@ int sfg_ct_innersum_dev(sfg_ctx *ctx, const uint64_t *in_dev, int nct, int level
 int sfg_geno_upload(sfg_ctx *ctx, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
 int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *geno_dev, size_t nrow, size_t ncol, size_t ld, sfg_geno **out);
 void sfg_geno_free(sfg_ctx *ctx, sfg_geno *g);
+/* Row-streamed registration.  The reference never holds its matrix: MatMult4StreamPreprocess (gwas/matmult.go:914-1041) pulls ONE ROW at a time out of
+ * GenoFileStream.NextRow (gwas/filestream.go:414-426).  sfg_geno_create makes the resident nrow x ncol matrix (contents undefined until written),
+ * sfg_geno_write_rows copies rows [row0, row0 + nrows) from a host chunk (row stride ld; the call returns when the chunk may be refilled), so a caller needs a
+ * staging buffer of a few thousand rows and nothing that scales with nrow * ncol.  sfg_geno_compare_rows compares a chunk of the rows of the matrix arriving now
+ * with the RESIDENT matrix `g` viewed with `flags` (0, or SFG_TRANSPOSE: the rows of its transpose) on the device, entry by entry, and ADDS the number of
+ * differing entries to *ndiff: that is how the second registration of pca.go:112-113 (X, then X^T from its own file) is recognised as a view of the first
+ * without X^T being held anywhere - exactly, not by a hash.  sfg_pinned_alloc / _free: page-locked host memory for the staging buffer (optional). */
+int sfg_geno_create(sfg_ctx *ctx, size_t nrow, size_t ncol, sfg_geno **out);
+int sfg_geno_write_rows(sfg_ctx *ctx, sfg_geno *g, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld);
+int sfg_geno_compare_rows(sfg_ctx *ctx, const sfg_geno *g, unsigned flags, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld, uint64_t *ndiff);
+int sfg_pinned_alloc(sfg_ctx *ctx, void **host_ptr, size_t bytes);
+int sfg_pinned_free(sfg_ctx *ctx, void *host_ptr);
 /* Plaintext coefficient cache of a resident matrix - the device-memory counterpart of the reference's on-disk DiagCache (MatMult4StreamPreprocess,
  * gwas/matmult.go:1228-1334, read back per iteration at :1386-1400).  After this call the products over `g` keep, per 8192 x 8192 block (and per SFG_SQUARE
  * flavour), the encoder's rounded coefficient rows (512 MB) until max_bytes are held; a later product over a cached block - in EITHER orientation: the
@@ -376,6 +388,15 @@ int sfg_mgpu_rank(const sfg_mgpu *mg, int local);
 sfg_ctx *sfg_mgpu_ctx(sfg_mgpu *mg, int local);           /* the context of a local rank: device buffers (sfg_malloc), evaluator ops, phase timers */
 const char *sfg_mgpu_transport(const sfg_mgpu *mg);       /* "none" (world 1), "rccl", "direct" */
 int sfg_mgpu_synchronize(sfg_mgpu *mg);
+/* What the RCCL communicator of local rank `local` itself reports (ncclCommCount / ncclCommUserRank); 0 / 0 when the engine holds none (world 1, direct transport).
+ * A record of a multi-GPU run can state "RCCL saw N ranks" from this instead of trusting the launcher's environment. */
+int sfg_mgpu_comm_info(sfg_mgpu *mg, int local, int *nranks, int *rank);
+/* Pre-flight of the exchange paths, for the first contact with a node (the exchanges stand behind gwas/pca.go:344,352): a reduce-scatter and an all-reduce of
+ * a known uint64 pattern (count_per_rank words per rank slice) through the very functions the products use, on the collectives' queue of every rank, checked on the
+ * host.  Every exchanging call - this one, sfg_mgpu_matmul* with SFG_TRANSPOSE - has an AGREEMENT POINT after its allocations and before its first collective: a rank
+ * that failed so far fails the call on every rank instead of leaving the others waiting in a collective; a rank that fails after it aborts its communicator
+ * (ncclCommAbort), which releases the peers, and the engine then refuses further exchanges. */
+int sfg_mgpu_preflight(sfg_mgpu *mg, size_t count_per_rank);
 /* key material to every local device: cryptoParams.RotKs / Rlk as sfg_ctx_load_rotkey / _relinkey */
 int sfg_mgpu_load_rotkey(sfg_mgpu *mg, uint64_t galois_el, const uint64_t *key_host, int montgomery_form);
 int sfg_mgpu_load_relinkey(sfg_mgpu *mg, const uint64_t *key_host, int montgomery_form);
@@ -393,6 +414,12 @@ const sfg_geno *sfg_mgpu_geno_shard(const sfg_mgeno *g, int local);
 int sfg_mgpu_geno_dims(const sfg_mgeno *g, size_t *nrow, size_t *ncol);
 int sfg_mgpu_geno_blocks(const sfg_mgeno *g, int local, size_t *blk0, size_t *blk1);
 int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *g, size_t max_bytes_per_rank);
+/* The row-streamed forms of sfg_geno_create / _write_rows / _compare_rows on the sharded matrix (MatMult4StreamPreprocess, gwas/matmult.go:914-1041, reads one row
+ * at a time: gwas/filestream.go:414-426): a chunk of whole-matrix rows is scattered to the ranks' column windows; a chunk of the rows of the TRANSPOSE is compared by
+ * the ranks whose windows hold those columns.  *ndiff accumulates over the local ranks. */
+int sfg_mgpu_geno_create(sfg_mgpu *mg, size_t nrow, size_t ncol, sfg_mgeno **out);
+int sfg_mgpu_geno_write_rows(sfg_mgpu *mg, sfg_mgeno *g, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld);
+int sfg_mgpu_geno_compare_rows(sfg_mgpu *mg, const sfg_mgeno *g, unsigned flags, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld, uint64_t *ndiff);
 /* MatMult4StreamCompute (matmult.go:1043-1236) on the sharded matrix.  Device-pointer form, A_dev[i] / out_dev[i] on local rank i's device:
  *   flags = 0 or SFG_SQUARE  (Q * X):    A_dev[i] = the whole input grid [s][ceil(nrow / 8192)] (replicated);  out_dev[i] = [s][blk1 - blk0], the rank's block columns
  *   | SFG_TRANSPOSE          (Q' * X^T): A_dev[i] = [s][blk1 - blk0], the inputs of the rank's SNP blocks;    out_dev[i] = the whole [s][ceil(nrow / 8192)], on every rank

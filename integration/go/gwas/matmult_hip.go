@@ -16,6 +16,8 @@ import (
 // readAllRows drains a GenoFileStream into one row-major int8 matrix: filters applied by the stream (filestream.go:345-355,
 // 419-423), values as stored (-1 = missing; the device zeroes negatives before sums and products as matmult.go:1292-1295 does).
 // NOTE: construct the stream with replaceMissing = false or true - both give the same product; with true the -1s are already 0.
+// Used by MatMult4Stream only, whose matrix is one association batch (assoc.go:371-424: 8192 SNPs of a chromosome file, or one block);
+// the PCA matrices go through MatMult4StreamPreprocess below, which never holds them.
 func readAllRows(gfs *GenoFileStream) ([]int8, int, int) {
 	gfs.Reset()
 	nrow, ncol := int(gfs.NumRowsToKeep()), int(gfs.NumColsToKeep())
@@ -77,8 +79,10 @@ func MatMult4StreamPreprocess(cps *crypto.CryptoParams, gfs *GenoFileStream, max
 	if hip.LookupGeno(cacheFilePrefix) != nil {
 		return // "skips existing files" (matmult.go:928-931)
 	}
-	geno, nrow, ncol := readAllRows(gfs)
-	hip.Default.RegisterGeno(cacheFilePrefix, geno, nrow, ncol)
+	// one row at a time, as the reference reads it (matmult.go:942-950: gfs.NextRow() per row of a block): hip.RegisterGeno fills a pinned staging buffer of
+	// at most 128 MB from this callback and hands the chunks to the device - nothing here scales with nrow * ncol
+	nrow, ncol := int(gfs.NumRowsToKeep()), int(gfs.NumColsToKeep())
+	hip.Default.RegisterGeno(cacheFilePrefix, nrow, ncol, gfs.NextRow, gfs.Reset)
 }
 
 // MatMult4StreamCompute - gwas/matmult.go:1043-1236, PCA path.

@@ -23,7 +23,6 @@ import "C"
 
 import (
 	"fmt"
-	"runtime"
 	"sync"
 	"unsafe"
 
@@ -290,18 +289,17 @@ type Geno struct {
 	NCol  int
 }
 
-// residentGeno is one uploaded matrix: its handle, stored shape and an order-independent content fingerprint.
+// residentGeno is one registered matrix: its handle and stored shape.
 type residentGeno struct {
 	g          *C.sfg_geno
 	mg         *C.sfg_mgeno
 	nrow, ncol int
-	print      uint64
 }
 
 var (
 	genoMu    sync.Mutex
 	genoByKey = map[string]*Geno{}
-	resident  []residentGeno // uploaded matrices, to find X when X^T is registered
+	resident  []residentGeno // registered matrices, to find X when X^T is registered
 )
 
 const (
@@ -309,69 +307,68 @@ const (
 	FlagTranspose = uint(C.SFG_TRANSPOSE)
 )
 
-// genoFingerprint is sum over (i, j) of mix(i, j, M[i][j]) mod 2^64 over the STORED orientation of a matrix: a sum, so that it can be
-// evaluated in any traversal order - in particular over the rows of a candidate transpose (transposed = true swaps the roles of the
-// two indices).  Two different matrices of the same shape collide with probability ~2^-64.  One pass, split over the CPUs.
-func genoFingerprint(rows []int8, nrow, ncol int, transposed bool) uint64 {
-	mix := func(i, j uint64, v int8) uint64 {
-		z := (i*0x9E3779B97F4A7C15 ^ j*0xC2B2AE3D27D4EB4F) + uint64(uint8(v))*0x165667B19E3779F9
-		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9
-		z = (z ^ (z >> 27)) * 0x94D049BB133111EB
-		return z ^ (z >> 31)
+// stagingRows is the number of matrix rows one chunk of the row-streamed registration carries: the staging buffer holds
+// stagingRows * ncol bytes of page-locked memory (sfg_pinned_alloc), at most stagingBytes - nothing in this package scales with nrow * ncol.
+const stagingBytes = 128 << 20
+
+func stagingRows(ncol int) int {
+	n := stagingBytes / ncol
+	if n < 1 {
+		n = 1
 	}
-	nw := runtime.NumCPU()
-	if nw > nrow {
-		nw = nrow
-	}
-	part := make([]uint64, nw)
-	var wg sync.WaitGroup
-	for w := 0; w < nw; w++ {
-		wg.Add(1)
-		go func(w int) {
-			defer wg.Done()
-			var acc uint64
-			for r := w * nrow / nw; r < (w+1)*nrow/nw; r++ {
-				row := rows[r*ncol : (r+1)*ncol]
-				for c, v := range row {
-					if transposed {
-						acc += mix(uint64(c), uint64(r), v)
-					} else {
-						acc += mix(uint64(r), uint64(c), v)
-					}
-				}
-			}
-			part[w] = acc
-		}(w)
-	}
-	wg.Wait()
-	var sum uint64
-	for _, a := range part {
-		sum += a
-	}
-	return sum
+	return n
 }
 
-// RegisterGeno uploads (or re-uses) the matrix behind a cache prefix.  rows is the row-major int8 matrix as GenoFileStream
-// delivers it (filters applied, missing = -1 kept: the device zeroes negatives before sums and products, matmult.go:1292-1300).
-// If the TRANSPOSE of this matrix is already resident - same shape swapped AND the same content (fingerprint of `rows` read as a
-// transpose = fingerprint of the stored matrix; shape alone would also match an unrelated second n x n matrix) - it is reused
-// with SFG_TRANSPOSE instead of uploading a second copy (pca.go:112-113 registers X, then X^T).
-func (h *Ctx) RegisterGeno(prefix string, rows []int8, nrow, ncol int) *Geno {
+// streamRows drives `visit(row0, nrows, chunk)` over the rows that next() yields (GenoFileStream.NextRow, filestream.go:414-426: one row per call, filters
+// applied), nrows rows of ncol bytes at a time in a pinned staging buffer.  visit returns false to stop early.
+func (h *Ctx) streamRows(nrow, ncol int, next func() []int8, visit func(row0, nrows int, chunk unsafe.Pointer) bool) {
+	per := stagingRows(ncol)
+	var buf unsafe.Pointer
+	h.check(C.sfg_pinned_alloc(h.p, &buf, C.size_t(per*ncol)), "pinned_alloc")
+	defer C.sfg_pinned_free(h.p, buf)
+	stage := unsafe.Slice((*int8)(buf), per*ncol)
+	for row0 := 0; row0 < nrow; row0 += per {
+		n := per
+		if nrow-row0 < n {
+			n = nrow - row0
+		}
+		for r := 0; r < n; r++ {
+			copy(stage[r*ncol:(r+1)*ncol], next())
+		}
+		if !visit(row0, n, buf) {
+			return
+		}
+	}
+}
+
+// RegisterGeno makes the matrix behind a cache prefix resident, reading it the way the reference does - one row at a time (MatMult4StreamPreprocess,
+// matmult.go:914-1041: gfs.NextRow per row) - so that no host allocation scales with nrow * ncol.  next() yields the rows in order (filters applied, missing = -1
+// kept: the device zeroes negatives before sums and products, matmult.go:1292-1300); reset() rewinds the stream (GenoFileStream.Reset, filestream.go:362-376).
+// If the TRANSPOSE of the arriving matrix is already resident (pca.go:112-113 registers X, then X^T from its own file) it is recognised on the device: every
+// chunk of arriving rows is compared, entry by entry, with the resident matrix read as its transpose (sfg_geno_compare_rows) - exact, not a hash, and X^T is never
+// held anywhere.  The prefix then becomes a SFG_TRANSPOSE view of the one int8 copy.  A shape match with different content (a second, unrelated n x n matrix) falls
+// through to a second pass over the stream that uploads it.
+func (h *Ctx) RegisterGeno(prefix string, nrow, ncol int, next func() []int8, reset func()) *Geno {
 	genoMu.Lock()
 	defer genoMu.Unlock()
 	if g, ok := genoByKey[prefix]; ok {
 		return g
 	}
-	var asTranspose uint64
-	haveT := false
 	for _, r := range resident {
 		if r.nrow != ncol || r.ncol != nrow {
 			continue
 		}
-		if !haveT {
-			asTranspose, haveT = genoFingerprint(rows, nrow, ncol, true), true
-		}
-		if r.print == asTranspose {
+		var ndiff C.uint64_t
+		reset()
+		h.streamRows(nrow, ncol, next, func(row0, n int, chunk unsafe.Pointer) bool {
+			if r.mg != nil {
+				h.mcheck(C.sfg_mgpu_geno_compare_rows(h.mg, r.mg, C.SFG_TRANSPOSE, C.size_t(row0), C.size_t(n), (*C.int8_t)(chunk), C.size_t(ncol), &ndiff), "mgpu_geno_compare_rows")
+			} else {
+				h.check(C.sfg_geno_compare_rows(h.p, r.g, C.SFG_TRANSPOSE, C.size_t(row0), C.size_t(n), (*C.int8_t)(chunk), C.size_t(ncol), &ndiff), "geno_compare_rows")
+			}
+			return ndiff == 0 // the first differing chunk settles it
+		})
+		if ndiff == 0 {
 			e := &Geno{r.g, r.mg, FlagTranspose, nrow, ncol}
 			genoByKey[prefix] = e
 			return e
@@ -382,11 +379,20 @@ func (h *Ctx) RegisterGeno(prefix string, rows []int8, nrow, ncol int) *Geno {
 	if h.mg != nil {
 		// the STORED orientation is the one whose columns are sharded over the GPUs: pca.go:112-113 registers X (individuals x SNPs) first, so SNP blocks
 		// are the shards, Q * X is output-sharded and Q' * X^T contraction-sharded, as SURVEY 8e lays out
-		h.mcheck(C.sfg_mgpu_geno_upload(h.mg, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &m), "mgpu_geno_upload")
+		h.mcheck(C.sfg_mgpu_geno_create(h.mg, C.size_t(nrow), C.size_t(ncol), &m), "mgpu_geno_create")
 	} else {
-		h.check(C.sfg_geno_upload(h.p, (*C.int8_t)(unsafe.Pointer(&rows[0])), C.size_t(nrow), C.size_t(ncol), C.size_t(ncol), &g), "geno_upload")
+		h.check(C.sfg_geno_create(h.p, C.size_t(nrow), C.size_t(ncol), &g), "geno_create")
 	}
-	resident = append(resident, residentGeno{g, m, nrow, ncol, genoFingerprint(rows, nrow, ncol, false)})
+	reset()
+	h.streamRows(nrow, ncol, next, func(row0, n int, chunk unsafe.Pointer) bool {
+		if m != nil {
+			h.mcheck(C.sfg_mgpu_geno_write_rows(h.mg, m, C.size_t(row0), C.size_t(n), (*C.int8_t)(chunk), C.size_t(ncol)), "mgpu_geno_write_rows")
+		} else {
+			h.check(C.sfg_geno_write_rows(h.p, g, C.size_t(row0), C.size_t(n), (*C.int8_t)(chunk), C.size_t(ncol)), "geno_write_rows")
+		}
+		return true
+	})
+	resident = append(resident, residentGeno{g, m, nrow, ncol})
 	e := &Geno{g, m, 0, nrow, ncol}
 	genoByKey[prefix] = e
 	return e

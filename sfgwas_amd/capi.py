@@ -83,6 +83,11 @@ def _sig(L):
         "sfg_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_from_device": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_geno_free": (None, [vp, vp]),
+        "sfg_geno_create": (i, [vp, sz, sz, C.POINTER(vp)]),
+        "sfg_geno_write_rows": (i, [vp, vp, sz, sz, vp, sz]),
+        "sfg_geno_compare_rows": (i, [vp, vp, C.c_uint, sz, sz, vp, sz, u64p]),
+        "sfg_pinned_alloc": (i, [vp, C.POINTER(vp), sz]),
+        "sfg_pinned_free": (i, [vp, vp]),
         "sfg_geno_set_plaintext_cache": (i, [vp, vp, C.c_size_t]),
         "sfg_geno_plaintext_cache_stats": (i, [vp, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "sfg_geno_from_bed": (i, [vp, vp, sz, sz, sz, vp, vp, C.POINTER(vp)]),
@@ -137,6 +142,11 @@ def _sig(L):
         "sfg_mgpu_shard": (i, [i, sz, i, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "sfg_mgpu_geno_upload": (i, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
         "sfg_mgpu_geno_adopt": (i, [vp, sz, sz, C.POINTER(vp), C.POINTER(vp)]),
+        "sfg_mgpu_geno_create": (i, [vp, sz, sz, C.POINTER(vp)]),
+        "sfg_mgpu_geno_write_rows": (i, [vp, vp, sz, sz, vp, sz]),
+        "sfg_mgpu_geno_compare_rows": (i, [vp, vp, C.c_uint, sz, sz, vp, sz, u64p]),
+        "sfg_mgpu_comm_info": (i, [vp, i, C.POINTER(i), C.POINTER(i)]),
+        "sfg_mgpu_preflight": (i, [vp, sz]),
         "sfg_mgpu_geno_synthetic": (i, [vp, sz, sz, u64, i, C.POINTER(vp)]),
         "sfg_mgpu_geno_free": (None, [vp, vp]),
         "sfg_mgpu_geno_shard": (vp, [vp, i]),
@@ -595,6 +605,25 @@ def _ctx_geno_free(self, g):
     lib().sfg_geno_free(self.h, g)
 
 
+def _ctx_geno_create(self, nrow, ncol):
+    g = C.c_void_p()
+    self.check(lib().sfg_geno_create(self.h, nrow, ncol, C.byref(g)), "geno_create")
+    return g
+
+
+def _ctx_geno_write_rows(self, g, row0, rows, ld=None):
+    """rows: int8 [nrows][>= ncol] (a C-contiguous chunk of whole rows; ld = its row stride)"""
+    rows = np.ascontiguousarray(rows, dtype=np.int8)
+    self.check(lib().sfg_geno_write_rows(self.h, g, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p), ld or rows.shape[1]), "geno_write_rows")
+
+
+def _ctx_geno_compare_rows(self, g, flags, row0, rows):
+    rows = np.ascontiguousarray(rows, dtype=np.int8)
+    nd = np.zeros(1, dtype=np.uint64)
+    self.check(lib().sfg_geno_compare_rows(self.h, g, flags, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p), rows.shape[1], p64(nd)), "geno_compare_rows")
+    return int(nd[0])
+
+
 def _ctx_fill_uniform_cts(self, nct, level, seed):
     d = DevArray(self, (nct, 2, level + 1, self.N))
     self.check(lib().sfg_fill_uniform_ct_dev(self.h, d.p, nct, level, seed), "fill_uniform_ct")
@@ -644,6 +673,9 @@ def _ctx_matmul_finalize(self, acc, s, max_level, ncolb, g0, g1, out=None):
 
 Context.geno_upload = _ctx_geno_upload
 Context.geno_free = _ctx_geno_free
+Context.geno_create = _ctx_geno_create
+Context.geno_write_rows = _ctx_geno_write_rows
+Context.geno_compare_rows = _ctx_geno_compare_rows
 Context.fill_uniform_cts = _ctx_fill_uniform_cts
 Context.fill_geno = _ctx_fill_geno
 Context.matmul_resident = _ctx_matmul_resident
@@ -717,6 +749,29 @@ class MultiGpu:
         g = C.c_void_p()
         self.check(lib().sfg_mgpu_geno_upload(self.h, geno.ctypes.data_as(C.c_void_p), geno.shape[0], geno.shape[1], geno.shape[1], C.byref(g)), "sfg_mgpu_geno_upload")
         return g
+
+    def geno_create(self, nrow, ncol):
+        g = C.c_void_p()
+        self.check(lib().sfg_mgpu_geno_create(self.h, nrow, ncol, C.byref(g)), "sfg_mgpu_geno_create")
+        return g
+
+    def geno_write_rows(self, g, row0, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int8)
+        self.check(lib().sfg_mgpu_geno_write_rows(self.h, g, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p), rows.shape[1]), "sfg_mgpu_geno_write_rows")
+
+    def geno_compare_rows(self, g, flags, row0, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int8)
+        nd = np.zeros(1, dtype=np.uint64)
+        self.check(lib().sfg_mgpu_geno_compare_rows(self.h, g, flags, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p), rows.shape[1], p64(nd)), "sfg_mgpu_geno_compare_rows")
+        return int(nd[0])
+
+    def preflight(self, count_per_rank=4096):
+        self.check(lib().sfg_mgpu_preflight(self.h, count_per_rank), "sfg_mgpu_preflight")
+
+    def comm_info(self, local=0):
+        n, r = C.c_int(), C.c_int()
+        self.check(lib().sfg_mgpu_comm_info(self.h, local, C.byref(n), C.byref(r)), "sfg_mgpu_comm_info")
+        return n.value, r.value
 
     def geno_synthetic(self, nrow, ncol, seed, packed=False):
         g = C.c_void_p()

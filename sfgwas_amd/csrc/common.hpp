@@ -80,6 +80,9 @@ struct SfgConfig {
     bool ntt_half_full = false;    // SFG_NTT_HALF_IMPL=full
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
     size_t ksw_budget = 4ULL << 30; // SFG_KSW_BUDGET_MB      key-switch scratch per input group / job chunk: more jobs per chunk = more reuse of a key (64 MB: +45 %, 1.5 GB: +2 %, 12 GB: -2 %)
+    std::string test_scratch_oom;  // SFG_TEST_SCRATCH_OOM=name:n  (test switch only) the n-th request of scratch buffer `name` inside a top-level call behaves as if the device were full: the eviction path of sfg_scratch runs
+    int i8_mover = 1280;           // SFG_I8_MOVER           workgroups of the plaintext transposition in its mover form (i8_move.hpp); 0 = the round-3 pass k_i8_pack_pt_digits (A/B)
+    int i8_mover_depth = 3;        // SFG_I8_MOVER_DEPTH     units (32 KiB) a mover workgroup keeps in flight + 1
     int enc_batch = 2048;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 128 MB of coefficient rows stay cache resident between the two now that the NTT's digit planes leave by streaming stores (round 5: 2048 -3 % of a 50k x 500k step against 1024, 3072 the same, 4096 worse; with plain stores 1024 was best)
     bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)
     // CU partitioning experiments (round 5): restrict a queue of the context to a set of compute units, "lo-hi[,lo-hi...]" over the bits of hipExtStreamCreateWithCUMask
@@ -148,6 +151,7 @@ struct sfg_ctx {
     std::map<std::string, std::pair<void *, size_t>> host_pool;   // named grow-only PINNED host scratch (sfg_host_scratch): the streamed scan's two file slots; freed with the context and by sfg_ctx_release_scratch
     std::map<std::string, unsigned long long> pool_epoch;    // the top-level call (ApiScope) that last asked for the buffer: when the device is full, buffers no call in progress uses are given back
     unsigned long long api_epoch = 0; int api_depth = 0;
+    int scratch_oom_seen = 0;                               // requests of cfg.test_scratch_oom's buffer so far (test switch)
     std::vector<PendingEvent> pending;                      // phase timers not yet read back (resolved by sfg_phases_resolve)
     std::string err;
     std::map<std::string, PhaseStat> phases;

@@ -39,6 +39,7 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_STAGE_GIANTS")) { c.stage_giants = atoi(e); if (c.stage_giants < 1) c.stage_giants = 1; if (c.stage_giants > 91) c.stage_giants = 91; }
     if (const char *e = env("SFG_STAGE_SAMEQ")) c.stage_same_queue = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
+    if (const char *e = env("SFG_TEST_SCRATCH_OOM")) { if (c.test_hooks) c.test_scratch_oom = e; }
     if (const char *e = env("SFG_TEST_TIE_BAND_LOG2")) { if (c.test_hooks) c.tie_band = ldexp(1.0, atoi(e)); }       // test hook: a wider band sends ordinary coefficients through the exact re-derivation
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
     if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
@@ -56,6 +57,8 @@ static void read_config(SfgConfig &c) {
     if (const char *e = env("SFG_ASSOC_I8")) c.assoc_i8 = atoi(e) != 0;
     if (const char *e = env("SFG_ASSOC_ROTCACHE_MB")) c.assoc_cache_budget = (size_t)atoll(e) << 20;
     if (const char *e = env("SFG_KSW_BUDGET_MB")) { c.ksw_budget = (size_t)atoll(e) << 20; if (c.ksw_budget < (16ULL << 20)) c.ksw_budget = 16ULL << 20; }
+    if (const char *e = env("SFG_I8_MOVER")) { c.i8_mover = atoi(e); if (c.i8_mover < 0) c.i8_mover = 0; c.i8_mover = c.i8_mover / 8 * 8; }
+    if (const char *e = env("SFG_I8_MOVER_DEPTH")) { c.i8_mover_depth = atoi(e); if (c.i8_mover_depth < 1 || c.i8_mover_depth > 3) c.i8_mover_depth = 3; }
     if (const char *e = env("SFG_ENC_BATCH")) { c.enc_batch = atoi(e); if (c.enc_batch < 64) c.enc_batch = 64; if (c.enc_batch > 8192) c.enc_batch = 8192; }
 }
 
@@ -322,11 +325,17 @@ void sfg_phases_resolve(sfg_ctx *ctx) {
 int sfg_scratch(sfg_ctx *ctx, const char *name, size_t bytes, void **out) {
     auto &e = ctx->pool[name];
     ctx->pool_epoch[name] = ctx->api_epoch;
-    if (e.second < bytes) {
+    bool inject = false;                                            // test switch: "the device is full" on the n-th request of one named buffer (tests/test_gpu_mgpu.py)
+    if (ctx->test_hooks && !ctx->cfg.test_scratch_oom.empty() && ctx->api_depth > 0) {
+        const std::string &t = ctx->cfg.test_scratch_oom; const size_t c = t.rfind(':');
+        if (t.compare(0, c, name) == 0 && strlen(name) == (c == std::string::npos ? t.size() : c))
+            inject = ++ctx->scratch_oom_seen == (c == std::string::npos ? 1 : atoi(t.c_str() + c + 1));
+    }
+    if (e.second < bytes || inject) {
         SFG_TRY(sfg_sync_all(ctx));
         if (e.first) SFG_HIP(ctx, hipFree(e.first));
         e.first = nullptr; e.second = 0;
-        hipError_t err = hipMalloc(&e.first, bytes);
+        hipError_t err = inject ? hipErrorOutOfMemory : hipMalloc(&e.first, bytes);
         if (err != hipSuccess && ctx->api_depth > 0) {
             // The pools grow to the largest shape each buffer has served and are kept for the next call of that shape.  When the device is full, give back what
             // only EARLIER top-level calls asked for (nothing of the call in progress: every buffer it uses was requested under its epoch) and try once more.

@@ -15,6 +15,7 @@
 // k_i8_untile adds them into the canonical accumulators with coefficient-contiguous runs.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "i8_move.hpp"            // I8Args, I8_PD and the low-occupancy form of the plaintext transposition
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -50,14 +51,6 @@ template <int NS> __device__ __forceinline__ double i8_horner(const v4i (&a)[NS]
     }
     return r < 0 ? r + q : r;
 }
-
-struct I8Args {
-    const double *rotf; const u64 *pt; u64 *out;
-    size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
-    int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt, pt_digits;
-    int kb;                                // 0: k is the row of the rot operand; else k' = g * kb + baby with baby < 91 real (streamed plaintext tiles: block rows start on a dword)
-    int8_t *A, *B; u64 *T;
-};
 
 // ---- rot planes -> A.  workgroup = (modulus m, chunk ch, 8 coefficients): 64 k x 32 rows x 8 coefficients through an 80 (96) KiB digit image.
 // ND = 6: the 46-bit modulus, whose fp64 plane holds the signed split {lo 23 bits, hi} per coefficient (k_rot_to_f64): v = hi 2^23 + lo
@@ -138,7 +131,6 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
 // column tile jt, 16 k, 128 coefficients), one digit at a time: 256 (k, column) rows of 128 contiguous bytes in; a lane takes four consecutive k of FOUR consecutive
 // coefficients (a dword each) and a 4 x 4 byte transpose turns them into one dword of four k per coefficient.  Image [cc 128][j 16][k4 4] dwords, j and k4 XORed with
 // bits of the lane's coefficient group so that the 32 lanes of a row group hit 32 banks.
-constexpr int I8_PD = 128;
 template <int ND>
 __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
     __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
@@ -182,6 +174,13 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
         }
         __syncthreads();
     }
+}
+// ---- the same as a low-occupancy mover (i8_move.hpp): job.nblocks workgroups (one per CU) walk the items with the next units' loads in flight in registers.
+// Alone on the chip this is the A/B of the pass above; its place is in front of the plaintext NTT's workgroups (k_ntt_half3_move, ntt.hip).
+template <int DEPTH, bool NT>
+__global__ void __launch_bounds__(256, 4) k_i8_move_pt(MoveJob job) {
+    __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
+    i8_move_block<DEPTH, NT>(job, blockIdx.x, img, (int)threadIdx.x);
 }
 // ---- the same from the DENSE digit planes of one encode batch (StagePack, kernels.hpp): plaintext p of the batch is shift shift0 + p = giant n, baby b of block
 // row g; its byte goes to column n, k' = g * kb + b.  A workgroup = (modulus, column tile jt, 16 k', 128 coefficients) as above, restricted to what this batch
@@ -510,6 +509,13 @@ int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, 
 }
 // bytes of the tile buffer of `nl` moduli with ND digits for K' contraction steps
 size_t mac_i8_tile_bytes(int Kp, int nl, int ND) { return (size_t)nl * (SFG_N / 2) * 6 * (((size_t)Kp + 63) / 64) * ND * 1024; }
+static void launch_move_alone(hipStream_t q, const MoveJob &j) {
+#define SFG_MV(D, T) hipLaunchKernelGGL((k_i8_move_pt<D, T>), dim3(j.nblocks), dim3(256), 0, q, j)
+    if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); }
+    else if (j.depth == 2) { if (j.nt) SFG_MV(2, true); else SFG_MV(2, false); }
+    else { if (j.nt) SFG_MV(1, true); else SFG_MV(1, false); }
+#undef SFG_MV
+}
 template <int ND>
 static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                             int l0, int nl, int accumulate, const MacStrides &st) {
@@ -577,7 +583,14 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * ND * 1024, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K_rot * std::min(32, R - r0) * (BIG ? 16.0 : 8.0) + (double)a.nch * 2 * ND * tile)); }
     if (!B_pre) { PhaseTimer t(ctx, "mac_i8_pack_pt");
-      if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD))), dim3(256), 0, ctx->stream, a);
+      const unsigned items = (unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD));
+      if (a.pt_digits && ctx->cfg.i8_mover > 0 && a.pt_n_stride * 8 < (1ULL << 31)) {      // the mover form of the pass (i8_move.hpp): fewer, longer-lived workgroups with the next units' loads in flight
+          MoveJob j; memset(&j.a5, 0, sizeof j.a5); memset(&j.a6, 0, sizeof j.a6);
+          if (ND == 5) { j.a5 = a; j.n5 = items; } else { j.a6 = a; j.n6 = items; }
+          j.first = 0; j.count = items; j.nblocks = std::min((unsigned)ctx->cfg.i8_mover, (items + 7u) / 8u * 8u); j.depth = ctx->cfg.i8_mover_depth; j.nt = 0;
+          launch_move_alone(ctx->stream, j);
+      }
+      else if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits<ND>, dim3(items), dim3(256), 0, ctx->stream, a);
       else hipLaunchKernelGGL(k_i8_pack_pt<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
     { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
@@ -674,4 +687,107 @@ extern "C" int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t 
     }
     (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rotf); (void)hipFree(ptp);
     return rc;
+}
+
+// ---- round 6: the mover (i8_move.hpp) against the pass, alone and in front of the plaintext NTT's workgroups.  Test hooks, not part of the C-ABI header.
+__global__ void __launch_bounds__(256) k_ub_fill(u64 *p, size_t n, u64 seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        u64 z = (i + seed) * 0x9E3779B97F4A7C15ULL; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32; p[i] = z;
+    }
+}
+__global__ void __launch_bounds__(256) k_ub_diff(const u64 *a, const u64 *b, size_t n, unsigned long long *cnt) {
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += a[i] != b[i];
+    if (c) atomicAdd(cnt, c);
+}
+static int move_job_for(sfg_ctx *ctx, const u64 *panel, int G, int L, int8_t *Bs, int8_t *Bb, MoveJob &pj) {
+    const int H = SFG_N / 2, d = SFG_D;
+    std::vector<int> plane_of, is_big; if (mac_dma_planes(ctx, L, plane_of, is_big) < 0) return 1;
+    int l_big = -1, l_small0 = -1, n_small = 0;
+    for (int l = 0; l < L; l++) { if (is_big[l]) l_big = l; else { if (l_small0 < 0) l_small0 = l; n_small++; } }
+    if (l_big < 0 || n_small != L - 1) SFG_FAIL(ctx, "mover: expects one 46-bit modulus and 35-bit ones");
+    const size_t plw = (size_t)L * H;
+    const int K = G * d, nch = (K + 63) / 64;
+    auto fill = [&](I8Args &a, int l0, int nl, int8_t *B) {
+        memset(&a, 0, sizeof a);
+        a.pt = panel; a.pt_k_stride = plw; a.pt_n_stride = (size_t)G * d * plw; a.pt_l_stride = H; a.K = K; a.Ncols = d; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = 6; a.pt_digits = 1; a.B = B;
+    };
+    fill(pj.a5, l_small0, n_small, Bs); fill(pj.a6, l_big, 1, Bb);
+    pj.n5 = (unsigned)(n_small * 6 * nch * 4 * (H / I8_PD)); pj.n6 = (unsigned)(6 * nch * 4 * (H / I8_PD));
+    if (pj.a5.pt_n_stride * 8 >= (1ULL << 32) / 2) SFG_FAIL(ctx, "mover: panel column stride does not fit the 32-bit lane offset");
+    return 0;
+}
+// mode 0: NTTs then the pass; 2: NTTs alone; 3: the pass alone; 4: the mover alone (nblocks workgroups); 5: mover workgroups in front of every NTT launch;
+// 6: check - random panel bytes through the pass and through the mover (alone), *ms_out = number of differing tile words (0 = identical);
+// 7: the same with the mover riding in NTT launches (the NTT writes another panel).  G block rows of 8281 plaintexts, cfg.enc_batch plaintexts per NTT launch.
+extern "C" int ubench_ntt_move(sfg_ctx *ctx, int mode, int G, int nblocks, int depth, int nt, int reps, double *ms_out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->test_hooks) SFG_FAIL(ctx, "ubench_ntt_move is a test hook: set SFG_ENABLE_TEST_HOOKS=1");
+    if (G < 1 || G > 24 || nblocks < 8 || nblocks % 8 || depth < 1 || depth > 3) SFG_FAIL(ctx, "ubench_ntt_move: bad arguments");
+    const int N = SFG_N, H = N / 2, L = 5, d = SFG_D;
+    const size_t plw = (size_t)L * H, nplain = (size_t)d * d, batch = (size_t)ctx->cfg.enc_batch;
+    const size_t total = (size_t)G * nplain; const int launches = (int)((total + batch - 1) / batch);
+    const bool check = mode == 6 || mode == 7;
+    double *pc; u64 *panel, *panel2 = nullptr; int8_t *Bs, *Bb, *Bs2 = nullptr, *Bb2 = nullptr;
+    const int K = G * d;
+    const size_t nBs = mac_i8_tile_bytes(K, 4, 5), nBb = mac_i8_tile_bytes(K, 1, 6);
+    SFG_TRY(sfg_scratch(ctx, "ub.pc", batch * H * 8, (void **)&pc));
+    SFG_TRY(sfg_scratch(ctx, "ub.pt", total * plw * 8 + (1 << 20), (void **)&panel));
+    SFG_TRY(sfg_scratch(ctx, "ub.Bs", nBs, (void **)&Bs));
+    SFG_TRY(sfg_scratch(ctx, "ub.Bb", nBb, (void **)&Bb));
+    if (check || mode == 5) SFG_TRY(sfg_scratch(ctx, "ub.pt2", total * plw * 8 + (1 << 20), (void **)&panel2));
+    if (check) { SFG_TRY(sfg_scratch(ctx, "ub.Bs2", nBs, (void **)&Bs2)); SFG_TRY(sfg_scratch(ctx, "ub.Bb2", nBb, (void **)&Bb2)); }
+    SFG_HIP(ctx, hipMemsetAsync(pc, 0, batch * H * 8, ctx->stream));
+    MoveJob pj; SFG_TRY(move_job_for(ctx, panel, G, L, Bs, Bb, pj));
+    pj.nblocks = (unsigned)nblocks; pj.depth = depth; pj.nt = nt;
+    PanelMap pm; pm.G = 0; pm.g = 0; pm.shift0 = 0; pm.packed_mask = mac_dma_packed_mask(ctx, L) | 0x80000000u | 0x40000000u;
+    auto pack_alone = [&](const MoveJob &j) {
+        hipLaunchKernelGGL(k_i8_pack_pt_digits<5>, dim3(j.n5), dim3(256), 0, ctx->stream, j.a5);
+        hipLaunchKernelGGL(k_i8_pack_pt_digits<6>, dim3(j.n6), dim3(256), 0, ctx->stream, j.a6);
+    };
+    // NTT launches (into ntt_out) with the job's items spread evenly over them
+    auto ntts = [&](u64 *ntt_out, const MoveJob *mv) -> int {
+        unsigned next = 0; const unsigned all = mv ? mv->n5 + mv->n6 : 0u, per = mv ? (all + launches - 1) / launches : 0u;
+        for (int i = 0; i < launches; i++) {
+            const size_t lo = (size_t)i * batch, nb = std::min(batch, total - lo);
+            MoveJob j; if (mv) { j = *mv; j.first = next; j.count = std::min(per, all - next); next += j.count; }
+            SFG_TRY(launch_ntt_plain_half(ctx, pc, ntt_out + lo * plw, nb, L, pm, nullptr, mv ? &j : nullptr));
+        }
+        if (mv && next != all) SFG_FAIL(ctx, "ubench_ntt_move: %u items left over", all - next);
+        return 0;
+    };
+    if (check) {
+        hipLaunchKernelGGL(k_ub_fill, dim3(4096), dim3(256), 0, ctx->stream, panel, total * plw, (u64)G * 977u);
+        SFG_HIP(ctx, hipMemsetAsync(Bs, 0x5A, nBs, ctx->stream)); SFG_HIP(ctx, hipMemsetAsync(Bb, 0x5A, nBb, ctx->stream));
+        SFG_HIP(ctx, hipMemsetAsync(Bs2, 0xA5, nBs, ctx->stream)); SFG_HIP(ctx, hipMemsetAsync(Bb2, 0xA5, nBb, ctx->stream));
+        pack_alone(pj);
+        MoveJob j2 = pj; j2.a5.B = Bs2; j2.a6.B = Bb2; j2.first = 0; j2.count = pj.n5 + pj.n6;
+        if (mode == 6) launch_move_alone(ctx->stream, j2); else SFG_TRY(ntts(panel2, &j2));
+        unsigned long long *cnt; SFG_TRY(sfg_scratch(ctx, "ub.cnt", 8, (void **)&cnt));
+        SFG_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_ub_diff, dim3(4096), dim3(256), 0, ctx->stream, (const u64 *)Bs, (const u64 *)Bs2, nBs / 8, cnt);
+        hipLaunchKernelGGL(k_ub_diff, dim3(4096), dim3(256), 0, ctx->stream, (const u64 *)Bb, (const u64 *)Bb2, nBb / 8, cnt);
+        unsigned long long h = 0;
+        SFG_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream)); SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *ms_out = (double)h;
+        return 0;
+    }
+    auto run = [&]() -> int {
+        if (mode == 0 || mode == 2) SFG_TRY(ntts(panel, nullptr));
+        if (mode == 0 || mode == 3) pack_alone(pj);
+        if (mode == 4) { MoveJob j = pj; j.first = 0; j.count = pj.n5 + pj.n6; launch_move_alone(ctx->stream, j); }
+        if (mode == 5) SFG_TRY(ntts(panel2, &pj));
+        SFG_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    hipEvent_t e0, e1; SFG_HIP(ctx, hipEventCreate(&e0)); SFG_HIP(ctx, hipEventCreate(&e1));
+    SFG_TRY(run());
+    SFG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; r++) SFG_TRY(run());
+    SFG_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    SFG_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0; SFG_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = (double)ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
 }

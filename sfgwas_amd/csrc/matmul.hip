@@ -166,6 +166,76 @@ extern "C" int sfg_geno_upload(sfg_ctx *ctx, const int8_t *host, size_t nrow, si
     sfg_geno *g = new sfg_geno(); g->dev = d; g->nrow = nrow; g->ncol = ncol; g->ld = ncol; g->owned = true;
     *out = g; return 0;
 }
+// ---- row-streamed registration.  The reference never holds its matrix: MatMult4StreamPreprocess (matmult.go:914-1041) pulls one row at a time out of
+// GenoFileStream.NextRow (filestream.go:414-426).  sfg_geno_create makes the resident matrix, sfg_geno_write_rows fills it chunk by chunk from whatever staging
+// buffer the host keeps (sfg_pinned_alloc gives a page-locked one), so no host allocation scales with nrow * ncol.  sfg_geno_compare_rows answers "is the matrix
+// now arriving row by row the one already resident - or its transpose?" (pca.go:112-113 registers X, then X^T from a second file) by comparing each chunk with the
+// resident copy ON the device, entry by entry: X^T is then recognised without being held anywhere, and the one int8 copy serves both orientations.
+extern "C" int sfg_geno_create(sfg_ctx *ctx, size_t nrow, size_t ncol, sfg_geno **out) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!out) SFG_FAIL(ctx, "sfg_geno_create: null result pointer");
+    *out = nullptr;
+    if (!nrow || !ncol) SFG_FAIL(ctx, "sfg_geno_create: bad dimensions");
+    int8_t *d = nullptr;
+    SFG_TRY(sfg_malloc(ctx, (void **)&d, nrow * ncol));
+    sfg_geno *g = new sfg_geno(); g->dev = d; g->nrow = nrow; g->ncol = ncol; g->ld = ncol; g->owned = true;
+    *out = g; return 0;
+}
+extern "C" int sfg_geno_write_rows(sfg_ctx *ctx, sfg_geno *g, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!g || !g->owned || g->packed) SFG_FAIL(ctx, "sfg_geno_write_rows: not a matrix made by sfg_geno_create");
+    if (!nrows) return 0;
+    if (!rows_host || ld < g->ncol || row0 > g->nrow || nrows > g->nrow - row0) SFG_FAIL(ctx, "sfg_geno_write_rows: rows [%zu, %zu) of a %zu x %zu matrix, row stride %zu", row0, row0 + nrows, g->nrow, g->ncol, ld);
+    if (!g->ptc.empty()) SFG_FAIL(ctx, "sfg_geno_write_rows: the matrix has cached plaintexts (sfg_geno_set_plaintext_cache): it must not change");
+    SFG_HIP(ctx, hipMemcpy2DAsync(const_cast<int8_t *>(g->dev) + row0 * g->ld, g->ld, rows_host, ld, g->ncol, nrows, hipMemcpyHostToDevice, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));           // the caller refills its staging buffer next
+    return 0;
+}
+// chunk[r][c] (dense, ncol_l columns) against logical row row0 + r of the stored matrix (transposed: stored[c][row0 + r]); consecutive lanes walk the STORED rows
+__global__ void __launch_bounds__(256) k_geno_compare(const int8_t *chunk, const int8_t *stored, size_t ld, size_t row0, size_t nrows, size_t ncol_l, int transposed, unsigned long long *ndiff) {
+    const size_t total = nrows * ncol_l;
+    unsigned long long bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t r, c;
+        if (transposed) { r = i % nrows; c = i / nrows; } else { r = i / ncol_l; c = i % ncol_l; }
+        const int8_t want = transposed ? stored[c * ld + row0 + r] : stored[(row0 + r) * ld + c];
+        bad += chunk[r * ncol_l + c] != want;
+    }
+    if (bad) atomicAdd(ndiff, bad);
+}
+extern "C" int sfg_geno_compare_rows(sfg_ctx *ctx, const sfg_geno *g, unsigned flags, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld, uint64_t *ndiff) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!g || g->packed || !ndiff) SFG_FAIL(ctx, "sfg_geno_compare_rows: needs an unpacked resident matrix and a result pointer");
+    const bool tr = flags & SFG_TRANSPOSE;
+    const size_t nrow_l = tr ? g->ncol : g->nrow, ncol_l = tr ? g->nrow : g->ncol;
+    if (!nrows) return 0;
+    if (!rows_host || ld < ncol_l || row0 > nrow_l || nrows > nrow_l - row0) SFG_FAIL(ctx, "sfg_geno_compare_rows: rows [%zu, %zu) of a %zu x %zu matrix, row stride %zu", row0, row0 + nrows, nrow_l, ncol_l, ld);
+    int8_t *chunk = nullptr; unsigned long long *cnt = nullptr;
+    SFG_TRY(sfg_scratch(ctx, "geno.cmp", nrows * ncol_l, (void **)&chunk));
+    SFG_TRY(sfg_scratch(ctx, "geno.cmpcnt", 8, (void **)&cnt));
+    SFG_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    SFG_HIP(ctx, hipMemcpy2DAsync(chunk, ncol_l, rows_host, ld, ncol_l, nrows, hipMemcpyHostToDevice, ctx->stream));
+    const size_t total = nrows * ncol_l;
+    hipLaunchKernelGGL(k_geno_compare, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65536)), dim3(256), 0, ctx->stream, (const int8_t *)chunk, g->dev, g->ld, row0, nrows, ncol_l, tr ? 1 : 0, cnt);
+    SFG_HIP(ctx, hipGetLastError());
+    unsigned long long h = 0;
+    SFG_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *ndiff += h;
+    return 0;
+}
+// page-locked host memory for a caller's staging buffer (the Go shim fills it from GenoFileStream.NextRow): H2D copies from it run at the PCIe rate
+extern "C" int sfg_pinned_alloc(sfg_ctx *ctx, void **host_ptr, size_t bytes) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!host_ptr || !bytes) SFG_FAIL(ctx, "sfg_pinned_alloc: bad arguments");
+    SFG_HIP(ctx, hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+extern "C" int sfg_pinned_free(sfg_ctx *ctx, void *host_ptr) {
+    SFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (host_ptr) SFG_HIP(ctx, hipHostFree(host_ptr));
+    return 0;
+}
 extern "C" int sfg_geno_from_device(sfg_ctx *ctx, const int8_t *dev, size_t nrow, size_t ncol, size_t ld, sfg_geno **out) {
     if (!nrow || !ncol || ld < ncol) SFG_FAIL(ctx, "sfg_geno_from_device: bad dimensions");
     sfg_geno *g = new sfg_geno(); g->dev = dev; g->nrow = nrow; g->ncol = ncol; g->ld = ld; g->owned = false;

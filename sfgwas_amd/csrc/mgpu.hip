@@ -38,6 +38,9 @@ struct Rccl {
     decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;          // optional (older builds): without it a failure after the agreement point cannot release the peers
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     std::string load() {
         if (so) return "";
         const char *names[] = {getenv("SFG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -47,6 +50,9 @@ struct Rccl {
         SFG_RCCL_SYM(GetUniqueId); SFG_RCCL_SYM(CommInitAll); SFG_RCCL_SYM(CommInitRank); SFG_RCCL_SYM(CommDestroy); SFG_RCCL_SYM(ReduceScatter); SFG_RCCL_SYM(AllReduce);
         SFG_RCCL_SYM(GetErrorString);
 #undef SFG_RCCL_SYM
+        CommAbort = (decltype(CommAbort))dlsym(so, "ncclCommAbort");
+        CommCount = (decltype(CommCount))dlsym(so, "ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))dlsym(so, "ncclCommUserRank");
         return "";
     }
 };
@@ -60,6 +66,7 @@ struct MgRank {
     bool own_coll = false;                  // coll was created by the engine (else it is the context's encode queue)
     hipStream_t spare = nullptr;            // SFG_MGPU_COLL_QUEUE=spare (diagnostics)
     hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_rs[2] = {nullptr, nullptr}, ev_c = nullptr;
+    uint64_t *status_dev = nullptr, *status_host = nullptr;      // the agreement word of a call (coll_agree): made with the rank, so that agreeing never allocates
     std::string err;
 };
 
@@ -97,6 +104,7 @@ struct sfg_mgpu {
                                             // local copy of the rank's own slice (the outputs are not a product): per-rank phase times of world sizes a one-GPU box cannot run
     size_t cache_budget = 72ULL << 30;      // SFG_MGPU_CACHE_GB: a rank's own Q'X^T rotation cache up to this size -> per-column pipelined reduce-scatter
     std::vector<MgRank> r;                  // local ranks
+    bool broken = false;                    // a rank failed after a call's agreement point and its communicator was aborted: the engine refuses further exchanges
     Rendezvous rv;
     std::string err;
 };
@@ -129,6 +137,16 @@ template <class F> static int run_ranks(sfg_mgpu *mg, F &&fn) {
     return 0;
 }
 
+// One top-level engine call for the scratch pools of EVERY rank (the ApiScope of common.hpp across the rank threads of a call: the phases of a call run in separate
+// run_ranks passes, and a buffer requested in the first one - mg.Ain, mg.Oout - must not look like an earlier call's when a later phase runs out of device memory).
+// Contexts are driven by one thread at a time; run_ranks joins its threads, so the calling thread may touch the counters between passes.
+struct MgApiScope {
+    sfg_mgpu *mg;
+    explicit MgApiScope(sfg_mgpu *m) : mg(m) { for (auto &R : mg->r) if (R.ctx && R.ctx->api_depth++ == 0) R.ctx->api_epoch++; }
+    ~MgApiScope() { for (auto &R : mg->r) if (R.ctx) R.ctx->api_depth--; }
+};
+#define MG_NEED(mg, cond, what) do { if (!(cond)) { if (mg) MG_FAIL(mg, "%s: %s", __func__, what); g_mgpu_create_error = std::string(__func__) + ": " + what; return 1; } } while (0)
+
 extern "C" int sfg_mgpu_shard(int world, size_t ncol, int rank, size_t *blk0, size_t *blk1, size_t *col0, size_t *col1) {
     if (world < 1 || rank < 0 || rank >= world || !ncol) return 1;
     const size_t nblk = (ncol + SFG_SLOTS - 1) / SFG_SLOTS, b0 = nblk * (size_t)rank / (size_t)world, b1 = nblk * ((size_t)rank + 1) / (size_t)world;
@@ -140,7 +158,7 @@ extern "C" int sfg_mgpu_shard(int world, size_t ncol, int rank, size_t *blk0, si
 static void mgpu_read_env(sfg_mgpu *mg) {
     if (const char *e = getenv("SFG_MGPU_TRANSPORT")) mg->direct = !strcmp(e, "direct");
     if (const char *e = getenv("SFG_MGPU_FORCE_COLLECTIVES")) mg->force_coll = atoi(e) != 0;
-    if (const char *e = getenv("SFG_MGPU_CACHE_GB")) mg->cache_budget = (size_t)(atof(e) * (double)(1ULL << 30));
+    if (const char *e = getenv("SFG_MGPU_CACHE_GB")) { double gb = atof(e); if (!(gb >= 0)) gb = 0; if (gb > 4096) gb = 4096; mg->cache_budget = (size_t)(gb * (double)(1ULL << 30)); }
 }
 static const char *rank_exec_init(MgRank &R) {
     if (hipSetDevice(R.device) != hipSuccess) return "hipSetDevice failed";
@@ -156,6 +174,7 @@ static const char *rank_exec_init(MgRank &R) {
     } else { if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed"; R.own_coll = true; }
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&R.ev_acc[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&R.ev_rs[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     if (hipEventCreateWithFlags(&R.ev_c, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+    if (hipMalloc((void **)&R.status_dev, 64) != hipSuccess || hipHostMalloc((void **)&R.status_host, 64, hipHostMallocDefault) != hipSuccess) return "status word allocation failed";
     return nullptr;
 }
 
@@ -175,6 +194,8 @@ extern "C" void sfg_mgpu_destroy(sfg_mgpu *mg) {
         if (R.spare) (void)hipStreamDestroy(R.spare);
         for (int i = 0; i < 2; i++) { if (R.ev_acc[i]) (void)hipEventDestroy(R.ev_acc[i]); if (R.ev_rs[i]) (void)hipEventDestroy(R.ev_rs[i]); }
         if (R.ev_c) (void)hipEventDestroy(R.ev_c);
+        if (R.status_dev) (void)hipFree(R.status_dev);
+        if (R.status_host) (void)hipHostFree(R.status_host);
         if (R.ctx) sfg_ctx_destroy(R.ctx);
     }
     delete mg;
@@ -247,22 +268,40 @@ extern "C" int sfg_mgpu_create_rank(sfg_mgpu **out, int device, int rank, int wo
     return mgpu_create_common(out, &device, 1, rank, world, id128, logN, nq, np, moduli, psi, scale);
 }
 extern "C" const char *sfg_mgpu_last_error(const sfg_mgpu *mg) { return mg ? mg->err.c_str() : g_mgpu_create_error.c_str(); }
-extern "C" int sfg_mgpu_world(const sfg_mgpu *mg) { return mg->world; }
-extern "C" int sfg_mgpu_nlocal(const sfg_mgpu *mg) { return (int)mg->r.size(); }
-extern "C" int sfg_mgpu_rank(const sfg_mgpu *mg, int local) { return local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].rank : -1; }
-extern "C" sfg_ctx *sfg_mgpu_ctx(sfg_mgpu *mg, int local) { return local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].ctx : nullptr; }
-extern "C" const char *sfg_mgpu_transport(const sfg_mgpu *mg) { return mg->solo ? "solo" : mg->world == 1 && !mg->force_coll ? "none" : mg->direct ? "direct" : "rccl"; }
+extern "C" int sfg_mgpu_world(const sfg_mgpu *mg) { return mg ? mg->world : 0; }
+extern "C" int sfg_mgpu_nlocal(const sfg_mgpu *mg) { return mg ? (int)mg->r.size() : 0; }
+extern "C" int sfg_mgpu_rank(const sfg_mgpu *mg, int local) { return mg && local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].rank : -1; }
+extern "C" sfg_ctx *sfg_mgpu_ctx(sfg_mgpu *mg, int local) { return mg && local >= 0 && local < (int)mg->r.size() ? mg->r[(size_t)local].ctx : nullptr; }
+extern "C" const char *sfg_mgpu_transport(const sfg_mgpu *mg) { return !mg ? "" : mg->solo ? "solo" : mg->world == 1 && !mg->force_coll ? "none" : mg->direct ? "direct" : "rccl"; }
+// What the communicator itself reports for local rank `local` (ncclCommCount / ncclCommUserRank): a record of a multi-GPU run can then state "RCCL saw N ranks"
+// instead of inferring it from the launcher's environment.  *nranks = *rank = 0 when the engine holds no communicator (world 1, direct transport, solo timing).
+extern "C" int sfg_mgpu_comm_info(sfg_mgpu *mg, int local, int *nranks, int *rank) {
+    MG_NEED(mg, mg != nullptr, "null engine");
+    MG_NEED(mg, local >= 0 && local < (int)mg->r.size(), "local rank out of range");
+    if (nranks) *nranks = 0; if (rank) *rank = 0;
+    MgRank &R = mg->r[(size_t)local];
+    if (!R.comm) return 0;
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) MG_FAIL(mg, "sfg_mgpu_comm_info: this RCCL build exports no ncclCommCount / ncclCommUserRank");
+    int n = 0, r = 0;
+    if (g_rccl.CommCount(R.comm, &n) != ncclSuccess || g_rccl.CommUserRank(R.comm, &r) != ncclSuccess) MG_FAIL(mg, "sfg_mgpu_comm_info: ncclCommCount / ncclCommUserRank failed");
+    if (nranks) *nranks = n; if (rank) *rank = r;
+    return 0;
+}
 
 extern "C" int sfg_mgpu_load_rotkey(sfg_mgpu *mg, uint64_t galois_el, const uint64_t *key_host, int montgomery_form) {
+    MG_NEED(mg, mg != nullptr, "null engine");
     return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_ctx_load_rotkey(R.ctx, galois_el, key_host, montgomery_form)); return 0; });
 }
 extern "C" int sfg_mgpu_load_relinkey(sfg_mgpu *mg, const uint64_t *key_host, int montgomery_form) {
+    MG_NEED(mg, mg != nullptr, "null engine");
     return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_ctx_load_relinkey(R.ctx, key_host, montgomery_form)); return 0; });
 }
 extern "C" int sfg_mgpu_fill_rotkeys_synthetic(sfg_mgpu *mg, const int *rot_left, int nrot, uint64_t seed) {
+    MG_NEED(mg, mg != nullptr, "null engine");
     return run_ranks(mg, [&](MgRank &R, int) { R_CTX(R, sfg_fill_rotkeys_synthetic(R.ctx, rot_left, nrot, seed)); return 0; });
 }
 extern "C" int sfg_mgpu_synchronize(sfg_mgpu *mg) {
+    MG_NEED(mg, mg != nullptr, "null engine");
     return run_ranks(mg, [&](MgRank &R, int) { R_HIP(R, hipSetDevice(R.device)); R_HIP(R, hipStreamSynchronize(R.coll)); R_CTX(R, sfg_ctx_synchronize(R.ctx)); return 0; });
 }
 
@@ -274,6 +313,7 @@ static sfg_mgeno *mgeno_new(sfg_mgpu *mg, size_t nrow, size_t ncol) {
 }
 extern "C" void sfg_mgpu_geno_free(sfg_mgpu *mg, sfg_mgeno *g) {
     if (!g) return;
+    if (!mg) { delete g; return; }            // (nothing to free the shards with: the engine that made them is gone and took its contexts' memory along)
     for (size_t i = 0; i < g->shard.size() && i < mg->r.size(); i++) {
         if (g->shard[i]) sfg_geno_free(mg->r[i].ctx, g->shard[i]);
         if (g->owned[i]) (void)sfg_free(mg->r[i].ctx, g->owned[i]);
@@ -282,6 +322,7 @@ extern "C" void sfg_mgpu_geno_free(sfg_mgpu *mg, sfg_mgeno *g) {
 }
 // geno_host: the party's WHOLE matrix, row-major int8 with row stride ld (what GenoFileStream delivers); every local rank uploads its own column window
 extern "C" int sfg_mgpu_geno_upload(sfg_mgpu *mg, const int8_t *geno_host, size_t nrow, size_t ncol, size_t ld, sfg_mgeno **out) {
+    MG_NEED(mg, mg != nullptr && out != nullptr, "null engine / result pointer");
     *out = nullptr;
     if (!geno_host || !nrow || !ncol || ld < ncol) MG_FAIL(mg, "sfg_mgpu_geno_upload: bad dimensions");
     sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
@@ -293,10 +334,60 @@ extern "C" int sfg_mgpu_geno_upload(sfg_mgpu *mg, const int8_t *geno_host, size_
     if (rc) { sfg_mgpu_geno_free(mg, g); return 1; }
     *out = g; return 0;
 }
+// Row-streamed form (MatMult4StreamPreprocess reads one row at a time: matmult.go:914-1041, filestream.go:414-426): _create makes every rank's window, _write_rows
+// scatters a chunk of whole-matrix rows to the ranks' column windows, _compare_rows compares a chunk of the rows of the matrix (or, with SFG_TRANSPOSE, of its
+// transpose: pca.go:113 registers X^T from a second file) with the resident shards on the devices and adds the number of differing entries to *ndiff.
+extern "C" int sfg_mgpu_geno_create(sfg_mgpu *mg, size_t nrow, size_t ncol, sfg_mgeno **out) {
+    MG_NEED(mg, mg != nullptr && out != nullptr, "null engine / result pointer");
+    *out = nullptr;
+    if (!nrow || !ncol) MG_FAIL(mg, "sfg_mgpu_geno_create: bad dimensions");
+    sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
+    const int rc = run_ranks(mg, [&](MgRank &R, int i) {
+        size_t c0, c1; (void)sfg_mgpu_shard(mg->world, ncol, R.rank, &g->blk0[(size_t)i], &g->blk1[(size_t)i], &c0, &c1);
+        if (c1 > c0) R_CTX(R, sfg_geno_create(R.ctx, nrow, c1 - c0, &g->shard[(size_t)i]));
+        return 0;
+    });
+    if (rc) { sfg_mgpu_geno_free(mg, g); return 1; }
+    *out = g; return 0;
+}
+extern "C" int sfg_mgpu_geno_write_rows(sfg_mgpu *mg, sfg_mgeno *g, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld) {
+    MG_NEED(mg, mg != nullptr, "null engine");
+    MG_NEED(mg, g && g->shard.size() == mg->r.size(), "the matrix belongs to another engine");
+    if (!nrows) return 0;
+    if (!rows_host || ld < g->ncol || row0 > g->nrow || nrows > g->nrow - row0) MG_FAIL(mg, "sfg_mgpu_geno_write_rows: rows [%zu, %zu) of a %zu x %zu matrix, row stride %zu", row0, row0 + nrows, g->nrow, g->ncol, ld);
+    return run_ranks(mg, [&](MgRank &R, int i) {
+        if (g->shard[(size_t)i]) R_CTX(R, sfg_geno_write_rows(R.ctx, g->shard[(size_t)i], row0, nrows, rows_host + g->blk0[(size_t)i] * SFG_SLOTS, ld));
+        return 0;
+    });
+}
+extern "C" int sfg_mgpu_geno_compare_rows(sfg_mgpu *mg, const sfg_mgeno *g, unsigned flags, size_t row0, size_t nrows, const int8_t *rows_host, size_t ld, uint64_t *ndiff) {
+    MG_NEED(mg, mg != nullptr, "null engine");
+    MG_NEED(mg, g && g->shard.size() == mg->r.size() && ndiff, "the matrix belongs to another engine / null result pointer");
+    const bool tr = flags & SFG_TRANSPOSE;
+    const size_t nrow_l = tr ? g->ncol : g->nrow, ncol_l = tr ? g->nrow : g->ncol;
+    if (!nrows) return 0;
+    if (!rows_host || ld < ncol_l || row0 > nrow_l || nrows > nrow_l - row0) MG_FAIL(mg, "sfg_mgpu_geno_compare_rows: rows [%zu, %zu) of a %zu x %zu matrix, row stride %zu", row0, row0 + nrows, nrow_l, ncol_l, ld);
+    std::vector<uint64_t> bad(mg->r.size(), 0);
+    const int rc = run_ranks(mg, [&](MgRank &R, int i) {
+        const sfg_geno *sh = g->shard[(size_t)i];
+        if (!sh) return 0;
+        const size_t c0 = g->blk0[(size_t)i] * SFG_SLOTS, c1 = c0 + sh->ncol;          // the rank's window of stored columns
+        if (!tr) { R_CTX(R, sfg_geno_compare_rows(R.ctx, sh, 0, row0, nrows, rows_host + c0, ld, &bad[(size_t)i])); return 0; }
+        // rows of the transpose are stored COLUMNS: this rank answers for the rows that fall into its window
+        const size_t lo = std::max(row0, c0), hi = std::min(row0 + nrows, c1);
+        if (lo < hi) R_CTX(R, sfg_geno_compare_rows(R.ctx, sh, SFG_TRANSPOSE, lo - c0, hi - lo, rows_host + (lo - row0) * ld, ld, &bad[(size_t)i]));
+        return 0;
+    });
+    if (rc) return rc;
+    for (uint64_t b : bad) *ndiff += b;
+    return 0;
+}
 // per-rank handles the caller made on the ranks' own contexts (sfg_geno_from_bed / _from_pgen / _from_device of the rank's window); ownership passes to the result.
 // shards[i] == NULL for a local rank whose window is empty.
 extern "C" int sfg_mgpu_geno_adopt(sfg_mgpu *mg, size_t nrow, size_t ncol, sfg_geno *const *shards, sfg_mgeno **out) {
+    MG_NEED(mg, mg != nullptr && out != nullptr, "null engine / result pointer");
     *out = nullptr;
+    MG_NEED(mg, shards != nullptr && nrow && ncol, "null shard list / empty matrix");
     sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
     for (size_t i = 0; i < mg->r.size(); i++) {
         size_t c0, c1; (void)sfg_mgpu_shard(mg->world, ncol, mg->r[i].rank, &g->blk0[i], &g->blk1[i], &c0, &c1);
@@ -309,6 +400,7 @@ extern "C" int sfg_mgpu_geno_adopt(sfg_mgpu *mg, size_t nrow, size_t ncol, sfg_g
 // bench.py / tests: every rank generates exactly the window of the SAME global synthetic matrix it owns (sfg_fill_geno_window_dev), so any world size multiplies
 // the same matrix.  packed != 0: 2-bit residency (sfg_geno_pack)
 extern "C" int sfg_mgpu_geno_synthetic(sfg_mgpu *mg, size_t nrow, size_t ncol, uint64_t seed, int packed, sfg_mgeno **out) {
+    MG_NEED(mg, mg != nullptr && out != nullptr, "null engine / result pointer");
     *out = nullptr;
     if (!nrow || !ncol) MG_FAIL(mg, "sfg_mgpu_geno_synthetic: bad dimensions");
     sfg_mgeno *g = mgeno_new(mg, nrow, ncol);
@@ -331,13 +423,15 @@ extern "C" int sfg_mgpu_geno_synthetic(sfg_mgpu *mg, size_t nrow, size_t ncol, u
     if (rc) { sfg_mgpu_geno_free(mg, g); return 1; }
     *out = g; return 0;
 }
-extern "C" const sfg_geno *sfg_mgpu_geno_shard(const sfg_mgeno *g, int local) { return local >= 0 && (size_t)local < g->shard.size() ? g->shard[(size_t)local] : nullptr; }
-extern "C" int sfg_mgpu_geno_dims(const sfg_mgeno *g, size_t *nrow, size_t *ncol) { if (nrow) *nrow = g->nrow; if (ncol) *ncol = g->ncol; return 0; }
+extern "C" const sfg_geno *sfg_mgpu_geno_shard(const sfg_mgeno *g, int local) { return g && local >= 0 && (size_t)local < g->shard.size() ? g->shard[(size_t)local] : nullptr; }
+extern "C" int sfg_mgpu_geno_dims(const sfg_mgeno *g, size_t *nrow, size_t *ncol) { if (!g) return 1; if (nrow) *nrow = g->nrow; if (ncol) *ncol = g->ncol; return 0; }
 extern "C" int sfg_mgpu_geno_blocks(const sfg_mgeno *g, int local, size_t *blk0, size_t *blk1) {
-    if (local < 0 || (size_t)local >= g->shard.size()) return 1;
+    if (!g || local < 0 || (size_t)local >= g->shard.size()) return 1;
     if (blk0) *blk0 = g->blk0[(size_t)local]; if (blk1) *blk1 = g->blk1[(size_t)local]; return 0;
 }
 extern "C" int sfg_mgpu_geno_set_plaintext_cache(sfg_mgpu *mg, const sfg_mgeno *g, size_t max_bytes_per_rank) {
+    MG_NEED(mg, mg != nullptr, "null engine");
+    MG_NEED(mg, g && g->shard.size() == mg->r.size(), "the matrix belongs to another engine");
     return run_ranks(mg, [&](MgRank &R, int i) { if (g->shard[(size_t)i]) R_CTX(R, sfg_geno_set_plaintext_cache(R.ctx, g->shard[(size_t)i], max_bytes_per_rank)); return 0; });
 }
 
@@ -375,6 +469,67 @@ static int coll_all_reduce(sfg_mgpu *mg, MgRank &R, uint64_t *buf, size_t count,
     return 0;
 }
 
+// ---------------------------------------------------------------- agreement before a call's first exchange
+// A rank that fails BEFORE it has enqueued its part of a collective (out of memory in a scratch pool, a context error) would leave its peers waiting in theirs for
+// ever: RCCL has no timeout, and run_ranks joins every thread.  So every exchanging call has an agreement point after its allocations and rotation caches and before
+// its first collective: each rank brings its status so far, all leave with the same verdict.  In-process ranks meet at the host rendezvous; one-rank-per-process
+// worlds all-reduce a status word through the communicator itself (a rank that failed still takes part - that is the point) and read it back.  After the agreement
+// point a failing rank ABORTS its communicator (ncclCommAbort) so that the peers' pending collectives return with an error instead of hanging, and the engine
+// refuses further exchanges (`broken`).
+static int coll_agree(sfg_mgpu *mg, MgRank &R, int local_rc) {
+    if (mg->solo || (mg->world == 1 && !mg->force_coll)) return local_rc;
+    if (mg->r.size() > 1) {
+        if (local_rc) mg->rv.fail();
+        if (!mg->rv.barrier() && !local_rc) { R.err = "a peer rank failed"; local_rc = 1; }
+    }
+    if (mg->single_process || mg->direct || !R.comm) return local_rc;
+    if (hipSetDevice(R.device) != hipSuccess) return 1;
+    *R.status_host = local_rc ? 1u : 0u;
+    hipStream_t st = R.coll;
+    if (hipMemcpyAsync(R.status_dev, R.status_host, 8, hipMemcpyHostToDevice, st) != hipSuccess) { if (!local_rc) R.err = "agreement: status upload failed"; return 1; }
+    const ncclResult_t e = g_rccl.AllReduce(R.status_dev, R.status_dev, 1, ncclUint64, ncclSum, R.comm, st);
+    if (e != ncclSuccess) { if (!local_rc) R.err = std::string("agreement all-reduce failed: ") + g_rccl.GetErrorString(e); return 1; }
+    if (hipMemcpyAsync(R.status_host, R.status_dev, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { if (!local_rc) R.err = "agreement: status read-back failed"; return 1; }
+    if (*R.status_host && !local_rc) { R.err = "a peer rank failed"; return 1; }
+    return local_rc;
+}
+static void coll_abort(sfg_mgpu *mg, MgRank &R) {
+    mg->broken = true;
+    if (mg->direct) { mg->rv.fail(); return; }
+    if (R.comm && g_rccl.CommAbort) { (void)hipSetDevice(R.device); (void)g_rccl.CommAbort(R.comm); R.comm = nullptr; }
+}
+
+// Pre-flight of the exchange paths (bench.py --gpus N runs it before the warm-up; a Go party may after hip.Init): a reduce-scatter and an all-reduce of a known
+// uint64 pattern through the very functions the products use, on the collectives' queue of every rank, checked on the host.  rank r contributes
+// v[x] = (r + 1) * 2^40 + x; the sum over ranks at position x is world (world + 1) / 2 * 2^40 + world x.  count_per_rank words per rank slice (>= 1).
+extern "C" int sfg_mgpu_preflight(sfg_mgpu *mg, size_t count_per_rank) {
+    MG_NEED(mg, mg != nullptr, "null engine");
+    if (mg->broken) MG_FAIL(mg, "sfg_mgpu_preflight: the engine's communicator was aborted by an earlier failure");
+    if (!count_per_rank || count_per_rank > (1u << 24)) MG_FAIL(mg, "sfg_mgpu_preflight: count_per_rank out of range");
+    if (mg->solo || (mg->world == 1 && !mg->force_coll)) return 0;
+    MgApiScope scope(mg);
+    const size_t w = (size_t)mg->world, total = w * count_per_rank;
+    return run_ranks(mg, [&](MgRank &R, int) {
+        R_HIP(R, hipSetDevice(R.device));
+        uint64_t *send = nullptr, *recv = nullptr; int rc = 0;
+        std::vector<uint64_t> h(total);
+        for (size_t x = 0; x < total; x++) h[x] = ((uint64_t)(R.rank + 1) << 40) + x;
+        if (sfg_scratch(R.ctx, "mg.pf_send", total * 8, (void **)&send) || sfg_scratch(R.ctx, "mg.pf_recv", total * 8, (void **)&recv)) { R.err = R.ctx->err; rc = 1; }
+        if (!rc && hipMemcpy(send, h.data(), total * 8, hipMemcpyHostToDevice) != hipSuccess) { R.err = "preflight upload failed"; rc = 1; }
+        if (coll_agree(mg, R, rc)) return 1;
+        const uint64_t base = (uint64_t)(w * (w + 1) / 2) << 40;
+        auto after = [&](int e) { if (e) coll_abort(mg, R); return e; };
+        if (after(coll_reduce_scatter(mg, R, send, recv, count_per_rank, R.coll))) return 1;
+        if (hipMemcpyAsync(h.data(), recv, count_per_rank * 8, hipMemcpyDeviceToHost, R.coll) != hipSuccess || hipStreamSynchronize(R.coll) != hipSuccess) { R.err = "preflight read-back failed"; return after(1); }
+        for (size_t x = 0; x < count_per_rank; x++) if (h[x] != base + w * ((size_t)R.rank * count_per_rank + x)) {
+            R.err = "preflight: reduce-scatter returned a wrong word at " + std::to_string(x); return after(1); }
+        if (after(coll_all_reduce(mg, R, send, total, R.coll))) return 1;
+        if (hipMemcpyAsync(h.data(), send, total * 8, hipMemcpyDeviceToHost, R.coll) != hipSuccess || hipStreamSynchronize(R.coll) != hipSuccess) { R.err = "preflight read-back failed"; return after(1); }
+        for (size_t x = 0; x < total; x++) if (h[x] != base + w * x) { R.err = "preflight: all-reduce returned a wrong word at " + std::to_string(x); return after(1); }
+        return 0;
+    });
+}
+
 // ---------------------------------------------------------------- the products
 // Q' * X^T of one rank: see the header of this file
 static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int s, int in_level, int L, const sfg_mgeno *g, unsigned flags, uint64_t *out) {
@@ -389,56 +544,79 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
     const int gpr = (d + world - 1) / world, g_lo = R.rank * gpr;
     const size_t col = (size_t)d * accw, colp = (size_t)world * gpr * accw, mine = (size_t)gpr * accw;
     if (world == 1 && !mg->force_coll) { R_CTX(R, sfg_matmul_resident_dev(ctx, A, s, in_level, L, shard, fl, out)); return 0; }
-    if (in_level < L) R_FAIL(R, "sfg_mgpu_matmul: input level %d below max_level %d", in_level, L);
-    size_t jobw = 0, tailw = 0;
-    R_CTX(R, sfg_rotcache_layout(ctx, s, L, &jobw, &tailw));
-    const size_t cache_w = (size_t)nloc * s * jobw + tailw;
-    // The rank's own baby-step rotations, once per product, for the per-column pipeline: as the int8 MAC's rot TILES where the context multiplies on the matrix core
-    // (1.3 GB per block row at s = 15; every column then multiplies there whatever the number of MAC groups - with fp64 rows a rank of more than two groups, i.e. a world
-    // of 4 or fewer at 100k x 1M, fell back to the fp64 kernel: 1.04 s of a 3.28 s rank step), else as fp64 operand rows (2.15 GB per block row) while they fit
     I8RotPre pre8;
-    if (nloc) R_CTX(R, i8_rotpre_build(ctx, (const u64 *)A, s, in_level, L, nloc, nullptr, mg->cache_budget, "mg.rot8", pre8));
-    const bool pipe = !nloc || pre8.G || cache_w * 8 <= mg->cache_budget;
+    bool pipe = false;
     uint64_t *acc_mine = nullptr, *acc2 = nullptr; double *cache = nullptr;
-    R_CTX(R, sfg_scratch(ctx, "mg.mine", (size_t)nbr_x * mine * 8, (void **)&acc_mine));
     hipStream_t cs = ctx->stream;
-    // (the collectives' queue must not start before earlier work of the compute queue that still reads these buffers: previous call's finalize)
-    R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
-    if (pipe) {
-        const bool fresh = ctx->pool.find("mg.acc2") == ctx->pool.end() || ctx->pool["mg.acc2"].second < 2 * colp * 8;
-        R_CTX(R, sfg_scratch(ctx, "mg.acc2", 2 * colp * 8, (void **)&acc2));
-        if (fresh || !nloc) R_HIP(R, hipMemsetAsync(acc2, 0, 2 * colp * 8, cs));       // the padded giant slots (>= 91) are never written by a product: zero once
-        if (nloc && !pre8.G) {
-            R_CTX(R, sfg_scratch(ctx, "mg.cache", cache_w * 8, (void **)&cache));
-            R_CTX(R, sfg_rotcache_build_rows_dev(ctx, A, s, in_level, L, nloc, 0, nloc, cache));
+    size_t acc_w = 0;
+    // ---- everything that allocates or can fail on this rank's own account, BEFORE the first exchange
+    auto prepare = [&]() -> int {
+        if (mg->broken) R_FAIL(R, "sfg_mgpu_matmul: the engine's communicator was aborted by an earlier failure");
+        if (in_level < L) R_FAIL(R, "sfg_mgpu_matmul: input level %d below max_level %d", in_level, L);
+        size_t jobw = 0, tailw = 0;
+        R_CTX(R, sfg_rotcache_layout(ctx, s, L, &jobw, &tailw));
+        const size_t cache_w = (size_t)nloc * s * jobw + tailw;
+        // The rank's own baby-step rotations, once per product, for the per-column pipeline: as the int8 MAC's rot TILES where the context multiplies on the matrix core
+        // (1.3 GB per block row at s = 15; every column then multiplies there whatever the number of MAC groups - with fp64 rows a rank of more than two groups, i.e. a world
+        // of 4 or fewer at 100k x 1M, fell back to the fp64 kernel: 1.04 s of a 3.28 s rank step), else as fp64 operand rows (2.15 GB per block row) while they fit
+        if (nloc) R_CTX(R, i8_rotpre_build(ctx, (const u64 *)A, s, in_level, L, nloc, nullptr, mg->cache_budget, "mg.rot8", pre8));
+        pipe = !nloc || pre8.G || cache_w * 8 <= mg->cache_budget;
+        R_CTX(R, sfg_scratch(ctx, "mg.mine", (size_t)nbr_x * mine * 8, (void **)&acc_mine));
+        if (mg->direct) { uint64_t *tmp = nullptr; R_CTX(R, sfg_scratch(ctx, "mg.ar", (size_t)s * nbr_x * outw * 8, (void **)&tmp)); }      // (the direct all-reduce's private copy: not after the agreement)
+        // (the collectives' queue must not start before earlier work of the compute queue that still reads these buffers: previous call's finalize)
+        R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
+        if (pipe) {
+            const bool fresh = ctx->pool.find("mg.acc2") == ctx->pool.end() || ctx->pool["mg.acc2"].second < 2 * colp * 8;
+            R_CTX(R, sfg_scratch(ctx, "mg.acc2", 2 * colp * 8, (void **)&acc2));
+            if (fresh || !nloc) R_HIP(R, hipMemsetAsync(acc2, 0, 2 * colp * 8, cs));       // the padded giant slots (>= 91) are never written by a product: zero once
+            if (nloc && !pre8.G) {
+                R_CTX(R, sfg_scratch(ctx, "mg.cache", cache_w * 8, (void **)&cache));
+                R_CTX(R, sfg_rotcache_build_rows_dev(ctx, A, s, in_level, L, nloc, 0, nloc, cache));
+            }
+            // column 0 is multiplied before the agreement too: it grows the product's own scratch pools (panel, tiles, accumulators) to their final shape
+            if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, 0, 1, 0, acc2));
+            else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, 0, 1, 0, acc2));
+        } else {                                           // the rank's own cache would not fit: the library's grouped rotation cache, reduce-scatters after the product
+            acc_w = ((size_t)nbr_x * d + ((size_t)world * gpr - d)) * accw;
+            R_CTX(R, sfg_scratch(ctx, "mg.acc2", acc_w * 8, (void **)&acc2));
+            R_HIP(R, hipMemsetAsync(acc2, 0, acc_w * 8, cs));
+            if (nloc) R_CTX(R, sfg_matmul_accumulate_dev(ctx, A, s, in_level, L, shard, fl, 0, nloc, 0, nbr_x, 0, acc2));
         }
-        for (int j = 0; j < nbr_x; j++) {              // column j is multiplied while column j - 1 is reduce-scattered
-            uint64_t *buf = acc2 + (size_t)(j & 1) * colp;
-            if (j >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[j & 1], 0));            // the reduce-scatter of column j - 2 has read this buffer
-            if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, j, j + 1, 0, buf));
-            else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
-            R_HIP(R, hipEventRecord(R.ev_acc[j & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[j & 1], 0));
-            if (coll_reduce_scatter(mg, R, buf, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
-            R_HIP(R, hipEventRecord(R.ev_rs[j & 1], R.coll));
+        return 0;
+    };
+    if (coll_agree(mg, R, prepare())) { i8_rotpre_free(pre8); return 1; }
+    // ---- from here on a failure aborts the communicator: the peers are inside (or about to enter) their collectives
+    auto exchange = [&]() -> int {
+        if (pipe) {
+            for (int j = 0; j < nbr_x; j++) {              // column j is multiplied while column j - 1 is reduce-scattered
+                uint64_t *buf = acc2 + (size_t)(j & 1) * colp;
+                if (j >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[j & 1], 0));            // the reduce-scatter of column j - 2 has read this buffer
+                if (j > 0) {
+                    if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, j, j + 1, 0, buf));
+                    else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
+                }
+                R_HIP(R, hipEventRecord(R.ev_acc[j & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[j & 1], 0));
+                if (coll_reduce_scatter(mg, R, buf, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
+                R_HIP(R, hipEventRecord(R.ev_rs[j & 1], R.coll));
+            }
+        } else {
+            R_HIP(R, hipEventRecord(R.ev_acc[0], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[0], 0));
+            for (int j = 0; j < nbr_x; j++)                 // the window of the last giants runs into the next block column: those slots are ignored by the finalize
+                if (coll_reduce_scatter(mg, R, acc2 + (size_t)j * col, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
         }
-    } else {                                           // the rank's own cache would not fit: the library's grouped rotation cache, reduce-scatters after the product
-        const size_t acc_w = ((size_t)nbr_x * d + ((size_t)world * gpr - d)) * accw;
-        R_CTX(R, sfg_scratch(ctx, "mg.acc2", acc_w * 8, (void **)&acc2));
-        R_HIP(R, hipMemsetAsync(acc2, 0, acc_w * 8, cs));
-        if (nloc) R_CTX(R, sfg_matmul_accumulate_dev(ctx, A, s, in_level, L, shard, fl, 0, nloc, 0, nbr_x, 0, acc2));
-        R_HIP(R, hipEventRecord(R.ev_acc[0], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[0], 0));
-        for (int j = 0; j < nbr_x; j++)                 // the window of the last giants runs into the next block column: those slots are ignored by the finalize
-            if (coll_reduce_scatter(mg, R, acc2 + (size_t)j * col, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
-    }
+        R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
+        R_CTX(R, sfg_reduce_rows_dev(ctx, acc_mine, (size_t)nbr_x * gpr * s * 2, L));
+        R_CTX(R, sfg_matmul_finalize_slots_dev(ctx, acc_mine, s, L, nbr_x, gpr, g_lo, 0, gpr, 0, out));
+        R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
+        if (coll_all_reduce(mg, R, out, (size_t)s * nbr_x * outw, R.coll)) return 1;     // aligned partial outputs of the ranks' giant shards
+        R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
+        R_CTX(R, sfg_reduce_rows_dev(ctx, out, (size_t)s * nbr_x * 2, L));
+        return 0;
+    };
+    const int rc = exchange();
     i8_rotpre_free(pre8);                               // (the tile buffers stay in the context's pool for the next product)
-    R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
-    R_CTX(R, sfg_reduce_rows_dev(ctx, acc_mine, (size_t)nbr_x * gpr * s * 2, L));
-    R_CTX(R, sfg_matmul_finalize_slots_dev(ctx, acc_mine, s, L, nbr_x, gpr, g_lo, 0, gpr, 0, out));
-    R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
-    if (coll_all_reduce(mg, R, out, (size_t)s * nbr_x * outw, R.coll)) return 1;     // aligned partial outputs of the ranks' giant shards
-    R_HIP(R, hipEventRecord(R.ev_c, R.coll)); R_HIP(R, hipStreamWaitEvent(cs, R.ev_c, 0));
-    R_CTX(R, sfg_reduce_rows_dev(ctx, out, (size_t)s * nbr_x * 2, L));
-    return 0;
+    if (rc) coll_abort(mg, R);
+    return rc;
 }
 
 // device-pointer form.  A_dev[i] / out_dev[i] belong to local rank i (device sfg_mgpu_ctx(mg, i)):
@@ -447,8 +625,15 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
 // Stream-ordered on each rank's context queue; sfg_mgpu_synchronize waits.
 extern "C" int sfg_mgpu_matmul_dev(sfg_mgpu *mg, const uint64_t *const *A_dev, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags,
                                    uint64_t *const *out_dev) {
+    MG_NEED(mg, mg != nullptr, "null engine");
     if (!g || g->shard.size() != mg->r.size()) MG_FAIL(mg, "sfg_mgpu_matmul: the matrix belongs to another engine");
     if (s < 1 || max_level < 1) MG_FAIL(mg, "sfg_mgpu_matmul: bad s / max_level");
+    MG_NEED(mg, A_dev != nullptr && out_dev != nullptr, "null pointer tables");
+    for (size_t i = 0; i < mg->r.size(); i++) {
+        const bool has_in = (flags & SFG_TRANSPOSE) ? g->blk1[i] > g->blk0[i] : true, has_out = (flags & SFG_TRANSPOSE) ? true : g->blk1[i] > g->blk0[i];
+        if ((has_in && has_out && !A_dev[i]) || (has_out && !out_dev[i])) MG_FAIL(mg, "sfg_mgpu_matmul_dev: null device pointer for local rank %zu", i);
+    }
+    MgApiScope scope(mg);
     return run_ranks(mg, [&](MgRank &R, int i) {
         R_HIP(R, hipSetDevice(R.device));
         if (flags & SFG_TRANSPOSE) return rank_contract(mg, R, i, A_dev[i], s, in_level, max_level, g, flags, out_dev[i]);
@@ -462,7 +647,10 @@ extern "C" int sfg_mgpu_matmul_dev(sfg_mgpu *mg, const uint64_t *const *A_dev, i
 //             a process fills the block columns of ITS ranks and leaves the others untouched)
 //   Q' * X^T: A_host [s][m_ct][...] (all SNP blocks; each rank takes its own) -> out_host [s][nbr][2][max_level][N], complete in every process
 extern "C" int sfg_mgpu_matmul(sfg_mgpu *mg, const uint64_t *A_host, int s, int in_level, int max_level, const sfg_mgeno *g, unsigned flags, uint64_t *out_host) {
+    MG_NEED(mg, mg != nullptr, "null engine");
     if (!g || g->shard.size() != mg->r.size()) MG_FAIL(mg, "sfg_mgpu_matmul: the matrix belongs to another engine");
+    MG_NEED(mg, A_host != nullptr && out_host != nullptr, "null host buffers");
+    MgApiScope scope(mg);                                // the I/O buffers below, the product's pools and the downloads are ONE call for the eviction rule of sfg_scratch
     const size_t N = SFG_N, ctw = 2 * (size_t)(in_level + 1) * N, outw = 2 * (size_t)max_level * N;
     const size_t nbr_x = (g->nrow + SFG_SLOTS - 1) / SFG_SLOTS, mct = (g->ncol + SFG_SLOTS - 1) / SFG_SLOTS;
     const bool tr = flags & SFG_TRANSPOSE;
@@ -499,7 +687,9 @@ extern "C" int sfg_mgpu_matmul(sfg_mgpu *mg, const uint64_t *A_host, int s, int 
 static int mgpu_assoc(sfg_mgpu *mg, int fmt, const char *path, size_t num_sample, size_t num_snp, const uint8_t *row_filter, const uint8_t *col_filter, size_t batch_snps,
                       const uint64_t *A_host, size_t nbr, int s, int in_level, int max_level, unsigned flags, uint64_t *out_host, size_t out_ct_capacity, size_t *out_ct,
                       double *sum_host, double *sqsum_host) {
-    if (s < 1 || !nbr || !out_host || !A_host) MG_FAIL(mg, "sfg_mgpu_assoc: bad arguments");
+    MG_NEED(mg, mg != nullptr, "null engine");
+    if (s < 1 || !nbr || !out_host || !A_host || !path) MG_FAIL(mg, "sfg_mgpu_assoc: bad arguments");
+    MgApiScope scope(mg);                                // (before the I/O buffers are requested: they belong to this call)
     const size_t N = SFG_N, ctw_in = 2 * (size_t)(in_level + 1) * N, ctw = 2 * (size_t)max_level * N;
     std::vector<size_t> totals(mg->r.size(), 0);
     const int rc = run_ranks(mg, [&](MgRank &R, int i) {
@@ -508,7 +698,6 @@ static int mgpu_assoc(sfg_mgpu *mg, int fmt, const char *path, size_t num_sample
         R_CTX(R, sfg_scratch(R.ctx, "mg.assoc_out", (size_t)s * out_ct_capacity * ctw * 8, (void **)&out));
         R_CTX(R, sfg_memcpy_h2d(R.ctx, A, A_host, (size_t)s * nbr * ctw_in * 8));
         std::vector<std::pair<size_t, size_t>> ranges;
-        ApiScope api_scope(R.ctx);
         R_CTX(R, assoc_stream_part(R.ctx, fmt, path, num_sample, num_snp, row_filter, col_filter, batch_snps, A, s, in_level, max_level, flags, out, out_ct_capacity, &totals[(size_t)i],
                                    sum_host, sqsum_host, R.rank, mg->world, &ranges));       // (sums: every rank writes the slices of its own batches - disjoint)
         for (const auto &rg : ranges) for (int r = 0; r < s; r++)

@@ -12,6 +12,7 @@
 // bit-identical to lattigo's Montgomery-form butterflies.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "i8_move.hpp"
 #include "ntt_core.hpp"
 
 // IN_MODE 0: rows of canonical u64; 1: half-coefficient input (integer-valued doubles) of a real-slot plaintext
@@ -144,11 +145,12 @@ __global__ void __launch_bounds__(512) k_ntt_inv(const u64 *in_, u64 *out_, ModP
 // Block -> (plaintext, modulus) for the plaintext NTT kernels.  The L workgroups of one plaintext read the same 64 KiB of coefficients; workgroups are
 // dealt round-robin over the 8 XCDs, each with its own L2, so they are numbered b, b + 8, ..., b + 8 (L - 1): same XCD, dispatched back to back -
 // the coefficients come from HBM once instead of once per modulus (measured with row = blockIdx.x: 4.6x the unique bytes).
-__device__ __forceinline__ bool plain_block(size_t nplain, int L, size_t &row, int &m) {
-    const size_t b = blockIdx.x, per = (size_t)8 * L, plain = (b / per) * 8 + (b % per) % 8;
+__device__ __forceinline__ bool plain_block_of(size_t b, size_t nplain, int L, size_t &row, int &m) {
+    const size_t per = (size_t)8 * L, plain = (b / per) * 8 + (b % per) % 8;
     m = (int)((b % per) / 8); row = plain * L + m;
     return plain < nplain;
 }
+__device__ __forceinline__ bool plain_block(size_t nplain, int L, size_t &row, int &m) { return plain_block_of(blockIdx.x, nplain, L, row, m); }
 constexpr int HLDS_DOUBLES = 16 * LDS_ROW;   // 67,584 B
 __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
@@ -351,13 +353,13 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
 // The digit planes are written once and read much later (by the transposition pass, after the whole panel): streaming stores keep them out of the way of the coefficient
 // rows the encode FFT has just left in the cache for this kernel - with them a launch pair takes 2048 plaintexts instead of 1024 (profiles/r05_ntt_streaming_stores.txt)
 #define NT_ST(p, v) __builtin_nontemporal_store((unsigned)(v), (p))
+// (the workgroup's body, for block number vb of a launch over nplain plaintexts: k_ntt_half3, and k_ntt_half3_move where mover workgroups come first in the grid)
 template <bool PERM, bool DIG>
-__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
-                                                      const uint32_t *perm) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void ntt_half3_wg(size_t vb, double *lds, const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all,
+                                             const ModConst *modc, const uint32_t *perm) {
     const int N = SFG_N, n = N / 2, tid = threadIdx.x;
     size_t row; int m;
-    if (!plain_block(nplain, L, row, m)) return;
+    if (!plain_block_of(vb, nplain, L, row, m)) return;
     const double *tw = tw_all + (size_t)m * N;
     const double2 *pack = pack_all + (size_t)m * (N / 2);
     const double q = modc[m].q, qinv = modc[m].qinv;
@@ -460,6 +462,23 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
         else ntt_half3_body(0, first, [&](int j, double x) { out[j] = f64_to_u64(canon(x, q, qinv)); }, lds, tw, pack, q, qinv, tid);
     }
 }
+template <bool PERM, bool DIG>
+__global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
+                                                      const uint32_t *perm) {
+    extern __shared__ double lds[];
+    ntt_half3_wg<PERM, DIG>(blockIdx.x, lds, pc_all, out_, nplain, L, pm, tw_all, pack_all, modc, perm);
+}
+// The same launch with MOVER workgroups in front (i8_move.hpp): the first job.nblocks workgroups of the grid - dispatched first, one to a CU while the CUs are empty -
+// transpose a slice of the PREVIOUS MAC launch's plaintext panel into the int8 MAC's tiles while the NTT workgroups behind them fill the other three slots of every CU.
+// The NTT is fp64-issue bound and leaves two thirds of the HBM rate idle; the mover is HBM bound and needs 8 v_perm per 16 bytes.  A launch has ONE LDS size and ONE
+// register budget, so a mover workgroup lives in the NTT's 34 KiB and 128 VGPRs; the NTT's block -> XCD numbering is kept (nblocks is a multiple of 8).
+template <bool PERM, int DEPTH, bool NT>
+__global__ void __launch_bounds__(256, 4) k_ntt_half3_move(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc,
+                                                           const uint32_t *perm, MoveJob job) {
+    extern __shared__ double lds[];
+    if (blockIdx.x < job.nblocks) { i8_move_block<DEPTH, NT>(job, blockIdx.x, reinterpret_cast<unsigned *>(lds), (int)threadIdx.x); return; }
+    ntt_half3_wg<PERM, true>((size_t)blockIdx.x - job.nblocks, lds, pc_all, out_, nplain, L, pm, tw_all, pack_all, modc, perm);
+}
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
 // CU, instead of one 512-thread workgroup holding a 132 KiB image.  Each half reads both halves of the input (the second read is an L2 hit: the two
 // workgroups of a row are numbered b and b + 8, same XCD) and pays the stage-1 product itself.
@@ -502,6 +521,10 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+#define SFG_MV_ATTR(P, D, T) if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3_move<P, D, T>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES)
+    SFG_MV_ATTR(false, 1, false); SFG_MV_ATTR(false, 1, true); SFG_MV_ATTR(false, 2, false); SFG_MV_ATTR(false, 2, true); SFG_MV_ATTR(false, 3, false); SFG_MV_ATTR(false, 3, true);
+    SFG_MV_ATTR(true, 1, false); SFG_MV_ATTR(true, 1, true); SFG_MV_ATTR(true, 2, false); SFG_MV_ATTR(true, 2, true); SFG_MV_ATTR(true, 3, false); SFG_MV_ATTR(true, 3, true);
+#undef SFG_MV_ATTR
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
 }
@@ -527,10 +550,26 @@ int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, in
     return 0;
 }
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
-int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm) {
+template <bool PERM>
+static void launch_half3_move(sfg_ctx *ctx, dim3 grid, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm, const MoveJob &j) {
+#define SFG_MV(D, T) hipLaunchKernelGGL((k_ntt_half3_move<PERM, D, T>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm, j)
+    if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); }
+    else if (j.depth == 2) { if (j.nt) SFG_MV(2, true); else SFG_MV(2, false); }
+    else { if (j.nt) SFG_MV(1, true); else SFG_MV(1, false); }
+#undef SFG_MV
+}
+int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm, const MoveJob *mv) {
     if (!nplain) return 0;
     const dim3 grid((unsigned)((nplain + 7) / 8 * 8 * L));
     const bool dig = pm.packed_mask >> 31;                 // digit planes for the int8 MAC (mac_i8.hip): its own instances, the default kernels are untouched
+    if (mv && mv->count) {
+        if (!dig || mv->nblocks % 8 || !mv->nblocks) SFG_FAIL(ctx, "plaintext NTT: mover workgroups need the digit-plane form and a multiple of 8 of them");
+        const dim3 g2(grid.x + mv->nblocks);
+        if (perm) launch_half3_move<true>(ctx, g2, pc, out_half, nplain, L, pm, perm, *mv);
+        else launch_half3_move<false>(ctx, g2, pc, out_half, nplain, L, pm, (const uint32_t *)nullptr, *mv);
+        SFG_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     if (perm && dig) hipLaunchKernelGGL((k_ntt_half3<true, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (perm) hipLaunchKernelGGL((k_ntt_half3<true, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (dig) hipLaunchKernelGGL((k_ntt_half3<false, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);

@@ -41,12 +41,13 @@ using CipherMatrix = std::vector<CipherVector>;
 
 // HBM-resident genotype matrices keyed by the reference's cacheFilePrefix (see gwas::MatMult4StreamPreprocess); owned by the
 // CryptoParams that created them and shared with its forks - no process-global table
-struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; bool owner = false; sfg_mgeno *mg = nullptr; };   // mg: sharded by SNP block over the GPUs of a multi-GPU CryptoParams
+struct ResidentGeno { sfg_geno *g = nullptr; unsigned flags = 0; bool owner = false; sfg_mgeno *mg = nullptr; uint64_t nrow = 0, ncol = 0; };   // mg: sharded by SNP block over the GPUs of a multi-GPU CryptoParams
 struct ResidentTable { std::mutex mu; std::map<std::string, ResidentGeno> tab; };
 
 struct CryptoParams {             // crypto.go:32-60 (the parts the hot path touches)
     sfg_ctx *ctx = nullptr;
     sfg_mgpu *mg = nullptr;          // set by NewCryptoParamsMulti: the party's node (one context per device, owned by the engine); ctx is then device 0's context
+    sfg_mgpu *mg_root = nullptr;     // forks: the engine of the object they were forked from (not owned) - the sharded matrices of the shared table multiply on it
     int logN = 14, nq = 0, np = 0;
     double scale = 0;
     std::vector<uint64_t> qi;                                        // ciphertext moduli q_0..q_{nq-1} (Params.Qi())
@@ -69,6 +70,7 @@ struct CryptoParams {             // crypto.go:32-60 (the parts the hot path tou
         auto c = std::make_unique<CryptoParams>();
         check(sfg_ctx_fork(ctx, &c->ctx), "sfg_ctx_fork");
         c->logN = logN; c->nq = nq; c->np = np; c->scale = scale; c->qi = qi; c->resident = resident;
+        c->mg_root = mg ? mg : mg_root;
         return c;
     }
 };
@@ -894,18 +896,51 @@ MatMult4Stream(crypto::CryptoParams *cps, const crypto::CipherMatrix &A, GenoFil
 // matmult.go:914 / :1043.  The DiagCache files of the reference become an HBM-resident int8 matrix keyed by the
 // same cacheFilePrefix; `transposeOf` registers a prefix as the transpose of an already resident matrix, which is how
 // pca.go:112-113 (X cache, X^T cache) maps onto ONE resident copy.
+// The matrix is read the way the reference reads it - one row at a time out of GenoFileStream::NextRow (matmult.go:942-950, filestream.go:414-426) - into a
+// staging buffer of a few thousand rows (kPreprocessStagingBytes) that sfg_geno_write_rows hands to the device: nothing here scales with nrow * ncol.  A prefix whose
+// matrix is the TRANSPOSE of a resident one is recognised on the device, chunk by chunk (sfg_geno_compare_rows: exact comparison, X^T is never held), and becomes a
+// view of the one int8 copy - the explicit `transposeOf` says so without reading the file.
+constexpr size_t kPreprocessStagingBytes = 64u << 20;
+template <class Visit> inline void streamRows(GenoFileStream *gfs, uint64_t nrow, uint64_t ncol, Visit visit, size_t stagingBytes = kPreprocessStagingBytes) {
+    gfs->Reset();
+    const uint64_t per = std::max<uint64_t>(1, stagingBytes / ncol);
+    std::vector<int8_t> stage(per * ncol);
+    for (uint64_t row0 = 0; row0 < nrow; row0 += per) {
+        const uint64_t n = std::min(per, nrow - row0);
+        for (uint64_t r = 0; r < n; r++) { auto row = gfs->NextRow(); if (row.size() != ncol) throw std::runtime_error("GenoFileStream: unexpected row length"); memcpy(&stage[r * ncol], row.data(), ncol); }
+        if (!visit(row0, n, stage.data())) return;
+    }
+}
 inline void MatMult4StreamPreprocess(crypto::CryptoParams *cps, GenoFileStream *gfs, int /*maxLevel*/, const std::string &cacheFilePrefix,
-                                     const std::string &transposeOf = "") {
+                                     const std::string &transposeOf = "", size_t stagingBytes = kPreprocessStagingBytes) {
     std::lock_guard<std::mutex> lk(cps->resident->mu);
     auto &tab = cps->resident->tab;
     if (tab.count(cacheFilePrefix)) return;                          // "Found cache file" (filestream.go:52-54): skip
-    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE, false, it->second.mg}; return; }
-    uint64_t nrow, ncol; std::vector<int8_t> geno = readAllRows(gfs, nrow, ncol);
-    crypto::ResidentGeno r;
+    if (!transposeOf.empty()) { auto it = tab.find(transposeOf); if (it == tab.end()) throw std::runtime_error("transposeOf prefix is not resident"); tab[cacheFilePrefix] = {it->second.g, SFG_TRANSPOSE, false, it->second.mg, it->second.nrow, it->second.ncol}; return; }
+    const uint64_t nrow = gfs->NumRowsToKeep(), ncol = gfs->NumColsToKeep();
+    sfg_mgpu *eng = cps->mg ? cps->mg : cps->mg_root;
+    auto fail = [&](const char *what) { throw std::runtime_error(std::string("MatMult4StreamPreprocess: ") + what + ": " + (eng ? sfg_mgpu_last_error(eng) : sfg_last_error(cps->ctx))); };
+    for (auto &kv : tab) {                                           // pca.go:113: is this the transpose of a matrix that is already resident?
+        const crypto::ResidentGeno &r = kv.second;
+        if (r.flags || r.nrow != ncol || r.ncol != nrow) continue;
+        uint64_t ndiff = 0;
+        streamRows(gfs, nrow, ncol, [&](uint64_t row0, uint64_t n, const int8_t *chunk) {
+            if (r.mg ? sfg_mgpu_geno_compare_rows(eng, r.mg, SFG_TRANSPOSE, row0, n, chunk, ncol, &ndiff) : sfg_geno_compare_rows(cps->ctx, r.g, SFG_TRANSPOSE, row0, n, chunk, ncol, &ndiff)) fail("compare_rows");
+            return ndiff == 0;
+        }, stagingBytes);
+        if (!ndiff) { tab[cacheFilePrefix] = {r.g, SFG_TRANSPOSE, false, r.mg, r.nrow, r.ncol}; return; }
+    }
+    crypto::ResidentGeno r; r.nrow = nrow; r.ncol = ncol;
     if (cps->mg) {               // the STORED orientation's columns (pca.go:112: X, individuals x SNPs) are the shards
-        if (sfg_mgpu_geno_upload(cps->mg, geno.data(), nrow, ncol, ncol, &r.mg)) throw std::runtime_error(std::string("MatMult4StreamPreprocess: ") + sfg_mgpu_last_error(cps->mg));
-    } else cps->check(sfg_geno_upload(cps->ctx, geno.data(), nrow, ncol, ncol, &r.g), "MatMult4StreamPreprocess");
+        if (sfg_mgpu_geno_create(cps->mg, nrow, ncol, &r.mg)) fail("geno_create");
+    } else cps->check(sfg_geno_create(cps->ctx, nrow, ncol, &r.g), "MatMult4StreamPreprocess");
     r.owner = true;
+    try {
+        streamRows(gfs, nrow, ncol, [&](uint64_t row0, uint64_t n, const int8_t *chunk) {
+            if (r.mg ? sfg_mgpu_geno_write_rows(cps->mg, r.mg, row0, n, chunk, ncol) : sfg_geno_write_rows(cps->ctx, r.g, row0, n, chunk, ncol)) fail("write_rows");
+            return true;
+        }, stagingBytes);
+    } catch (...) { if (r.mg) sfg_mgpu_geno_free(cps->mg, r.mg); else sfg_geno_free(cps->ctx, r.g); throw; }
     tab[cacheFilePrefix] = r;
 }
 inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, const crypto::CipherMatrix &A, int maxLevel, const std::string &cacheFilePrefix,
@@ -919,7 +954,9 @@ inline crypto::CipherMatrix MatMult4StreamCompute(crypto::CryptoParams *cps, con
     if (rg.mg) {                 // every GPU of the node: shards, the exchange of Q' X^T and the gather happen inside the library (mgpu.hip)
         const int s = (int)A.size(), inLevel = A[0][0].Level();
         std::vector<uint64_t> a = flattenCipherMatrix(A), o((size_t)s * m_ct * 2 * maxLevel * cps->N());
-        if (sfg_mgpu_matmul(cps->mg, a.data(), s, inLevel, maxLevel, rg.mg, rg.flags, o.data())) throw std::runtime_error(std::string("MatMult4StreamCompute: ") + sfg_mgpu_last_error(cps->mg));
+        sfg_mgpu *eng = cps->mg ? cps->mg : cps->mg_root;              // a fork multiplies on the engine of its root (one call at a time per engine: the caller's rule, as for any context)
+        if (!eng) throw std::runtime_error("MatMult4StreamCompute: the matrix of prefix " + cacheFilePrefix + " is sharded over a multi-GPU engine this CryptoParams has no access to");
+        if (sfg_mgpu_matmul(eng, a.data(), s, inLevel, maxLevel, rg.mg, rg.flags, o.data())) throw std::runtime_error(std::string("MatMult4StreamCompute: ") + sfg_mgpu_last_error(eng));
         return unflatten(o, s, m_ct, maxLevel - 1, A[0][0].Scale() * cps->scale, cps->N());
     }
     if (!rg.g) {

@@ -25,8 +25,18 @@ int main(int argc, char **argv) {
         crypto::CipherMatrix A = gwas::unflatten(readU64(dir + "/A.bin"), s, nbr, level, 17179869184.0, N);
         crypto::CipherMatrix AT = gwas::unflatten(readU64(dir + "/AT.bin"), s, m_ct, level, 17179869184.0, N);
         gwas::GenoFileStream gfs(dir + "/geno.bin", nrow, ncol, true);
-        gwas::MatMult4StreamPreprocess(cps.get(), &gfs, maxLevel, dir + "/cache_X");                         // pca.go:112
-        gwas::MatMult4StreamPreprocess(cps.get(), nullptr, maxLevel, dir + "/cache_XT", dir + "/cache_X");     // pca.go:113: the transposed view of the same shards
+        // pca.go:112: X, read one row at a time into a 1 MiB staging buffer (a few rows per chunk: every chunk is scattered to the three ranks' windows)
+        gwas::MatMult4StreamPreprocess(cps.get(), &gfs, maxLevel, dir + "/cache_X", "", 1u << 20);
+        // pca.go:113: X^T from ITS OWN file, as the reference has it (gwas.go:597 geno_pca_transpose.bin) - recognised on the devices as the transpose of the resident
+        // shards (chunks of 300 kB straddle the ranks' column windows), so no second copy is made
+        gwas::GenoFileStream gfsT(dir + "/geno_t.bin", ncol, nrow, true);
+        gwas::MatMult4StreamPreprocess(cps.get(), &gfsT, maxLevel, dir + "/cache_XT", "", 300u << 10);
+        { std::lock_guard<std::mutex> lk(cps->resident->mu); const auto &e = cps->resident->tab.at(dir + "/cache_XT");
+          if (e.flags != SFG_TRANSPOSE || e.owner || e.mg != cps->resident->tab.at(dir + "/cache_X").mg) throw std::runtime_error("X^T was not recognised as the transpose of the resident X"); }
+        // an unrelated matrix of X^T's shape is NOT taken for it (one entry differs): it becomes a matrix of its own
+        gwas::GenoFileStream gfsU(dir + "/geno_u.bin", ncol, nrow, true);
+        gwas::MatMult4StreamPreprocess(cps.get(), &gfsU, maxLevel, dir + "/cache_U", "", 300u << 10);
+        { std::lock_guard<std::mutex> lk(cps->resident->mu); const auto &e = cps->resident->tab.at(dir + "/cache_U"); if (e.flags || !e.owner) throw std::runtime_error("a different matrix was taken for X^T"); }
         auto o1 = gwas::MatMult4StreamCompute(cps.get(), A, maxLevel, dir + "/cache_X", m_ct);                // pca.go:344 -> matmult.go:42
         auto o2 = gwas::MatMult4StreamCompute(cps.get(), AT, maxLevel, dir + "/cache_XT", nbr);               // pca.go:352 -> matmult.go:91
         if ((int)o1.size() != s || (int)o1[0].size() != m_ct || (int)o2[0].size() != nbr || o1[0][0].Level() != maxLevel - 1) throw std::runtime_error("bad output shape");

@@ -267,3 +267,84 @@ def test_adopted_shards_packed_residency_and_the_plaintext_cache(ref, monkeypatc
         mg.geno_free(g)                                    # owns the adopted handles
     finally:
         mg.close()
+
+
+def test_preflight_and_what_the_communicator_reports(ref, monkeypatch):
+    """sfg_mgpu_preflight pushes a known uint64 pattern through the engine's reduce-scatter and all-reduce (the functions the products use) and checks it on the host;
+    sfg_mgpu_comm_info reads the rank count off the RCCL communicator itself.  World 1 over RCCL (forced exchange), worlds 2 and 3 over the direct transport."""
+    mg = make_engine(monkeypatch, [0], {"SFG_MGPU_FORCE_COLLECTIVES": "1"})
+    try:
+        assert mg.transport == "rccl"
+        mg.preflight(4096)
+        mg.preflight(1)
+        assert mg.comm_info(0) == (1, 0)                 # ncclCommCount, ncclCommUserRank
+        with pytest.raises(Exception, match="out of range"):
+            mg.comm_info(3)
+    finally:
+        mg.close()
+    for n in (2, 3):
+        mg = make_engine(monkeypatch, [0] * n)
+        try:
+            mg.preflight(1000)
+            assert mg.comm_info(n - 1) == (0, 0)         # the direct transport holds no communicator
+        finally:
+            mg.close()
+    mg = make_engine(monkeypatch, [0])                   # world 1, no exchange: nothing to check, and that is not an error
+    try:
+        mg.preflight(16)
+        assert mg.comm_info(0) == (0, 0)
+    finally:
+        mg.close()
+
+
+def test_two_rank_engine_products_against_the_oracle_directly():
+    """The engine's own oracle test at the C-ABI (not through the C++ mirror): 2 ranks over the direct transport, X = 70 x (8192 + 40) - two SNP blocks, one per rank.
+    Q X (output-sharded: each rank one block column) and Q' X^T (contraction-sharded: per-column reduce-scatter over the padded giant slots, reduce, finalize of the
+    owned giants, all-reduce) against orc_matmult4stream (gwas/matmult.go:1043-1236, 1238-1505) with real key-switching keys: every output word."""
+    from sfgwas_amd import capi
+    ring = ol.Ring(14, ol.Q_PN14, ol.P_PN14)
+    keys = ol.RotKeys(ring)
+    rnd = np.random.default_rng(43)
+    nrow, ncol, s, level = 70, SLOTS + 40, 2, 5
+    geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
+    mg = capi.MultiGpu(ol.Q_PN14, ol.P_PN14, devices=[0, 0])
+    try:
+        assert mg.transport == "direct"
+        for k in sorted(set(range(1, D)) | {g * D for g in range(1, D) if g * D < SLOTS}):
+            key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 700 + k)
+            keys.add(ring.galois(k), key)
+            mg.load_rotkey(ring.galois(k), key)
+        g = mg.geno_create(nrow, ncol)                                   # registered the way MatMult4StreamPreprocess reads it: row chunks
+        for lo in range(0, nrow, 32):
+            mg.geno_write_rows(g, lo, geno[lo:lo + 32])
+        A = np.stack([np.stack([ring.fill_uniform(level, 150 + i)]) for i in range(s)])                          # Q : s x 1 block row
+        AT = np.stack([np.stack([ring.fill_uniform(level, 170 + 2 * i + b) for b in range(2)]) for i in range(s)])  # Q': s x 2 SNP blocks
+        got = mg.matmul(A, s, level, L, g, 0)
+        want, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, A, level, L, geno)
+        assert np.array_equal(got, want), f"Q X: {np.count_nonzero(got != want)} words differ"
+        got_t = mg.matmul(AT, s, level, L, g, T)
+        want_t, _, _ = ol.matmult4stream(ring, keys, 2.0 ** 34, AT, level, L, np.ascontiguousarray(geno.T))
+        assert np.array_equal(got_t, want_t), f"Q' X^T: {np.count_nonzero(got_t != want_t)} words differ"
+        mg.geno_free(g)
+    finally:
+        mg.close()
+
+
+@pytest.mark.parametrize("victim", ["mg.mine:2", "mm.skew:3"])
+def test_scratch_eviction_inside_an_engine_call_keeps_the_calls_own_buffers(ref, monkeypatch, victim):
+    """sfg_mgpu_matmul asks for its I/O buffers (mg.Ain, mg.Oout) in a first pass over the ranks and multiplies in a second; when the device is full the
+    scratch pool gives back what EARLIER top-level calls asked for - which must not include the running call's own input and output.  SFG_TEST_SCRATCH_OOM (test switch)
+    makes the n-th request of one buffer behave as 'device full' on every rank, in the SECOND product of an engine (so that buffers of an earlier call exist): the
+    eviction path runs with mg.Ain / mg.Oout live, and every output word must still be right."""
+    geno, small, Ah, Ash, want, wants = ref
+    mg = make_engine(monkeypatch, [0, 0], {"SFG_ENABLE_TEST_HOOKS": "1", "SFG_TEST_SCRATCH_OOM": victim})
+    g = mg.geno_upload(geno)
+    try:
+        for rep in range(2):
+            got = mg.matmul(Ah[T], S, LEVEL, L, g, T)
+            assert np.array_equal(got, want[T]), f"call {rep}: {np.count_nonzero(got != want[T])} words differ"
+        got = mg.matmul(Ah[0], S, LEVEL, L, g, 0)
+        assert np.array_equal(got, want[0])
+    finally:
+        mg.geno_free(g)
+        mg.close()

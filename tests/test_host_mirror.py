@@ -1030,6 +1030,8 @@ def test_host_mirror_on_a_multi_gpu_party_matches_the_oracle(tmp_path):
     nrow, ncol, s, level, L = 70, 2 * slots + 40, 2, 5, 5
     geno = rnd.integers(-1, 3, (nrow, ncol)).astype(np.int8)
     geno.tofile(tmp_path / "geno.bin")
+    np.ascontiguousarray(geno.T).tofile(tmp_path / "geno_t.bin")                                  # pca.go:113 registers X^T from its own file (gwas.go:597)
+    other = np.ascontiguousarray(geno.T); other[ncol - 1, nrow - 1] ^= 1; other.tofile(tmp_path / "geno_u.bin")     # X^T's shape, one entry different
     steps = set(range(1, d)) | {g * d for g in range(1, d) if g * d < slots} | {slots - 1}       # every baby and giant step (the engine's rank-local rotation cache rotates all 91 babies)
     blob = [np.array([len(steps)], dtype=np.uint64)]
     for k in sorted(steps):
