@@ -153,6 +153,47 @@ def cpu_baseline(seconds, L, N, D):
                       f"mode (encode excluded); CPU restatement, not the Go binary"}
 
 
+def cpu_end_to_end(ctx, P, threads, cores):
+    """north_star: "the reference Go CPU path timed on the same host".  The Go binary cannot be built (no toolchain, un-vendored modules), so this is the repository's
+    CPU restatement of the WHOLE MatMult4Stream (oracle/sfgwas_oracle.c: orc_matmult4stream = GetDiag, rotation-before-encode, big-float inverse embedding + NTT +
+    MForm per diagonal, the baby-step key switches, the lazy u128 MAC, REDC, the giant-step key switches; gwas/matmult.go:1238-1505) on ONE 8192 x 8192 block at
+    s = kp, work-shared over the giant steps with OpenMP on the granted cores, built -O3 -march=native on this host.  The restatement is a checker, not a tuned CPU
+    implementation; the figure is a reported baseline, labelled as such.  Encoder precision: the double-double form (enc_prec = 1, what the parity gate runs) is timed
+    on the whole block; the reference's big-float encoder is restated at 113 bits (__float128), whose extra cost per diagonal is measured on a 1024 x 1024 block
+    (2047 diagonals) and added for all 8192."""
+    import numpy as np
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL)
+    os.environ["SFG_ORACLE_SO"] = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
+    ol = oracle_lib()
+    ol._lib = None                                          # (the gate ran on the -O2 test build: reload as the native one)
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    except OSError:
+        pass
+    ring = ol.Ring(P.LOGN, P.Q_PN14, P.P_PN14)
+    keys = ol.RotKeys(ring)
+    for k in P.rotations_for_matmul():                      # the bench context's synthetic keys (timing-equivalent to real ones)
+        g = ring.galois(k)
+        keys.add(g, ctx.export_rotkey(g))
+    rnd = np.random.default_rng(0xE2E)
+
+    def run(n, s, prec):
+        geno = rnd.integers(0, 3, (n, n)).astype(np.int8)
+        A = np.stack([np.stack([ring.fill_uniform(P.MAX_LEVEL, 900 + i)]) for i in range(s)])
+        t0 = time.perf_counter()
+        ol.matmult4stream(ring, keys, P.DEFAULT_SCALE, A, P.MAX_LEVEL, P.MAX_LEVEL, geno, enc_prec=prec)
+        return time.perf_counter() - t0
+    t_block = run(P.SLOTS, KP, 1)
+    t_dd, t_q = run(1024, 1, 1), run(1024, 1, 0)
+    extra = max(t_q - t_dd, 0.0) / 2047 * P.SLOTS
+    macs = P.SLOTS * P.SLOTS * KP * 2 * P.MAX_LEVEL * (P.N // P.SLOTS)
+    return {"value": macs / t_block, "unit": "ring-MAC/s (useful, end to end)", "cores": int(threads), "cores_granted_vs_present": cores, "kind": "port",
+            "seconds_per_block": t_block, "value_113bit_encoder": macs / (t_block + extra), "seconds_per_block_113bit_encoder": t_block + extra,
+            "sample": f"orc_matmult4stream on one {P.SLOTS} x {P.SLOTS} block, s = {KP}, all 8192 diagonals: encode (double-double) + NTT + MForm + {KP * 90} baby-step and "
+                      f"giant-step key switches + lazy u128 MAC + REDC, OpenMP over giant steps on {int(threads)} threads: {t_block:.1f} s; 113-bit encoder: + "
+                      f"{extra:.1f} s per block (from {t_dd:.1f} s vs {t_q:.1f} s on a 1024 x 1024 block, s = 1); CPU restatement (the repository's checker), not the Go binary"}
+
+
 class Coll:
     """The collectives of the N > 1 path on device tensors.  nccl: RCCL, stream-ordered by torch.distributed.  gloo: staged through host
     memory (several ranks may then share one GPU: a correctness rehearsal of the same sequence, not a measurement)."""
@@ -268,6 +309,42 @@ def roofline_blocks(phase_tot, args, dims, world, dt, value):
 PHASES = ("rotate", "skew", "encode", "mac", "mac_small", "mac_big", "ntt_plain", "ntt_plain_all", "mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile")
 
 
+class Watchdog:
+    """A bounded wait around calls that only return when every rank has entered them (ncclCommInitRank, the first collectives): after `seconds` the process prints
+    what it was waiting in and ends with exit code 3 (os._exit: the stuck thread cannot be interrupted).  Never a re-exec - the GPU box forbids that."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.t = threading.Timer(seconds, self._fire, (seconds, what))
+        self.t.daemon = True
+        self.t.start()
+
+    @staticmethod
+    def _fire(seconds, what):
+        print(f"[bench] WATCHDOG: {what} did not finish within {seconds:.0f} s - a rank is missing or the fabric is stuck; exiting with code 3", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def cancel(self):
+        self.t.cancel()
+
+
+# SHA-256 digests of both products per config (inputs are seeded, so they are constants of the repository; equal for every world size).  c4 is what
+# tests/test_gpu_fullsize.py pins together with oracle comparisons at c4's launch shapes; c2 / c3 are the single-GPU lines of tests/test_gpu_multirank.py.
+PINNED_DIGESTS = {
+    "c4": ("cab05b5a8326ff9dc51f0e139c2261d47dc2a8830541a134273bffbc6f3888e6", "ce9b0e28cb6318dafb77b27fbdff1d4491f3fcb3e70548d5bfac723753d7ee62"),
+    "c3": ("75244cd9836057918b53e584e72004d7aee63a5908e80a2e8a1181730467718a", "4e072d7c88b672eb61068ff02e799c17f92b5a58da579c42e12d9329ff3591d8"),
+    "c2": ("fbececb714c4aab7ab983ebc25838a00ec5c24ff123268c9c4999b645f3d37d3", "06753f44a4a7795161f6abe191e28332b0e3db0d127c73c5e93d0591cbbd6672"),
+}
+
+
+def digests_match_pinned(config, digests):
+    """True / False; None when the config has no pinned value"""
+    pin = PINNED_DIGESTS.get(config)
+    if not pin or not digests:
+        return None
+    return (digests["out1_sha256"], digests["out2_sha256"]) == pin
+
+
 def main_lib_engine(args):
     """N > 1 with the multi-GPU sequence INSIDE the library (sfg_mgpu_*, sfgwas_amd/csrc/mgpu.hip): this script only makes the synthetic inputs, calls the two
     products per step, keeps the clock and hashes the outputs.  One process per GPU (the driver's launch: each rank joins with sfg_mgpu_create_rank and a 128-byte
@@ -300,6 +377,7 @@ def main_lib_engine(args):
         devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
         if len(devices) != world:
             raise SystemExit(f"--devices names {len(devices)} ranks, --gpus {world}")
+        watchdog = Watchdog(float(os.environ.get("SFG_BENCH_COMM_TIMEOUT_S", "300")), "communicator creation (ncclCommInitAll) / pre-flight collectives")
         mg = capi.MultiGpu(P.Q_PN14, P.P_PN14, devices=devices)
     else:
         rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
@@ -307,22 +385,55 @@ def main_lib_engine(args):
             raise SystemExit(f"--gpus {world} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)          # host-side only: the id, barriers, the clock's max, the digest gather.  The data path's
-        box = [capi.MultiGpu.unique_id() if rank == 0 else None]              # collectives are the library's own RCCL calls.
+        devices = [local_rank]                                                # collectives are the library's own RCCL calls.
+
+        def agree(ok, what):
+            """every rank leaves with the same verdict (MIN over gloo) BEFORE anybody enters a call that only returns when all ranks have entered it"""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if args.allow_engine_fallback:
+                    if rank == 0:
+                        print(f"[bench] {what} failed on a rank: falling back to --engine torch (--allow-engine-fallback)", file=sys.stderr, flush=True)
+                    dist.destroy_process_group()
+                    return False
+                raise SystemExit(f"[bench] rank {rank}: {what} failed on {'this' if not ok else 'another'} rank; no fallback without --allow-engine-fallback")
+            return True
+        # (1) can every rank make a context on its device at all?  ncclCommInitRank below returns only when ALL ranks have called it: a rank that dies before it
+        # would leave the others waiting for ever (ADVICE r5), so the cheap failure modes are found and agreed on first.
+        err = None
+        try:
+            probe = capi.Context(P.Q_PN14, P.P_PN14, device=local_rank)
+            probe.close()
+        except Exception as e:                                               # noqa: BLE001 - whatever it is, the other ranks must hear of it
+            err = e
+            print(f"[bench] rank {rank}: cannot create a context on device {local_rank}: {e}", file=sys.stderr, flush=True)
+        if not agree(err is None, "sfg_ctx_create"):
+            return "fallback"
+        box = [capi.MultiGpu.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        devices = [local_rank]
+        # (2) communicator creation and the first collectives under a watchdog: RCCL has no timeout of its own.  The watchdog ends THIS process (never a re-exec)
+        watchdog = Watchdog(float(os.environ.get("SFG_BENCH_COMM_TIMEOUT_S", "300")), f"rank {rank}: communicator creation / pre-flight collectives")
         try:
             mg = capi.MultiGpu(P.Q_PN14, P.P_PN14, rank=rank, world=world, uid=box[0], device=local_rank)
-            ok = 1
+            ok = True
         except capi.SfgError as e:
-            print(f"[bench] rank {rank}: sfg_mgpu_create_rank failed ({e}); falling back to --engine torch", file=sys.stderr, flush=True)
-            mg, ok = None, 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                        # every rank takes the same path
-        if int(flag.item()) == 0:
+            print(f"[bench] rank {rank}: sfg_mgpu_create_rank failed: {e}", file=sys.stderr, flush=True)
+            mg, ok = None, False
+        if not agree(ok, "sfg_mgpu_create_rank"):
             if mg is not None:
                 mg.close()
-            dist.destroy_process_group()
+            watchdog.cancel()
             return "fallback"
+    # (3) pre-flight: a reduce-scatter and an all-reduce of a known pattern through the engine's own exchange functions, checked on the host (sfg_mgpu_preflight);
+    # what the communicator itself says about the world (ncclCommCount) goes into the line
+    mg.preflight(1 << 16)
+    comm_ranks = [mg.comm_info(i)[0] for i in range(mg.nlocal)]
+    watchdog.cancel()
+    if not single:
+        allr = [None] * world
+        dist.all_gather_object(allr, comm_ranks)
+        comm_ranks = [x for sub in allr for x in sub]
     lib = capi.lib()
     nloc = mg.nlocal
     shared_device = len(set(devices)) < len(devices)
@@ -466,10 +577,16 @@ def main_lib_engine(args):
                        "rotation_cache_QX": "replicated",
                        "QtXt_reduce_scatter": "per output block column, on the collectives' queue beside the next column's product"},
         }
+        # what a multi-GPU record must be able to say by itself: how many ranks RCCL saw, which engine ran, and whether the words are the pinned ones
+        res["rccl_ranks"] = comm_ranks[0] if len(set(comm_ranks)) == 1 else comm_ranks
+        res["rccl_ranks_of"] = "ncclCommCount of every rank's communicator (sfg_mgpu_comm_info); 0 = no communicator (direct transport / world 1)"
+        res["engine_fallback"] = False
+        res["preflight"] = "ok: reduce-scatter + all-reduce of a known uint64 pattern through the engine's exchange functions, 65536 words per rank slice, checked on the host"
         if gate is not None:
             res["parity_gate"] = gate
         if digests is not None:
             res["digests"] = digests
+            res["digests_match_pinned"] = digests_match_pinned(args.config, digests)
         res["encoder_near_ties"] = {"count": near_ties, "within_2^-50": unprovable.value, "what": "rank 0; see the N = 1 line"}
         if phase_tot.get("mac_small", [0, 0, 0])[1] and "mac_i8_pack_pt" in phase_tot:
             res["roofline"] = roofline_blocks(phase_tot, args, (n_ind, m_snp, nbr_x, mct_x, N, L, D, SLOTS, LEVEL), world, dt, value)
@@ -492,8 +609,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("SFG_BENCH_CONFIG", "c4"))
-    ap.add_argument("--cpu-seconds", type=float, default=18.0, help="bounded CPU-baseline sample (seconds of wall time)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bounded CPU-baseline sample (seconds of wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-end-to-end", action="store_true", help="skip the end-to-end CPU leg (one 8192 x 8192 block through the whole CPU restatement, ~ 30 s)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle parity gate")
     ap.add_argument("--no-digest", action="store_true", help="skip the SHA-256 digests of the outputs")
     ap.add_argument("--backend", default=os.environ.get("SFG_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
@@ -505,16 +623,28 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="engine lib: ONE process drives all N GPUs (sfg_mgpu_create + ncclCommInitAll, one host thread per device) - the form a Go party process uses - "
                          "instead of one process per GPU")
+    ap.add_argument("--allow-engine-fallback", action="store_true",
+                    help="N > 1, engine lib: if the library's engine cannot be created on some rank, run the torch-issued sequence instead (the line then says "
+                         "engine_fallback: true).  Default: exit non-zero with the failing rank's error - a scaling record must not change what it measures silently")
     ap.add_argument("--devices", default=None, help="--single-process: comma-separated device indices of the N ranks (a repeated device selects the in-process "
                                                     "'direct' transport: a rehearsal of N > 1 on one GPU; timings then mean nothing)")
     args = ap.parse_args()
+    # switches of this script that need more than the product library offers: the timing-only solo rank and the kernel A/B switches live in the experimenters' build
+    # (sfgwas_amd/lib_ab, `make -C sfgwas_amd/csrc ab`); the forced exchange at one rank is a test switch of the product library
+    if os.environ.get("SFG_MGPU_SOLO") and not os.environ.get("SFG_LIB_PATH"):
+        from sfgwas_amd import capi as _capi
+        os.environ["SFG_LIB_PATH"] = _capi.ab_lib()
+        _capi.LIB_PATH = os.environ["SFG_LIB_PATH"]
+    if os.environ.get("SFG_MGPU_FORCE_COLLECTIVES") == "1":
+        os.environ.setdefault("SFG_ENABLE_TEST_HOOKS", "1")
     # SFG_MGPU_FORCE_COLLECTIVES=1 runs the library's exchange even with one rank (over RCCL): `--gpus 1` then takes the engine too
     if ((args.gpus > 1 or os.environ.get("SFG_MGPU_FORCE_COLLECTIVES") == "1" or os.environ.get("SFG_MGPU_SOLO")) and args.engine == "lib" and args.backend == "nccl"
             and not os.environ.get("SFG_BENCH_SOLO") and os.environ.get("SFG_BENCH_FORCE_COLLECTIVES") != "1"):
         rc = main_lib_engine(args)
         if rc != "fallback":
             return rc
-        args.engine = "torch"             # the library's engine could not be created on this node (every rank saw the same failure): the torch-issued sequence
+        args.engine = "torch"             # --allow-engine-fallback: the library's engine could not be created on this node (every rank agreed): the torch-issued sequence
+        args.engine_fallback = True
     return main_torch(args)
 
 
@@ -832,6 +962,11 @@ def main_torch(args):
             res["parity_gate"] = gate
         if digests is not None:
             res["digests"] = digests
+            res["digests_match_pinned"] = digests_match_pinned(args.config, digests)
+        if world > 1:
+            res["engine_fallback"] = bool(getattr(args, "engine_fallback", False))       # true: --allow-engine-fallback was given AND the library's engine could not be created
+            res["rccl_ranks"] = dist.get_world_size() if use_dist and args.backend == "nccl" else 0
+            res["rccl_ranks_of"] = "torch.distributed world size of the nccl (= RCCL) process group (--engine torch); 0 = gloo rehearsal"
         res["encoder_near_ties"] = {"count": near_ties, "within_2^-50": unprovable.value, "what": "encoder coefficients within 2^-40 of a rounding tie on rank 0 (0 = every plaintext provably "
                                                                  "rounded as the reference's 256-bit EncoderBig rounds it); a non-zero within_2^-50 count makes the library's synchronising entry points fail "
                                                                  "(about once per 10^15 coefficients; 2 x 10^11 per step here)"}
@@ -891,6 +1026,11 @@ def main_torch(args):
         res["phases_ms_per_step"] = {k: v[0] / args.steps for k, v in phase_tot.items()}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L, N, D)
+            if not args.no_cpu_end_to_end:
+                try:
+                    res["cpu_baseline"]["end_to_end"] = cpu_end_to_end(ctx, P, res["cpu_baseline"]["cores"], res["cpu_baseline"]["cores_granted_vs_present"])
+                except Exception as e:                       # noqa: BLE001 - a baseline leg must not lose the measured line
+                    res["cpu_baseline"]["end_to_end"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
     lib.sfg_geno_free(ctx.h, gh)
     ctx.close()

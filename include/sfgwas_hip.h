@@ -40,6 +40,26 @@ typedef struct sfg_geno sfg_geno;
  * derived from the smallest primitive root exactly as lattigo derives it. */
 int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int np,
                    const uint64_t *moduli, const uint64_t *psi, double scale);
+/* The configuration a deployment legitimately tunes - the counterpart of the reference's TOML keys (gwas/gwas.go:40-117 `Config`; SURVEY section 5: "GPU knobs = new
+ * optional TOML keys; defaults must reproduce reference behaviour").  Zero in a field = the library's default.  None of these changes a result word.  The same fields can
+ * be given by an operator through the environment (read once, at creation; it overrides this struct): SFG_MM_GROUP, SFG_MM_ACC_BUDGET_MB, SFG_ASSOC_ROTCACHE_MB,
+ * SFG_KSW_BUDGET_MB, SFG_ENC_BATCH, SFG_UPLOAD_BLOCKING, SFG_MGPU_TRANSPORT, SFG_MGPU_CACHE_GB, SFG_RCCL_LIB.  Kernel A/B and diagnostic switches are NOT part of this
+ * library: they exist in the experimenters' build only (`make -C sfgwas_amd/csrc ab`). */
+typedef struct sfg_config {
+    uint32_t struct_size;            /* sizeof(sfg_config) of the caller's header (sfg_config_default sets it): lets the struct grow */
+    int mm_group;                    /* block rows of the matrix multiplied per MAC launch; 0 = 8, or 10 .. 24 when their operands fit the free HBM */
+    size_t acc_budget_bytes;         /* accumulators of the block columns of one pass; 0 = 24 GiB */
+    size_t assoc_rotcache_bytes;     /* largest call-wide baby-step rotation cache of an association scan; 0 = 160 GiB; SIZE_MAX = none (rebuilt per batch, as the reference does) */
+    size_t ksw_budget_bytes;         /* key-switch scratch per job chunk; 0 = 4 GiB */
+    int enc_batch;                   /* diagonals per encode FFT / plaintext-NTT launch pair, 64 .. 8192; 0 = 2048 */
+    int upload_blocking;             /* != 0: blocking pointer-table uploads (needed under rocprofv3 --pmc) */
+    const char *mgpu_transport;      /* sfg_mgpu_create*_ex: NULL / "rccl" (default) or "direct" (one process only: ranks read their peers' buffers) */
+    size_t mgpu_cache_bytes;         /* sfg_mgpu_create*_ex: a rank's own Q'X^T rotation cache up to this size -> per-column pipelined exchange; 0 = 72 GiB; SIZE_MAX = never */
+    const char *rccl_lib;            /* sfg_mgpu_create*_ex: library name to dlopen instead of librccl.so.1 */
+} sfg_config;
+void sfg_config_default(sfg_config *c);
+int sfg_ctx_create_ex(sfg_ctx **out, int device, int logN, int nq, int np,
+                      const uint64_t *moduli, const uint64_t *psi, double scale, const sfg_config *config /* NULL = defaults */);
 /* a second caller on the same keys: replaces checking a private evaluator out of the pool (crypto.go:287-316,
  * ckks.NewEvaluator per goroutine at matmult.go:1110,1200,1371).  Load keys before forks run concurrently. */
 int sfg_ctx_fork(sfg_ctx *parent, sfg_ctx **out);
@@ -380,6 +400,11 @@ int sfg_mgpu_unique_id(uint8_t *id128);
 int sfg_mgpu_create(sfg_mgpu **out, const int *devices, int n, int logN, int nq, int np, const uint64_t *moduli, const uint64_t *psi, double scale);
 int sfg_mgpu_create_rank(sfg_mgpu **out, int device, int rank, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
                          const uint64_t *psi, double scale);
+/* the same with a configuration (sfg_config above; NULL = defaults): every rank's context takes it, the engine takes mgpu_transport / mgpu_cache_bytes / rccl_lib */
+int sfg_mgpu_create_ex(sfg_mgpu **out, const int *devices, int n, int logN, int nq, int np, const uint64_t *moduli, const uint64_t *psi, double scale,
+                       const sfg_config *config);
+int sfg_mgpu_create_rank_ex(sfg_mgpu **out, int device, int rank, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
+                            const uint64_t *psi, double scale, const sfg_config *config);
 void sfg_mgpu_destroy(sfg_mgpu *mg);
 const char *sfg_mgpu_last_error(const sfg_mgpu *mg);      /* mg may be NULL: error of a failed create */
 int sfg_mgpu_world(const sfg_mgpu *mg);

@@ -184,11 +184,36 @@ func addSub(cryptoParams *CryptoParams, X, Y CipherVector, op string) CipherVect
 }
 
 // InnerSumAll - crypto/basics.go:278-292: sum of the vector's ciphertexts, then 13 rotate-by-2^k-and-add steps.
+// The reference adds ciphertext by ciphertext with eval.Add (:283-288), i.e. with lattigo's own level and scale matching between operands.  Where every
+// ciphertext of X has the same level and scale - every call site of the PCA path: matmult.go:96,137,175 sum the outputs of one CMult, pca.go:477 and
+// qrfact.go:364 pass a single ciphertext - the sum runs on the device with the rotations.  A vector of mixed levels or scales (assoc.go:813,819 may see
+// one after a Rebalance, the only call sites that can) is summed by the reference's own lines on the host, so that whatever lattigo's Add does about the
+// mismatch is what happens here too; the device then takes the one summed ciphertext through the 13 rotation steps.
 func InnerSumAll(cryptoParams *CryptoParams, X CipherVector) *ckks.Ciphertext {
 	h := hip.Default
-	level := minLevel(X)
-	out := h.InnerSumAll(h.FlattenVec(X, len(X), level), len(X), level)
-	return h.CtFromFlat(out, level, X[0].Scale())
+	uniform := true
+	for i := 1; i < len(X); i++ {
+		if X[i].Level() != X[0].Level() || X[i].Scale() != X[0].Scale() {
+			uniform = false
+			break
+		}
+	}
+	if uniform {
+		level := X[0].Level()
+		out := h.InnerSumAll(h.FlattenVec(X, len(X), level), len(X), level)
+		return h.CtFromFlat(out, level, X[0].Scale())
+	}
+	vecsum := X[0].CopyNew().Ciphertext() // basics.go:280-288, verbatim
+	for i := 1; i < len(X); i++ {
+		cryptoParams.WithEvaluator(func(eval ckks.Evaluator) error {
+			eval.Add(X[i], vecsum, vecsum)
+			return nil
+		})
+	}
+	level := vecsum.Level()
+	one := CipherVector{vecsum}
+	out := h.InnerSumAll(h.FlattenVec(one, 1, level), 1, level)
+	return h.CtFromFlat(out, level, vecsum.Scale())
 }
 
 // CRescale - crypto/basics.go:707-719 (in place in the reference: the returned vector replaces X's entries).

@@ -9,6 +9,39 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFG_LIB_PATH") or os.path.join(_HERE, "lib", "libsfgwas_hip.so")      # SFG_LIB_PATH: same-box A/B of two builds
+AB_LIB_PATH = os.path.join(_HERE, "lib_ab", "libsfgwas_hip.so")      # the experimenters' build (`make -C sfgwas_amd/csrc ab`): superseded kernels + their A/B switches
+# what the product library reads from the environment (sfgwas_amd/csrc/ctx.hip: read_config); every other SFG_* switch exists in the A/B build only
+DEPLOYMENT_SWITCHES = {"SFG_MM_GROUP", "SFG_MM_ACC_BUDGET_MB", "SFG_ASSOC_ROTCACHE_MB", "SFG_KSW_BUDGET_MB", "SFG_ENC_BATCH", "SFG_UPLOAD_BLOCKING",
+                       "SFG_MGPU_TRANSPORT", "SFG_MGPU_CACHE_GB", "SFG_RCCL_LIB", "SFG_ENABLE_TEST_HOOKS",
+                       "SFG_TEST_SCRATCH_OOM", "SFG_TEST_TIE_BAND_LOG2", "SFG_MGPU_FORCE_COLLECTIVES"}
+
+
+def ab_lib():
+    """path of the A/B build, made on demand (a few minutes the first time; `make ab` is part of __graft_entry__.build)"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "ab", "-j8"], stdout=subprocess.DEVNULL)
+    return AB_LIB_PATH
+
+
+def env_for(switches):
+    """environment additions for a child process that sets `switches`: the A/B library when any of them is not a deployment switch"""
+    e = {k: str(v) for k, v in switches.items()}
+    if any(k.startswith("SFG_") and k not in DEPLOYMENT_SWITCHES for k in e):
+        e["SFG_LIB_PATH"] = ab_lib()
+    return e
+
+
+class SfgConfig(C.Structure):
+    """include/sfgwas_hip.h: sfg_config"""
+    _fields_ = [("struct_size", C.c_uint32), ("mm_group", C.c_int), ("acc_budget_bytes", C.c_size_t), ("assoc_rotcache_bytes", C.c_size_t),
+                ("ksw_budget_bytes", C.c_size_t), ("enc_batch", C.c_int), ("upload_blocking", C.c_int), ("mgpu_transport", C.c_char_p),
+                ("mgpu_cache_bytes", C.c_size_t), ("rccl_lib", C.c_char_p)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(SfgConfig)
+        for k, v in kw.items():
+            setattr(self, k, v)
 
 u64p = C.POINTER(C.c_uint64)
 _lib = None
@@ -26,6 +59,10 @@ def _sig(L):
     vp, i, u64, d, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_size_t
     S = {
         "sfg_ctx_create": (i, [C.POINTER(vp), i, i, i, i, u64p, u64p, d]),
+        "sfg_ctx_create_ex": (i, [C.POINTER(vp), i, i, i, i, u64p, u64p, d, vp]),
+        "sfg_config_default": (None, [vp]),
+        "sfg_mgpu_create_ex": (i, [C.POINTER(vp), C.POINTER(i), i, i, i, i, u64p, u64p, d, vp]),
+        "sfg_mgpu_create_rank_ex": (i, [C.POINTER(vp), i, i, i, vp, i, i, i, u64p, u64p, d, vp]),
         "sfg_ctx_fork": (i, [vp, C.POINTER(vp)]),
         "sfg_ctx_destroy": (None, [vp]),
         "sfg_last_error": (C.c_char_p, [vp]),
@@ -190,7 +227,7 @@ def p64(a):
 class Context:
     """sfg_ctx wrapper. moduli = q list + p list; psi=None derives lattigo's root."""
 
-    def __init__(self, q, p, scale=2.0 ** 34, logN=14, device=0, psi=None):
+    def __init__(self, q, p, scale=2.0 ** 34, logN=14, device=0, psi=None, config=None):
         L = lib()
         self.q, self.p = list(q), list(p)
         self.nq, self.np_ = len(q), len(p)
@@ -198,7 +235,10 @@ class Context:
         mods = np.array(self.q + self.p, dtype=np.uint64)
         h = C.c_void_p()
         ps = None if psi is None else p64(np.array(psi, dtype=np.uint64))
-        rc = L.sfg_ctx_create(C.byref(h), device, logN, self.nq, self.np_, p64(mods), ps, float(scale))
+        if config is None:
+            rc = L.sfg_ctx_create(C.byref(h), device, logN, self.nq, self.np_, p64(mods), ps, float(scale))
+        else:                                               # config: SfgConfig (include/sfgwas_hip.h: sfg_config)
+            rc = L.sfg_ctx_create_ex(C.byref(h), device, logN, self.nq, self.np_, p64(mods), ps, float(scale), C.byref(config))
         if rc:
             raise SfgError("sfg_ctx_create: " + L.sfg_last_error(None).decode())
         self.h = h
@@ -688,19 +728,20 @@ class MultiGpu:
     """sfg_mgpu wrapper.  devices = [0, 1, ...] makes a single-process engine (one rank per entry; a repeated device selects the in-process `direct` transport);
     rank / world / uid join a multi-process world (one rank per process)."""
 
-    def __init__(self, q, p, devices=None, scale=2.0 ** 34, logN=14, rank=None, world=None, uid=None, device=0):
+    def __init__(self, q, p, devices=None, scale=2.0 ** 34, logN=14, rank=None, world=None, uid=None, device=0, config=None):
         L = lib()
         self.q, self.p = list(q), list(p)
         self.nq, self.np_ = len(q), len(p)
         self.N, self.slots = 1 << logN, (1 << logN) // 2
         mods = np.array(self.q + self.p, dtype=np.uint64)
         h = C.c_void_p()
+        cfgp = None if config is None else C.byref(config)
         if uid is None:
             devs = (C.c_int * len(devices))(*devices)
-            rc = L.sfg_mgpu_create(C.byref(h), devs, len(devices), logN, self.nq, self.np_, p64(mods), None, float(scale))
+            rc = L.sfg_mgpu_create_ex(C.byref(h), devs, len(devices), logN, self.nq, self.np_, p64(mods), None, float(scale), cfgp)
         else:
             buf = (C.c_uint8 * 128).from_buffer_copy(bytes(uid))
-            rc = L.sfg_mgpu_create_rank(C.byref(h), device, rank, world, buf, logN, self.nq, self.np_, p64(mods), None, float(scale))
+            rc = L.sfg_mgpu_create_rank_ex(C.byref(h), device, rank, world, buf, logN, self.nq, self.np_, p64(mods), None, float(scale), cfgp)
         if rc:
             raise SfgError("sfg_mgpu_create: " + L.sfg_mgpu_last_error(None).decode())
         self.h = h

@@ -81,7 +81,7 @@ struct SfgConfig {
     bool upload_blocking = false;  // SFG_UPLOAD_BLOCKING   blocking pointer-table uploads (rocprofv3 --pmc)
     size_t ksw_budget = 4ULL << 30; // SFG_KSW_BUDGET_MB      key-switch scratch per input group / job chunk: more jobs per chunk = more reuse of a key (64 MB: +45 %, 1.5 GB: +2 %, 12 GB: -2 %)
     std::string test_scratch_oom;  // SFG_TEST_SCRATCH_OOM=name:n  (test switch only) the n-th request of scratch buffer `name` inside a top-level call behaves as if the device were full: the eviction path of sfg_scratch runs
-    int i8_mover = 1280;           // SFG_I8_MOVER           workgroups of the plaintext transposition in its mover form (i8_move.hpp); 0 = the round-3 pass k_i8_pack_pt_digits (A/B)
+    int i8_mover = 0;              // SFG_I8_MOVER=n (A/B build)  n workgroups of the plaintext transposition in its mover form (i8_move.hpp) instead of the pass k_i8_pack_pt_digits: 1280 is 3 % faster alone, nothing in a product (profiles/r06_mover_ubench.txt)
     int i8_mover_depth = 3;        // SFG_I8_MOVER_DEPTH     units (32 KiB) a mover workgroup keeps in flight + 1
     int enc_batch = 2048;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 128 MB of coefficient rows stay cache resident between the two now that the NTT's digit planes leave by streaming stores (round 5: 2048 -3 % of a 50k x 500k step against 1024, 3072 the same, 4096 worse; with plain stores 1024 was best)
     bool mac_plain_pt = false;     // SFG_MAC_PT=plain      plaintext panel as plain u64 words (A/B of the packed-limb panel format)
@@ -176,8 +176,14 @@ void sfg_ptc_invalidate_all(sfg_ctx *ctx);     // matmul.hip: forget every cache
 extern thread_local std::string g_create_error;
 
 #define SFG_FAIL(ctx, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); (ctx)->err = _b; return 1; } while (0)
+// (the A/B build names the failing call; the product names file and line only - its binary carries no expression text)
+#ifdef SFG_AB
 #define SFG_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[512]; \
     snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); (ctx)->err = _b; return 1; } } while (0)
+#else
+#define SFG_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[512]; \
+    snprintf(_b, sizeof _b, "HIP call failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); (ctx)->err = _b; return 1; } } while (0)
+#endif
 #define SFG_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 // workspace (grow-only scratch owned by the context)

@@ -25,41 +25,70 @@ int ntt_set_attrs(sfg_ctx *ctx);
 int encode_set_attrs(sfg_ctx *ctx);
 int mac_i8_set_attrs(sfg_ctx *ctx);
 
-static void read_config(SfgConfig &c) {
+// The configuration surface.
+//   * What a deployment legitimately tunes is in the public sfg_config (include/sfgwas_hip.h; sfg_ctx_create_ex / sfg_mgpu_create_ex) and, for operators who cannot
+//     change the caller, in ten environment variables read ONCE at context creation: SFG_MM_GROUP, SFG_MM_ACC_BUDGET_MB, SFG_ASSOC_ROTCACHE_MB, SFG_KSW_BUDGET_MB,
+//     SFG_ENC_BATCH, SFG_UPLOAD_BLOCKING (here) and SFG_MGPU_TRANSPORT, SFG_MGPU_CACHE_GB, SFG_RCCL_LIB (mgpu.hip), plus the test switch itself.
+//   * Three test-only switches exist in this build and are honoured only under SFG_ENABLE_TEST_HOOKS=1: SFG_TEST_SCRATCH_OOM, SFG_TEST_TIE_BAND_LOG2 and
+//     SFG_MGPU_FORCE_COLLECTIVES (the exchange at world size 1).
+//   * Every A/B and diagnostic switch of rounds 1 - 6 (which MAC kernel, which NTT form, queue schedules, CU masks, ...) and the superseded kernels they select exist
+//     only in the A/B build (`make ab` -> sfgwas_amd/lib_ab/libsfgwas_hip.so, -DSFG_AB): a party process that inherits a stray variable from its shell cannot change
+//     which kernels multiply.
+static void apply_public_config(SfgConfig &c, const sfg_config *pc) {
+    if (!pc || pc->struct_size < sizeof(uint32_t) * 2) return;
+    const size_t have = pc->struct_size;
+#define SFG_CFG_HAS(f) (have >= offsetof(sfg_config, f) + sizeof(pc->f))
+    if (SFG_CFG_HAS(mm_group) && pc->mm_group > 0) { c.mm_group = pc->mm_group; c.mm_group_auto = false; }
+    if (SFG_CFG_HAS(acc_budget_bytes) && pc->acc_budget_bytes) c.acc_budget = pc->acc_budget_bytes;
+    if (SFG_CFG_HAS(assoc_rotcache_bytes) && pc->assoc_rotcache_bytes) c.assoc_cache_budget = pc->assoc_rotcache_bytes == SIZE_MAX ? 0 : pc->assoc_rotcache_bytes;
+    if (SFG_CFG_HAS(ksw_budget_bytes) && pc->ksw_budget_bytes) c.ksw_budget = std::max<size_t>(pc->ksw_budget_bytes, 16ULL << 20);
+    if (SFG_CFG_HAS(enc_batch) && pc->enc_batch > 0) c.enc_batch = std::min(std::max(pc->enc_batch, 64), 8192);
+    if (SFG_CFG_HAS(upload_blocking) && pc->upload_blocking) c.upload_blocking = true;
+#undef SFG_CFG_HAS
+}
+static void read_config(SfgConfig &c, const sfg_config *pc) {
     auto env = [](const char *n) { return getenv(n); };
+    apply_public_config(c, pc);
+    // ---- deployment: the environment overrides the caller's struct (an operator's last word)
+    if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
+    if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
+    if (const char *e = env("SFG_ASSOC_ROTCACHE_MB")) c.assoc_cache_budget = (size_t)atoll(e) << 20;
+    if (const char *e = env("SFG_KSW_BUDGET_MB")) { c.ksw_budget = (size_t)atoll(e) << 20; if (c.ksw_budget < (16ULL << 20)) c.ksw_budget = 16ULL << 20; }
+    if (const char *e = env("SFG_ENC_BATCH")) { c.enc_batch = atoi(e); if (c.enc_batch < 64) c.enc_batch = 64; if (c.enc_batch > 8192) c.enc_batch = 8192; }
+    if (env("SFG_UPLOAD_BLOCKING")) c.upload_blocking = true;
+    // ---- tests
+    if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
+    if (c.test_hooks) {
+        if (const char *e = env("SFG_TEST_SCRATCH_OOM")) c.test_scratch_oom = e;
+        if (const char *e = env("SFG_TEST_TIE_BAND_LOG2")) c.tie_band = ldexp(1.0, atoi(e));       // a wider band sends ordinary coefficients through the exact re-derivation
+    }
+#ifdef SFG_AB
+    // ---- the A/B build only: experiment switches (defaults = the measured configuration; results identical words unless a line says INVALID)
     if (const char *e = env("SFG_MAC_IMPL")) { c.mac_reg = !strcmp(e, "reg"); c.mac_bc = strcmp(e, "dma") != 0 && !c.mac_reg; c.mac_i8 = !strcmp(e, "i8"); }      // bc | dma | reg | i8
     if (const char *e = env("SFG_I8_KEEP_RESERVE_GB")) c.i8_keep_reserve = (size_t)atoll(e) << 30;
     if (const char *e = env("SFG_MAC_I8_BIG")) c.mac_i8_big = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_ROT")) { c.mac_i8_nolds = strcmp(e, "lds") != 0; c.mac_i8_ring = !strcmp(e, "ring"); }      // ring (default) | cache | lds
     if (env("SFG_MAC_I8_WG")) c.mac_i8_ring = false;
-    if (const char *e = env("SFG_ENABLE_TEST_HOOKS")) c.test_hooks = atoi(e) == 1;
-    if (const char *e = env("SFG_MAC_I8_DIAG")) { if (c.test_hooks) c.mac_i8_diag = atoi(e); }       // timing diagnostics with INVALID results: honoured under the test switch only
+    if (const char *e = env("SFG_MAC_I8_DIAG")) { if (c.test_hooks) c.mac_i8_diag = atoi(e); }       // timing diagnostics with INVALID results
     if (const char *e = env("SFG_MAC_I8_WAVES")) c.mac_i8_waves = atoi(e) == 6 ? 6 : 12;
     if (const char *e = env("SFG_MAC_I8_STAGE")) c.stage_pack = atoi(e) != 0;
     if (const char *e = env("SFG_STAGE_GIANTS")) { c.stage_giants = atoi(e); if (c.stage_giants < 1) c.stage_giants = 1; if (c.stage_giants > 91) c.stage_giants = 91; }
     if (const char *e = env("SFG_STAGE_SAMEQ")) c.stage_same_queue = atoi(e) != 0;
     if (const char *e = env("SFG_MAC_I8_WG")) c.mac_i8_wg1 = atoi(e) == 1;
-    if (const char *e = env("SFG_TEST_SCRATCH_OOM")) { if (c.test_hooks) c.test_scratch_oom = e; }
-    if (const char *e = env("SFG_TEST_TIE_BAND_LOG2")) { if (c.test_hooks) c.tie_band = ldexp(1.0, atoi(e)); }       // test hook: a wider band sends ordinary coefficients through the exact re-derivation
     if (const char *e = env("SFG_MAC_WC")) c.mac_wc = atoi(e) == 2 ? 2 : 1;
-    if (const char *e = env("SFG_MM_GROUP")) { c.mm_group = atoi(e); if (c.mm_group < 1) c.mm_group = 1; c.mm_group_auto = false; }
-    if (const char *e = env("SFG_MM_ACC_BUDGET_MB")) c.acc_budget = (size_t)atoll(e) << 20;
     if (const char *e = env("SFG_MM_OVERLAP")) c.no_overlap = atoi(e) == 0;
     if (env("SFG_MM_NO_OVERLAP")) c.no_overlap = true;
     if (const char *e = env("SFG_MM_ENC_OVERLAP")) c.no_enc_overlap = atoi(e) == 0;
     if (const char *e = env("SFG_NTT_HALF_IMPL")) c.ntt_half_full = !strcmp(e, "full");
     if (const char *e = env("SFG_NTT_FWD_IMPL")) c.ntt_fwd_full = !strcmp(e, "full");
-    c.upload_blocking = env("SFG_UPLOAD_BLOCKING") != nullptr;
     if (const char *e = env("SFG_MAC_PT")) c.mac_plain_pt = !strcmp(e, "plain");
     if (const char *e = env("SFG_CU_MAIN")) c.cu_main = e;
     if (const char *e = env("SFG_CU_ENC")) c.cu_enc = e;
     if (const char *e = env("SFG_CU_AUX")) c.cu_aux = e;
     if (const char *e = env("SFG_ASSOC_I8")) c.assoc_i8 = atoi(e) != 0;
-    if (const char *e = env("SFG_ASSOC_ROTCACHE_MB")) c.assoc_cache_budget = (size_t)atoll(e) << 20;
-    if (const char *e = env("SFG_KSW_BUDGET_MB")) { c.ksw_budget = (size_t)atoll(e) << 20; if (c.ksw_budget < (16ULL << 20)) c.ksw_budget = 16ULL << 20; }
     if (const char *e = env("SFG_I8_MOVER")) { c.i8_mover = atoi(e); if (c.i8_mover < 0) c.i8_mover = 0; c.i8_mover = c.i8_mover / 8 * 8; }
     if (const char *e = env("SFG_I8_MOVER_DEPTH")) { c.i8_mover_depth = atoi(e); if (c.i8_mover_depth < 1 || c.i8_mover_depth > 3) c.i8_mover_depth = 3; }
-    if (const char *e = env("SFG_ENC_BATCH")) { c.enc_batch = atoi(e); if (c.enc_batch < 64) c.enc_batch = 64; if (c.enc_batch > 8192) c.enc_batch = 8192; }
+#endif
 }
 
 // copy the shared scalars / table pointers into the context (read-only mirrors: the launch code reads ctx->q, ctx->modc, ...)
@@ -69,6 +98,7 @@ static void ctx_bind_shared(sfg_ctx *ctx, SfgShared *sh) {
     memcpy(ctx->q, sh->q, sizeof sh->q); memcpy(ctx->psi, sh->psi, sizeof sh->psi); memcpy(ctx->modc_host, sh->modc_host, sizeof sh->modc_host);
     ctx->tw_fwd = sh->tw_fwd; ctx->tw_inv = sh->tw_inv; ctx->pack_fwd = sh->pack_fwd; ctx->pack_inv = sh->pack_inv; ctx->modc = sh->modc;
 }
+#ifdef SFG_AB
 // a queue restricted to the compute units named by `spec` ("lo-hi[,lo-hi...]", bits of hipExtStreamCreateWithCUMask); empty spec: nullptr (caller creates a plain queue)
 static hipStream_t stream_with_cu_mask(const std::string &spec) {
     if (spec.empty()) return nullptr;
@@ -86,19 +116,24 @@ static hipStream_t stream_with_cu_mask(const std::string &spec) {
     if (hipExtStreamCreateWithCUMask(&st, 16, mask) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return st;
 }
+#endif
 // per-caller execution state: two queues, ordering events, the pinned staging ring
 static const char *ctx_exec_init(sfg_ctx *ctx) {
     if (hipSetDevice(ctx->device) != hipSuccess) return "hipSetDevice failed";
     const SfgConfig &c = ctx->sh->cfg;
+#ifdef SFG_AB
     if (!c.cu_main.empty() && !(ctx->own_stream = stream_with_cu_mask(c.cu_main))) return "SFG_CU_MAIN: bad CU list or hipExtStreamCreateWithCUMask failed";
+    if (!c.cu_aux.empty() && !(ctx->aux_stream = stream_with_cu_mask(c.cu_aux))) return "SFG_CU_AUX: bad CU list or hipExtStreamCreateWithCUMask failed";
+    if (!c.cu_enc.empty() && !(ctx->enc_stream = stream_with_cu_mask(c.cu_enc))) return "SFG_CU_ENC: bad CU list or hipExtStreamCreateWithCUMask failed";
+#else
+    (void)c;
+#endif
     if (!ctx->own_stream && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
     ctx->stream = ctx->own_stream;
-    if (!c.cu_aux.empty() && !(ctx->aux_stream = stream_with_cu_mask(c.cu_aux))) return "SFG_CU_AUX: bad CU list or hipExtStreamCreateWithCUMask failed";
     if (!ctx->aux_stream) {   // the auxiliary queue yields to the main one: its element-wise key-switch kernels fill gaps, they must not displace MAC workgroups
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo) != hipSuccess) return "hipStreamCreate failed";
     }
-    if (!c.cu_enc.empty() && !(ctx->enc_stream = stream_with_cu_mask(c.cu_enc))) return "SFG_CU_ENC: bad CU list or hipExtStreamCreateWithCUMask failed";
     if (!ctx->enc_stream && hipStreamCreateWithFlags(&ctx->enc_stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_pipe[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
     for (int i = 0; i < 4; i++) if (hipEventCreateWithFlags(&ctx->ev_enc[i], hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
@@ -108,8 +143,14 @@ static const char *ctx_exec_init(sfg_ctx *ctx) {
     return nullptr;
 }
 
+extern "C" void sfg_config_default(sfg_config *c) { if (c) { memset(c, 0, sizeof *c); c->struct_size = (uint32_t)sizeof *c; } }
 extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int np,
                               const uint64_t *moduli, const uint64_t *psi, double scale) {
+    return sfg_ctx_create_ex(out, device, logN, nq, np, moduli, psi, scale, nullptr);
+}
+extern "C" int sfg_ctx_create_ex(sfg_ctx **out, int device, int logN, int nq, int np,
+                                 const uint64_t *moduli, const uint64_t *psi, double scale, const sfg_config *config) {
+    if (!out) { g_create_error = "null result pointer"; return 1; }
     *out = nullptr;
     if (logN != SFG_LOGN) { g_create_error = "only logN = 14 (PN14QP438) is built into this library"; return 1; }
     if (nq < 1 || np < 1 || nq + np > SFG_MAXMOD) { g_create_error = "bad modulus counts"; return 1; }
@@ -120,7 +161,7 @@ extern "C" int sfg_ctx_create(sfg_ctx **out, int device, int logN, int nq, int n
     SfgShared *sh = new SfgShared();
     ctx->sh = sh; ctx->device = device;
     sh->device = device; sh->nq = nq; sh->np = np; sh->nmod = nq + np; sh->beta = (nq + np - 1) / np; sh->scale = scale;
-    read_config(sh->cfg);
+    read_config(sh->cfg, config);
     auto fail = [&](const char *m) { std::string msg = m; sfg_ctx_destroy(ctx); g_create_error = msg; return 1; };
     if (const char *e = ctx_exec_init(ctx)) return fail(e);
     const int N = SFG_N;

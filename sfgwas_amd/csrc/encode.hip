@@ -730,7 +730,7 @@ extern "C" int sfg_ctx_encoder_unprovable(sfg_ctx *ctx, unsigned long long *coun
     return 0;
 }
 extern "C" int sfg_ctx_encoder_inject_unsafe_for_test(sfg_ctx *ctx, unsigned long long n) {      // test hook: pretend n such coefficients were seen
-    if (!ctx->test_hooks) SFG_FAIL(ctx, "sfg_ctx_encoder_inject_unsafe_for_test: test hook, enabled only in a process that set SFG_ENABLE_TEST_HOOKS=1 before creating the context");
+    if (!ctx->test_hooks) SFG_FAIL(ctx, "sfg_ctx_encoder_inject_unsafe_for_test: test hook, enabled only in a process that set the test switch before creating the context");
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long c[2] = {0, n};
     SFG_HIP(ctx, hipMemcpy((unsigned long long *)ctx->tie_count_dev + 1, c + 1, 8, hipMemcpyHostToDevice));

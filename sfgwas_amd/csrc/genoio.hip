@@ -192,7 +192,7 @@ extern "C" int sfg_geno_download(sfg_ctx *ctx, const sfg_geno *g, int8_t *host) 
 }
 extern "C" int sfg_geno_transpose(sfg_ctx *ctx, const sfg_geno *g, sfg_geno **out) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    if (g->packed) SFG_FAIL(ctx, "sfg_geno_transpose: packed matrix (the products take SFG_TRANSPOSE on the one copy; sfg_geno_unpack first for a materialised transpose)");
+    if (g->packed) SFG_FAIL(ctx, "sfg_geno_transpose: packed matrix (the products take the transpose flag on the one copy; sfg_geno_unpack first for a materialised transpose)");
     int8_t *d = nullptr;
     SFG_HIP(ctx, hipMalloc(&d, g->nrow * g->ncol));
     hipLaunchKernelGGL(k_geno_transpose, dim3((unsigned)((g->ncol + 63) / 64), (unsigned)((g->nrow + 63) / 64)), dim3(256), 0, ctx->stream, g->dev, g->nrow, g->ncol, g->ld, d);

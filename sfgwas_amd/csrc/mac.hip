@@ -45,6 +45,7 @@ struct MacArgs {
 // LDS image of one chunk: [kk][c][row] with the 2*RH rows of a coefficient contiguous, so a thread pulls its
 // rows with ds_read_b128 (two rows per read; 16 distinct 16-byte words per wave-read at a stride of 2*RH*8 B,
 // which spreads over all 64 banks) and every value read feeds 2 columns x 3..4 FMAs.
+#ifdef SFG_AB          // the register-staged kernel of round 1: A/B build only (make ab)
 template <bool BIG, int RH>
 __global__ void __launch_bounds__(MAC_THREADS, 2) k_mac(MacArgs a, const ModConst *modc) {
     constexpr int RW = BIG ? 2 : 1;                    // doubles per staged rot word
@@ -194,6 +195,7 @@ static int launch_mac_rt(sfg_ctx *ctx, MacArgs a, int rt) {
     SFG_HIP(ctx, hipGetLastError());
     return 0;
 }
+#endif
 
 int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate) {
     MacStrides st;
@@ -204,6 +206,10 @@ int launch_mac(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int
 }
 
 int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, int K, int R, int Ncols, int L, int accumulate, const MacStrides &st) {
+#ifndef SFG_AB
+    (void)rot; (void)pt; (void)out; (void)K; (void)R; (void)Ncols; (void)L; (void)accumulate; (void)st;
+    SFG_FAIL(ctx, "the register-staged MAC kernel exists in the A/B build only (make ab)");
+#else
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac: L out of range");
     for (int r0 = 0; r0 < R; r0 += MAC_RMAX) {
@@ -231,9 +237,10 @@ int launch_mac_strided(sfg_ctx *ctx, const u64 *rot, const u64 *pt, u64 *out, in
         }
     }
     return 0;
+#endif
 }
 
-// SFG_MAC_IMPL=reg selects the register-staged kernel of this file; default is the LDS-DMA kernel (mac_dma.hip)
+// (A/B build: SFG_MAC_IMPL=reg selects the register-staged kernel of this file)
 bool mac_use_dma(const sfg_ctx *ctx) { return !ctx->cfg.mac_reg; }
 
 extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt, uint64_t *out, int K, int R, int Ncols, int L, int accumulate) {
@@ -256,7 +263,7 @@ extern "C" int sfg_mac_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt
         st.rot_k = (size_t)R * L * SFG_N; st.rot_r = (size_t)L * SFG_N;
         st.pt_k = (size_t)Ncols * L * SFG_N; st.pt_n = (size_t)L * SFG_N;
         st.out_n = (size_t)R * L * SFG_N; st.out_r = (size_t)L * SFG_N;
-        // default build: the small-modulus plaintext rows go through the packed-limb format the product path uses (SFG_MAC_PT=plain: as given)
+        // default build: the small-modulus plaintext rows go through the packed-limb format the product path uses (A/B build, plain panel: as given)
         const unsigned pmask = mac_dma_packed_mask(ctx, L);
         u64 *ptp = nullptr; double *rsum = nullptr;
         if (!rc && pmask) {

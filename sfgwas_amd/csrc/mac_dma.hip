@@ -42,6 +42,7 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_base) {
 
 // WC = column waves per workgroup.  WC = 2: one 8-wave workgroup per CU (24 columns).  WC = 1: 4-wave workgroups of 12 columns,
 // TWO per CU with a ring each: their barriers and DMA waits are not synchronised, so one computes while the other waits.
+#ifdef SFG_AB          // the 8 x 3-tile LDS-DMA kernel of round 1: A/B build only (make ab)
 template <bool BIG, int WC_> struct MacRing {
     // slot bytes: WC 2: 32 / 48 KiB, WC 1: 24 / 40 KiB
     static constexpr int RW = BIG ? 2 : 1, JOBS = (DM_KC * DM_ROWS * DM_CL * 8 * RW + DM_KC * DM_CG * DM_CT * WC_ * DM_CL * 8) / 1024;
@@ -260,6 +261,7 @@ __global__ void __launch_bounds__(64 * 4 * WC_, 2) k_mac_dma(DmaArgs a, const Mo
         }
     }
 }
+#endif
 
 // rotation cache -> fp64 operand form.  in: [nct][2][nl][N] u64 ciphertext rows; out row (ct, poly) holds the
 // planes of moduli 0..L-1: a "big" modulus (>= 2^36) takes 2N doubles {low 23 bits, high bits} interleaved per
@@ -292,14 +294,18 @@ __global__ void __launch_bounds__(256) k_pack_pt(const u64 *in, u64 *out, size_t
 }
 
 int mac_dma_set_attrs(sfg_ctx *ctx) {
+#ifndef SFG_AB
+    (void)ctx; return 0;
+#else
     constexpr int lds_b2 = MacRing<true, 2>::LDS, lds_s2 = MacRing<false, 2>::LDS, lds_s1 = MacRing<false, 1>::LDS;
     auto kb2 = k_mac_dma<true, 2>; auto ks2 = k_mac_dma<false, 2>; auto ks1 = k_mac_dma<false, 1>;
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s2));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b2));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)ks1, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s1));
     return 0;
+#endif
 }
-// bit l set: the plaintext rows of modulus l use the packed-limb format (small moduli with the default broadcast kernel; not with SFG_MAC_PT=plain / SFG_MAC_IMPL=dma|reg)
+// bit l set: the plaintext rows of modulus l use the packed-limb format (small moduli with the default broadcast kernel; not with the A/B build's plain panel / dma / reg kernels)
 unsigned mac_dma_packed_mask(sfg_ctx *ctx, int L) {
     if (ctx->cfg.mac_plain_pt || ctx->cfg.mac_reg || !ctx->cfg.mac_bc) return 0u;       // the packed format is the broadcast kernel's
     unsigned m = 0; for (int l = 0; l < L; l++) if (ctx->q[l] < (1ULL << 36)) m |= 1u << l;
@@ -360,6 +366,9 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
                    const MacStrides &st, const double *rotsum) {
     if (ctx->cfg.mac_bc && (st.pt_packed || mac_dma_packed_mask(ctx, L) == 0) && !ctx->cfg.mac_plain_pt)      // default: the DPP-broadcast kernel (mac_bc.hip)
         return launch_mac_bc(ctx, rotf, rows_per_k, pt, out, K, R, Ncols, L, accumulate, st, rotsum);
+#ifndef SFG_AB
+    SFG_FAIL(ctx, "the LDS-DMA baseline MAC kernel exists in the A/B build only (make ab)");
+#else
     const int N = SFG_N;
     if (K <= 0 || R <= 0 || Ncols <= 0) return 0;
     if (!rotf) SFG_FAIL(ctx, "sfg_mac: internal: a rot operand given as int8 tiles only reached the fp64 kernel");
@@ -408,4 +417,5 @@ int launch_mac_dma(sfg_ctx *ctx, const double *rotf, size_t rows_per_k, const u6
         }
     }
     return 0;
+#endif
 }

@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
         __syncthreads();
     }
 }
+#ifdef SFG_AB
 // ---- the same as a low-occupancy mover (i8_move.hpp): job.nblocks workgroups (one per CU) walk the items with the next units' loads in flight in registers.
 // Alone on the chip this is the A/B of the pass above; its place is in front of the plaintext NTT's workgroups (k_ntt_half3_move, ntt.hip).
 template <int DEPTH, bool NT>
@@ -182,6 +183,8 @@ __global__ void __launch_bounds__(256, 4) k_i8_move_pt(MoveJob job) {
     __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
     i8_move_block<DEPTH, NT>(job, blockIdx.x, img, (int)threadIdx.x);
 }
+#endif
+#ifdef SFG_AB          // streamed transposition (round 4 - 5 experiment, measured slower) and the mover form of the pass (round 6, no gain): A/B build only
 // ---- the same from the DENSE digit planes of one encode batch (StagePack, kernels.hpp): plaintext p of the batch is shift shift0 + p = giant n, baby b of block
 // row g; its byte goes to column n, k' = g * kb + b.  A workgroup = (modulus, column tile jt, 16 k', 128 coefficients) as above, restricted to what this batch
 // owns: columns [n_lo, n_hi) x the dwords of block row g (kb is a multiple of 4, so a 16-byte run splits between block rows on dword boundaries).  Owned positions
@@ -233,6 +236,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_stage(I8StageArgs a) {
         __syncthreads();
     }
 }
+#endif
 // ---- the MAC.  grid = nl * N/2 workgroups of njt waves
 template <int ND>
 __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *modc) {
@@ -280,6 +284,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8(I8Args a, const ModConst *mod
         for (int e = 0; e < 4; e++) o[e] = (u64)i8_horner(acc[t], e, q, qinv, wide);
     }
 }
+#ifdef SFG_AB          // LDS-staged rot tiles (round 3, measured slower than the cache-shared and the ring forms): A/B build only
 // ---- the same with the rot tiles of the pair staged through LDS (six column waves: the product's 91 columns).  Through the cache alone the six waves fetched
 // them 2.8 x (PMC); here the workgroup loads the 20 KiB of a chunk once - the next chunk's pieces travel in registers beside the current chunk's MFMAs - and every
 // wave reads its 20 operand tiles from the 2 x 20 KiB image.
@@ -338,6 +343,7 @@ __global__ void __launch_bounds__(384, 1) k_mac_i8_lds(I8Args a, const ModConst 
         for (int e = 0; e < 4; e++) o[e] = (u64)i8_horner(acc[t], e, q, qinv, false);       // (five digits: q < 2^39)
     }
 }
+#endif
 // ---- the MAC with both operand streams prefetched through an LDS ring by the DMA engine (round 4; the default for full 91-column launches).
 // Counters (profiles/r04_pmc_mac_i8.json) show that k_mac_i8 fetches exactly its operand bytes (31.88 GB per launch against 31.88 GB algorithmic: the six column
 // waves of a pair do share the rot tiles, in the L1) - and yet runs at 55 % of the achievable HBM rate: a wave requests a chunk's 25 KiB, waits for all of it,
@@ -349,7 +355,7 @@ __device__ __forceinline__ void i8_dma16(const void *gsrc, void *lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 // DEPTH slots of 10 ND KiB: three for the 35-bit moduli (150 KiB), two for the 46-bit one (120 KiB: its 144 MFMAs per chunk cover one chunk of lookahead)
-// DIAG (timing diagnostics only, results invalid; SFG_MAC_I8_DIAG): 1 = one MFMA per rot tile instead of ND (the matrix pipe nearly idle), 2 = no DMA after the prologue
+// DIAG (timing diagnostics only, results invalid; A/B build): 1 = one MFMA per rot tile instead of ND (the matrix pipe nearly idle), 2 = no DMA after the prologue
 // (the memory system idle): which side of the ring sets the chunk time
 // HALVES = 2: twelve waves, a wave = one COEFFICIENT (c or N-1-c) x 16 columns: 2 row tiles x (2 ND - 1) sums, three waves on every SIMD instead of 2-2-1-1.  The
 // timing diagnostics showed the matrix side of the six-wave form (3.85 ms of a 5.02 ms launch with the memory system idle; 4.29 ms with the matrix pipe idle) set by
@@ -471,8 +477,10 @@ int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (c
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 10 * 6 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<6, 2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 10 * 6 * 1024));
+#ifdef SFG_AB
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
+#endif
     return 0;
 }
 // bytes of the two operand streams and the tile-ordered results of one launch (for the group-size choice in matmul.hip)
@@ -481,6 +489,10 @@ size_t mac_i8_stream_bytes(int K, int nl, int ND, int copies_of_rot) {
     return (size_t)nl * (N * nch * 2 * ND * 1024 * copies_of_rot + H * 6 * nch * ND * 1024 + H * 2 * 6 * 2 * 256 * 8);
 }
 int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, int L) {
+#ifndef SFG_AB
+    (void)sp; (void)shift_lo; (void)nshift; (void)L;
+    SFG_FAIL(ctx, "the streamed transposition exists in the A/B build only (make ab)");
+#else
     const int H = SFG_N / 2, d = SFG_D;
     if (shift_lo % d) SFG_FAIL(ctx, "i8 stage pack: internal: a batch starts inside a giant step");
     I8StageArgs a;
@@ -506,9 +518,11 @@ int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, 
     ctx->stream = saved;
     SFG_HIP(ctx, hipGetLastError());
     return 0;
+#endif
 }
 // bytes of the tile buffer of `nl` moduli with ND digits for K' contraction steps
 size_t mac_i8_tile_bytes(int Kp, int nl, int ND) { return (size_t)nl * (SFG_N / 2) * 6 * (((size_t)Kp + 63) / 64) * ND * 1024; }
+#ifdef SFG_AB
 static void launch_move_alone(hipStream_t q, const MoveJob &j) {
 #define SFG_MV(D, T) hipLaunchKernelGGL((k_i8_move_pt<D, T>), dim3(j.nblocks), dim3(256), 0, q, j)
     if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); }
@@ -516,6 +530,7 @@ static void launch_move_alone(hipStream_t q, const MoveJob &j) {
     else { if (j.nt) SFG_MV(1, true); else SFG_MV(1, false); }
 #undef SFG_MV
 }
+#endif
 template <int ND>
 static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                             int l0, int nl, int accumulate, const MacStrides &st) {
@@ -584,13 +599,15 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K_rot * std::min(32, R - r0) * (BIG ? 16.0 : 8.0) + (double)a.nch * 2 * ND * tile)); }
     if (!B_pre) { PhaseTimer t(ctx, "mac_i8_pack_pt");
       const unsigned items = (unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD));
+#ifdef SFG_AB
       if (a.pt_digits && ctx->cfg.i8_mover > 0 && a.pt_n_stride * 8 < (1ULL << 31)) {      // the mover form of the pass (i8_move.hpp): fewer, longer-lived workgroups with the next units' loads in flight
           MoveJob j; memset(&j.a5, 0, sizeof j.a5); memset(&j.a6, 0, sizeof j.a6);
           if (ND == 5) { j.a5 = a; j.n5 = items; } else { j.a6 = a; j.n6 = items; }
           j.first = 0; j.count = items; j.nblocks = std::min((unsigned)ctx->cfg.i8_mover, (items + 7u) / 8u * 8u); j.depth = ctx->cfg.i8_mover_depth; j.nt = 0;
           launch_move_alone(ctx->stream, j);
-      }
-      else if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits<ND>, dim3(items), dim3(256), 0, ctx->stream, a);
+      } else
+#endif
+      if (a.pt_digits) hipLaunchKernelGGL(k_i8_pack_pt_digits<ND>, dim3(items), dim3(256), 0, ctx->stream, a);
       else hipLaunchKernelGGL(k_i8_pack_pt<ND>, dim3((unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PP))), dim3(256), 0, ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * H * ((double)K * Ncols * (a.pt_digits ? (double)ND : 8.0) + (double)a.njt * a.nch * ND * tile)); }
     { PhaseTimer t(ctx, BIG ? "mac_big" : "mac_small");            // the MAC proper: both operand streams read once, tile-ordered results written
@@ -598,11 +615,15 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
           if (BIG && ctx->cfg.mac_i8_waves == 12) hipLaunchKernelGGL((k_mac_i8_ring<6, 2, 0, 2>), dim3((unsigned)(nl * H)), dim3(768), 2 * 10 * 6 * 1024, ctx->stream, a, ctx->modc);
           else if (BIG) hipLaunchKernelGGL((k_mac_i8_ring<6, 2>), dim3((unsigned)(nl * H)), dim3(384), 2 * 10 * 6 * 1024, ctx->stream, a, ctx->modc);
           else if (ctx->cfg.mac_i8_waves == 12 && !ctx->cfg.mac_i8_diag) hipLaunchKernelGGL((k_mac_i8_ring<5, 3, 0, 2>), dim3((unsigned)(nl * H)), dim3(768), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+#ifdef SFG_AB
           else if (ctx->cfg.mac_i8_diag == 1) hipLaunchKernelGGL((k_mac_i8_ring<5, 3, 1>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
           else if (ctx->cfg.mac_i8_diag == 2) hipLaunchKernelGGL((k_mac_i8_ring<5, 3, 2>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
+#endif
           else hipLaunchKernelGGL((k_mac_i8_ring<5, 3>), dim3((unsigned)(nl * H)), dim3(384), 3 * 10 * 5 * 1024, ctx->stream, a, ctx->modc);
       }
+#ifdef SFG_AB
       else if (!BIG && a.njt == 6 && !ctx->cfg.mac_i8_nolds) hipLaunchKernelGGL(k_mac_i8_lds, dim3((unsigned)(nl * H)), dim3(384), 0, ctx->stream, a, ctx->modc);
+#endif
       else if (ctx->cfg.mac_i8_wg1) hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H * a.njt)), dim3(64), 0, ctx->stream, a, ctx->modc);
       else hipLaunchKernelGGL(k_mac_i8<ND>, dim3((unsigned)(nl * H)), dim3(64 * a.njt), 0, ctx->stream, a, ctx->modc);
       SFG_HIP(ctx, hipGetLastError());
@@ -656,7 +677,7 @@ __global__ void __launch_bounds__(256) k_i8_words_to_planes(const u64 *in, u64 *
 }
 extern "C" int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t *pt_half, uint64_t *out, int K, int R, int Ncols, int L, int accumulate, int pt_form) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->test_hooks) SFG_FAIL(ctx, "sfg_mac_i8_dev is a test hook: set SFG_ENABLE_TEST_HOOKS=1 before sfg_ctx_create");
+    if (!ctx->test_hooks) SFG_FAIL(ctx, "sfg_mac_i8_dev is a test hook: the context was not created under the test switch");
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "sfg_mac_i8: L out of range");
     if (K < 1 || R < 1 || Ncols < 1) SFG_FAIL(ctx, "sfg_mac_i8: K, R and Ncols must be positive (got %d, %d, %d)", K, R, Ncols);
     if (Ncols > 96 || (long long)K * 6 >= 131072) SFG_FAIL(ctx, "sfg_mac_i8: at most 96 columns and K < 21846 per launch");
@@ -665,7 +686,7 @@ extern "C" int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t 
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) return 1;
     unsigned big_mask = 0, small_mask = 0; for (int l = 0; l < L; l++) (is_big[l] ? big_mask : small_mask) |= 1u << l;
-    if (big_mask && !ctx->cfg.mac_i8_big) SFG_FAIL(ctx, "sfg_mac_i8: a modulus above 2^36 is on the fp64 kernel in this context (SFG_MAC_I8_BIG=0, or it exceeds six signed digits: q > 0x7F7F7F7F7F80)");
+    if (big_mask && !ctx->cfg.mac_i8_big) SFG_FAIL(ctx, "sfg_mac_i8: a modulus above 2^36 is on the fp64 kernel in this context (it exceeds six signed digits: q > 0x7F7F7F7F7F80; or the A/B build's switch)");
     const size_t rrows = (size_t)K * R, prows = (size_t)K * Ncols * L;
     double *rotf = nullptr; u64 *ptp = nullptr;
     int rc = 0;
@@ -689,6 +710,7 @@ extern "C" int sfg_mac_i8_dev(sfg_ctx *ctx, const uint64_t *rot, const uint64_t 
     return rc;
 }
 
+#ifdef SFG_AB
 // ---- round 6: the mover (i8_move.hpp) against the pass, alone and in front of the plaintext NTT's workgroups.  Test hooks, not part of the C-ABI header.
 __global__ void __launch_bounds__(256) k_ub_fill(u64 *p, size_t n, u64 seed) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -722,7 +744,7 @@ static int move_job_for(sfg_ctx *ctx, const u64 *panel, int G, int L, int8_t *Bs
 // 7: the same with the mover riding in NTT launches (the NTT writes another panel).  G block rows of 8281 plaintexts, cfg.enc_batch plaintexts per NTT launch.
 extern "C" int ubench_ntt_move(sfg_ctx *ctx, int mode, int G, int nblocks, int depth, int nt, int reps, double *ms_out) {
     SFG_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->test_hooks) SFG_FAIL(ctx, "ubench_ntt_move is a test hook: set SFG_ENABLE_TEST_HOOKS=1");
+    if (!ctx->test_hooks) SFG_FAIL(ctx, "ubench_ntt_move is a test hook");
     if (G < 1 || G > 24 || nblocks < 8 || nblocks % 8 || depth < 1 || depth > 3) SFG_FAIL(ctx, "ubench_ntt_move: bad arguments");
     const int N = SFG_N, H = N / 2, L = 5, d = SFG_D;
     const size_t plw = (size_t)L * H, nplain = (size_t)d * d, batch = (size_t)ctx->cfg.enc_batch;
@@ -791,3 +813,4 @@ extern "C" int ubench_ntt_move(sfg_ctx *ctx, int mode, int G, int nblocks, int d
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }
+#endif

@@ -733,7 +733,7 @@ static int matmul_resident_range(sfg_ctx *ctx, const uint64_t *A, int s, int in_
     // Several column groups would each rebuild the rotation cache of every block row (91 key switches per input
     // ciphertext).  When the whole cache fits (48 GiB; Q*X at 100k x 1M: 13 block rows = 28 GB) it is built once here.
     const double *rotf_all = rotf_ext, *rotsum_all = nullptr;
-    if (rotf_ext && !mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    if (rotf_ext && !mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (the A/B build selected the register-staged kernel)");
     if (!rotf_ext && !pre8 && mac_use_dma(ctx) && j1 - j0 > jg && b1 > b0) {
         std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
         if (nplanes < 0) return 1;
@@ -803,7 +803,7 @@ extern "C" int sfg_matmul_resident_range_dev(sfg_ctx *ctx, const uint64_t *A, in
 // the job-major staging buffers and scatter them into the MAC layout.  All 91 baby steps are rotated (a superset of the reference's active table
 // whenever the operand has a ragged block only; rotations of inactive baby steps meet zero plaintexts), so the cache does not depend on a rank's window.
 static int rotcache_rowf(sfg_ctx *ctx, int L, size_t &rowf) {
-    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "rotation cache objects need the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "rotation cache objects need the LDS-DMA MAC (the A/B build selected the register-staged kernel)");
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "rotcache: max_level out of range");
     std::vector<int> plane_of, is_big; const int nplanes = mac_dma_planes(ctx, L, plane_of, is_big);
     if (nplanes < 0) return 1;
@@ -991,7 +991,7 @@ extern "C" int sfg_matmul_accumulate_rc_dev(sfg_ctx *ctx, const double *cache, i
     ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (!cache) SFG_FAIL(ctx, "matmul: null rotation cache");
-    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul: a prebuilt rotation cache needs the LDS-DMA MAC (the A/B build selected the register-staged kernel)");
     Shape sh = make_shape(g, flags);
     return matmul_accumulate(ctx, nullptr, s, max_level, max_level, sh, flags, b0, b1, j0, j1, accumulate, (u64 *)acc, cache, nullptr);
 }
@@ -1077,7 +1077,7 @@ extern "C" int sfg_diagcache_write(sfg_ctx *ctx, const sfg_geno *g, unsigned fla
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (files_written) *files_written = 0;
     if (!g || !prefix) SFG_FAIL(ctx, "sfg_diagcache_write: null argument");
-    if (flags & ~SFG_TRANSPOSE) SFG_FAIL(ctx, "sfg_diagcache_write: only SFG_TRANSPOSE is meaningful here (MatMult4StreamPreprocess neither squares nor sums)");
+    if (flags & ~SFG_TRANSPOSE) SFG_FAIL(ctx, "sfg_diagcache_write: only the transpose flag is meaningful here (MatMult4StreamPreprocess neither squares nor sums)");
     const int LV = max_level + 1;                    // EncodeDiagWithEncoder makes level-maxLevel plaintexts: maxLevel + 1 moduli rows are written, maxLevel are multiplied
     if (max_level < 1 || LV > ctx->nq) SFG_FAIL(ctx, "sfg_diagcache_write: max_level out of range");
     if (g->packed) {
@@ -1181,7 +1181,7 @@ extern "C" int sfg_matmul_from_cache(sfg_ctx *ctx, const uint64_t *A, int s, int
     ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->phases.clear();
-    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul_from_cache needs the LDS-DMA MAC (unset SFG_MAC_IMPL)");
+    if (!mac_use_dma(ctx)) SFG_FAIL(ctx, "matmul_from_cache needs the LDS-DMA MAC (the A/B build selected the register-staged kernel)");
     const int N = SFG_N, d = SFG_D, L = max_level;
     if (L < 1 || L > ctx->nq) SFG_FAIL(ctx, "matmul_from_cache: max_level out of range");
     const int lev = in_level > max_level ? max_level : in_level, nl = lev + 1, nl_in = in_level + 1;

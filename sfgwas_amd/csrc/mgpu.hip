@@ -41,11 +41,11 @@ struct Rccl {
     decltype(&ncclCommAbort) CommAbort = nullptr;          // optional (older builds): without it a failure after the agreement point cannot release the peers
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
-    std::string load() {
+    std::string load(const char *configured = nullptr) {
         if (so) return "";
-        const char *names[] = {getenv("SFG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char *names[] = {getenv("SFG_RCCL_LIB"), configured, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) { if (!n || !*n) continue; so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
-        if (!so) return std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?") + " - set SFG_RCCL_LIB, or use SFG_MGPU_TRANSPORT=direct in a single process";
+        if (!so) return std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?") + " - name the library (sfg_config.rccl_lib), or use the direct transport in a single process";
 #define SFG_RCCL_SYM(f) f = (decltype(f))dlsym(so, "nccl" #f); if (!f) return std::string("RCCL symbol missing: nccl" #f)
         SFG_RCCL_SYM(GetUniqueId); SFG_RCCL_SYM(CommInitAll); SFG_RCCL_SYM(CommInitRank); SFG_RCCL_SYM(CommDestroy); SFG_RCCL_SYM(ReduceScatter); SFG_RCCL_SYM(AllReduce);
         SFG_RCCL_SYM(GetErrorString);
@@ -102,7 +102,8 @@ struct sfg_mgpu {
     bool single_process = true, direct = false, force_coll = false;
     bool solo = false;                      // SFG_MGPU_SOLO=r/w: TIMING ONLY - this process computes the share of rank r of a w-rank world on one GPU, every exchange replaced by a
                                             // local copy of the rank's own slice (the outputs are not a product): per-rank phase times of world sizes a one-GPU box cannot run
-    size_t cache_budget = 72ULL << 30;      // SFG_MGPU_CACHE_GB: a rank's own Q'X^T rotation cache up to this size -> per-column pipelined reduce-scatter
+    size_t cache_budget = 72ULL << 30;      // sfg_config.mgpu_cache_bytes / SFG_MGPU_CACHE_GB: a rank's own Q'X^T rotation cache up to this size -> per-column pipelined reduce-scatter
+    std::string rccl_lib;                   // sfg_config.rccl_lib
     std::vector<MgRank> r;                  // local ranks
     bool broken = false;                    // a rank failed after a call's agreement point and its communicator was aborted: the engine refuses further exchanges
     Rendezvous rv;
@@ -118,9 +119,15 @@ struct sfg_mgeno {
 thread_local std::string g_mgpu_create_error;
 #define MG_FAIL(mg, ...) do { char _b[640]; snprintf(_b, sizeof _b, __VA_ARGS__); (mg)->err = _b; return 1; } while (0)
 #define R_FAIL(R, ...) do { char _b[640]; snprintf(_b, sizeof _b, __VA_ARGS__); (R).err = _b; return 1; } while (0)
+#ifdef SFG_AB
 #define R_HIP(R, call) do { hipError_t _e = (call); if (_e != hipSuccess) R_FAIL(R, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 #define R_CTX(R, call) do { if ((call)) { (R).err = std::string(#call).substr(0, std::string(#call).find('(')) + ": " + (R).ctx->err; return 1; } } while (0)
 #define R_NCCL(R, call) do { ncclResult_t _e = (call); if (_e != ncclSuccess) R_FAIL(R, "%s failed: %s", #call, g_rccl.GetErrorString(_e)); } while (0)
+#else         // (the product's binary carries no expression text: file and line, and the context's own message)
+#define R_HIP(R, call) do { hipError_t _e = (call); if (_e != hipSuccess) R_FAIL(R, "HIP call failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define R_CTX(R, call) do { if ((call)) { (R).err = "mgpu.hip:" + std::to_string(__LINE__) + ": " + (R).ctx->err; return 1; } } while (0)
+#define R_NCCL(R, call) do { ncclResult_t _e = (call); if (_e != ncclSuccess) R_FAIL(R, "RCCL call failed: %s (mgpu.hip:%d)", g_rccl.GetErrorString(_e), __LINE__); } while (0)
+#endif
 
 // one host thread per local rank (the library's rule: one thread drives a context at a time); first failure wins
 template <class F> static int run_ranks(sfg_mgpu *mg, F &&fn) {
@@ -155,10 +162,15 @@ extern "C" int sfg_mgpu_shard(int world, size_t ncol, int rank, size_t *blk0, si
     return 0;
 }
 
-static void mgpu_read_env(sfg_mgpu *mg) {
+// the engine's share of the configuration surface (ctx.hip has the rule): sfg_config, then the operator's environment; the forced exchange at world 1 is a test switch
+static void mgpu_read_config(sfg_mgpu *mg, const sfg_config *pc) {
+    if (pc && pc->struct_size >= offsetof(sfg_config, mgpu_transport) + sizeof(pc->mgpu_transport) && pc->mgpu_transport) mg->direct = !strcmp(pc->mgpu_transport, "direct");
+    if (pc && pc->struct_size >= offsetof(sfg_config, mgpu_cache_bytes) + sizeof(pc->mgpu_cache_bytes) && pc->mgpu_cache_bytes) mg->cache_budget = pc->mgpu_cache_bytes == SIZE_MAX ? 0 : pc->mgpu_cache_bytes;
+    if (pc && pc->struct_size >= offsetof(sfg_config, rccl_lib) + sizeof(pc->rccl_lib) && pc->rccl_lib) mg->rccl_lib = pc->rccl_lib;
     if (const char *e = getenv("SFG_MGPU_TRANSPORT")) mg->direct = !strcmp(e, "direct");
-    if (const char *e = getenv("SFG_MGPU_FORCE_COLLECTIVES")) mg->force_coll = atoi(e) != 0;
     if (const char *e = getenv("SFG_MGPU_CACHE_GB")) { double gb = atof(e); if (!(gb >= 0)) gb = 0; if (gb > 4096) gb = 4096; mg->cache_budget = (size_t)(gb * (double)(1ULL << 30)); }
+    const char *hooks = getenv("SFG_ENABLE_TEST_HOOKS");
+    if (hooks && atoi(hooks) == 1) if (const char *e = getenv("SFG_MGPU_FORCE_COLLECTIVES")) mg->force_coll = atoi(e) != 0;
 }
 static const char *rank_exec_init(MgRank &R) {
     if (hipSetDevice(R.device) != hipSuccess) return "hipSetDevice failed";
@@ -166,9 +178,14 @@ static const char *rank_exec_init(MgRank &R) {
     // (tools/r5_order.sh, tools/r5_collq.sh, profiles/r05_mgpu_queue_count.txt), with a fourth library stream IN USE and the product on the context's own queue every
     // kernel of the step starts 15 - 30 us later (a rank's step 1.65 s against 1.46 s); a stream that only exists costs nothing, and with GPU_MAX_HW_QUEUES <= 3, or with
     // the product on a stream the caller made, the effect vanishes - it depends on which hardware queues the runtime hands the streams.
+#ifdef SFG_AB
     const char *cq = getenv("SFG_MGPU_COLL_QUEUE");       // diagnostics (tools/r5_collq.sh): "own" = a queue of the engine's whatever the schedule, "spare" = made but not used
     const bool own = cq && !strcmp(cq, "own"), spare = cq && !strcmp(cq, "spare");
-    if (!own && (spare || R.ctx->cfg.no_enc_overlap || R.ctx->cfg.no_overlap)) {
+#else
+    const bool own = false, spare = false;
+#endif
+    const bool enc_busy = R.ctx->cfg.stage_pack && !R.ctx->cfg.stage_same_queue;      // (A/B build: the streamed transposition runs on the encode queue whatever the overlap switches say)
+    if (!own && !enc_busy && (spare || R.ctx->cfg.no_enc_overlap || R.ctx->cfg.no_overlap)) {
         if (spare && hipStreamCreateWithFlags(&R.spare, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
         R.coll = R.ctx->enc_stream; R.own_coll = false;
     } else { if (hipStreamCreateWithFlags(&R.coll, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed"; R.own_coll = true; }
@@ -210,31 +227,33 @@ extern "C" int sfg_mgpu_unique_id(uint8_t *id128) {
 }
 
 static int mgpu_create_common(sfg_mgpu **out, const int *devices, int n, int rank0, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
-                              const uint64_t *psi, double scale) {
+                              const uint64_t *psi, double scale, const sfg_config *config) {
     *out = nullptr;
     if (n < 1 || n > 64 || world < n || world > 64 * 1024) { g_mgpu_create_error = "sfg_mgpu_create: bad device / rank counts"; return 1; }
     sfg_mgpu *mg = new sfg_mgpu();
     mg->world = world; mg->single_process = id128 == nullptr; mg->rv.n = n;
-    mgpu_read_env(mg);
+    mgpu_read_config(mg, config);
     auto fail = [&](const std::string &m) { g_mgpu_create_error = m; sfg_mgpu_destroy(mg); return 1; };
+#ifdef SFG_AB
     if (const char *e = getenv("SFG_MGPU_SOLO")) {
         int r = 0, w = 0;
         if (sscanf(e, "%d/%d", &r, &w) != 2 || w < 1 || r < 0 || r >= w || n != 1 || id128) return fail("SFG_MGPU_SOLO=r/w needs one local device and a single process");
         mg->solo = true; mg->world = world = w; rank0 = r;
     }
+#endif
     bool dup = false;
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) dup = dup || devices[i] == devices[j];
     if (dup) mg->direct = true;                      // several ranks on one device (RCCL refuses that): the in-process transport
-    if (mg->direct && !mg->single_process) return fail("sfg_mgpu_create_rank: the direct transport exists inside one process only (unset SFG_MGPU_TRANSPORT)");
+    if (mg->direct && !mg->single_process) return fail("sfg_mgpu_create_rank: the direct transport exists inside one process only");
     mg->r.resize((size_t)n);
     for (int i = 0; i < n; i++) {
         MgRank &R = mg->r[(size_t)i]; R.rank = rank0 + i; R.device = devices[i];
-        if (sfg_ctx_create(&R.ctx, devices[i], logN, nq, np, moduli, psi, scale)) return fail(std::string("sfg_mgpu_create: device ") + std::to_string(devices[i]) + ": " + sfg_last_error(nullptr));
+        if (sfg_ctx_create_ex(&R.ctx, devices[i], logN, nq, np, moduli, psi, scale, config)) return fail(std::string("sfg_mgpu_create: device ") + std::to_string(devices[i]) + ": " + sfg_last_error(nullptr));
         if (const char *e = rank_exec_init(R)) return fail(e);
     }
     const bool need_comm = (world > 1 || mg->force_coll) && !mg->solo;
     if (need_comm && !mg->direct) {
-        { std::lock_guard<std::mutex> lk(g_rccl_mu); const std::string e = g_rccl.load(); if (!e.empty()) return fail(e); }
+        { std::lock_guard<std::mutex> lk(g_rccl_mu); const std::string e = g_rccl.load(mg->rccl_lib.empty() ? nullptr : mg->rccl_lib.c_str()); if (!e.empty()) return fail(e); }
         if (mg->single_process) {
             std::vector<ncclComm_t> comms((size_t)n);
             const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), n, devices);
@@ -260,12 +279,24 @@ static int mgpu_create_common(sfg_mgpu **out, const int *devices, int n, int ran
 }
 extern "C" int sfg_mgpu_create(sfg_mgpu **out, const int *devices, int n, int logN, int nq, int np, const uint64_t *moduli, const uint64_t *psi, double scale) {
     if (!devices) { g_mgpu_create_error = "sfg_mgpu_create: null device list"; *out = nullptr; return 1; }
-    return mgpu_create_common(out, devices, n, 0, n, nullptr, logN, nq, np, moduli, psi, scale);
+    return mgpu_create_common(out, devices, n, 0, n, nullptr, logN, nq, np, moduli, psi, scale, nullptr);
+}
+extern "C" int sfg_mgpu_create_ex(sfg_mgpu **out, const int *devices, int n, int logN, int nq, int np, const uint64_t *moduli, const uint64_t *psi, double scale,
+                                  const sfg_config *config) {
+    if (!out) { g_mgpu_create_error = "sfg_mgpu_create: null result pointer"; return 1; }
+    if (!devices) { g_mgpu_create_error = "sfg_mgpu_create: null device list"; *out = nullptr; return 1; }
+    return mgpu_create_common(out, devices, n, 0, n, nullptr, logN, nq, np, moduli, psi, scale, config);
 }
 extern "C" int sfg_mgpu_create_rank(sfg_mgpu **out, int device, int rank, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
                                     const uint64_t *psi, double scale) {
     if (!id128 || rank < 0 || rank >= world) { g_mgpu_create_error = "sfg_mgpu_create_rank: bad rank / missing id"; *out = nullptr; return 1; }
-    return mgpu_create_common(out, &device, 1, rank, world, id128, logN, nq, np, moduli, psi, scale);
+    return mgpu_create_common(out, &device, 1, rank, world, id128, logN, nq, np, moduli, psi, scale, nullptr);
+}
+extern "C" int sfg_mgpu_create_rank_ex(sfg_mgpu **out, int device, int rank, int world, const uint8_t *id128, int logN, int nq, int np, const uint64_t *moduli,
+                                       const uint64_t *psi, double scale, const sfg_config *config) {
+    if (!out) { g_mgpu_create_error = "sfg_mgpu_create_rank: null result pointer"; return 1; }
+    if (!id128 || rank < 0 || rank >= world) { g_mgpu_create_error = "sfg_mgpu_create_rank: bad rank / missing id"; *out = nullptr; return 1; }
+    return mgpu_create_common(out, &device, 1, rank, world, id128, logN, nq, np, moduli, psi, scale, config);
 }
 extern "C" const char *sfg_mgpu_last_error(const sfg_mgpu *mg) { return mg ? mg->err.c_str() : g_mgpu_create_error.c_str(); }
 extern "C" int sfg_mgpu_world(const sfg_mgpu *mg) { return mg ? mg->world : 0; }

@@ -151,6 +151,7 @@ __device__ __forceinline__ bool plain_block_of(size_t b, size_t nplain, int L, s
     return plain < nplain;
 }
 __device__ __forceinline__ bool plain_block(size_t nplain, int L, size_t &row, int &m) { return plain_block_of(blockIdx.x, nplain, L, row, m); }
+#ifdef SFG_AB          // the full-image form of the plaintext NTT (round 1): A/B build only
 constexpr int HLDS_DOUBLES = 16 * LDS_ROW;   // 67,584 B
 __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out_, size_t nplain, int L, PanelMap pm, const double *tw_all, const double2 *pack_all, const ModConst *modc) {
     extern __shared__ double lds[];
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(256) k_ntt_half(const double *pc_all, u64 *out
         out[j] = packed ? pack_limbs(w) : w;
     }
 }
+#endif
 // Same transform with every exchange split in two rounds through a HALF image (33 KiB instead of 66 KiB): three
 // workgroups (12 waves) fit a CU instead of two.  Round structure:
 //   A->B  by column half h (pp = tid + 256 h  <=>  b < 16 or b >= 16): everyone writes its column h, (a, c) readers take 16 b's
@@ -468,6 +470,7 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
     extern __shared__ double lds[];
     ntt_half3_wg<PERM, DIG>(blockIdx.x, lds, pc_all, out_, nplain, L, pm, tw_all, pack_all, modc, perm);
 }
+#ifdef SFG_AB          // round 6 experiment (microbenchmark gate not met: profiles/r06_mover_ubench.txt): A/B build only
 // The same launch with MOVER workgroups in front (i8_move.hpp): the first job.nblocks workgroups of the grid - dispatched first, one to a CU while the CUs are empty -
 // transpose a slice of the PREVIOUS MAC launch's plaintext panel into the int8 MAC's tiles while the NTT workgroups behind them fill the other three slots of every CU.
 // The NTT is fp64-issue bound and leaves two thirds of the HBM rate idle; the mover is HBM bound and needs 8 v_perm per 16 bytes.  A launch has ONE LDS size and ONE
@@ -479,6 +482,7 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3_move(const double *pc_all,
     if (blockIdx.x < job.nblocks) { i8_move_block<DEPTH, NT>(job, blockIdx.x, reinterpret_cast<unsigned *>(lds), (int)threadIdx.x); return; }
     ntt_half3_wg<PERM, true>((size_t)blockIdx.x - job.nblocks, lds, pc_all, out_, nplain, L, pm, tw_all, pack_all, modc, perm);
 }
+#endif
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
 // CU, instead of one 512-thread workgroup holding a 132 KiB image.  Each half reads both halves of the input (the second read is an L2 hit: the two
 // workgroups of a row are numbered b and b + 8, same XCD) and pays the stage-1 product itself.
@@ -515,16 +519,20 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     hipError_t e = hipFuncSetAttribute((const void *)k_ntt_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * 8);
+#ifdef SFG_AB
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_DOUBLES * 8);
+#endif
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
+#ifdef SFG_AB
 #define SFG_MV_ATTR(P, D, T) if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3_move<P, D, T>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES)
     SFG_MV_ATTR(false, 1, false); SFG_MV_ATTR(false, 1, true); SFG_MV_ATTR(false, 2, false); SFG_MV_ATTR(false, 2, true); SFG_MV_ATTR(false, 3, false); SFG_MV_ATTR(false, 3, true);
     SFG_MV_ATTR(true, 1, false); SFG_MV_ATTR(true, 1, true); SFG_MV_ATTR(true, 2, false); SFG_MV_ATTR(true, 2, true); SFG_MV_ATTR(true, 3, false); SFG_MV_ATTR(true, 3, true);
 #undef SFG_MV_ATTR
+#endif
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
 }
@@ -550,6 +558,7 @@ int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, in
     return 0;
 }
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
+#ifdef SFG_AB
 template <bool PERM>
 static void launch_half3_move(sfg_ctx *ctx, dim3 grid, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm, const MoveJob &j) {
 #define SFG_MV(D, T) hipLaunchKernelGGL((k_ntt_half3_move<PERM, D, T>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm, j)
@@ -558,10 +567,14 @@ static void launch_half3_move(sfg_ctx *ctx, dim3 grid, const double *pc, u64 *ou
     else { if (j.nt) SFG_MV(1, true); else SFG_MV(1, false); }
 #undef SFG_MV
 }
+#endif
 int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm, const MoveJob *mv) {
     if (!nplain) return 0;
     const dim3 grid((unsigned)((nplain + 7) / 8 * 8 * L));
     const bool dig = pm.packed_mask >> 31;                 // digit planes for the int8 MAC (mac_i8.hip): its own instances, the default kernels are untouched
+#ifndef SFG_AB
+    if (mv && mv->count) SFG_FAIL(ctx, "plaintext NTT: mover workgroups exist in the A/B build only (make ab)");
+#else
     if (mv && mv->count) {
         if (!dig || mv->nblocks % 8 || !mv->nblocks) SFG_FAIL(ctx, "plaintext NTT: mover workgroups need the digit-plane form and a multiple of 8 of them");
         const dim3 g2(grid.x + mv->nblocks);
@@ -570,10 +583,13 @@ int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t 
         SFG_HIP(ctx, hipGetLastError());
         return 0;
     }
+#endif
     if (perm && dig) hipLaunchKernelGGL((k_ntt_half3<true, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (perm) hipLaunchKernelGGL((k_ntt_half3<true, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (dig) hipLaunchKernelGGL((k_ntt_half3<false, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
+#ifdef SFG_AB
     else if (ctx->cfg.ntt_half_full) hipLaunchKernelGGL(k_ntt_half, grid, dim3(256), HLDS_DOUBLES * 8, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc);
+#endif
     else hipLaunchKernelGGL((k_ntt_half3<false, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);
     SFG_HIP(ctx, hipGetLastError());
     return 0;

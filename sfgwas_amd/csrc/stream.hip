@@ -219,7 +219,11 @@ int assoc_stream_part(sfg_ctx *ctx, int fmt, const char *path, size_t num_sample
         if (!rc) ST_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
     }
     if (rc) { cleanup(); return rc; }
-    const bool trace = getenv("SFG_ASSOC_TRACE") != nullptr;       // (debug: wall times of the cache build and of every batch's product, each synchronised)
+#ifdef SFG_AB
+    const bool trace = getenv("SFG_ASSOC_TRACE") != nullptr;
+#else
+    const bool trace = false;
+#endif       // (debug: wall times of the cache build and of every batch's product, each synchronised)
     if (trace) fprintf(stderr, "[assoc] buffers: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
     // the reader fills the first two slots while the rotation cache is built
     Reader rd; rd.fd = fd; rd.bt = &bt; rd.slot[0] = hb[0]; rd.slot[1] = hb[1]; rd.direct = direct;

@@ -71,15 +71,13 @@ def check_products(mg, geno, Ah, want, flag_sets):
         mg.geno_free(g)
 
 
-@pytest.mark.parametrize("coll_queue", ["enc", "own"])
-def test_world_1_exchange_over_rccl(ref, monkeypatch, coll_queue):
-    """the exchange runs on the context's encode queue by default; `own`: a queue of the engine's (what SFG_MM_OVERLAP=1 SFG_MM_ENC_OVERLAP=1 selects)"""
+def test_world_1_exchange_over_rccl(ref, monkeypatch):
+    """the exchange forced at one rank (a test switch): ncclCommInitAll, ncclReduceScatter on the collectives' queue beside the next column, ncclAllReduce"""
     geno, small, Ah, Ash, want, wants = ref
-    monkeypatch.delenv("SFG_MGPU_COLL_QUEUE", raising=False)
-    mg = make_engine(monkeypatch, [0], {"SFG_MGPU_FORCE_COLLECTIVES": "1", **({"SFG_MGPU_COLL_QUEUE": "own"} if coll_queue == "own" else {})})
+    mg = make_engine(monkeypatch, [0], {"SFG_MGPU_FORCE_COLLECTIVES": "1"})
     try:
         assert (mg.world, mg.nlocal, mg.transport) == (1, 1, "rccl")
-        check_products(mg, geno, Ah, want, (0, T, T | SQ) if coll_queue == "enc" else (T,))
+        check_products(mg, geno, Ah, want, (0, T, T | SQ))
     finally:
         mg.close()
 

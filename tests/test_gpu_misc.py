@@ -158,3 +158,33 @@ def test_device_generators_match_host_definitions(ctx):
     assert 0.003 < (X == -1).mean() < 0.02                     # ~1/128 missing
     maf = np.where(X < 0, 0, X).mean(0) / 2
     assert 0.03 < maf.min() and maf.max() < 0.6                # p_j ~ U(0.05, 0.5)
+
+
+def test_public_configuration_struct_changes_schedules_not_words():
+    """sfg_config (include/sfgwas_hip.h) through sfg_ctx_create_ex: MAC group size, accumulator budget, encode batch - the deployment's knobs - give the words of the
+    default context; a struct from an OLDER header (smaller struct_size: trailing fields unknown to the caller) is accepted; sfg_config_default zeroes and sizes it."""
+    import ctypes as C
+    from sfgwas_amd import capi
+    import oracle_lib as ol
+    lib = capi.lib()
+    cfg = capi.SfgConfig()
+    cfg.mm_group = 99
+    lib.sfg_config_default(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(capi.SfgConfig) and cfg.mm_group == 0
+    D, LEVEL, L = 91, 5, 5
+    rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < 8192]
+    outs = []
+    old = capi.SfgConfig(mm_group=1, enc_batch=300)
+    old.struct_size = capi.SfgConfig.acc_budget_bytes.offset                      # a caller compiled against a header that ended after mm_group
+    for config in (None, capi.SfgConfig(mm_group=1, acc_budget_bytes=300 << 20, enc_batch=512, upload_blocking=1), old):
+        ctx = capi.Context(ol.Q_PN14, ol.P_PN14, config=config)
+        ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(rots))(*rots), len(rots), 0xBEEF), "keys")
+        nrow, ncol, s = 2 * 8192 + 40, 8192 + 9, 2
+        gd, gh = ctx.fill_geno(nrow, ncol, 78)
+        A = ctx.fill_uniform_cts(s * 3, LEVEL, 6)
+        out = ctx.matmul_resident(A, s, LEVEL, L, gh)
+        outs.append(out.host().copy())
+        for d in (A, out, gd):
+            d.free()
+        ctx.geno_free(gh); ctx.close()
+    assert outs[0].any() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

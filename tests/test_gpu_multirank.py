@@ -127,11 +127,13 @@ def test_library_engine_one_process_two_ranks_on_one_device_reproduces_the_singl
     same(plain("c2"), got, "c2, library engine, 2 ranks in one process")
 
 
-def test_library_engine_three_ranks_c3_and_unpipelined_c2(plain):
-    """50 000 x 500 000 on three ranks (62 SNP blocks -> 20 + 21 + 21, 7 output block columns: the two column buffers change hands five times; 31 giant slots per
-    rank, 93 > 91) and the unpipelined form at 10 000 x 100 000"""
-    got = lib_line("c3", 3, ["--single-process", "--devices", "0,0,0"], LIB_SHARED_ENV)
-    same(plain("c3"), got, "c3, library engine, 3 ranks in one process")
+def test_library_engine_two_ranks_c3_and_three_ranks_unpipelined_c2(plain):
+    """50 000 x 500 000 on two ranks (62 SNP blocks -> 31 + 31, 7 output block columns: the two column buffers change hands five times; 46 giant slots per rank,
+    92 > 91) against the digests bench.py pins for c3 (the line says so itself: digests_match_pinned), and the unpipelined form at 10 000 x 100 000 on three ranks.
+    The line of an N > 1 run states what it ran on: the engine, no fallback, the pre-flight, the rank count the communicator reports (0: direct transport)."""
+    got = lib_line("c3", 2, ["--single-process", "--devices", "0,0"], LIB_SHARED_ENV)
+    assert got["digests_match_pinned"] is True, got["digests"]
+    assert got["engine_fallback"] is False and got["rccl_ranks"] == 0 and got["preflight"].startswith("ok")
     got = lib_line("c2", 3, ["--single-process", "--devices", "0,0,0"], dict(LIB_SHARED_ENV, SFG_MGPU_CACHE_GB="0"))
     same(plain("c2"), got, "c2, library engine, 3 ranks, reduce-scatters after the product")
 
@@ -141,6 +143,7 @@ def test_library_engine_over_rccl_at_world_1_in_both_process_models(plain):
     (ncclCommInitAll) and under the launcher the driver uses (one process per GPU: sfg_mgpu_unique_id on rank 0 -> TCP store -> sfg_mgpu_create_rank)"""
     got = lib_line("c2", 1, [], {"SFG_MGPU_FORCE_COLLECTIVES": "1"})
     assert got["config"]["collectives"].startswith("RCCL (called by the library")
+    assert got["rccl_ranks"] == 1 and got["engine_fallback"] is False and got["preflight"].startswith("ok")       # ncclCommCount of the one-rank communicator
     same(plain("c2"), got, "c2, library engine, RCCL at world 1, one process")
     got = lib_line("c2", 1, [], {"SFG_MGPU_FORCE_COLLECTIVES": "1"}, launcher=True)
     assert got["config"]["engine"].endswith("sfg_mgpu_create_rank") and got["config"]["collectives"].startswith("RCCL")

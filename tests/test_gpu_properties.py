@@ -123,6 +123,11 @@ def test_zero_and_all_missing_matrix_give_zero(env):
         env.lib.sfg_geno_free(env.ctx.h, gh)
 
 
+def child_env(switches):
+    from sfgwas_amd import capi
+    return capi.env_for(switches)
+
+
 _CHILD = r"""
 import sys, ctypes as C, numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
@@ -144,7 +149,8 @@ np.save(sys.argv[1], h)
 
 
 def test_group_size_and_mac_kernel_invariance(tmp_path):
-    """the same product in separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8, the register-staged MAC, and a small
+    """The product's words (outs[0], outs[1], outs[3], outs[4]: the product library with deployment switches only) against every superseded kernel, each selected by its
+    A/B switch in the experimenters' build (sfgwas_amd/lib_ab, `make ab`).  The same product in separate processes: SFG_MM_GROUP=1, SFG_MM_GROUP=8, the register-staged MAC, and a small
     accumulator budget (one block column per pass -> the product-wide rotation cache is built once and reused), the round-1 LDS-DMA MAC in both
     workgroup shapes, the plain plaintext panel, the full-image NTT kernels, the fp64 DPP-broadcast MAC for every modulus (SFG_MAC_IMPL=bc; the default runs the small moduli on the int8 matrix core)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -155,7 +161,7 @@ def test_group_size_and_mac_kernel_invariance(tmp_path):
                        ("ntt_full", {"SFG_NTT_FWD_IMPL": "full", "SFG_NTT_HALF_IMPL": "full"}), ("bc", {"SFG_MAC_IMPL": "bc"}), ("bc_g1", {"SFG_MAC_IMPL": "bc", "SFG_MM_GROUP": "1"}), ("i8_lds", {"SFG_MAC_I8_ROT": "lds"}), ("i8_big", {"SFG_MAC_I8_BIG": "0"}),
                        ("i8_cache", {"SFG_MAC_I8_ROT": "cache"}), ("i8_wg1", {"SFG_MAC_I8_WG": "1"}), ("i8_w6", {"SFG_MAC_I8_WAVES": "6"}), ("i8_w6_big0", {"SFG_MAC_I8_WAVES": "6", "SFG_MAC_I8_BIG": "0"})]:
         f = str(tmp_path / (name + ".npy"))
-        e = dict(os.environ); e.update(envv)
+        e = dict(os.environ); e.update(child_env(envv))      # kernel A/B switches exist in the A/B build only: those children load sfgwas_amd/lib_ab, the others the product
         r = subprocess.run([sys.executable, "-c", _CHILD, f], cwd=root, env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(f))
@@ -244,7 +250,7 @@ def test_schedule_invariance_at_kp15_multi_pass_size(tmp_path):
                        ("two_queues", {"SFG_MM_OVERLAP": "1", "SFG_MM_GROUP": "3", "SFG_MM_ACC_BUDGET_MB": "6000", "SFG_UPLOAD_BLOCKING": "1"}),
                        ("full_ntt", {"SFG_NTT_HALF_IMPL": "full", "SFG_NTT_FWD_IMPL": "full", "SFG_MM_GROUP": "5", "SFG_MAC_IMPL": "dma"})]:
         f = str(tmp_path / (name + ".txt"))
-        e = dict(os.environ); e.update(envv)
+        e = dict(os.environ); e.update(child_env(envv))
         r = subprocess.run([sys.executable, "-c", _CHILD_LARGE, f], cwd=root, env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append(open(f).read())

@@ -141,9 +141,9 @@ def _ctx_with_env(capi, **env):
 
 def test_gwy_four_call_sequence_over_sixteen_streamed_batches(tmp_path):
     """The logistic path's gWY (assoc.go:1338,1375,1404,1422) calls GenoBlockMult four times per block with s = ncov, 1 (square = true), 1, 1 on the SAME
-    batches.  16 batches of 64 kept SNPs streamed from one .bed: every call with the call-wide baby-step rotation cache as int8 rot tiles (the default), as fp64
-    operand rows (SFG_ASSOC_I8=0), without it (SFG_ASSOC_ROTCACHE_MB=0: the reference's per-batch rebuild) and, where the file system allows, with O_DIRECT
-    reads - identical words; batch 5 of every call against the oracle."""
+    batches.  16 batches of 64 kept SNPs streamed from one .bed: every call with the call-wide baby-step rotation cache as int8 rot tiles (the default),
+    without it (SFG_ASSOC_ROTCACHE_MB=0: the reference's per-batch rebuild) and, where the file system allows, with O_DIRECT reads - identical words; batch 5 of every
+    call against the oracle.  (The cache as fp64 operand rows - round 3's form - lives in the A/B build only since round 6.)"""
     from sfgwas_amd import capi
     ns, nv, batch, level, maxl, ncov = 300, 1100, 64, 5, 5, 5
     rnd = np.random.default_rng(23)
@@ -156,7 +156,7 @@ def test_gwy_four_call_sequence_over_sixteen_streamed_batches(tmp_path):
     slots, d = ring.slots, 91
     shifts = set(range(ns)) | set(range(slots - batch + 1, slots))
     rots = sorted({sh % d for sh in shifts if sh % d} | {(sh // d) * d for sh in shifts if sh // d})
-    ctxs = {"cached": capi.Context(ol.Q_PN14, ol.P_PN14), "per_batch": _ctx_with_env(capi, SFG_ASSOC_ROTCACHE_MB=0), "cached_fp64": _ctx_with_env(capi, SFG_ASSOC_I8=0)}
+    ctxs = {"cached": capi.Context(ol.Q_PN14, ol.P_PN14), "per_batch": _ctx_with_env(capi, SFG_ASSOC_ROTCACHE_MB=0)}
     for k in rots:
         g = ring.galois(k)
         key = capi.random_rotkey(ring.moduli, ring.beta, ring.N, 900 + k)
@@ -185,13 +185,13 @@ def test_gwy_four_call_sequence_over_sixteen_streamed_batches(tmp_path):
                 assert got_ct.value == len(bt)
                 outs[(name, direct)] = dout.host()
                 dA.free(); dout.free()
-        # the call-wide cache is kept as the int8 MAC's rot tiles (default), as fp64 operand rows (SFG_ASSOC_I8=0, round 3's form) or not at all
+        # the call-wide cache is kept as the int8 MAC's rot tiles (default) or not at all
         kept = {}
         for name, ctx in ctxs.items():
             n8, nf = C.c_size_t(), C.c_size_t()
             capi.lib().sfg_ctx_scratch_bytes(ctx.h, b"assoc.rot8", C.byref(n8)); capi.lib().sfg_ctx_scratch_bytes(ctx.h, b"assoc.rotf", C.byref(nf))
             kept[name] = (n8.value > 0, nf.value > 0)
-        assert kept == {"cached": (True, False), "per_batch": (False, False), "cached_fp64": (False, True)}, kept
+        assert kept == {"cached": (True, False), "per_batch": (False, False)}, kept
         ref = outs[("cached", False)]
         for key_, o in outs.items():
             assert np.array_equal(o, ref), f"s={s} square={square}: {key_} differs from the cached path"
