@@ -282,12 +282,39 @@ def roofline_blocks(phase_tot, args, dims, world, dt, value):
                        "(three 50 KiB slots), read once; bytes = the two streams + tile-ordered results written.  The 46-bit modulus runs the same kernel with six digits "
                        "(k_mac_i8_ring<6, 2>, phase mac_big)",
                "helpers_ms_per_step": {k: phase_tot[k][0] / args.steps for k in ("mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile") if k in phase_tot}}
-    dom, other = (ntt_blk, mac_blk) if ntt_total_ms >= ms_small else (mac_blk, ntt_blk)
+    # The riding transposition: most plaintext-NTT launches carry mover workgroups that transpose the previous MAC launch's plaintext panel into
+    # the int8 MAC's tiles - ONE kernel, k_ntt_half3_move, doing an fp64-issue-bound job and an HBM-bound job side by side.  Its algorithmic bytes are the NTT's plus
+    # the movers' (1 B in + 1 B out per digit byte); it is priced against HBM (the closer roof), with the NTT's issue-slot fraction inside that launch beside it.
+    ms_rd, n_rd, by_rd_ntt = phase_tot.get("ntt_plain_ride", [0.0, 0, 0.0])
+    n_rd_all = phase_tot.get("ntt_ride_all", [0.0, 0, 0.0])[1]
+    by_mv = phase_tot.get("pt_ride", [0.0, 0, 0.0])[2]
+    ride_blk, ride_total_ms = None, 0.0
+    if n_rd and n_rd_all:
+        rd_avg_ms = ms_rd / n_rd
+        ride_total_ms = rd_avg_ms * n_rd_all
+        rd_bytes = (by_rd_ntt + by_mv) / n_rd
+        rd_gbps = rd_bytes / (rd_avg_ms * 1e-3) / 1e9
+        rd_plains = (by_rd_ntt / n_rd) / bytes_per_plain
+        rd_instr_s = rd_plains * L * 256 * NTT_FP64_INSTR / (rd_avg_ms * 1e-3)
+        ride_blk = {"bound": "hbm", "achieved": rd_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rd_gbps / HBM_PEAK_GBS, "kernel": "k_ntt_half3_move<false, 1, true>",
+                    "avg_launch_ms": rd_avg_ms, "launches": n_rd_all, "launches_timed": n_rd, "total_ms_in_timed_region": ride_total_ms,
+                    "alg_bytes_per_launch": rd_bytes, "alg_bytes_ntt": by_rd_ntt / n_rd, "alg_bytes_movers": by_mv / n_rd,
+                    "fp64_issue": {"frac": rd_instr_s / FP64_VALU_SPEC_FMA_S, "what": "the NTT workgroups' fp64 issue slots over the same launch duration (2016 per thread and row)"},
+                    "plain_launch": {"kernel": "k_ntt_half3<false, true>", "avg_launch_ms": ntt_avg_ms, "launches": n_ntt_all, "fp64_issue_frac": ntt_blk["frac"],
+                                     "what": "the same NTT without mover workgroups (the encodes no delayed MAC launch rides in: the first of a call and of every block-row group)"},
+                    "what": "plaintext (panel) NTT with the riding transposition: per launch 2048 plaintexts x 5 moduli of half-size NTTs (fp64 issue bound: 64 KiB in, "
+                            "26 B x N/2 out per plaintext) and, on 192 mover workgroups dispatched first (one per CU, beside three NTT workgroups), 1/launches of the previous "
+                            "MAC launch's [k][coefficient] -> [coefficient][16 k] byte transposition (HBM bound: 1 B in + 1 B out per digit byte).  The pair shares the memory "
+                            "system: priced against the HBM peak with both jobs' algorithmic bytes"}
+    if ride_blk and ride_total_ms >= ms_small:
+        dom, other = ride_blk, mac_blk
+    else:
+        dom, other = (ntt_blk, mac_blk) if ntt_total_ms >= ms_small else (mac_blk, ntt_blk)
     alg_step = 2 * n_ind * m_snp + (KP * nbr_x + KP * mct_x) * ctw * 8 + (KP * mct_x + KP * nbr_x) * outw * 8
     hbm_alg = alg_step * args.steps / dt / 1e9
     traffic, traffic_src = None, "no counter pass of this kernel in profiles/"
     try:
-        for name in ("r05_pmc_ntt.json", "r03_pmc_traffic_per_launch_i8.json"):
+        for name in ("r06_pmc_ntt_ride.json", "r05_pmc_ntt.json", "r03_pmc_traffic_per_launch_i8.json"):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -306,7 +333,8 @@ def roofline_blocks(phase_tot, args, dims, world, dt, value):
                                  "what": "SURVEY §8(d): int8 genotypes once per product + ciphertexts in/out, divided by the WHOLE step time"})
 
 
-PHASES = ("rotate", "skew", "encode", "mac", "mac_small", "mac_big", "ntt_plain", "ntt_plain_all", "mac_i8_pack_pt", "mac_i8_pack_rot", "mac_i8_untile")
+PHASES = ("rotate", "skew", "encode", "mac", "mac_small", "mac_big", "ntt_plain", "ntt_plain_all", "ntt_plain_ride", "ntt_ride_all", "pt_ride", "mac_i8_pack_pt", "mac_i8_pack_rot",
+          "mac_i8_untile")
 
 
 class Watchdog:

@@ -14,6 +14,7 @@
 // move the high parts of all points through a 64 KiB LDS image (re, im), then the low parts.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "i8_move.hpp"            // PtRide: the riding transposition's items are dealt out over the NTT launches made here
 #include <cmath>
 #include <type_traits>
 
@@ -584,7 +585,8 @@ int launch_skew(sfg_ctx *ctx, const int8_t *blk, size_t ld, int r, int c, int tr
 
 // encode diagonals [shift0, shift0+nshift) of a skewed block D into pt[nshift][L][N]
 // half_rows + G > 0: `pt` is the base of a grouped panel and rows are scattered by PanelMap (half rows only)
-int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask, const PcCache *pcache, StagePack *sp) {
+int encode_rows_launches(const sfg_ctx *ctx, int nshift) { const int B = ctx->cfg.enc_batch; return (nshift + B - 1) / B; }
+int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows, int G, int g, unsigned packed_mask, const PcCache *pcache, StagePack *sp, PtRide *ride) {
     EncTables *et = (EncTables *)ctx->enc_tables();
     const size_t lds_bytes = ENC_LDS_BYTES;
     if (sp && (shift0 % SFG_D || !half_rows || !(packed_mask >> 31))) SFG_FAIL(ctx, "encode: internal: the streamed transposition takes whole giant steps of digit-plane rows");
@@ -602,9 +604,11 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         }
         if (cmode == 2) pc = pcache->slot + (size_t)(shift0 + s0) * SFG_SLOTS;
         // the panel NTT is timed on a sample (every 16th launch carries an event pair: 50 000 launches per power iteration) and counted in full
+        // (launches that carry mover workgroups of the riding transposition are timed and counted apart: phases ntt_plain_ride / ntt_ride_all, their mover bytes in pt_ride)
         const bool sampled = half_rows && G > 0 && (ctx->ntt_plain_seq++ & 15) == 0;
-        PhaseTimer tn(ctx, "ntt_plain", sampled);
-        if (half_rows && G > 0) { PhaseStat &all = ctx->phases["ntt_plain_all"]; all.launches += 1; }
+        const bool riding = !sp && half_rows && G > 0 && ride && ride->on && ride->next < ride->total();
+        PhaseTimer tn(ctx, riding ? "ntt_plain_ride" : "ntt_plain", sampled);
+        if (half_rows && G > 0) { PhaseStat &all = ctx->phases[riding ? "ntt_ride_all" : "ntt_plain_all"]; all.launches += 1; }
         if (sp) {
             // the staging buffer is free once the previous batch has been transposed (that ran beside this batch's FFT)
             if (sp->pending) SFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, sp->ev_pack, 0));
@@ -616,8 +620,19 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
             SFG_HIP(ctx, hipEventRecord(sp->ev_pack, sp->q));
             sp->pending = true;
         }
-        else if (cmode == 3) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm)); }
-        else if (half_rows && G > 0) { PanelMap pm{G, g, shift0 + s0, packed_mask}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm)); }
+        else if (half_rows && G > 0) {
+            // the riding transposition: this launch's share of the previous MAC launch's panel goes along as mover workgroups (k_ntt_half3_move)
+            MoveJob mj; const MoveJob *mv = nullptr; double moved = 0;
+            if (ride && ride->on && ride->next < ride->total()) {
+                mj = ride->job; mj.first = ride->next; mj.count = std::min(ride->per, ride->total() - ride->next); ride->next += mj.count; mv = &mj;
+                const unsigned hi = mj.first + mj.count, n5 = mj.n5, in5 = mj.first < n5 ? std::min(hi, n5) - mj.first : 0u;
+                moved = in5 * ride->item_bytes5 + (mj.count - in5) * ride->item_bytes6;
+                if (sampled) { PhaseStat &ps = ctx->phases["pt_ride"]; ps.launches += 1; ps.bytes += moved; }       // (the timed launches' share: same sample as ntt_plain_ride)
+            }
+            PanelMap pm{G, g, shift0 + s0, packed_mask};
+            if (cmode == 3) SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm, mv));
+            else SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm, nullptr, mv));
+        }
         else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));
         if (sampled) {      // algorithmic bytes: the coefficient row in, L output rows of N/2 words (or five digit planes of N/2 bytes for the int8 MAC's moduli)

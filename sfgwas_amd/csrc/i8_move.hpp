@@ -27,6 +27,16 @@ struct MoveJob {
     int depth = 3, nt = 0;                 // host side: which instance of the kernel (units in flight per workgroup; streaming loads and stores)
 };
 
+// One delayed MAC launch's transposition riding in the NTT launches of the next launch's encode (kernels.hpp).  The product rides with `nblocks` = cfg.pt_ride mover
+// workgroups per NTT launch, one unit in flight, streaming loads and stores - the best point of profiles/r06_mover_ubench.txt.
+struct PtRide {
+    bool on = false;
+    MoveJob job;                           // first / count are set per NTT launch
+    unsigned next = 0, per = 0;            // next item to hand out; items per NTT launch
+    unsigned total() const { return job.n5 + job.n6; }
+    double item_bytes5 = 0, item_bytes6 = 0;      // bytes read + written per item (phase statistics)
+};
+
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct I8MoveItem { const unsigned char *src; int8_t *dst; int kq, jt; };
 template <int ND>

@@ -18,6 +18,10 @@ int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const Mo
 int launch_ntt_inv(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
 int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, int L);
 struct MoveJob;                                   // i8_move.hpp: mover workgroups of the previous MAC launch's plaintext transposition riding in front of the NTT's
+// The riding transposition (round 6): the plaintext panel of MAC launch k - 1 goes into the int8 MAC's tiles INSIDE the plaintext-NTT launches of launch k's encode
+// (k_ntt_half3_move: `nblocks` mover workgroups first in every grid, one to a CU beside three NTT workgroups).  matmul.hip fills one per delayed MAC launch;
+// launch_encode_rows deals its items out evenly over the NTT launches it makes and i8_ride_finish moves whatever is left.
+struct PtRide;
 int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm = nullptr, const MoveJob *mv = nullptr);
 int launch_expand_half(sfg_ctx *ctx, const u64 *half, u64 *full, size_t nrows);
 int launch_ntt_fwd_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat, const RowMap &rm);
@@ -25,6 +29,7 @@ int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, cons
 // mac.hip
 struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; bool i8_big = false; bool pt_digits_big = false;
                     const int8_t *B_small = nullptr, *B_big = nullptr; int kb = 0;
+                    int B_mode = 0;       // B_* given and B_mode 0: streamed tiles (k' = g * kb + baby); 1: the pass's layout, already transposed (riding mover): no pass; 2: the pass runs into these buffers
                     const int8_t *A_small = nullptr, *A_big = nullptr; };   // A_*: the transposed rot tiles of this launch are given (I8RotPre): no copy to look up or make   // B_*: the int8 MAC's plaintext tiles are already in place (streamed transposition, StagePack): no panel, k' = g * kb + baby   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                         int l0, int nl, int accumulate, const MacStrides &st);       // mac_i8.hip
@@ -53,7 +58,13 @@ struct StagePack {
 // plaintexts per batch of the streamed transposition: cfg.stage_giants whole giant steps (default 11: 1001 plaintexts, 5005 NTT workgroups; SFG_STAGE_GIANTS)
 int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, int L);      // mac_i8.hip
 int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, int L, u64 *pt, bool half_rows = false, int G = 0, int g = 0, unsigned packed_mask = 0, const PcCache *pcache = nullptr,
-                       StagePack *sp = nullptr);
+                       StagePack *sp = nullptr, PtRide *ride = nullptr);
+int encode_rows_launches(const sfg_ctx *ctx, int nshift);          // NTT launches launch_encode_rows makes for nshift diagonals (panel form)
+// mac_i8.hip: the riding transposition of one delayed MAC launch (panel of K = ng * 91 k-rows x 91 columns -> tile buffers mi8.Bs / mi8.Bb); ride.on stays false where the
+// moduli are not one run of 35-bit ones plus at most one 46-bit one
+int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, int L, int launches, PtRide &ride);
+int i8_ride_finish(sfg_ctx *ctx, PtRide &ride);                     // items no NTT launch took: a launch of mover workgroups alone on the current stream
+int i8_ride_tiles(sfg_ctx *ctx, int K, int L, int8_t **Bs, int8_t **Bb);          // the two tile buffers (a launch that transposes by the pass uses them as well: B_mode 2)
 // genoio.hip: dense int8 copy [nr][ld_out] of the stored sub-block (r0.., c0..) of a 2-bit packed matrix (c0 a multiple of 4)
 int launch_geno_unpack(sfg_ctx *ctx, const sfg_geno *g, size_t r0, size_t c0, size_t nr, size_t nc, int8_t *out, size_t ld_out);
 // rotate.hip

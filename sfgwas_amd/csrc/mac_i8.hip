@@ -175,15 +175,14 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
         __syncthreads();
     }
 }
-#ifdef SFG_AB
 // ---- the same as a low-occupancy mover (i8_move.hpp): job.nblocks workgroups (one per CU) walk the items with the next units' loads in flight in registers.
-// Alone on the chip this is the A/B of the pass above; its place is in front of the plaintext NTT's workgroups (k_ntt_half3_move, ntt.hip).
+// Its place is in front of the plaintext NTT's workgroups (k_ntt_half3_move, ntt.hip: the riding transposition); alone on the chip it moves what no NTT launch took
+// (i8_ride_finish) and, in the A/B build, is the A/B of the pass above.
 template <int DEPTH, bool NT>
 __global__ void __launch_bounds__(256, 4) k_i8_move_pt(MoveJob job) {
     __shared__ __attribute__((aligned(16))) unsigned img[I8_PD * 64];
     i8_move_block<DEPTH, NT>(job, blockIdx.x, img, (int)threadIdx.x);
 }
-#endif
 #ifdef SFG_AB          // streamed transposition (round 4 - 5 experiment, measured slower) and the mover form of the pass (round 6, no gain): A/B build only
 // ---- the same from the DENSE digit planes of one encode batch (StagePack, kernels.hpp): plaintext p of the batch is shift shift0 + p = giant n, baby b of block
 // row g; its byte goes to column n, k' = g * kb + b.  A workgroup = (modulus, column tile jt, 16 k', 128 coefficients) as above, restricted to what this batch
@@ -522,15 +521,68 @@ int launch_i8_pack_stage(sfg_ctx *ctx, StagePack &sp, int shift_lo, int nshift, 
 }
 // bytes of the tile buffer of `nl` moduli with ND digits for K' contraction steps
 size_t mac_i8_tile_bytes(int Kp, int nl, int ND) { return (size_t)nl * (SFG_N / 2) * 6 * (((size_t)Kp + 63) / 64) * ND * 1024; }
-#ifdef SFG_AB
 static void launch_move_alone(hipStream_t q, const MoveJob &j) {
 #define SFG_MV(D, T) hipLaunchKernelGGL((k_i8_move_pt<D, T>), dim3(j.nblocks), dim3(256), 0, q, j)
-    if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); }
-    else if (j.depth == 2) { if (j.nt) SFG_MV(2, true); else SFG_MV(2, false); }
-    else { if (j.nt) SFG_MV(1, true); else SFG_MV(1, false); }
+#ifdef SFG_AB
+    if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); return; }
+    if (j.depth == 2) { if (j.nt) SFG_MV(2, true); else SFG_MV(2, false); return; }
+    if (!j.nt) { SFG_MV(1, false); return; }
+#endif
+    SFG_MV(1, true);
 #undef SFG_MV
 }
+// ---- the riding transposition (kernels.hpp PtRide): tile buffers, the job of one delayed MAC launch, what is left of it
+static bool i8_ride_moduli(sfg_ctx *ctx, int L, int &l_small0, int &n_small, int &l_big) {
+    std::vector<int> plane_of, is_big; if (mac_dma_planes(ctx, L, plane_of, is_big) < 0) return false;
+    l_big = -1; l_small0 = -1; n_small = 0; int nbig = 0;
+    for (int l = 0; l < L; l++) { if (is_big[l]) { l_big = l; nbig++; } else { if (l_small0 < 0) l_small0 = l; n_small++; } }
+    if (nbig > 1 || !n_small) return false;
+    for (int l = 0; l < L; l++) if (!is_big[l] && (l < l_small0 || l >= l_small0 + n_small)) return false;      // the 35-bit moduli must be one run: one MAC launch, one tile buffer
+    if (l_big >= 0 && (!ctx->cfg.mac_i8_big || ctx->q[l_big] > SFG_I8_BIG_QMAX)) return false;
+    return true;
+}
+int i8_ride_tiles(sfg_ctx *ctx, int K, int L, int8_t **Bs, int8_t **Bb) {
+    int l_small0, n_small, l_big;
+    *Bs = *Bb = nullptr;
+    if (!i8_ride_moduli(ctx, L, l_small0, n_small, l_big)) return 0;
+    SFG_TRY(sfg_scratch(ctx, "mi8.Bs", mac_i8_tile_bytes(K, n_small, 5), (void **)Bs));
+    if (l_big >= 0) SFG_TRY(sfg_scratch(ctx, "mi8.Bb", mac_i8_tile_bytes(K, 1, 6), (void **)Bb));
+    return 0;
+}
+int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, int L, int launches, PtRide &ride) {
+    const int H = SFG_N / 2;
+    ride = PtRide();
+    int l_small0, n_small, l_big;
+    if (ctx->cfg.pt_ride <= 0 || launches < 1 || Ncols > 96 || !i8_ride_moduli(ctx, L, l_small0, n_small, l_big)) return 0;
+    if (pt_n * 8 >= (1ULL << 31) || pt_k * 8 * 16 >= (1ULL << 31)) return 0;                  // the mover's per-lane offsets are 32-bit
+    int8_t *Bs, *Bb; SFG_TRY(i8_ride_tiles(ctx, K, L, &Bs, &Bb));
+    const int nch = (K + 63) / 64, njt = (Ncols + 15) / 16;
+    auto fill = [&](I8Args &a, int l0, int nl, int8_t *B) {
+        memset(&a, 0, sizeof a);
+        a.pt = panel; a.pt_k_stride = pt_k; a.pt_n_stride = pt_n; a.pt_l_stride = H; a.K = K; a.Ncols = Ncols; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = njt; a.pt_digits = 1; a.B = B;
+    };
+    MoveJob &j = ride.job;
+    fill(j.a5, l_small0, n_small, Bs); j.n5 = (unsigned)((size_t)n_small * njt * nch * 4 * (H / I8_PD));
+    if (l_big >= 0) { fill(j.a6, l_big, 1, Bb); j.n6 = (unsigned)((size_t)njt * nch * 4 * (H / I8_PD)); } else { memset(&j.a6, 0, sizeof j.a6); j.n6 = 0; }
+    j.nblocks = (unsigned)ctx->cfg.pt_ride; j.depth = 1; j.nt = 1; j.first = 0; j.count = 0;
+#ifdef SFG_AB
+    j.depth = ctx->cfg.i8_mover_depth_ride; j.nt = ctx->cfg.i8_mover_nt_ride;
 #endif
+    ride.next = 0; ride.per = (ride.total() + (unsigned)launches - 1) / (unsigned)launches;
+    ride.item_bytes5 = 5.0 * 2 * 32768; ride.item_bytes6 = 6.0 * 2 * 32768;         // a unit = one digit plane of an item: 256 rows of 128 bytes in, 128 pieces of 256 bytes out
+    ride.on = true;
+    return 0;
+}
+int i8_ride_finish(sfg_ctx *ctx, PtRide &ride) {
+    if (!ride.on || ride.next >= ride.total()) return 0;
+    MoveJob j = ride.job; j.first = ride.next; j.count = ride.total() - ride.next; ride.next = ride.total();
+    j.nblocks = std::min(2048u, (j.count + 7u) / 8u * 8u);                       // alone on the chip the mover wants many workgroups (profiles/r06_mover_ubench.txt)
+    PhaseTimer t(ctx, "mac_i8_pack_pt");
+    launch_move_alone(ctx->stream, j);
+    SFG_HIP(ctx, hipGetLastError());
+    t.stop(1);
+    return 0;
+}
 template <int ND>
 static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
                             int l0, int nl, int accumulate, const MacStrides &st) {
@@ -545,13 +597,16 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     for (int t = l0; t < l0 + nl; t++) {
         if (ctx->q[t] > (BIG ? SFG_I8_BIG_QMAX : (1ULL << 38))) SFG_FAIL(ctx, "sfg_mac (i8): modulus %d = %llu does not fit %d signed base-256 digits / the exact fp64 recombination", t, (unsigned long long)ctx->q[t], ND);
     }
-    const int8_t *B_pre = BIG ? st.B_big : st.B_small;              // streamed transposition: the plaintext tiles are in place, k' = g * kb + baby
-    if (B_pre && (K % SFG_D || !st.kb || Ncols != SFG_D)) SFG_FAIL(ctx, "sfg_mac (i8): internal: prepacked tiles need whole block rows and 91 columns");
+    const int8_t *B_given = BIG ? st.B_big : st.B_small;            // B_mode 0: streamed transposition, the plaintext tiles are in place, k' = g * kb + baby;
+    const bool B_stream = B_given && st.B_mode == 0;                // 1: in place in the pass's own layout (the riding mover made them); 2: the pass below runs into this buffer
+    const int8_t *B_pre = B_given && st.B_mode != 2 ? B_given : nullptr;
+    if (B_given && !B_stream && !st.pt_digits) SFG_FAIL(ctx, "sfg_mac (i8): internal: given tile buffers take digit-plane panels");
+    if (B_stream && (K % SFG_D || !st.kb || Ncols != SFG_D)) SFG_FAIL(ctx, "sfg_mac (i8): internal: prepacked tiles need whole block rows and 91 columns");
     const int8_t *A_pre = BIG ? st.A_big : st.A_small;             // the transposed rot tiles of exactly this launch, made by launch_i8_pack_rot_to (I8RotPre)
-    if (A_pre && (B_pre || r0 != 0 || R > 32)) SFG_FAIL(ctx, "sfg_mac (i8): internal: given rot tiles cover one block of <= 32 rows, with the plaintext panel");
+    if (A_pre && (B_stream || r0 != 0 || R > 32)) SFG_FAIL(ctx, "sfg_mac (i8): internal: given rot tiles cover one block of <= 32 rows, with the plaintext panel");
     const int K_rot = K;                                            // rows of the rot operand
-    if (B_pre) K = K / SFG_D * st.kb;
-    I8Args a; a.kb = B_pre ? st.kb : 0;
+    if (B_stream) K = K / SFG_D * st.kb;
+    I8Args a; a.kb = B_stream ? st.kb : 0;
     a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
     a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = H; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
     a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
@@ -588,7 +643,7 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
         if (repack) { slots[slot].src = (const void *)rotf; memcpy(slots[slot].sig, sig, sizeof sig); }
         slots[slot].last_use = ++ctx->i8_clock;
     }
-    if (B_pre) a.B = const_cast<int8_t *>(B_pre);
+    if (B_given) a.B = const_cast<int8_t *>(B_given);
     else SFG_TRY(sfg_scratch(ctx, !ctx->cfg.stage_pack ? "mi8.B" : BIG ? "mi8.Bb" : "mi8.Bs", nB, (void **)&a.B));        // (with the streamed transposition on: the buffers of the streamed tiles, a launch uses them one way or the other)
     SFG_TRY(sfg_scratch(ctx, "mi8.T", nT * 8, (void **)&a.T));
     // (a regrown B / T buffer belongs to this launch alone; the A copies have their own buffers)

@@ -12,6 +12,7 @@
 // as int8 and serves both X and X^T (SFG_TRANSPOSE).  Active baby/giant tables follow matmult.go:1329-1336.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "i8_move.hpp"            // PtRide
 #include <algorithm>
 #include <string>
 
@@ -425,7 +426,8 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
                     const bool enc2 = !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G2 - 1) / G2) * (j1 - j0) >= 2;
                     const bool streamable2 = ctx->cfg.mac_i8 && ctx->cfg.mac_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc2;      // then the panel holds 4 block rows
-                    size_t need = (size_t)(streamable2 ? std::min(G2, 4) : G2) * nplain * L * ((size_t)N / 2) * 8 * (enc2 ? 2 : 1);
+                    const bool ride2 = ctx->cfg.mac_i8 && ctx->cfg.pt_ride > 0 && !enc2 && !streamable2 && j1 - j0 >= 2;      // (the riding transposition keeps two panels too)
+                    size_t need = (size_t)(streamable2 ? std::min(G2, 4) : G2) * nplain * L * ((size_t)N / 2) * 8 * (enc2 || ride2 ? 2 : 1);
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
@@ -463,7 +465,13 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     const bool streamable = use_i8 && use_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc_ov && !pre8;
     const int Gp = streamable ? std::min(G, 4) : G;
     const size_t panel_words = (size_t)Gp * nplain * L * prow;
-    SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov ? 2 : 1), (void **)&pt));
+    // The riding transposition (kernels.hpp PtRide): the panel of MAC launch k - 1 is transposed by mover workgroups inside the plaintext-NTT launches of launch k's
+    // encode, which writes the OTHER panel; MAC launch k - 1 follows that encode on the same queue and finds its tiles in place.  Taken where every modulus multiplies
+    // on the int8 matrix core from digit-plane panels; the first launch after a change of block-row group (its rot operand's buffer is about to be rebuilt) and the
+    // call's last launch transpose by the pass as before.
+    const bool ride_want = use_i8 && !streamable && !enc_ov && ctx->cfg.pt_ride > 0 && j1 - j0 >= 2 &&       // (a launch rides in the encode of the NEXT block column of its group)
+                           (use_i8_big || [&] { for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) return false; return true; }());
+    SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov || ride_want ? 2 : 1), (void **)&pt));
     u64 *const pt_base = pt;
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
     int8_t *unpacked = nullptr;
@@ -498,10 +506,31 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         SFG_HIP(ctx, hipEventRecord(ctx->ev_pipe[0], ctx->aux_stream));
     }
     int gi = 0, it = 0;
+    // a MAC launch: the plaintext panel `ptp` of `gsn` block rows against the group's rot operand, into block column accumulator `accj`
+    struct MacJob { bool on = false; u64 *ptp = nullptr; int gsn = 0, sub0 = 0, gi = 0, acc_flag = 0; u64 *accj = nullptr; const double *rotf_grp = nullptr, *rotsum_grp = nullptr; StagePack *sp = nullptr; };
+    int8_t *rideBs = nullptr, *rideBb = nullptr;               // the riding launches' tile buffers (a launch of the same call that transposes by the pass uses them too)
+    auto run_mac = [&](const MacJob &m, int B_mode) -> int {
+        PhaseTimer t(ctx, "mac");
+        MacStrides st;
+        if (m.sp) { st.B_small = m.sp->Bs; st.B_big = m.sp->Bb; st.kb = m.sp->kb; }
+        else if (rideBs) { st.B_small = rideBs; st.B_big = rideBb; st.B_mode = B_mode; }
+        if (pre8) { st.A_small = pre8->As[m.gi]; st.A_big = pre8->Ab[m.gi]; }
+        st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
+        st.pt_k = plw; st.pt_n = (size_t)m.gsn * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
+        st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
+        int r2;
+        if (dma) r2 = launch_mac_dma(ctx, pre8 ? nullptr : m.rotf_grp + (size_t)m.sub0 * d * s * 2 * rowf, (size_t)s * 2, m.ptp, m.accj, m.gsn * d, 2 * s, d, L, m.acc_flag, st, m.rotsum_grp);
+        else r2 = launch_mac_strided(ctx, rotc, m.ptp, m.accj, d, 2 * s, d, L, m.acc_flag, st);
+        t.stop(1);
+        return r2;
+    };
+    MacJob held;                                               // the delayed MAC launch whose panel the next encode's NTT launches transpose
     struct StreamRestore { sfg_ctx *c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore_main{ctx, main_stream};       // whatever path leaves the loop
     if (enc_ov) SFG_TRY(sfg_stream_after(ctx, ctx->enc_stream, main_stream));      // the genotypes, the cache slots and whatever the caller enqueued before
     for (int bg = b0; bg < b1 && !rc; bg += G, gi++) {
         const int ng = std::min(G, b1 - bg);
+        // (the delayed launch of the previous group reads a rot operand buffer that is rebuilt below: it goes first, transposing by the pass)
+        if (held.on) { rc = run_mac(held, 2); held.on = false; if (rc) break; }
         // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
         const double *rotf_grp = rotf, *rotsum_grp = rotsum;
         if (rotf_pre) { rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf; rotsum_grp = rotsum_pre ? rotsum_pre + (size_t)gi * s * 2 * rowf : nullptr; }
@@ -550,7 +579,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 // the transposition queue starts behind everything this queue has done (the previous MAC launch read the tiles, the memsets above)
                 rc = sfg_stream_after(ctx, sp.q, ctx->stream); if (rc) break;
             }
-            const int pbuf = enc_ov ? (it & 1) : 0;
+            const int pbuf = enc_ov || ride_want ? (it & 1) : 0;
             pt = pt_base + (size_t)pbuf * panel_words;
             if (enc_ov) {                                  // encode on its queue: after the MAC that last read this panel buffer
                 if (it >= 2) SFG_HIP(ctx, hipStreamWaitEvent(ctx->enc_stream, ctx->ev_enc[2 + pbuf], 0));
@@ -559,6 +588,21 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
           // A launch that cannot stream (a block with fewer than 8192 diagonals: the corner of a ragged matrix) goes through the plaintext panel.  Where streaming
           // is the rule the panel holds only Gp block rows, and such a launch is multiplied in sub-launches of Gp rows that accumulate onto each other.
           const int step = stream ? ng : std::min(ng, Gp);
+          // riding: this launch's encode carries the held launch's transposition; its own MAC is held in turn (whole-group launches only)
+          const bool ride_this = ride_want && !stream && step == ng;
+          PtRide ride;
+          if (ride_this && !rideBs) { rc = i8_ride_tiles(ctx, G * d, L, &rideBs, &rideBb); if (rc) break; }
+          if (held.on && ride_this && rideBs) {
+              int launches = 0;
+              for (int g = 0; g < ng; g++) {
+                  const int nr = sh.rows_of(bg + g);
+                  if (nr + nc > SFG_SLOTS) launches += encode_rows_launches(ctx, SFG_SLOTS);
+                  else launches += encode_rows_launches(ctx, nr) + (nc > 1 ? encode_rows_launches(ctx, nc - 1) : 0);
+              }
+              rc = i8_ride_prepare(ctx, held.ptp, held.gsn * d, d, plw, (size_t)held.gsn * d * plw, L, launches, ride); if (rc) break;
+              if (ride.on && (ride.job.a5.B != rideBs || (ride.job.n6 && ride.job.a6.B != rideBb))) { rc = 1; ctx->err = "matmul: internal: the riding transposition's tile buffers moved"; break; }
+          }
+          if (held.on && !ride.on) { rc = run_mac(held, rideBs ? 2 : 0); held.on = false; if (rc) break; }       // nothing to ride in: the held launch goes now, by the pass
           for (int sub0 = 0; sub0 < ng && !rc; sub0 += step) {
             const int gs = std::min(step, ng - sub0);
             for (int g = sub0; g < sub0 + gs && !rc; g++) {
@@ -607,7 +651,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     for (int r = 0; r < nruns && !rc; r++) {
                         if (stream) sp.g = g;
                         if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, gs, g - sub0, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u),
-                                                         pcc.mode ? &pcc : nullptr, stream ? &sp : nullptr);
+                                                         pcc.mode ? &pcc : nullptr, stream ? &sp : nullptr, ride.on ? &ride : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }
                     t.stop(nruns);
@@ -621,25 +665,21 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             if (rc) break;
             if (!stream && streamable) ctx->sp_shape = -1;       // (this launch transposes through the tile buffers the streamed launches keep partly cleared)
             if (stream && sp.pending) SFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, sp.ev_pack, 0));       // the last batch is in the tiles
+            // the held launch: whatever of its transposition no NTT launch of this encode took, then its MAC on the tiles
+            if (held.on) { rc = i8_ride_finish(ctx, ride); if (!rc) rc = run_mac(held, 1); held.on = false; if (rc) break; }
             {
-                PhaseTimer t(ctx, "mac");
-                MacStrides st;
-                if (stream) { st.B_small = sp.Bs; st.B_big = sp.Bb; st.kb = sp.kb; }
-                if (pre8) { st.A_small = pre8->As[gi]; st.A_big = pre8->Ab[gi]; }
-                st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
-                st.pt_k = plw; st.pt_n = (size_t)gs * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
-                st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
-                const int acc_flag = (accumulate || !first_group || sub0 > 0) ? 1 : 0;      // the first (sub-)launch of a fresh call overwrites
-                u64 *accj = acc + (size_t)(bj - j0) * d * accw;
-                if (dma) rc = launch_mac_dma(ctx, pre8 ? nullptr : rotf_grp + (size_t)sub0 * d * s * 2 * rowf, (size_t)s * 2, pt, accj, gs * d, 2 * s, d, L, acc_flag, st, rotsum_grp);
-                else rc = launch_mac_strided(ctx, rotc, pt, accj, d, 2 * s, d, L, acc_flag, st);
-                t.stop(1);
+                MacJob m; m.on = true; m.ptp = pt; m.gsn = gs; m.sub0 = sub0; m.gi = gi; m.sp = stream ? &sp : nullptr;
+                m.acc_flag = (accumulate || !first_group || sub0 > 0) ? 1 : 0;      // the first (sub-)launch of a fresh call overwrites
+                m.accj = acc + (size_t)(bj - j0) * d * accw; m.rotf_grp = rotf_grp; m.rotsum_grp = rotsum_grp;
+                if (ride_this && rideBs) held = m;                                 // multiplied after the next launch's encode has transposed this panel
+                else rc = run_mac(m, rideBs ? 2 : 0);
             }
           }
             if (enc_ov && !rc) SFG_HIP(ctx, hipEventRecord(ctx->ev_enc[2 + pbuf], main_stream));
         }
         first_group = false;
     }
+    if (held.on && !rc) rc = run_mac(held, 2);                  // the call's last launch: nothing follows to ride in
     return rc;
 }
 

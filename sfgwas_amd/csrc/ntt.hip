@@ -470,7 +470,6 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3(const double *pc_all, u64 
     extern __shared__ double lds[];
     ntt_half3_wg<PERM, DIG>(blockIdx.x, lds, pc_all, out_, nplain, L, pm, tw_all, pack_all, modc, perm);
 }
-#ifdef SFG_AB          // round 6 experiment (microbenchmark gate not met: profiles/r06_mover_ubench.txt): A/B build only
 // The same launch with MOVER workgroups in front (i8_move.hpp): the first job.nblocks workgroups of the grid - dispatched first, one to a CU while the CUs are empty -
 // transpose a slice of the PREVIOUS MAC launch's plaintext panel into the int8 MAC's tiles while the NTT workgroups behind them fill the other three slots of every CU.
 // The NTT is fp64-issue bound and leaves two thirds of the HBM rate idle; the mover is HBM bound and needs 8 v_perm per 16 bytes.  A launch has ONE LDS size and ONE
@@ -482,7 +481,6 @@ __global__ void __launch_bounds__(256, 4) k_ntt_half3_move(const double *pc_all,
     if (blockIdx.x < job.nblocks) { i8_move_block<DEPTH, NT>(job, blockIdx.x, reinterpret_cast<unsigned *>(lds), (int)threadIdx.x); return; }
     ntt_half3_wg<PERM, true>((size_t)blockIdx.x - job.nblocks, lds, pc_all, out_, nplain, L, pm, tw_all, pack_all, modc, perm);
 }
-#endif
 // Forward NTT of general rows as TWO such workgroups per row (the key switch, Rescale, the bootstrap shares): 256 threads and 33 KiB each, three to a
 // CU, instead of one 512-thread workgroup holding a 132 KiB image.  Each half reads both halves of the input (the second read is an L2 hit: the two
 // workgroups of a row are numbered b and b + 8, same XCD) and pays the stage-1 product itself.
@@ -527,12 +525,13 @@ int ntt_set_attrs(sfg_ctx *ctx) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES);
-#ifdef SFG_AB
 #define SFG_MV_ATTR(P, D, T) if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ntt_half3_move<P, D, T>, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS_BYTES)
-    SFG_MV_ATTR(false, 1, false); SFG_MV_ATTR(false, 1, true); SFG_MV_ATTR(false, 2, false); SFG_MV_ATTR(false, 2, true); SFG_MV_ATTR(false, 3, false); SFG_MV_ATTR(false, 3, true);
-    SFG_MV_ATTR(true, 1, false); SFG_MV_ATTR(true, 1, true); SFG_MV_ATTR(true, 2, false); SFG_MV_ATTR(true, 2, true); SFG_MV_ATTR(true, 3, false); SFG_MV_ATTR(true, 3, true);
-#undef SFG_MV_ATTR
+    SFG_MV_ATTR(false, 1, true); SFG_MV_ATTR(true, 1, true);              // the product's riding transposition: one unit in flight, streaming loads and stores
+#ifdef SFG_AB
+    SFG_MV_ATTR(false, 1, false); SFG_MV_ATTR(false, 2, false); SFG_MV_ATTR(false, 2, true); SFG_MV_ATTR(false, 3, false); SFG_MV_ATTR(false, 3, true);
+    SFG_MV_ATTR(true, 1, false); SFG_MV_ATTR(true, 2, false); SFG_MV_ATTR(true, 2, true); SFG_MV_ATTR(true, 3, false); SFG_MV_ATTR(true, 3, true);
 #endif
+#undef SFG_MV_ATTR
     if (e != hipSuccess) SFG_FAIL(ctx, "cannot raise dynamic LDS limit for the NTT kernels");
     return 0;
 }
@@ -558,32 +557,32 @@ int launch_ntt_plain(sfg_ctx *ctx, const double *pc, u64 *out, size_t nplain, in
     return 0;
 }
 // half rows [nplain][L][N/2] from half-coefficient plaintexts
-#ifdef SFG_AB
 template <bool PERM>
 static void launch_half3_move(sfg_ctx *ctx, dim3 grid, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm, const MoveJob &j) {
 #define SFG_MV(D, T) hipLaunchKernelGGL((k_ntt_half3_move<PERM, D, T>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm, j)
-    if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); }
-    else if (j.depth == 2) { if (j.nt) SFG_MV(2, true); else SFG_MV(2, false); }
-    else { if (j.nt) SFG_MV(1, true); else SFG_MV(1, false); }
+#ifdef SFG_AB
+    if (j.depth == 3) { if (j.nt) SFG_MV(3, true); else SFG_MV(3, false); return; }
+    if (j.depth == 2) { if (j.nt) SFG_MV(2, true); else SFG_MV(2, false); return; }
+    if (!j.nt) { SFG_MV(1, false); return; }
+#endif
+    SFG_MV(1, true);
 #undef SFG_MV
 }
-#endif
 int launch_ntt_plain_half(sfg_ctx *ctx, const double *pc, u64 *out_half, size_t nplain, int L, PanelMap pm, const uint32_t *perm, const MoveJob *mv) {
     if (!nplain) return 0;
     const dim3 grid((unsigned)((nplain + 7) / 8 * 8 * L));
     const bool dig = pm.packed_mask >> 31;                 // digit planes for the int8 MAC (mac_i8.hip): its own instances, the default kernels are untouched
-#ifndef SFG_AB
-    if (mv && mv->count) SFG_FAIL(ctx, "plaintext NTT: mover workgroups exist in the A/B build only (make ab)");
-#else
     if (mv && mv->count) {
         if (!dig || mv->nblocks % 8 || !mv->nblocks) SFG_FAIL(ctx, "plaintext NTT: mover workgroups need the digit-plane form and a multiple of 8 of them");
+#ifndef SFG_AB
+        if (mv->depth != 1 || !mv->nt) SFG_FAIL(ctx, "plaintext NTT: the product build holds the mover with one unit in flight and streaming accesses only (other forms: make ab)");
+#endif
         const dim3 g2(grid.x + mv->nblocks);
         if (perm) launch_half3_move<true>(ctx, g2, pc, out_half, nplain, L, pm, perm, *mv);
         else launch_half3_move<false>(ctx, g2, pc, out_half, nplain, L, pm, (const uint32_t *)nullptr, *mv);
         SFG_HIP(ctx, hipGetLastError());
         return 0;
     }
-#endif
     if (perm && dig) hipLaunchKernelGGL((k_ntt_half3<true, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (perm) hipLaunchKernelGGL((k_ntt_half3<true, false>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, perm);
     else if (dig) hipLaunchKernelGGL((k_ntt_half3<false, true>), grid, dim3(256), H3_LDS_BYTES, ctx->stream, pc, out_half, nplain, L, pm, ctx->tw_fwd, ctx->pack_fwd, ctx->modc, (const uint32_t *)nullptr);

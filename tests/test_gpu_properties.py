@@ -243,15 +243,20 @@ def test_schedule_invariance_at_kp15_multi_pass_size(tmp_path):
     """Both products of a power iteration at kp = 15 on a 50 000 x 131 077 matrix (7 ragged block rows x 17 block
     columns: several block-row groups, two column passes at the default accumulator budget, the shared rotation cache
     engage).  The digest of every output word must not depend on the schedule: default (one queue) vs the two-queue overlap (SFG_MM_OVERLAP=1) + groups of 3 +
-    a 3-column accumulator budget + the register-staged MAC kernel for the third run."""
+    a 3-column accumulator budget + the register-staged MAC kernel for the third run, and - round 6 - with and without the riding transposition."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
     for name, envv in [("default", {}),
                        ("two_queues", {"SFG_MM_OVERLAP": "1", "SFG_MM_GROUP": "3", "SFG_MM_ACC_BUDGET_MB": "6000", "SFG_UPLOAD_BLOCKING": "1"}),
-                       ("full_ntt", {"SFG_NTT_HALF_IMPL": "full", "SFG_NTT_FWD_IMPL": "full", "SFG_MM_GROUP": "5", "SFG_MAC_IMPL": "dma"})]:
+                       ("full_ntt", {"SFG_NTT_HALF_IMPL": "full", "SFG_NTT_FWD_IMPL": "full", "SFG_MM_GROUP": "5", "SFG_MAC_IMPL": "dma"}),
+                       # the riding transposition (round 6, the default's schedule: a MAC launch's plaintext panel is transposed inside the NTT launches of the next
+                       # launch's encode): off, i.e. the pass before every MAC launch; and with other mover shapes over groups of 2 block rows (four groups: the
+                       # launches held over a group boundary take the pass)
+                       ("no_ride", {"SFG_PT_RIDE": "0"}),
+                       ("ride_deep", {"SFG_PT_RIDE": "64", "SFG_PT_RIDE_DEPTH": "3", "SFG_PT_RIDE_NT": "0", "SFG_MM_GROUP": "2"})]:
         f = str(tmp_path / (name + ".txt"))
         e = dict(os.environ); e.update(child_env(envv))
         r = subprocess.run([sys.executable, "-c", _CHILD_LARGE, f], cwd=root, env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append(open(f).read())
-    assert digests[0] == digests[1] == digests[2], digests
+    assert len(set(digests)) == 1, digests
