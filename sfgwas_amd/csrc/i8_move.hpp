@@ -13,6 +13,7 @@
 struct I8Args {
     const double *rotf; const u64 *pt; u64 *out;
     size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
+    size_t pt_l0_off;                      // words from a plaintext's start to the row of modulus l0; row of modulus l0 + m is pt_l_stride * m further (compact digit-plane panels: 5 or 6 planes apart)
     int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt, pt_digits;
     int kb;                                // 0: k is the row of the rot operand; else k' = g * kb + baby with baby < 91 real (streamed plaintext tiles: block rows start on a dword)
     int8_t *A, *B; u64 *T;
@@ -47,7 +48,7 @@ __device__ __forceinline__ I8MoveItem i8_move_item(const I8Args &a, unsigned ite
     const int kq = (int)(b % (unsigned)(a.nch * 4)); b /= (unsigned)(a.nch * 4);
     const int jt = (int)(b % (unsigned)a.njt), m = (int)(b / (unsigned)a.njt);
     I8MoveItem r;
-    r.src = reinterpret_cast<const unsigned char *>(a.pt + (size_t)(a.l0 + m) * a.pt_l_stride) + cb * I8_PD;
+    r.src = reinterpret_cast<const unsigned char *>(a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride) + cb * I8_PD;
     r.dst = a.B + (((((size_t)m * H + cb * I8_PD) * a.njt + jt) * a.nch + (kq >> 2)) * ND) * 1024 + (kq & 3) * 256;
     r.kq = kq; r.jt = jt;
     return r;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt(I8Args a) {
     const int kq = b % (a.nch * 4); b /= a.nch * 4;
     const int jt = b % a.njt, m = b / a.njt;
     const int c0 = cb * I8_PP, cc = tid & (I8_PP - 1), slot = tid >> 5;
-    const u64 *src = a.pt + (size_t)(a.l0 + m) * a.pt_l_stride + c0 + cc;
+    const u64 *src = a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride + c0 + cc;
 #pragma unroll 2
     for (int it = 0; it < 8; it++) {
         const int item = it * 8 + slot, j = item >> 2, k4 = item & 3, n = jt * 16 + j;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
     const int jt = b % a.njt, m = b / a.njt;
     const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
     const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + (size_t)(a.l0 + m) * a.pt_l_stride) + c0 + cq * 4;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride) + c0 + cq * 4;
     constexpr int NI = 8;                                   // items whose loads are issued together (4 dwords each; 2, 4, 8 measured: 8 = the plain loop's time, round 4)
     for (int d = 0; d < ND; d++) {
         for (int it0 = 0; it0 < 8; it0 += NI) {
@@ -549,7 +549,14 @@ int i8_ride_tiles(sfg_ctx *ctx, int K, int L, int8_t **Bs, int8_t **Bb) {
     if (l_big >= 0) SFG_TRY(sfg_scratch(ctx, "mi8.Bb", mac_i8_tile_bytes(K, 1, 6), (void **)Bb));
     return 0;
 }
-int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, int L, int launches, PtRide &ride) {
+// words from a plaintext's start to modulus l's row, and between rows of like moduli, in a panel of `compact` (5 / 6 digit planes of N/2 bytes per row) or full (N/2 words) rows
+void i8_panel_rows(const sfg_ctx *ctx, bool compact, int l, bool big, size_t &l_off, size_t &l_stride) {
+    const size_t H = SFG_N / 2;
+    if (!compact) { l_off = (size_t)l * H; l_stride = H; return; }
+    size_t planes = 0; for (int t = 0; t < l; t++) planes += ctx->q[t] < (1ULL << 36) ? 5 : 6;
+    l_off = planes * H / 8; l_stride = (size_t)(big ? 6 : 5) * H / 8;
+}
+int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, bool compact, int L, int launches, PtRide &ride) {
     const int H = SFG_N / 2;
     ride = PtRide();
     int l_small0, n_small, l_big;
@@ -559,7 +566,8 @@ int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_
     const int nch = (K + 63) / 64, njt = (Ncols + 15) / 16;
     auto fill = [&](I8Args &a, int l0, int nl, int8_t *B) {
         memset(&a, 0, sizeof a);
-        a.pt = panel; a.pt_k_stride = pt_k; a.pt_n_stride = pt_n; a.pt_l_stride = H; a.K = K; a.Ncols = Ncols; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = njt; a.pt_digits = 1; a.B = B;
+        a.pt = panel; a.pt_k_stride = pt_k; a.pt_n_stride = pt_n; a.K = K; a.Ncols = Ncols; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = njt; a.pt_digits = 1; a.B = B;
+        i8_panel_rows(ctx, compact, l0, l0 == l_big, a.pt_l0_off, a.pt_l_stride);
     };
     MoveJob &j = ride.job;
     fill(j.a5, l_small0, n_small, Bs); j.n5 = (unsigned)((size_t)n_small * njt * nch * 4 * (H / I8_PD));
@@ -608,7 +616,9 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (B_stream) K = K / SFG_D * st.kb;
     I8Args a; a.kb = B_stream ? st.kb : 0;
     a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
-    a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.pt_l_stride = H; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
+    a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
+    if (st.pt_compact && !st.pt_digits) SFG_FAIL(ctx, "sfg_mac (i8): internal: compact panel rows hold digit planes");
+    i8_panel_rows(ctx, st.pt_compact, l0, BIG, a.pt_l0_off, a.pt_l_stride);
     a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
     a.nch = (K + 63) / 64; a.njt = (Ncols + 15) / 16; a.pt_digits = st.pt_digits ? 1 : 0;
     const size_t nA = (size_t)nl * N * a.nch * 2 * ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
@@ -787,7 +797,7 @@ static int move_job_for(sfg_ctx *ctx, const u64 *panel, int G, int L, int8_t *Bs
     const int K = G * d, nch = (K + 63) / 64;
     auto fill = [&](I8Args &a, int l0, int nl, int8_t *B) {
         memset(&a, 0, sizeof a);
-        a.pt = panel; a.pt_k_stride = plw; a.pt_n_stride = (size_t)G * d * plw; a.pt_l_stride = H; a.K = K; a.Ncols = d; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = 6; a.pt_digits = 1; a.B = B;
+        a.pt = panel; a.pt_k_stride = plw; a.pt_n_stride = (size_t)G * d * plw; a.pt_l_stride = H; a.pt_l0_off = (size_t)l0 * H; a.K = K; a.Ncols = d; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = 6; a.pt_digits = 1; a.B = B;
     };
     fill(pj.a5, l_small0, n_small, Bs); fill(pj.a6, l_big, 1, Bb);
     pj.n5 = (unsigned)(n_small * 6 * nch * 4 * (H / I8_PD)); pj.n6 = (unsigned)(6 * nch * 4 * (H / I8_PD));

@@ -427,7 +427,13 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     const bool enc2 = !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G2 - 1) / G2) * (j1 - j0) >= 2;
                     const bool streamable2 = ctx->cfg.mac_i8 && ctx->cfg.mac_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc2;      // then the panel holds 4 block rows
                     const bool ride2 = ctx->cfg.mac_i8 && ctx->cfg.pt_ride > 0 && !enc2 && !streamable2 && j1 - j0 >= 2;      // (the riding transposition keeps two panels too)
-                    size_t need = (size_t)(streamable2 ? std::min(G2, 4) : G2) * nplain * L * ((size_t)N / 2) * 8 * (enc2 || ride2 ? 2 : 1);
+                    size_t ptb = (size_t)L * ((size_t)N / 2) * 8;                    // bytes per plaintext: compact rows where every modulus is on the int8 MAC (as decided below)
+                    if (ctx->cfg.pt_compact && ctx->cfg.mac_i8 && !streamable2 && mac_dma_packed_mask(ctx, L)) {
+                        bool big_ok = true; size_t planes = 0;
+                        for (int l = 0; l < L; l++) { const bool sm = ctx->q[l] < (1ULL << 36); planes += sm ? 5 : 6; if (!sm && !ctx->cfg.mac_i8_big) big_ok = false; }
+                        if (big_ok && ((b1 - b0 + G2 - 1) / G2 <= 2 || j1 - j0 >= 4)) ptb = planes * ((size_t)N / 2);
+                    }
+                    size_t need = (size_t)(streamable2 ? std::min(G2, 4) : G2) * nplain * ptb * (enc2 || ride2 ? 2 : 1);
                     if (!rotf_pre) need += ((size_t)G2 * d + 3) * s * 2 * (size_t)npl * N * 8 * (pipe2 ? 2 : 1);
                     if (ctx->cfg.mac_i8) {                         // + the two operand streams and the tile-ordered results of the int8 MAC (small moduli)
                         int nsm = 0; for (int l = 0; l < L; l++) nsm += ctx->q[l] < (1ULL << 36);
@@ -464,7 +470,13 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // where every modulus multiplies on the int8 matrix core from streamed tiles, the panel serves only the rare launches that cannot stream: Gp block rows of it
     const bool streamable = use_i8 && use_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc_ov && !pre8;
     const int Gp = streamable ? std::min(G, 4) : G;
-    const size_t panel_words = (size_t)Gp * nplain * L * prow;
+    // Compact panel rows (round 6): where every modulus of the product multiplies on the int8 matrix core the panel holds nothing but digit planes - five (six) planes of
+    // N/2 bytes per modulus, back to back: 208 KiB per plaintext at L = 5 instead of five rows of N/2 words (320 KiB).  Room for the second panel of the riding transposition.
+    bool all_small = true; for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) all_small = false;
+    const bool compact = ctx->cfg.pt_compact && dma && use_i8 && (use_i8_big || all_small) && !streamable;
+    size_t plw = (size_t)L * prow;                           // words per plaintext
+    if (compact) { size_t planes = 0; for (int l = 0; l < L; l++) planes += ctx->q[l] < (1ULL << 36) ? 5 : 6; plw = planes * ((size_t)N / 2) / 8; }
+    const size_t panel_words = (size_t)Gp * nplain * plw;
     // The riding transposition (kernels.hpp PtRide): the panel of MAC launch k - 1 is transposed by mover workgroups inside the plaintext-NTT launches of launch k's
     // encode, which writes the OTHER panel; MAC launch k - 1 follows that encode on the same queue and finds its tiles in place.  Taken where every modulus multiplies
     // on the int8 matrix core from digit-plane panels; the first launch after a change of block-row group (its rot operand's buffer is about to be rebuilt) and the
@@ -483,7 +495,6 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         if (!rot_ext) SFG_TRY(sfg_scratch(ctx, "mm.rotf", grp_slices * s * 2 * rowf * 8 * (pipelined ? 2 : 1), (void **)&rotf));
         if (!rot_ext && packed_mask) SFG_TRY(sfg_scratch(ctx, "mm.rotsum", (size_t)2 * s * 2 * rowf * 8, (void **)&rotsum));     // one per ring half
     }
-    const size_t plw = (size_t)L * prow;                     // words per plaintext
     int rc = 0;
     bool first_group = true;
     // rotation cache of one group into half `buf` of mm.rotf (on whatever stream is current)
@@ -517,6 +528,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         if (pre8) { st.A_small = pre8->As[m.gi]; st.A_big = pre8->Ab[m.gi]; }
         st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
         st.pt_k = plw; st.pt_n = (size_t)m.gsn * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
+        st.pt_compact = compact;
         st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
         int r2;
         if (dma) r2 = launch_mac_dma(ctx, pre8 ? nullptr : m.rotf_grp + (size_t)m.sub0 * d * s * 2 * rowf, (size_t)s * 2, m.ptp, m.accj, m.gsn * d, 2 * s, d, L, m.acc_flag, st, m.rotsum_grp);
@@ -599,7 +611,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                   if (nr + nc > SFG_SLOTS) launches += encode_rows_launches(ctx, SFG_SLOTS);
                   else launches += encode_rows_launches(ctx, nr) + (nc > 1 ? encode_rows_launches(ctx, nc - 1) : 0);
               }
-              rc = i8_ride_prepare(ctx, held.ptp, held.gsn * d, d, plw, (size_t)held.gsn * d * plw, L, launches, ride); if (rc) break;
+              rc = i8_ride_prepare(ctx, held.ptp, held.gsn * d, d, plw, (size_t)held.gsn * d * plw, compact, L, launches, ride); if (rc) break;
               if (ride.on && (ride.job.a5.B != rideBs || (ride.job.n6 && ride.job.a6.B != rideBb))) { rc = 1; ctx->err = "matmul: internal: the riding transposition's tile buffers moved"; break; }
           }
           if (held.on && !ride.on) { rc = run_mac(held, rideBs ? 2 : 0); held.on = false; if (rc) break; }       // nothing to ride in: the held launch goes now, by the pass
@@ -650,7 +662,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
                         if (stream) sp.g = g;
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, gs, g - sub0, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u),
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, gs, g - sub0, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u) | (compact ? PT_COMPACT : 0u),
                                                          pcc.mode ? &pcc : nullptr, stream ? &sp : nullptr, ride.on ? &ride : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }

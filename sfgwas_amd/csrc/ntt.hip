@@ -410,6 +410,12 @@ __device__ __forceinline__ void ntt_half3_wg(size_t vb, double *lds, const doubl
     const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
     const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
     u64 *out = out_ + (dst * L + m) * (size_t)n;
+    if constexpr (DIG) if (pm.packed_mask & PT_COMPACT) {      // compact panel rows: the moduli's 5 / 6 digit planes of a plaintext back to back (bit l of the mask: modulus l has five)
+        const unsigned lm = (1u << L) - 1u, small = pm.packed_mask & lm;
+        const int ns_all = __popc(small), ns_below = __popc(small & ((1u << m) - 1u));
+        const size_t row_bytes = ((size_t)ns_all * 5 + (size_t)(L - ns_all) * 6) * n, off = ((size_t)ns_below * 5 + (size_t)(m - ns_below) * 6) * n;
+        out = reinterpret_cast<u64 *>(reinterpret_cast<uint8_t *>(out_) + dst * row_bytes + off);
+    }
     // (the format test is hoisted: inside the store loop it costs a branch per word)
 #ifdef SFG_NTT_DIAG          // timing diagnostics only: 1 = no panel stores (kept alive by an impossible value), 2 = stores without canon / packing
     if (SFG_NTT_DIAG == 1) { ntt_half3_body(0, first, [&](int j, double x) { if (x == 0.123) out[j] = pack_limbs_f64(canon_le(x, q, qinv)); }, lds, tw, pack, q, qinv, tid); return; }

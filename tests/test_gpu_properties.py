@@ -252,7 +252,7 @@ def test_schedule_invariance_at_kp15_multi_pass_size(tmp_path):
                        # the riding transposition (round 6, the default's schedule: a MAC launch's plaintext panel is transposed inside the NTT launches of the next
                        # launch's encode): off, i.e. the pass before every MAC launch; and with other mover shapes over groups of 2 block rows (four groups: the
                        # launches held over a group boundary take the pass)
-                       ("no_ride", {"SFG_PT_RIDE": "0"}),
+                       ("no_ride", {"SFG_PT_RIDE": "0", "SFG_PT_COMPACT": "0"}),        # (and the panel's rows as full words, round 5's layout)
                        ("ride_deep", {"SFG_PT_RIDE": "64", "SFG_PT_RIDE_DEPTH": "3", "SFG_PT_RIDE_NT": "0", "SFG_MM_GROUP": "2"})]:
         f = str(tmp_path / (name + ".txt"))
         e = dict(os.environ); e.update(child_env(envv))
