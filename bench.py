@@ -250,7 +250,7 @@ def roofline_blocks(phase_tot, args, dims, world, dt, value):
     n_ntt_all = phase_tot.get("ntt_plain_all", [0.0, 0, 0.0])[1]
     ntt_avg_ms = ms_ntt / max(n_ntt, 1)
     ntt_total_ms = ntt_avg_ms * n_ntt_all
-    bytes_per_plain = (N // 2) * (8 + 5 * (L - 1) + 8)                   # coefficient row in, five digit planes per small modulus + one word row out
+    bytes_per_plain = (N // 2) * (8 + 5 * (L - 1) + 6)                   # coefficient row in; five digit planes per 35-bit modulus and six for the 46-bit one out (encode.hip credits the same)
     plains_per_launch = (by_ntt / max(n_ntt, 1)) / bytes_per_plain
     NTT_FP64_INSTR = 2016                                               # fp64 vector instructions per thread of k_ntt_half3 (static count of the gfx950 ISA)
     ntt_instr_s = plains_per_launch * L * 256 * NTT_FP64_INSTR / (ntt_avg_ms * 1e-3) if n_ntt else 0.0
@@ -324,7 +324,8 @@ def roofline_blocks(phase_tot, args, dims, world, dt, value):
                 best = max(ks, key=lambda k: pm[k]["launches"])
                 traffic = pm[best]["hbm_bytes_per_launch"]
                 traffic_src = (f"profiles/{name} (static: separate rocprofv3 --pmc passes at config {pm.get('_config')}; "
-                               "this kernel's launch shape - 2048 plaintexts x 5 moduli - is the same at every config)")
+                               "the NTT's launch shape - 2048 plaintexts x 5 moduli - is the same at every config; the riding movers' share per launch is the "
+                               "MAC group's, i.e. that of the config the passes ran at)")
                 break
     except Exception:
         pass

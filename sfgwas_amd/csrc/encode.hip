@@ -636,7 +636,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
         else if (half_rows) { PanelMap pm{0, 0, 0}; SFG_TRY(launch_ntt_plain_half(ctx, pc, pt + (size_t)s0 * L * (SFG_N / 2), nb, L, pm)); }
         else SFG_TRY(launch_ntt_plain(ctx, pc, pt + (size_t)s0 * L * SFG_N, nb, L));
         if (sampled) {      // algorithmic bytes: the coefficient row in, L output rows of N/2 words (or five digit planes of N/2 bytes for the int8 MAC's moduli)
-            double wr = 0; for (int l = 0; l < L; l++) wr += ((packed_mask >> 31) && ((packed_mask >> l) & 1u)) ? 5.0 : 8.0;
+            double wr = 0; for (int l = 0; l < L; l++) wr += ((packed_mask >> 31) && ((packed_mask >> l) & 1u)) ? 5.0 : ((packed_mask >> 30) & 1u) ? 6.0 : 8.0;     // (six planes for the 46-bit row of an all-int8 product)
             tn.stop(1, (double)nb * (SFG_N / 2) * (8.0 + wr));
         }
     }

@@ -22,7 +22,6 @@
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int I8_ND = 5;                   // digits per operand word of a 35-bit modulus (the 46-bit one: 6)
-constexpr int I8_PC = 8;                   // coefficients per packing workgroup (64-byte source runs)
 
 // ND signed base-256 digits of an integer |v| < 2^(8 ND - 1) (two's complement arithmetic shift)
 template <int ND> __device__ __forceinline__ void i8_digits(long long v, int8_t d[ND]) {
@@ -52,34 +51,68 @@ template <int NS> __device__ __forceinline__ double i8_horner(const v4i (&a)[NS]
     return r < 0 ? r + q : r;
 }
 
-// ---- rot planes -> A.  workgroup = (modulus m, chunk ch, 8 coefficients): 64 k x 32 rows x 8 coefficients through an 80 (96) KiB digit image.
+// ---- rot planes -> A.  workgroup = (modulus m, chunk ch, half chunk kh, 16 coefficients, row tile rt): 32 k x 16 rows x 16 coefficients through a 40 (48) KiB digit
+// image, four (three) workgroups per CU.  Round 6: 128-byte source runs (16 coefficients; until then 8 coefficients x 64 k x both row tiles through 80 KiB - two
+// workgroups per CU whose load and store phases hardly overlapped, 64-byte runs: 2.1 TB/s) with all 32 loads of a thread in flight, and a thread takes FOUR consecutive
+// k of its (coefficient, row) so that a digit of the four is one dword of the tile: five dword stores per four elements instead of twenty byte stores, lanes = 16
+// coefficients x the 4 dwords of a 16-byte lane row on 64 distinct banks (a coefficient's lane rows are XORed with its number: no padding).
 // ND = 6: the 46-bit modulus, whose fp64 plane holds the signed split {lo 23 bits, hi} per coefficient (k_rot_to_f64): v = hi 2^23 + lo
+constexpr int I8_PC = 16;                  // coefficients per rot packing workgroup
+template <int ND> constexpr int i8_rot_img_stride() { return ND * 512; }              // bytes per coefficient in the image: ND digits x 32 lane rows x 16 bytes
 template <int ND>
 __global__ void __launch_bounds__(256) k_i8_pack_rot(I8Args a) {
-    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 8][rt 2][a ND][1 KiB]
+    extern __shared__ __attribute__((aligned(16))) int8_t img[];         // [cc 16][a ND][lane row (32) ^ cc][16 bytes]
+    constexpr int CS = i8_rot_img_stride<ND>();
     const int N = SFG_N, tid = threadIdx.x;
-    const int xb = blockIdx.x % (N / I8_PC), ch = (blockIdx.x / (N / I8_PC)) % a.nch, m = blockIdx.x / (N / I8_PC) / a.nch;
-    const int x0 = xb * I8_PC, cc = tid & (I8_PC - 1);
+    int b = blockIdx.x;
+    const int rt = b & 1; b >>= 1;
+    const int khalf = b & 1; b >>= 1;
+    const int xb = b % (N / I8_PC), ch = (b / (N / I8_PC)) % a.nch, m = b / (N / I8_PC) / a.nch;
+    const int x0 = xb * I8_PC, cc = tid & (I8_PC - 1), kkq = (tid >> 4) & 3, kh2 = (tid >> 6) & 1, rh = tid >> 7;
     const double *src = ND == 6 ? a.rotf + (size_t)a.plane0 * N + 2 * (x0 + cc) : a.rotf + (size_t)(a.plane0 + m) * N + x0 + cc;
-    for (int p = tid / I8_PC; p < 64 * 32; p += 256 / I8_PC) {
-        const int kk = p >> 5, r = p & 31, k = ch * 64 + kk;
-        long long v = 0;
-        int ks = k; bool kv = k < a.K;
-        if (a.kb) { const int gg = k / a.kb, baby = k - gg * a.kb; kv = kv && baby < SFG_D; ks = gg * SFG_D + baby; }
-        if (kv && a.r0 + r < a.R) {
-            const double *e = src + (size_t)ks * a.rotf_k_stride + (size_t)(a.r0 + r) * a.rotf_r_stride;
-            v = ND == 6 ? (long long)e[1] * 8388608LL + (long long)e[0] : (long long)e[0];
-        }
-        int8_t d[ND]; i8_digits<ND>(v, d);
-        int8_t *o = img + cc * (2 * ND * 1024) + (r >> 4) * (ND * 1024) + i8_tile_off(r & 15, kk);
+    // the four k of this thread: ch * 64 + 32 khalf + 16 kh2 + 4 kkq + j (the same for every row)
+    size_t koff[4]; bool kv[4];
 #pragma unroll
-        for (int i = 0; i < ND; i++) o[i * 1024] = d[i];
+    for (int j = 0; j < 4; j++) {
+        const int k = ch * 64 + 32 * khalf + 16 * kh2 + 4 * kkq + j;
+        int ks = k; kv[j] = k < a.K;
+        if (a.kb) { const int gg = k / a.kb, baby = k - gg * a.kb; kv[j] = kv[j] && baby < SFG_D; ks = gg * SFG_D + baby; }
+        koff[j] = kv[j] ? (size_t)ks * a.rotf_k_stride : 0;
+    }
+    double lo[8][4], hi[ND == 6 ? 8 : 1][4];
+#pragma unroll
+    for (int ri = 0; ri < 8; ri++) {
+        const int r = a.r0 + rt * 16 + rh * 8 + ri;
+        const double *e = src + (size_t)(r < a.R ? r : a.r0) * a.rotf_r_stride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { lo[ri][j] = e[koff[j]]; if (ND == 6) hi[ri][j] = e[koff[j] + 1]; }
+    }
+#pragma unroll
+    for (int ri = 0; ri < 8; ri++) {
+        const int r16 = rh * 8 + ri;
+        const bool rv = a.r0 + rt * 16 + r16 < a.R;
+        unsigned dw[ND];
+#pragma unroll
+        for (int i = 0; i < ND; i++) dw[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            long long v = ND == 6 ? (long long)hi[ND == 6 ? ri : 0][j] * 8388608LL + (long long)lo[ri][j] : (long long)lo[ri][j];
+            if (!(rv && kv[j])) v = 0;
+            int8_t d[ND]; i8_digits<ND>(v, d);
+#pragma unroll
+            for (int i = 0; i < ND; i++) dw[i] |= (unsigned)(uint8_t)d[i] << (8 * j);
+        }
+        // lane row of (row r16, kk = 16 kh2 + 4 kkq + j) inside this half chunk: r16 + 16 kh2; its 16 bytes hold kk & 15 = 4 kkq + j
+        unsigned *o = reinterpret_cast<unsigned *>(img + cc * CS + (((r16 + 16 * kh2) ^ cc) << 4) + 4 * kkq);
+#pragma unroll
+        for (int i = 0; i < ND; i++) o[i * 128] = dw[i];
     }
     __syncthreads();
-    for (int c2 = 0; c2 < I8_PC; c2++) {
-        uint4 *dst = reinterpret_cast<uint4 *>(a.A + ((((size_t)m * N + x0 + c2) * a.nch + ch) * 2 * ND) * 1024);
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(img + c2 * (2 * ND * 1024));
-        for (int i = tid; i < 2 * ND * 64; i += 256) dst[i] = s4[i];
+    // per coefficient and digit the half chunk is 512 contiguous bytes of the 1 KiB tile (lanes 32 khalf .. + 31)
+    for (int idx = tid; idx < I8_PC * ND * 32; idx += 256) {
+        const int c2 = idx / (ND * 32), rem = idx - c2 * (ND * 32), dg = rem >> 5, lr = rem & 31;
+        const uint4 w = *reinterpret_cast<const uint4 *>(img + c2 * CS + dg * 512 + ((lr ^ c2) << 4));
+        *reinterpret_cast<uint4 *>(a.A + ((((((size_t)m * N + x0 + c2) * a.nch + ch) * 2 + rt) * ND + dg) * 1024) + khalf * 512 + lr * 16) = w;
     }
 }
 // ---- panel words -> B.  workgroup = (modulus m, column tile jt, 16 k, 32 coefficients): 256 (k, column) rows of 256 contiguous bytes in, 160 pieces of 256
@@ -470,8 +503,8 @@ __global__ void __launch_bounds__(256) k_i8_untile(I8Args a, const ModConst *mod
 }
 
 int mac_i8_set_attrs(sfg_ctx *ctx) {       // per device, at context creation (ctx.hip)
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 5 * 1024));
-    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * 2 * 6 * 1024));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<5>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * i8_rot_img_stride<5>()));
+    SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_i8_pack_rot<6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_PC * i8_rot_img_stride<6>()));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 10 * 6 * 1024));
     SFG_HIP(ctx, hipFuncSetAttribute((const void *)k_mac_i8_ring<5, 3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * 5 * 1024));
@@ -660,7 +693,7 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (!A_pre && !repack && ctx->pool[nm].second < nA) SFG_FAIL(ctx, "sfg_mac (i8): internal: kept rot copy smaller than its operand");
     const double tile = 1024.0;
     if (repack) { PhaseTimer t(ctx, "mac_i8_pack_rot");
-      hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * ND * 1024, ctx->stream, a);
+      hipLaunchKernelGGL(k_i8_pack_rot<ND>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC) * 4)), dim3(256), I8_PC * i8_rot_img_stride<ND>(), ctx->stream, a);
       SFG_HIP(ctx, hipGetLastError()); t.stop(1, (double)nl * N * ((double)K_rot * std::min(32, R - r0) * (BIG ? 16.0 : 8.0) + (double)a.nch * 2 * ND * tile)); }
     if (!B_pre) { PhaseTimer t(ctx, "mac_i8_pack_pt");
       const unsigned items = (unsigned)((size_t)nl * a.njt * a.nch * 4 * (H / I8_PD));
@@ -708,8 +741,8 @@ int launch_i8_pack_rot_to(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride
     a.nch = (K + 63) / 64; a.kb = 0; a.A = A_out;
     const int N = SFG_N;
     PhaseTimer t(ctx, "mac_i8_pack_rot");
-    if (big) hipLaunchKernelGGL(k_i8_pack_rot<6>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * 6 * 1024, ctx->stream, a);
-    else hipLaunchKernelGGL(k_i8_pack_rot<5>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC))), dim3(256), I8_PC * 2 * 5 * 1024, ctx->stream, a);
+    if (big) hipLaunchKernelGGL(k_i8_pack_rot<6>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC) * 4)), dim3(256), I8_PC * i8_rot_img_stride<6>(), ctx->stream, a);
+    else hipLaunchKernelGGL(k_i8_pack_rot<5>, dim3((unsigned)((size_t)nl * a.nch * (N / I8_PC) * 4)), dim3(256), I8_PC * i8_rot_img_stride<5>(), ctx->stream, a);
     SFG_HIP(ctx, hipGetLastError());
     t.stop(1);
     return 0;
