@@ -84,6 +84,7 @@ struct SfgConfig {
     int i8_mover = 0;              // SFG_I8_MOVER=n (A/B build)  n workgroups of the plaintext transposition in its mover form (i8_move.hpp) instead of the pass k_i8_pack_pt_digits: 1280 is 3 % faster alone, nothing in a product (profiles/r06_mover_ubench.txt)
     int i8_mover_depth = 3;        // SFG_I8_MOVER_DEPTH     units (32 KiB) a mover workgroup keeps in flight + 1
     bool pt_compact = true;        // panel rows of an all-int8 product hold only their digit planes (208 KiB per plaintext instead of 320 KiB at L = 5).  SFG_PT_COMPACT=0 in the A/B build
+    bool pt_kmajor = true;         // the compact panel K-major: [column][plane][128-byte coefficient block][k][128 B] (2 KiB source runs for the transposition).  SFG_PT_KMAJOR=0 in the A/B build
     int pt_ride = 192;             // mover workgroups of the riding transposition per plaintext-NTT launch (kernels.hpp PtRide; 0 = the transposition pass before every MAC launch).  SFG_PT_RIDE in the A/B build
     int i8_mover_depth_ride = 1, i8_mover_nt_ride = 1;     // (A/B build: SFG_PT_RIDE_DEPTH, SFG_PT_RIDE_NT)
     int enc_batch = 2048;          // SFG_ENC_BATCH          diagonals per FFT / plaintext-NTT launch pair: 128 MB of coefficient rows stay cache resident between the two now that the NTT's digit planes leave by streaming stores (round 5: 2048 -3 % of a 50k x 500k step against 1024, 3072 the same, 4096 worse; with plain stores 1024 was best)

@@ -89,6 +89,7 @@ static void read_config(SfgConfig &c, const sfg_config *pc) {
     if (const char *e = env("SFG_I8_MOVER")) { c.i8_mover = atoi(e); if (c.i8_mover < 0) c.i8_mover = 0; c.i8_mover = c.i8_mover / 8 * 8; }
     if (const char *e = env("SFG_PT_RIDE")) { c.pt_ride = atoi(e); if (c.pt_ride < 0) c.pt_ride = 0; c.pt_ride = c.pt_ride / 8 * 8; }
     if (const char *e = env("SFG_PT_COMPACT")) c.pt_compact = atoi(e) != 0;
+    if (const char *e = env("SFG_PT_KMAJOR")) c.pt_kmajor = atoi(e) != 0;
     if (const char *e = env("SFG_PT_RIDE_DEPTH")) { c.i8_mover_depth_ride = atoi(e); if (c.i8_mover_depth_ride < 1 || c.i8_mover_depth_ride > 3) c.i8_mover_depth_ride = 1; }
     if (const char *e = env("SFG_PT_RIDE_NT")) c.i8_mover_nt_ride = atoi(e) != 0;
     if (const char *e = env("SFG_I8_MOVER_DEPTH")) { c.i8_mover_depth = atoi(e); if (c.i8_mover_depth < 1 || c.i8_mover_depth > 3) c.i8_mover_depth = 3; }

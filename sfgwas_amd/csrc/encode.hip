@@ -630,6 +630,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
                 if (sampled) { PhaseStat &ps = ctx->phases["pt_ride"]; ps.launches += 1; ps.bytes += moved; }       // (the timed launches' share: same sample as ntt_plain_ride)
             }
             PanelMap pm{G, g, shift0 + s0, packed_mask};
+            if (packed_mask & PT_KMAJOR) pm.K = G * SFG_D;            // K-major panel: a column holds the G block rows' 91 baby steps each
             if (cmode == 3) SFG_TRY(launch_ntt_plain_half(ctx, pcache->slot, pt, nb, L, pm, pcache->perm, mv));
             else SFG_TRY(launch_ntt_plain_half(ctx, pc, pt, nb, L, pm, nullptr, mv));
         }

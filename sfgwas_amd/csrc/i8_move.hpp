@@ -13,10 +13,12 @@
 struct I8Args {
     const double *rotf; const u64 *pt; u64 *out;
     size_t rotf_k_stride, rotf_r_stride, pt_k_stride, pt_n_stride, pt_l_stride, out_n_stride, out_r_stride;
+    size_t pt_d_stride, pt_cb_stride;      // bytes between the digit planes of a modulus row / between its 128-byte coefficient blocks (N/2 and 128 unless the panel is K-major)
     size_t pt_l0_off;                      // words from a plaintext's start to the row of modulus l0; row of modulus l0 + m is pt_l_stride * m further (compact digit-plane panels: 5 or 6 planes apart)
     int K, R, Ncols, accumulate, r0, l0, nl, plane0, nch, njt, pt_digits;
     int kb;                                // 0: k is the row of the rot operand; else k' = g * kb + baby with baby < 91 real (streamed plaintext tiles: block rows start on a dword)
     int8_t *A, *B; u64 *T;
+    int fake;                              // A/B build, microbenchmark only (results INVALID): bit 0 = the mover reads 32 KiB contiguous per unit, bit 1 = writes 32 KiB contiguous, bit 2 = sleeps instead of moving
 };
 constexpr int I8_PD = 128;                 // coefficients per transposition item (128-byte source runs)
 
@@ -48,7 +50,7 @@ __device__ __forceinline__ I8MoveItem i8_move_item(const I8Args &a, unsigned ite
     const int kq = (int)(b % (unsigned)(a.nch * 4)); b /= (unsigned)(a.nch * 4);
     const int jt = (int)(b % (unsigned)a.njt), m = (int)(b / (unsigned)a.njt);
     I8MoveItem r;
-    r.src = reinterpret_cast<const unsigned char *>(a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride) + cb * I8_PD;
+    r.src = reinterpret_cast<const unsigned char *>(a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride) + (size_t)cb * a.pt_cb_stride;
     r.dst = a.B + (((((size_t)m * H + cb * I8_PD) * a.njt + jt) * a.nch + (kq >> 2)) * ND) * 1024 + (kq & 3) * 256;
     r.kq = kq; r.jt = jt;
     return r;
@@ -70,7 +72,7 @@ __device__ __forceinline__ I8MoveLane i8_move_lane(const I8Args &a, int tid) {
 template <int ND, bool NT>
 __device__ __forceinline__ void i8_move_issue(const I8Args &a, const I8MoveLane &l, unsigned item, int d, v4u (&w)[8]) {
     const I8MoveItem t = i8_move_item<ND>(a, item);
-    const unsigned char *src = t.src + (size_t)d * (SFG_N / 2);
+    const unsigned char *src = t.src + (size_t)d * a.pt_d_stride;
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int n0 = t.jt * 16 + it * 8 + l.wave * 2;                    // scalar: the even column of this wave's pair
@@ -83,6 +85,14 @@ __device__ __forceinline__ void i8_move_issue(const I8Args &a, const I8MoveLane 
             const unsigned vo = ok ? l.voff - jo - (k0 + 4 * l.k4 < a.K ? 0u : l.koff) : (unsigned)l.cq8 * 16u;
             const size_t so = ok ? ((size_t)n0 * a.pt_n_stride + (size_t)k0 * a.pt_k_stride) * 8 : ((size_t)(t.jt * 16) * a.pt_n_stride + (size_t)(t.kq * 16) * a.pt_k_stride) * 8;
             const v4u *p = reinterpret_cast<const v4u *>(src + so + vo);
+#ifdef SFG_AB
+            if (a.fake & 1) p = reinterpret_cast<const v4u *>(reinterpret_cast<const unsigned char *>(a.pt) + ((size_t)item * ND + d) * 32768 + (size_t)((it * 4 + x) * 256 + l.wave * 64 + (int)(threadIdx.x & 63)) * 16);
+            if (a.fake & 8) {      // the read pattern of a panel laid out [column][plane][128-byte coefficient block][k][128 B]: the 16 k of a column are one 2 KiB run
+                const int m = (int)(item / ((unsigned)(a.nch * 4) * (unsigned)(SFG_N / 2 / I8_PD)) / (unsigned)a.njt), cb = (int)(item % (SFG_N / 2 / I8_PD));
+                const size_t pl = (ND == 6 ? 0 : 6 + m * 5) + d, n = (size_t)t.jt * 16 + it * 8 + l.wave * 2 + l.jb, k = (size_t)t.kq * 16 + 4 * l.k4 + x;
+                p = reinterpret_cast<const v4u *>(reinterpret_cast<const unsigned char *>(a.pt) + (((n * 26 + pl) * 64 + cb) * ((size_t)a.nch * 64) + k) * 128 + l.cq8 * 16);
+            }
+#endif
             w[it * 4 + x] = NT ? __builtin_nontemporal_load(p) : *p;
         }
     }
@@ -121,6 +131,9 @@ __device__ __forceinline__ void i8_move_finish(const I8Args &a, const I8MoveLane
     for (int i = 0; i < 8; i++) {
         const v4u o = *reinterpret_cast<const v4u *>(img + (p0 + 16 * i) * 64 + ((l16 ^ i) << 2));      // ((pc >> 4) & 7 = i: p0 < 16)
         v4u *p = reinterpret_cast<v4u *>(dst + (size_t)(16 * i) * cstride + so);
+#ifdef SFG_AB
+        if (a.fake & 2) p = reinterpret_cast<v4u *>(a.B + ((size_t)item * ND + d) * 32768 + (size_t)(i * 256 + tid) * 16);
+#endif
         if (NT) __builtin_nontemporal_store(o, p); else *p = o;
     }
     __syncthreads();
@@ -130,6 +143,9 @@ template <int ND, int DEPTH, bool NT>
 __device__ __forceinline__ void i8_move_run(const I8Args &a, unsigned item0, unsigned item_end, unsigned stride, unsigned *img, int tid) {
     if (item0 >= item_end) return;
     const unsigned nu = ((item_end - item0 + stride - 1) / stride) * ND;
+#ifdef SFG_AB
+    if (a.fake & 4) { for (unsigned u = 0; u < nu; u++) for (int i = 0; i < (a.fake >> 8); i++) __builtin_amdgcn_s_sleep(127); return; }       // hold the slot, move nothing
+#endif
     v4u wa[8], wb[8], wc[8];
     const I8MoveLane l = i8_move_lane(a, tid);
     auto issue = [&](unsigned u, v4u (&w)[8]) { i8_move_issue<ND, NT>(a, l, item0 + (u / ND) * stride, (int)(u % ND), w); };

@@ -11,8 +11,11 @@ struct RowMap { int rpg; size_t gstride_in, gstride_out; };
 // where the plaintext of diagonal `shift` (= shift0 + index in the batch) of block row g lands inside a panel that holds G
 // block rows: slot ((shift / 91) * G + g) * 91 + shift % 91, i.e. [giant][g][baby] so that k = g*91 + baby is contiguous.
 // G == 0: dense (slot = index in the batch)
-struct PanelMap { int G, g, shift0; unsigned packed_mask = 0; };   // packed_mask bit l: rows of modulus l are written as packed-limb words (mac_dma.hip); bit 31: as digit planes instead (mac_i8.hip); bit 30: the 46-bit modulus too (six planes); bit 29: compact rows (every modulus in planes, a plaintext's planes back to back)
+struct PanelMap { int G, g, shift0; unsigned packed_mask = 0; int K = 0; };   // packed_mask bit l: rows of modulus l are written as packed-limb words (mac_dma.hip); bit 31: as digit planes instead (mac_i8.hip); bit 30: the 46-bit modulus too (six planes); bit 29: compact rows (every modulus in planes, a plaintext's planes back to back)
 constexpr unsigned PT_COMPACT = 1u << 29;
+// bit 28 (with bit 29): K-MAJOR panel - [column][plane][128-byte coefficient block][k < K][128 B]: the k rows of a column's coefficient block are adjacent, so a transposition
+// unit reads 16 runs of 2 KiB instead of 256 runs of 128 B (PanelMap::K = rows per column; G == 0: plaintext p of the launch is column p / K, row p % K)
+constexpr unsigned PT_KMAJOR = 1u << 28;
 
 // ntt.hip
 int launch_ntt_fwd(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, const ModPattern &pat);
@@ -30,7 +33,7 @@ int launch_ntt_inv_map(sfg_ctx *ctx, const u64 *in, u64 *out, size_t nrows, cons
 // mac.hip
 struct MacStrides { size_t rot_k, rot_r, pt_k, pt_n, out_n, out_r; bool pt_half = false; bool pt_packed = false; bool pt_digits = false; bool i8 = false; bool i8_big = false; bool pt_digits_big = false;
                     const int8_t *B_small = nullptr, *B_big = nullptr; int kb = 0;
-                    bool pt_compact = false;  // digit-plane panel rows packed: a plaintext is its moduli's 5 / 6 planes of N/2 bytes back to back (208 KiB at PN14QP438, L = 5) instead of L rows of N/2 words (320 KiB); PanelMap bit 29
+                    int pt_layout = 0, pt_L = 0;  // 1: digit-plane panel rows packed - a plaintext is its pt_L moduli's 5 / 6 planes of N/2 bytes back to back (208 KiB at PN14QP438, L = 5) instead of L rows of N/2 words (320 KiB), PanelMap bit 29; 2: K-major, bits 29 + 28 (mac_i8.hip i8_panel_rows)
                     int B_mode = 0;       // B_* given and B_mode 0: streamed tiles (k' = g * kb + baby); 1: the pass's layout, already transposed (riding mover): no pass; 2: the pass runs into these buffers
                     const int8_t *A_small = nullptr, *A_big = nullptr; };   // A_*: the transposed rot tiles of this launch are given (I8RotPre): no copy to look up or make   // B_*: the int8 MAC's plaintext tiles are already in place (streamed transposition, StagePack): no panel, k' = g * kb + baby   // i8: small moduli on the int8 MAC (mac_i8.hip); pt_digits: their panel rows hold five digit planes   // in words; pt_half: pt rows hold N/2 words (mirror-symmetric plaintexts)
 int launch_mac_i8_small(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, const u64 *pt, u64 *out, int K, int R, int r0, int Ncols,
@@ -64,7 +67,7 @@ int launch_encode_rows(sfg_ctx *ctx, const int8_t *D, int shift0, int nshift, in
 int encode_rows_launches(const sfg_ctx *ctx, int nshift);          // NTT launches launch_encode_rows makes for nshift diagonals (panel form)
 // mac_i8.hip: the riding transposition of one delayed MAC launch (panel of K = ng * 91 k-rows x 91 columns -> tile buffers mi8.Bs / mi8.Bb); ride.on stays false where the
 // moduli are not one run of 35-bit ones plus at most one 46-bit one
-int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, bool compact, int L, int launches, PtRide &ride);
+int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, int layout, int L, int launches, PtRide &ride);
 int i8_ride_finish(sfg_ctx *ctx, PtRide &ride);                     // items no NTT launch took: a launch of mover workgroups alone on the current stream
 int i8_ride_tiles(sfg_ctx *ctx, int K, int L, int8_t **Bs, int8_t **Bb);          // the two tile buffers (a launch that transposes by the pass uses them as well: B_mode 2)
 // genoio.hip: dense int8 copy [nr][ld_out] of the stored sub-block (r0.., c0..) of a 2-bit packed matrix (c0 a multiple of 4)

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
     const int jt = b % a.njt, m = b / a.njt;
     const int c0 = cb * I8_PD, cq = tid & 31, slot = tid >> 5;
     const int ch = kq >> 2, g = kq & 3, l16 = tid & 15;
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride) + c0 + cq * 4;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pt + a.pt_l0_off + (size_t)m * a.pt_l_stride) + (size_t)cb * a.pt_cb_stride + cq * 4;
     constexpr int NI = 8;                                   // items whose loads are issued together (4 dwords each; 2, 4, 8 measured: 8 = the plain loop's time, round 4)
     for (int d = 0; d < ND; d++) {
         for (int it0 = 0; it0 < 8; it0 += NI) {
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) k_i8_pack_pt_digits(I8Args a) {
                 for (int x = 0; x < 4; x++) {
                     const int k = kq * 16 + k4 * 4 + x;
                     const bool ok = k < a.K && n < a.Ncols;
-                    const unsigned v = *reinterpret_cast<const unsigned *>(src + (ok ? ((size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride) * 8 : (size_t)0) + (size_t)d * H);
+                    const unsigned v = *reinterpret_cast<const unsigned *>(src + (ok ? ((size_t)n * a.pt_n_stride + (size_t)k * a.pt_k_stride) * 8 : (size_t)0) + (size_t)d * a.pt_d_stride);
                     w[u][x] = ok ? v : 0u;
                 }
             }
@@ -582,25 +582,34 @@ int i8_ride_tiles(sfg_ctx *ctx, int K, int L, int8_t **Bs, int8_t **Bb) {
     if (l_big >= 0) SFG_TRY(sfg_scratch(ctx, "mi8.Bb", mac_i8_tile_bytes(K, 1, 6), (void **)Bb));
     return 0;
 }
-// words from a plaintext's start to modulus l's row, and between rows of like moduli, in a panel of `compact` (5 / 6 digit planes of N/2 bytes per row) or full (N/2 words) rows
-void i8_panel_rows(const sfg_ctx *ctx, bool compact, int l, bool big, size_t &l_off, size_t &l_stride) {
+// Panel layouts (MacStrides::pt_layout).  0: L rows of N/2 words per plaintext; 1 (compact): a plaintext's 5 / 6 digit planes of N/2 bytes per modulus back to back;
+// 2 (K-major): [column][plane][128-byte coefficient block][k < K][128 B].  Fills the row addressing of modulus l0 (and the like moduli after it) in `a`; pt_k / pt_n
+// (words between consecutive k / columns) are the caller's for layouts 0 and 1 and follow from K for layout 2.
+void i8_panel_rows(const sfg_ctx *ctx, int layout, int K, int L, int l, bool big, I8Args &a) {
     const size_t H = SFG_N / 2;
-    if (!compact) { l_off = (size_t)l * H; l_stride = H; return; }
-    size_t planes = 0; for (int t = 0; t < l; t++) planes += ctx->q[t] < (1ULL << 36) ? 5 : 6;
-    l_off = planes * H / 8; l_stride = (size_t)(big ? 6 : 5) * H / 8;
+    a.pt_d_stride = H; a.pt_cb_stride = I8_PD;
+    if (layout == 0) { a.pt_l0_off = (size_t)l * H; a.pt_l_stride = H; return; }
+    size_t below = 0, all = 0; for (int t = 0; t < L; t++) { const size_t pl = ctx->q[t] < (1ULL << 36) ? 5 : 6; if (t < l) below += pl; all += pl; }
+    const size_t nd = big ? 6 : 5;
+    if (layout == 1) { a.pt_l0_off = below * H / 8; a.pt_l_stride = nd * H / 8; return; }
+    const size_t blk = (size_t)K * 128;                          // bytes of one coefficient block of a plane: K rows of 128 B
+    a.pt_d_stride = 64 * blk; a.pt_cb_stride = blk;
+    a.pt_l0_off = below * 64 * blk / 8; a.pt_l_stride = nd * 64 * blk / 8;
+    a.pt_k_stride = 16; a.pt_n_stride = all * 64 * blk / 8;
 }
-int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, bool compact, int L, int launches, PtRide &ride) {
+int i8_ride_prepare(sfg_ctx *ctx, const u64 *panel, int K, int Ncols, size_t pt_k, size_t pt_n, int layout, int L, int launches, PtRide &ride) {
     const int H = SFG_N / 2;
     ride = PtRide();
     int l_small0, n_small, l_big;
     if (ctx->cfg.pt_ride <= 0 || launches < 1 || Ncols > 96 || !i8_ride_moduli(ctx, L, l_small0, n_small, l_big)) return 0;
-    if (pt_n * 8 >= (1ULL << 31) || pt_k * 8 * 16 >= (1ULL << 31)) return 0;                  // the mover's per-lane offsets are 32-bit
+    if (layout != 2 && (pt_n * 8 >= (1ULL << 31) || pt_k * 8 * 16 >= (1ULL << 31))) return 0;                  // the mover's per-lane offsets are 32-bit
+    if (layout == 2 && (size_t)K * 128 * 64 * 32 >= (1ULL << 31)) return 0;                   // (K-major: a column is at most 32 planes of 64 blocks of K x 128 B)
     int8_t *Bs, *Bb; SFG_TRY(i8_ride_tiles(ctx, K, L, &Bs, &Bb));
     const int nch = (K + 63) / 64, njt = (Ncols + 15) / 16;
     auto fill = [&](I8Args &a, int l0, int nl, int8_t *B) {
         memset(&a, 0, sizeof a);
         a.pt = panel; a.pt_k_stride = pt_k; a.pt_n_stride = pt_n; a.K = K; a.Ncols = Ncols; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = njt; a.pt_digits = 1; a.B = B;
-        i8_panel_rows(ctx, compact, l0, l0 == l_big, a.pt_l0_off, a.pt_l_stride);
+        i8_panel_rows(ctx, layout, K, L, l0, l0 == l_big, a);
     };
     MoveJob &j = ride.job;
     fill(j.a5, l_small0, n_small, Bs); j.n5 = (unsigned)((size_t)n_small * njt * nch * 4 * (H / I8_PD));
@@ -647,11 +656,12 @@ static int launch_mac_i8_nd(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stri
     if (A_pre && (B_stream || r0 != 0 || R > 32)) SFG_FAIL(ctx, "sfg_mac (i8): internal: given rot tiles cover one block of <= 32 rows, with the plaintext panel");
     const int K_rot = K;                                            // rows of the rot operand
     if (B_stream) K = K / SFG_D * st.kb;
-    I8Args a; a.kb = B_stream ? st.kb : 0;
+    I8Args a; memset(&a, 0, sizeof a); a.kb = B_stream ? st.kb : 0;
     a.rotf = rotf; a.pt = pt; a.out = out; a.rotf_k_stride = rotf_k_stride; a.rotf_r_stride = rotf_r_stride;
     a.pt_k_stride = st.pt_k; a.pt_n_stride = st.pt_n; a.out_n_stride = st.out_n; a.out_r_stride = st.out_r;
-    if (st.pt_compact && !st.pt_digits) SFG_FAIL(ctx, "sfg_mac (i8): internal: compact panel rows hold digit planes");
-    i8_panel_rows(ctx, st.pt_compact, l0, BIG, a.pt_l0_off, a.pt_l_stride);
+    if (st.pt_layout && !st.pt_digits) SFG_FAIL(ctx, "sfg_mac (i8): internal: compact panel rows hold digit planes");
+    if (st.pt_layout == 2 && B_stream) SFG_FAIL(ctx, "sfg_mac (i8): internal: a K-major panel with streamed tiles");
+    i8_panel_rows(ctx, st.pt_layout, K, st.pt_L, l0, BIG, a);
     a.K = K; a.R = R; a.Ncols = Ncols; a.accumulate = accumulate; a.r0 = r0; a.l0 = l0; a.nl = nl; a.plane0 = plane0;
     a.nch = (K + 63) / 64; a.njt = (Ncols + 15) / 16; a.pt_digits = st.pt_digits ? 1 : 0;
     const size_t nA = (size_t)nl * N * a.nch * 2 * ND * 1024, nB = (size_t)nl * H * a.njt * a.nch * ND * 1024, nT = (size_t)nl * H * 2 * a.njt * 2 * 256;
@@ -830,7 +840,7 @@ static int move_job_for(sfg_ctx *ctx, const u64 *panel, int G, int L, int8_t *Bs
     const int K = G * d, nch = (K + 63) / 64;
     auto fill = [&](I8Args &a, int l0, int nl, int8_t *B) {
         memset(&a, 0, sizeof a);
-        a.pt = panel; a.pt_k_stride = plw; a.pt_n_stride = (size_t)G * d * plw; a.pt_l_stride = H; a.pt_l0_off = (size_t)l0 * H; a.K = K; a.Ncols = d; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = 6; a.pt_digits = 1; a.B = B;
+        a.pt = panel; a.pt_k_stride = plw; a.pt_n_stride = (size_t)G * d * plw; a.pt_l_stride = H; a.pt_l0_off = (size_t)l0 * H; a.pt_d_stride = H; a.pt_cb_stride = I8_PD; a.K = K; a.Ncols = d; a.l0 = l0; a.nl = nl; a.nch = nch; a.njt = 6; a.pt_digits = 1; a.B = B;
     };
     fill(pj.a5, l_small0, n_small, Bs); fill(pj.a6, l_big, 1, Bb);
     pj.n5 = (unsigned)(n_small * 6 * nch * 4 * (H / I8_PD)); pj.n6 = (unsigned)(6 * nch * 4 * (H / I8_PD));
@@ -860,7 +870,9 @@ extern "C" int ubench_ntt_move(sfg_ctx *ctx, int mode, int G, int nblocks, int d
     SFG_HIP(ctx, hipMemsetAsync(pc, 0, batch * H * 8, ctx->stream));
     MoveJob pj; SFG_TRY(move_job_for(ctx, panel, G, L, Bs, Bb, pj));
     pj.nblocks = (unsigned)nblocks; pj.depth = depth; pj.nt = nt;
+    if (const char *e = getenv("SFG_UB_MOVER_FAKE")) pj.a5.fake = pj.a6.fake = atoi(e);          // timing experiments with INVALID results (i8_move.hpp)
     PanelMap pm; pm.G = 0; pm.g = 0; pm.shift0 = 0; pm.packed_mask = mac_dma_packed_mask(ctx, L) | 0x80000000u | 0x40000000u;
+    if (pj.a5.fake & 16) { pm.packed_mask |= PT_COMPACT | PT_KMAJOR; pm.K = K; }                  // the NTTs write the K-major panel pattern (the launch's plaintexts: column p / K, row p % K)
     auto pack_alone = [&](const MoveJob &j) {
         hipLaunchKernelGGL(k_i8_pack_pt_digits<5>, dim3(j.n5), dim3(256), 0, ctx->stream, j.a5);
         hipLaunchKernelGGL(k_i8_pack_pt_digits<6>, dim3(j.n6), dim3(256), 0, ctx->stream, j.a6);

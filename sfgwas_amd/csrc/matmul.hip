@@ -78,6 +78,18 @@ __global__ void __launch_bounds__(256) k_pt_zero(u64 *pt, size_t pitch_words, si
     const int l = (int)((x / prow) % L);
     pt[seg * pitch_words + x] = ((packed_mask >> l) & 1u) ? PACKED_ZERO : 0ULL;
 }
+// the same for a K-major panel ([column][plane][128-byte coefficient block][k < K][128 B], kernels.hpp PT_KMAJOR): rows [k0, k1) of columns [n0, n1), every plane
+__global__ void __launch_bounds__(256) k_pt_zero_kmajor(uint8_t *pt, int K, int planes, int n0, int k0, int nk) {
+    const size_t blk = ((size_t)(n0 + blockIdx.y) * planes * 64 + blockIdx.x) * (size_t)K * 128 + (size_t)k0 * 128;
+    uint4 *p = reinterpret_cast<uint4 *>(pt + blk);
+    for (int i = threadIdx.x; i < nk * 8; i += 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+static int launch_pt_zero_kmajor(sfg_ctx *ctx, u64 *pt, int K, int planes, int n0, int n1, int k0, int k1) {
+    if (n1 <= n0 || k1 <= k0) return 0;
+    hipLaunchKernelGGL(k_pt_zero_kmajor, dim3((unsigned)(planes * 64), (unsigned)(n1 - n0)), dim3(256), 0, ctx->stream, reinterpret_cast<uint8_t *>(pt), K, planes, n0, k0, k1 - k0);
+    SFG_HIP(ctx, hipGetLastError());
+    return 0;
+}
 static int launch_pt_zero(sfg_ctx *ctx, u64 *pt, size_t pitch_words, size_t seg_words, int nseg, int L, size_t prow, unsigned packed_mask) {
     if (!packed_mask) {
         if (nseg == 1) SFG_HIP(ctx, hipMemsetAsync(pt, 0, seg_words * 8, ctx->stream));
@@ -475,7 +487,12 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     bool all_small = true; for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) all_small = false;
     const bool compact = ctx->cfg.pt_compact && dma && use_i8 && (use_i8_big || all_small) && !streamable;
     size_t plw = (size_t)L * prow;                           // words per plaintext
-    if (compact) { size_t planes = 0; for (int l = 0; l < L; l++) planes += ctx->q[l] < (1ULL << 36) ? 5 : 6; plw = planes * ((size_t)N / 2) / 8; }
+    int pt_planes = 0;
+    if (compact) { for (int l = 0; l < L; l++) pt_planes += ctx->q[l] < (1ULL << 36) ? 5 : 6; plw = (size_t)pt_planes * ((size_t)N / 2) / 8; }
+    // K-major panel (round 6): the compact panel's bytes ordered [column][plane][128-byte coefficient block][k][128 B], so that the 16 k of a transposition unit's
+    // column are one 2 KiB run (the NTT's stores are 128-byte runs either way).  Whole-group launches only (a sub-launch would change K between encode and MAC).
+    const bool kmajor = compact && ctx->cfg.pt_kmajor && Gp == G && (size_t)G * d * 128 * 64 * 32 < (1ULL << 31);
+    const int pt_layout = kmajor ? 2 : compact ? 1 : 0;
     const size_t panel_words = (size_t)Gp * nplain * plw;
     // The riding transposition (kernels.hpp PtRide): the panel of MAC launch k - 1 is transposed by mover workgroups inside the plaintext-NTT launches of launch k's
     // encode, which writes the OTHER panel; MAC launch k - 1 follows that encode on the same queue and finds its tiles in place.  Taken where every modulus multiplies
@@ -528,7 +545,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
         if (pre8) { st.A_small = pre8->As[m.gi]; st.A_big = pre8->Ab[m.gi]; }
         st.rot_k = (size_t)s * ctw; st.rot_r = (size_t)nl * N;          // rotc[baby][i][poly][nl][N]: row r = i*2+poly
         st.pt_k = plw; st.pt_n = (size_t)m.gsn * d * plw; st.pt_half = dma; st.pt_packed = packed_mask != 0; st.pt_digits = st.i8 = use_i8; st.i8_big = st.pt_digits_big = use_i8_big;   // pt[giant][g][baby]: k = g*91 + baby
-        st.pt_compact = compact;
+        st.pt_layout = pt_layout; st.pt_L = L;
         st.out_n = accw; st.out_r = (size_t)L * N;                      // acc[j][giant][r]
         int r2;
         if (dma) r2 = launch_mac_dma(ctx, pre8 ? nullptr : m.rotf_grp + (size_t)m.sub0 * d * s * 2 * rowf, (size_t)s * 2, m.ptp, m.accj, m.gsn * d, 2 * s, d, L, m.acc_flag, st, m.rotsum_grp);
@@ -611,7 +628,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                   if (nr + nc > SFG_SLOTS) launches += encode_rows_launches(ctx, SFG_SLOTS);
                   else launches += encode_rows_launches(ctx, nr) + (nc > 1 ? encode_rows_launches(ctx, nc - 1) : 0);
               }
-              rc = i8_ride_prepare(ctx, held.ptp, held.gsn * d, d, plw, (size_t)held.gsn * d * plw, compact, L, launches, ride); if (rc) break;
+              rc = i8_ride_prepare(ctx, held.ptp, held.gsn * d, d, plw, (size_t)held.gsn * d * plw, pt_layout, L, launches, ride); if (rc) break;
               if (ride.on && (ride.job.a5.B != rideBs || (ride.job.n6 && ride.job.a6.B != rideBb))) { rc = 1; ctx->err = "matmul: internal: the riding transposition's tile buffers moved"; break; }
           }
           if (held.on && !ride.on) { rc = run_mac(held, rideBs ? 2 : 0); held.on = false; if (rc) break; }       // nothing to ride in: the held launch goes now, by the pass
@@ -652,6 +669,10 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                 const bool full = nruns == 1 && runs[0][1] - runs[0][0] == SFG_SLOTS;
                 // zero what the encoder will not write: plaintext slot of (giant, g, baby) is ((giant*ng + g)*91 + baby)
                 if (stream) {      // (the tiles' unowned positions are zero already, owned ones without a plaintext are written as zeros)
+                } else if (kmajor) {      // (K-major panel: rows of block row g in column 90 past shift 8191, or in every column)
+                    const int kb0 = (g - sub0) * d;
+                    if (full) rc = launch_pt_zero_kmajor(ctx, pt, gs * d, pt_planes, d - 1, d, kb0 + (SFG_SLOTS - (d - 1) * d), kb0 + d);
+                    else rc = launch_pt_zero_kmajor(ctx, pt, gs * d, pt_planes, 0, d, kb0, kb0 + d);
                 } else if (full) {        // only the 89 slots past shift 8191 (giant 90, baby 2..90)
                     rc = launch_pt_zero(ctx, pt + (((size_t)(d - 1) * gs + (g - sub0)) * d + (SFG_SLOTS - (d - 1) * d)) * plw, 0, (nplain - SFG_SLOTS) * plw, 1, L, prow, packed_mask);
                 } else {           // ragged block: all 91 x 91 slots of this block row
@@ -662,7 +683,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     PhaseTimer t(ctx, "encode");
                     for (int r = 0; r < nruns && !rc; r++) {
                         if (stream) sp.g = g;
-                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, gs, g - sub0, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u) | (compact ? PT_COMPACT : 0u),
+                        if (dma) rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt, true, gs, g - sub0, packed_mask | (use_i8 ? 0x80000000u : 0u) | (use_i8_big ? 0x40000000u : 0u) | (compact ? PT_COMPACT : 0u) | (kmajor ? PT_KMAJOR : 0u),
                                                          pcc.mode ? &pcc : nullptr, stream ? &sp : nullptr, ride.on ? &ride : nullptr);
                         else rc = launch_encode_rows(ctx, skew, runs[r][0], runs[r][1] - runs[r][0], L, pt + (size_t)runs[r][0] * plw, false);
                     }

@@ -410,11 +410,16 @@ __device__ __forceinline__ void ntt_half3_wg(size_t vb, double *lds, const doubl
     const size_t plain = row / L; const int shift = pm.shift0 + (int)plain;
     const size_t dst = pm.G ? ((size_t)(shift / SFG_D) * pm.G + pm.g) * SFG_D + (size_t)(shift % SFG_D) : plain;
     u64 *out = out_ + (dst * L + m) * (size_t)n;
+    size_t dstride = n, cbm = 0;       // bytes between the digit planes of this row; K-major: (bytes between 128-byte coefficient blocks) - 128, so that byte j of a plane is at j + (j >> 7) * cbm
     if constexpr (DIG) if (pm.packed_mask & PT_COMPACT) {      // compact panel rows: the moduli's 5 / 6 digit planes of a plaintext back to back (bit l of the mask: modulus l has five)
         const unsigned lm = (1u << L) - 1u, small = pm.packed_mask & lm;
         const int ns_all = __popc(small), ns_below = __popc(small & ((1u << m) - 1u));
-        const size_t row_bytes = ((size_t)ns_all * 5 + (size_t)(L - ns_all) * 6) * n, off = ((size_t)ns_below * 5 + (size_t)(m - ns_below) * 6) * n;
-        out = reinterpret_cast<u64 *>(reinterpret_cast<uint8_t *>(out_) + dst * row_bytes + off);
+        const size_t planes_all = (size_t)ns_all * 5 + (size_t)(L - ns_all) * 6, planes_below = (size_t)ns_below * 5 + (size_t)(m - ns_below) * 6;
+        if (pm.packed_mask & PT_KMAJOR) {
+            const size_t K = (size_t)pm.K, col = pm.G ? (size_t)(shift / SFG_D) : plain / K, row = pm.G ? (size_t)pm.g * SFG_D + (size_t)(shift % SFG_D) : plain % K;
+            out = reinterpret_cast<u64 *>(reinterpret_cast<uint8_t *>(out_) + ((col * planes_all + planes_below) * 64 * K + row) * 128);
+            dstride = 64 * K * 128; cbm = K * 128 - 128;
+        } else out = reinterpret_cast<u64 *>(reinterpret_cast<uint8_t *>(out_) + dst * (planes_all * n) + planes_below * n);
     }
     // (the format test is hoisted: inside the store loop it costs a branch per word)
 #ifdef SFG_NTT_DIAG          // timing diagnostics only: 1 = no panel stores (kept alive by an impossible value), 2 = stores without canon / packing
@@ -433,11 +438,12 @@ __device__ __forceinline__ void ntt_half3_wg(size_t vb, double *lds, const doubl
             unsigned l0, l1, l2, l3, h0, h1, h2, h3;
             dig6(x0, l0, h0); dig6(x1, l1, h1); dig6(x2, l2, h2); dig6(x3, l3, h3);
             unsigned o[4]; bytes_tr4(l0, l1, l2, l3, o);
+            uint8_t *ob = o8 + j0 + (size_t)(j0 >> 7) * cbm;
 #pragma unroll
-            for (int d = 0; d < 4; d++) NT_ST(reinterpret_cast<unsigned *>(o8 + d * n + j0), o[d]);
+            for (int d = 0; d < 4; d++) NT_ST(reinterpret_cast<unsigned *>(ob + d * dstride), o[d]);
             unsigned p[4]; bytes_tr4(h0, h1, h2, h3, p);
-            NT_ST(reinterpret_cast<unsigned *>(o8 + 4 * n + j0), p[0]);
-            NT_ST(reinterpret_cast<unsigned *>(o8 + 5 * n + j0), p[1]);
+            NT_ST(reinterpret_cast<unsigned *>(ob + 4 * dstride), p[0]);
+            NT_ST(reinterpret_cast<unsigned *>(ob + 5 * dstride), p[1]);
         };
         if constexpr (PERM) ntt_half3_body<decltype(first), decltype(st6), decltype(fill), true>(0, first, st6, lds, tw, pack, q, qinv, tid, fill);
         else ntt_half3_body<decltype(first), decltype(st6), NoFill, true>(0, first, st6, lds, tw, pack, q, qinv, tid);
@@ -453,9 +459,10 @@ __device__ __forceinline__ void ntt_half3_wg(size_t vb, double *lds, const doubl
             unsigned l0, l1, l2, l3, h0, h1, h2, h3;
             dig(x0, l0, h0); dig(x1, l1, h1); dig(x2, l2, h2); dig(x3, l3, h3);
             unsigned o[4]; bytes_tr4(l0, l1, l2, l3, o);
+            uint8_t *ob = o8 + j0 + (size_t)(j0 >> 7) * cbm;
 #pragma unroll
-            for (int d = 0; d < 4; d++) NT_ST(reinterpret_cast<unsigned *>(o8 + d * n + j0), o[d]);
-            NT_ST(reinterpret_cast<unsigned *>(o8 + 4 * n + j0), (h0 & 255u) | ((h1 & 255u) << 8) | ((h2 & 255u) << 16) | (h3 << 24));
+            for (int d = 0; d < 4; d++) NT_ST(reinterpret_cast<unsigned *>(ob + d * dstride), o[d]);
+            NT_ST(reinterpret_cast<unsigned *>(ob + 4 * dstride), (h0 & 255u) | ((h1 & 255u) << 8) | ((h2 & 255u) << 16) | (h3 << 24));
         };
         if constexpr (PERM) ntt_half3_body<decltype(first), decltype(st8), decltype(fill), true>(0, first, st8, lds, tw, pack, q, qinv, tid, fill);
         else ntt_half3_body<decltype(first), decltype(st8), NoFill, true>(0, first, st8, lds, tw, pack, q, qinv, tid);

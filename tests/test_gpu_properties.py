@@ -253,7 +253,7 @@ def test_schedule_invariance_at_kp15_multi_pass_size(tmp_path):
                        # launch's encode): off, i.e. the pass before every MAC launch; and with other mover shapes over groups of 2 block rows (four groups: the
                        # launches held over a group boundary take the pass)
                        ("no_ride", {"SFG_PT_RIDE": "0", "SFG_PT_COMPACT": "0"}),        # (and the panel's rows as full words, round 5's layout)
-                       ("ride_deep", {"SFG_PT_RIDE": "64", "SFG_PT_RIDE_DEPTH": "3", "SFG_PT_RIDE_NT": "0", "SFG_MM_GROUP": "2"})]:
+                       ("ride_deep", {"SFG_PT_RIDE": "64", "SFG_PT_RIDE_DEPTH": "3", "SFG_PT_RIDE_NT": "0", "SFG_MM_GROUP": "2", "SFG_PT_KMAJOR": "0"})]:       # (and the compact panel plaintext-major)
         f = str(tmp_path / (name + ".txt"))
         e = dict(os.environ); e.update(child_env(envv))
         r = subprocess.run([sys.executable, "-c", _CHILD_LARGE, f], cwd=root, env=e, capture_output=True, text=True)

@@ -16,4 +16,4 @@ r = d.get("roofline", {})
 print(sys.argv[2], round(d["ms_per_step"]), d.get("digests_match_pinned"), {k: round(v, 1) for k, v in ph.items() if k in ("encode", "mac_i8_pack_pt", "mac_small", "mac_big", "mac_i8_untile")}, r.get("kernel"), round(r.get("avg_launch_ms", 0), 4), r.get("launches"), "mac launches", r.get("second_kernel", {}).get("launches"))
 PY
 }
-for cfg in ${CFGS:-c3 c4}; do for v in 0 1; do CFG=$cfg run ${cfg}_compact_$v SFG_PT_COMPACT=$v || exit 1; done; done
+for cfg in ${CFGS:-c3 c4}; do for v in ${VARS:-"SFG_PT_COMPACT=0" "SFG_PT_COMPACT=1"}; do CFG=$cfg run ${cfg}_$v $v || exit 1; done; done
