@@ -500,7 +500,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // call's last launch transpose by the pass as before.
     const bool ride_want = use_i8 && !streamable && !enc_ov && ctx->cfg.pt_ride > 0 && j1 - j0 >= 2 &&       // (a launch rides in the encode of the NEXT block column of its group)
                            (use_i8_big || [&] { for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) return false; return true; }());
-    SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov || ride_want ? 2 : 1), (void **)&pt));
+    // (+ 64 KiB: the transposition walks whole chunks of 64 k, and in the K-major panel the rows K .. K + 63 of the last column's last coefficient block - read, then
+    //  masked - lie up to 8 KiB past the panel)
+    SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov || ride_want ? 2 : 1) + 65536, (void **)&pt));
     u64 *const pt_base = pt;
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
     int8_t *unpacked = nullptr;
