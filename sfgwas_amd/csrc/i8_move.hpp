@@ -6,7 +6,7 @@
 // fit beside NTT workgroups are latency bound (profiles/r05_fused_ntt_pack_ubench.txt).  Here a workgroup walks a list of units (unit = one digit plane of one
 // (modulus, column tile, 16 k, 128 coefficients) item: 256 rows of 128 bytes in, 128 pieces of 256 bytes out) with the loads of the next DEPTH - 1 units in flight in
 // registers while the current one goes through the LDS image: (DEPTH - 1) x 32 KiB per CU always outstanding, no other workgroup needed.  Same LDS image, same stores,
-// same bytes as the pass (tests/test_gpu_mover.py compares the tile buffers).  VALU work is 8 v_perm per 16 bytes - nothing beside the NTT's butterflies.
+// same bytes as the pass (tests/test_gpu_mover.py compares the tile buffers word by word).  VALU work is 8 v_perm per 16 bytes - nothing beside the NTT's butterflies.
 #pragma once
 #include "common.hpp"
 
