@@ -104,7 +104,8 @@ struct I8RotPre { int G = 0, nbr = 0, s = 0, L = 0; std::vector<int8_t *> As, Ab
 int i8_rotpre_build(sfg_ctx *ctx, const u64 *A_dev, int s, int in_level, int max_level, int nbr, const std::vector<std::vector<uint8_t>> *tabs, size_t budget_bytes, const char *prefix, I8RotPre &pre);   // pre.G == 0 afterwards: not taken (fp64 path)
 void i8_rotpre_free(I8RotPre &pre);
 int matmul_resident_range_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int blk0, int blk1, uint64_t *out);
-int matmul_accumulate_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int j0, int j1, int accumulate, uint64_t *acc);
+int matmul_accumulate_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int j0, int j1, int accumulate, uint64_t *acc,
+                            size_t acc_col_words = 0);        // acc_col_words: words between consecutive block columns' accumulators (0: dense [column][91 giants]...)
 int launch_i8_pack_rot_to(sfg_ctx *ctx, const double *rotf, size_t rotf_k_stride, size_t rotf_r_stride, int plane0, int K, int R, int l0, int nl, bool big, int8_t *A_out);      // mac_i8.hip
 size_t mac_i8_rot_tile_bytes(int K, int nl, int ND);
 // the rotation cache of an association scan in whichever form the context multiplies with

@@ -402,7 +402,7 @@ static int build_rot_row_tab(sfg_ctx *ctx, const u64 *A, int s, int nl_in, int n
 // for operand block rows [b0, b1) and block columns [j0, j1).
 static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, int max_level, const Shape &sh, unsigned flags,
                              int b0, int b1, int j0, int j1, int accumulate, u64 *acc, const double *rotf_pre = nullptr, const double *rotsum_pre = nullptr,
-                             const I8RotPre *pre8 = nullptr) {
+                             const I8RotPre *pre8 = nullptr, size_t acc_col_words = 0) {          // acc_col_words: words between the accumulators of consecutive block columns (0: dense, 91 giants)
     const int N = SFG_N, d = SFG_D, L = max_level;
     if (pre8 && (rotf_pre || !mac_use_dma(ctx) || b0 != 0 || b1 != pre8->nbr || sh.nbr != pre8->nbr || s != pre8->s || L != pre8->L))
         SFG_FAIL(ctx, "matmul: internal: the int8 rot tiles were built for another product (block rows %d, s = %d, level %d)", pre8->nbr, pre8->s, pre8->L);
@@ -413,7 +413,12 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     if (b0 < 0 || b1 > sh.nbr || b0 > b1 || j0 < 0 || j1 > sh.m_ct || j0 > j1) SFG_FAIL(ctx, "matmul: block range out of bounds");
     const size_t ctw = (size_t)2 * nl * N, accw = (size_t)s * 2 * L * N;
     const int ncolb = j1 - j0;
-    if (b0 == b1 || j0 == j1) { if (!accumulate) SFG_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ncolb * d * accw * 8, ctx->stream)); return 0; }
+    const size_t acc_col = acc_col_words ? acc_col_words : (size_t)d * accw;
+    if (acc_col < (size_t)d * accw) SFG_FAIL(ctx, "matmul: internal: accumulator column stride below 91 giant steps");
+    if (b0 == b1 || j0 == j1) {
+        if (!accumulate) for (int c = 0; c < ncolb; c++) SFG_HIP(ctx, hipMemsetAsync(acc + (size_t)c * acc_col, 0, (size_t)d * accw * 8, ctx->stream));
+        return 0;
+    }
     const bool dma = mac_use_dma(ctx);                          // LDS-DMA MAC: half-row plaintexts, fp64 rot operand, block-row groups
     const size_t prow = dma ? (size_t)N / 2 : (size_t)N;     // words per plaintext modulus row
     // G block rows share one MAC launch (K = G*91): accumulators are written once per group instead of
@@ -438,7 +443,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
                     const bool pipe2 = !rotf_pre && b1 - b0 > G2 && !ctx->cfg.no_overlap;
                     const bool enc2 = !ctx->cfg.no_overlap && !ctx->cfg.no_enc_overlap && (size_t)((b1 - b0 + G2 - 1) / G2) * (j1 - j0) >= 2;
                     const bool streamable2 = ctx->cfg.mac_i8 && ctx->cfg.mac_i8_big && ctx->cfg.mac_i8_ring && ctx->cfg.stage_pack && !enc2;      // then the panel holds 4 block rows
-                    const bool ride2 = ctx->cfg.mac_i8 && ctx->cfg.pt_ride > 0 && !enc2 && !streamable2 && j1 - j0 >= 2;      // (the riding transposition keeps two panels too)
+                    const bool ride2 = ctx->cfg.mac_i8 && ctx->cfg.pt_ride > 0 && !enc2 && !streamable2 && (j1 - j0 >= 2 || (pre8 && b1 - b0 > G2));      // (the riding transposition keeps two panels too)
                     size_t ptb = (size_t)L * ((size_t)N / 2) * 8;                    // bytes per plaintext: compact rows where every modulus is on the int8 MAC (as decided below)
                     if (ctx->cfg.pt_compact && ctx->cfg.mac_i8 && !streamable2 && mac_dma_packed_mask(ctx, L)) {
                         bool big_ok = true; size_t planes = 0;
@@ -498,7 +503,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // encode, which writes the OTHER panel; MAC launch k - 1 follows that encode on the same queue and finds its tiles in place.  Taken where every modulus multiplies
     // on the int8 matrix core from digit-plane panels; the first launch after a change of block-row group (its rot operand's buffer is about to be rebuilt) and the
     // call's last launch transpose by the pass as before.
-    const bool ride_want = use_i8 && !streamable && !enc_ov && ctx->cfg.pt_ride > 0 && j1 - j0 >= 2 &&       // (a launch rides in the encode of the NEXT block column of its group)
+    // (a launch rides in the encode of the NEXT block column of its group - or of the next group's first column where the rot tiles of every group are the caller's,
+    //  I8RotPre: nothing is rebuilt between groups then, so the multi-GPU engine's one-column calls over several groups ride as well)
+    const bool ride_want = use_i8 && !streamable && !enc_ov && ctx->cfg.pt_ride > 0 && (j1 - j0 >= 2 || (pre8 && b1 - b0 > G)) &&
                            (use_i8_big || [&] { for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) return false; return true; }());
     // (+ 64 KiB: the transposition walks whole chunks of 64 k, and in the K-major panel the rows K .. K + 63 of the last column's last coefficient block - read, then
     //  masked - lie up to 8 KiB past the panel)
@@ -560,8 +567,9 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     if (enc_ov) SFG_TRY(sfg_stream_after(ctx, ctx->enc_stream, main_stream));      // the genotypes, the cache slots and whatever the caller enqueued before
     for (int bg = b0; bg < b1 && !rc; bg += G, gi++) {
         const int ng = std::min(G, b1 - bg);
-        // (the delayed launch of the previous group reads a rot operand buffer that is rebuilt below: it goes first, transposing by the pass)
-        if (held.on) { rc = run_mac(held, 2); held.on = false; if (rc) break; }
+        // (the delayed launch of the previous group reads a rot operand buffer that is rebuilt below: it goes first, transposing by the pass - unless the rot tiles
+        //  of all groups are the caller's)
+        if (held.on && !pre8) { rc = run_mac(held, 2); held.on = false; if (rc) break; }
         // ---- rotation caches of the group's block rows (or the product-wide cache built by the caller)
         const double *rotf_grp = rotf, *rotsum_grp = rotsum;
         if (rotf_pre) { rotf_grp = rotf_pre + (size_t)(bg - b0) * d * s * 2 * rowf; rotsum_grp = rotsum_pre ? rotsum_pre + (size_t)gi * s * 2 * rowf : nullptr; }
@@ -705,7 +713,7 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
             {
                 MacJob m; m.on = true; m.ptp = pt; m.gsn = gs; m.sub0 = sub0; m.gi = gi; m.sp = stream ? &sp : nullptr;
                 m.acc_flag = (accumulate || !first_group || sub0 > 0) ? 1 : 0;      // the first (sub-)launch of a fresh call overwrites
-                m.accj = acc + (size_t)(bj - j0) * d * accw; m.rotf_grp = rotf_grp; m.rotsum_grp = rotsum_grp;
+                m.accj = acc + (size_t)(bj - j0) * acc_col; m.rotf_grp = rotf_grp; m.rotsum_grp = rotsum_grp;
                 if (ride_this && rideBs) held = m;                                 // multiplied after the next launch's encode has transposed this panel
                 else rc = run_mac(m, rideBs ? 2 : 0);
             }
@@ -1045,12 +1053,12 @@ int matmul_resident_range_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int ma
 }
 // accumulate phase of a product (sfg_matmul_accumulate_rc_dev) against int8 rot tiles that cover ALL operand block rows of the (possibly transposed) matrix: the
 // multi-GPU engine's Q' X^T multiplies one output block column per call against the tiles of the rank's own block rows (mgpu.hip)
-int matmul_accumulate_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int j0, int j1, int accumulate, uint64_t *acc) {
+int matmul_accumulate_i8pre(sfg_ctx *ctx, const I8RotPre &pre, int s, int max_level, const sfg_geno *g, unsigned flags, int j0, int j1, int accumulate, uint64_t *acc, size_t acc_col_words) {
     ApiScope api_scope(ctx);
     SFG_HIP(ctx, hipSetDevice(ctx->device));
     if (!pre.G) SFG_FAIL(ctx, "matmul: no int8 rot tiles");
     Shape sh = make_shape(g, flags);
-    return matmul_accumulate(ctx, nullptr, s, max_level, max_level, sh, flags, 0, pre.nbr, j0, j1, accumulate, (u64 *)acc, nullptr, nullptr, &pre);
+    return matmul_accumulate(ctx, nullptr, s, max_level, max_level, sh, flags, 0, pre.nbr, j0, j1, accumulate, (u64 *)acc, nullptr, nullptr, &pre, acc_col_words);
 }
 // GetDiagBool (matmult.go:627-631) for other translation units
 int sfg_diag_bool(int r, int c, int dim, int index) { return diag_bool(r, c, dim, index); }

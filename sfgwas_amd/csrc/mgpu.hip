@@ -577,6 +577,8 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
     if (world == 1 && !mg->force_coll) { R_CTX(R, sfg_matmul_resident_dev(ctx, A, s, in_level, L, shard, fl, out)); return 0; }
     I8RotPre pre8;
     bool pipe = false;
+    int PW = 1;                                          // block columns per multiply call of the pipeline: with int8 rot tiles TWO, so that the second column's encode carries the
+                                                         // first one's plaintext transposition (kernels.hpp PtRide; a one-column call of one MAC group has nothing to ride in)
     uint64_t *acc_mine = nullptr, *acc2 = nullptr; double *cache = nullptr;
     hipStream_t cs = ctx->stream;
     size_t acc_w = 0;
@@ -597,15 +599,17 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
         // (the collectives' queue must not start before earlier work of the compute queue that still reads these buffers: previous call's finalize)
         R_HIP(R, hipEventRecord(R.ev_c, cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_c, 0));
         if (pipe) {
-            const bool fresh = ctx->pool.find("mg.acc2") == ctx->pool.end() || ctx->pool["mg.acc2"].second < 2 * colp * 8;
-            R_CTX(R, sfg_scratch(ctx, "mg.acc2", 2 * colp * 8, (void **)&acc2));
-            if (fresh || !nloc) R_HIP(R, hipMemsetAsync(acc2, 0, 2 * colp * 8, cs));       // the padded giant slots (>= 91) are never written by a product: zero once
+            PW = pre8.G ? 2 : 1;
+            const size_t acc2_bytes = (size_t)2 * PW * colp * 8;
+            const bool fresh = ctx->pool.find("mg.acc2") == ctx->pool.end() || ctx->pool["mg.acc2"].second < acc2_bytes;
+            R_CTX(R, sfg_scratch(ctx, "mg.acc2", acc2_bytes, (void **)&acc2));
+            if (fresh || !nloc) R_HIP(R, hipMemsetAsync(acc2, 0, acc2_bytes, cs));       // the padded giant slots (>= 91) are never written by a product: zero once
             if (nloc && !pre8.G) {
                 R_CTX(R, sfg_scratch(ctx, "mg.cache", cache_w * 8, (void **)&cache));
                 R_CTX(R, sfg_rotcache_build_rows_dev(ctx, A, s, in_level, L, nloc, 0, nloc, cache));
             }
-            // column 0 is multiplied before the agreement too: it grows the product's own scratch pools (panel, tiles, accumulators) to their final shape
-            if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, 0, 1, 0, acc2));
+            // the first column(s) are multiplied before the agreement too: that grows the product's own scratch pools (panel, tiles, accumulators) to their final shape
+            if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, 0, std::min(PW, nbr_x), 0, acc2, colp));
             else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, 0, 1, 0, acc2));
         } else {                                           // the rank's own cache would not fit: the library's grouped rotation cache, reduce-scatters after the product
             acc_w = ((size_t)nbr_x * d + ((size_t)world * gpr - d)) * accw;
@@ -619,16 +623,18 @@ static int rank_contract(sfg_mgpu *mg, MgRank &R, int li, const uint64_t *A, int
     // ---- from here on a failure aborts the communicator: the peers are inside (or about to enter) their collectives
     auto exchange = [&]() -> int {
         if (pipe) {
-            for (int j = 0; j < nbr_x; j++) {              // column j is multiplied while column j - 1 is reduce-scattered
-                uint64_t *buf = acc2 + (size_t)(j & 1) * colp;
-                if (j >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[j & 1], 0));            // the reduce-scatter of column j - 2 has read this buffer
+            for (int j = 0, p = 0; j < nbr_x; j += PW, p++) {      // columns [j, j + PW) are multiplied while the previous PW columns are reduce-scattered
+                const int je = std::min(nbr_x, j + PW);
+                uint64_t *buf = acc2 + (size_t)(p & 1) * PW * colp;
+                if (p >= 2) R_HIP(R, hipStreamWaitEvent(cs, R.ev_rs[p & 1], 0));            // the reduce-scatters of the call before last have read this buffer
                 if (j > 0) {
-                    if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, j, j + 1, 0, buf));
-                    else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, j + 1, 0, buf));
+                    if (nloc && pre8.G) R_CTX(R, matmul_accumulate_i8pre(ctx, pre8, s, L, shard, fl, j, je, 0, buf, colp));
+                    else if (nloc) R_CTX(R, sfg_matmul_accumulate_rc_dev(ctx, cache, s, L, shard, fl, 0, nloc, j, je, 0, buf));
                 }
-                R_HIP(R, hipEventRecord(R.ev_acc[j & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[j & 1], 0));
-                if (coll_reduce_scatter(mg, R, buf, acc_mine + (size_t)j * mine, mine, R.coll)) return 1;
-                R_HIP(R, hipEventRecord(R.ev_rs[j & 1], R.coll));
+                R_HIP(R, hipEventRecord(R.ev_acc[p & 1], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[p & 1], 0));
+                for (int c = j; c < je; c++)
+                    if (coll_reduce_scatter(mg, R, buf + (size_t)(c - j) * colp, acc_mine + (size_t)c * mine, mine, R.coll)) return 1;
+                R_HIP(R, hipEventRecord(R.ev_rs[p & 1], R.coll));
             }
         } else {
             R_HIP(R, hipEventRecord(R.ev_acc[0], cs)); R_HIP(R, hipStreamWaitEvent(R.coll, R.ev_acc[0], 0));
