@@ -319,7 +319,14 @@ __device__ __forceinline__ void ntt_half3_body(int hs, First first, Store store,
             {
                 const double2 *pk = pack + (size_t)((p >> 6) + 8 * hs) * 512 + (p & 63);
 #pragma unroll
-                for (int i = 0; i < 8; i++) { const double2 e = pk[i * 64]; tl[2 * i] = e.x; tl[2 * i + 1] = e.y; }
+                for (int i = 0; i < 8; i++) {
+#if defined(SFG_NTT_DIAG) && SFG_NTT_DIAG == 4          // timing only: no phase-C twiddle loads
+                    const double2 e = make_double2((double)(p + 2 * i + 3), (double)(p + 2 * i + 4)); (void)pk;
+#else
+                    const double2 e = pk[i * 64];
+#endif
+                    tl[2 * i] = e.x; tl[2 * i + 1] = e.y;
+                }
             }
             ct_stage<16, 8>(wc, q, qinv, [&](int g) { return tl[0 + g]; });
             ct_stage<16, 4>(wc, q, qinv, [&](int g) { return tl[1 + g]; });
@@ -370,7 +377,11 @@ __device__ __forceinline__ void ntt_half3_wg(size_t vb, double *lds, const doubl
     if (PERM) { const uint32_t e = perm[pm.shift0 + (int)(row / L)]; pc = pc_all + (size_t)(e & 0xFFFFu) * n; gal = e >> 16; }
     const double W = tw[1], Wq = W * qinv;
     // stage 1 on the antisymmetric input: r_j = p_j + W p_{n+j} = p_j - W p_{n-j}, r_0 = p_0
+#if defined(SFG_NTT_DIAG) && SFG_NTT_DIAG == 5              // timing only: no coefficient-row loads
+    auto first = [&](int j) { const double lo = (double)(j + 7), hi = j == 0 ? 0.0 : (double)(n - j + 5); return lo - mulmod_lazy(hi, W, Wq, q); };
+#else
     auto first = [&](int j) { const double lo = pc[j], hi = j == 0 ? 0.0 : pc[n - j]; return lo - mulmod_lazy(hi, W, Wq, q); };
+#endif
     // PERM: source driven.  A thread reads the pairs (p_i, p_{n-i}), i = tid + 256 k < n/2, coalesced.  p_i is coefficient raw = i g mod 2N of the image, i.e.
     // +-coefficient J of its stored half (quadrants of raw: [0,n] J = raw, +; (n,N) J = N - raw, -; [N,N+n] J = raw - N, -; (N+n,2N) J = 2N - raw, +), and
     // because g = 1 mod 4 its partner p_{n-i} is coefficient n - J (signs +, +, -, -): the pair yields r_J and r_{n-J}.  The 8192 stage-1 values then go to
