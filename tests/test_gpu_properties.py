@@ -198,12 +198,12 @@ def test_more_than_thirty_rows_per_k_slice_across_groups():
     D, N, L, LEVEL, SLOTS = 91, 16384, 5, 5, 8192
     rots = list(range(1, D)) + [g * D for g in range(1, D) if g * D < SLOTS]
     ctx.check(lib.sfg_fill_rotkeys_synthetic(ctx.h, (C.c_int * len(rots))(*rots), len(rots), 0xBEEF), "keys")
-    nrow, ncol, s = 2 * SLOTS + 500, 70, 17
+    nrow, ncol, s = 2 * SLOTS + 500, SLOTS + 70, 17          # (two block columns: the second one's encode carries the first one's transposition - round 6 - in both row passes' tiles)
     nbr = 3
     gd, gh = ctx.fill_geno(nrow, ncol, 0x77)
     A = ctx.fill_uniform_cts(s * nbr, LEVEL, 0x1234)
     full = ctx.matmul_resident(A, s, LEVEL, L, gh).host()
-    assert full.shape == (s, 1, 2, L, N) and full.any()
+    assert full.shape == (s, 2, 2, L, N) and full.any()
     Ah = A.host().reshape(s, nbr, 2, LEVEL + 1, N)
     for r0, r1 in ((0, 8), (8, 17)):
         sub = capi.DevArray.from_host(ctx, np.ascontiguousarray(Ah[r0:r1]))
