@@ -505,11 +505,13 @@ static int matmul_accumulate(sfg_ctx *ctx, const u64 *A, int s, int in_level, in
     // call's last launch transpose by the pass as before.
     // (a launch rides in the encode of the NEXT block column of its group - or of the next group's first column where the rot tiles of every group are the caller's,
     //  I8RotPre: nothing is rebuilt between groups then, so the multi-GPU engine's one-column calls over several groups ride as well)
-    const bool ride_want = use_i8 && !streamable && !enc_ov && ctx->cfg.pt_ride > 0 && (j1 - j0 >= 2 || (pre8 && b1 - b0 > G)) &&
-                           (use_i8_big || [&] { for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) return false; return true; }());
+    bool ride_want = use_i8 && !streamable && !enc_ov && ctx->cfg.pt_ride > 0 && (j1 - j0 >= 2 || (pre8 && b1 - b0 > G)) &&
+                     (use_i8_big || [&] { for (int l = 0; l < L; l++) if (ctx->q[l] >= (1ULL << 36)) return false; return true; }());
     // (+ 64 KiB: the transposition walks whole chunks of 64 k, and in the K-major panel the rows K .. K + 63 of the last column's last coefficient block - read, then
     //  masked - lie up to 8 KiB past the panel)
-    SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov || ride_want ? 2 : 1) + 65536, (void **)&pt));
+    // A caller's group size (SFG_MM_GROUP, sfg_config.mm_group) may leave room for one panel only: the product then transposes by the pass, as before round 6
+    if (ride_want && sfg_scratch(ctx, "mm.pt", panel_words * 8 * 2 + 65536, (void **)&pt)) { ctx->err.clear(); ride_want = false; }
+    if (!ride_want) SFG_TRY(sfg_scratch(ctx, "mm.pt", panel_words * 8 * (enc_ov ? 2 : 1) + 65536, (void **)&pt));
     u64 *const pt_base = pt;
     SFG_TRY(sfg_scratch(ctx, "mm.skew", (size_t)SFG_SLOTS * SFG_SLOTS, (void **)&skew));
     int8_t *unpacked = nullptr;
